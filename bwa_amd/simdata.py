@@ -1,0 +1,146 @@
+"""Seeded synthetic genomes and reads (configs C1-C5).
+
+There is no genome data and no network on the build or GPU boxes, so every benchmark and parity
+test runs on data generated here.  Everything is a pure function of its seed (numpy PCG64), so the
+GPU box regenerates byte-identical inputs.
+
+Genome recipe: `n_contigs` contigs of uniform-random ACGT, then (optionally) repeat families are
+stamped in: `n_interspersed` copies of a few 300 bp elements, each copy mutated at `divergence`,
+and `n_tandem` tandem arrays (unit 20-60 bp, 5-40 copies, lightly mutated).  The repeats make the
+max_occ / frac_rep / multi-chain paths of BWA-MEM fire (bwamem.c:291-309), which a purely random
+genome never does.
+
+Read model (same as BASELINE.md section 2): uniform start, random strand, per-base 1 % substitution,
+0.15 % deletion, 0.15 % insertion; pairs are FR with insert ~ N(400, 40) clipped at >= 200.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_ASCII = np.frombuffer(b"ACGTN", dtype=np.uint8)
+
+
+def make_genome(total_len: int, n_contigs: int = 4, seed: int = 42, n_interspersed: int | None = None,
+                n_tandem: int | None = None, divergence: float = 0.10, repeats: bool = True):
+    """Return (codes uint8[total_len] in 0..3, contig_lengths list)."""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=total_len, dtype=np.uint8)
+    # contig lengths: roughly geometric so that there are big and small contigs
+    w = np.array([0.5 ** min(i, 6) for i in range(n_contigs)], dtype=np.float64)
+    lens = np.maximum((w / w.sum() * total_len).astype(np.int64), 1000)
+    lens[0] += total_len - lens.sum()
+    assert lens.sum() == total_len and (lens > 0).all()
+    if repeats:
+        if n_interspersed is None:
+            n_interspersed = max(8, total_len // 1400)   # ~ the 1500 copies / 2 Mb of the SURVEY probe
+        if n_tandem is None:
+            n_tandem = max(2, total_len // 40000)
+        n_fam = 4
+        fams = [rng.integers(0, 4, size=300, dtype=np.uint8) for _ in range(n_fam)]
+        pos = rng.integers(0, total_len - 400, size=n_interspersed)
+        fam = rng.integers(0, n_fam, size=n_interspersed)
+        strand = rng.integers(0, 2, size=n_interspersed)
+        for p, f, s in zip(pos.tolist(), fam.tolist(), strand.tolist()):
+            e = fams[f].copy()
+            m = rng.random(300) < divergence
+            e[m] = (e[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) & 3
+            if s:
+                e = (3 - e)[::-1]
+            g[p:p + 300] = e
+        for _ in range(n_tandem):
+            unit = rng.integers(0, 4, size=int(rng.integers(20, 61)), dtype=np.uint8)
+            ncopy = int(rng.integers(5, 41))
+            arr = np.tile(unit, ncopy)
+            m = rng.random(arr.size) < 0.02
+            arr[m] = (arr[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) & 3
+            p = int(rng.integers(0, total_len - arr.size - 1))
+            g[p:p + arr.size] = arr
+    return g, [int(x) for x in lens]
+
+
+def write_fasta(path: str, g: np.ndarray, lens, prefix: str = "chr"):
+    off = 0
+    with open(path, "wb") as f:
+        for i, ln in enumerate(lens):
+            f.write(f">{prefix}{i + 1}\n".encode())
+            f.write(_ASCII[g[off:off + ln]].tobytes())
+            f.write(b"\n")
+            off += ln
+
+
+def _mutate(ref_codes: np.ndarray, starts: np.ndarray, length: int, rng, sub: float, dele: float, ins: float):
+    """Vectorised read synthesis: returns uint8[n, length] codes sampled from ref_codes at `starts`."""
+    n = starts.shape[0]
+    is_ins = rng.random((n, length)) < ins
+    is_del = rng.random((n, length)) < dele
+    is_ins[:, 0] = False
+    is_del[:, 0] = False
+    # reference offset consumed before output position j
+    consumed = np.arange(length, dtype=np.int64)[None, :] - np.cumsum(is_ins, axis=1) + np.cumsum(is_del, axis=1)
+    idx = starts[:, None] + consumed
+    np.clip(idx, 0, ref_codes.shape[0] - 1, out=idx)
+    reads = ref_codes[idx]
+    rnd = rng.integers(0, 4, size=(n, length), dtype=np.uint8)
+    reads = np.where(is_ins, rnd, reads)
+    m = rng.random((n, length)) < sub
+    reads = np.where(m, (reads + rng.integers(1, 4, size=(n, length), dtype=np.uint8)) & 3, reads).astype(np.uint8)
+    return reads
+
+
+def _revcomp(a: np.ndarray) -> np.ndarray:
+    out = (3 - a)[:, ::-1]
+    return np.ascontiguousarray(out)
+
+
+def make_reads_se(g: np.ndarray, n: int, length: int = 150, seed: int = 43, sub: float = 0.01, dele: float = 0.0015,
+                  ins: float = 0.0015, n_frac: float = 0.0):
+    """n single-end reads as uint8[n, length] nt4 codes (0..3, 4 = N)."""
+    rng = np.random.default_rng(seed)
+    span = length + 40
+    starts = rng.integers(0, g.shape[0] - span, size=n)
+    reads = _mutate(g, starts, length, rng, sub, dele, ins)
+    rev = rng.random(n) < 0.5
+    reads[rev] = _revcomp(reads[rev])
+    if n_frac > 0:
+        m = rng.random((n, length)) < n_frac
+        reads[m] = 4
+    return reads
+
+
+def make_reads_pe(g: np.ndarray, n_pairs: int, length: int = 150, seed: int = 44, ins_mean: float = 400.0,
+                  ins_sd: float = 40.0, sub: float = 0.01, dele: float = 0.0015, ins: float = 0.0015):
+    """n_pairs FR pairs -> (r1, r2) each uint8[n_pairs, length]."""
+    rng = np.random.default_rng(seed)
+    isz = np.maximum(rng.normal(ins_mean, ins_sd, size=n_pairs).astype(np.int64), max(200, length + 10))
+    starts = rng.integers(0, g.shape[0] - isz.max() - 80, size=n_pairs)
+    r1 = _mutate(g, starts, length, rng, sub, dele, ins)
+    # read 2: reverse complement of the fragment's far end
+    far = starts + isz - length
+    r2f = _mutate(g, far, length, rng, sub, dele, ins)
+    r2 = _revcomp(r2f)
+    flip = rng.random(n_pairs) < 0.5  # fragment from the reverse strand: swap roles
+    a = np.where(flip[:, None], r2, r1)
+    b = np.where(flip[:, None], r1, r2)
+    return np.ascontiguousarray(a), np.ascontiguousarray(b)
+
+
+def make_reads_long(g: np.ndarray, n: int, length: int = 10000, seed: int = 7, sub: float = 0.015, dele: float = 0.04,
+                    ins: float = 0.09):
+    """PacBio-CLR-like long reads (config C5)."""
+    rng = np.random.default_rng(seed)
+    starts = rng.integers(0, g.shape[0] - int(length * 1.2) - 10, size=n)
+    reads = _mutate(g, starts, length, rng, sub, dele, ins)
+    rev = rng.random(n) < 0.5
+    reads[rev] = _revcomp(reads[rev])
+    return reads
+
+
+def write_fastq(path: str, reads: np.ndarray, name_prefix: str = "r", suffix: str = ""):
+    n, length = reads.shape
+    seq = _ASCII[reads]
+    qual = b"I" * length
+    with open(path, "wb") as f:
+        for i in range(n):
+            f.write(b"@" + f"{name_prefix}{i}{suffix}".encode() + b"\n")
+            f.write(seq[i].tobytes())
+            f.write(b"\n+\n" + qual + b"\n")
