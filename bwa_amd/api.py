@@ -1,0 +1,153 @@
+"""Python binding (ctypes) of the C-ABI in include/bwagpu.h.
+
+This is plumbing for tests and bench.py: every call goes straight into libbwagpu.so, the HIP library built by
+`bwa_amd.build`.  There is no CPU implementation behind it; if the library is missing or no GPU is visible the
+constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .structs import ALNREG_DTYPE, MemOpt
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "csrc", "libbwagpu.so")
+
+INTV3_DTYPE = np.dtype([("x0", "<u8"), ("x2", "<u8"), ("info", "<u8")])
+GCHAIN_DTYPE = np.dtype([("n_seeds", "<i4"), ("rid", "<i4"), ("w", "<i4"), ("kept", "<i4"), ("is_alt", "<i4"),
+                         ("frac_rep", "<f4"), ("pos", "<i8")])
+GSEED_DTYPE = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4"), ("score", "<i4"), ("_pad", "<i4")])
+assert GCHAIN_DTYPE.itemsize == 32 and GSEED_DTYPE.itemsize == 24
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "n_reads", "n_bases", "n_intv", "n_seeds", "n_chains", "n_regs_raw", "n_regs", "n_occ_blocks", "n_lf_steps",
+        "n_ext_calls", "n_ext_cells", "n_glb_calls", "n_glb_cells", "ref_bases", "n_sw_calls", "n_sw_cells")] + [
+        (n, C.c_float) for n in ("ms_seed", "ms_sa", "ms_chain", "ms_seedsw", "ms_extend", "ms_dedup", "ms_total")] + [
+        ("n_retries", C.c_int32), ("reserved_", C.c_int32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved_"}
+
+
+EXPORTS = [
+    "bwagpu_create", "bwagpu_create_from_files", "bwagpu_destroy", "bwagpu_strerror", "bwagpu_last_error", "bwagpu_version",
+    "bwagpu_index_info", "bwagpu_densify_sa", "bwagpu_set_stats", "bwagpu_get_stats", "bwagpu_align_bseq", "bwagpu_align_flat",
+    "bwagpu_free", "bwagpu_batch_upload", "bwagpu_batch_run", "bwagpu_batch_download", "bwagpu_set_taps", "bwagpu_tap_intervals",
+    "bwagpu_tap_chains", "bwagpu_tap_regs_raw",
+]
+
+
+class BwaGpuError(RuntimeError):
+    pass
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise BwaGpuError(f"{path} not found: build the HIP library first (python -m bwa_amd.build); there is no CPU fallback")
+    L = C.CDLL(path)
+    L.bwagpu_strerror.restype = C.c_char_p
+    L.bwagpu_last_error.restype = C.c_char_p
+    L.bwagpu_last_error.argtypes = [C.c_void_p]
+    L.bwagpu_version.restype = C.c_char_p
+    L.bwagpu_create_from_files.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_int]
+    L.bwagpu_destroy.argtypes = [C.c_void_p]
+    L.bwagpu_index_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bwagpu_densify_sa.argtypes = [C.c_void_p, C.c_int]
+    L.bwagpu_set_stats.argtypes = [C.c_void_p, C.c_int]
+    L.bwagpu_set_taps.argtypes = [C.c_void_p, C.c_int]
+    L.bwagpu_get_stats.argtypes = [C.c_void_p, C.c_void_p]
+    L.bwagpu_align_flat.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bwagpu_batch_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.bwagpu_batch_run.argtypes = [C.c_void_p, C.c_void_p]
+    L.bwagpu_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bwagpu_tap_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bwagpu_tap_chains.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bwagpu_tap_regs_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bwagpu_free.argtypes = [C.c_void_p]
+    return L
+
+
+class BwaGpu:
+    """One handle = one GPU with the index resident in HBM."""
+
+    def __init__(self, prefix: str, device: int = 0, lib_path: str | None = None):
+        self.L = load_library(lib_path)
+        self.h = C.c_void_p()
+        rc = self.L.bwagpu_create_from_files(C.byref(self.h), prefix.encode(), device)
+        if rc != 0:
+            raise BwaGpuError(f"bwagpu_create_from_files({prefix}) failed: {self.L.bwagpu_strerror(rc).decode()}")
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise BwaGpuError(f"{self.L.bwagpu_strerror(rc).decode()}: {self.L.bwagpu_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.L.bwagpu_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def set_stats(self, on=True):
+        self._chk(self.L.bwagpu_set_stats(self.h, int(on)))
+
+    def set_taps(self, on=True):
+        self._chk(self.L.bwagpu_set_taps(self.h, int(on)))
+
+    def densify_sa(self, intv: int):
+        self._chk(self.L.bwagpu_densify_sa(self.h, intv))
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._chk(self.L.bwagpu_get_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+    # -- hot path -------------------------------------------------------------------------------------------
+    def upload(self, seqs: np.ndarray, off: np.ndarray):
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        self._n = off.shape[0] - 1
+        self._chk(self.L.bwagpu_batch_upload(self.h, self._n, seqs.ctypes.data, off.ctypes.data))
+
+    def run(self, opt: MemOpt):
+        self._chk(self.L.bwagpu_batch_run(self.h, C.byref(opt)))
+
+    def _take(self, ptr, n, dtype):
+        out = np.frombuffer(C.string_at(ptr, n * dtype.itemsize), dtype=dtype).copy() if n else np.zeros(0, dtype=dtype)
+        self.L.bwagpu_free(ptr)
+        return out
+
+    def download(self):
+        counts = np.zeros(self._n, dtype=np.int32)
+        p = C.c_void_p()
+        n = C.c_int64()
+        self._chk(self.L.bwagpu_batch_download(self.h, counts.ctypes.data, C.byref(p), C.byref(n)))
+        return counts, self._take(p, n.value, ALNREG_DTYPE)
+
+    def align(self, opt: MemOpt, seqs: np.ndarray, off: np.ndarray):
+        self.upload(seqs, off)
+        self.run(opt)
+        return self.download()
+
+    # -- taps -------------------------------------------------------------------------------------------------
+    def tap_intervals(self):
+        counts = np.zeros(self._n, dtype=np.int32)
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.bwagpu_tap_intervals(self.h, counts.ctypes.data, C.byref(p), C.byref(n)))
+        return counts, self._take(p, n.value, INTV3_DTYPE)
+
+    def tap_chains(self):
+        counts = np.zeros(self._n, dtype=np.int32)
+        pc, nc, ps, ns = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+        self._chk(self.L.bwagpu_tap_chains(self.h, counts.ctypes.data, C.byref(pc), C.byref(nc), C.byref(ps), C.byref(ns)))
+        return counts, self._take(pc, nc.value, GCHAIN_DTYPE), self._take(ps, ns.value, GSEED_DTYPE)
+
+    def tap_regs_raw(self):
+        counts = np.zeros(self._n, dtype=np.int32)
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.bwagpu_tap_regs_raw(self.h, counts.ctypes.data, C.byref(p), C.byref(n)))
+        return counts, self._take(p, n.value, ALNREG_DTYPE)

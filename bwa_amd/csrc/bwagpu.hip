@@ -1,0 +1,517 @@
+// bwagpu.hip -- host side of libbwagpu.so: index upload, batch arenas, kernel sequencing, the C-ABI of
+// include/bwagpu.h.  Device code lives in the dev_*.h headers included below (one translation unit so that the
+// per-lane routines inline into their kernels).
+//
+// Pipeline of one batch (all on one HIP stream, no host round-trips between stages):
+//   k_seed    one lane/read   SMEM seeding (3 passes) -> SA intervals; reserves slot space, B-tree nodes
+//   k_sa      one lane/seed   suffix-array lookups (LF walk to a sampled row)
+//   k_chain   one lane/read   B-tree chaining, chain weights, chain filter -> kept chains + flattened seeds
+//   k_seedsw  one lane/read   (long reads only) mem_flt_chained_seeds: local SW re-scoring of short seeds
+//   k_extend  one lane/read   banded extension of seeds (ksw_extend2) -> raw alignment regions
+//   k_dedup   one lane/read   sort / redundancy removal / patching (ksw_global2 score) -> final regions
+// Arenas are sized from the batch's base count and grown (whole batch re-run) if a stage reports overflow.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+
+#include "dev_common.h"
+#include "dev_fm.h"
+#include "dev_sort.h"
+#include "dev_seed.h"
+#include "dev_chain.h"
+#include "dev_ext.h"
+#include "dev_dedup.h"
+#include "dev_seedsw.h"
+
+#define BWAGPU_VERSION "bwagpu 0.1 (gfx950)"
+
+struct DevBuf {
+	void *p = nullptr; size_t cap = 0;
+	int ensure(size_t bytes) {
+		if (bytes <= cap) return 0;
+		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+		size_t want = bytes + (bytes >> 3) + 256;
+		if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
+		cap = want;
+		return 0;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	template <class T> T *as() const { return (T*)p; }
+};
+
+struct bwagpu_s {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[8] = {};
+	std::string err;
+	// index
+	DevIndex ix = {};
+	DevBuf d_bwt, d_sa, d_pac, d_ctg_off, d_ctg_len, d_ctg_alt;
+	i64 l_pac = 0; int n_seqs = 0; u64 seq_len = 0; int sa_intv = 0;
+	u64 bwt_blocks = 0;
+	// batch
+	int n_reads = 0, max_len = 0; i64 n_bases = 0;
+	bool have_batch = false, ran = false;
+	int stats_on = 0, taps_on = 1;
+	bwagpu_stats_t stats = {};
+	DevBuf d_seq, d_off, d_ctr, d_tmp_intv, d_tmp_mem, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
+	DevBuf d_slot_pos, d_slot_iv, d_slot_next, d_slot_chain, d_slot_ord, d_slot_kept, d_slot_srt, d_slot_cseed, d_slot_cchain;
+	DevBuf d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
+	i64 intv_cap = 0, slot_cap = 0, node_cap = 0, reg_cap = 0; int mem_cap = 0;
+	std::vector<i64> h_off;
+};
+
+#define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return BWAGPU_EHIP; } } while (0)
+
+extern "C" const char *bwagpu_version(void) { return BWAGPU_VERSION; }
+
+extern "C" const char *bwagpu_strerror(int code)
+{
+	switch (code) {
+	case BWAGPU_OK: return "ok";
+	case BWAGPU_ENODEV: return "no usable HIP device";
+	case BWAGPU_EINVAL: return "invalid argument";
+	case BWAGPU_ENOMEM: return "out of memory";
+	case BWAGPU_EIO: return "index files missing or inconsistent";
+	case BWAGPU_EHIP: return "HIP runtime error";
+	case BWAGPU_EUNSUP: return "unsupported option on the device path";
+	default: return "unknown error";
+	}
+}
+extern "C" const char *bwagpu_last_error(const bwagpu_t *h) { return h ? h->err.c_str() : ""; }
+extern "C" void bwagpu_free(void *p) { free(p); }
+
+static int upload(bwagpu_t *h, DevBuf &b, const void *src, size_t bytes)
+{
+	if (b.ensure(bytes ? bytes : 16)) { h->err = "hipMalloc failed"; return BWAGPU_ENOMEM; }
+	if (bytes) HIPCHK(h, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+	return 0;
+}
+
+extern "C" int bwagpu_create(bwagpu_t **out, const bwagpu_index_desc_t *d, int device)
+{
+	if (!out || !d || !d->bwt || !d->sa || !d->pac || d->n_seqs <= 0) return BWAGPU_EINVAL;
+	if (d->sa_intv <= 0 || (d->sa_intv & (d->sa_intv - 1))) return BWAGPU_EINVAL;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BWAGPU_ENODEV;
+	if (hipSetDevice(device) != hipSuccess) return BWAGPU_ENODEV;
+	bwagpu_t *h = new bwagpu_s();
+	h->device = device;
+	int rc;
+	if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return BWAGPU_ENODEV; }
+	for (int i = 0; i < 8; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return BWAGPU_ENODEV; }
+	// the last Occ record of the .bwt is a trailing 32-byte half block; pad the upload to whole 64-byte blocks
+	u64 nblk = (d->bwt_size + 15) / 16;
+	std::vector<uint32_t> padded;
+	const uint32_t *src = d->bwt;
+	if (d->bwt_size % 16) { padded.assign(nblk * 16, 0); memcpy(padded.data(), d->bwt, d->bwt_size * 4); src = padded.data(); }
+	if ((rc = upload(h, h->d_bwt, src, nblk * 64))) goto fail;
+	if ((rc = upload(h, h->d_sa, d->sa, d->n_sa * 8))) goto fail;
+	if ((rc = upload(h, h->d_pac, d->pac, (size_t)(d->l_pac / 4 + 1)))) goto fail;
+	if ((rc = upload(h, h->d_ctg_off, d->ctg_offset, (size_t)d->n_seqs * 8))) goto fail;
+	if ((rc = upload(h, h->d_ctg_len, d->ctg_len, (size_t)d->n_seqs * 4))) goto fail;
+	if ((rc = upload(h, h->d_ctg_alt, d->ctg_is_alt, (size_t)d->n_seqs * 4))) goto fail;
+	h->bwt_blocks = nblk;
+	h->ix.bwt = h->d_bwt.as<uint4>();
+	h->ix.primary = d->primary; for (int i = 0; i < 5; ++i) h->ix.L2[i] = d->L2[i];
+	h->ix.seq_len = d->seq_len;
+	h->ix.sa = h->d_sa.as<u64>(); h->ix.sa_mask = (u64)d->sa_intv - 1;
+	h->ix.sa_shift = 0; while ((1 << h->ix.sa_shift) < d->sa_intv) ++h->ix.sa_shift;
+	h->ix.pac = h->d_pac.as<u8>(); h->ix.l_pac = d->l_pac;
+	h->ix.n_seqs = d->n_seqs; h->ix.ctg_off = h->d_ctg_off.as<i64>(); h->ix.ctg_len = h->d_ctg_len.as<i32>(); h->ix.ctg_alt = h->d_ctg_alt.as<i32>();
+	h->l_pac = d->l_pac; h->n_seqs = d->n_seqs; h->seq_len = d->seq_len; h->sa_intv = d->sa_intv;
+	*out = h;
+	return BWAGPU_OK;
+fail:
+	bwagpu_destroy(h);
+	return rc;
+}
+
+extern "C" void bwagpu_destroy(bwagpu_t *h)
+{
+	if (!h) return;
+	DevBuf *all[] = { &h->d_bwt, &h->d_sa, &h->d_pac, &h->d_ctg_off, &h->d_ctg_len, &h->d_ctg_alt, &h->d_seq, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
+		&h->d_tmp_mem, &h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_iv, &h->d_slot_next,
+		&h->d_slot_chain, &h->d_slot_ord, &h->d_slot_kept, &h->d_slot_srt, &h->d_slot_cseed, &h->d_slot_cchain, &h->d_chain_n, &h->d_node_off,
+		&h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
+	for (DevBuf *b : all) b->release();
+	for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+	if (h->stream) (void)hipStreamDestroy(h->stream);
+	delete h;
+}
+
+// ---- index files (formats: bwt.c:385-462, bntseq.c:97-211, bwa.c:300-312) -------------------------------------
+static bool read_file(const std::string &fn, std::vector<char> &out)
+{
+	FILE *fp = fopen(fn.c_str(), "rb");
+	if (!fp) return false;
+	fseek(fp, 0, SEEK_END); long sz = ftell(fp); fseek(fp, 0, SEEK_SET);
+	out.resize((size_t)sz);
+	bool ok = sz == 0 || fread(out.data(), 1, (size_t)sz, fp) == (size_t)sz;
+	fclose(fp);
+	return ok;
+}
+
+extern "C" int bwagpu_create_from_files(bwagpu_t **out, const char *prefix, int device)
+{
+	if (!out || !prefix) return BWAGPU_EINVAL;
+	std::string pre(prefix);
+	std::vector<char> fb, fs, fp;
+	if (!read_file(pre + ".bwt", fb) || fb.size() < 40 || !read_file(pre + ".sa", fs) || fs.size() < 56 || !read_file(pre + ".pac", fp)) return BWAGPU_EIO;
+	bwagpu_index_desc_t d; memset(&d, 0, sizeof d);
+	const u64 *hb = (const u64*)fb.data();
+	d.primary = hb[0]; d.L2[0] = 0; for (int i = 0; i < 4; ++i) d.L2[i + 1] = hb[1 + i];
+	d.seq_len = d.L2[4];
+	d.bwt = (const uint32_t*)(fb.data() + 40); d.bwt_size = (fb.size() - 40) / 4;
+	const u64 *hs = (const u64*)fs.data();
+	if (hs[0] != d.primary || hs[6] != d.seq_len) return BWAGPU_EIO;
+	d.sa_intv = (int)hs[5];
+	if (d.sa_intv <= 0) return BWAGPU_EIO;
+	d.n_sa = (d.seq_len + d.sa_intv) / d.sa_intv;
+	if (fs.size() < 56 + (d.n_sa - 1) * 8) return BWAGPU_EIO;
+	std::vector<u64> sa(d.n_sa);
+	sa[0] = (u64)-1;                                   // bwt_restore_sa forces sa[0] = -1 (bwt.c:437)
+	memcpy(sa.data() + 1, fs.data() + 56, (d.n_sa - 1) * 8);
+	d.sa = sa.data();
+	// .ann: "l_pac n_seqs seed" then per contig "gi name [anno]" / "offset len n_ambs"
+	FILE *fa = fopen((pre + ".ann").c_str(), "r");
+	if (!fa) return BWAGPU_EIO;
+	long long xx; int n_seqs; unsigned seed;
+	if (fscanf(fa, "%lld%d%u", &xx, &n_seqs, &seed) != 3 || n_seqs <= 0) { fclose(fa); return BWAGPU_EIO; }
+	d.l_pac = xx; d.n_seqs = n_seqs;
+	std::vector<i64> coff(n_seqs); std::vector<i32> clen(n_seqs), calt(n_seqs, 0); std::vector<std::string> names(n_seqs);
+	for (int i = 0; i < n_seqs; ++i) {
+		char name[8192]; unsigned gi; int c, n_ambs, len;
+		if (fscanf(fa, "%u%8191s", &gi, name) != 2) { fclose(fa); return BWAGPU_EIO; }
+		names[i] = name;
+		while ((c = fgetc(fa)) != '\n' && c != EOF) {}
+		if (fscanf(fa, "%lld%d%d", &xx, &len, &n_ambs) != 3) { fclose(fa); return BWAGPU_EIO; }
+		coff[i] = xx; clen[i] = len;
+	}
+	fclose(fa);
+	if (FILE *fl = fopen((pre + ".alt").c_str(), "r")) {   // first column of each non-@ line names an ALT contig
+		char line[8192];
+		while (fgets(line, sizeof line, fl)) {
+			if (line[0] == '@') continue;
+			char *e = line; while (*e && *e != '\t' && *e != '\n' && *e != '\r') ++e; *e = 0;
+			for (int i = 0; i < n_seqs; ++i) if (names[i] == line) calt[i] = 1;
+		}
+		fclose(fl);
+	}
+	if ((i64)fp.size() < d.l_pac / 4 + 1) return BWAGPU_EIO;
+	d.pac = (const u8*)fp.data();
+	d.ctg_offset = coff.data(); d.ctg_len = clen.data(); d.ctg_is_alt = calt.data();
+	return bwagpu_create(out, &d, device);
+}
+
+extern "C" int bwagpu_index_info(const bwagpu_t *h, int64_t *l_pac, int32_t *n_seqs, uint64_t *seq_len, int *sa_intv)
+{
+	if (!h) return BWAGPU_EINVAL;
+	if (l_pac) *l_pac = h->l_pac;
+	if (n_seqs) *n_seqs = h->n_seqs;
+	if (seq_len) *seq_len = h->seq_len;
+	if (sa_intv) *sa_intv = h->sa_intv;
+	return BWAGPU_OK;
+}
+
+extern "C" int bwagpu_set_stats(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->stats_on = enable ? 1 : 0; return BWAGPU_OK; }
+extern "C" int bwagpu_set_taps(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->taps_on = enable ? 1 : 0; return BWAGPU_OK; }
+extern "C" int bwagpu_get_stats(const bwagpu_t *h, bwagpu_stats_t *out) { if (!h || !out) return BWAGPU_EINVAL; *out = h->stats; return BWAGPU_OK; }
+
+// ---- SA densification ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_densify(DevIndex ix, u64 *out, u64 n_out, int new_shift)
+{
+	u32 steps = 0;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (u64)gridDim.x * blockDim.x)
+		out[i] = i == 0 ? ~0ull : fm_sa(ix, i << new_shift, &steps);
+}
+
+extern "C" int bwagpu_densify_sa(bwagpu_t *h, int new_intv)
+{
+	if (!h || new_intv <= 0 || (new_intv & (new_intv - 1)) || new_intv > h->sa_intv) return BWAGPU_EINVAL;
+	if (new_intv == h->sa_intv) return BWAGPU_OK;
+	HIPCHK(h, hipSetDevice(h->device));
+	int sh = 0; while ((1 << sh) < new_intv) ++sh;
+	u64 n_out = (h->seq_len + new_intv) / new_intv;
+	DevBuf nb;
+	if (nb.ensure(n_out * 8)) { h->err = "hipMalloc failed (dense SA)"; return BWAGPU_ENOMEM; }
+	hipLaunchKernelGGL(k_densify, dim3(8192), dim3(256), 0, h->stream, h->ix, nb.as<u64>(), n_out, sh);
+	HIPCHK(h, hipGetLastError());
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	h->d_sa.release();
+	h->d_sa = nb;
+	h->ix.sa = h->d_sa.as<u64>(); h->ix.sa_mask = (u64)new_intv - 1; h->ix.sa_shift = sh; h->sa_intv = new_intv;
+	return BWAGPU_OK;
+}
+
+// ---- batches -------------------------------------------------------------------------------------------------
+static const int BLOCK = 256;
+static const int MAX_RESIDENT_THREADS = 256 * 2048;   // 256 CUs x 32 waves x 64 lanes
+
+extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, const int64_t *off)
+{
+	if (!h || n < 0 || (n > 0 && (!seqs || !off))) return BWAGPU_EINVAL;
+	HIPCHK(h, hipSetDevice(h->device));
+	h->have_batch = false; h->ran = false;
+	h->n_reads = n; h->max_len = 0; h->n_bases = n ? off[n] - off[0] : 0;
+	if (n && off[0] != 0) return BWAGPU_EINVAL;
+	for (int i = 0; i < n; ++i) {
+		i64 l = off[i + 1] - off[i];
+		if (l < 0 || l > 0x3fffffff) return BWAGPU_EINVAL;
+		if (l > h->max_len) h->max_len = (int)l;
+	}
+	h->h_off.assign(off, off + n + 1);
+	if (h->d_seq.ensure((size_t)h->n_bases + 16) || h->d_off.ensure((size_t)(n + 1) * 8)) { h->err = "hipMalloc failed (reads)"; return BWAGPU_ENOMEM; }
+	if (n) {
+		HIPCHK(h, hipMemcpyAsync(h->d_seq.p, seqs, (size_t)h->n_bases, hipMemcpyHostToDevice, h->stream));
+		HIPCHK(h, hipMemcpyAsync(h->d_off.p, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, h->stream));
+		HIPCHK(h, hipStreamSynchronize(h->stream));
+	}
+	// first guess of the arena sizes (grown on overflow)
+	i64 nb = h->n_bases > 1024 ? h->n_bases : 1024;
+	h->intv_cap = nb / 6 + 4096;
+	h->slot_cap = nb / 4 + 4096;
+	h->node_cap = h->slot_cap / 4 + 2 * (i64)n + 64;
+	h->reg_cap = nb / 8 + 4096;
+	h->mem_cap = h->max_len < 64 ? 64 : h->max_len;
+	h->have_batch = true;
+	return BWAGPU_OK;
+}
+
+static int alloc_batch(bwagpu_t *h, int n_threads)
+{
+	int n = h->n_reads; size_t sc = (size_t)h->slot_cap;
+	int bad = 0;
+	bad |= h->d_ctr.ensure(sizeof(Counters));
+	bad |= h->d_tmp_intv.ensure((size_t)n_threads * 2 * (h->max_len + 1) * sizeof(BiIntv));
+	bad |= h->d_tmp_mem.ensure((size_t)n_threads * h->mem_cap * sizeof(Intv3));
+	bad |= h->d_intv_n.ensure((size_t)n * 4 + 16); bad |= h->d_intv_off.ensure((size_t)n * 8 + 16);
+	bad |= h->d_intv.ensure((size_t)h->intv_cap * sizeof(Intv3));
+	bad |= h->d_seed_n.ensure((size_t)n * 4 + 16); bad |= h->d_seed_off.ensure((size_t)n * 8 + 16);
+	bad |= h->d_slot_pos.ensure(sc * 8); bad |= h->d_slot_iv.ensure(sc * 4); bad |= h->d_slot_next.ensure(sc * 4);
+	bad |= h->d_slot_chain.ensure(sc * sizeof(ChainRec)); bad |= h->d_slot_ord.ensure(sc * 4); bad |= h->d_slot_kept.ensure(sc * 4);
+	bad |= h->d_slot_srt.ensure(sc * 8); bad |= h->d_slot_cseed.ensure(sc * sizeof(bwagpu_seed_t)); bad |= h->d_slot_cchain.ensure(sc * sizeof(bwagpu_chain_t));
+	bad |= h->d_chain_n.ensure((size_t)n * 4 + 16); bad |= h->d_node_off.ensure((size_t)n * 8 + 16);
+	bad |= h->d_nodes.ensure((size_t)h->node_cap * BT_NODE_INTS * 4);
+	bad |= h->d_reg_off.ensure((size_t)n * 8 + 16); bad |= h->d_reg_cap_r.ensure((size_t)n * 4 + 16);
+	bad |= h->d_reg_n_raw.ensure((size_t)n * 4 + 16); bad |= h->d_reg_n.ensure((size_t)n * 4 + 16);
+	bad |= h->d_regs.ensure((size_t)h->reg_cap * sizeof(bwagpu_alnreg_t));
+	if (h->taps_on) bad |= h->d_regs_raw.ensure((size_t)h->reg_cap * sizeof(bwagpu_alnreg_t));
+	int n_waves = (n_threads + 63) / 64;
+	bad |= h->d_dp_h.ensure((size_t)n_waves * (h->max_len + 2) * DPS * 4);
+	bad |= h->d_dp_e.ensure((size_t)n_waves * (h->max_len + 2) * DPS * 4);
+	bad |= h->d_minhsp.ensure((size_t)(h->max_len + 2) * 4);
+	if (bad) { h->err = "hipMalloc failed (batch arenas)"; return BWAGPU_ENOMEM; }
+	return 0;
+}
+
+extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
+{
+	if (!h || !opt || !h->have_batch) return BWAGPU_EINVAL;
+	if (opt->e_del <= 0 || opt->e_ins <= 0 || opt->max_occ <= 0 || opt->min_seed_len <= 0 || opt->w < 0) return BWAGPU_EINVAL;
+	HIPCHK(h, hipSetDevice(h->device));
+	memset(&h->stats, 0, sizeof h->stats);
+	h->stats.n_reads = h->n_reads; h->stats.n_bases = h->n_bases;
+	h->ran = false;
+	if (h->n_reads == 0) { h->ran = true; return BWAGPU_OK; }
+	int n = h->n_reads;
+	// resident lanes: enough to fill the chip, bounded by the seeding scratch budget (2 interval stacks per lane)
+	size_t per_lane = (size_t)2 * (h->max_len + 1) * sizeof(BiIntv) + (size_t)h->mem_cap * sizeof(Intv3) + (size_t)2 * (h->max_len + 2) * 4;
+	size_t budget = (size_t)12 << 30;
+	i64 max_thr = (i64)(budget / per_lane);
+	if (max_thr > MAX_RESIDENT_THREADS) max_thr = MAX_RESIDENT_THREADS;
+	if (max_thr < BLOCK) max_thr = BLOCK;
+	int n_threads = (int)(((i64)n + BLOCK - 1) / BLOCK * BLOCK);
+	if (n_threads > max_thr) n_threads = (int)(max_thr / BLOCK * BLOCK);
+	// mem_flt_chained_seeds thresholds per read length (bwamem.c:626-628); log() stays on the host
+	std::vector<i32> minhsp(h->max_len + 2, -1);
+	bool any_seedsw = false;
+	for (int l = 1; l <= h->max_len; ++l) {
+		double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log((double)l);
+		if (!(min_l > 0.05f * l)) { minhsp[l] = (int)(opt->a * min_l + .499); any_seedsw = true; }
+	}
+	for (int attempt = 0; attempt < 12; ++attempt) {
+		int rc = alloc_batch(h, n_threads);
+		if (rc) return rc;
+		HIPCHK(h, hipMemcpyAsync(h->d_minhsp.p, minhsp.data(), minhsp.size() * 4, hipMemcpyHostToDevice, h->stream));
+		HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
+		Batch B; memset(&B, 0, sizeof B);
+		B.n_reads = n; B.max_len = h->max_len; B.stats = h->stats_on;
+		B.seq = h->d_seq.as<u8>(); B.off = h->d_off.as<i64>(); B.ctr = h->d_ctr.as<Counters>();
+		B.tmp_intv = h->d_tmp_intv.as<BiIntv>(); B.tmp_mem = h->d_tmp_mem.as<Intv3>(); B.mem_cap = h->mem_cap;
+		B.intv_n = h->d_intv_n.as<i32>(); B.intv_off = h->d_intv_off.as<i64>(); B.intv = h->d_intv.as<Intv3>(); B.intv_cap = h->intv_cap;
+		B.seed_n = h->d_seed_n.as<i32>(); B.seed_off = h->d_seed_off.as<i64>(); B.slot_cap = h->slot_cap;
+		B.slot_pos = h->d_slot_pos.as<u64>(); B.slot_iv = h->d_slot_iv.as<i32>(); B.slot_next = h->d_slot_next.as<i32>();
+		B.slot_chain = h->d_slot_chain.as<ChainRec>(); B.slot_ord = h->d_slot_ord.as<i32>(); B.slot_kept = h->d_slot_kept.as<i32>();
+		B.slot_srt = h->d_slot_srt.as<u64>(); B.slot_cseed = h->d_slot_cseed.as<bwagpu_seed_t>(); B.slot_cchain = h->d_slot_cchain.as<bwagpu_chain_t>();
+		B.chain_n = h->d_chain_n.as<i32>(); B.node_off = h->d_node_off.as<i64>(); B.nodes = h->d_nodes.as<i32>(); B.node_cap = h->node_cap;
+		B.reg_off = h->d_reg_off.as<i64>(); B.reg_cap_r = h->d_reg_cap_r.as<i32>(); B.reg_n_raw = h->d_reg_n_raw.as<i32>(); B.reg_n = h->d_reg_n.as<i32>();
+		B.regs = h->d_regs.as<bwagpu_alnreg_t>(); B.reg_cap = h->reg_cap;
+		B.regs_raw = h->taps_on ? h->d_regs_raw.as<bwagpu_alnreg_t>() : nullptr;
+		B.dp_h = h->d_dp_h.as<i32>(); B.dp_e = h->d_dp_e.as<i32>(); B.dp_waves = (n_threads + 63) / 64;
+		B.seedsw_minhsp = h->d_minhsp.as<i32>();
+		dim3 grid(n_threads / BLOCK), block(BLOCK);
+		HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+		hipLaunchKernelGGL(k_seed, grid, block, 0, h->stream, h->ix, *opt, B);
+		HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+		i64 sa_blocks = (h->slot_cap + BLOCK - 1) / BLOCK;
+		if (sa_blocks > MAX_RESIDENT_THREADS / BLOCK) sa_blocks = MAX_RESIDENT_THREADS / BLOCK;
+		hipLaunchKernelGGL(k_sa, dim3((unsigned)sa_blocks), block, 0, h->stream, h->ix, B);
+		HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+		hipLaunchKernelGGL(k_chain, grid, block, 0, h->stream, h->ix, *opt, B);
+		HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+		if (any_seedsw) hipLaunchKernelGGL(k_seedsw, grid, block, 0, h->stream, h->ix, *opt, B);
+		HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
+		hipLaunchKernelGGL(k_extend, grid, block, 0, h->stream, h->ix, *opt, B);
+		HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
+		hipLaunchKernelGGL(k_dedup, grid, block, 0, h->stream, h->ix, *opt, B);
+		HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
+		HIPCHK(h, hipGetLastError());
+		Counters c;
+		HIPCHK(h, hipMemcpyAsync(&c, h->d_ctr.p, sizeof c, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(h, hipStreamSynchronize(h->stream));
+		if (c.overflow) {   // grow what overflowed and redo the batch; nothing of the failed attempt is kept
+			if (c.overflow & 1) h->intv_cap = h->intv_cap * 2;
+			if (c.overflow & 2) h->slot_cap = h->slot_cap * 2;
+			if (c.overflow & 6) h->node_cap = h->slot_cap / 4 + 2 * (i64)n + 64 > h->node_cap * 2 ? h->slot_cap / 4 + 2 * (i64)n + 64 : h->node_cap * 2;
+			if (c.overflow & 8) h->reg_cap = h->reg_cap * 2;
+			if (c.overflow & 16) h->mem_cap = h->mem_cap * 4;
+			++h->stats.n_retries;
+			continue;
+		}
+		float ms[6];
+		for (int i = 0; i < 6; ++i) HIPCHK(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+		h->stats.ms_seed = ms[0]; h->stats.ms_sa = ms[1]; h->stats.ms_chain = ms[2]; h->stats.ms_seedsw = ms[3]; h->stats.ms_extend = ms[4]; h->stats.ms_dedup = ms[5];
+		HIPCHK(h, hipEventElapsedTime(&h->stats.ms_total, h->ev[0], h->ev[6]));
+		h->stats.n_seeds = (i64)c.seed_used;
+		h->stats.n_intv = (i64)c.intv_used;
+		h->stats.n_chains = (i64)c.n_chains; h->stats.n_regs_raw = (i64)c.n_regs_raw; h->stats.n_regs = (i64)c.n_regs;
+		h->stats.n_occ_blocks = (i64)c.occ_blocks; h->stats.n_lf_steps = (i64)c.lf_steps;
+		h->stats.n_ext_calls = (i64)c.ext_calls; h->stats.n_ext_cells = (i64)c.ext_cells;
+		h->stats.n_glb_calls = (i64)c.glb_calls; h->stats.n_glb_cells = (i64)c.glb_cells; h->stats.ref_bases = (i64)c.ref_bases;
+		h->stats.n_sw_calls = (i64)c.sw_calls; h->stats.n_sw_cells = (i64)c.sw_cells;
+		h->ran = true;
+		return BWAGPU_OK;
+	}
+	h->err = "arena growth did not converge";
+	return BWAGPU_ENOMEM;
+}
+
+// gather per-read variable-length device records into read order on the host
+template <class T>
+static int gather(bwagpu_t *h, const DevBuf &d_n, const DevBuf &d_off, const DevBuf &d_rec, i64 rec_cap, int32_t *counts, T **out, int64_t *n_out)
+{
+	int n = h->n_reads;
+	std::vector<i32> cnt(n); std::vector<i64> off(n);
+	if (n) {
+		HIPCHK(h, hipMemcpy(cnt.data(), d_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+		HIPCHK(h, hipMemcpy(off.data(), d_off.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+	}
+	i64 tot = 0, hi = 0;
+	for (int i = 0; i < n; ++i) { tot += cnt[i]; if (cnt[i] && off[i] + cnt[i] > hi) hi = off[i] + cnt[i]; }
+	if (hi > rec_cap) { h->err = "internal: record range beyond arena"; return BWAGPU_EHIP; }
+	std::vector<T> all((size_t)hi);
+	if (hi) HIPCHK(h, hipMemcpy(all.data(), d_rec.p, (size_t)hi * sizeof(T), hipMemcpyDeviceToHost));
+	T *res = (T*)malloc((size_t)(tot ? tot : 1) * sizeof(T));
+	if (!res) return BWAGPU_ENOMEM;
+	i64 k = 0;
+	for (int i = 0; i < n; ++i) {
+		if (counts) counts[i] = cnt[i];
+		if (cnt[i]) memcpy(res + k, all.data() + off[i], (size_t)cnt[i] * sizeof(T));
+		k += cnt[i];
+	}
+	*out = res; *n_out = tot;
+	return BWAGPU_OK;
+}
+
+extern "C" int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg_t **regs_out, int64_t *n_regs_out)
+{
+	if (!h || !h->ran || !regs_out || !n_regs_out) return BWAGPU_EINVAL;
+	HIPCHK(h, hipSetDevice(h->device));
+	if (h->n_reads == 0) { *regs_out = (bwagpu_alnreg_t*)malloc(sizeof(bwagpu_alnreg_t)); *n_regs_out = 0; return BWAGPU_OK; }
+	return gather<bwagpu_alnreg_t>(h, h->d_reg_n, h->d_reg_off, h->d_regs, h->reg_cap, counts, regs_out, n_regs_out);
+}
+
+extern "C" int bwagpu_align_flat(bwagpu_t *h, const bwagpu_opt_t *opt, int n, const uint8_t *seqs, const int64_t *off,
+								 int32_t *counts, bwagpu_alnreg_t **regs_out, int64_t *n_regs_out)
+{
+	int rc;
+	if ((rc = bwagpu_batch_upload(h, n, seqs, off))) return rc;
+	if ((rc = bwagpu_batch_run(h, opt))) return rc;
+	return bwagpu_batch_download(h, counts, regs_out, n_regs_out);
+}
+
+// nst_nt4_table (bntseq.c:46-63) as a function: A/a C/c G/g T/t -> 0..3, everything else 4
+static inline uint8_t nt4(unsigned char c)
+{
+	switch (c) {
+	case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3;
+	default: return 4;
+	}
+}
+
+extern "C" int bwagpu_align_bseq(bwagpu_t *h, const bwagpu_opt_t *opt, int n, bwagpu_bseq1_t *seqs, bwagpu_alnreg_v *regs)
+{
+	if (!h || !opt || n < 0 || (n > 0 && (!seqs || !regs))) return BWAGPU_EINVAL;
+	std::vector<i64> off((size_t)n + 1, 0);
+	for (int i = 0; i < n; ++i) off[i + 1] = off[i] + seqs[i].l_seq;
+	std::vector<u8> flat((size_t)off[n] + 1);
+	for (int i = 0; i < n; ++i) {   // in-place nt4 encoding, the contract of mem_align1_core (bwamem.c:1087-1088)
+		char *s = seqs[i].seq;
+		for (int j = 0; j < seqs[i].l_seq; ++j) { unsigned char c = (unsigned char)s[j]; s[j] = (char)(c < 4 ? c : nt4(c)); }
+		memcpy(flat.data() + off[i], s, (size_t)seqs[i].l_seq);
+	}
+	std::vector<int32_t> counts((size_t)n);
+	bwagpu_alnreg_t *all = nullptr; int64_t tot = 0;
+	int rc = bwagpu_align_flat(h, opt, n, flat.data(), off.data(), counts.data(), &all, &tot);
+	if (rc) return rc;
+	i64 k = 0;
+	for (int i = 0; i < n; ++i) {
+		regs[i].n = regs[i].m = (size_t)counts[i];
+		regs[i].a = (bwagpu_alnreg_t*)malloc((size_t)(counts[i] ? counts[i] : 1) * sizeof(bwagpu_alnreg_t));
+		if (!regs[i].a) { free(all); return BWAGPU_ENOMEM; }
+		memcpy(regs[i].a, all + k, (size_t)counts[i] * sizeof(bwagpu_alnreg_t));
+		k += counts[i];
+	}
+	free(all);
+	return BWAGPU_OK;
+}
+
+// ---- stage taps ----------------------------------------------------------------------------------------------
+extern "C" int bwagpu_tap_intervals(bwagpu_t *h, int32_t *counts, bwagpu_intv_t **out, int64_t *n_out)
+{
+	if (!h || !h->ran || !out || !n_out) return BWAGPU_EINVAL;
+	static_assert(sizeof(bwagpu_intv_t) == sizeof(Intv3), "layout");
+	return gather<bwagpu_intv_t>(h, h->d_intv_n, h->d_intv_off, h->d_intv, h->intv_cap, counts, out, n_out);
+}
+
+extern "C" int bwagpu_tap_chains(bwagpu_t *h, int32_t *counts, bwagpu_chain_t **chains, int64_t *n_chains, bwagpu_seed_t **seeds, int64_t *n_seeds)
+{
+	if (!h || !h->ran || !chains || !n_chains || !seeds || !n_seeds) return BWAGPU_EINVAL;
+	int n = h->n_reads;
+	std::vector<int32_t> cn((size_t)n);
+	int rc = gather<bwagpu_chain_t>(h, h->d_chain_n, h->d_seed_off, h->d_slot_cchain, h->slot_cap, cn.data(), chains, n_chains);
+	if (rc) return rc;
+	// seeds of the kept chains: count per read = sum of its chains' n_seeds
+	std::vector<i32> sn((size_t)n); std::vector<i64> off((size_t)n);
+	if (n) HIPCHK(h, hipMemcpy(off.data(), h->d_seed_off.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+	i64 k = 0, tot = 0, hi = 0;
+	for (int i = 0; i < n; ++i) { int s = 0; for (int j = 0; j < cn[i]; ++j) s += (*chains)[k + j].n_seeds; k += cn[i]; sn[i] = s; tot += s; if (s && off[i] + s > hi) hi = off[i] + s; }
+	std::vector<bwagpu_seed_t> all((size_t)hi);
+	if (hi) HIPCHK(h, hipMemcpy(all.data(), h->d_slot_cseed.p, (size_t)hi * sizeof(bwagpu_seed_t), hipMemcpyDeviceToHost));
+	bwagpu_seed_t *res = (bwagpu_seed_t*)malloc((size_t)(tot ? tot : 1) * sizeof(bwagpu_seed_t));
+	k = 0;
+	for (int i = 0; i < n; ++i) { if (sn[i]) memcpy(res + k, all.data() + off[i], (size_t)sn[i] * sizeof(bwagpu_seed_t)); k += sn[i]; if (counts) counts[i] = cn[i]; }
+	*seeds = res; *n_seeds = tot;
+	return BWAGPU_OK;
+}
+
+extern "C" int bwagpu_tap_regs_raw(bwagpu_t *h, int32_t *counts, bwagpu_alnreg_t **out, int64_t *n_out)
+{
+	if (!h || !h->ran || !h->taps_on || !out || !n_out) return BWAGPU_EINVAL;
+	return gather<bwagpu_alnreg_t>(h, h->d_reg_n_raw, h->d_reg_off, h->d_regs_raw, h->reg_cap, counts, out, n_out);
+}

@@ -1,0 +1,283 @@
+// dev_chain.h -- seeds -> chains (mem_chain, bwamem.c:277-342) and the chain filter (mem_chain_flt,
+// bwamem.c:353-411).  One lane per read; all state lives in the read's slot-space region.
+#pragma once
+#include "dev_fm.h"
+#include "dev_sort.h"
+#include "dev_seed.h"
+
+// ---- contig lookup ---------------------------------------------------------------------------------------
+DEVFN int dev_pos2rid(const DevIndex &ix, i64 pos_f)
+{	// bns_pos2rid (bntseq.c:354-368)
+	if (pos_f >= ix.l_pac) return -1;
+	int lo = 0, hi = ix.n_seqs;
+	while (hi - lo > 1) {
+		int mid = (lo + hi) >> 1;
+		if (ix.ctg_off[mid] <= pos_f) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+DEVFN i64 dev_depos(const DevIndex &ix, i64 pos, int *is_rev)
+{	// bns_depos (bntseq.h:87-90)
+	*is_rev = pos >= ix.l_pac;
+	return *is_rev ? (ix.l_pac << 1) - 1 - pos : pos;
+}
+DEVFN int dev_intv2rid(const DevIndex &ix, i64 rb, i64 re)
+{	// bns_intv2rid (bntseq.c:370-379)
+	int r;
+	if (rb < ix.l_pac && re > ix.l_pac) return -2;
+	int a = dev_pos2rid(ix, dev_depos(ix, rb, &r));
+	int b = rb < re ? dev_pos2rid(ix, dev_depos(ix, re - 1, &r)) : a;
+	return a == b ? a : -1;
+}
+
+// ---- B-tree over chain positions (kbtree.h as instantiated at bwamem.c:212-213: t = 5, <= 9 keys/node).
+// Duplicate positions are legal and their in-order place depends on the node layout, so the structure is
+// reproduced literally.  Keys are chain indices; nodes are 24-int records.
+#define BT_T 5
+#define BT_MAXK 9
+struct BTree {
+	i32 *nd;            // node pool of this read
+	int n_nodes, root;
+	const ChainRec *ch; // chain pool (positions)
+	DEVFN i32 &N(int x) { return nd[x * BT_NODE_INTS]; }
+	DEVFN i32 &INT(int x) { return nd[x * BT_NODE_INTS + 1]; }
+	DEVFN i32 &KEY(int x, int i) { return nd[x * BT_NODE_INTS + 2 + i]; }
+	DEVFN i32 &CH(int x, int i) { return nd[x * BT_NODE_INTS + 2 + BT_MAXK + i]; }
+	DEVFN int alloc(int internal) { int x = n_nodes++; N(x) = 0; INT(x) = internal; return x; }
+	// __kb_getp_aux (kbtree.h:117-131)
+	DEVFN int search(int x, i64 pos, int *r) {
+		int n = N(x), lo = 0, hi = n;
+		if (n == 0) return -1;
+		while (lo < hi) {
+			int mid = (lo + hi) >> 1;
+			if (ch[KEY(x, mid)].pos < pos) lo = mid + 1; else hi = mid;
+		}
+		if (lo == n) { *r = 1; return n - 1; }
+		*r = pos < ch[KEY(x, lo)].pos ? -1 : 0;
+		return *r < 0 ? lo - 1 : lo;
+	}
+	// kb_intervalp, lower side (kbtree.h:152-168)
+	DEVFN int lower(i64 pos) {
+		int x = root, low = -1;
+		for (;;) {
+			int r = 0, i = search(x, pos, &r);
+			if (i >= 0 && r == 0) return KEY(x, i);
+			if (i >= 0) low = KEY(x, i);
+			if (!INT(x)) return low;
+			x = CH(x, i + 1);
+		}
+	}
+	// __kb_split (kbtree.h:173-190)
+	DEVFN void split(int x, int i, int y) {
+		int z = alloc(INT(y));
+		N(z) = BT_T - 1;
+		for (int j = 0; j < BT_T - 1; ++j) KEY(z, j) = KEY(y, j + BT_T);
+		if (INT(y)) for (int j = 0; j < BT_T; ++j) CH(z, j) = CH(y, j + BT_T);
+		N(y) = BT_T - 1;
+		int xn = N(x);
+		for (int j = xn; j > i; --j) CH(x, j + 1) = CH(x, j);
+		CH(x, i + 1) = z;
+		for (int j = xn - 1; j >= i; --j) KEY(x, j + 1) = KEY(x, j);
+		KEY(x, i) = KEY(y, BT_T - 1);
+		N(x) = xn + 1;
+	}
+	// kb_putp / __kb_putp_aux (kbtree.h:191-224)
+	DEVFN void insert(int k) {
+		i64 pos = ch[k].pos; int r;
+		if (N(root) == BT_MAXK) {
+			int s = alloc(1);
+			CH(s, 0) = root;
+			split(s, 0, root);
+			root = s;
+		}
+		int x = root;
+		for (;;) {
+			if (!INT(x)) {
+				int i = search(x, pos, &r), n = N(x);
+				for (int j = n - 1; j > i; --j) KEY(x, j + 1) = KEY(x, j);
+				KEY(x, i + 1) = k; N(x) = n + 1;
+				return;
+			}
+			int i = search(x, pos, &r) + 1;
+			if (N(CH(x, i)) == BT_MAXK) {
+				split(x, i, CH(x, i));
+				if (pos > ch[KEY(x, i)].pos) ++i;
+			}
+			x = CH(x, i);
+		}
+	}
+	// __kb_traverse (kbtree.h:336-358): plain in-order walk with an explicit stack (depth <= log_5 n + 1)
+	DEVFN int inorder(i32 *out) {
+		int sx[24], si[24], sp = 0, n = 0;
+		sx[0] = root; si[0] = 0;
+		while (sp >= 0) {
+			int x = sx[sp];
+			if (!INT(x)) { for (int j = 0; j < N(x); ++j) out[n++] = KEY(x, j); --sp; continue; }
+			int st = si[sp], i = st >> 1;
+			if (!(st & 1)) { si[sp] = st | 1; ++sp; sx[sp] = CH(x, i); si[sp] = 0; continue; } // descend into child i
+			if (i < N(x)) { out[n++] = KEY(x, i); si[sp] = 2 * (i + 1); } else --sp;             // back from child i
+		}
+		return n;
+	}
+};
+
+struct ChainWGreater {   // flt_lt (bwamem.c:350): heavier chains first
+	const ChainRec *ch;
+	DEVFN bool operator()(const i32 &a, const i32 &b) const { return ch[a].w > ch[b].w; }
+};
+
+__device__ void chain_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r)
+{
+	int len = (int)(B.off[r + 1] - B.off[r]);
+	int ns = B.seed_n[r], n_iv = B.intv_n[r];
+	i64 so = B.seed_off[r];
+	B.chain_n[r] = 0; B.reg_off[r] = 0; B.reg_cap_r[r] = 0; B.reg_n_raw[r] = 0; B.reg_n[r] = 0;
+	if (ns == 0) return;
+	const Intv3 *iv = B.intv + B.intv_off[r];
+	// fraction of the read covered by over-abundant seeds (bwamem.c:291-298)
+	int b = 0, e = 0, l_rep = 0;
+	for (int i = 0; i < n_iv; ++i) {
+		int sb = (int)(iv[i].info >> 32), se = (int)(u32)iv[i].info;
+		if (iv[i].x2 <= (u64)opt.max_occ) continue;
+		if (sb > e) { l_rep += e - b; b = sb; e = se; }
+		else e = e > se ? e : se;
+	}
+	l_rep += e - b;
+	float frac_rep = (float)l_rep / len;
+
+	ChainRec *ch = B.slot_chain + so;
+	i32 *next = B.slot_next + so;
+	const u64 *pos = B.slot_pos + so;
+	const i32 *siv = B.slot_iv + so;
+	BTree bt; bt.nd = B.nodes + B.node_off[r] * BT_NODE_INTS; bt.n_nodes = 0; bt.ch = ch;
+	bt.root = bt.alloc(0);
+	int n_ch = 0;
+	for (int s = 0; s < ns; ++s) {
+		Intv3 p = iv[siv[s]];
+		int qbeg = (int)(p.info >> 32), slen = (int)((u32)p.info - (u32)(p.info >> 32));
+		i64 rbeg = (i64)pos[s];
+		int rid = dev_intv2rid(ix, rbeg, rbeg + slen);
+		if (rid < 0) continue;
+		bool add = true;
+		if (n_ch) {
+			int lo = bt.lower(rbeg);
+			if (lo >= 0) {   // test_and_merge (bwamem.c:216-237)
+				ChainRec &c = ch[lo];
+				i64 qend = c.last_qbeg + c.last_len, rend = c.last_rbeg + c.last_len;
+				if (rid == c.rid) {
+					if (qbeg >= c.first_qbeg && qbeg + slen <= qend && rbeg >= c.pos && rbeg + slen <= rend) add = false; // contained
+					else if ((c.last_rbeg < ix.l_pac || c.pos < ix.l_pac) && rbeg >= ix.l_pac) add = true;            // other strand
+					else {
+						i64 x = qbeg - c.last_qbeg, y = rbeg - c.last_rbeg;
+						if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - c.last_len < opt.max_chain_gap && y - c.last_len < opt.max_chain_gap) {
+							next[c.last] = s; next[s] = -1;
+							c.last = s; c.last_qbeg = qbeg; c.last_len = slen; c.last_rbeg = rbeg; ++c.n;
+							add = false;
+						}
+					}
+				}
+			}
+		}
+		if (add) {
+			ChainRec c;
+			c.pos = rbeg; c.last_rbeg = rbeg; c.first = c.last = s; c.first_qbeg = c.last_qbeg = qbeg; c.last_len = slen;
+			c.n = 1; c.rid = rid; c.w = 0; c.kept = 0; c.first_shadow = -1; c.is_alt = ix.ctg_alt[rid] ? 1 : 0;
+			next[s] = -1;
+			ch[n_ch] = c;
+			bt.insert(n_ch);
+			++n_ch;
+		}
+	}
+	if (n_ch == 0) return;
+	i32 *ord = B.slot_ord + so, *kept = B.slot_kept + so;
+	int n = bt.inorder(ord);
+
+	// ---- mem_chain_flt (bwamem.c:353-411) ----
+	int k = 0;
+	for (int i = 0; i < n; ++i) {
+		ChainRec &c = ch[ord[i]];
+		// mem_chain_weight (bwamem.c:239-258)
+		i64 end = 0; int w = 0;
+		for (int s = c.first; s >= 0; s = next[s]) {
+			Intv3 p = iv[siv[s]]; int qb = (int)(p.info >> 32), sl = (int)((u32)p.info - (u32)(p.info >> 32));
+			if (qb >= end) w += sl; else if (qb + sl > end) w += (int)(qb + sl - end);
+			if (qb + sl > end) end = qb + sl;
+		}
+		int wq = w; w = 0; end = 0;
+		for (int s = c.first; s >= 0; s = next[s]) {
+			Intv3 p = iv[siv[s]]; int sl = (int)((u32)p.info - (u32)(p.info >> 32)); i64 rb = (i64)pos[s];
+			if (rb >= end) w += sl; else if (rb + sl > end) w += (int)(rb + sl - end);
+			if (rb + sl > end) end = rb + sl;
+		}
+		if (wq < w) w = wq;
+		if (w >= 1 << 30) w = (1 << 30) - 1;
+		c.w = w; c.first_shadow = -1; c.kept = 0;
+		if (w >= opt.min_chain_weight) ord[k++] = ord[i];
+	}
+	n = k;
+	if (n == 0) return;
+	ChainWGreater cmp; cmp.ch = ch;
+	dev_introsort(ord, n, cmp);
+	int nk = 0;
+	ch[ord[0]].kept = 3; kept[nk++] = 0;
+	for (int i = 1; i < n; ++i) {
+		ChainRec &ci = ch[ord[i]];
+		int bi = ci.first_qbeg, ei = ci.last_qbeg + ci.last_len;
+		bool large_ovlp = false; int kk;
+		for (kk = 0; kk < nk; ++kk) {
+			ChainRec &cj = ch[ord[kept[kk]]];
+			int bj = cj.first_qbeg, ej = cj.last_qbeg + cj.last_len;
+			int b_max = bj > bi ? bj : bi, e_min = ej < ei ? ej : ei;
+			if (e_min > b_max && (!cj.is_alt || ci.is_alt)) {
+				int li = ei - bi, lj = ej - bj, min_l = li < lj ? li : lj;
+				if (e_min - b_max >= min_l * opt.mask_level && min_l < opt.max_chain_gap) {
+					large_ovlp = true;
+					if (cj.first_shadow < 0) cj.first_shadow = i;
+					if (ci.w < cj.w * opt.drop_ratio && cj.w - ci.w >= opt.min_seed_len << 1) break;
+				}
+			}
+		}
+		if (kk == nk) { kept[nk++] = i; ci.kept = large_ovlp ? 2 : 3; }
+	}
+	for (int i = 0; i < nk; ++i) {
+		ChainRec &c = ch[ord[kept[i]]];
+		if (c.first_shadow >= 0) ch[ord[c.first_shadow]].kept = 1;
+	}
+	int i = 0;
+	for (k = 0; i < n; ++i) {
+		int kp = ch[ord[i]].kept;
+		if (kp == 0 || kp == 3) continue;
+		if (++k >= opt.max_chain_extend) break;
+	}
+	for (; i < n; ++i) if (ch[ord[i]].kept < 3) ch[ord[i]].kept = 0;
+	// ---- publish the kept chains: headers + seeds flattened chain by chain ----
+	bwagpu_chain_t *oc = B.slot_cchain + so;
+	bwagpu_seed_t *os = B.slot_cseed + so;
+	int m = 0; k = 0;
+	for (i = 0; i < n; ++i) {
+		ChainRec &c = ch[ord[i]];
+		if (c.kept == 0) continue;
+		bwagpu_chain_t h;
+		h.n_seeds = c.n; h.rid = c.rid; h.w = c.w; h.kept = c.kept; h.is_alt = c.is_alt; h.frac_rep = frac_rep; h.pos = c.pos;
+		oc[k++] = h;
+		for (int s = c.first; s >= 0; s = next[s]) {
+			Intv3 p = iv[siv[s]];
+			bwagpu_seed_t sd;
+			sd.rbeg = (i64)pos[s]; sd.qbeg = (int)(p.info >> 32); sd.len = (int)((u32)p.info - (u32)(p.info >> 32)); sd.score = sd.len; sd.pad_ = 0;
+			os[m++] = sd;
+		}
+	}
+	B.chain_n[r] = k;
+	if (k == 0) return;
+	u64 roff = atomicAdd(&B.ctr->reg_used, (unsigned long long)m);
+	if (roff + m > (u64)B.reg_cap) { atomicOr(&B.ctr->overflow, 8ull); B.chain_n[r] = 0; return; }
+	B.reg_off[r] = (i64)roff; B.reg_cap_r[r] = m;
+}
+
+__global__ void __launch_bounds__(256) k_chain(DevIndex ix, bwagpu_opt_t opt, Batch B)
+{
+	int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+	u64 nch = 0;
+	for (int r = tid; r < B.n_reads; r += nth) { chain_read(ix, opt, B, r); nch += B.chain_n[r]; }
+	if (B.stats) atomicAdd(&B.ctr->n_chains, (unsigned long long)nch);
+}

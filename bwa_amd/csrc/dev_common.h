@@ -1,0 +1,112 @@
+// dev_common.h -- shared device-side types of the MI355X BWA-MEM core (gfx950, wave64).
+//
+// Data layout in HBM:
+//   * FM-index blocks are kept exactly as in the reference's .bwt (bwtindex.c:150-172): one 64-byte block per
+//     128 BWT symbols = 4 x u64 running Occ(A,C,G,T) followed by 8 x u32 of 2-bit symbols.  A block is one
+//     64-byte HBM burst, fetched by a lane as 4 x dwordx4.
+//   * reads: 1 byte per base (nt4 codes 0..4), concatenated, int64 offsets.
+//   * per-read variable-size results live in bump-allocated arenas ("slot space"); a read reserves its slots
+//     with one atomicAdd and never moves.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/bwagpu.h"
+
+typedef uint64_t u64;
+typedef int64_t i64;
+typedef uint32_t u32;
+typedef int32_t i32;
+typedef uint8_t u8;
+
+#define DEVFN __device__ __forceinline__
+
+// The index as the kernels see it.
+struct DevIndex {
+	const uint4 *bwt;      // 64-byte blocks, 4 x uint4 each
+	u64 primary, L2[5], seq_len;
+	const u64 *sa;         // sampled (or densified) suffix array
+	u64 sa_mask;           // sa_intv - 1
+	int sa_shift;          // log2(sa_intv)
+	const u8 *pac;
+	i64 l_pac;
+	int n_seqs;
+	const i64 *ctg_off;
+	const i32 *ctg_len;
+	const i32 *ctg_alt;
+};
+
+// SA interval kept by the seeding stage: {x0, x2, info}; the reverse-strand start x[1] of bwtintv_t (bwt.h:62)
+// is not needed after seeding (mem_chain reads x[0], x[2] and info only, bwamem.c:299-309).
+struct Intv3 { u64 x0, x2, info; };
+
+// Full bi-interval used inside the SMEM search.
+struct BiIntv { u64 x0, x1, x2; u64 info; };
+
+// Chain record while chaining (per read, indexed in slot space).
+struct ChainRec {
+	i64 pos;               // mem_chain_t::pos = rbeg of the first seed
+	i64 last_rbeg;         // rbeg of the last seed
+	i32 first, last;       // first / last seed slot (linked through Batch::slot_next)
+	i32 first_qbeg, last_qbeg, last_len;
+	i32 n;                 // number of seeds
+	i32 rid;
+	i32 w;                 // weight (mem_chain_weight)
+	i32 kept;              // mem_chain_t::kept (0 dropped, 1/2 overlapping, 3 clean)
+	i32 first_shadow;      // mem_chain_t::first: first chain shadowed by this one (-1 none)
+	i32 is_alt;
+};
+
+struct Counters {          // device-side bump allocators + flags
+	unsigned long long intv_used, seed_used, node_used, reg_used;
+	unsigned long long overflow;   // bit0 intv, bit1 seed, bit2 node, bit3 reg, bit4 tmp-intv scratch
+	// algorithmic work counters (bwagpu_stats_t)
+	unsigned long long n_intv, n_chains, n_regs_raw, n_regs;
+	unsigned long long occ_blocks, lf_steps, ext_calls, ext_cells, glb_calls, glb_cells, ref_bases, sw_calls, sw_cells;
+};
+
+// Everything one batch needs on the device.
+struct Batch {
+	int n_reads;
+	int max_len;               // longest read of the batch
+	int stats;                 // collect work counters
+	const u8 *seq;             // concatenated nt4 codes
+	const i64 *off;            // n_reads + 1
+	Counters *ctr;
+	// --- seeding scratch: per resident thread, two interval stacks of (max_len+1) entries each + a MEM list
+	BiIntv *tmp_intv;          // [n_seed_threads][2*(max_len+1)]
+	Intv3 *tmp_mem;            // [n_seed_threads][mem_cap]
+	int mem_cap;
+	// --- seeding results
+	i32 *intv_n;               // per read
+	i64 *intv_off;             // per read, into intv[]
+	Intv3 *intv; i64 intv_cap;
+	// --- slot space (one slot per SA lookup / seed)
+	i32 *seed_n;               // per read
+	i64 *seed_off;             // per read
+	i64 slot_cap;
+	u64 *slot_pos;             // SA row before the lookup kernel, reference position (rbeg) after it
+	i32 *slot_iv;              // index of the seed's interval within the read's interval list
+	i32 *slot_next;            // next seed of the same chain (-1 = end)
+	ChainRec *slot_chain;      // chain pool
+	i32 *slot_ord;             // in-order / sorted chain indices
+	i32 *slot_kept;            // indices of kept chains (mem_chain_flt's `chains` vector)
+	u64 *slot_srt;             // mem_chain2aln's srt[] (score<<32 | seed index)
+	bwagpu_seed_t *slot_cseed; // seeds of the kept chains, flattened chain by chain
+	bwagpu_chain_t *slot_cchain; // kept chains (header), slot_cchain[seed_off[r] + i]
+	i32 *chain_n;              // per read: chains after filtering
+	// --- B-tree nodes
+	i64 *node_off;             // per read
+	i32 *nodes; i64 node_cap;  // 21 ints per node
+	// --- alignment regions
+	i64 *reg_off;              // per read
+	i32 *reg_cap_r;            // per read capacity (= seeds in kept chains)
+	i32 *reg_n_raw;            // per read: regions after mem_chain2aln
+	i32 *reg_n;                // per read: regions after mem_sort_dedup_patch
+	bwagpu_alnreg_t *regs; i64 reg_cap;
+	bwagpu_alnreg_t *regs_raw; // copy of the pre-dedup regions when taps are enabled (else null)
+	// --- DP scratch: per resident wave, interleaved by lane: [(j * 64) + lane]
+	i32 *dp_h, *dp_e;          // (max_len + 2) * 64 ints per wave each
+	int dp_waves;
+	// --- per-length table for mem_flt_chained_seeds: min HSP score, or -1 when the stage is off
+	const i32 *seedsw_minhsp;
+};

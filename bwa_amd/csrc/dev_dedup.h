@@ -1,0 +1,152 @@
+// dev_dedup.h -- mem_sort_dedup_patch (bwamem.c:463-515) with mem_patch_reg (bwamem.c:432-461), whose global
+// alignment is bwa_gen_cigar2 in score-only mode (bwa.c:148-194) -> ksw_global2 without traceback (ksw.c:604-619).
+#pragma once
+#include "dev_ext.h"
+
+#define DEV_NEG_INF (-0x40000000)
+
+// Score of the banded global alignment of query[0..qlen) (q[q0 + j*qdir]) against target ref_base(t0 + i*tdir).
+__device__ int dev_ksw_global2_score(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen,
+									 i64 t0, int tdir, int tlen, int w, i32 *H, i32 *E, u64 &cells)
+{
+	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+	int j;
+	H[0] = 0; E[0] = DEV_NEG_INF;
+	for (j = 1; j <= qlen && j <= w; ++j) { H[j * DPS] = -(o_ins + e_ins * j); E[j * DPS] = DEV_NEG_INF; }
+	for (; j <= qlen; ++j) H[j * DPS] = E[j * DPS] = DEV_NEG_INF;
+	for (int i = 0; i < tlen; ++i) {
+		const int8_t *srow = opt.mat + ref_base(ix, t0 + (i64)i * tdir) * 5;
+		int beg = i > w ? i - w : 0, end = i + w + 1 < qlen ? i + w + 1 : qlen;
+		int f = DEV_NEG_INF, h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : DEV_NEG_INF;
+		cells += (u64)(end > beg ? end - beg : 0);
+		for (j = beg; j < end; ++j) {
+			int m = H[j * DPS] + srow[q[q0 + j * qdir]], e = E[j * DPS], h, t;
+			H[j * DPS] = h1;
+			h = m >= e ? m : e; if (h < f) h = f;
+			h1 = h;
+			t = m - oe_del; e -= e_del; E[j * DPS] = e > t ? e : t;
+			t = m - oe_ins; f -= e_ins; if (t > f) f = t;
+		}
+		H[end * DPS] = h1; E[end * DPS] = DEV_NEG_INF;
+	}
+	return H[qlen * DPS];
+}
+
+// bwa_gen_cigar2 (bwa.c:148-194), score only: both sequences are reversed for reverse-strand hits so that gaps
+// end up left-aligned on the forward strand.
+__device__ int dev_global_score(const DevIndex &ix, const bwagpu_opt_t &opt, int w_, int l_query, const u8 *query, i64 rb, i64 re,
+								i32 *H, i32 *E, u64 &calls, u64 &cells)
+{
+	i64 l_pac = ix.l_pac;
+	if (l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac)) return 0;
+	int rlen = (int)(re - rb), rev = rb >= l_pac;
+	int q0 = rev ? l_query - 1 : 0, qdir = rev ? -1 : 1; i64 t0 = rev ? re - 1 : rb; int tdir = rev ? -1 : 1;
+	if (l_query == rlen && w_ == 0) {
+		int score = 0;
+		for (int i = 0; i < l_query; ++i) score += opt.mat[ref_base(ix, t0 + (i64)i * tdir) * 5 + query[q0 + i * qdir]];
+		return score;
+	}
+	int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+	int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+	int mg = max_ins > max_del ? max_ins : max_del, dl = rlen - l_query;
+	if (dl < 0) dl = -dl;
+	if (mg < 1) mg = 1;
+	int w = (mg + dl + 1) >> 1; if (w > w_) w = w_;
+	if (w < dl + 3) w = dl + 3;
+	++calls;
+	return dev_ksw_global2_score(ix, opt, query, q0, qdir, l_query, t0, tdir, rlen, w, H, E, cells);
+}
+
+// mem_patch_reg (bwamem.c:432-461)
+__device__ int dev_patch_reg(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *query, const bwagpu_alnreg_t &a, const bwagpu_alnreg_t &b,
+							 int *w_out, i32 *H, i32 *E, u64 &calls, u64 &cells)
+{
+	if (a.rb < ix.l_pac && b.rb >= ix.l_pac) return 0;
+	if (a.qb >= b.qb || a.qe >= b.qe || a.re >= b.re) return 0;
+	int w = (int)((a.re - b.rb) - (a.qe - b.qb)); if (w < 0) w = -w;
+	double r = (double)(a.re - b.rb) / (b.re - a.rb) - (double)(a.qe - b.qb) / (b.qe - a.qb); if (r < 0.) r = -r;
+	if (a.re < b.rb || a.qe < b.qb) { if (w > opt.w << 1 || r >= 0.05f) return 0; }
+	else if (w > opt.w << 2 || r >= 0.05f * 2) return 0;
+	w += a.w + b.w;
+	if (w > opt.w << 2) w = opt.w << 2;
+	int score = dev_global_score(ix, opt, w, b.qe - a.qb, query + a.qb, a.rb, b.re, H, E, calls, cells);
+	int q_s = (int)((double)(b.qe - a.qb) / ((b.qe - b.qb) + (a.qe - a.qb)) * (b.score + a.score) + .499);
+	int r_s = (int)((double)(b.re - a.rb) / ((b.re - b.rb) + (a.re - a.rb)) * (b.score + a.score) + .499);
+	if ((double)score / (q_s > r_s ? q_s : r_s) < 0.90f) return 0;
+	*w_out = w;
+	return score;
+}
+
+struct RegEndLess { DEVFN bool operator()(const bwagpu_alnreg_t &a, const bwagpu_alnreg_t &b) const { return a.re < b.re; } };
+struct RegBestLess {
+	DEVFN bool operator()(const bwagpu_alnreg_t &a, const bwagpu_alnreg_t &b) const {
+		return a.score > b.score || (a.score == b.score && (a.rb < b.rb || (a.rb == b.rb && a.qb < b.qb)));
+	}
+};
+
+__device__ void dedup_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, i32 *H, i32 *E, u64 &calls, u64 &cells)
+{
+	int n = B.reg_n_raw[r];
+	bwagpu_alnreg_t *a = B.regs + B.reg_off[r];
+	const u8 *query = B.seq + B.off[r];
+	if (B.regs_raw) for (int i = 0; i < n; ++i) B.regs_raw[B.reg_off[r] + i] = a[i];
+	if (n > 1) {
+		int m;
+		dev_introsort(a, n, RegEndLess());
+		for (int i = 0; i < n; ++i) a[i].n_comp = 1;
+		for (int i = 1; i < n; ++i) {
+			bwagpu_alnreg_t &p = a[i];
+			if (p.rid != a[i - 1].rid || p.rb >= a[i - 1].re + opt.max_chain_gap) continue;
+			for (int j = i - 1; j >= 0 && p.rid == a[j].rid && p.rb < a[j].re + opt.max_chain_gap; --j) {
+				bwagpu_alnreg_t &q = a[j];
+				i64 orr, oq, mr, mq; int score, w;
+				if (q.qe == q.qb) continue;
+				orr = q.re - p.rb;
+				oq = q.qb < p.qb ? q.qe - p.qb : p.qe - q.qb;
+				mr = q.re - q.rb < p.re - p.rb ? q.re - q.rb : p.re - p.rb;
+				mq = q.qe - q.qb < p.qe - p.qb ? q.qe - q.qb : p.qe - p.qb;
+				if (orr > opt.mask_level_redun * mr && oq > opt.mask_level_redun * mq) {
+					if (p.score < q.score) { p.qe = p.qb; break; }
+					else q.qe = q.qb;
+				} else if (q.rb < p.rb && (score = dev_patch_reg(ix, opt, query, q, p, &w, H, E, calls, cells)) > 0) {
+					p.n_comp += q.n_comp + 1;
+					if (q.seedcov > p.seedcov) p.seedcov = q.seedcov;
+					if (q.sub > p.sub) p.sub = q.sub;
+					if (q.csub > p.csub) p.csub = q.csub;
+					p.qb = q.qb; p.rb = q.rb;
+					p.truesc = p.score = score;
+					p.w = w;
+					q.qb = q.qe;
+				}
+			}
+		}
+		m = 0;
+		for (int i = 0; i < n; ++i) if (a[i].qe > a[i].qb) { if (m != i) a[m] = a[i]; ++m; }
+		n = m;
+		dev_introsort(a, n, RegBestLess());
+		for (int i = 1; i < n; ++i)
+			if (a[i].score == a[i - 1].score && a[i].rb == a[i - 1].rb && a[i].qb == a[i - 1].qb) a[i].qe = a[i].qb;
+		m = n > 0 ? 1 : 0;
+		for (int i = 1; i < n; ++i) if (a[i].qe > a[i].qb) { if (m != i) a[m] = a[i]; ++m; }
+		n = m;
+	}
+	for (int i = 0; i < n; ++i)   // bwamem.c:1111-1115
+		if (a[i].rid >= 0 && ix.ctg_alt[a[i].rid]) a[i].is_alt = 1;
+	B.reg_n[r] = n;
+}
+
+__global__ void __launch_bounds__(256) k_dedup(DevIndex ix, bwagpu_opt_t opt, Batch B)
+{
+	int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+	int wave = tid >> 6, lane = tid & 63;
+	i32 *H = B.dp_h + (size_t)wave * (B.max_len + 2) * DPS + lane;
+	i32 *E = B.dp_e + (size_t)wave * (B.max_len + 2) * DPS + lane;
+	u64 calls = 0, cells = 0, nreg = 0;
+	for (int r = tid; r < B.n_reads; r += nth) { dedup_read(ix, opt, B, r, H, E, calls, cells); nreg += B.reg_n[r]; }
+	if (B.stats) {
+		atomicAdd(&B.ctr->glb_calls, (unsigned long long)calls);
+		atomicAdd(&B.ctr->glb_cells, (unsigned long long)cells);
+		atomicAdd(&B.ctr->n_regs, (unsigned long long)nreg);
+	}
+}

@@ -1,0 +1,127 @@
+// dev_fm.h -- FM-index primitives on the device (rank, bidirectional extension, SA lookup).
+#pragma once
+#include "dev_common.h"
+
+struct OccBlock { uint4 c01, c23, w0, w1; };
+
+DEVFN OccBlock load_block(const DevIndex &ix, u64 blk)
+{
+	const uint4 *p = ix.bwt + blk * 4;
+	OccBlock b;
+	b.c01 = p[0]; b.c23 = p[1]; b.w0 = p[2]; b.w1 = p[3];
+	return b;
+}
+
+// symbols 1,2,3 among the top n (<=32) bases of a 32-base pair; base i of a u32 word sits in bits (15-i)*2
+// (bwt.h:74-80), so two consecutive words form a big-endian run of 32 bases.
+DEVFN void count_pair(u32 whi, u32 wlo, int n, u32 &c1, u32 &c2, u32 &c3)
+{
+	if (n <= 0) return;
+	u64 p = (u64)whi << 32 | wlo;
+	u64 mask = 0x5555555555555555ull;
+	if (n < 32) mask &= ~0ull << (64 - 2 * n);
+	u64 lo = p & mask, hi = (p >> 1) & mask;
+	c3 += __popcll(hi & lo);
+	c2 += __popcll(hi & ~lo);
+	c1 += __popcll(lo & ~hi);
+}
+
+// Occ counts of a block up to in-block offset `o` (0..127) inclusive == bwt_occ4 (bwt.c:169-186) for an
+// already primary-adjusted k.
+DEVFN void block_occ4(const OccBlock &b, int o, u64 cnt[4])
+{
+	int n = o + 1;
+	u32 c1 = 0, c2 = 0, c3 = 0;
+	count_pair(b.w0.x, b.w0.y, n, c1, c2, c3);
+	count_pair(b.w0.z, b.w0.w, n - 32, c1, c2, c3);
+	count_pair(b.w1.x, b.w1.y, n - 64, c1, c2, c3);
+	count_pair(b.w1.z, b.w1.w, n - 96, c1, c2, c3);
+	cnt[0] = ((u64)b.c01.y << 32 | b.c01.x) + (u32)(n - c1 - c2 - c3);
+	cnt[1] = ((u64)b.c01.w << 32 | b.c01.z) + c1;
+	cnt[2] = ((u64)b.c23.y << 32 | b.c23.x) + c2;
+	cnt[3] = ((u64)b.c23.w << 32 | b.c23.z) + c3;
+}
+
+// bwt_2occ4 (bwt.c:189-218): ranks at k and l (k <= l as used by bwt_extend).  Returns the number of distinct
+// 64-byte blocks touched (the N_blk unit of SURVEY.md 8d).
+DEVFN int occ4_pair(const DevIndex &ix, u64 k, u64 l, u64 ck[4], u64 cl[4])
+{
+	const u64 NEG1 = ~0ull;
+	int nblk = 0;
+	u64 kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
+	if (k == NEG1) { ck[0] = ck[1] = ck[2] = ck[3] = 0; }
+	if (l == NEG1) { cl[0] = cl[1] = cl[2] = cl[3] = 0; }
+	if (k != NEG1 && l != NEG1 && (kk >> 7) == (ll >> 7)) {
+		OccBlock b = load_block(ix, kk >> 7);
+		block_occ4(b, (int)(kk & 127), ck);
+		block_occ4(b, (int)(ll & 127), cl);
+		return 1;
+	}
+	if (k != NEG1) { OccBlock b = load_block(ix, kk >> 7); block_occ4(b, (int)(kk & 127), ck); ++nblk; }
+	if (l != NEG1) { OccBlock b = load_block(ix, ll >> 7); block_occ4(b, (int)(ll & 127), cl); ++nblk; }
+	return nblk;
+}
+
+// bwt_extend (bwt.c:262-275).  is_back = 1 prepends a base to the match (the FM-index's native direction),
+// is_back = 0 appends the complement on the other strand.  ok[c] for all four c.
+DEVFN int fm_extend(const DevIndex &ix, const BiIntv &ik, BiIntv ok[4], int is_back)
+{
+	u64 tk[4], tl[4];
+	u64 a = is_back ? ik.x0 : ik.x1, other = is_back ? ik.x1 : ik.x0;
+	int nblk = occ4_pair(ix, a - 1, a - 1 + ik.x2, tk, tl);
+	u64 s3 = tl[3] - tk[3], s2 = tl[2] - tk[2], s1 = tl[1] - tk[1], s0 = tl[0] - tk[0];
+	u64 o3 = other + (a <= ix.primary && a + ik.x2 - 1 >= ix.primary);
+	u64 o2 = o3 + s3, o1 = o2 + s2, o0 = o1 + s1;
+	u64 n0 = ix.L2[0] + 1 + tk[0], n1 = ix.L2[1] + 1 + tk[1], n2 = ix.L2[2] + 1 + tk[2], n3 = ix.L2[3] + 1 + tk[3];
+	ok[0].x2 = s0; ok[1].x2 = s1; ok[2].x2 = s2; ok[3].x2 = s3;
+	if (is_back) {
+		ok[0].x0 = n0; ok[1].x0 = n1; ok[2].x0 = n2; ok[3].x0 = n3;
+		ok[0].x1 = o0; ok[1].x1 = o1; ok[2].x1 = o2; ok[3].x1 = o3;
+	} else {
+		ok[0].x1 = n0; ok[1].x1 = n1; ok[2].x1 = n2; ok[3].x1 = n3;
+		ok[0].x0 = o0; ok[1].x0 = o1; ok[2].x0 = o2; ok[3].x0 = o3;
+	}
+	return nblk;
+}
+
+// Single-child variant: only ok[c] is materialised (registers), same arithmetic.
+DEVFN int fm_extend1(const DevIndex &ix, const BiIntv &ik, int c, int is_back, BiIntv &out)
+{
+	u64 tk[4], tl[4];
+	u64 a = is_back ? ik.x0 : ik.x1, other = is_back ? ik.x1 : ik.x0;
+	int nblk = occ4_pair(ix, a - 1, a - 1 + ik.x2, tk, tl);
+	u64 o = other + (a <= ix.primary && a + ik.x2 - 1 >= ix.primary);
+	if (c < 3) o += tl[3] - tk[3];
+	if (c < 2) o += tl[2] - tk[2];
+	if (c < 1) o += tl[1] - tk[1];
+	u64 na = ix.L2[c] + 1 + tk[c];
+	out.x2 = tl[c] - tk[c];
+	if (is_back) { out.x0 = na; out.x1 = o; } else { out.x1 = na; out.x0 = o; }
+	return nblk;
+}
+
+DEVFN void fm_init(const DevIndex &ix, int c, BiIntv &ik)
+{	// bwt_set_intv (bwt.h:82)
+	ik.x0 = ix.L2[c] + 1; ik.x2 = ix.L2[c + 1] - ix.L2[c]; ik.x1 = ix.L2[3 - c] + 1; ik.info = 0;
+}
+
+// bwt_sa (bwt.c:86-96) with bwt_invPsi (bwt.c:53-59): walk LF until a sampled row.  *steps += walk length.
+DEVFN u64 fm_sa(const DevIndex &ix, u64 k, u32 *steps)
+{
+	u64 sa = 0;
+	while (k & ix.sa_mask) {
+		++sa;
+		if (k == ix.primary) { k = 0; continue; }
+		u64 x = k - (k > ix.primary);          // position in the $-less BWT string (note: '>' here)
+		OccBlock b = load_block(ix, x >> 7);   // k and x differ by at most one and never straddle a block edge
+		int o = (int)(x & 127);                // because occ(k) adjusts k the same way when k > primary
+		u32 w = o < 64 ? (o < 32 ? (o < 16 ? b.w0.x : b.w0.y) : (o < 48 ? b.w0.z : b.w0.w))
+					   : (o < 96 ? (o < 80 ? b.w1.x : b.w1.y) : (o < 112 ? b.w1.z : b.w1.w));
+		int c = (w >> ((~o & 15) << 1)) & 3;
+		u64 cnt[4];
+		block_occ4(b, o, cnt);                 // == bwt_occ(k, c): count of c in BWT[0..x]
+		k = ix.L2[c] + cnt[c];
+	}
+	*steps += (u32)sa;
+	return sa + ix.sa[k >> ix.sa_shift];
+}

@@ -1,0 +1,224 @@
+/* include/bwagpu.h -- C-ABI of the MI355X-native BWA-MEM alignment core (libbwagpu.so).
+ *
+ * The library replaces exactly one thing in lh3/bwa: the first parallel loop of mem_process_seqs()
+ *     kt_for(opt->n_threads, worker1, &w, n)                       (reference bwamem.c:1252)
+ * i.e. "for every read i: regs[i] = mem_align1_core(opt, bwt, bns, pac, l_seq, seq, aux)"
+ * (reference bwamem.c:1081-1117, 1203-1215).  Everything it computes on the way -- SMEM seeding over the
+ * FM-index (bwt.c:189-379), suffix-array lookup (bwt.c:53-96), chaining and chain filtering
+ * (bwamem.c:216-411), banded seed extension (ksw.c:416-515 via bwamem.c:658-812) and region
+ * de-duplication/patching (bwamem.c:432-515, ksw.c:540-642) -- runs as HIP kernels on gfx950 with the index
+ * resident in HBM.  Results (mem_alnreg_t records) are bit-identical to the reference's.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch types cross this boundary;
+ *   - every function returns 0 on success or a negative BWAGPU_E* code (the reference itself has no error
+ *     returns on this path: it exit()s via err_fatal, utils.c:90-122; a drop-in wrapper prints
+ *     bwagpu_strerror() and exits to mimic that);
+ *   - a handle is single-caller / non-reentrant, like step 1 of the reference's kt_pipeline
+ *     (kthread.c:93-104 guarantees one batch at a time in mem_process_seqs);
+ *   - there is NO CPU fallback: without a HIP device bwagpu_create() fails with BWAGPU_ENODEV.
+ *
+ * Struct layouts below are byte-for-byte those of the reference (checked by tests against the compiled
+ * reference): bwagpu_opt_t == mem_opt_t (bwamem.h:52-84, 168 B), bwagpu_alnreg_t == mem_alnreg_t
+ * (bwamem.h:86-104, 88 B), bwagpu_alnreg_v == mem_alnreg_v (bwamem.h:106), bwagpu_bseq1_t == bseq1_t
+ * (bwa.h:58-61, 48 B).  A reference-side caller may pass its own structs through a pointer cast.
+ */
+#ifndef BWAGPU_H
+#define BWAGPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BWAGPU_OK        0
+#define BWAGPU_ENODEV   -1  /* no usable HIP device / HIP runtime error at start-up */
+#define BWAGPU_EINVAL   -2  /* bad argument */
+#define BWAGPU_ENOMEM   -3  /* host or device allocation failed */
+#define BWAGPU_EIO      -4  /* index files missing or inconsistent */
+#define BWAGPU_EHIP     -5  /* HIP runtime error during a batch (see bwagpu_last_error) */
+#define BWAGPU_EUNSUP   -6  /* option combination not implemented on the device path yet */
+
+typedef struct bwagpu_s bwagpu_t;
+
+/* == mem_opt_t, reference bwamem.h:52-84 */
+typedef struct {
+	int a, b;
+	int o_del, e_del;
+	int o_ins, e_ins;
+	int pen_unpaired;
+	int pen_clip5, pen_clip3;
+	int w;
+	int zdrop;
+	uint64_t max_mem_intv;
+	int T;
+	int flag;
+	int min_seed_len;
+	int min_chain_weight;
+	int max_chain_extend;
+	float split_factor;
+	int split_width;
+	int max_occ;
+	int max_chain_gap;
+	int n_threads;
+	int chunk_size;
+	float mask_level;
+	float drop_ratio;
+	float XA_drop_ratio;
+	float mask_level_redun;
+	float mapQ_coef_len;
+	int mapQ_coef_fac;
+	int max_ins;
+	int max_matesw;
+	int max_XA_hits, max_XA_hits_alt;
+	int8_t mat[25];
+} bwagpu_opt_t;
+
+/* == mem_alnreg_t, reference bwamem.h:86-104 */
+typedef struct {
+	int64_t rb, re;
+	int qb, qe;
+	int rid;
+	int score;
+	int truesc;
+	int sub;
+	int alt_sc;
+	int csub;
+	int sub_n;
+	int w;
+	int seedcov;
+	int secondary;
+	int secondary_all;
+	int seedlen0;
+	int n_comp:30, is_alt:2;
+	float frac_rep;
+	uint64_t hash;
+} bwagpu_alnreg_t;
+
+/* == mem_alnreg_v, reference bwamem.h:106 */
+typedef struct { size_t n, m; bwagpu_alnreg_t *a; } bwagpu_alnreg_v;
+
+/* == bseq1_t, reference bwa.h:58-61 */
+typedef struct {
+	int l_seq, id;
+	char *name, *comment, *seq, *qual, *sam;
+} bwagpu_bseq1_t;
+
+/* The reference index as plain arrays.  A reference-side caller fills it from bwt_t (bwt.h:48-60), bntseq_t
+ * (bntseq.h:41-64) and the pac pointer of bwaidx_t (bwa.h:48-56); see INTEGRATION.md for the 15-line stub. */
+typedef struct {
+	/* FM-index: interleaved Occ/BWT words exactly as in bwt_t::bwt (bwtindex.c:150-172) */
+	const uint32_t *bwt;     /* bwt_t::bwt      */
+	uint64_t bwt_size;       /* bwt_t::bwt_size (number of uint32 words) */
+	uint64_t primary;        /* bwt_t::primary  */
+	uint64_t L2[5];          /* bwt_t::L2       */
+	uint64_t seq_len;        /* bwt_t::seq_len  */
+	/* sampled suffix array */
+	const uint64_t *sa;      /* bwt_t::sa (sa[0] == (uint64_t)-1) */
+	uint64_t n_sa;           /* bwt_t::n_sa     */
+	int sa_intv;             /* bwt_t::sa_intv (power of two) */
+	/* 2-bit packed forward reference */
+	const uint8_t *pac;      /* bwaidx_t::pac, l_pac/4+1 bytes */
+	int64_t l_pac;           /* bntseq_t::l_pac */
+	/* contig table */
+	int32_t n_seqs;          /* bntseq_t::n_seqs */
+	const int64_t *ctg_offset;  /* anns[i].offset */
+	const int32_t *ctg_len;     /* anns[i].len    */
+	const int32_t *ctg_is_alt;  /* anns[i].is_alt */
+} bwagpu_index_desc_t;
+
+/* Counters of one batch (for the roofline denominator) and per-stage device times. */
+typedef struct {
+	int64_t n_reads, n_bases;
+	int64_t n_intv;          /* SA intervals kept by mem_collect_intv          */
+	int64_t n_seeds;         /* bwt_sa calls (N_sa)                            */
+	int64_t n_chains;        /* chains after mem_chain_flt                     */
+	int64_t n_regs_raw;      /* regions before mem_sort_dedup_patch            */
+	int64_t n_regs;          /* regions returned                               */
+	/* filled only when stats collection is enabled (bwagpu_set_stats): */
+	int64_t n_occ_blocks;    /* N_blk: 64-byte index blocks touched by seeding */
+	int64_t n_lf_steps;      /* N_lf : bwt_invPsi steps inside bwt_sa          */
+	int64_t n_ext_calls;     /* ksw_extend2 calls                              */
+	int64_t n_ext_cells;     /* ksw_extend2 DP cells                           */
+	int64_t n_glb_calls;     /* ksw_global2 (score-only) calls                 */
+	int64_t n_glb_cells;     /* ksw_global2 DP cells                           */
+	int64_t ref_bases;       /* W_ref: reference bases covered by extension windows */
+	int64_t n_sw_calls;      /* mem_seed_sw local alignments (long reads)      */
+	int64_t n_sw_cells;
+	/* device time per stage, milliseconds (HIP events on the library's stream) */
+	float ms_seed, ms_sa, ms_chain, ms_seedsw, ms_extend, ms_dedup, ms_total;
+	int32_t n_retries;       /* arena-growth reruns */
+	int32_t reserved_;
+} bwagpu_stats_t;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------ */
+
+/* Create a handle on HIP device `device` and upload the index once (replaces nothing in the reference; it is
+ * the extra call a drop-in adds after bwa_idx_load, fastmap.c:362-368).  The descriptor's arrays are copied to
+ * HBM; the caller keeps ownership of its host copies. */
+int bwagpu_create(bwagpu_t **h, const bwagpu_index_desc_t *idx, int device);
+
+/* Same, reading <prefix>.bwt/.sa/.pac/.ann/.amb/.alt from disk in the reference's on-disk formats
+ * (replaces bwa_idx_load_from_disk(hint, BWA_IDX_ALL), bwa.c:289-321, for a stand-alone host). */
+int bwagpu_create_from_files(bwagpu_t **h, const char *prefix, int device);
+
+void bwagpu_destroy(bwagpu_t *h);
+const char *bwagpu_strerror(int code);
+const char *bwagpu_last_error(const bwagpu_t *h);
+const char *bwagpu_version(void);
+
+/* Index facts (for callers that loaded from files). */
+int bwagpu_index_info(const bwagpu_t *h, int64_t *l_pac, int32_t *n_seqs, uint64_t *seq_len, int *sa_intv);
+
+/* Optional: replace the sampled SA (interval sa_intv, ~31 dependent index reads per lookup, bwt.c:86-96) by a
+ * denser one built on the device (new_intv in {1,2,4,8,16}; values identical by definition of the SA).  Spends
+ * HBM capacity to delete dependent loads. */
+int bwagpu_densify_sa(bwagpu_t *h, int new_intv);
+
+/* Enable (1) / disable (0) collection of the algorithmic work counters in bwagpu_stats_t. */
+int bwagpu_set_stats(bwagpu_t *h, int enable);
+int bwagpu_get_stats(const bwagpu_t *h, bwagpu_stats_t *out);
+
+/* ---- the hot path -------------------------------------------------------------------------------------- */
+
+/* Drop-in replacement for the worker1 loop (reference bwamem.c:1203-1215, 1252).
+ *   seqs[i].seq holds ASCII bases or 0..4 codes; on return it holds 0..4 codes (the in-place mutation
+ *   contract of mem_align1_core, bwamem.c:1087-1088).  regs[i] receives {n, m, a} with a malloc()ed array
+ *   the caller free()s, exactly as worker2 does (bwamem.c:1227,1231).  With MEM_F_PE set in opt->flag nothing
+ *   changes on this path: both mates are aligned independently (bwamem.c:1209-1213). */
+int bwagpu_align_bseq(bwagpu_t *h, const bwagpu_opt_t *opt, int n, bwagpu_bseq1_t *seqs, bwagpu_alnreg_v *regs);
+
+/* Flat form of the same call: reads are nt4 codes (0..4) concatenated in `seqs`, read i = seqs[off[i]..off[i+1]).
+ *   counts[i] = number of regions of read i; *regs_out = malloc()ed array of all regions in read order
+ *   (caller frees with bwagpu_free); *n_regs_out = total. */
+int bwagpu_align_flat(bwagpu_t *h, const bwagpu_opt_t *opt, int n, const uint8_t *seqs, const int64_t *off,
+					  int32_t *counts, bwagpu_alnreg_t **regs_out, int64_t *n_regs_out);
+void bwagpu_free(void *p);
+
+/* Split form for callers that overlap transfers with compute, and for measuring the device path with the batch
+ * already resident in HBM: upload -> run (device only, asynchronous kernels + one final sync) -> download. */
+int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, const int64_t *off);
+int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt);
+int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg_t **regs_out, int64_t *n_regs_out);
+
+/* ---- stage taps (parity tests; device results of the last batch_run, read order) ------------------------ */
+/* Taps are on by default; switching them off (0) skips the copy of the pre-dedup regions kept for
+ * bwagpu_tap_regs_raw (a benchmark setting). */
+int bwagpu_set_taps(bwagpu_t *h, int enable);
+/* SA intervals after mem_collect_intv (bwamem.c:140-188): per read counts + records {x0, x2, info}. */
+typedef struct { uint64_t x0, x2, info; } bwagpu_intv_t;
+int bwagpu_tap_intervals(bwagpu_t *h, int32_t *counts, bwagpu_intv_t **out, int64_t *n_out);
+/* Chains after mem_chain_flt (+ mem_flt_chained_seeds): per read chain counts, chain headers, flat seeds. */
+typedef struct { int32_t n_seeds, rid, w, kept, is_alt; float frac_rep; int64_t pos; } bwagpu_chain_t;
+typedef struct { int64_t rbeg; int32_t qbeg, len, score, pad_; } bwagpu_seed_t;
+int bwagpu_tap_chains(bwagpu_t *h, int32_t *counts, bwagpu_chain_t **chains, int64_t *n_chains,
+					  bwagpu_seed_t **seeds, int64_t *n_seeds);
+/* Regions after mem_chain2aln, before mem_sort_dedup_patch. */
+int bwagpu_tap_regs_raw(bwagpu_t *h, int32_t *counts, bwagpu_alnreg_t **out, int64_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

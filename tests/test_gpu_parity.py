@@ -1,0 +1,157 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C-ABI of libbwagpu.so, against
+  * the committed reference outputs (tests/golden/, generated from the compiled reference),
+  * the plain-C oracle on larger seeded inputs (and the compiled reference itself where oracle/_ref is present),
+  * size-independent properties at benchmark scale.
+Bit-exact: all quantities on this path are integers (scores, coordinates) plus one float that is a pure function
+of integers (frac_rep); records are compared byte for byte."""
+import os
+import numpy as np
+import pytest
+
+import testdata
+from cmputil import assert_regs_equal, golden_opts, golden_sets
+from bwa_amd import simdata
+from bwa_amd.structs import ALNREG_DTYPE, default_opt, pacbio_opt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small():
+    from bwa_amd.api import BwaGpu
+    import orcapi
+    prefix, g = testdata.small_index()
+    gpu, orc = BwaGpu(prefix), orcapi.OrcIndex(prefix)
+    yield gpu, orc, g
+    gpu.close(); orc.close()
+
+
+@pytest.fixture(scope="module")
+def medium():
+    """2 Mb repeat-rich genome; needs the reference's `bwa index` (oracle/_ref/bwa travels with the snapshot)."""
+    import refapi
+    if not refapi.have_ref():
+        pytest.skip("oracle/_ref not available")
+    from bwa_amd.api import BwaGpu
+    import orcapi
+    fa, g = testdata.medium_index()
+    gpu, orc, ref = BwaGpu(fa), orcapi.OrcIndex(fa), refapi.RefIndex(fa)
+    yield gpu, orc, ref, g
+    gpu.close(); orc.close(); ref.close()
+
+
+def test_native_library_is_loaded(small):
+    gpu = small[0]
+    assert b"gfx950" in gpu.L.bwagpu_version()
+    maps = open("/proc/self/maps").read()
+    assert "libbwagpu.so" in maps and "hostsim" not in maps
+
+
+def test_golden_regs(small):
+    gpu = small[0]
+    opts = golden_opts()
+    for name, oname, reads, counts, regs in golden_sets(os.path.join(testdata.GOLDEN, "golden_regs.npz")):
+        seqs, off = testdata.flat(reads)
+        c, r = gpu.align(opts[oname], seqs, off)
+        assert_regs_equal(counts, regs.astype(ALNREG_DTYPE), c, r, f"golden {name}")
+
+
+def test_golden_stage_taps(small):
+    gpu = small[0]
+    z = np.load(os.path.join(testdata.GOLDEN, "golden_stages.npz"))
+    seqs, off = testdata.flat(z["reads"])
+    gpu.align(golden_opts()["default"], seqs, off)
+    n, iv = gpu.tap_intervals()
+    assert np.array_equal(n, z["intv_n"])
+    for f in ("x0", "x2", "info"):
+        assert np.array_equal(iv[f], z["intv"][f])
+    cn, ch, cs = gpu.tap_chains()
+    assert np.array_equal(cn, z["chain_n"])
+    for f, g in (("n_seeds", "n"), ("rid", "rid"), ("w", "w"), ("kept", "kept"), ("is_alt", "is_alt"), ("frac_rep", "frac_rep"), ("pos", "pos")):
+        assert np.array_equal(ch[f], z["chain_hdr"][g]), f
+    for f in ("rbeg", "qbeg", "len", "score"):
+        assert np.array_equal(cs[f], z["chain_seeds"][f]), f
+    rn, rr = gpu.tap_regs_raw()
+    assert np.array_equal(rn, z["raw_n"]) and rr.tobytes() == z["raw_regs"].astype(ALNREG_DTYPE).tobytes()
+
+
+def test_edge_cases(small):
+    gpu, orc, g = small
+    opt = default_opt()
+    c, r = gpu.align(opt, np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64))
+    assert len(c) == 0 and len(r) == 0
+    rng = np.random.default_rng(5)
+    base = simdata.make_reads_se(g, 300, length=300, seed=21)
+    rag = [r_[: int(rng.integers(1, 300))] for r_ in base] + [np.zeros(0, dtype=np.uint8), np.full(60, 4, dtype=np.uint8), base[0][:18]]
+    rag.append(simdata.make_reads_long(g, 1, length=1200, seed=22, sub=0.01, dele=0.005, ins=0.005)[0])
+    seqs, off = testdata.ragged(rag)
+    assert_regs_equal(*orc.align(opt, seqs, off), *gpu.align(opt, seqs, off), "ragged")
+    rep = simdata.make_reads_se(g, 64, seed=23)
+    seqs, off = testdata.flat(np.concatenate([np.tile(rep[:1], (64, 1)), rep]))
+    o2 = default_opt(); o2.max_occ = 2000
+    assert_regs_equal(*orc.align(o2, seqs, off), *gpu.align(o2, seqs, off), "arena growth")
+
+
+@pytest.mark.parametrize("name,n,kw,oname", [
+    ("se150", 30000, dict(seed=31, n_frac=0.002), "default"),
+    ("se100_noisy", 8000, dict(length=100, seed=32, sub=0.04, dele=0.006, ins=0.006), "default"),
+    ("se250_odd", 6000, dict(length=250, seed=33, sub=0.03, dele=0.005, ins=0.005), "odd"),
+    ("se36", 8000, dict(length=36, seed=34), "default"),
+])
+def test_medium_short_reads_vs_oracle_and_reference(medium, name, n, kw, oname):
+    gpu, orc, ref, g = medium
+    seqs, off = testdata.flat(simdata.make_reads_se(g, n, **kw))
+    opt = golden_opts()[oname]
+    cg, rg = gpu.align(opt, seqs, off)
+    assert_regs_equal(*orc.align(opt, seqs, off), cg, rg, name + " vs oracle")
+    assert_regs_equal(*ref.align(opt, seqs, off), cg, rg, name + " vs compiled reference")
+
+
+def test_medium_paired_and_long_reads(medium):
+    gpu, orc, ref, g = medium
+    r1, r2 = simdata.make_reads_pe(g, 8000, seed=35)
+    inter = np.empty((16000, 150), dtype=np.uint8); inter[0::2] = r1; inter[1::2] = r2   # mates interleaved (bwamem.h:146-150)
+    seqs, off = testdata.flat(inter)
+    opt = default_opt(); opt.flag |= 0x2
+    assert_regs_equal(*ref.align(opt, seqs, off), *gpu.align(opt, seqs, off), "PE mates")
+    seqs, off = testdata.flat(simdata.make_reads_long(g, 48, length=4000, seed=36))
+    assert_regs_equal(*ref.align(pacbio_opt(), seqs, off), *gpu.align(pacbio_opt(), seqs, off), "pacbio 4 kb")
+
+
+def test_dense_sa_gives_identical_results(medium):
+    from bwa_amd.api import BwaGpu
+    gpu, orc, ref, g = medium
+    fa, _ = testdata.medium_index()
+    seqs, off = testdata.flat(simdata.make_reads_se(g, 5000, seed=37))
+    base = gpu.align(default_opt(), seqs, off)
+    g2 = BwaGpu(fa)
+    g2.densify_sa(1)
+    assert_regs_equal(*base, *g2.align(default_opt(), seqs, off), "sa_intv 1")
+    g2.close()
+
+
+def test_properties_at_scale(medium):
+    """200 k reads: results are independent of batch composition (a permuted batch gives the permuted results) and
+    equal the oracle on a sample; every region lies within one contig strand."""
+    gpu, orc, ref, g = medium
+    n = 200000
+    reads = simdata.make_reads_se(g, n, seed=38)
+    seqs, off = testdata.flat(reads)
+    opt = default_opt()
+    c, r = gpu.align(opt, seqs, off)
+    starts = np.concatenate([[0], np.cumsum(c)])
+    perm = np.random.default_rng(39).permutation(n)
+    cp, rp = gpu.align(opt, *testdata.flat(reads[perm]))
+    assert np.array_equal(cp, c[perm])
+    sp = np.concatenate([[0], np.cumsum(cp)])
+    for k in range(0, n, 997):
+        i = perm[k]
+        assert r[starts[i]:starts[i + 1]].tobytes() == rp[sp[k]:sp[k + 1]].tobytes()
+    sub = np.arange(0, n, 41)
+    co, ro = orc.align(opt, *testdata.flat(reads[sub]))
+    assert np.array_equal(co, c[sub])
+    so = np.concatenate([[0], np.cumsum(co)])
+    for k, i in enumerate(sub):
+        assert ro[so[k]:so[k + 1]].tobytes() == r[starts[i]:starts[i + 1]].tobytes()
+    l_pac = ref.l_pac
+    assert ((r["rb"] < r["re"]) & (r["qb"] < r["qe"]) & (r["re"] <= 2 * l_pac) & ~((r["rb"] < l_pac) & (r["re"] > l_pac))).all()
