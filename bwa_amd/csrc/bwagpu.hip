@@ -24,6 +24,7 @@
 #include "dev_seed.h"
 #include "dev_chain.h"
 #include "dev_ext.h"
+#include "dev_extw.h"
 #include "dev_dedup.h"
 #include "dev_seedsw.h"
 
@@ -251,6 +252,7 @@ extern "C" int bwagpu_densify_sa(bwagpu_t *h, int new_intv)
 // ---- batches -------------------------------------------------------------------------------------------------
 static const int BLOCK = 256;
 static const int MAX_RESIDENT_THREADS = 256 * 2048;   // 256 CUs x 32 waves x 64 lanes
+static const int WAVE_EXT_MAX_LEN = 1200;               // 4 waves x (8+5) B/column must fit the 64 KiB dynamic-LDS limit
 
 extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, const int64_t *off)
 {
@@ -366,7 +368,12 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
 		if (any_seedsw) hipLaunchKernelGGL(k_seedsw, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
-		hipLaunchKernelGGL(k_extend, grid, block, 0, h->stream, h->ix, *opt, B);
+		if (h->max_len <= WAVE_EXT_MAX_LEN) {   // wave-per-read extension with the DP columns in LDS
+			int lds_wave = (8 * (h->max_len + 2) + 5 * ((h->max_len + 3) & ~3) + 15) & ~15;
+			i64 nblk = ((i64)n + 3) / 4, cap = 256 * 8;
+			hipLaunchKernelGGL(k_extend_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave);
+		} else                                  // long reads: lane-per-read scalar DP with the columns in HBM scratch
+			hipLaunchKernelGGL(k_extend, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
 		hipLaunchKernelGGL(k_dedup, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[6], h->stream));

@@ -1,0 +1,275 @@
+// dev_extw.h -- wave-cooperative seed extension: one wavefront (64 lanes) per read.
+//
+// ksw_extend2 (ksw.c:416-515) opens gaps from the diagonal term M, not from H, so within one DP row
+//     F(i,j) = max_{k<j} ( max(M(i,k) - oe_ins, 0) - (j-1-k) * e_ins )
+// is a max-plus prefix scan over M(i,.) and the whole row can be computed lane-parallel: lanes own columns,
+// rows stay sequential, and the reference's row-by-row band trimming (beg/end), its tie rules and its z-drop
+// test are reproduced exactly with ballots and wave reductions.  The per-column state {H(i-1,j-1), E(i,j)} and
+// the query profile live in LDS (one private region per wave); columns the band does not touch keep their old
+// contents exactly like the reference's never-cleared eh[] array (the "stale cell" rule).
+// The order-dependent control logic of mem_chain2aln (bwamem.c:658-812) runs wave-uniformly; lane 0 does the
+// global stores.
+#pragma once
+#include "dev_ext.h"
+
+#define W_NEG (-0x3fffffff)
+
+DEVFN void wave_sync()
+{	// intra-wave ordering point for LDS/global data handed from one lane to another
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+DEVFN int wave_max_i32(int v)
+{
+	for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = v > t ? v : t; }
+	return v;
+}
+DEVFN int wave_incl_scan_max(int v, int lane)
+{
+	for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(v, d); if (lane >= d && t > v) v = t; }
+	return v;
+}
+
+struct WaveLds { int2 *eh; int8_t *qp; int qstride; };
+
+__device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, int mat_max, const u8 *q, int q0, int qdir, int qlen,
+								   i64 t0, int tdir, int tlen, int w, int end_bonus, int h0, const WaveLds &L, u64 &cells)
+{
+	const int lane = threadIdx.x & 63;
+	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = opt.zdrop;
+	int2 *eh = L.eh; int8_t *qp = L.qp; const int qs = L.qstride;
+	// query profile (ksw.c:425-428) and first row (ksw.c:430-433: H(-1,-1) = h0, then an insertion ramp)
+	for (int k = 0; k < 5; ++k)
+		for (int j = lane; j < qlen; j += 64) qp[k * qs + j] = opt.mat[k * 5 + q[q0 + j * qdir]];
+	const int v1 = h0 > oe_ins ? h0 - oe_ins : 0;
+	for (int j = lane; j <= qlen; j += 64) {
+		int hv = j == 0 ? h0 : v1 - (j - 1) * e_ins;
+		eh[j] = make_int2(hv > 0 ? hv : 0, 0);
+	}
+	wave_sync();
+	int lim = (int)((double)(qlen * mat_max + end_bonus - o_ins) / e_ins + 1.); if (lim < 1) lim = 1; if (w > lim) w = lim;
+	lim = (int)((double)(qlen * mat_max + end_bonus - o_del) / e_del + 1.); if (lim < 1) lim = 1; if (w > lim) w = lim;
+	int beg = 0, end = qlen, max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, treg = 0;
+	for (int i = 0; i < tlen; ++i) {
+		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
+		const int tb = __shfl(treg, i & 63);
+		const int8_t *qrow = qp + tb * qs;
+		if (beg < i - w) beg = i - w;
+		if (end > i + w + 1) end = i + w + 1;
+		if (end > qlen) end = qlen;
+		int h1_init = 0;
+		if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
+		int m = 0, mj = -1, carry = W_NEG, hprev = h1_init, first_nz = -1, last_nz = -1, bnd = 0;
+		cells += (u64)(end > beg ? end - beg : 0);
+		for (int b = beg; b < end; b += 64) {
+			const int j = b + lane; const bool act = j < end;
+			int2 old = act ? eh[j] : make_int2(0, 0);
+			if (b != beg && lane == 0) old.x = bnd;        // H(i-1, b-1): saved before the previous pass overwrote eh[b].x
+			const int nb = b + 64;
+			const int bnd_next = nb < end ? eh[nb].x : 0;  // save the next pass's boundary cell before lane 63 overwrites it
+			wave_sync();
+			const int M = act ? (old.x ? old.x + qrow[j] : 0) : 0;
+			int g = M - oe_ins; if (g < 0) g = 0;
+			const int a = act ? g + j * e_ins : W_NEG;
+			const int inc = wave_incl_scan_max(a, lane);
+			int exc = __shfl_up(inc, 1); if (lane == 0) exc = W_NEG;
+			if (carry > exc) exc = carry;
+			const int f = j == beg ? 0 : exc - (j - 1) * e_ins;      // F(i,j): best insertion ending left of column j
+			int h = M > old.y ? M : old.y; if (f > h) h = f;         // H(i,j) = max(M, E, F), ksw.c:470-471
+			int t2 = M - oe_del; if (t2 < 0) t2 = 0;
+			int e_new = old.y - e_del; if (t2 > e_new) e_new = t2;   // E(i+1,j), ksw.c:475-479
+			if (act) {
+				eh[j].y = e_new;
+				eh[j + 1].x = h;                                      // becomes H(i,j) = diagonal of column j+1 in row i+1
+				if (j == beg) eh[j].x = h1_init;
+			}
+			int hleft = __shfl_up(h, 1); if (lane == 0) hleft = hprev;   // eh[j].h after this row = H(i,j-1)
+			const u64 nzm = __ballot(act && (hleft != 0 || e_new != 0));
+			if (nzm) { if (first_nz < 0) first_nz = b + __ffsll((unsigned long long)nzm) - 1; last_nz = b + 63 - __clzll((long long)nzm); }
+			const int pm = wave_max_i32(act ? h : -1);
+			if (pm >= m) { const u64 mm = __ballot(act && h == pm); m = pm; mj = b + 63 - __clzll((long long)mm); }   // last column wins ties
+			const int c63 = __shfl(inc, 63); if (c63 > carry) carry = c63;
+			const int nact = end - b < 64 ? end - b : 64;
+			hprev = __shfl(h, nact - 1);
+			bnd = bnd_next;
+			wave_sync();
+		}
+		const int h1 = beg < end ? hprev : h1_init;      // H(i, end-1) as left in h1 by the reference's column loop
+		const int jfin = beg < end ? end : beg;
+		if (lane == 0) { eh[end].x = h1; eh[end].y = 0; }
+		wave_sync();
+		if (jfin == qlen) { if (h1 >= gscore) max_ie = i; if (h1 > gscore) gscore = h1; }
+		if (m == 0) break;
+		if (m > max) {
+			int off = mj - i; if (off < 0) off = -off;
+			max = m; max_i = i; max_j = mj;
+			if (off > max_off) max_off = off;
+		} else if (zdrop > 0) {
+			const int di = i - max_i, dj = mj - max_j;
+			if (di > dj) { if (max - m - (di - dj) * e_del > zdrop) break; }
+			else if (max - m - (dj - di) * e_ins > zdrop) break;
+		}
+		// band for the next row (ksw.c:502-505): skip leading / trailing columns whose {h,e} are both zero
+		const int nbeg = first_nz >= 0 ? first_nz : end;
+		const int jl = h1 != 0 ? end : (last_nz >= 0 ? last_nz : nbeg - 1);
+		beg = nbeg;
+		end = jl + 2 < qlen ? jl + 2 : qlen;
+	}
+	ExtRes r; r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+	return r;
+}
+
+// mem_chain2aln for all chains of one read, executed by one wavefront.
+__device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const WaveLds &L,
+							  u64 &n_calls, u64 &n_cells, u64 &n_refb)
+{
+	const int lane = threadIdx.x & 63;
+	int n_ch = B.chain_n[r];
+	if (n_ch == 0) { if (lane == 0) B.reg_n_raw[r] = 0; return; }
+	const u8 *query = B.seq + B.off[r];
+	int l_query = (int)(B.off[r + 1] - B.off[r]);
+	i64 so = B.seed_off[r], l_pac = ix.l_pac;
+	const bwagpu_chain_t *chains = B.slot_cchain + so;
+	const bwagpu_seed_t *seeds_all = B.slot_cseed + so;
+	u64 *srt_all = B.slot_srt + so;
+	bwagpu_alnreg_t *av = B.regs + B.reg_off[r];
+	int n_av = 0, sbeg = 0, mat_max = opt_mat_max(opt);
+	for (int ci = 0; ci < n_ch; ++ci) {
+		const bwagpu_chain_t c = chains[ci];
+		const bwagpu_seed_t *seeds = seeds_all + sbeg;
+		u64 *srt = srt_all + sbeg;
+		int n = c.n_seeds;
+		sbeg += n;
+		if (n == 0) continue;
+		i64 rmax0 = l_pac << 1, rmax1 = 0;
+		for (int i = 0; i < n; ++i) {
+			bwagpu_seed_t t = seeds[i];
+			i64 b = t.rbeg - (t.qbeg + dev_max_gap(opt, t.qbeg));
+			i64 e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + dev_max_gap(opt, l_query - t.qbeg - t.len));
+			if (b < rmax0) rmax0 = b;
+			if (e > rmax1) rmax1 = e;
+		}
+		if (rmax0 < 0) rmax0 = 0;
+		if (rmax1 > l_pac << 1) rmax1 = l_pac << 1;
+		if (rmax0 < l_pac && l_pac < rmax1) { if (seeds[0].rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac; }
+		{
+			int is_rev; int rid = dev_pos2rid(ix, dev_depos(ix, seeds[0].rbeg, &is_rev));
+			i64 fb = ix.ctg_off[rid], fe = fb + ix.ctg_len[rid];
+			if (is_rev) { i64 t = fb; fb = (l_pac << 1) - fe; fe = (l_pac << 1) - t; }
+			if (rmax0 < fb) rmax0 = fb;
+			if (rmax1 > fe) rmax1 = fe;
+		}
+		n_refb += (u64)(rmax1 - rmax0);
+		if (lane == 0) {
+			for (int i = 0; i < n; ++i) srt[i] = (u64)seeds[i].score << 32 | (u32)i;
+			dev_introsort(srt, n, U64Less());
+		}
+		wave_sync();
+		for (int k = n - 1; k >= 0; --k) {
+			bwagpu_seed_t s = seeds[(u32)srt[k]];
+			int ii;
+			for (ii = 0; ii < n_av; ++ii) {
+				const bwagpu_alnreg_t &p = av[ii];
+				i64 rd; int qd, w, mg;
+				if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) continue;
+				if (s.len - p.seedlen0 > .1 * l_query) continue;
+				qd = s.qbeg - p.qb; rd = s.rbeg - p.rb;
+				mg = dev_max_gap(opt, qd < rd ? qd : (int)rd); w = mg < p.w ? mg : p.w;
+				if (qd - rd < w && rd - qd < w) break;
+				qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+				mg = dev_max_gap(opt, qd < rd ? qd : (int)rd); w = mg < p.w ? mg : p.w;
+				if (qd - rd < w && rd - qd < w) break;
+			}
+			if (ii < n_av) {
+				int i;
+				for (i = k + 1; i < n; ++i) {
+					if (srt[i] == 0) continue;
+					bwagpu_seed_t t = seeds[(u32)srt[i]];
+					if (t.len < s.len * .95) continue;
+					if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) break;
+					if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) break;
+				}
+				if (i == n) {
+					wave_sync();                       // every lane has finished reading srt[k..] before it is modified
+					if (lane == 0) srt[k] = 0;
+					wave_sync();
+					continue;
+				}
+			}
+			bwagpu_alnreg_t a;
+			a.rb = a.re = 0; a.qb = a.qe = 0; a.rid = c.rid; a.score = a.truesc = -1; a.sub = a.alt_sc = a.csub = a.sub_n = 0;
+			a.w = opt.w; a.seedcov = 0; a.secondary = a.secondary_all = 0; a.seedlen0 = 0; a.n_comp = 0; a.is_alt = 0;
+			a.frac_rep = 0.f; a.hash = 0;
+			int aw0 = opt.w, aw1 = opt.w;
+			if (s.qbeg) {
+				ExtRes x; x.qle = x.tle = x.gtle = 0; x.gscore = -1; x.max_off = 0; x.score = -1;
+				int tl = (int)(s.rbeg - rmax0);
+				for (int i = 0; i < 2; ++i) {
+					int prev = a.score;
+					aw0 = opt.w << i;
+					x = wave_ksw_extend2(ix, opt, mat_max, query, s.qbeg - 1, -1, s.qbeg, s.rbeg - 1, -1, tl, aw0, opt.pen_clip5, s.len * opt.a, L, n_cells);
+					++n_calls;
+					a.score = x.score;
+					if (a.score == prev || x.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
+				}
+				if (x.gscore <= 0 || x.gscore <= a.score - opt.pen_clip5) { a.qb = s.qbeg - x.qle; a.rb = s.rbeg - x.tle; a.truesc = a.score; }
+				else { a.qb = 0; a.rb = s.rbeg - x.gtle; a.truesc = x.gscore; }
+			} else { a.score = a.truesc = s.len * opt.a; a.qb = 0; a.rb = s.rbeg; }
+			if (s.qbeg + s.len != l_query) {
+				ExtRes x; x.qle = x.tle = x.gtle = 0; x.gscore = -1; x.max_off = 0; x.score = -1;
+				int sc0 = a.score, qe = s.qbeg + s.len;
+				i64 re = s.rbeg + s.len;
+				for (int i = 0; i < 2; ++i) {
+					int prev = a.score;
+					aw1 = opt.w << i;
+					x = wave_ksw_extend2(ix, opt, mat_max, query, qe, 1, l_query - qe, re, 1, (int)(rmax1 - re), aw1, opt.pen_clip3, sc0, L, n_cells);
+					++n_calls;
+					a.score = x.score;
+					if (a.score == prev || x.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
+				}
+				if (x.gscore <= 0 || x.gscore <= a.score - opt.pen_clip3) { a.qe = qe + x.qle; a.re = re + x.tle; a.truesc += a.score - sc0; }
+				else { a.qe = l_query; a.re = re + x.gtle; a.truesc += x.gscore - sc0; }
+			} else { a.qe = l_query; a.re = s.rbeg + s.len; }
+			int cov = 0;
+			for (int i = 0; i < n; ++i) {
+				bwagpu_seed_t t = seeds[i];
+				if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) cov += t.len;
+			}
+			a.seedcov = cov;
+			a.w = aw0 > aw1 ? aw0 : aw1;
+			a.seedlen0 = s.len;
+			a.frac_rep = c.frac_rep;
+			if (lane == 0) av[n_av] = a;
+			++n_av;
+			wave_sync();
+		}
+	}
+	if (lane == 0) B.reg_n_raw[r] = n_av;
+}
+
+// One wavefront per read, 4 waves per workgroup; dynamic LDS = 4 private regions of
+// 8*(max_len+2) bytes of {H,E} columns + 5*qstride bytes of query profile.
+__global__ void __launch_bounds__(256) k_extend_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int lds_per_wave)
+{
+	HIP_DYNAMIC_SHARED(unsigned char, dyn_lds)
+	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_blk, n_waves = gridDim.x * (blockDim.x >> 6);
+	WaveLds L;
+	unsigned char *base = dyn_lds + (size_t)wave_in_blk * lds_per_wave;
+	L.eh = (int2*)base;
+	L.qstride = (B.max_len + 3) & ~3;
+	L.qp = (int8_t*)(base + (size_t)8 * (B.max_len + 2));
+	u64 calls = 0, cells = 0, refb = 0, nraw = 0;
+	for (int r = wave; r < B.n_reads; r += n_waves) {
+		ext_read_wave(ix, opt, B, r, L, calls, cells, refb);
+		wave_sync();
+		nraw += B.reg_n_raw[r];
+	}
+	if (B.stats && lane == 0) {
+		atomicAdd(&B.ctr->ext_calls, (unsigned long long)calls);
+		atomicAdd(&B.ctr->ext_cells, (unsigned long long)cells);
+		atomicAdd(&B.ctr->ref_bases, (unsigned long long)refb);
+		atomicAdd(&B.ctr->n_regs_raw, (unsigned long long)nraw);
+	}
+}

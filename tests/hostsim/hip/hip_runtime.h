@@ -1,26 +1,35 @@
 // tests/hostsim/hip/hip_runtime.h -- TEST INFRASTRUCTURE ONLY.
 //
 // A minimal *mock* of the HIP runtime so that the unmodified product source bwa_amd/csrc/bwagpu.hip can be
-// compiled with g++ and exercised by the CPU-only test-suite (this container has no GPU).  Kernels are run
-// serially: hipLaunchKernelGGL loops over the grid and block and sets threadIdx/blockIdx for each "lane".
-// That is valid for this code base because its v1 kernels are lane-serial (no __syncthreads, no shuffles).
-// The mock is never part of the product: libbwagpu.so is built by hipcc against the real runtime and has no
-// CPU path.  The library built here is tests/hostsim/libbwagpu_hostsim.so.
+// compiled with g++ and exercised by the CPU-only test-suite (this container has no GPU).
+//
+// Execution model: hipLaunchKernelGGL runs the grid block by block; inside a block every lane is a ucontext
+// fiber.  A fiber runs until it reaches a wave collective (__shfl*, __ballot, wave barrier) where it parks until
+// all live lanes of its 64-lane wave have arrived -- i.e. lanes are *not* in lock-step between collectives, which
+// is stricter than the hardware and catches missing intra-wave synchronisation.  Lane-serial kernels never
+// yield.  Static/dynamic __shared__ memory is one host buffer (blocks run one at a time).
+//
+// The mock is never part of the product: libbwagpu.so is built by hipcc against the real runtime and has no CPU
+// path.  The library built from this header is tests/hostsim/libbwagpu_hostsim.so.
 #pragma once
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <chrono>
+#include <functional>
 
 #define __global__
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#define __shared__ static
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct uint4 { uint32_t x, y, z, w; };
-extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+struct int2 { int x, y; };
+static inline int2 make_int2(int x, int y) { int2 r; r.x = x; r.y = y; return r; }
+extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorMock = 1 };
@@ -48,11 +57,27 @@ static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMem
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
 static inline unsigned long long atomicOr(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p |= v; return o; }
+static inline unsigned int atomicAdd(unsigned int *p, unsigned int v) { unsigned int o = *p; *p += v; return o; }
+static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
 
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) do { \
-		dim3 g_ = (grid), b_ = (block); gridDim = g_; blockDim = b_; \
-		for (unsigned bx_ = 0; bx_ < g_.x; ++bx_) for (unsigned tx_ = 0; tx_ < b_.x; ++tx_) { \
-			blockIdx = dim3(bx_, 0, 0); threadIdx = dim3(tx_, 0, 0); kernel(__VA_ARGS__); } \
-	} while (0)
+// ---- wave collectives (implemented in mock_globals.cpp on top of the fiber scheduler) ----
+void mock_exchange(uint64_t v, uint64_t out[64], uint64_t *active_mask);
+void mock_launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body);
+extern unsigned char *mock_dyn_lds;
+
+static inline int mock_lane() { return (int)(threadIdx.x & 63); }
+static inline int __shfl(int v, int src) { uint64_t o[64], m; mock_exchange((uint32_t)v, o, &m); return (m >> (src & 63) & 1) ? (int)(uint32_t)o[src & 63] : v; }
+static inline int __shfl_up(int v, int d) { uint64_t o[64], m; mock_exchange((uint32_t)v, o, &m); int s = mock_lane() - d; return (s >= 0 && (m >> s & 1)) ? (int)(uint32_t)o[s] : v; }
+static inline int __shfl_down(int v, int d) { uint64_t o[64], m; mock_exchange((uint32_t)v, o, &m); int s = mock_lane() + d; return (s < 64 && (m >> s & 1)) ? (int)(uint32_t)o[s] : v; }
+static inline int __shfl_xor(int v, int x) { uint64_t o[64], m; mock_exchange((uint32_t)v, o, &m); int s = mock_lane() ^ x; return (m >> s & 1) ? (int)(uint32_t)o[s] : v; }
+static inline unsigned long long __ballot(int p) { uint64_t o[64], m; mock_exchange(p ? 1 : 0, o, &m); unsigned long long r = 0; for (int i = 0; i < 64; ++i) if ((m >> i & 1) && o[i]) r |= 1ull << i; return r; }
+static inline void mock_wave_barrier() { uint64_t o[64], m; mock_exchange(0, o, &m); }
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_wave_barrier() mock_wave_barrier()
+#define HIP_DYNAMIC_SHARED(type, var) type *var = (type*)mock_dyn_lds;
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) mock_launch((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); })

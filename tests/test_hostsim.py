@@ -22,30 +22,42 @@ def sim():
     s.close()
 
 
+# The mock runs every lane as a fiber and every wave collective as a rendezvous, so the wave-cooperative extension
+# kernel costs ~0.1 s per read here; the CPU suite therefore checks a prefix of each golden set (the GPU suite
+# checks all of it).
+N_SIM = {"se150": 48, "se150_N": 32, "se100_noisy": 32, "se250_odd": 16, "se40": 48, "se17": 50, "long2k_pacbio": 2, "long1500_default": 2}
+
+
 def test_hostsim_regs_match_golden(sim):
     opts = golden_opts()
     for name, oname, reads, counts, regs in golden_sets(os.path.join(testdata.GOLDEN, "golden_regs.npz")):
-        seqs, off = testdata.flat(reads)
+        k = N_SIM.get(name, 16)
+        seqs, off = testdata.flat(reads[:k])
         c, r = sim.align(opts[oname], seqs, off)
-        assert_regs_equal(counts, regs.astype(ALNREG_DTYPE), c, r, f"golden {name}")
+        assert_regs_equal(counts[:k], regs.astype(ALNREG_DTYPE)[: int(counts[:k].sum())], c, r, f"golden {name}")
 
 
 def test_hostsim_stage_taps_match_golden(sim):
     z = np.load(os.path.join(testdata.GOLDEN, "golden_stages.npz"))
-    seqs, off = testdata.flat(z["reads"])
+    k = 40
+    seqs, off = testdata.flat(z["reads"][:k])
     sim.align(golden_opts()["default"], seqs, off)
     n, iv = sim.tap_intervals()
-    assert np.array_equal(n, z["intv_n"])
+    assert np.array_equal(n, z["intv_n"][:k])
+    ni = int(z["intv_n"][:k].sum())
     for f, g in (("x0", "x0"), ("x2", "x2"), ("info", "info")):
-        assert np.array_equal(iv[f], z["intv"][g])
+        assert np.array_equal(iv[f], z["intv"][g][:ni])
     cn, ch, cs = sim.tap_chains()
-    assert np.array_equal(cn, z["chain_n"])
+    assert np.array_equal(cn, z["chain_n"][:k])
+    nc = int(z["chain_n"][:k].sum())
     for f, g in (("n_seeds", "n"), ("rid", "rid"), ("w", "w"), ("kept", "kept"), ("is_alt", "is_alt"), ("frac_rep", "frac_rep"), ("pos", "pos")):
-        assert np.array_equal(ch[f], z["chain_hdr"][g]), f
+        assert np.array_equal(ch[f], z["chain_hdr"][g][:nc]), f
+    ns = int(z["chain_hdr"]["n"][:nc].sum())
     for f in ("rbeg", "qbeg", "len", "score"):
-        assert np.array_equal(cs[f], z["chain_seeds"][f]), f
+        assert np.array_equal(cs[f], z["chain_seeds"][f][:ns]), f
     rn, rr = sim.tap_regs_raw()
-    assert np.array_equal(rn, z["raw_n"]) and rr.tobytes() == z["raw_regs"].astype(ALNREG_DTYPE).tobytes()
+    nr = int(z["raw_n"][:k].sum())
+    assert np.array_equal(rn, z["raw_n"][:k]) and rr.tobytes() == z["raw_regs"].astype(ALNREG_DTYPE)[:nr].tobytes()
 
 
 def test_hostsim_edge_cases_and_arena_growth(sim):
@@ -57,14 +69,17 @@ def test_hostsim_edge_cases_and_arena_growth(sim):
     assert len(c) == 0 and len(r) == 0
     # ragged: empty read, all-N read, reads shorter than the seed length, one long read
     rng = np.random.default_rng(5)
-    base = simdata.make_reads_se(g, 200, length=300, seed=21)
+    base = simdata.make_reads_se(g, 24, length=300, seed=21)
     rag = [r_[: int(rng.integers(1, 300))] for r_ in base] + [np.zeros(0, dtype=np.uint8), np.full(60, 4, dtype=np.uint8), base[0][:18]]
-    rag.append(simdata.make_reads_long(g, 1, length=1200, seed=22, sub=0.01, dele=0.005, ins=0.005)[0])
     seqs, off = testdata.ragged(rag)
     assert_regs_equal(*orc.align(opt, seqs, off), *sim.align(opt, seqs, off), "ragged")
+    # one read longer than the wave kernel's LDS limit: the batch takes the lane-per-read extension kernel
+    rag.append(simdata.make_reads_long(g, 1, length=1300, seed=22, sub=0.01, dele=0.005, ins=0.005)[0])
+    seqs, off = testdata.ragged(rag)
+    assert_regs_equal(*orc.align(opt, seqs, off), *sim.align(opt, seqs, off), "ragged + long")
     # a batch made of copies of a repeat element: far more seeds per read than the first arena guess -> growth + rerun
-    rep = simdata.make_reads_se(g, 64, seed=23)
-    hot = np.tile(rep[:1], (64, 1))
+    rep = simdata.make_reads_se(g, 8, seed=23)
+    hot = np.tile(rep[:1], (24, 1))
     seqs, off = testdata.flat(np.concatenate([hot, rep]))
     o2 = default_opt(); o2.max_occ = 2000
     assert_regs_equal(*orc.align(o2, seqs, off), *sim.align(o2, seqs, off), "arena growth")
