@@ -252,7 +252,7 @@ extern "C" int bwagpu_densify_sa(bwagpu_t *h, int new_intv)
 // ---- batches -------------------------------------------------------------------------------------------------
 static const int BLOCK = 256;
 static const int MAX_RESIDENT_THREADS = 256 * 2048;   // 256 CUs x 32 waves x 64 lanes
-static const int WAVE_EXT_MAX_LEN = 1200;               // 4 waves x (8+5) B/column must fit the 64 KiB dynamic-LDS limit
+static const int WAVE_EXT_MAX_LEN = 1100;               // 4 waves x (8+5) B/column must fit the 64 KiB dynamic-LDS limit
 
 extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, const int64_t *off)
 {
@@ -368,8 +368,10 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
 		if (any_seedsw) hipLaunchKernelGGL(k_seedsw, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
-		if (h->max_len <= WAVE_EXT_MAX_LEN) {   // wave-per-read extension with the DP columns in LDS
-			int lds_wave = (8 * (h->max_len + 2) + 5 * ((h->max_len + 3) & ~3) + 15) & ~15;
+		// wave-per-read extension with the DP columns in LDS; its row-max scan packs (score << 6 | lane) into 31 bits
+		i64 max_score = (i64)h->max_len * (opt->a > 0 ? opt->a : 1) * 2 + 1024;
+		if (h->max_len <= WAVE_EXT_MAX_LEN && max_score < (1 << 24)) {
+			int lds_wave = (8 * (h->max_len + 2 + 64) + 5 * ((h->max_len + 64 + 3) & ~3) + 15) & ~15;
 			i64 nblk = ((i64)n + 3) / 4, cap = 256 * 8;
 			hipLaunchKernelGGL(k_extend_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave);
 		} else                                  // long reads: lane-per-read scalar DP with the columns in HBM scratch

@@ -19,16 +19,32 @@ DEVFN void wave_sync()
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 }
-DEVFN int wave_max_i32(int v)
+// ---- cross-lane primitives on DPP (no LDS round trip) ----------------------------------------------------------
+// gfx9-family DPP controls: row_shr:n = 0x110+n (within a row of 16 lanes), row_bcast15 = 0x142 (lane 15 of each row
+// to the next row), row_bcast31 = 0x143 (lane 31 to rows 2-3), wave_shr:1 = 0x138 (whole-wave shift by one lane).
+// With bound_ctrl = 0 a lane without a valid source keeps `old`.
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+#define DPP_WAVE_SHR1 0x138
+
+DEVFN int imax(int a, int b) { return a > b ? a : b; }
+// Inclusive prefix maximum over the 64 lanes; lane 63 ends up with the wave maximum.  `old` is INT_MIN, the identity
+// of signed max, which lets the compiler fold each mov_dpp + max pair into a single v_max_i32_dpp.
+#define I32_MIN ((int)0x80000000)
+DEVFN int wave_incl_scan_max(int v)
 {
-	for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = v > t ? v : t; }
+	v = imax(v, __builtin_amdgcn_update_dpp(I32_MIN, v, DPP_ROW_SHR(1), 0xf, 0xf, false));
+	v = imax(v, __builtin_amdgcn_update_dpp(I32_MIN, v, DPP_ROW_SHR(2), 0xf, 0xf, false));
+	v = imax(v, __builtin_amdgcn_update_dpp(I32_MIN, v, DPP_ROW_SHR(4), 0xf, 0xf, false));
+	v = imax(v, __builtin_amdgcn_update_dpp(I32_MIN, v, DPP_ROW_SHR(8), 0xf, 0xf, false));
+	v = imax(v, __builtin_amdgcn_update_dpp(I32_MIN, v, DPP_ROW_BCAST15, 0xa, 0xf, false));
+	v = imax(v, __builtin_amdgcn_update_dpp(I32_MIN, v, DPP_ROW_BCAST31, 0xc, 0xf, false));
 	return v;
 }
-DEVFN int wave_incl_scan_max(int v, int lane)
-{
-	for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(v, d); if (lane >= d && t > v) v = t; }
-	return v;
-}
+// value of the lane below (lane 0 receives `fill`)
+DEVFN int wave_shift_up1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHR1, 0xf, 0xf, false); }
+DEVFN int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }   // pin a wave-uniform value into an SGPR
 
 struct WaveLds { int2 *eh; int8_t *qp; int qstride; };
 
@@ -53,45 +69,45 @@ __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, 
 	int beg = 0, end = qlen, max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, treg = 0;
 	for (int i = 0; i < tlen; ++i) {
 		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
-		const int tb = __shfl(treg, i & 63);
+		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
 		const int8_t *qrow = qp + tb * qs;
 		if (beg < i - w) beg = i - w;
 		if (end > i + w + 1) end = i + w + 1;
 		if (end > qlen) end = qlen;
+		beg = uni(beg); end = uni(end);
 		int h1_init = 0;
 		if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
 		int m = 0, mj = -1, carry = W_NEG, hprev = h1_init, first_nz = -1, last_nz = -1, bnd = 0;
 		cells += (u64)(end > beg ? end - beg : 0);
 		for (int b = beg; b < end; b += 64) {
 			const int j = b + lane; const bool act = j < end;
-			int2 old = act ? eh[j] : make_int2(0, 0);
-			if (b != beg && lane == 0) old.x = bnd;        // H(i-1, b-1): saved before the previous pass overwrote eh[b].x
-			const int nb = b + 64;
-			const int bnd_next = nb < end ? eh[nb].x : 0;  // save the next pass's boundary cell before lane 63 overwrites it
+			// the LDS region is padded by 64 columns, so inactive lanes may read (never write) past `end`
+			int2 old = eh[j];
+			const int sc = qrow[j];
+			const int bnd_next = eh[b + 64].x;             // next pass's diagonal for its lane 0, before lane 63 overwrites it
+			if (b != beg && lane == 0) old.x = bnd;
 			wave_sync();
-			const int M = act ? (old.x ? old.x + qrow[j] : 0) : 0;
-			int g = M - oe_ins; if (g < 0) g = 0;
-			const int a = act ? g + j * e_ins : W_NEG;
-			const int inc = wave_incl_scan_max(a, lane);
-			int exc = __shfl_up(inc, 1); if (lane == 0) exc = W_NEG;
-			if (carry > exc) exc = carry;
-			const int f = j == beg ? 0 : exc - (j - 1) * e_ins;      // F(i,j): best insertion ending left of column j
-			int h = M > old.y ? M : old.y; if (f > h) h = f;         // H(i,j) = max(M, E, F), ksw.c:470-471
-			int t2 = M - oe_del; if (t2 < 0) t2 = 0;
-			int e_new = old.y - e_del; if (t2 > e_new) e_new = t2;   // E(i+1,j), ksw.c:475-479
+			const int M = old.x ? old.x + sc : 0;          // ksw.c:469: a dead diagonal cell stays dead
+			const int a = act ? imax(M - oe_ins, 0) + j * e_ins : W_NEG;
+			const int inc = wave_incl_scan_max(a);
+			const int exc = imax(wave_shift_up1(inc, W_NEG), carry);
+			const int f = j == beg ? 0 : exc - (j - 1) * e_ins;       // F(i,j): best insertion ending left of column j
+			const int h = imax(imax(M, old.y), f);                    // H(i,j) = max(M, E, F), ksw.c:470-471
+			const int e_new = imax(imax(old.y - e_del, M - oe_del), 0); // E(i+1,j), ksw.c:475-479
 			if (act) {
 				eh[j].y = e_new;
-				eh[j + 1].x = h;                                      // becomes H(i,j) = diagonal of column j+1 in row i+1
-				if (j == beg) eh[j].x = h1_init;
+				eh[j + 1].x = h;                                       // becomes the diagonal of column j+1 in row i+1
 			}
-			int hleft = __shfl_up(h, 1); if (lane == 0) hleft = hprev;   // eh[j].h after this row = H(i,j-1)
-			const u64 nzm = __ballot(act && (hleft != 0 || e_new != 0));
+			if (j == beg) eh[j].x = h1_init;
+			const int hleft = wave_shift_up1(h, hprev);               // eh[j].h after this row = H(i,j-1)
+			const u64 nzm = __ballot(act && (hleft | e_new) != 0);
 			if (nzm) { if (first_nz < 0) first_nz = b + __ffsll((unsigned long long)nzm) - 1; last_nz = b + 63 - __clzll((long long)nzm); }
-			const int pm = wave_max_i32(act ? h : -1);
-			if (pm >= m) { const u64 mm = __ballot(act && h == pm); m = pm; mj = b + 63 - __clzll((long long)mm); }   // last column wins ties
-			const int c63 = __shfl(inc, 63); if (c63 > carry) carry = c63;
+			// row maximum with "last column wins ties" (ksw.c:473-474): one scan over (h << 6 | lane)
+			const int key = __builtin_amdgcn_readlane(wave_incl_scan_max(act ? (h << 6 | lane) : -1), 63);
+			if ((key >> 6) >= m) { m = key >> 6; mj = b + (key & 63); }
+			carry = imax(carry, __builtin_amdgcn_readlane(inc, 63));
 			const int nact = end - b < 64 ? end - b : 64;
-			hprev = __shfl(h, nact - 1);
+			hprev = __builtin_amdgcn_readlane(h, nact - 1);
 			bnd = bnd_next;
 			wave_sync();
 		}
@@ -249,7 +265,7 @@ __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const
 }
 
 // One wavefront per read, 4 waves per workgroup; dynamic LDS = 4 private regions of
-// 8*(max_len+2) bytes of {H,E} columns + 5*qstride bytes of query profile.
+// 8*(max_len+2+64) bytes of {H,E} columns + 5*qstride bytes of query profile.
 __global__ void __launch_bounds__(256) k_extend_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int lds_per_wave)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, dyn_lds)
@@ -257,9 +273,9 @@ __global__ void __launch_bounds__(256) k_extend_wave(DevIndex ix, bwagpu_opt_t o
 	const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_blk, n_waves = gridDim.x * (blockDim.x >> 6);
 	WaveLds L;
 	unsigned char *base = dyn_lds + (size_t)wave_in_blk * lds_per_wave;
-	L.eh = (int2*)base;
-	L.qstride = (B.max_len + 3) & ~3;
-	L.qp = (int8_t*)(base + (size_t)8 * (B.max_len + 2));
+	L.eh = (int2*)base;                                      // max_len + 2 columns + 64 of read-only padding
+	L.qstride = (B.max_len + 64 + 3) & ~3;
+	L.qp = (int8_t*)(base + (size_t)8 * (B.max_len + 2 + 64));
 	u64 calls = 0, cells = 0, refb = 0, nraw = 0;
 	for (int r = wave; r < B.n_reads; r += n_waves) {
 		ext_read_wave(ix, opt, B, r, L, calls, cells, refb);

@@ -76,6 +76,24 @@ static inline int __shfl_down(int v, int d) { uint64_t o[64], m; mock_exchange((
 static inline int __shfl_xor(int v, int x) { uint64_t o[64], m; mock_exchange((uint32_t)v, o, &m); int s = mock_lane() ^ x; return (m >> s & 1) ? (int)(uint32_t)o[s] : v; }
 static inline unsigned long long __ballot(int p) { uint64_t o[64], m; mock_exchange(p ? 1 : 0, o, &m); unsigned long long r = 0; for (int i = 0; i < 64; ++i) if ((m >> i & 1) && o[i]) r |= 1ull << i; return r; }
 static inline void mock_wave_barrier() { uint64_t o[64], m; mock_exchange(0, o, &m); }
+// DPP / readlane emulation (gfx9 semantics; bound_ctrl = 0 keeps `old` where the source lane is invalid or masked off)
+static inline int mock_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+{
+	uint64_t o[64], m; mock_exchange((uint32_t)src, o, &m);
+	int l = mock_lane(), row = l >> 4, s = -1;
+	if (!((row_mask >> row) & 1) || !((bank_mask >> ((l & 15) >> 2)) & 1)) return old;
+	if (ctrl >= 0x111 && ctrl <= 0x11f) { int n = ctrl - 0x110; s = (l & 15) >= n ? l - n : -1; }
+	else if (ctrl == 0x138) s = l >= 1 ? l - 1 : -1;
+	else if (ctrl == 0x142) s = row >= 1 ? row * 16 - 1 : -1;
+	else if (ctrl == 0x143) s = row >= 2 ? 31 : -1;
+	else abort();
+	if (s < 0 || !((m >> s) & 1)) return bound_ctrl ? 0 : old;
+	return (int)(uint32_t)o[s];
+}
+static inline int mock_readlane(int v, int src) { uint64_t o[64], m; mock_exchange((uint32_t)v, o, &m); return (int)(uint32_t)o[src & 63]; }
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) mock_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
+#define __builtin_amdgcn_readlane(v, l) mock_readlane((v), (l))
+#define __builtin_amdgcn_readfirstlane(v) (v)   /* used only on wave-uniform values */
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_wave_barrier() mock_wave_barrier()
 #define HIP_DYNAMIC_SHARED(type, var) type *var = (type*)mock_dyn_lds;
