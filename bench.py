@@ -108,7 +108,14 @@ def main():
     from bwa_amd.structs import default_opt
 
     fa, g = build_or_load_index(args.genome_mbp, args.cache, rank, barrier)
-    gpu = BwaGpu(fa, device=local)           # index resident in this GPU's HBM (no CPU fallback: raises without a GPU)
+    if dist is not None:                     # rank 0 loads + uploads, the others receive the index over RCCL/xGMI
+        from bwa_amd import dist as bdist
+        t_b = time.perf_counter()
+        gpu = bdist.broadcast_index(fa, device=local, src=0)
+        if rank == 0:
+            log(f"[bench] index broadcast to {world} GPUs in {time.perf_counter() - t_b:.2f}s")
+    else:
+        gpu = BwaGpu(fa, device=local)       # index resident in this GPU's HBM (no CPU fallback: raises without a GPU)
     if args.dense_sa:
         gpu.densify_sa(args.dense_sa)
     gpu.set_taps(False)

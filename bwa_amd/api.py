@@ -38,8 +38,14 @@ EXPORTS = [
     "bwagpu_create", "bwagpu_create_from_files", "bwagpu_destroy", "bwagpu_strerror", "bwagpu_last_error", "bwagpu_version",
     "bwagpu_index_info", "bwagpu_densify_sa", "bwagpu_set_stats", "bwagpu_get_stats", "bwagpu_align_bseq", "bwagpu_align_flat",
     "bwagpu_free", "bwagpu_batch_upload", "bwagpu_batch_run", "bwagpu_batch_download", "bwagpu_set_taps", "bwagpu_tap_intervals",
-    "bwagpu_tap_chains", "bwagpu_tap_regs_raw",
+    "bwagpu_tap_chains", "bwagpu_tap_regs_raw", "bwagpu_index_buffers", "bwagpu_index_export", 
 ]
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [("bwt", C.c_void_p), ("bwt_size", C.c_uint64), ("primary", C.c_uint64), ("L2", C.c_uint64 * 5), ("seq_len", C.c_uint64),
+                ("sa", C.c_void_p), ("n_sa", C.c_uint64), ("sa_intv", C.c_int), ("pac", C.c_void_p), ("l_pac", C.c_int64),
+                ("n_seqs", C.c_int32), ("ctg_offset", C.c_void_p), ("ctg_len", C.c_void_p), ("ctg_is_alt", C.c_void_p)]
 
 
 class BwaGpuError(RuntimeError):
@@ -70,6 +76,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.bwagpu_tap_chains.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwagpu_tap_regs_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwagpu_free.argtypes = [C.c_void_p]
+    L.bwagpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
+    L.bwagpu_index_buffers.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    L.bwagpu_index_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
 
 
@@ -82,6 +91,41 @@ class BwaGpu:
         rc = self.L.bwagpu_create_from_files(C.byref(self.h), prefix.encode(), device)
         if rc != 0:
             raise BwaGpuError(f"bwagpu_create_from_files({prefix}) failed: {self.L.bwagpu_strerror(rc).decode()}")
+
+    @classmethod
+    def empty(cls, meta: dict, device: int = 0, lib_path: str | None = None):
+        """Receiving side of an index broadcast: allocate the HBM buffers described by `meta` without uploading."""
+        self = cls.__new__(cls)
+        self.L = load_library(lib_path)
+        self.h = C.c_void_p()
+        d = IndexDesc()
+        for k in ("bwt_size", "primary", "seq_len", "n_sa", "sa_intv", "l_pac", "n_seqs"):
+            setattr(d, k, meta[k])
+        for i in range(5):
+            d.L2[i] = meta["L2"][i]
+        off = np.ascontiguousarray(meta["ctg_offset"], dtype=np.int64)
+        ln = np.ascontiguousarray(meta["ctg_len"], dtype=np.int32)
+        alt = np.ascontiguousarray(meta["ctg_is_alt"], dtype=np.int32)
+        d.ctg_offset, d.ctg_len, d.ctg_is_alt = off.ctypes.data, ln.ctypes.data, alt.ctypes.data
+        rc = self.L.bwagpu_create(C.byref(self.h), C.byref(d), device)
+        if rc != 0:
+            raise BwaGpuError(f"bwagpu_create(empty) failed: {self.L.bwagpu_strerror(rc).decode()}")
+        return self
+
+    def index_meta(self) -> dict:
+        d = IndexDesc()
+        self._chk(self.L.bwagpu_index_export(self.h, C.byref(d), None, None, None))
+        off = np.zeros(d.n_seqs, dtype=np.int64); ln = np.zeros(d.n_seqs, dtype=np.int32); alt = np.zeros(d.n_seqs, dtype=np.int32)
+        self._chk(self.L.bwagpu_index_export(self.h, C.byref(d), off.ctypes.data, ln.ctypes.data, alt.ctypes.data))
+        return {"bwt_size": d.bwt_size, "primary": d.primary, "L2": [int(x) for x in d.L2], "seq_len": d.seq_len, "n_sa": d.n_sa,
+                "sa_intv": d.sa_intv, "l_pac": d.l_pac, "n_seqs": d.n_seqs, "ctg_offset": off, "ctg_len": ln, "ctg_is_alt": alt}
+
+    def index_buffers(self):
+        """[(device pointer, bytes)] of the BWT/Occ blocks, the SA and the pac -- the payload of the index broadcast."""
+        p = [C.c_void_p() for _ in range(3)]
+        n = [C.c_uint64() for _ in range(3)]
+        self._chk(self.L.bwagpu_index_buffers(self.h, C.byref(p[0]), C.byref(n[0]), C.byref(p[1]), C.byref(n[1]), C.byref(p[2]), C.byref(n[2])))
+        return [(p[i].value, n[i].value) for i in range(3)]
 
     def _chk(self, rc):
         if rc != 0:

@@ -53,7 +53,8 @@ struct bwagpu_s {
 	DevIndex ix = {};
 	DevBuf d_bwt, d_sa, d_pac, d_ctg_off, d_ctg_len, d_ctg_alt;
 	i64 l_pac = 0; int n_seqs = 0; u64 seq_len = 0; int sa_intv = 0;
-	u64 bwt_blocks = 0;
+	u64 bwt_blocks = 0, bwt_bytes = 0, sa_bytes = 0, pac_bytes = 0, bwt_size = 0, n_sa = 0;
+	std::vector<i64> h_ctg_off; std::vector<i32> h_ctg_len, h_ctg_alt;
 	// batch
 	int n_reads = 0, max_len = 0; i64 n_bases = 0;
 	bool have_batch = false, ran = false;
@@ -95,7 +96,9 @@ static int upload(bwagpu_t *h, DevBuf &b, const void *src, size_t bytes)
 
 extern "C" int bwagpu_create(bwagpu_t **out, const bwagpu_index_desc_t *d, int device)
 {
-	if (!out || !d || !d->bwt || !d->sa || !d->pac || d->n_seqs <= 0) return BWAGPU_EINVAL;
+	if (!out || !d || d->n_seqs <= 0 || !d->ctg_offset || !d->ctg_len || !d->ctg_is_alt) return BWAGPU_EINVAL;
+	const bool alloc_only = !d->bwt && !d->sa && !d->pac;   // receiving side of an index broadcast
+	if (!alloc_only && (!d->bwt || !d->sa || !d->pac)) return BWAGPU_EINVAL;
 	if (d->sa_intv <= 0 || (d->sa_intv & (d->sa_intv - 1))) return BWAGPU_EINVAL;
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BWAGPU_ENODEV;
@@ -109,10 +112,16 @@ extern "C" int bwagpu_create(bwagpu_t **out, const bwagpu_index_desc_t *d, int d
 	u64 nblk = (d->bwt_size + 15) / 16;
 	std::vector<uint32_t> padded;
 	const uint32_t *src = d->bwt;
-	if (d->bwt_size % 16) { padded.assign(nblk * 16, 0); memcpy(padded.data(), d->bwt, d->bwt_size * 4); src = padded.data(); }
-	if ((rc = upload(h, h->d_bwt, src, nblk * 64))) goto fail;
-	if ((rc = upload(h, h->d_sa, d->sa, d->n_sa * 8))) goto fail;
-	if ((rc = upload(h, h->d_pac, d->pac, (size_t)(d->l_pac / 4 + 1)))) goto fail;
+	if (!alloc_only && d->bwt_size % 16) { padded.assign(nblk * 16, 0); memcpy(padded.data(), d->bwt, d->bwt_size * 4); src = padded.data(); }
+	h->bwt_bytes = nblk * 64; h->sa_bytes = d->n_sa * 8; h->pac_bytes = (u64)(d->l_pac / 4 + 1);
+	h->bwt_size = d->bwt_size; h->n_sa = d->n_sa;
+	if (alloc_only) {
+		if (h->d_bwt.ensure(h->bwt_bytes) || h->d_sa.ensure(h->sa_bytes) || h->d_pac.ensure(h->pac_bytes)) { rc = BWAGPU_ENOMEM; goto fail; }
+	} else {
+		if ((rc = upload(h, h->d_bwt, src, nblk * 64))) goto fail;
+		if ((rc = upload(h, h->d_sa, d->sa, d->n_sa * 8))) goto fail;
+		if ((rc = upload(h, h->d_pac, d->pac, (size_t)(d->l_pac / 4 + 1)))) goto fail;
+	}
 	if ((rc = upload(h, h->d_ctg_off, d->ctg_offset, (size_t)d->n_seqs * 8))) goto fail;
 	if ((rc = upload(h, h->d_ctg_len, d->ctg_len, (size_t)d->n_seqs * 4))) goto fail;
 	if ((rc = upload(h, h->d_ctg_alt, d->ctg_is_alt, (size_t)d->n_seqs * 4))) goto fail;
@@ -125,6 +134,9 @@ extern "C" int bwagpu_create(bwagpu_t **out, const bwagpu_index_desc_t *d, int d
 	h->ix.pac = h->d_pac.as<u8>(); h->ix.l_pac = d->l_pac;
 	h->ix.n_seqs = d->n_seqs; h->ix.ctg_off = h->d_ctg_off.as<i64>(); h->ix.ctg_len = h->d_ctg_len.as<i32>(); h->ix.ctg_alt = h->d_ctg_alt.as<i32>();
 	h->l_pac = d->l_pac; h->n_seqs = d->n_seqs; h->seq_len = d->seq_len; h->sa_intv = d->sa_intv;
+	h->h_ctg_off.assign(d->ctg_offset, d->ctg_offset + d->n_seqs);
+	h->h_ctg_len.assign(d->ctg_len, d->ctg_len + d->n_seqs);
+	h->h_ctg_alt.assign(d->ctg_is_alt, d->ctg_is_alt + d->n_seqs);
 	*out = h;
 	return BWAGPU_OK;
 fail:
@@ -209,6 +221,25 @@ extern "C" int bwagpu_create_from_files(bwagpu_t **out, const char *prefix, int 
 	return bwagpu_create(out, &d, device);
 }
 
+extern "C" int bwagpu_index_buffers(bwagpu_t *h, void **bwt, uint64_t *bwt_bytes, void **sa, uint64_t *sa_bytes, void **pac, uint64_t *pac_bytes)
+{
+	if (!h || !bwt || !bwt_bytes || !sa || !sa_bytes || !pac || !pac_bytes) return BWAGPU_EINVAL;
+	*bwt = h->d_bwt.p; *bwt_bytes = h->bwt_bytes; *sa = h->d_sa.p; *sa_bytes = h->sa_bytes; *pac = h->d_pac.p; *pac_bytes = h->pac_bytes;
+	return BWAGPU_OK;
+}
+
+extern "C" int bwagpu_index_export(const bwagpu_t *h, bwagpu_index_desc_t *d, int64_t *ctg_offset, int32_t *ctg_len, int32_t *ctg_is_alt)
+{
+	if (!h || !d) return BWAGPU_EINVAL;
+	memset(d, 0, sizeof *d);
+	d->bwt_size = h->bwt_size; d->primary = h->ix.primary; for (int i = 0; i < 5; ++i) d->L2[i] = h->ix.L2[i];
+	d->seq_len = h->seq_len; d->n_sa = h->n_sa; d->sa_intv = h->sa_intv; d->l_pac = h->l_pac; d->n_seqs = h->n_seqs;
+	if (ctg_offset) memcpy(ctg_offset, h->h_ctg_off.data(), (size_t)h->n_seqs * 8);
+	if (ctg_len) memcpy(ctg_len, h->h_ctg_len.data(), (size_t)h->n_seqs * 4);
+	if (ctg_is_alt) memcpy(ctg_is_alt, h->h_ctg_alt.data(), (size_t)h->n_seqs * 4);
+	return BWAGPU_OK;
+}
+
 extern "C" int bwagpu_index_info(const bwagpu_t *h, int64_t *l_pac, int32_t *n_seqs, uint64_t *seq_len, int *sa_intv)
 {
 	if (!h) return BWAGPU_EINVAL;
@@ -246,6 +277,7 @@ extern "C" int bwagpu_densify_sa(bwagpu_t *h, int new_intv)
 	h->d_sa.release();
 	h->d_sa = nb;
 	h->ix.sa = h->d_sa.as<u64>(); h->ix.sa_mask = (u64)new_intv - 1; h->ix.sa_shift = sh; h->sa_intv = new_intv;
+	h->n_sa = n_out; h->sa_bytes = n_out * 8;
 	return BWAGPU_OK;
 }
 

@@ -160,6 +160,14 @@ typedef struct {
  * HBM; the caller keeps ownership of its host copies. */
 int bwagpu_create(bwagpu_t **h, const bwagpu_index_desc_t *idx, int device);
 
+/* Multi-GPU start-up: the index is uploaded once by one rank and broadcast to the others over
+ * RCCL/xGMI.  A receiving rank calls bwagpu_create() with bwt = sa = pac = NULL (sizes, scalars and the small contig
+ * table filled in): the HBM buffers are allocated but left for the collective to fill.  bwagpu_index_buffers() exposes
+ * the three device buffers (pointer + byte size) on both sides; bwagpu_index_export() returns the scalars and contig
+ * table of a loaded handle so that they can be sent to the other ranks. */
+int bwagpu_index_buffers(bwagpu_t *h, void **bwt, uint64_t *bwt_bytes, void **sa, uint64_t *sa_bytes, void **pac, uint64_t *pac_bytes);
+int bwagpu_index_export(const bwagpu_t *h, bwagpu_index_desc_t *scalars, int64_t *ctg_offset, int32_t *ctg_len, int32_t *ctg_is_alt);
+
 /* Same, reading <prefix>.bwt/.sa/.pac/.ann/.amb/.alt from disk in the reference's on-disk formats
  * (replaces bwa_idx_load_from_disk(hint, BWA_IDX_ALL), bwa.c:289-321, for a stand-alone host). */
 int bwagpu_create_from_files(bwagpu_t **h, const char *prefix, int device);

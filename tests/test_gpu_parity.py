@@ -155,3 +155,35 @@ def test_properties_at_scale(medium):
         assert ro[so[k]:so[k + 1]].tobytes() == r[starts[i]:starts[i + 1]].tobytes()
     l_pac = ref.l_pac
     assert ((r["rb"] < r["re"]) & (r["qb"] < r["qe"]) & (r["re"] <= 2 * l_pac) & ~((r["rb"] < l_pac) & (r["re"] > l_pac))).all()
+
+
+def test_index_broadcast_over_rccl_single_rank(small):
+    """The multi-GPU start-up path on one GPU: a world_size-1 RCCL group, the index buffers wrapped as device tensors
+    (CUDA array interface) and broadcast; the handle must align exactly like one created directly."""
+    import torch
+    import torch.distributed as dist
+    from bwa_amd import dist as bdist
+    gpu, orc, g = small
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29631")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        prefix, _ = testdata.small_index()
+        g2 = bdist.broadcast_index(prefix, device=0, src=0)
+        ptr, nbytes = g2.index_buffers()[0]
+        t = bdist._as_tensor(ptr, nbytes, True)
+        assert t.is_cuda and t.numel() == nbytes
+        ref_bytes = np.fromfile(prefix + ".bwt", dtype=np.uint8)[40:]
+        assert np.array_equal(t[: len(ref_bytes)].cpu().numpy(), ref_bytes)       # the device buffer really is the .bwt payload
+        e = bdist.BwaGpu.empty(g2.index_meta())                                    # receiving side: allocate, then fill by copy
+        for (dp, dn), (sp, sn) in zip(e.index_buffers(), g2.index_buffers()):
+            bdist._as_tensor(dp, dn, True).copy_(bdist._as_tensor(sp, sn, True))
+        torch.cuda.synchronize()
+        seqs, off = testdata.flat(simdata.make_reads_se(g, 3000, seed=81))
+        want = gpu.align(default_opt(), seqs, off)
+        assert_regs_equal(*want, *g2.align(default_opt(), seqs, off), "broadcast handle")
+        assert_regs_equal(*want, *e.align(default_opt(), seqs, off), "received handle")
+        g2.close(); e.close()
+    finally:
+        dist.destroy_process_group()
