@@ -11,6 +11,11 @@ import os
 
 import numpy as np
 
+try:   # torch bundles its own HIP runtime (libamdhip64); loading it first keeps one runtime per process
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 from .structs import ALNREG_DTYPE, MemOpt
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -5,55 +5,34 @@
 #include "dev_sort.h"
 #include "dev_seed.h"
 
-// ---- contig lookup ---------------------------------------------------------------------------------------
-DEVFN int dev_pos2rid(const DevIndex &ix, i64 pos_f)
-{	// bns_pos2rid (bntseq.c:354-368)
-	if (pos_f >= ix.l_pac) return -1;
-	int lo = 0, hi = ix.n_seqs;
-	while (hi - lo > 1) {
-		int mid = (lo + hi) >> 1;
-		if (ix.ctg_off[mid] <= pos_f) lo = mid; else hi = mid;
-	}
-	return lo;
-}
-DEVFN i64 dev_depos(const DevIndex &ix, i64 pos, int *is_rev)
-{	// bns_depos (bntseq.h:87-90)
-	*is_rev = pos >= ix.l_pac;
-	return *is_rev ? (ix.l_pac << 1) - 1 - pos : pos;
-}
-DEVFN int dev_intv2rid(const DevIndex &ix, i64 rb, i64 re)
-{	// bns_intv2rid (bntseq.c:370-379)
-	int r;
-	if (rb < ix.l_pac && re > ix.l_pac) return -2;
-	int a = dev_pos2rid(ix, dev_depos(ix, rb, &r));
-	int b = rb < re ? dev_pos2rid(ix, dev_depos(ix, re - 1, &r)) : a;
-	return a == b ? a : -1;
-}
-
 // ---- B-tree over chain positions (kbtree.h as instantiated at bwamem.c:212-213: t = 5, <= 9 keys/node).
 // Duplicate positions are legal and their in-order place depends on the node layout, so the structure is
-// reproduced literally.  Keys are chain indices; nodes are 24-int records.
+// reproduced literally.  A node is a 160-byte record {n, internal, chain index[9], child[10],
+// position[9]}: the positions are stored in the node so that one descent step costs one memory latency (all nine
+// keys are fetched together and the lower bound is a branch-free count), not a pointer chase per comparison.
 #define BT_T 5
 #define BT_MAXK 9
 struct BTree {
 	i32 *nd;            // node pool of this read
 	int n_nodes, root;
-	const ChainRec *ch; // chain pool (positions)
 	DEVFN i32 &N(int x) { return nd[x * BT_NODE_INTS]; }
 	DEVFN i32 &INT(int x) { return nd[x * BT_NODE_INTS + 1]; }
 	DEVFN i32 &KEY(int x, int i) { return nd[x * BT_NODE_INTS + 2 + i]; }
 	DEVFN i32 &CH(int x, int i) { return nd[x * BT_NODE_INTS + 2 + BT_MAXK + i]; }
+	DEVFN i64 &POS(int x, int i) { return ((i64*)(nd + x * BT_NODE_INTS + 22))[i]; }
 	DEVFN int alloc(int internal) { int x = n_nodes++; N(x) = 0; INT(x) = internal; return x; }
-	// __kb_getp_aux (kbtree.h:117-131)
+	// __kb_getp_aux (kbtree.h:117-131): index of the first key >= pos; *r = 0 if it equals pos, -1 if pos is smaller
+	// (then the index before it is returned), 1 if every key is smaller (n-1 returned); -1 for an empty node.
 	DEVFN int search(int x, i64 pos, int *r) {
-		int n = N(x), lo = 0, hi = n;
+		const i64 *pp = (const i64*)(nd + x * BT_NODE_INTS + 22);
+		int n = N(x);
+		i64 k0 = pp[0], k1 = pp[1], k2 = pp[2], k3 = pp[3], k4 = pp[4], k5 = pp[5], k6 = pp[6], k7 = pp[7], k8 = pp[8];
 		if (n == 0) return -1;
-		while (lo < hi) {
-			int mid = (lo + hi) >> 1;
-			if (ch[KEY(x, mid)].pos < pos) lo = mid + 1; else hi = mid;
-		}
+		int lo = (n > 0 && k0 < pos) + (n > 1 && k1 < pos) + (n > 2 && k2 < pos) + (n > 3 && k3 < pos) + (n > 4 && k4 < pos)
+			   + (n > 5 && k5 < pos) + (n > 6 && k6 < pos) + (n > 7 && k7 < pos) + (n > 8 && k8 < pos);   // keys are sorted: lower bound = #smaller
 		if (lo == n) { *r = 1; return n - 1; }
-		*r = pos < ch[KEY(x, lo)].pos ? -1 : 0;
+		i64 kl = lo == 0 ? k0 : lo == 1 ? k1 : lo == 2 ? k2 : lo == 3 ? k3 : lo == 4 ? k4 : lo == 5 ? k5 : lo == 6 ? k6 : lo == 7 ? k7 : k8;
+		*r = pos < kl ? -1 : 0;
 		return *r < 0 ? lo - 1 : lo;
 	}
 	// kb_intervalp, lower side (kbtree.h:152-168)
@@ -71,19 +50,19 @@ struct BTree {
 	DEVFN void split(int x, int i, int y) {
 		int z = alloc(INT(y));
 		N(z) = BT_T - 1;
-		for (int j = 0; j < BT_T - 1; ++j) KEY(z, j) = KEY(y, j + BT_T);
+		for (int j = 0; j < BT_T - 1; ++j) { KEY(z, j) = KEY(y, j + BT_T); POS(z, j) = POS(y, j + BT_T); }
 		if (INT(y)) for (int j = 0; j < BT_T; ++j) CH(z, j) = CH(y, j + BT_T);
 		N(y) = BT_T - 1;
 		int xn = N(x);
 		for (int j = xn; j > i; --j) CH(x, j + 1) = CH(x, j);
 		CH(x, i + 1) = z;
-		for (int j = xn - 1; j >= i; --j) KEY(x, j + 1) = KEY(x, j);
-		KEY(x, i) = KEY(y, BT_T - 1);
+		for (int j = xn - 1; j >= i; --j) { KEY(x, j + 1) = KEY(x, j); POS(x, j + 1) = POS(x, j); }
+		KEY(x, i) = KEY(y, BT_T - 1); POS(x, i) = POS(y, BT_T - 1);
 		N(x) = xn + 1;
 	}
 	// kb_putp / __kb_putp_aux (kbtree.h:191-224)
-	DEVFN void insert(int k) {
-		i64 pos = ch[k].pos; int r;
+	DEVFN void insert(int k, i64 pos) {
+		int r;
 		if (N(root) == BT_MAXK) {
 			int s = alloc(1);
 			CH(s, 0) = root;
@@ -94,14 +73,14 @@ struct BTree {
 		for (;;) {
 			if (!INT(x)) {
 				int i = search(x, pos, &r), n = N(x);
-				for (int j = n - 1; j > i; --j) KEY(x, j + 1) = KEY(x, j);
-				KEY(x, i + 1) = k; N(x) = n + 1;
+				for (int j = n - 1; j > i; --j) { KEY(x, j + 1) = KEY(x, j); POS(x, j + 1) = POS(x, j); }
+				KEY(x, i + 1) = k; POS(x, i + 1) = pos; N(x) = n + 1;
 				return;
 			}
 			int i = search(x, pos, &r) + 1;
 			if (N(CH(x, i)) == BT_MAXK) {
 				split(x, i, CH(x, i));
-				if (pos > ch[KEY(x, i)].pos) ++i;
+				if (pos > POS(x, i)) ++i;
 			}
 			x = CH(x, i);
 		}
@@ -148,15 +127,16 @@ __device__ void chain_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Ba
 	ChainRec *ch = B.slot_chain + so;
 	i32 *next = B.slot_next + so;
 	const u64 *pos = B.slot_pos + so;
-	const i32 *siv = B.slot_iv + so;
-	BTree bt; bt.nd = B.nodes + B.node_off[r] * BT_NODE_INTS; bt.n_nodes = 0; bt.ch = ch;
+	const i32 *sqb = B.slot_qbeg + so, *sln = B.slot_len + so, *srid = B.slot_rid + so;
+	BTree bt; bt.nd = B.nodes + B.node_off[r] * BT_NODE_INTS; bt.n_nodes = 0;
 	bt.root = bt.alloc(0);
 	int n_ch = 0;
+	// the per-seed inputs do not depend on the tree: fetch them one seed ahead of the (latency-bound) tree walk
+	i64 nx_rbeg = (i64)pos[0]; int nx_qbeg = sqb[0], nx_len = sln[0], nx_rid = srid[0];
 	for (int s = 0; s < ns; ++s) {
-		Intv3 p = iv[siv[s]];
-		int qbeg = (int)(p.info >> 32), slen = (int)((u32)p.info - (u32)(p.info >> 32));
-		i64 rbeg = (i64)pos[s];
-		int rid = dev_intv2rid(ix, rbeg, rbeg + slen);
+		const int qbeg = nx_qbeg, slen = nx_len, rid = nx_rid;
+		const i64 rbeg = nx_rbeg;
+		if (s + 1 < ns) { nx_rbeg = (i64)pos[s + 1]; nx_qbeg = sqb[s + 1]; nx_len = sln[s + 1]; nx_rid = srid[s + 1]; }
 		if (rid < 0) continue;
 		bool add = true;
 		if (n_ch) {
@@ -184,7 +164,7 @@ __device__ void chain_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Ba
 			c.n = 1; c.rid = rid; c.w = 0; c.kept = 0; c.first_shadow = -1; c.is_alt = ix.ctg_alt[rid] ? 1 : 0;
 			next[s] = -1;
 			ch[n_ch] = c;
-			bt.insert(n_ch);
+			bt.insert(n_ch, rbeg);
 			++n_ch;
 		}
 	}
@@ -199,13 +179,13 @@ __device__ void chain_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Ba
 		// mem_chain_weight (bwamem.c:239-258)
 		i64 end = 0; int w = 0;
 		for (int s = c.first; s >= 0; s = next[s]) {
-			Intv3 p = iv[siv[s]]; int qb = (int)(p.info >> 32), sl = (int)((u32)p.info - (u32)(p.info >> 32));
+			int qb = sqb[s], sl = sln[s];
 			if (qb >= end) w += sl; else if (qb + sl > end) w += (int)(qb + sl - end);
 			if (qb + sl > end) end = qb + sl;
 		}
 		int wq = w; w = 0; end = 0;
 		for (int s = c.first; s >= 0; s = next[s]) {
-			Intv3 p = iv[siv[s]]; int sl = (int)((u32)p.info - (u32)(p.info >> 32)); i64 rb = (i64)pos[s];
+			int sl = sln[s]; i64 rb = (i64)pos[s];
 			if (rb >= end) w += sl; else if (rb + sl > end) w += (int)(rb + sl - end);
 			if (rb + sl > end) end = rb + sl;
 		}
@@ -261,9 +241,8 @@ __device__ void chain_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Ba
 		h.n_seeds = c.n; h.rid = c.rid; h.w = c.w; h.kept = c.kept; h.is_alt = c.is_alt; h.frac_rep = frac_rep; h.pos = c.pos;
 		oc[k++] = h;
 		for (int s = c.first; s >= 0; s = next[s]) {
-			Intv3 p = iv[siv[s]];
 			bwagpu_seed_t sd;
-			sd.rbeg = (i64)pos[s]; sd.qbeg = (int)(p.info >> 32); sd.len = (int)((u32)p.info - (u32)(p.info >> 32)); sd.score = sd.len; sd.pad_ = 0;
+			sd.rbeg = (i64)pos[s]; sd.qbeg = sqb[s]; sd.len = sln[s]; sd.score = sd.len; sd.pad_ = 0;
 			os[m++] = sd;
 		}
 	}
@@ -272,6 +251,42 @@ __device__ void chain_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Ba
 	u64 roff = atomicAdd(&B.ctr->reg_used, (unsigned long long)m);
 	if (roff + m > (u64)B.reg_cap) { atomicOr(&B.ctr->overflow, 8ull); B.chain_n[r] = 0; return; }
 	B.reg_off[r] = (i64)roff; B.reg_cap_r[r] = m;
+}
+
+// ---- heavy-first ordering for the wave-per-read extension kernel ------------------------------------------------------
+// Reads are binned by floor(log2(weight)); bins are laid out heaviest first.  Per-block LDS histograms keep the global
+// atomics down to one per bin per block.
+DEVFN int order_bin(int w) { return w <= 0 ? 0 : 32 - __clz(w); }   // 0, then 1 + floor(log2 w)
+
+__global__ void __launch_bounds__(256) k_order_count(Batch B, const i32 *weight)
+{
+	__shared__ u32 hist[ORDER_BINS];
+	if (threadIdx.x < ORDER_BINS) hist[threadIdx.x] = 0;
+	__syncthreads();
+	for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < B.n_reads; r += gridDim.x * blockDim.x)
+		atomicAdd(&hist[order_bin(weight[r])], 1u);
+	__syncthreads();
+	if (threadIdx.x < ORDER_BINS && hist[threadIdx.x]) atomicAdd(&B.bin_cnt[threadIdx.x], hist[threadIdx.x]);
+}
+__global__ void k_order_scan(Batch B)
+{
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		u32 acc = 0;
+		for (int b = ORDER_BINS - 1; b >= 0; --b) { u32 c = B.bin_cnt[b]; B.bin_cnt[ORDER_BINS + b] = acc; acc += c; }   // heaviest bin first
+	}
+}
+// each block handles one contiguous chunk of reads: local histogram -> one global reservation per bin -> scatter
+__global__ void __launch_bounds__(256) k_order_fill(Batch B, const i32 *weight, int chunk)
+{
+	__shared__ u32 hist[ORDER_BINS], base[ORDER_BINS];
+	if (threadIdx.x < ORDER_BINS) hist[threadIdx.x] = 0;
+	__syncthreads();
+	int lo = blockIdx.x * chunk, hi = lo + chunk < B.n_reads ? lo + chunk : B.n_reads;
+	for (int r = lo + threadIdx.x; r < hi; r += blockDim.x) atomicAdd(&hist[order_bin(weight[r])], 1u);
+	__syncthreads();
+	if (threadIdx.x < ORDER_BINS) { base[threadIdx.x] = hist[threadIdx.x] ? atomicAdd(&B.bin_cnt[ORDER_BINS + threadIdx.x], hist[threadIdx.x]) : 0; hist[threadIdx.x] = 0; }
+	__syncthreads();
+	for (int r = lo + threadIdx.x; r < hi; r += blockDim.x) { int b = order_bin(weight[r]); B.order[base[b] + atomicAdd(&hist[b], 1u)] = r; }
 }
 
 __global__ void __launch_bounds__(256) k_chain(DevIndex ix, bwagpu_opt_t opt, Batch B)

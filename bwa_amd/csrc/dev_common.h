@@ -56,6 +56,8 @@ struct ChainRec {
 	i32 is_alt;
 };
 
+#define ORDER_BINS 32
+
 struct Counters {          // device-side bump allocators + flags
 	unsigned long long intv_used, seed_used, node_used, reg_used;
 	unsigned long long overflow;   // bit0 intv, bit1 seed, bit2 node, bit3 reg, bit4 tmp-intv scratch
@@ -85,7 +87,8 @@ struct Batch {
 	i64 *seed_off;             // per read
 	i64 slot_cap;
 	u64 *slot_pos;             // SA row before the lookup kernel, reference position (rbeg) after it
-	i32 *slot_iv;              // index of the seed's interval within the read's interval list
+	i32 *slot_qbeg, *slot_len; // the seed's query start and length (copied from its interval by k_seed)
+	i32 *slot_rid;             // contig id of the seed, -1/-2 if it bridges contigs/strands (filled by k_sa)
 	i32 *slot_next;            // next seed of the same chain (-1 = end)
 	ChainRec *slot_chain;      // chain pool
 	i32 *slot_ord;             // in-order / sorted chain indices
@@ -109,4 +112,8 @@ struct Batch {
 	int dp_waves;
 	// --- per-length table for mem_flt_chained_seeds: min HSP score, or -1 when the stage is off
 	const i32 *seedsw_minhsp;
+	// --- heavy-first processing order of the reads (k_order_*): reads binned by log2(weight), heaviest bin first, so
+	// that the few reads with thousands of seeds start first and lanes of a wave get reads of similar cost
+	i32 *order;                // [n_reads] permutation of read indices
+	u32 *bin_cnt;              // [2 * ORDER_BINS]: counts, then fill cursors / starts
 };

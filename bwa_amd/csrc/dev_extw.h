@@ -277,7 +277,8 @@ __global__ void __launch_bounds__(256) k_extend_wave(DevIndex ix, bwagpu_opt_t o
 	L.qstride = (B.max_len + 64 + 3) & ~3;
 	L.qp = (int8_t*)(base + (size_t)8 * (B.max_len + 2 + 64));
 	u64 calls = 0, cells = 0, refb = 0, nraw = 0;
-	for (int r = wave; r < B.n_reads; r += n_waves) {
+	for (int k = wave; k < B.n_reads; k += n_waves) {
+		const int r = B.order[k];
 		ext_read_wave(ix, opt, B, r, L, calls, cells, refb);
 		wave_sync();
 		nraw += B.reg_n_raw[r];

@@ -125,3 +125,29 @@ DEVFN u64 fm_sa(const DevIndex &ix, u64 k, u32 *steps)
 	*steps += (u32)sa;
 	return sa + ix.sa[k >> ix.sa_shift];
 }
+
+// ---- contig lookup ---------------------------------------------------------------------------------------
+DEVFN int dev_pos2rid(const DevIndex &ix, i64 pos_f)
+{	// bns_pos2rid (bntseq.c:354-368)
+	if (pos_f >= ix.l_pac) return -1;
+	int lo = 0, hi = ix.n_seqs;
+	while (hi - lo > 1) {
+		int mid = (lo + hi) >> 1;
+		if (ix.ctg_off[mid] <= pos_f) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+DEVFN i64 dev_depos(const DevIndex &ix, i64 pos, int *is_rev)
+{	// bns_depos (bntseq.h:87-90)
+	*is_rev = pos >= ix.l_pac;
+	return *is_rev ? (ix.l_pac << 1) - 1 - pos : pos;
+}
+DEVFN int dev_intv2rid(const DevIndex &ix, i64 rb, i64 re)
+{	// bns_intv2rid (bntseq.c:370-379)
+	int r;
+	if (rb < ix.l_pac && re > ix.l_pac) return -2;
+	int a = dev_pos2rid(ix, dev_depos(ix, rb, &r));
+	int b = rb < re ? dev_pos2rid(ix, dev_depos(ix, re - 1, &r)) : a;
+	return a == b ? a : -1;
+}
+

@@ -87,7 +87,7 @@ __device__ int dev_seed_strategy1(const DevIndex &ix, const u8 *q, int len, int 
 
 struct IntvInfoLess { DEVFN bool operator()(const Intv3 &a, const Intv3 &b) const { return a.info < b.info; } };
 
-#define BT_NODE_INTS 24   // n, internal, 9 keys, 10 children (+2 pad)
+#define BT_NODE_INTS 40   // n, internal, 9 chain indices, 10 children, (pad), 9 x i64 positions = 160 bytes
 
 // The seeding pass for one read + reservation of everything later stages need for it.
 __device__ void seed_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, int tslot, u32 &nblk)
@@ -153,13 +153,14 @@ __device__ void seed_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Bat
 		int count = 0;
 		for (i64 k = 0; (u64)k < p.x2 && count < opt.max_occ; k += step, ++count, ++s) {
 			B.slot_pos[soff + s] = p.x0 + (u64)k;
-			B.slot_iv[soff + s] = i;
+			B.slot_qbeg[soff + s] = (i32)(p.info >> 32);
+			B.slot_len[soff + s] = (i32)((u32)p.info - (u32)(p.info >> 32));
 		}
 	}
 	B.seed_n[r] = (i32)ns; B.seed_off[r] = (i64)soff; B.node_off[r] = (i64)noff;
 }
 
-__global__ void __launch_bounds__(256) k_seed(DevIndex ix, bwagpu_opt_t opt, Batch B)
+__global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
 	int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
 	u32 nblk = 0; u64 nintv = 0;
@@ -180,7 +181,10 @@ __global__ void __launch_bounds__(256) k_sa(DevIndex ix, Batch B)
 	u64 n = B.ctr->seed_used;
 	if (n > (u64)B.slot_cap) n = (u64)B.slot_cap;
 	u32 steps = 0;
-	for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (u64)gridDim.x * blockDim.x)
-		B.slot_pos[s] = fm_sa(ix, B.slot_pos[s], &steps);
+	for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (u64)gridDim.x * blockDim.x) {
+		u64 rbeg = fm_sa(ix, B.slot_pos[s], &steps);
+		B.slot_pos[s] = rbeg;
+		B.slot_rid[s] = dev_intv2rid(ix, (i64)rbeg, (i64)rbeg + B.slot_len[s]);   // bns_intv2rid of mem_chain (bwamem.c:312)
+	}
 	if (B.stats) atomicAdd(&B.ctr->lf_steps, (unsigned long long)steps);
 }

@@ -57,6 +57,7 @@ static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMem
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
 static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
@@ -75,6 +76,8 @@ static inline int __shfl_up(int v, int d) { uint64_t o[64], m; mock_exchange((ui
 static inline int __shfl_down(int v, int d) { uint64_t o[64], m; mock_exchange((uint32_t)v, o, &m); int s = mock_lane() + d; return (s < 64 && (m >> s & 1)) ? (int)(uint32_t)o[s] : v; }
 static inline int __shfl_xor(int v, int x) { uint64_t o[64], m; mock_exchange((uint32_t)v, o, &m); int s = mock_lane() ^ x; return (m >> s & 1) ? (int)(uint32_t)o[s] : v; }
 static inline unsigned long long __ballot(int p) { uint64_t o[64], m; mock_exchange(p ? 1 : 0, o, &m); unsigned long long r = 0; for (int i = 0; i < 64; ++i) if ((m >> i & 1) && o[i]) r |= 1ull << i; return r; }
+void mock_block_barrier();
+#define __syncthreads() mock_block_barrier()
 static inline void mock_wave_barrier() { uint64_t o[64], m; mock_exchange(0, o, &m); }
 // DPP / readlane emulation (gfx9 semantics; bound_ctrl = 0 keeps `old` where the source lane is invalid or masked off)
 static inline int mock_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)

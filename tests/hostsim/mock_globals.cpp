@@ -8,6 +8,7 @@ dim3 threadIdx, blockIdx, blockDim, gridDim;
 static unsigned char g_lds[160 * 1024] __attribute__((aligned(64)));
 unsigned char *mock_dyn_lds = g_lds;
 
+static unsigned blk_gen = 0, blk_arrived = 0, blk_live = 0;
 namespace {
 const size_t STACK = 512 * 1024;
 struct Wave { uint64_t buf[2][64]; uint64_t mask[2]; uint64_t live_mask = 0; int live = 0, arrived = 0; unsigned gen = 0; };
@@ -31,6 +32,8 @@ void fiber_main()
 	Wave &w = waves[cur >> 6];
 	--w.live; w.live_mask &= ~(1ull << (cur & 63));
 	release_if_complete(w);
+	--blk_live;
+	if (blk_live > 0 && blk_arrived == blk_live) { blk_arrived = 0; ++blk_gen; }
 	swapcontext(&f.ctx, &sched_ctx);
 }
 }
@@ -48,6 +51,13 @@ void mock_exchange(uint64_t v, uint64_t out[64], uint64_t *active_mask)
 	}
 	memcpy(out, w.buf[g & 1], sizeof(uint64_t) * 64);
 	*active_mask = w.mask[g & 1];
+}
+
+void mock_block_barrier()
+{
+	unsigned g = blk_gen;
+	if (++blk_arrived == blk_live) { blk_arrived = 0; ++blk_gen; }
+	while (blk_gen == g) { int me = cur; swapcontext(&fibers[me].ctx, &sched_ctx); }
 }
 
 void mock_launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body)
@@ -69,6 +79,7 @@ void mock_launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()
 			Wave &w = waves[t >> 6];
 			++w.live; w.live_mask |= 1ull << (t & 63);
 		}
+		blk_live = nt; blk_arrived = 0;
 		unsigned remaining = nt;
 		while (remaining) {
 			unsigned progressed = 0;
