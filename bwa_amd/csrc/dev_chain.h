@@ -199,25 +199,31 @@ __device__ void chain_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Ba
 	ChainWGreater cmp; cmp.ch = ch;
 	dev_introsort(ord, n, cmp);
 	int nk = 0;
-	ch[ord[0]].kept = 3; kept[nk++] = 0;
+	int4 *kinfo = B.slot_kinfo + so;
+	{
+		ChainRec &c0 = ch[ord[0]];
+		c0.kept = 3; kept[0] = 0; kinfo[0] = make_int4(c0.first_qbeg, c0.last_qbeg + c0.last_len, c0.w, c0.is_alt); nk = 1;
+	}
 	for (int i = 1; i < n; ++i) {
 		ChainRec &ci = ch[ord[i]];
-		int bi = ci.first_qbeg, ei = ci.last_qbeg + ci.last_len;
+		const int bi = ci.first_qbeg, ei = ci.last_qbeg + ci.last_len, wi = ci.w, alti = ci.is_alt;
 		bool large_ovlp = false; int kk;
+		// the pairwise test against every kept chain is quadratic for reads in repeats (hundreds of chains of similar
+		// weight are all kept): stream the packed {beg,end,w,flags} records instead of chasing chain records
 		for (kk = 0; kk < nk; ++kk) {
-			ChainRec &cj = ch[ord[kept[kk]]];
-			int bj = cj.first_qbeg, ej = cj.last_qbeg + cj.last_len;
-			int b_max = bj > bi ? bj : bi, e_min = ej < ei ? ej : ei;
-			if (e_min > b_max && (!cj.is_alt || ci.is_alt)) {
-				int li = ei - bi, lj = ej - bj, min_l = li < lj ? li : lj;
+			const int4 kj = kinfo[kk];
+			const int bj = kj.x, ej = kj.y;
+			const int b_max = bj > bi ? bj : bi, e_min = ej < ei ? ej : ei;
+			if (e_min > b_max && (!(kj.w & 1) || alti)) {
+				const int li = ei - bi, lj = ej - bj, min_l = li < lj ? li : lj;
 				if (e_min - b_max >= min_l * opt.mask_level && min_l < opt.max_chain_gap) {
 					large_ovlp = true;
-					if (cj.first_shadow < 0) cj.first_shadow = i;
-					if (ci.w < cj.w * opt.drop_ratio && cj.w - ci.w >= opt.min_seed_len << 1) break;
+					if (!(kj.w & 2)) { ch[ord[kept[kk]]].first_shadow = i; kinfo[kk].w = kj.w | 2; }
+					if (wi < kj.z * opt.drop_ratio && kj.z - wi >= opt.min_seed_len << 1) break;
 				}
 			}
 		}
-		if (kk == nk) { kept[nk++] = i; ci.kept = large_ovlp ? 2 : 3; }
+		if (kk == nk) { kept[nk] = i; kinfo[nk] = make_int4(bi, ei, wi, alti); ++nk; ci.kept = large_ovlp ? 2 : 3; }
 	}
 	for (int i = 0; i < nk; ++i) {
 		ChainRec &c = ch[ord[kept[i]]];

@@ -93,6 +93,7 @@ struct Batch {
 	ChainRec *slot_chain;      // chain pool
 	i32 *slot_ord;             // in-order / sorted chain indices
 	i32 *slot_kept;            // indices of kept chains (mem_chain_flt's `chains` vector)
+	int4 *slot_kinfo;          // {query begin, query end, weight, is_alt | has_first<<1} of each kept chain, packed for streaming
 	u64 *slot_srt;             // mem_chain2aln's srt[] (score<<32 | seed index)
 	bwagpu_seed_t *slot_cseed; // seeds of the kept chains, flattened chain by chain
 	bwagpu_chain_t *slot_cchain; // kept chains (header), slot_cchain[seed_off[r] + i]

@@ -28,6 +28,8 @@
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct uint4 { uint32_t x, y, z, w; };
 struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+static inline int4 make_int4(int x, int y, int z, int w) { int4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 static inline int2 make_int2(int x, int y) { int2 r; r.x = x; r.y = y; return r; }
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 
