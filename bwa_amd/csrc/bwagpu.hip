@@ -405,6 +405,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
 		HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
 		hipLaunchKernelGGL(k_seed, grid, block, 0, h->stream, h->ix, *opt, B);
+		hipLaunchKernelGGL(k_expand, grid, block, 0, h->stream, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
 		i64 sa_blocks = (h->slot_cap + BLOCK - 1) / BLOCK;
 		if (sa_blocks > MAX_RESIDENT_THREADS / BLOCK) sa_blocks = MAX_RESIDENT_THREADS / BLOCK;

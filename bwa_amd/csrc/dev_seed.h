@@ -89,88 +89,212 @@ struct IntvInfoLess { DEVFN bool operator()(const Intv3 &a, const Intv3 &b) cons
 
 #define BT_NODE_INTS 40   // n, internal, 9 chain indices, 10 children, (pad), 9 x i64 positions = 160 bytes
 
-// The seeding pass for one read + reservation of everything later stages need for it.
-__device__ void seed_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, int tslot, u32 &nblk)
+// ---- seeding as a per-lane state machine ---------------------------------------------------------------------------
+// mem_collect_intv (bwamem.c:140-188) is three passes of nested, data-dependent loops around one expensive primitive,
+// the FM extension (two 64-byte block reads + ~300 integer ops).  Written as nested loops, the lanes of a wave spread
+// over five different extension sites and loop depths and the wave executes them one after the other (measured: ~12 %
+// lane utilisation).  Here every lane runs the same loop: a cheap switch advances its private state
+// (pass / forward sweep / backward row / re-seeding / LAST-like pass) up to the point where it needs an extension, all
+// lanes then perform their extension together, and a second switch consumes the result.  Lanes pull reads from a
+// global counter, so a lane that finishes a read early starts the next one instead of idling.
+enum { SS_FETCH = 0, SS_PASS1, SS_PASS2, SS_PASS3, SS_FWD, SS_BWD, SS_STRAT, SS_FINAL, SS_DONE };
+
+struct SeedLane {
+	int st, r, len, x, k2, old_n, pass;
+	const u8 *q;
+	// current SMEM search (bwt_smem1a, bwt.c:289-351)
+	u64 min_intv, last_x2;
+	int sx, i, n0, nprev, nc, j, c, ret, last_start;
+	bool any;
+	BiIntv ik, p;
+	BiIntv *s0, *s1, *prev, *curr;
+	SeedEmit em;
+};
+
+DEVFN void smem_finish(SeedLane &L) { if (L.pass == 1) { L.x = L.ret; L.st = SS_PASS1; } else L.st = SS_PASS2; }
+
+// start backward row i (bwt.c:326-345); rows without a usable base (i < 0 or N) need no extension at all
+DEVFN void bwd_begin_row(SeedLane &L)
 {
-	const u8 *q = B.seq + B.off[r];
-	int len = (int)(B.off[r + 1] - B.off[r]);
-	B.intv_n[r] = 0; B.intv_off[r] = 0; B.seed_n[r] = 0; B.seed_off[r] = 0; B.node_off[r] = 0;
-	if (len < opt.min_seed_len) return;   // mem_chain (bwamem.c:286)
-	int cap = B.max_len + 1;
-	BiIntv *s0 = B.tmp_intv + (size_t)tslot * 2 * cap, *s1 = s0 + cap;
-	SeedEmit em; em.mem = B.tmp_mem + (size_t)tslot * B.mem_cap; em.n = 0; em.cap = B.mem_cap; em.overflow = false;
-	em.min_seed_len = opt.min_seed_len;
-	int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
-	// pass 1: all SMEMs
-	int x = 0;
-	while (x < len) {
-		if (q[x] < 4) x = dev_smem1(ix, q, len, x, 1, s0, s1, cap, em, nblk);
-		else ++x;
+	for (;;) {
+		if (L.i < -1) { smem_finish(L); return; }
+		L.c = L.i < 0 ? -1 : (L.q[L.i] < 4 ? (int)L.q[L.i] : -1);
+		L.j = 0; L.nc = 0; L.last_x2 = 0;
+		if (L.c >= 0) { L.st = SS_BWD; return; }
+		// every interval stops here; only the longest one (first in prev[]) can be a new MEM
+		BiIntv p = L.prev[0];
+		if (!L.any || L.i + 1 < L.last_start) { L.em.add(p.x0, p.x2, L.i + 1, (int)p.info); L.any = true; L.last_start = L.i + 1; }
+		smem_finish(L);
+		return;
 	}
-	// pass 2: re-seed from the middle of long, rare SMEMs
-	int old_n = em.n;
-	for (int k = 0; k < old_n; ++k) {
-		Intv3 p = em.mem[k];
-		int start = (int)(p.info >> 32), end = (int)(u32)p.info;
-		if (end - start < split_len || p.x2 > (u64)opt.split_width) continue;
-		dev_smem1(ix, q, len, (start + end) >> 1, p.x2 + 1, s0, s1, cap, em, nblk);
-	}
-	// pass 3: LAST-like seeds
-	if (opt.max_mem_intv > 0) {
-		x = 0;
-		while (x < len) {
-			if (q[x] < 4) x = dev_seed_strategy1(ix, q, len, x, opt.min_seed_len, opt.max_mem_intv, em, nblk);
-			else ++x;
-		}
-	}
-	if (em.overflow) { atomicOr(&B.ctr->overflow, 16ull); return; }
-	// sort by (start, end); equal keys are identical intervals, so the sort need not mimic ks_introsort's ties
-	dev_introsort(em.mem, em.n, IntvInfoLess());
-	// publish the intervals
-	int n = em.n;
+}
+
+DEVFN void fwd_finish(SeedLane &L, int cap)
+{	// forward sweep done: the change points sit top-down in s0, longest match first
+	L.prev = L.s0 + (cap - L.n0); L.nprev = L.n0; L.curr = L.s1;
+	L.any = false; L.last_start = 0;
+	L.i = L.sx - 1;
+	bwd_begin_row(L);
+}
+
+DEVFN void smem_start(const DevIndex &ix, SeedLane &L, int x, u64 min_intv, int pass, int cap)
+{
+	L.pass = pass; L.sx = x; L.min_intv = min_intv < 1 ? 1 : min_intv;
+	if (L.q[x] > 3) { L.ret = x + 1; smem_finish(L); return; }   // bwt.c:296
+	fm_init(ix, L.q[x], L.ik); L.ik.info = (u64)(x + 1);
+	L.i = x + 1; L.n0 = 0;
+	if (L.i >= L.len || L.q[L.i] > 3) {                          // nothing to extend: push and go backward
+		L.s0[cap - 1] = L.ik; L.n0 = 1; L.ret = (int)L.ik.info;
+		fwd_finish(L, cap);
+	} else L.st = SS_FWD;
+}
+
+// publish one finished read: sort its intervals, copy them out, reserve slot space / B-tree nodes / seed slots
+__device__ void seed_publish(const bwagpu_opt_t &opt, const Batch &B, SeedLane &L)
+{
+	const int r = L.r;
+	if (L.em.overflow) { atomicOr(&B.ctr->overflow, 16ull); return; }
+	int n = L.em.n;
 	if (n == 0) return;
+	dev_introsort(L.em.mem, n, IntvInfoLess());   // equal keys are identical intervals: tie order is immaterial
 	u64 ioff = atomicAdd(&B.ctr->intv_used, (unsigned long long)n);
 	if (ioff + n > (u64)B.intv_cap) { atomicOr(&B.ctr->overflow, 1ull); return; }
-	// number of SA lookups (mem_chain's inner loop bounds, bwamem.c:304-305)
 	i64 ns = 0;
-	for (int i = 0; i < n; ++i) {
-		Intv3 p = em.mem[i];
+	for (int i = 0; i < n; ++i) {   // number of SA lookups per interval (mem_chain's inner loop bounds, bwamem.c:304-305)
+		Intv3 p = L.em.mem[i];
 		B.intv[ioff + i] = p;
 		u64 step = p.x2 > (u64)opt.max_occ ? p.x2 / opt.max_occ : 1;
 		u64 cnt = (p.x2 + step - 1) / step;
 		ns += (i64)(cnt < (u64)opt.max_occ ? cnt : (u64)opt.max_occ);
 	}
-	B.intv_n[r] = n; B.intv_off[r] = (i64)ioff;
 	u64 soff = atomicAdd(&B.ctr->seed_used, (unsigned long long)ns);
 	u64 nnode = (u64)ns / 4 + 2;
 	u64 noff = atomicAdd(&B.ctr->node_used, (unsigned long long)nnode);
 	if (soff + ns > (u64)B.slot_cap) { atomicOr(&B.ctr->overflow, 2ull); return; }
 	if (noff + nnode > (u64)B.node_cap) { atomicOr(&B.ctr->overflow, 4ull); return; }
-	i64 s = 0;
-	for (int i = 0; i < n; ++i) {
-		Intv3 p = em.mem[i];
-		int step = p.x2 > (u64)opt.max_occ ? (int)(p.x2 / opt.max_occ) : 1;
-		int count = 0;
-		for (i64 k = 0; (u64)k < p.x2 && count < opt.max_occ; k += step, ++count, ++s) {
-			B.slot_pos[soff + s] = p.x0 + (u64)k;
-			B.slot_qbeg[soff + s] = (i32)(p.info >> 32);
-			B.slot_len[soff + s] = (i32)((u32)p.info - (u32)(p.info >> 32));
-		}
-	}
+	B.intv_n[r] = n; B.intv_off[r] = (i64)ioff;
 	B.seed_n[r] = (i32)ns; B.seed_off[r] = (i64)soff; B.node_off[r] = (i64)noff;
 }
 
 __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
-	int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+	const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+	const int cap = B.max_len + 1;
+	const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
+	SeedLane L;
+	L.s0 = B.tmp_intv + (size_t)tid * 2 * cap; L.s1 = L.s0 + cap;
+	L.em.mem = B.tmp_mem + (size_t)tid * B.mem_cap; L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len;
+	L.st = SS_FETCH; L.r = -1; L.len = 0; L.q = B.seq;
 	u32 nblk = 0; u64 nintv = 0;
-	for (int r = tid; r < B.n_reads; r += nth) {
-		seed_read(ix, opt, B, r, tid, nblk);
-		nintv += B.intv_n[r];
+	while (L.st != SS_DONE) {
+		// ---- advance the lane's state up to its next extension -----------------------------------------------------
+		switch (L.st) {
+		case SS_FETCH: {
+			int r = (int)atomicAdd(&B.ctr->next_read, 1ull);
+			if (r >= B.n_reads) { L.st = SS_DONE; break; }
+			L.r = r; L.q = B.seq + B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
+			B.intv_n[r] = 0; B.intv_off[r] = 0; B.seed_n[r] = 0; B.seed_off[r] = 0; B.node_off[r] = 0;
+			L.em.n = 0; L.em.overflow = false;
+			if (L.len < opt.min_seed_len) break;                  // mem_chain returns at once (bwamem.c:286); fetch the next read
+			L.x = 0; L.st = SS_PASS1;
+			break; }
+		case SS_PASS1:   // pass 1: all SMEMs, left to right (bwamem.c:147-157)
+			if (L.x >= L.len) { L.old_n = L.em.n; L.k2 = 0; L.st = SS_PASS2; }
+			else if (L.q[L.x] > 3) ++L.x;
+			else smem_start(ix, L, L.x, 1, 1, cap);
+			break;
+		case SS_PASS2:   // pass 2: re-seed from the middle of long, rare SMEMs (bwamem.c:160-168)
+			if (L.k2 >= L.old_n) { L.x = 0; L.st = opt.max_mem_intv > 0 ? SS_PASS3 : SS_FINAL; }
+			else {
+				Intv3 p = L.em.mem[L.k2++];
+				int start = (int)(p.info >> 32), end = (int)(u32)p.info;
+				if (end - start >= split_len && p.x2 <= (u64)opt.split_width) smem_start(ix, L, (start + end) >> 1, p.x2 + 1, 2, cap);
+			}
+			break;
+		case SS_PASS3:   // pass 3: LAST-like seeds (bwamem.c:170-185, bwt_seed_strategy1 bwt.c:358-379)
+			if (L.x >= L.len) L.st = SS_FINAL;
+			else if (L.q[L.x] > 3) ++L.x;
+			else {
+				fm_init(ix, L.q[L.x], L.ik); L.sx = L.x; L.i = L.x + 1;
+				if (L.i >= L.len) { L.x = L.len; }
+				else if (L.q[L.i] > 3) { L.x = L.i + 1; }
+				else L.st = SS_STRAT;
+			}
+			break;
+		case SS_FINAL:
+			seed_publish(opt, B, L);
+			nintv += B.intv_n[L.r];
+			L.st = SS_FETCH;
+			break;
+		default: break;
+		}
+		// ---- the one expensive, convergent step: an FM extension ---------------------------------------------------------
+		const int st = L.st;
+		if (st == SS_FWD || st == SS_BWD || st == SS_STRAT) {
+			BiIntv ok;
+			if (st == SS_BWD) { L.p = L.prev[L.j]; nblk += fm_extend1(ix, L.p, L.c, 1, ok); }
+			else nblk += fm_extend1(ix, L.ik, 3 - L.q[L.i], 0, ok);
+			if (st == SS_FWD) {           // forward sweep of bwt_smem1a (bwt.c:304-320)
+				bool stop = false;
+				if (ok.x2 != L.ik.x2) {
+					L.s0[cap - 1 - L.n0] = L.ik; ++L.n0; L.ret = (int)L.ik.info;
+					if (ok.x2 < L.min_intv) stop = true;
+				}
+				if (!stop) {
+					ok.info = (u64)(L.i + 1); L.ik = ok; ++L.i;
+					if (L.i >= L.len || L.q[L.i] > 3) { L.s0[cap - 1 - L.n0] = L.ik; ++L.n0; L.ret = (int)L.ik.info; stop = true; }
+				}
+				if (stop) fwd_finish(L, cap);
+			} else if (st == SS_BWD) {    // one interval of one backward row (bwt.c:328-342)
+				if (ok.x2 < L.min_intv) {
+					if (L.nc == 0 && (!L.any || L.i + 1 < L.last_start)) {
+						L.em.add(L.p.x0, L.p.x2, L.i + 1, (int)L.p.info); L.any = true; L.last_start = L.i + 1;
+					}
+				} else if (L.nc == 0 || ok.x2 != L.last_x2) {
+					ok.info = L.p.info; L.curr[L.nc++] = ok; L.last_x2 = ok.x2;
+				}
+				if (++L.j == L.nprev) {
+					if (L.nc == 0) smem_finish(L);
+					else { L.prev = L.curr; L.nprev = L.nc; L.curr = (L.curr == L.s1) ? L.s0 : L.s1; --L.i; bwd_begin_row(L); }
+				}
+			} else {                      // bwt_seed_strategy1 (bwt.c:364-377)
+				if (ok.x2 < opt.max_mem_intv && L.i - L.sx >= opt.min_seed_len) {
+					if (ok.x2 > 0) L.em.add(ok.x0, ok.x2, L.sx, L.i + 1);
+					L.x = L.i + 1; L.st = SS_PASS3;
+				} else {
+					L.ik = ok; ++L.i;
+					if (L.i >= L.len) { L.x = L.len; L.st = SS_PASS3; }
+					else if (L.q[L.i] > 3) { L.x = L.i + 1; L.st = SS_PASS3; }
+				}
+			}
+		}
 	}
 	if (B.stats) {
 		atomicAdd(&B.ctr->occ_blocks, (unsigned long long)nblk);
 		atomicAdd(&B.ctr->n_intv, (unsigned long long)nintv);
+	}
+}
+
+// One lane per SA interval: expand it into its SA rows (mem_chain's k-loop, bwamem.c:304-305) in the read's slot range.
+__global__ void __launch_bounds__(256) k_expand(bwagpu_opt_t opt, Batch B)
+{
+	for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < B.n_reads; r += gridDim.x * blockDim.x) {
+		const int n = B.intv_n[r];
+		if (n == 0 || B.seed_n[r] == 0) continue;
+		const Intv3 *iv = B.intv + B.intv_off[r];
+		const i64 soff = B.seed_off[r];
+		i64 s = 0;
+		for (int i = 0; i < n; ++i) {
+			Intv3 p = iv[i];
+			int step = p.x2 > (u64)opt.max_occ ? (int)(p.x2 / opt.max_occ) : 1;
+			int count = 0;
+			const i32 qb = (i32)(p.info >> 32), sl = (i32)((u32)p.info - (u32)(p.info >> 32));
+			for (i64 k = 0; (u64)k < p.x2 && count < opt.max_occ; k += step, ++count, ++s) {
+				B.slot_pos[soff + s] = p.x0 + (u64)k;
+				B.slot_qbeg[soff + s] = qb;
+				B.slot_len[soff + s] = sl;
+			}
+		}
 	}
 }
 
