@@ -84,20 +84,56 @@ DEVFN int fm_extend(const DevIndex &ix, const BiIntv &ik, BiIntv ok[4], int is_b
 	return nblk;
 }
 
-// Single-child variant: only ok[c] is materialised (registers), same arithmetic.
+// symbols 1,2,3 among the top n bases of a 32-base pair, branch-free (n may be <= 0 or >= 32)
+DEVFN void count_pair_bf(u32 whi, u32 wlo, int n, u32 &c1, u32 &c2, u32 &c3)
+{
+	int ne = n < 0 ? 0 : (n > 32 ? 32 : n);
+	u64 p = (u64)whi << 32 | wlo;
+	u64 keep = ne >= 32 ? ~0ull : ~(~0ull >> (2 * ne));        // top 2*ne bits
+	u64 mask = 0x5555555555555555ull & keep;
+	u64 lo = p & mask, hi = (p >> 1) & mask;
+	c3 += __popcll(hi & lo);
+	c2 += __popcll(hi & ~lo);
+	c1 += __popcll(lo & ~hi);
+}
+DEVFN void block_occ4_bf(const OccBlock &b, int o, u64 cnt[4])
+{
+	int n = o + 1;
+	u32 c1 = 0, c2 = 0, c3 = 0;
+	count_pair_bf(b.w0.x, b.w0.y, n, c1, c2, c3);
+	count_pair_bf(b.w0.z, b.w0.w, n - 32, c1, c2, c3);
+	count_pair_bf(b.w1.x, b.w1.y, n - 64, c1, c2, c3);
+	count_pair_bf(b.w1.z, b.w1.w, n - 96, c1, c2, c3);
+	cnt[0] = ((u64)b.c01.y << 32 | b.c01.x) + (u32)(n - c1 - c2 - c3);
+	cnt[1] = ((u64)b.c01.w << 32 | b.c01.z) + c1;
+	cnt[2] = ((u64)b.c23.y << 32 | b.c23.x) + c2;
+	cnt[3] = ((u64)b.c23.w << 32 | b.c23.z) + c3;
+}
+
+// Single-child bwt_extend for the seeding kernel: only ok[c] is produced, and the whole routine is one straight-line
+// instruction stream (both Occ blocks are always fetched -- the same block twice when k and l share it, an L1 hit --
+// and every data-dependent choice is a select), so that all lanes of a wave run it together whatever their state.
+// Returns the number of distinct 64-byte blocks touched (N_blk of SURVEY.md 8d).
 DEVFN int fm_extend1(const DevIndex &ix, const BiIntv &ik, int c, int is_back, BiIntv &out)
 {
+	const u64 a = is_back ? ik.x0 : ik.x1, other = is_back ? ik.x1 : ik.x0;
+	const u64 k = a - 1, l = a - 1 + ik.x2;                    // a >= 1 always (intervals start at L2[c]+1)
+	const u64 kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
+	const OccBlock bk = load_block(ix, kk >> 7), bl = load_block(ix, ll >> 7);
 	u64 tk[4], tl[4];
-	u64 a = is_back ? ik.x0 : ik.x1, other = is_back ? ik.x1 : ik.x0;
-	int nblk = occ4_pair(ix, a - 1, a - 1 + ik.x2, tk, tl);
+	block_occ4_bf(bk, (int)(kk & 127), tk);
+	block_occ4_bf(bl, (int)(ll & 127), tl);
+	const u64 d1 = tl[1] - tk[1], d2 = tl[2] - tk[2], d3 = tl[3] - tk[3];
 	u64 o = other + (a <= ix.primary && a + ik.x2 - 1 >= ix.primary);
-	if (c < 3) o += tl[3] - tk[3];
-	if (c < 2) o += tl[2] - tk[2];
-	if (c < 1) o += tl[1] - tk[1];
-	u64 na = ix.L2[c] + 1 + tk[c];
-	out.x2 = tl[c] - tk[c];
-	if (is_back) { out.x0 = na; out.x1 = o; } else { out.x1 = na; out.x0 = o; }
-	return nblk;
+	o += c < 3 ? d3 : 0; o += c < 2 ? d2 : 0; o += c < 1 ? d1 : 0;
+	const u64 tkc = c == 0 ? tk[0] : c == 1 ? tk[1] : c == 2 ? tk[2] : tk[3];
+	const u64 tlc = c == 0 ? tl[0] : c == 1 ? tl[1] : c == 2 ? tl[2] : tl[3];
+	const u64 L2c = c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
+	const u64 na = L2c + 1 + tkc;
+	out.x2 = tlc - tkc;
+	out.x0 = is_back ? na : o;
+	out.x1 = is_back ? o : na;
+	return (kk >> 7) == (ll >> 7) ? 1 : 2;
 }
 
 DEVFN void fm_init(const DevIndex &ix, int c, BiIntv &ik)

@@ -231,9 +231,12 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 		// ---- the one expensive, convergent step: an FM extension ---------------------------------------------------------
 		const int st = L.st;
 		if (st == SS_FWD || st == SS_BWD || st == SS_STRAT) {
-			BiIntv ok;
-			if (st == SS_BWD) { L.p = L.prev[L.j]; nblk += fm_extend1(ix, L.p, L.c, 1, ok); }
-			else nblk += fm_extend1(ix, L.ik, 3 - L.q[L.i], 0, ok);
+			BiIntv ok, src;
+			const int back = st == SS_BWD;
+			if (back) L.p = L.prev[L.j];
+			src.x0 = back ? L.p.x0 : L.ik.x0; src.x1 = back ? L.p.x1 : L.ik.x1; src.x2 = back ? L.p.x2 : L.ik.x2; src.info = 0;
+			const int cb = back ? L.c : 3 - (int)L.q[L.i];
+			nblk += fm_extend1(ix, src, cb, back, ok);       // the only extension site of the kernel
 			if (st == SS_FWD) {           // forward sweep of bwt_smem1a (bwt.c:304-320)
 				bool stop = false;
 				if (ok.x2 != L.ik.x2) {
@@ -298,17 +301,43 @@ __global__ void __launch_bounds__(256) k_expand(bwagpu_opt_t opt, Batch B)
 	}
 }
 
-// One lane per SA lookup: slot_pos[s] (an SA row) -> reference position.  ~31 dependent block reads each with
-// the reference's sa_intv = 32; a single read when the SA has been densified.
+// SA lookups (bwt_sa, bwt.c:86-96): ~31 dependent LF steps each with the reference's sa_intv = 32, a single read when the
+// SA has been densified.  The walk length is geometric, so lanes are persistent: every lane owns one lookup at a time and
+// takes the next slot as soon as its walk reaches a sampled row -- all lanes execute the same LF step every iteration.
 __global__ void __launch_bounds__(256) k_sa(DevIndex ix, Batch B)
 {
 	u64 n = B.ctr->seed_used;
 	if (n > (u64)B.slot_cap) n = (u64)B.slot_cap;
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	u32 steps = 0;
-	for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (u64)gridDim.x * blockDim.x) {
-		u64 rbeg = fm_sa(ix, B.slot_pos[s], &steps);
-		B.slot_pos[s] = rbeg;
-		B.slot_rid[s] = dev_intv2rid(ix, (i64)rbeg, (i64)rbeg + B.slot_len[s]);   // bns_intv2rid of mem_chain (bwamem.c:312)
+	u64 k = 0, sa = 0; bool have = false;
+	for (;;) {
+		if (!have) {
+			if (s >= n) break;
+			k = B.slot_pos[s]; sa = 0; have = true;
+		}
+		if (k & ix.sa_mask) {           // one bwt_invPsi step (bwt.c:53-59)
+			++sa;
+			if (k == ix.primary) k = 0;
+			else {
+				u64 x = k - (k > ix.primary);
+				OccBlock b = load_block(ix, x >> 7);
+				int o = (int)(x & 127);
+				u32 w = o < 64 ? (o < 32 ? (o < 16 ? b.w0.x : b.w0.y) : (o < 48 ? b.w0.z : b.w0.w))
+							   : (o < 96 ? (o < 80 ? b.w1.x : b.w1.y) : (o < 112 ? b.w1.z : b.w1.w));
+				int c = (w >> ((~o & 15) << 1)) & 3;
+				u64 cnt[4];
+				block_occ4_bf(b, o, cnt);
+				k = (c == 0 ? ix.L2[0] + cnt[0] : c == 1 ? ix.L2[1] + cnt[1] : c == 2 ? ix.L2[2] + cnt[2] : ix.L2[3] + cnt[3]);
+			}
+		} else {                        // sampled row reached: finish this lookup, move to the lane's next slot
+			u64 rbeg = sa + ix.sa[k >> ix.sa_shift];
+			steps += (u32)sa;
+			B.slot_pos[s] = rbeg;
+			B.slot_rid[s] = dev_intv2rid(ix, (i64)rbeg, (i64)rbeg + B.slot_len[s]);   // bns_intv2rid of mem_chain (bwamem.c:312)
+			s += stride; have = false;
+		}
 	}
 	if (B.stats) atomicAdd(&B.ctr->lf_steps, (unsigned long long)steps);
 }
