@@ -1,0 +1,70 @@
+// bwamem_host.h -- host side of the stand-alone aligner: the reference's mem_process_seqs() surface
+// (bwamem.h:161, bwamem.c:1235-1264) re-written from scratch around libbwagpu.so.
+//
+//   worker1 loop  -> bwagpu_align_bseq()            (device, include/bwagpu.h)
+//   mem_pestat    -> hostmem::pestat()              (bwamem_pair.c:72-135)
+//   worker2 loop  -> hostmem::finalize_se / finalize_pe
+//                    mark-primary (bwamem.c:519-584), mapQ (:982-1006), CIGAR/NM/MD (bwa.c:148-234 + ksw.c:540-642),
+//                    XA (bwamem_extra.c:124-172), SAM record (bwamem.c:851-976), mate rescue / pairing
+//                    (bwamem_pair.c:137-419)
+// Output must be byte-identical to the reference's SAM; tests/test_host_finalize.py checks that against
+// oracle/_ref/libbwaref.so on the CPU (no GPU needed: regions come from the oracle).
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../../include/bwagpu.h"
+
+namespace hostmem {
+
+// flags of mem_opt_t::flag (bwamem.h:40-50)
+enum { F_PE = 0x2, F_NOPAIRING = 0x4, F_ALL = 0x8, F_NO_MULTI = 0x10, F_NO_RESCUE = 0x20, F_REF_HDR = 0x100, F_SOFTCLIP = 0x200,
+	   F_SMARTPE = 0x400, F_PRIMARY5 = 0x800, F_KEEP_SUPP_MAPQ = 0x1000, F_XB = 0x2000 };
+
+struct Contig { int64_t offset; int32_t len, n_ambs, is_alt; uint32_t gi; std::string name, anno; };
+
+// what bntseq_t + pac give the finalize code (bntseq.h:41-64)
+struct RefSeqs {
+	int64_t l_pac = 0;
+	std::vector<Contig> ctg;
+	std::vector<uint8_t> pac;
+	int pos2rid(int64_t pos_f) const;                              // bns_pos2rid (bntseq.c:354-368)
+	void get_seq(int64_t beg, int64_t end, std::vector<uint8_t> &out) const;   // bns_get_seq (bntseq.c:403-424)
+	bool fetch_seq(int64_t &beg, int64_t mid, int64_t &end, int &rid, std::vector<uint8_t> &out) const;   // bns_fetch_seq (:426-451)
+};
+
+struct Pestat { int low, high, failed; double avg, std; };          // == mem_pestat_t (bwamem.h:108-112)
+
+struct Aln {   // == the information of mem_aln_t (bwamem.h:114-126)
+	int64_t pos = -1; int rid = -1, flag = 0; bool is_rev = false, is_alt = false; int mapq = 0, NM = 0;
+	std::vector<uint32_t> cigar; std::string md; std::string xa; bool has_xa = false;
+	int score = 0, sub = 0, alt_sc = 0;
+};
+
+struct Read {   // == bseq1_t as the finalize code needs it
+	const char *name; const char *comment; const uint8_t *seq /* nt4 codes */; const char *qual; int l_seq;
+};
+
+typedef std::vector<bwagpu_alnreg_t> Regs;
+
+uint64_t hash_64(uint64_t key);                                     // utils.h:98-109
+int mark_primary_se(const bwagpu_opt_t &opt, Regs &a, int64_t id);  // bwamem.c:547-584
+void reorder_primary5(int T, Regs &a);                              // bwamem.c:1008-1030
+int approx_mapq_se(const bwagpu_opt_t &opt, const bwagpu_alnreg_t &a);   // bwamem.c:982-1006
+Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint8_t *query, const bwagpu_alnreg_t *ar);   // bwamem.c:1119-1189
+void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, const Read &s, const std::vector<Aln> &list, int which, const Aln *mate, const char *rg_id);   // bwamem.c:851-976
+void reg2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, const Read &s, Regs &a, int extra_flag, const Aln *mate, const char *rg_id);   // bwamem.c:1033-1079
+void pestat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const std::vector<Regs> &regs, Pestat pes[4], bool verbose);   // bwamem_pair.c:72-135
+int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uint64_t id, const Read s[2], Regs a[2], std::string out[2], const char *rg_id);   // bwamem_pair.c:276-419
+
+// DP kernels of the finalize stage
+int ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins, int w, std::vector<uint32_t> *cigar);   // ksw.c:540-642
+struct KswResult { int score, te, qe, score2, te2, tb, qb; };
+KswResult ksw_align2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins, int xtra);   // ksw.c:379-400
+int sort_dedup_nopatch(const bwagpu_opt_t &opt, Regs &a);           // mem_sort_dedup_patch with bns == 0 (bwamem_pair.c:201)
+
+template <class T, class LT> void introsort(T *a, long n, LT lt);   // ks_introsort (ksort.h:176-226), defined in host_sort.h
+
+bool load_refseqs(const std::string &prefix, RefSeqs &out, std::string &err);
+
+}  // namespace hostmem

@@ -1,0 +1,91 @@
+// host_api.cpp -- batch-level finalize (the reference's worker2 loop, bwamem.c:1217-1233, 1256-1260) over a thread pool,
+// and a flat C entry point used by the tests to compare this host code with the reference on the CPU.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <atomic>
+#include <thread>
+#include "bwamem_host.h"
+
+namespace hostmem {
+
+// kt_for-like (kthread.c:49): the per-read outputs are independent, so any work split gives the same result
+template <class F> static void parallel_for(int n_threads, long n, F f)
+{
+	if (n_threads <= 1 || n <= 1) { for (long i = 0; i < n; ++i) f(i); return; }
+	std::atomic<long> next(0);
+	std::vector<std::thread> th;
+	for (int t = 0; t < n_threads; ++t)
+		th.emplace_back([&]() { for (;;) { long i = next.fetch_add(16); if (i >= n) break; long e = i + 16 < n ? i + 16 : n; for (; i < e; ++i) f(i); } });
+	for (auto &t : th) t.join();
+}
+
+// regs[i] for all reads of a batch -> SAM text per read (sam[i]); PE when opt.flag & F_PE (mates interleaved)
+void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_processed, int n, const Read *reads, std::vector<Regs> &regs,
+					const Pestat *pes0, int n_threads, const char *rg_id, std::vector<std::string> &sam, bool verbose)
+{
+	sam.assign(n, std::string());
+	if (opt.flag & F_PE) {
+		Pestat pes[4];
+		if (pes0) memcpy(pes, pes0, sizeof pes); else pestat(opt, ref.l_pac, n, regs, pes, verbose);
+		parallel_for(n_threads, n >> 1, [&](long i) {
+			std::string out[2];
+			sam_pe(opt, ref, pes, (uint64_t)((n_processed >> 1) + i), &reads[i << 1], &regs[i << 1], out, rg_id);
+			sam[i << 1].swap(out[0]); sam[i << 1 | 1].swap(out[1]);
+		});
+	} else {
+		parallel_for(n_threads, n, [&](long i) {
+			mark_primary_se(opt, regs[i], n_processed + i);
+			if (opt.flag & F_PRIMARY5) reorder_primary5(opt.T, regs[i]);
+			reg2sam(opt, ref, sam[i], reads[i], regs[i], 0, 0, rg_id);
+		});
+	}
+}
+
+}  // namespace hostmem
+
+using namespace hostmem;
+
+extern "C" {
+
+void *bwamem_host_create(const char *prefix)
+{
+	RefSeqs *r = new RefSeqs();
+	std::string err;
+	if (!load_refseqs(prefix, *r, err)) { fprintf(stderr, "[E::%s] %s\n", __func__, err.c_str()); delete r; return 0; }
+	return r;
+}
+void bwamem_host_destroy(void *h) { delete (RefSeqs*)h; }
+void bwamem_host_set_alt(void *h, int rid, int flag) { ((RefSeqs*)h)->ctg[rid].is_alt = flag; }
+
+// same shape as refshim_regs2sam (oracle/ref_shim.c): names NUL-separated, seqs are nt4 codes, regs flat in read order
+char *bwamem_host_regs2sam(void *h, const bwagpu_opt_t *opt, int64_t n_processed, int n, const char *names, const uint8_t *seqs, const char *quals,
+						   const int64_t *off, const int32_t *counts, const bwagpu_alnreg_t *regs, const Pestat *pes0, int n_threads, int64_t *out_len)
+{
+	const RefSeqs &ref = *(RefSeqs*)h;
+	std::vector<Read> reads(n); std::vector<Regs> rv(n);
+	const char *nm = names; int64_t roff = 0;
+	for (int i = 0; i < n; ++i) {
+		reads[i].name = nm; nm += strlen(nm) + 1;
+		reads[i].comment = 0; reads[i].seq = seqs + off[i]; reads[i].qual = quals ? quals + off[i] : 0; reads[i].l_seq = (int)(off[i + 1] - off[i]);
+		rv[i].assign(regs + roff, regs + roff + counts[i]); roff += counts[i];
+	}
+	std::vector<std::string> sam;
+	finalize_batch(*opt, ref, n_processed, n, reads.data(), rv, pes0, n_threads, 0, sam, false);
+	size_t tot = 0;
+	for (auto &s : sam) tot += s.size();
+	char *out = (char*)malloc(tot + 1); size_t p = 0;
+	for (auto &s : sam) { memcpy(out + p, s.data(), s.size()); p += s.size(); }
+	out[tot] = 0; *out_len = (int64_t)tot;
+	return out;
+}
+
+void bwamem_host_free(void *p) { free(p); }
+
+void bwamem_host_ksw_align2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins, int xtra, int out[7])
+{
+	KswResult r = ksw_align2(qlen, query, tlen, target, mat, o_del, e_del, o_ins, e_ins, xtra);
+	out[0] = r.score; out[1] = r.te; out[2] = r.qe; out[3] = r.score2; out[4] = r.te2; out[5] = r.tb; out[6] = r.qb;
+}
+
+}  // extern "C"

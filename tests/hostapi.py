@@ -1,0 +1,60 @@
+"""ctypes access to bwa_amd/csrc/host/libbwamem_host.so -- the product's host finalize code (no GPU needed)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_DIR = os.path.join(ROOT, "bwa_amd", "csrc", "host")
+HOST_SO = os.path.join(HOST_DIR, "libbwamem_host.so")
+_lib = None
+
+
+def build():
+    srcs = [os.path.join(HOST_DIR, f) for f in sorted(os.listdir(HOST_DIR)) if f.endswith((".cpp", ".h")) and not f.startswith("main_")]
+    if os.path.exists(HOST_SO) and all(os.path.getmtime(HOST_SO) >= os.path.getmtime(s) for s in srcs):
+        return HOST_SO
+    cpp = [s for s in srcs if s.endswith(".cpp")]
+    subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-ffp-contract=off"] + cpp + ["-o", HOST_SO, "-lpthread"], check=True)
+    return HOST_SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.bwamem_host_create.restype = C.c_void_p
+        L.bwamem_host_create.argtypes = [C.c_char_p]
+        L.bwamem_host_destroy.argtypes = [C.c_void_p]
+        L.bwamem_host_set_alt.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.bwamem_host_regs2sam.restype = C.c_void_p
+        L.bwamem_host_regs2sam.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.bwamem_host_free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class HostFinalize:
+    def __init__(self, prefix):
+        self.h = lib().bwamem_host_create(prefix.encode())
+        assert self.h
+
+    def set_alt(self, rid, flag=1):
+        lib().bwamem_host_set_alt(self.h, rid, flag)
+
+    def regs2sam(self, opt, names, seqs_nt4: np.ndarray, quals: bytes, off, counts, regs, n_processed=0, pes0=None, n_threads=4) -> bytes:
+        n = off.shape[0] - 1
+        nm = b"".join(x.encode() + b"\0" for x in names)
+        ln = C.c_int64(0)
+        regs = np.ascontiguousarray(regs)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        seqs_nt4 = np.ascontiguousarray(seqs_nt4, dtype=np.uint8)
+        p = lib().bwamem_host_regs2sam(self.h, C.byref(opt), n_processed, n, nm, seqs_nt4.ctypes.data, quals, off.ctypes.data, counts.ctypes.data, regs.ctypes.data, pes0, n_threads, C.byref(ln))
+        s = C.string_at(p, ln.value)
+        lib().bwamem_host_free(p)
+        return s
+
+    def close(self):
+        if self.h:
+            lib().bwamem_host_destroy(self.h)
+            self.h = None

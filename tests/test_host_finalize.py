@@ -1,0 +1,141 @@
+"""CPU: the product's from-scratch host finalize (bwa_amd/csrc/host: mark-primary, mapQ, CIGAR/NM/MD, XA, SAM records,
+insert-size statistics, mate rescue, pairing) against the compiled reference.  Regions come from the reference's own
+mem_align1_core, so this isolates the host code: its SAM text must equal mem_process_seqs' byte for byte."""
+import ctypes as C
+import numpy as np
+import pytest
+
+import refapi
+import testdata
+from bwa_amd import simdata
+from bwa_amd.structs import default_opt, pacbio_opt
+
+pytestmark = pytest.mark.skipif(not refapi.have_ref(), reason="oracle/_ref not built")
+ASCII = np.frombuffer(b"ACGTN", dtype=np.uint8)
+
+
+@pytest.fixture(scope="module")
+def pair():
+    import hostapi
+    fa, g = testdata.medium_index()
+    ref, host = refapi.RefIndex(fa), hostapi.HostFinalize(fa)
+    yield ref, host, g
+    ref.close(); host.close()
+
+
+def _check(ref, host, opt, reads, what, n_processed=0, ragged=None):
+    seqs, off = ragged if ragged is not None else testdata.flat(reads)
+    n = off.shape[0] - 1
+    names = [f"q{i >> 1}" if (opt.flag & 2) else f"q{i}" for i in range(n)]
+    quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
+    want = ref.process_seqs(opt, names, ASCII[seqs].tobytes(), quals, off, n_processed=n_processed)
+    counts, regs = ref.align(opt, seqs, off)
+    got = host.regs2sam(opt, names, seqs, quals, off, counts, regs, n_processed=n_processed)
+    if got != want:
+        for a, b in zip(want.split(b"\n"), got.split(b"\n")):
+            assert a == b, f"{what}: first differing SAM line\nwant {a[:300]!r}\ngot  {b[:300]!r}"
+    assert got == want, what
+
+
+def _interleave(r1, r2):
+    out = np.empty((2 * r1.shape[0], r1.shape[1]), dtype=np.uint8)
+    out[0::2], out[1::2] = r1, r2
+    return out
+
+
+@pytest.mark.parametrize("flag,kw", [
+    (0, dict(seed=301, n_frac=0.003)),
+    (0x8, dict(seed=302)),                                   # -a  (MEM_F_ALL)
+    (0x200 | 0x2000, dict(seed=303)),                        # -Y, XB tags
+    (0x800 | 0x10, dict(seed=304, length=250, sub=0.03, dele=0.01, ins=0.01)),   # -5 -M
+    (0x1000 | 0x100, dict(seed=305, length=100, sub=0.05, dele=0.008, ins=0.008)),   # -q -V
+])
+def test_single_end_sam(pair, flag, kw):
+    ref, host, g = pair
+    opt = default_opt(); opt.flag |= flag
+    _check(ref, host, opt, simdata.make_reads_se(g, 6000, **kw), f"SE flag {flag:#x}", n_processed=12345)
+
+
+def test_single_end_alt_contig_and_thresholds(pair):
+    ref, host, g = pair
+    ref.set_alt(2, 1); host.set_alt(2, 1)
+    try:
+        opt = default_opt(); opt.T = 20; opt.max_XA_hits = 3
+        _check(ref, host, opt, simdata.make_reads_se(g, 6000, seed=306), "SE with ALT contig")
+        opt.flag |= 0x2
+        _check(ref, host, opt, _interleave(*simdata.make_reads_pe(g, 3000, seed=307)), "PE with ALT contig")
+    finally:
+        ref.set_alt(2, 0); host.set_alt(2, 0)
+
+
+def test_single_end_long_and_ragged(pair):
+    ref, host, g = pair
+    _check(ref, host, pacbio_opt(), simdata.make_reads_long(g, 30, length=4000, seed=308), "pacbio 4 kb")
+    rng = np.random.default_rng(309)
+    base = simdata.make_reads_se(g, 400, length=300, seed=310)
+    rag = [r[: int(rng.integers(1, 300))] for r in base] + [np.full(40, 4, dtype=np.uint8), base[0][:10]]
+    _check(ref, host, default_opt(), None, "ragged", ragged=testdata.ragged(rag))
+
+
+@pytest.mark.parametrize("flag,kw", [
+    (0x2, dict(seed=311)),
+    (0x2, dict(seed=312, sub=0.06, dele=0.01, ins=0.01)),                      # noisy: many ends unmapped -> mate rescue
+    (0x2, dict(seed=313, ins_mean=230.0, ins_sd=60.0)),                         # overlapping mates, wide distribution
+    (0x2 | 0x20, dict(seed=314, sub=0.04)),                                     # -S  no rescue
+    (0x2 | 0x4, dict(seed=315)),                                                # -P  no pairing
+    (0x2 | 0x8, dict(seed=316, sub=0.03)),                                      # -a
+])
+def test_paired_end_sam(pair, flag, kw):
+    ref, host, g = pair
+    opt = default_opt(); opt.flag |= flag
+    _check(ref, host, opt, _interleave(*simdata.make_reads_pe(g, 4000, **kw)), f"PE flag {flag:#x}", n_processed=8000)
+
+
+def test_paired_end_mixed_orientations_and_chimeras(pair):
+    """Pairs whose second mate is not reverse-complemented (FF), swapped, or taken from elsewhere: exercises the four
+    orientation branches of mate rescue and the no-pairing fallback."""
+    ref, host, g = pair
+    r1, r2 = simdata.make_reads_pe(g, 3000, seed=317)
+    rng = np.random.default_rng(318)
+    kind = rng.integers(0, 4, size=r1.shape[0])
+    r2 = r2.copy()
+    ff = kind == 1
+    r2[ff] = (3 - r2[ff])[:, ::-1]                     # same strand as mate 1
+    chim = kind == 2
+    r2[chim] = simdata.make_reads_se(g, int(chim.sum()), seed=319)
+    opt = default_opt(); opt.flag |= 0x2
+    _check(ref, host, opt, _interleave(r1, r2), "PE mixed")
+
+
+def test_ksw_align2_fuzz():
+    """ksw_align2 (striped SSE2 in the reference) vs the host restatement: score, te, qe, score2, te2, tb, qb."""
+    import hostapi
+    R, H = refapi.lib(), hostapi.lib()
+
+    class Kswr(C.Structure):
+        _fields_ = [(n, C.c_int) for n in ("score", "te", "qe", "score2", "te2", "tb", "qb")]
+    R.ksw_align2.restype = Kswr
+    rng = np.random.default_rng(320)
+    opts = [default_opt(), pacbio_opt()]
+    out = (C.c_int * 7)()
+    for it in range(3000):
+        o = opts[it % 2]
+        qlen = int(rng.integers(20, 260)); tlen = int(rng.integers(qlen, qlen + 500))
+        t = rng.integers(0, 4, size=tlen).astype(np.uint8)
+        p = int(rng.integers(0, tlen - qlen + 1))
+        q = t[p:p + qlen].copy()
+        m = rng.random(qlen) < rng.choice([0.03, 0.1, 0.21])
+        q[m] = rng.integers(0, 5, size=int(m.sum())).astype(np.uint8)
+        if rng.random() < 0.5:
+            c = int(rng.integers(5, qlen - 5)); q = np.concatenate([q[:c], q[c + int(rng.integers(1, 4)):], rng.integers(0, 4, size=4).astype(np.uint8)])[:qlen]
+        if rng.random() < 0.3:   # a second, weaker copy of the query elsewhere in the target -> score2/te2
+            p2 = int(rng.integers(0, tlen - qlen + 1)); half = qlen // 2
+            t[p2:p2 + half] = q[:half] % 4
+        q = np.ascontiguousarray(q); t = np.ascontiguousarray(t)
+        xtra = 0x40000 | 0x80000 | (0x10000 if qlen * o.a < 250 else 0) | (19 * o.a)
+        if it % 7 == 0:
+            xtra &= ~0x10000
+        a = R.ksw_align2(qlen, q.ctypes.data_as(C.c_void_p), tlen, t.ctypes.data_as(C.c_void_p), 5, C.cast(o.mat, C.c_void_p), o.o_del, o.e_del, o.o_ins, o.e_ins, xtra, None)
+        H.bwamem_host_ksw_align2(qlen, q.ctypes.data_as(C.c_void_p), tlen, t.ctypes.data_as(C.c_void_p), C.cast(o.mat, C.c_void_p), o.o_del, o.e_del, o.o_ins, o.e_ins, xtra, out)
+        want = [a.score, a.te, a.qe, a.score2, a.te2, a.tb, a.qb]
+        assert want == list(out), f"case {it}: qlen {qlen} tlen {tlen} xtra {xtra:#x}: reference {want} host {list(out)}"
