@@ -28,5 +28,31 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return OUT
 
 
+HOST = os.path.join(CSRC, "host")
+HOST_SO = os.path.join(HOST, "libbwamem_host.so")
+CLI = os.path.join(HERE, "bwa-amd")
+HOST_FLAGS = ["-O2", "-g", "-std=c++17", "-fPIC", "-Wall", "-Wno-misleading-indentation", "-ffp-contract=off"]
+
+
+def build_host(force: bool = False, verbose: bool = True):
+    """Host finalize library (g++, no HIP) and the stand-alone `bwa-amd` command line (links libbwagpu.so)."""
+    srcs = [os.path.join(HOST, f) for f in sorted(os.listdir(HOST)) if f.endswith((".cpp", ".h"))]
+    lib_cpp = [s for s in srcs if s.endswith(".cpp") and not os.path.basename(s).startswith("main_")]
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if force or not os.path.exists(HOST_SO) or os.path.getmtime(HOST_SO) < newest:
+        cmd = ["g++"] + HOST_FLAGS + ["-shared"] + lib_cpp + ["-o", HOST_SO, "-lpthread"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    if force or not os.path.exists(CLI) or os.path.getmtime(CLI) < max(newest, os.path.getmtime(OUT)):
+        cmd = ["g++"] + HOST_FLAGS + lib_cpp + [os.path.join(HOST, "main_mem.cpp"), "-o", CLI, "-L" + CSRC, "-lbwagpu",
+                                               "-Wl,-rpath,$ORIGIN/csrc", "-Wl,-rpath,/opt/rocm/lib", "-lz", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return HOST_SO, CLI
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_host(force="--force" in sys.argv)

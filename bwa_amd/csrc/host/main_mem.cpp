@@ -1,0 +1,335 @@
+// main_mem.cpp -- `bwa-amd mem`: the stand-alone command line around libbwagpu.so + the host finalize code.
+// Mirrors the reference's `bwa mem` (fastmap.c:141-406): same option letters and meaning, same batching rule
+// (chunk_size * n_threads bases per batch unless -K, fastmap.c:394), same SAM header (bwa.c:407-439), so that for the same
+// input and the same -K the output equals `bwa mem`'s except for the @PG line.  Not implemented: -H from a file, -o/-f.
+#include <ctype.h>
+#include <getopt.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+#include <chrono>
+#include <future>
+#include <string>
+#include <vector>
+#include "bwamem_host.h"
+
+namespace hostmem {
+void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_processed, int n, const Read *reads, std::vector<Regs> &regs,
+					const Pestat *pes0, int n_threads, const char *rg_id, std::vector<std::string> &sam, bool verbose);
+}
+using namespace hostmem;
+
+static int g_verbose = 3;
+
+// ---- options -----------------------------------------------------------------------------------------------------------
+static void fill_scmat(int a, int b, int8_t mat[25])
+{	// bwa_fill_scmat (bwa.c:136-145)
+	int k = 0;
+	for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[k++] = i == j ? a : -b; mat[k++] = -1; }
+	for (int j = 0; j < 5; ++j) mat[k++] = -1;
+}
+
+static void opt_init(bwagpu_opt_t *o)
+{	// mem_opt_init (bwamem.c:74-110)
+	memset(o, 0, sizeof *o);
+	o->a = 1; o->b = 4; o->o_del = o->o_ins = 6; o->e_del = o->e_ins = 1; o->w = 100; o->T = 30; o->zdrop = 100;
+	o->pen_unpaired = 17; o->pen_clip5 = o->pen_clip3 = 5; o->max_mem_intv = 20; o->min_seed_len = 19; o->split_width = 10;
+	o->max_occ = 500; o->max_chain_gap = 10000; o->max_ins = 10000; o->mask_level = 0.50f; o->drop_ratio = 0.50f;
+	o->XA_drop_ratio = 0.80f; o->split_factor = 1.5f; o->chunk_size = 10000000; o->n_threads = 1; o->max_XA_hits = 5;
+	o->max_XA_hits_alt = 200; o->max_matesw = 50; o->mask_level_redun = 0.95f; o->min_chain_weight = 0;
+	o->max_chain_extend = 1 << 30; o->mapQ_coef_len = 50; o->mapQ_coef_fac = (int)log(o->mapQ_coef_len);
+	fill_scmat(o->a, o->b, o->mat);
+}
+
+static std::string unescape(const char *s)
+{	// bwa_escape (bwa.c:441-455)
+	std::string r;
+	for (const char *p = s; *p; ++p) {
+		if (*p == '\\') { ++p; if (*p == 't') r += '\t'; else if (*p == 'n') r += '\n'; else if (*p == 'r') r += '\r'; else if (*p == '\\') r += '\\'; if (!*p) break; }
+		else r += *p;
+	}
+	return r;
+}
+
+// ---- FASTA/FASTQ input (what kseq_read + bseq_read deliver, kseq.h:175-220, bwa.c:79-112) ----------------------------
+struct Seq { std::string name, comment, seq, qual; bool has_comment = false, has_qual = false; };
+
+struct Reader {
+	gzFile fp = nullptr; std::vector<char> buf; int pos = 0, len = 0; int last = 0; bool eof = false;
+	bool open(const char *fn) { fp = strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(fileno(stdin), "r"); buf.resize(1 << 16); return fp != nullptr; }
+	int getc_() { if (pos >= len) { if (eof) return -1; len = gzread(fp, buf.data(), (unsigned)buf.size()); pos = 0; if (len <= 0) { eof = true; return -1; } } return (unsigned char)buf[pos++]; }
+	bool read(Seq &s) {
+		int c;
+		if (last == 0) { while ((c = getc_()) != -1 && c != '>' && c != '@') {} if (c == -1) return false; last = c; }
+		s.name.clear(); s.comment.clear(); s.seq.clear(); s.qual.clear(); s.has_comment = s.has_qual = false;
+		while ((c = getc_()) != -1 && !isspace(c)) s.name += (char)c;
+		if (c != '\n' && c != -1) { s.has_comment = true; while ((c = getc_()) != -1 && c != '\n') s.comment += (char)c; while (!s.comment.empty() && s.comment.back() == '\r') s.comment.pop_back(); }
+		if (!s.has_comment) while (!s.name.empty() && s.name.back() == '\r') s.name.pop_back();
+		while ((c = getc_()) != -1 && c != '>' && c != '+' && c != '@') {
+			if (c == '\n') continue;
+			s.seq += (char)c;
+			while ((c = getc_()) != -1 && c != '\n') s.seq += (char)c;
+		}
+		while (!s.seq.empty() && isspace((unsigned char)s.seq.back())) s.seq.pop_back();
+		{ std::string t; for (char ch : s.seq) if (!isspace((unsigned char)ch)) t += ch; s.seq.swap(t); }
+		if (c == '>' || c == '@') last = c; else last = 0;
+		if (c != '+') return true;
+		while ((c = getc_()) != -1 && c != '\n') {}          // skip the rest of the '+' line
+		if (c == -1) return true;
+		s.has_qual = true;
+		while (s.qual.size() < s.seq.size()) {
+			bool got = false;
+			while ((c = getc_()) != -1 && c != '\n') { if (c != '\r') s.qual += (char)c; got = true; }
+			if (c == -1 && !got) break;
+		}
+		last = 0;
+		return true;
+	}
+};
+
+static void trim_readno(std::string &s) { if (s.size() > 2 && s[s.size() - 2] == '/' && isdigit((unsigned char)s.back())) s.resize(s.size() - 2); }
+
+static bool read_batch(Reader &r1, Reader *r2, int chunk, std::vector<Seq> &out)
+{
+	out.clear();
+	long size = 0; Seq s;
+	while (r1.read(s)) {
+		Seq s2;
+		if (r2 && !r2->read(s2)) { fprintf(stderr, "[W::%s] the 2nd file has fewer sequences.\n", "bseq_read"); break; }
+		trim_readno(s.name); size += (long)s.seq.size(); out.push_back(s);
+		if (r2) { trim_readno(s2.name); size += (long)s2.seq.size(); out.push_back(s2); }
+		if (size >= chunk && (out.size() & 1) == 0) break;
+	}
+	return !out.empty();
+}
+
+static inline uint8_t nt4(unsigned char c)
+{	// nst_nt4_table (bntseq.c:46-63)
+	switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}
+
+// ---- one batch: == mem_process_seqs (bwamem.c:1235-1264) ----------------------------------------------------------------
+static void process_seqs(bwagpu_t *gpu, const RefSeqs &ref, const bwagpu_opt_t &opt, int64_t n_processed, std::vector<Seq*> &seqs, const Pestat *pes0,
+						 const char *rg_id, bool copy_comment, std::vector<std::string> &sam)
+{
+	auto t0 = std::chrono::steady_clock::now();
+	const int n = (int)seqs.size();
+	std::vector<int64_t> off((size_t)n + 1, 0);
+	for (int i = 0; i < n; ++i) off[i + 1] = off[i] + (int64_t)seqs[i]->seq.size();
+	std::vector<uint8_t> flat((size_t)off[n] + 1);
+	for (int i = 0; i < n; ++i) { const std::string &s = seqs[i]->seq; uint8_t *d = flat.data() + off[i]; for (size_t j = 0; j < s.size(); ++j) d[j] = nt4((unsigned char)s[j]); }
+	std::vector<int32_t> counts((size_t)n);
+	bwagpu_alnreg_t *all = nullptr; int64_t tot = 0;
+	int rc = bwagpu_align_flat(gpu, &opt, n, flat.data(), off.data(), counts.data(), &all, &tot);   // was: kt_for(worker1) (bwamem.c:1252)
+	if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu)); exit(EXIT_FAILURE); }
+	std::vector<Regs> regs((size_t)n); std::vector<Read> reads((size_t)n);
+	int64_t k = 0;
+	for (int i = 0; i < n; ++i) {
+		regs[i].assign(all + k, all + k + counts[i]); k += counts[i];
+		reads[i].name = seqs[i]->name.c_str();
+		reads[i].comment = copy_comment && seqs[i]->has_comment ? seqs[i]->comment.c_str() : nullptr;
+		reads[i].seq = flat.data() + off[i]; reads[i].qual = seqs[i]->has_qual ? seqs[i]->qual.c_str() : nullptr; reads[i].l_seq = (int)seqs[i]->seq.size();
+	}
+	bwagpu_free(all);
+	if (opt.flag & F_PE) for (int i = 0; i + 1 < n; i += 2) if (seqs[i]->name != seqs[i + 1]->name) { fprintf(stderr, "[mem_sam_pe] paired reads have different names: \"%s\", \"%s\"\n", seqs[i]->name.c_str(), seqs[i + 1]->name.c_str()); exit(EXIT_FAILURE); }
+	finalize_batch(opt, ref, n_processed, n, reads.data(), regs, pes0, opt.n_threads, rg_id, sam, g_verbose >= 3);
+	if (g_verbose >= 3) fprintf(stderr, "[M::%s] Processed %d reads in %.3f real sec\n", "mem_process_seqs", n, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+}
+
+static bool slurp(const std::string &fn, std::vector<char> &out)
+{
+	FILE *fp = fopen(fn.c_str(), "rb");
+	if (!fp) return false;
+	fseek(fp, 0, SEEK_END); long sz = ftell(fp); fseek(fp, 0, SEEK_SET);
+	out.resize((size_t)sz);
+	bool ok = fread(out.data(), 1, (size_t)sz, fp) == (size_t)sz;
+	fclose(fp);
+	return ok;
+}
+
+static int usage()
+{
+	fprintf(stderr, "\nUsage: bwa-amd mem [options] <idxbase> <in1.fq> [in2.fq]\n\n"
+			"Options are those of `bwa mem` (0.7.19): -t -k -w -d -r -y -c -D -W -m -S -P -A -B -O -E -L -U -x -p -R -H -j -5 -q -K -v -T -h -z -a -C -V -Y -M -u -I -N -G -s -X -Q\n"
+			"The FM-index seeding, chaining and seed extension of every read run on the GPU (libbwagpu.so); output equals bwa mem's.\n\n");
+	return 1;
+}
+
+int main(int argc, char *argv[])
+{
+	if (argc < 2 || strcmp(argv[1], "mem") != 0) return usage();
+	std::string pg = "@PG\tID:bwa-amd\tPN:bwa-amd\tVN:0.1\tCL:" + std::string(argv[0]);
+	for (int i = 1; i < argc; ++i) { pg += ' '; pg += argv[i]; }
+	--argc; ++argv;
+	bwagpu_opt_t opt, opt0; opt_init(&opt); memset(&opt0, 0, sizeof opt0);
+	Pestat pes[4]; memset(pes, 0, sizeof pes); for (int i = 0; i < 4; ++i) pes[i].failed = 1;
+	const Pestat *pes0 = nullptr;
+	const char *mode = nullptr; char *p;
+	int c, fixed_chunk = -1, ignore_alt = 0, copy_comment = 0, device = getenv("BWAGPU_DEVICE") ? atoi(getenv("BWAGPU_DEVICE")) : 0;
+	std::string hdr_line, rg_line, rg_id;
+	while ((c = getopt(argc, argv, "51qpaMCSPVYjuk:c:v:s:r:t:R:A:B:O:E:U:w:L:d:T:Q:D:m:I:N:W:x:G:h:y:K:X:H:z:")) >= 0) {
+		if (c == 'k') opt.min_seed_len = atoi(optarg), opt0.min_seed_len = 1;
+		else if (c == '1') {}
+		else if (c == 'x') mode = optarg;
+		else if (c == 'w') opt.w = atoi(optarg), opt0.w = 1;
+		else if (c == 'A') opt.a = atoi(optarg), opt0.a = 1;
+		else if (c == 'B') opt.b = atoi(optarg), opt0.b = 1;
+		else if (c == 'T') opt.T = atoi(optarg), opt0.T = 1;
+		else if (c == 'U') opt.pen_unpaired = atoi(optarg), opt0.pen_unpaired = 1;
+		else if (c == 't') opt.n_threads = atoi(optarg), opt.n_threads = opt.n_threads > 1 ? opt.n_threads : 1;
+		else if (c == 'P') opt.flag |= F_NOPAIRING;
+		else if (c == 'a') opt.flag |= F_ALL;
+		else if (c == 'p') opt.flag |= F_PE | F_SMARTPE;
+		else if (c == 'M') opt.flag |= F_NO_MULTI;
+		else if (c == 'S') opt.flag |= F_NO_RESCUE;
+		else if (c == 'Y') opt.flag |= F_SOFTCLIP;
+		else if (c == 'V') opt.flag |= F_REF_HDR;
+		else if (c == '5') opt.flag |= F_PRIMARY5 | F_KEEP_SUPP_MAPQ;
+		else if (c == 'q') opt.flag |= F_KEEP_SUPP_MAPQ;
+		else if (c == 'u') opt.flag |= F_XB;
+		else if (c == 'c') opt.max_occ = atoi(optarg), opt0.max_occ = 1;
+		else if (c == 'd') opt.zdrop = atoi(optarg), opt0.zdrop = 1;
+		else if (c == 'v') g_verbose = atoi(optarg);
+		else if (c == 'j') ignore_alt = 1;
+		else if (c == 'r') opt.split_factor = (float)atof(optarg), opt0.split_factor = 1.f;
+		else if (c == 'D') opt.drop_ratio = (float)atof(optarg), opt0.drop_ratio = 1.f;
+		else if (c == 'm') opt.max_matesw = atoi(optarg), opt0.max_matesw = 1;
+		else if (c == 's') opt.split_width = atoi(optarg), opt0.split_width = 1;
+		else if (c == 'G') opt.max_chain_gap = atoi(optarg), opt0.max_chain_gap = 1;
+		else if (c == 'N') opt.max_chain_extend = atoi(optarg), opt0.max_chain_extend = 1;
+		else if (c == 'W') opt.min_chain_weight = atoi(optarg), opt0.min_chain_weight = 1;
+		else if (c == 'y') opt.max_mem_intv = (uint64_t)atol(optarg), opt0.max_mem_intv = 1;
+		else if (c == 'C') copy_comment = 1;
+		else if (c == 'K') fixed_chunk = atoi(optarg);
+		else if (c == 'X') opt.mask_level = (float)atof(optarg);
+		else if (c == 'h') {
+			opt0.max_XA_hits = opt0.max_XA_hits_alt = 1;
+			opt.max_XA_hits = opt.max_XA_hits_alt = (int)strtol(optarg, &p, 10);
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) opt.max_XA_hits_alt = (int)strtol(p + 1, &p, 10);
+		}
+		else if (c == 'z') opt.XA_drop_ratio = (float)atof(optarg);
+		else if (c == 'Q') { opt0.mapQ_coef_len = 1; opt.mapQ_coef_len = (float)atoi(optarg); opt.mapQ_coef_fac = opt.mapQ_coef_len > 0 ? (int)log(opt.mapQ_coef_len) : 0; }
+		else if (c == 'O') { opt0.o_del = opt0.o_ins = 1; opt.o_del = opt.o_ins = (int)strtol(optarg, &p, 10); if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) opt.o_ins = (int)strtol(p + 1, &p, 10); }
+		else if (c == 'E') { opt0.e_del = opt0.e_ins = 1; opt.e_del = opt.e_ins = (int)strtol(optarg, &p, 10); if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) opt.e_ins = (int)strtol(p + 1, &p, 10); }
+		else if (c == 'L') { opt0.pen_clip5 = opt0.pen_clip3 = 1; opt.pen_clip5 = opt.pen_clip3 = (int)strtol(optarg, &p, 10); if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) opt.pen_clip3 = (int)strtol(p + 1, &p, 10); }
+		else if (c == 'R') {   // bwa_set_rg (bwa.c:457-488)
+			if (strstr(optarg, "@RG") != optarg) { fprintf(stderr, "[E::bwa_set_rg] the read group line is not started with @RG\n"); return 1; }
+			if (strchr(optarg, '\t')) { fprintf(stderr, "[E::bwa_set_rg] the read group line contained literal <tab> characters -- replace with escaped tabs: \\t\n"); return 1; }
+			rg_line = unescape(optarg);
+			size_t q = rg_line.find("\tID:");
+			if (q == std::string::npos) { fprintf(stderr, "[E::bwa_set_rg] no ID within the read group line\n"); return 1; }
+			for (q += 4; q < rg_line.size() && rg_line[q] != '\t' && rg_line[q] != '\n'; ++q) rg_id += rg_line[q];
+		}
+		else if (c == 'H') { if (optarg[0] == '@') { if (!hdr_line.empty()) hdr_line += '\n'; hdr_line += unescape(optarg); } }
+		else if (c == 'I') {
+			pes0 = pes; pes[1].failed = 0; pes[1].avg = strtod(optarg, &p); pes[1].std = pes[1].avg * .1;
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes[1].std = strtod(p + 1, &p);
+			pes[1].high = (int)(pes[1].avg + 4. * pes[1].std + .499); pes[1].low = (int)(pes[1].avg - 4. * pes[1].std + .499);
+			if (pes[1].low < 1) pes[1].low = 1;
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes[1].high = (int)(strtod(p + 1, &p) + .499);
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes[1].low = (int)(strtod(p + 1, &p) + .499);
+		}
+		else return 1;
+	}
+	if (!rg_line.empty()) { if (!hdr_line.empty()) hdr_line += '\n'; hdr_line += rg_line; }
+	if (opt.n_threads < 1) opt.n_threads = 1;
+	if (optind + 1 >= argc || optind + 3 < argc) return usage();
+	if (mode) {   // presets (fastmap.c:330-358)
+		if (strcmp(mode, "intractg") == 0) {
+			if (!opt0.o_del) opt.o_del = 16; if (!opt0.o_ins) opt.o_ins = 16; if (!opt0.b) opt.b = 9;
+			if (!opt0.pen_clip5) opt.pen_clip5 = 5; if (!opt0.pen_clip3) opt.pen_clip3 = 5;
+		} else if (strcmp(mode, "pacbio") == 0 || strcmp(mode, "pbref") == 0 || strcmp(mode, "ont2d") == 0) {
+			if (!opt0.o_del) opt.o_del = 1; if (!opt0.e_del) opt.e_del = 1; if (!opt0.o_ins) opt.o_ins = 1; if (!opt0.e_ins) opt.e_ins = 1;
+			if (!opt0.b) opt.b = 1; if (opt0.split_factor == 0.) opt.split_factor = 10.;
+			const bool ont = strcmp(mode, "ont2d") == 0;
+			if (!opt0.min_chain_weight) opt.min_chain_weight = ont ? 20 : 40;
+			if (!opt0.min_seed_len) opt.min_seed_len = ont ? 14 : 17;
+			if (!opt0.pen_clip5) opt.pen_clip5 = 0; if (!opt0.pen_clip3) opt.pen_clip3 = 0;
+		} else { fprintf(stderr, "[E::%s] unknown read type '%s'\n", "main_mem", mode); return 1; }
+	} else if (opt0.a) {   // update_a (fastmap.c:125-139)
+		if (!opt0.b) opt.b *= opt.a; if (!opt0.T) opt.T *= opt.a; if (!opt0.o_del) opt.o_del *= opt.a; if (!opt0.e_del) opt.e_del *= opt.a;
+		if (!opt0.o_ins) opt.o_ins *= opt.a; if (!opt0.e_ins) opt.e_ins *= opt.a; if (!opt0.zdrop) opt.zdrop *= opt.a;
+		if (!opt0.pen_clip5) opt.pen_clip5 *= opt.a; if (!opt0.pen_clip3) opt.pen_clip3 *= opt.a; if (!opt0.pen_unpaired) opt.pen_unpaired *= opt.a;
+	}
+	fill_scmat(opt.a, opt.b, opt.mat);
+
+	// ---- index: host copy for the finalize code, device copy for the hot path ----
+	const std::string prefix = argv[optind];
+	RefSeqs ref; std::string err;
+	if (!load_refseqs(prefix, ref, err)) { fprintf(stderr, "[E::%s] fail to locate the index files: %s\n", "main_mem", err.c_str()); return 1; }
+	if (ignore_alt) for (auto &ctg : ref.ctg) ctg.is_alt = 0;
+	bwagpu_t *gpu = nullptr;
+	{
+		std::vector<char> fb, fs;
+		if (!slurp(prefix + ".bwt", fb) || fb.size() < 40 || !slurp(prefix + ".sa", fs) || fs.size() < 56) { fprintf(stderr, "[E::%s] fail to read %s.bwt/.sa\n", "main_mem", prefix.c_str()); return 1; }
+		bwagpu_index_desc_t d; memset(&d, 0, sizeof d);
+		const uint64_t *hb = (const uint64_t*)fb.data(), *hs = (const uint64_t*)fs.data();
+		d.primary = hb[0]; for (int i = 0; i < 4; ++i) d.L2[i + 1] = hb[1 + i]; d.seq_len = d.L2[4];
+		d.bwt = (const uint32_t*)(fb.data() + 40); d.bwt_size = (fb.size() - 40) / 4;
+		d.sa_intv = (int)hs[5]; d.n_sa = (d.seq_len + d.sa_intv) / d.sa_intv;
+		if (hs[0] != d.primary || hs[6] != d.seq_len || fs.size() < 56 + (d.n_sa - 1) * 8) { fprintf(stderr, "[E::%s] SA-BWT inconsistency\n", "main_mem"); return 1; }
+		std::vector<uint64_t> sa(d.n_sa); sa[0] = (uint64_t)-1; memcpy(sa.data() + 1, fs.data() + 56, (d.n_sa - 1) * 8);
+		d.sa = sa.data(); d.pac = ref.pac.data(); d.l_pac = ref.l_pac; d.n_seqs = (int)ref.ctg.size();
+		std::vector<int64_t> off(d.n_seqs); std::vector<int32_t> len(d.n_seqs), alt(d.n_seqs);
+		for (int i = 0; i < d.n_seqs; ++i) { off[i] = ref.ctg[i].offset; len[i] = ref.ctg[i].len; alt[i] = ref.ctg[i].is_alt; }
+		d.ctg_offset = off.data(); d.ctg_len = len.data(); d.ctg_is_alt = alt.data();
+		int rc = bwagpu_create(&gpu, &d, device);
+		if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s\n", "main_mem", bwagpu_strerror(rc)); return 1; }
+	}
+	bwagpu_set_taps(gpu, 0);
+
+	Reader r1, r2; Reader *pr2 = nullptr;
+	if (!r1.open(argv[optind + 1])) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", "main_mem", argv[optind + 1]); return 1; }
+	if (optind + 2 < argc) {
+		if (opt.flag & F_PE) { if (g_verbose >= 2) fprintf(stderr, "[W::%s] when '-p' is in use, the second query file is ignored.\n", "main_mem"); }
+		else { if (!r2.open(argv[optind + 2])) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", "main_mem", argv[optind + 2]); return 1; } pr2 = &r2; opt.flag |= F_PE; }
+	}
+	// SAM header (bwa_print_sam_hdr, bwa.c:407-439)
+	{
+		bool has_hd = hdr_line.rfind("@HD\t", 0) == 0 || hdr_line.find("\n@HD\t") != std::string::npos;
+		bool has_sq = hdr_line.rfind("@SQ\t", 0) == 0 || hdr_line.find("\n@SQ\t") != std::string::npos;
+		if (!has_hd) fputs("@HD\tVN:1.5\tSO:unsorted\tGO:query\n", stdout);
+		if (!has_sq) for (auto &ctg : ref.ctg) { printf("@SQ\tSN:%s\tLN:%d", ctg.name.c_str(), ctg.len); fputs(ctg.is_alt ? "\tAH:*\n" : "\n", stdout); }
+		if (!hdr_line.empty()) printf("%s\n", hdr_line.c_str());
+		printf("%s\n", pg.c_str());
+	}
+	const int chunk = fixed_chunk > 0 ? fixed_chunk : opt.chunk_size * opt.n_threads;
+	int64_t n_processed = 0;
+	std::vector<Seq> cur, nxt;
+	bool have = read_batch(r1, pr2, chunk, cur);
+	while (have) {
+		// overlap the next batch's input with this batch's compute (the role of kt_pipeline's step 0, kthread.c:119)
+		std::future<bool> fut = std::async(std::launch::async, [&]() { return read_batch(r1, pr2, chunk, nxt); });
+		long bp = 0; for (auto &s : cur) bp += (long)s.seq.size();
+		if (g_verbose >= 3) fprintf(stderr, "[M::%s] read %d sequences (%ld bp)...\n", "process", (int)cur.size(), bp);
+		const int n = (int)cur.size();
+		std::vector<std::string> out((size_t)n);
+		if (opt.flag & F_SMARTPE) {   // -p: adjacent records with equal names are pairs (bseq_classify, bwa.c:114-130)
+			std::vector<Seq*> se, pe; std::vector<int> ise, ipe;
+			bool has_last = true; int i;
+			for (i = 1; i < n; ++i) {
+				if (has_last) {
+					if (cur[i].name == cur[i - 1].name) { pe.push_back(&cur[i - 1]); pe.push_back(&cur[i]); ipe.push_back(i - 1); ipe.push_back(i); has_last = false; }
+					else { se.push_back(&cur[i - 1]); ise.push_back(i - 1); }
+				} else has_last = true;
+			}
+			if (has_last) { se.push_back(&cur[i - 1]); ise.push_back(i - 1); }
+			bwagpu_opt_t tmp = opt; std::vector<std::string> sam;
+			if (!se.empty()) { tmp.flag &= ~F_PE; process_seqs(gpu, ref, tmp, n_processed, se, nullptr, rg_id.c_str(), copy_comment, sam); for (size_t k = 0; k < se.size(); ++k) out[ise[k]].swap(sam[k]); }
+			if (!pe.empty()) { tmp.flag |= F_PE; process_seqs(gpu, ref, tmp, n_processed + (int64_t)se.size(), pe, pes0, rg_id.c_str(), copy_comment, sam); for (size_t k = 0; k < pe.size(); ++k) out[ipe[k]].swap(sam[k]); }
+		} else {
+			std::vector<Seq*> all((size_t)n);
+			for (int i = 0; i < n; ++i) all[i] = &cur[i];
+			process_seqs(gpu, ref, opt, n_processed, all, pes0, rg_id.c_str(), copy_comment, out);
+		}
+		n_processed += n;
+		for (auto &s : out) fwrite(s.data(), 1, s.size(), stdout);
+		have = fut.get();
+		cur.swap(nxt);
+	}
+	fflush(stdout);
+	bwagpu_destroy(gpu);
+	return 0;
+}

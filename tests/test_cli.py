@@ -1,0 +1,90 @@
+"""The stand-alone command line `bwa-amd mem` (bwa_amd/csrc/host/main_mem.cpp) against the reference's `bwa mem`:
+same FASTQ/FASTA input, same options, same -K -> the SAM must be identical except for the @PG line.
+CPU variant: the CLI linked against the mock-runtime build of the device library (tests/hostsim), small inputs.
+GPU variant (-m gpu): the real binary, larger inputs."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import refapi
+import testdata
+from bwa_amd import simdata
+
+pytestmark = pytest.mark.skipif(not refapi.have_ref(), reason="oracle/_ref not built")
+ROOT = testdata.ROOT
+
+
+def _body(sam: bytes) -> bytes:
+    return b"\n".join(l for l in sam.split(b"\n") if not l.startswith(b"@PG"))
+
+
+def _run(binary, args, env=None):
+    p = subprocess.run([binary, "mem"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return _body(p.stdout)
+
+
+def _sim_cli():
+    import hostsim_build
+    from bwa_amd import build as b
+    hostsim_build.build()
+    sim = os.path.join(ROOT, "tests", "hostsim")
+    out = os.path.join(sim, "bwa-amd-sim")
+    host = os.path.join(ROOT, "bwa_amd", "csrc", "host")
+    srcs = [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith(".cpp")]
+    deps = srcs + [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".h")] + [os.path.join(sim, "libbwagpu_hostsim.so")]
+    if not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in deps):
+        subprocess.run(["g++"] + b.HOST_FLAGS + srcs + ["-o", out, "-L" + sim, "-lbwagpu_hostsim", "-Wl,-rpath," + sim, "-lz", "-lpthread"], check=True)
+    return out
+
+
+def _write_inputs(tmp_path, g, n_pairs, seed):
+    r1, r2 = simdata.make_reads_pe(g, n_pairs, seed=seed)
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    simdata.write_fastq(f1, r1); simdata.write_fastq(f2, r2)
+    # interleaved + gzip + comments + /1 /2 suffixes, plus a few unpaired records in between
+    inter = str(tmp_path / "inter.fq.gz")
+    with gzip.open(inter, "wb") as f:
+        a = simdata._ASCII
+        for i in range(n_pairs):
+            for k, r in ((1, r1), (2, r2)):
+                f.write(f"@p{i}/{k} BC:Z:ACGT{i}\n".encode() + a[r[i]].tobytes() + b"\n+\n" + b"F" * r.shape[1] + b"\n")
+            if i % 7 == 3:
+                f.write(f"@single{i} XX:i:{i}\n".encode() + a[r1[i][::-1] % 4].tobytes() + b"\n+\n" + b"5" * r1.shape[1] + b"\n")
+    fasta = str(tmp_path / "reads.fa")
+    with open(fasta, "wb") as f:
+        for i in range(min(n_pairs, 40)):
+            s = simdata._ASCII[r1[i]].tobytes()
+            f.write(f">fa{i}\n".encode() + s[:70] + b"\n" + s[70:] + b"\n")
+    return f1, f2, inter, fasta
+
+
+def _compare_all(cli, fa, f1, f2, inter, fasta, env=None):
+    K = ["-K", "100000000", "-t", "4"]
+    assert _run(refapi.REF_BWA, K + [fa, f1]) == _run(cli, K + [fa, f1], env), "single-end"
+    assert _run(refapi.REF_BWA, K + [fa, f1, f2]) == _run(cli, K + [fa, f1, f2], env), "paired-end, two files"
+    x = ["-p", "-C", "-R", "@RG\\tID:grp1\\tSM:s1", "-Y", "-M"]
+    assert _run(refapi.REF_BWA, K + x + [fa, inter]) == _run(cli, K + x + [fa, inter], env), "smart pairing, comments, read group"
+    y = ["-a", "-k", "17", "-A", "2", "-T", "40", "-h", "3,10", "-I", "400,50", "-5"]
+    assert _run(refapi.REF_BWA, K + y + [fa, f1, f2]) == _run(cli, K + y + [fa, f1, f2], env), "scaled scores (-A 2), -I, -a, -5"
+    assert _run(refapi.REF_BWA, K + [fa, fasta]) == _run(cli, K + [fa, fasta], env), "multi-line FASTA input"
+    assert _run(refapi.REF_BWA, ["-K", "3000", "-t", "2", fa, f1, f2]) == _run(cli, ["-K", "3000", "-t", "2", fa, f1, f2], env), "many small batches (-K 3000)"
+
+
+def test_cli_hostsim(tmp_path):
+    prefix, g = testdata.small_index()
+    # the reference binary wants <prefix>.bwt etc.; both programs take the same prefix
+    f1, f2, inter, fasta = _write_inputs(tmp_path, g, 40, seed=401)
+    _compare_all(_sim_cli(), prefix, f1, f2, inter, fasta)
+
+
+@pytest.mark.gpu
+def test_cli_gpu(tmp_path):
+    from bwa_amd import build as b
+    _, cli = b.build_host(verbose=False)
+    fa, g = testdata.medium_index()
+    f1, f2, inter, fasta = _write_inputs(tmp_path, g, 20000, seed=402)
+    _compare_all(cli, fa, f1, f2, inter, fasta)
