@@ -72,6 +72,22 @@ def cpu_baseline(fa: str, reads: np.ndarray, threads: int):
     return n / tot
 
 
+def end_to_end(fa: str, n_reads: int, threads: int):
+    """The stand-alone `bwa-amd mem` (GPU hot path + from-scratch host finalize + SAM text) on the same FASTQ sample as the
+    CPU baseline; reads/s over its own per-batch timing lines, i.e. the same scope as cpu_baseline."""
+    cli = os.path.join(ROOT, "bwa_amd", "bwa-amd")
+    fq = os.path.join(os.path.dirname(fa), f"sample_{n_reads}.fq")
+    if not (os.path.exists(cli) and os.path.exists(fq)):
+        return None
+    p = subprocess.run([cli, "mem", "-t", str(threads), "-K", "100000000", "-v", "3", fa, fq], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    n = tot = 0.0
+    for m in re.finditer(r"Processed (\d+) reads in ([\d.]+) real sec", p.stderr):
+        n += int(m.group(1)); tot += float(m.group(2))
+    if p.returncode != 0 or tot <= 0:
+        return None
+    return n / tot
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,6 +213,10 @@ def main():
             if rps:
                 out["cpu_baseline"] = {"value": round(rps / 1e6, 4), "unit": "Mreads/s", "cores": threads, "kind": "reference",
                                        "sample": f"first {n_s} reads of the same batch, `bwa mem -t {threads} -K 100000000` (whole mem_process_seqs incl. SAM text), {time.time() - t:.1f}s wall"}
+            gpu.close()
+            e2e = end_to_end(fa, n_s, min(threads, 64))
+            if e2e:
+                out["end_to_end"] = {"value": round(e2e / 1e6, 4), "unit": "Mreads/s", "what": f"`bwa-amd mem -t {min(threads, 64)}` on the same {n_s}-read FASTQ sample: H2D + device hot path + D2H + host finalize + SAM text (same scope as cpu_baseline)"}
         print(json.dumps(out), flush=True)
     gpu.close()
     if dist is not None:
