@@ -37,23 +37,22 @@ def log(*a):
 
 
 def build_or_load_index(genome_mbp: float, cache: str, rank: int, barrier):
-    """Seeded synthetic genome + reference-format index (built once per box with the reference's own `bwa index`)."""
+    """Seeded synthetic genome + reference-format index, built on the GPU by bwa_amd.index (byte-identical to `bwa index`
+    output, tests/test_index_build.py) and cached on the box."""
     from bwa_amd import simdata
     total = int(genome_mbp * 1_000_000)
-    tag = f"g{total}_s42"
-    fa = os.path.join(cache, tag + ".fa")
+    prefix = os.path.join(cache, f"g{total}_s42")
     g, lens = simdata.make_genome(total, n_contigs=8, seed=42)
-    if rank == 0 and not os.path.exists(fa + ".sa"):
+    if rank == 0 and not os.path.exists(prefix + ".sa"):
+        from bwa_amd.index import build_index
         os.makedirs(cache, exist_ok=True)
         t = time.time()
-        simdata.write_fasta(fa, g, lens)
-        bwa = os.path.join(ROOT, "oracle", "_ref", "bwa")
-        if not os.path.exists(bwa):
-            raise SystemExit("bench: oracle/_ref/bwa (index builder) is missing; run `python __graft_entry__.py` where /root/reference exists")
-        subprocess.run([bwa, "index", fa], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        log(f"[bench] built {genome_mbp} Mbp index in {time.time() - t:.1f}s")
+        build_index(prefix, g, [(f"chr{i + 1}", l) for i, l in enumerate(lens)])
+        import torch
+        torch.cuda.empty_cache()
+        log(f"[bench] built {genome_mbp} Mbp index on the device in {time.time() - t:.1f}s")
     barrier()
-    return fa, g
+    return prefix, g
 
 
 def cpu_baseline(fa: str, reads: np.ndarray, threads: int):
@@ -95,7 +94,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--genome-mbp", type=float, default=32.0)
+    ap.add_argument("--genome-mbp", type=float, default=512.0)
     ap.add_argument("--cache", default=os.environ.get("BWA_AMD_CACHE", "/tmp/bwa_amd_bench"))
     ap.add_argument("--dense-sa", type=int, default=0, help="densify the SA on the device to this interval (0 = keep the reference's 32)")
     ap.add_argument("--cpu-sample", type=int, default=200_000)
