@@ -318,7 +318,7 @@ extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, cons
 
 static int alloc_batch(bwagpu_t *h, int n_threads)
 {
-	int n = h->n_reads; size_t sc = (size_t)h->slot_cap;
+	int n = h->n_reads; size_t sc = (size_t)h->slot_cap + 8;   // +8: chunked readers may touch a few slots past the last read's range
 	int bad = 0;
 	bad |= h->d_ctr.ensure(sizeof(Counters));
 	bad |= h->d_tmp_intv.ensure((size_t)n_threads * 2 * (h->max_len + 1) * sizeof(BiIntv));

@@ -100,9 +100,8 @@ struct BTree {
 	}
 };
 
-struct ChainWGreater {   // flt_lt (bwamem.c:350): heavier chains first
-	const ChainRec *ch;
-	DEVFN bool operator()(const i32 &a, const i32 &b) const { return ch[a].w > ch[b].w; }
+struct ChainWGreater {   // flt_lt (bwamem.c:350): heavier chains first; elements are {weight, chain index} pairs so that the
+	DEVFN bool operator()(const int2 &a, const int2 &b) const { return a.x > b.x; }   // sort touches no other memory
 };
 
 __device__ void chain_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r)
@@ -196,8 +195,12 @@ __device__ void chain_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Ba
 	}
 	n = k;
 	if (n == 0) return;
-	ChainWGreater cmp; cmp.ch = ch;
-	dev_introsort(ord, n, cmp);
+	{	// ks_introsort moves whole chain records; sorting {weight, index} pairs performs the same comparisons and moves
+		int2 *pw = (int2*)(B.slot_srt + so);
+		for (int i = 0; i < n; ++i) pw[i] = make_int2(ch[ord[i]].w, ord[i]);
+		dev_introsort(pw, n, ChainWGreater());
+		for (int i = 0; i < n; ++i) ord[i] = pw[i].y;
+	}
 	int nk = 0;
 	int4 *kinfo = B.slot_kinfo + so;
 	{
@@ -210,20 +213,26 @@ __device__ void chain_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Ba
 		bool large_ovlp = false; int kk;
 		// the pairwise test against every kept chain is quadratic for reads in repeats (hundreds of chains of similar
 		// weight are all kept): stream the packed {beg,end,w,flags} records instead of chasing chain records
-		for (kk = 0; kk < nk; ++kk) {
-			const int4 kj = kinfo[kk];
-			const int bj = kj.x, ej = kj.y;
-			const int b_max = bj > bi ? bj : bi, e_min = ej < ei ? ej : ei;
-			if (e_min > b_max && (!(kj.w & 1) || alti)) {
-				const int li = ei - bi, lj = ej - bj, min_l = li < lj ? li : lj;
-				if (e_min - b_max >= min_l * opt.mask_level && min_l < opt.max_chain_gap) {
-					large_ovlp = true;
-					if (!(kj.w & 2)) { ch[ord[kept[kk]]].first_shadow = i; kinfo[kk].w = kj.w | 2; }
-					if (wi < kj.z * opt.drop_ratio && kj.z - wi >= opt.min_seed_len << 1) break;
+		bool dropped = false;
+		for (kk = 0; kk < nk && !dropped; kk += 4) {
+			// four records per step (one 64-byte line): the loop is a chain of dependent L1 round trips otherwise.
+			// Reading up to three records past nk stays inside the slot arena (it is allocated with slack); they are ignored.
+			const int4 k4[4] = { kinfo[kk], kinfo[kk + 1], kinfo[kk + 2], kinfo[kk + 3] };
+			for (int u = 0; u < 4 && kk + u < nk; ++u) {
+				const int4 kj = k4[u];
+				const int bj = kj.x, ej = kj.y;
+				const int b_max = bj > bi ? bj : bi, e_min = ej < ei ? ej : ei;
+				if (e_min > b_max && (!(kj.w & 1) || alti)) {
+					const int li = ei - bi, lj = ej - bj, min_l = li < lj ? li : lj;
+					if (e_min - b_max >= min_l * opt.mask_level && min_l < opt.max_chain_gap) {
+						large_ovlp = true;
+						if (!(kj.w & 2)) { ch[ord[kept[kk + u]]].first_shadow = i; kinfo[kk + u].w = kj.w | 2; }
+						if (wi < kj.z * opt.drop_ratio && kj.z - wi >= opt.min_seed_len << 1) { dropped = true; break; }
+					}
 				}
 			}
 		}
-		if (kk == nk) { kept[nk] = i; kinfo[nk] = make_int4(bi, ei, wi, alti); ++nk; ci.kept = large_ovlp ? 2 : 3; }
+		if (!dropped) { kept[nk] = i; kinfo[nk] = make_int4(bi, ei, wi, alti); ++nk; ci.kept = large_ovlp ? 2 : 3; }
 	}
 	for (int i = 0; i < nk; ++i) {
 		ChainRec &c = ch[ord[kept[i]]];

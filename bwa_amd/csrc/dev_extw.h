@@ -184,29 +184,43 @@ __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const
 		wave_sync();
 		for (int k = n - 1; k >= 0; --k) {
 			bwagpu_seed_t s = seeds[(u32)srt[k]];
-			int ii;
-			for (ii = 0; ii < n_av; ++ii) {
-				const bwagpu_alnreg_t &p = av[ii];
-				i64 rd; int qd, w, mg;
-				if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) continue;
-				if (s.len - p.seedlen0 > .1 * l_query) continue;
-				qd = s.qbeg - p.qb; rd = s.rbeg - p.rb;
-				mg = dev_max_gap(opt, qd < rd ? qd : (int)rd); w = mg < p.w ? mg : p.w;
-				if (qd - rd < w && rd - qd < w) break;
-				qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
-				mg = dev_max_gap(opt, qd < rd ? qd : (int)rd); w = mg < p.w ? mg : p.w;
-				if (qd - rd < w && rd - qd < w) break;
-			}
-			if (ii < n_av) {
-				int i;
-				for (i = k + 1; i < n; ++i) {
-					if (srt[i] == 0) continue;
-					bwagpu_seed_t t = seeds[(u32)srt[i]];
-					if (t.len < s.len * .95) continue;
-					if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) break;
-					if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) break;
+			// "is the seed already covered by an earlier alignment of this read?" (bwamem.c:697-713) is an existence query --
+			// the reference only uses whether its scan stopped early -- so 64 earlier regions are tested per step
+			bool covered = false;
+			for (int base = 0; base < n_av && !covered; base += 64) {
+				const int ii = base + lane;
+				bool hit = false;
+				if (ii < n_av) {
+					const bwagpu_alnreg_t &p = av[ii];
+					if (!(s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) && !(s.len - p.seedlen0 > .1 * l_query)) {
+						i64 rd; int qd, w, mg;
+						qd = s.qbeg - p.qb; rd = s.rbeg - p.rb;
+						mg = dev_max_gap(opt, qd < rd ? qd : (int)rd); w = mg < p.w ? mg : p.w;
+						if (qd - rd < w && rd - qd < w) hit = true;
+						else {
+							qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+							mg = dev_max_gap(opt, qd < rd ? qd : (int)rd); w = mg < p.w ? mg : p.w;
+							if (qd - rd < w && rd - qd < w) hit = true;
+						}
+					}
 				}
-				if (i == n) {
+				covered = __ballot(hit) != 0;
+			}
+			if (covered) {   // extend anyway only if an overlapping seed sits on another diagonal (bwamem.c:714-732): also an existence query
+				bool other = false;
+				for (int base = k + 1; base < n && !other; base += 64) {
+					const int i = base + lane;
+					bool hit = false;
+					if (i < n && srt[i] != 0) {
+						bwagpu_seed_t t = seeds[(u32)srt[i]];
+						if (!(t.len < s.len * .95)) {
+							if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) hit = true;
+							else if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) hit = true;
+						}
+					}
+					other = __ballot(hit) != 0;
+				}
+				if (!other) {
 					wave_sync();                       // every lane has finished reading srt[k..] before it is modified
 					if (lane == 0) srt[k] = 0;
 					wave_sync();
@@ -248,10 +262,11 @@ __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const
 				else { a.qe = l_query; a.re = re + x.gtle; a.truesc += x.gscore - sc0; }
 			} else { a.qe = l_query; a.re = s.rbeg + s.len; }
 			int cov = 0;
-			for (int i = 0; i < n; ++i) {
+			for (int i = lane; i < n; i += 64) {   // seedcov (bwamem.c:801-805): lanes stride over the chain's seeds
 				bwagpu_seed_t t = seeds[i];
 				if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) cov += t.len;
 			}
+			for (int o = 32; o > 0; o >>= 1) cov += __shfl_xor(cov, o);
 			a.seedcov = cov;
 			a.w = aw0 > aw1 ? aw0 : aw1;
 			a.seedlen0 = s.len;
