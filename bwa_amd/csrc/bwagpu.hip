@@ -61,7 +61,7 @@ struct bwagpu_s {
 	int stats_on = 0, taps_on = 1;
 	bwagpu_stats_t stats = {};
 	DevBuf d_seq, d_off, d_ctr, d_tmp_intv, d_tmp_mem, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
-	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_next, d_slot_chain, d_slot_ord, d_slot_kept, d_slot_kinfo, d_slot_srt, d_slot_cseed, d_slot_cchain;
+	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_blob;
 	DevBuf d_order, d_bin_cnt, d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
 	i64 intv_cap = 0, slot_cap = 0, node_cap = 0, reg_cap = 0; int mem_cap = 0;
 	std::vector<i64> h_off;
@@ -148,8 +148,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 {
 	if (!h) return;
 	DevBuf *all[] = { &h->d_bwt, &h->d_sa, &h->d_pac, &h->d_ctg_off, &h->d_ctg_len, &h->d_ctg_alt, &h->d_seq, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
-		&h->d_tmp_mem, &h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_next,
-		&h->d_slot_chain, &h->d_slot_ord, &h->d_slot_kept, &h->d_slot_kinfo, &h->d_slot_srt, &h->d_slot_cseed, &h->d_slot_cchain, &h->d_chain_n, &h->d_node_off,
+		&h->d_tmp_mem, &h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
 	for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -326,9 +325,7 @@ static int alloc_batch(bwagpu_t *h, int n_threads)
 	bad |= h->d_intv_n.ensure((size_t)n * 4 + 16); bad |= h->d_intv_off.ensure((size_t)n * 8 + 16);
 	bad |= h->d_intv.ensure((size_t)h->intv_cap * sizeof(Intv3));
 	bad |= h->d_seed_n.ensure((size_t)n * 4 + 16); bad |= h->d_seed_off.ensure((size_t)n * 8 + 16);
-	bad |= h->d_slot_pos.ensure(sc * 8); bad |= h->d_slot_qbeg.ensure(sc * 4); bad |= h->d_slot_len.ensure(sc * 4); bad |= h->d_slot_rid.ensure(sc * 4); bad |= h->d_slot_next.ensure(sc * 4);
-	bad |= h->d_slot_chain.ensure(sc * sizeof(ChainRec)); bad |= h->d_slot_ord.ensure(sc * 4); bad |= h->d_slot_kept.ensure(sc * 4); bad |= h->d_slot_kinfo.ensure(sc * 16);
-	bad |= h->d_slot_srt.ensure(sc * 8); bad |= h->d_slot_cseed.ensure(sc * sizeof(bwagpu_seed_t)); bad |= h->d_slot_cchain.ensure(sc * sizeof(bwagpu_chain_t));
+	bad |= h->d_slot_pos.ensure(sc * 8); bad |= h->d_slot_qbeg.ensure(sc * 4); bad |= h->d_slot_len.ensure(sc * 4); bad |= h->d_slot_rid.ensure(sc * 4); bad |= h->d_slot_blob.ensure(sc * SLOT_BLOB_BYTES);
 	bad |= h->d_chain_n.ensure((size_t)n * 4 + 16); bad |= h->d_node_off.ensure((size_t)n * 8 + 16);
 	bad |= h->d_nodes.ensure((size_t)h->node_cap * BT_NODE_INTS * 4);
 	bad |= h->d_reg_off.ensure((size_t)n * 8 + 16); bad |= h->d_reg_cap_r.ensure((size_t)n * 4 + 16);
@@ -392,9 +389,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.tmp_intv = h->d_tmp_intv.as<BiIntv>(); B.tmp_mem = h->d_tmp_mem.as<Intv3>(); B.mem_cap = h->mem_cap;
 		B.intv_n = h->d_intv_n.as<i32>(); B.intv_off = h->d_intv_off.as<i64>(); B.intv = h->d_intv.as<Intv3>(); B.intv_cap = h->intv_cap;
 		B.seed_n = h->d_seed_n.as<i32>(); B.seed_off = h->d_seed_off.as<i64>(); B.slot_cap = h->slot_cap;
-		B.slot_pos = h->d_slot_pos.as<u64>(); B.slot_qbeg = h->d_slot_qbeg.as<i32>(); B.slot_len = h->d_slot_len.as<i32>(); B.slot_rid = h->d_slot_rid.as<i32>(); B.slot_next = h->d_slot_next.as<i32>();
-		B.slot_chain = h->d_slot_chain.as<ChainRec>(); B.slot_ord = h->d_slot_ord.as<i32>(); B.slot_kept = h->d_slot_kept.as<i32>(); B.slot_kinfo = h->d_slot_kinfo.as<int4>();
-		B.slot_srt = h->d_slot_srt.as<u64>(); B.slot_cseed = h->d_slot_cseed.as<bwagpu_seed_t>(); B.slot_cchain = h->d_slot_cchain.as<bwagpu_chain_t>();
+		B.slot_pos = h->d_slot_pos.as<u64>(); B.slot_qbeg = h->d_slot_qbeg.as<i32>(); B.slot_len = h->d_slot_len.as<i32>(); B.slot_rid = h->d_slot_rid.as<i32>(); B.slot_blob = h->d_slot_blob.as<u8>();
 		B.chain_n = h->d_chain_n.as<i32>(); B.node_off = h->d_node_off.as<i64>(); B.nodes = h->d_nodes.as<i32>(); B.node_cap = h->node_cap;
 		B.reg_off = h->d_reg_off.as<i64>(); B.reg_cap_r = h->d_reg_cap_r.as<i32>(); B.reg_n_raw = h->d_reg_n_raw.as<i32>(); B.reg_n = h->d_reg_n.as<i32>();
 		B.regs = h->d_regs.as<bwagpu_alnreg_t>(); B.reg_cap = h->reg_cap;
@@ -549,21 +544,31 @@ extern "C" int bwagpu_tap_intervals(bwagpu_t *h, int32_t *counts, bwagpu_intv_t 
 extern "C" int bwagpu_tap_chains(bwagpu_t *h, int32_t *counts, bwagpu_chain_t **chains, int64_t *n_chains, bwagpu_seed_t **seeds, int64_t *n_seeds)
 {
 	if (!h || !h->ran || !chains || !n_chains || !seeds || !n_seeds) return BWAGPU_EINVAL;
-	int n = h->n_reads;
-	std::vector<int32_t> cn((size_t)n);
-	int rc = gather<bwagpu_chain_t>(h, h->d_chain_n, h->d_seed_off, h->d_slot_cchain, h->slot_cap, cn.data(), chains, n_chains);
-	if (rc) return rc;
-	// seeds of the kept chains: count per read = sum of its chains' n_seeds
-	std::vector<i32> sn((size_t)n); std::vector<i64> off((size_t)n);
-	if (n) HIPCHK(h, hipMemcpy(off.data(), h->d_seed_off.p, (size_t)n * 8, hipMemcpyDeviceToHost));
-	i64 k = 0, tot = 0, hi = 0;
-	for (int i = 0; i < n; ++i) { int s = 0; for (int j = 0; j < cn[i]; ++j) s += (*chains)[k + j].n_seeds; k += cn[i]; sn[i] = s; tot += s; if (s && off[i] + s > hi) hi = off[i] + s; }
-	std::vector<bwagpu_seed_t> all((size_t)hi);
-	if (hi) HIPCHK(h, hipMemcpy(all.data(), h->d_slot_cseed.p, (size_t)hi * sizeof(bwagpu_seed_t), hipMemcpyDeviceToHost));
-	bwagpu_seed_t *res = (bwagpu_seed_t*)malloc((size_t)(tot ? tot : 1) * sizeof(bwagpu_seed_t));
-	k = 0;
-	for (int i = 0; i < n; ++i) { if (sn[i]) memcpy(res + k, all.data() + off[i], (size_t)sn[i] * sizeof(bwagpu_seed_t)); k += sn[i]; if (counts) counts[i] = cn[i]; }
-	*seeds = res; *n_seeds = tot;
+	HIPCHK(h, hipSetDevice(h->device));
+	const int n = h->n_reads;
+	std::vector<i32> cn((size_t)n), sn((size_t)n); std::vector<i64> off((size_t)n);
+	if (n) {
+		HIPCHK(h, hipMemcpy(cn.data(), h->d_chain_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+		HIPCHK(h, hipMemcpy(sn.data(), h->d_seed_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+		HIPCHK(h, hipMemcpy(off.data(), h->d_seed_off.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+	}
+	std::vector<bwagpu_chain_t> vc; std::vector<bwagpu_seed_t> vs; std::vector<bwagpu_chain_t> tc; std::vector<bwagpu_seed_t> ts;
+	for (int i = 0; i < n; ++i) {   // per-read regions: kept chain headers at +80n, their seeds at +112n (RegionView)
+		if (counts) counts[i] = cn[i];
+		if (cn[i] == 0) continue;
+		const u8 *base = h->d_slot_blob.as<u8>() + off[i] * SLOT_BLOB_BYTES;
+		tc.resize((size_t)cn[i]);
+		HIPCHK(h, hipMemcpy(tc.data(), base + (size_t)80 * sn[i], (size_t)cn[i] * sizeof(bwagpu_chain_t), hipMemcpyDeviceToHost));
+		int ks = 0; for (auto &c : tc) ks += c.n_seeds;
+		ts.resize((size_t)ks);
+		if (ks) HIPCHK(h, hipMemcpy(ts.data(), base + (size_t)112 * sn[i], (size_t)ks * sizeof(bwagpu_seed_t), hipMemcpyDeviceToHost));
+		vc.insert(vc.end(), tc.begin(), tc.end()); vs.insert(vs.end(), ts.begin(), ts.end());
+	}
+	*chains = (bwagpu_chain_t*)malloc((vc.size() + 1) * sizeof(bwagpu_chain_t)); *seeds = (bwagpu_seed_t*)malloc((vs.size() + 1) * sizeof(bwagpu_seed_t));
+	if (!*chains || !*seeds) return BWAGPU_ENOMEM;
+	if (!vc.empty()) memcpy(*chains, vc.data(), vc.size() * sizeof(bwagpu_chain_t));
+	if (!vs.empty()) memcpy(*seeds, vs.data(), vs.size() * sizeof(bwagpu_seed_t));
+	*n_chains = (int64_t)vc.size(); *n_seeds = (int64_t)vs.size();
 	return BWAGPU_OK;
 }
 

@@ -123,8 +123,9 @@ __device__ void chain_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Ba
 	l_rep += e - b;
 	float frac_rep = (float)l_rep / len;
 
-	ChainRec *ch = B.slot_chain + so;
-	i32 *next = B.slot_next + so;
+	const RegionView R = region_of(B.slot_blob, so, ns);
+	ChainRec *ch = R.chain;
+	i32 *next = R.next;
 	const u64 *pos = B.slot_pos + so;
 	const i32 *sqb = B.slot_qbeg + so, *sln = B.slot_len + so, *srid = B.slot_rid + so;
 	BTree bt; bt.nd = B.nodes + B.node_off[r] * BT_NODE_INTS; bt.n_nodes = 0;
@@ -168,7 +169,7 @@ __device__ void chain_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Ba
 		}
 	}
 	if (n_ch == 0) return;
-	i32 *ord = B.slot_ord + so, *kept = B.slot_kept + so;
+	i32 *ord = R.ord, *kept = R.kept;
 	int n = bt.inorder(ord);
 
 	// ---- mem_chain_flt (bwamem.c:353-411) ----
@@ -196,13 +197,13 @@ __device__ void chain_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Ba
 	n = k;
 	if (n == 0) return;
 	{	// ks_introsort moves whole chain records; sorting {weight, index} pairs performs the same comparisons and moves
-		int2 *pw = (int2*)(B.slot_srt + so);
+		int2 *pw = (int2*)R.srt;
 		for (int i = 0; i < n; ++i) pw[i] = make_int2(ch[ord[i]].w, ord[i]);
 		dev_introsort(pw, n, ChainWGreater());
 		for (int i = 0; i < n; ++i) ord[i] = pw[i].y;
 	}
 	int nk = 0;
-	int4 *kinfo = B.slot_kinfo + so;
+	int4 *kinfo = R.kinfo;
 	{
 		ChainRec &c0 = ch[ord[0]];
 		c0.kept = 3; kept[0] = 0; kinfo[0] = make_int4(c0.first_qbeg, c0.last_qbeg + c0.last_len, c0.w, c0.is_alt); nk = 1;
@@ -246,8 +247,8 @@ __device__ void chain_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Ba
 	}
 	for (; i < n; ++i) if (ch[ord[i]].kept < 3) ch[ord[i]].kept = 0;
 	// ---- publish the kept chains: headers + seeds flattened chain by chain ----
-	bwagpu_chain_t *oc = B.slot_cchain + so;
-	bwagpu_seed_t *os = B.slot_cseed + so;
+	bwagpu_chain_t *oc = R.cchain;
+	bwagpu_seed_t *os = R.cseed;
 	int m = 0; k = 0;
 	for (i = 0; i < n; ++i) {
 		ChainRec &c = ch[ord[i]];

@@ -57,6 +57,7 @@ struct ChainRec {
 };
 
 #define ORDER_BINS 32
+#define SLOT_BLOB_BYTES 160   // 64 chain record + 16 packed kept-chain record + 32 kept chain header + 24 seed + 8 sort key + 3 x 4 ints (+4 pad)
 
 struct Counters {          // device-side bump allocators + flags
 	unsigned long long intv_used, seed_used, node_used, reg_used;
@@ -66,6 +67,25 @@ struct Counters {          // device-side bump allocators + flags
 	unsigned long long n_intv, n_chains, n_regs_raw, n_regs;
 	unsigned long long occ_blocks, lf_steps, ext_calls, ext_cells, glb_calls, glb_cells, ref_bases, sw_calls, sw_cells;
 };
+
+// Sub-arrays of one read's private region (n = its number of seed slots); offsets keep every array naturally aligned.
+struct RegionView {
+	ChainRec *chain;          // chain pool                                   [0, 64n)
+	int4 *kinfo;              // packed {beg, end, weight, flags} of kept chains  [64n, 80n)
+	bwagpu_chain_t *cchain;   // kept chains (headers)                        [80n, 112n)
+	bwagpu_seed_t *cseed;     // seeds of the kept chains, chain by chain     [112n, 136n)
+	u64 *srt;                 // sort keys (chain filter, mem_chain2aln)      [136n, 144n)
+	i32 *next, *ord, *kept;   // seed links, chain order, kept list           [144n, 156n)
+};
+DEVFN RegionView region_of(u8 *blob, i64 seed_off, int n)
+{
+	u8 *b = blob + seed_off * SLOT_BLOB_BYTES;
+	RegionView v;
+	v.chain = (ChainRec*)b; v.kinfo = (int4*)(b + (size_t)64 * n); v.cchain = (bwagpu_chain_t*)(b + (size_t)80 * n);
+	v.cseed = (bwagpu_seed_t*)(b + (size_t)112 * n); v.srt = (u64*)(b + (size_t)136 * n);
+	v.next = (i32*)(b + (size_t)144 * n); v.ord = (i32*)(b + (size_t)148 * n); v.kept = (i32*)(b + (size_t)152 * n);
+	return v;
+}
 
 // Everything one batch needs on the device.
 struct Batch {
@@ -90,14 +110,11 @@ struct Batch {
 	u64 *slot_pos;             // SA row before the lookup kernel, reference position (rbeg) after it
 	i32 *slot_qbeg, *slot_len; // the seed's query start and length (copied from its interval by k_seed)
 	i32 *slot_rid;             // contig id of the seed, -1/-2 if it bridges contigs/strands (filled by k_sa)
-	i32 *slot_next;            // next seed of the same chain (-1 = end)
-	ChainRec *slot_chain;      // chain pool
-	i32 *slot_ord;             // in-order / sorted chain indices
-	i32 *slot_kept;            // indices of kept chains (mem_chain_flt's `chains` vector)
-	int4 *slot_kinfo;          // {query begin, query end, weight, is_alt | has_first<<1} of each kept chain, packed for streaming
-	u64 *slot_srt;             // mem_chain2aln's srt[] (score<<32 | seed index)
-	bwagpu_seed_t *slot_cseed; // seeds of the kept chains, flattened chain by chain
-	bwagpu_chain_t *slot_cchain; // kept chains (header), slot_cchain[seed_off[r] + i]
+	// Per-read private work area of the chaining / extension stages: ONE contiguous block of SLOT_BLOB_BYTES * n_seeds bytes
+	// per read at slot_blob + seed_off * SLOT_BLOB_BYTES, carved into the sub-arrays below by RegionView.  A lane (or wave)
+	// working on a read then touches one compact region instead of a dozen arena-wide arrays (fewer TLB entries / DRAM pages
+	// per read, and the next read of the lane starts in a fresh region).
+	u8 *slot_blob;
 	i32 *chain_n;              // per read: chains after filtering
 	// --- B-tree nodes
 	i64 *node_off;             // per read

@@ -100,9 +100,10 @@ __device__ void ext_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Batc
 	const u8 *query = B.seq + B.off[r];
 	int l_query = (int)(B.off[r + 1] - B.off[r]);
 	i64 so = B.seed_off[r], l_pac = ix.l_pac;
-	const bwagpu_chain_t *chains = B.slot_cchain + so;
-	const bwagpu_seed_t *seeds_all = B.slot_cseed + so;
-	u64 *srt_all = B.slot_srt + so;
+	const RegionView R = region_of(B.slot_blob, so, B.seed_n[r]);
+	const bwagpu_chain_t *chains = R.cchain;
+	const bwagpu_seed_t *seeds_all = R.cseed;
+	u64 *srt_all = R.srt;
 	bwagpu_alnreg_t *av = B.regs + B.reg_off[r];
 	int n_av = 0, sbeg = 0, mat_max = opt_mat_max(opt);
 	for (int ci = 0; ci < n_ch; ++ci) {

@@ -39,8 +39,9 @@ __device__ void seedsw_read(const DevIndex &ix, const bwagpu_opt_t &opt, const B
 	if (min_hsp < 0) return;                       // "don't run the following for short reads" (bwamem.c:628)
 	const u8 *query = B.seq + B.off[r];
 	i64 so = B.seed_off[r], l_pac = ix.l_pac;
-	bwagpu_chain_t *chains = B.slot_cchain + so;
-	bwagpu_seed_t *seeds = B.slot_cseed + so;
+	const RegionView R = region_of(B.slot_blob, so, B.seed_n[r]);
+	bwagpu_chain_t *chains = R.cchain;
+	bwagpu_seed_t *seeds = R.cseed;
 	int sbeg = 0, m = 0;
 	for (int ci = 0; ci < n_ch; ++ci) {
 		int n = chains[ci].n_seeds, k = 0;
