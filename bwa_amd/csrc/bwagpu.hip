@@ -51,7 +51,8 @@ struct bwagpu_s {
 	std::string err;
 	// index
 	DevIndex ix = {};
-	DevBuf d_bwt, d_sa, d_pac, d_ctg_off, d_ctg_len, d_ctg_alt;
+	struct IndexBufs { DevBuf d_bwt, d_sa, d_pac, d_ctg_off, d_ctg_len, d_ctg_alt; int refs = 1; };
+	IndexBufs *ibuf = nullptr;      // shared by bwagpu_clone()d handles
 	i64 l_pac = 0; int n_seqs = 0; u64 seq_len = 0; int sa_intv = 0;
 	u64 bwt_blocks = 0, bwt_bytes = 0, sa_bytes = 0, pac_bytes = 0, bwt_size = 0, n_sa = 0;
 	std::vector<i64> h_ctg_off; std::vector<i32> h_ctg_len, h_ctg_alt;
@@ -105,6 +106,7 @@ extern "C" int bwagpu_create(bwagpu_t **out, const bwagpu_index_desc_t *d, int d
 	if (hipSetDevice(device) != hipSuccess) return BWAGPU_ENODEV;
 	bwagpu_t *h = new bwagpu_s();
 	h->device = device;
+	h->ibuf = new bwagpu_s::IndexBufs();
 	int rc;
 	if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return BWAGPU_ENODEV; }
 	for (int i = 0; i < 8; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return BWAGPU_ENODEV; }
@@ -116,23 +118,23 @@ extern "C" int bwagpu_create(bwagpu_t **out, const bwagpu_index_desc_t *d, int d
 	h->bwt_bytes = nblk * 64; h->sa_bytes = d->n_sa * 8; h->pac_bytes = (u64)(d->l_pac / 4 + 1);
 	h->bwt_size = d->bwt_size; h->n_sa = d->n_sa;
 	if (alloc_only) {
-		if (h->d_bwt.ensure(h->bwt_bytes) || h->d_sa.ensure(h->sa_bytes) || h->d_pac.ensure(h->pac_bytes)) { rc = BWAGPU_ENOMEM; goto fail; }
+		if (h->ibuf->d_bwt.ensure(h->bwt_bytes) || h->ibuf->d_sa.ensure(h->sa_bytes) || h->ibuf->d_pac.ensure(h->pac_bytes)) { rc = BWAGPU_ENOMEM; goto fail; }
 	} else {
-		if ((rc = upload(h, h->d_bwt, src, nblk * 64))) goto fail;
-		if ((rc = upload(h, h->d_sa, d->sa, d->n_sa * 8))) goto fail;
-		if ((rc = upload(h, h->d_pac, d->pac, (size_t)(d->l_pac / 4 + 1)))) goto fail;
+		if ((rc = upload(h, h->ibuf->d_bwt, src, nblk * 64))) goto fail;
+		if ((rc = upload(h, h->ibuf->d_sa, d->sa, d->n_sa * 8))) goto fail;
+		if ((rc = upload(h, h->ibuf->d_pac, d->pac, (size_t)(d->l_pac / 4 + 1)))) goto fail;
 	}
-	if ((rc = upload(h, h->d_ctg_off, d->ctg_offset, (size_t)d->n_seqs * 8))) goto fail;
-	if ((rc = upload(h, h->d_ctg_len, d->ctg_len, (size_t)d->n_seqs * 4))) goto fail;
-	if ((rc = upload(h, h->d_ctg_alt, d->ctg_is_alt, (size_t)d->n_seqs * 4))) goto fail;
+	if ((rc = upload(h, h->ibuf->d_ctg_off, d->ctg_offset, (size_t)d->n_seqs * 8))) goto fail;
+	if ((rc = upload(h, h->ibuf->d_ctg_len, d->ctg_len, (size_t)d->n_seqs * 4))) goto fail;
+	if ((rc = upload(h, h->ibuf->d_ctg_alt, d->ctg_is_alt, (size_t)d->n_seqs * 4))) goto fail;
 	h->bwt_blocks = nblk;
-	h->ix.bwt = h->d_bwt.as<uint4>();
+	h->ix.bwt = h->ibuf->d_bwt.as<uint4>();
 	h->ix.primary = d->primary; for (int i = 0; i < 5; ++i) h->ix.L2[i] = d->L2[i];
 	h->ix.seq_len = d->seq_len;
-	h->ix.sa = h->d_sa.as<u64>(); h->ix.sa_mask = (u64)d->sa_intv - 1;
+	h->ix.sa = h->ibuf->d_sa.as<u64>(); h->ix.sa_mask = (u64)d->sa_intv - 1;
 	h->ix.sa_shift = 0; while ((1 << h->ix.sa_shift) < d->sa_intv) ++h->ix.sa_shift;
-	h->ix.pac = h->d_pac.as<u8>(); h->ix.l_pac = d->l_pac;
-	h->ix.n_seqs = d->n_seqs; h->ix.ctg_off = h->d_ctg_off.as<i64>(); h->ix.ctg_len = h->d_ctg_len.as<i32>(); h->ix.ctg_alt = h->d_ctg_alt.as<i32>();
+	h->ix.pac = h->ibuf->d_pac.as<u8>(); h->ix.l_pac = d->l_pac;
+	h->ix.n_seqs = d->n_seqs; h->ix.ctg_off = h->ibuf->d_ctg_off.as<i64>(); h->ix.ctg_len = h->ibuf->d_ctg_len.as<i32>(); h->ix.ctg_alt = h->ibuf->d_ctg_alt.as<i32>();
 	h->l_pac = d->l_pac; h->n_seqs = d->n_seqs; h->seq_len = d->seq_len; h->sa_intv = d->sa_intv;
 	h->h_ctg_off.assign(d->ctg_offset, d->ctg_offset + d->n_seqs);
 	h->h_ctg_len.assign(d->ctg_len, d->ctg_len + d->n_seqs);
@@ -147,7 +149,12 @@ fail:
 extern "C" void bwagpu_destroy(bwagpu_t *h)
 {
 	if (!h) return;
-	DevBuf *all[] = { &h->d_bwt, &h->d_sa, &h->d_pac, &h->d_ctg_off, &h->d_ctg_len, &h->d_ctg_alt, &h->d_seq, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
+	if (h->ibuf && --h->ibuf->refs == 0) {
+		DevBuf *ib[] = { &h->ibuf->d_bwt, &h->ibuf->d_sa, &h->ibuf->d_pac, &h->ibuf->d_ctg_off, &h->ibuf->d_ctg_len, &h->ibuf->d_ctg_alt };
+		for (DevBuf *b : ib) b->release();
+		delete h->ibuf;
+	}
+	DevBuf *all[] = { &h->d_seq, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_tmp_mem, &h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
@@ -220,10 +227,31 @@ extern "C" int bwagpu_create_from_files(bwagpu_t **out, const char *prefix, int 
 	return bwagpu_create(out, &d, device);
 }
 
+// A second handle on the same device that shares the index already resident in HBM (no copy) but has its own stream and
+// batch arenas: two handles driven from two host threads keep two batches in flight, so the latency-bound tails of one
+// batch (chaining of repeat-rich reads) overlap with the throughput-bound kernels of the other.
+extern "C" int bwagpu_clone(bwagpu_t *src, bwagpu_t **out)
+{
+	if (!src || !out) return BWAGPU_EINVAL;
+	if (hipSetDevice(src->device) != hipSuccess) return BWAGPU_ENODEV;
+	bwagpu_t *h = new bwagpu_s();
+	h->device = src->device;
+	if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return BWAGPU_ENODEV; }
+	for (int i = 0; i < 8; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return BWAGPU_ENODEV; }
+	h->ibuf = src->ibuf; ++h->ibuf->refs;
+	h->ix = src->ix; h->l_pac = src->l_pac; h->n_seqs = src->n_seqs; h->seq_len = src->seq_len; h->sa_intv = src->sa_intv;
+	h->bwt_blocks = src->bwt_blocks; h->bwt_bytes = src->bwt_bytes; h->sa_bytes = src->sa_bytes; h->pac_bytes = src->pac_bytes;
+	h->bwt_size = src->bwt_size; h->n_sa = src->n_sa;
+	h->h_ctg_off = src->h_ctg_off; h->h_ctg_len = src->h_ctg_len; h->h_ctg_alt = src->h_ctg_alt;
+	h->stats_on = src->stats_on; h->taps_on = src->taps_on;
+	*out = h;
+	return BWAGPU_OK;
+}
+
 extern "C" int bwagpu_index_buffers(bwagpu_t *h, void **bwt, uint64_t *bwt_bytes, void **sa, uint64_t *sa_bytes, void **pac, uint64_t *pac_bytes)
 {
 	if (!h || !bwt || !bwt_bytes || !sa || !sa_bytes || !pac || !pac_bytes) return BWAGPU_EINVAL;
-	*bwt = h->d_bwt.p; *bwt_bytes = h->bwt_bytes; *sa = h->d_sa.p; *sa_bytes = h->sa_bytes; *pac = h->d_pac.p; *pac_bytes = h->pac_bytes;
+	*bwt = h->ibuf->d_bwt.p; *bwt_bytes = h->bwt_bytes; *sa = h->ibuf->d_sa.p; *sa_bytes = h->sa_bytes; *pac = h->ibuf->d_pac.p; *pac_bytes = h->pac_bytes;
 	return BWAGPU_OK;
 }
 
@@ -265,6 +293,7 @@ extern "C" int bwagpu_densify_sa(bwagpu_t *h, int new_intv)
 {
 	if (!h || new_intv <= 0 || (new_intv & (new_intv - 1)) || new_intv > h->sa_intv) return BWAGPU_EINVAL;
 	if (new_intv == h->sa_intv) return BWAGPU_OK;
+	if (h->ibuf->refs > 1) { h->err = "densify the SA before cloning the handle"; return BWAGPU_EINVAL; }
 	HIPCHK(h, hipSetDevice(h->device));
 	int sh = 0; while ((1 << sh) < new_intv) ++sh;
 	u64 n_out = (h->seq_len + new_intv) / new_intv;
@@ -273,9 +302,9 @@ extern "C" int bwagpu_densify_sa(bwagpu_t *h, int new_intv)
 	hipLaunchKernelGGL(k_densify, dim3(8192), dim3(256), 0, h->stream, h->ix, nb.as<u64>(), n_out, sh);
 	HIPCHK(h, hipGetLastError());
 	HIPCHK(h, hipStreamSynchronize(h->stream));
-	h->d_sa.release();
-	h->d_sa = nb;
-	h->ix.sa = h->d_sa.as<u64>(); h->ix.sa_mask = (u64)new_intv - 1; h->ix.sa_shift = sh; h->sa_intv = new_intv;
+	h->ibuf->d_sa.release();
+	h->ibuf->d_sa = nb;
+	h->ix.sa = h->ibuf->d_sa.as<u64>(); h->ix.sa_mask = (u64)new_intv - 1; h->ix.sa_shift = sh; h->sa_intv = new_intv;
 	h->n_sa = n_out; h->sa_bytes = n_out * 8;
 	return BWAGPU_OK;
 }

@@ -172,6 +172,10 @@ int bwagpu_index_export(const bwagpu_t *h, bwagpu_index_desc_t *scalars, int64_t
  * (replaces bwa_idx_load_from_disk(hint, BWA_IDX_ALL), bwa.c:289-321, for a stand-alone host). */
 int bwagpu_create_from_files(bwagpu_t **h, const char *prefix, int device);
 
+/* Another handle on the same GPU sharing the resident index (no copy), with its own stream and batch arenas.  Two handles
+ * driven from two host threads keep two batches in flight (the kt_pipeline of the reference overlaps I/O the same way,
+ * kthread.c:119).  Clone after bwagpu_densify_sa, not before.  Each handle is destroyed separately. */
+int bwagpu_clone(bwagpu_t *src, bwagpu_t **out);
 void bwagpu_destroy(bwagpu_t *h);
 const char *bwagpu_strerror(int code);
 const char *bwagpu_last_error(const bwagpu_t *h);

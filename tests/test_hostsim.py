@@ -84,3 +84,17 @@ def test_hostsim_edge_cases_and_arena_growth(sim):
     o2 = default_opt(); o2.max_occ = 2000
     assert_regs_equal(*orc.align(o2, seqs, off), *sim.align(o2, seqs, off), "arena growth")
     orc.close()
+
+
+def test_hostsim_cloned_handle_shares_index(sim):
+    """bwagpu_clone: a second handle on the same resident index gives the same results; both stay usable and are destroyed
+    independently (the mock runtime is single-threaded, so the two are driven one after the other here)."""
+    prefix, g = testdata.small_index()
+    seqs, off = testdata.flat(simdata.make_reads_se(g, 24, seed=91))
+    opt = default_opt()
+    a = sim.align(opt, seqs, off)
+    other = sim.clone()
+    b = other.align(opt, seqs, off)
+    assert_regs_equal(*a, *b, "clone")
+    other.close()
+    assert_regs_equal(*a, *sim.align(opt, seqs, off), "original after the clone is destroyed")
