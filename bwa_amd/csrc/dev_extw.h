@@ -45,16 +45,24 @@ DEVFN int wave_incl_scan_max(int v)
 // value of the lane below (lane 0 receives `fill`)
 DEVFN int wave_shift_up1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHR1, 0xf, 0xf, false); }
 DEVFN int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }   // pin a wave-uniform value into an SGPR
+DEVFN i64 uni64(i64 v)
+{
+	int lo = __builtin_amdgcn_readfirstlane((int)(u32)(u64)v), hi = __builtin_amdgcn_readfirstlane((int)(u32)((u64)v >> 32));
+	return (i64)((u64)(u32)hi << 32 | (u32)lo);
+}
+DEVFN bwagpu_seed_t uni_seed(bwagpu_seed_t s) { s.rbeg = uni64(s.rbeg); s.qbeg = uni(s.qbeg); s.len = uni(s.len); s.score = uni(s.score); return s; }
 
 struct WaveLds { int2 *eh; int8_t *qp; int qstride; };
 
-__device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, int mat_max, const u8 *q, int q0, int qdir, int qlen,
-								   i64 t0, int tdir, int tlen, int w, int end_bonus, int h0, const WaveLds &L, u64 &cells)
+__device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, int mat_max, const u8 *q, int q0, const int qdir, int qlen,
+								   i64 t0, const int tdir, int tlen, int w, int end_bonus, int h0, const WaveLds &L, u64 &cells)
 {
 	const int lane = threadIdx.x & 63;
 	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
 	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = opt.zdrop;
 	int2 *eh = L.eh; int8_t *qp = L.qp; const int qs = L.qstride;
+	// every argument is wave-uniform: keep it in SGPRs so that the row loop's control flow and address arithmetic are scalar
+	q0 = uni(q0); qlen = uni(qlen); tlen = uni(tlen); w = uni(w); h0 = uni(h0); end_bonus = uni(end_bonus); t0 = uni64(t0);
 	// query profile (ksw.c:425-428) and first row (ksw.c:430-433: H(-1,-1) = h0, then an insertion ramp)
 	for (int k = 0; k < 5; ++k)
 		for (int j = lane; j < qlen; j += 64) qp[k * qs + j] = opt.mat[k * 5 + q[q0 + j * qdir]];
@@ -141,27 +149,29 @@ __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const
 							  u64 &n_calls, u64 &n_cells, u64 &n_refb)
 {
 	const int lane = threadIdx.x & 63;
-	int n_ch = B.chain_n[r];
+	r = uni(r);
+	int n_ch = uni(B.chain_n[r]);
 	if (n_ch == 0) { if (lane == 0) B.reg_n_raw[r] = 0; return; }
-	const u8 *query = B.seq + B.off[r];
-	int l_query = (int)(B.off[r + 1] - B.off[r]);
-	i64 so = B.seed_off[r], l_pac = ix.l_pac;
-	const RegionView R = region_of(B.slot_blob, so, B.seed_n[r]);
+	const i64 qoff = uni64(B.off[r]);
+	const u8 *query = B.seq + qoff;
+	int l_query = uni((int)(B.off[r + 1] - qoff));
+	i64 so = uni64(B.seed_off[r]), l_pac = ix.l_pac;
+	const RegionView R = region_of(B.slot_blob, so, uni(B.seed_n[r]));
 	const bwagpu_chain_t *chains = R.cchain;
 	const bwagpu_seed_t *seeds_all = R.cseed;
 	u64 *srt_all = R.srt;
-	bwagpu_alnreg_t *av = B.regs + B.reg_off[r];
+	bwagpu_alnreg_t *av = B.regs + uni64(B.reg_off[r]);
 	int n_av = 0, sbeg = 0, mat_max = opt_mat_max(opt);
 	for (int ci = 0; ci < n_ch; ++ci) {
 		const bwagpu_chain_t c = chains[ci];
 		const bwagpu_seed_t *seeds = seeds_all + sbeg;
 		u64 *srt = srt_all + sbeg;
-		int n = c.n_seeds;
+		int n = uni(c.n_seeds);
 		sbeg += n;
 		if (n == 0) continue;
 		i64 rmax0 = l_pac << 1, rmax1 = 0;
 		for (int i = 0; i < n; ++i) {
-			bwagpu_seed_t t = seeds[i];
+			bwagpu_seed_t t = uni_seed(seeds[i]);
 			i64 b = t.rbeg - (t.qbeg + dev_max_gap(opt, t.qbeg));
 			i64 e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + dev_max_gap(opt, l_query - t.qbeg - t.len));
 			if (b < rmax0) rmax0 = b;
@@ -177,6 +187,7 @@ __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const
 			if (rmax0 < fb) rmax0 = fb;
 			if (rmax1 > fe) rmax1 = fe;
 		}
+		rmax0 = uni64(rmax0); rmax1 = uni64(rmax1);
 		n_refb += (u64)(rmax1 - rmax0);
 		if (lane == 0) {
 			for (int i = 0; i < n; ++i) srt[i] = (u64)seeds[i].score << 32 | (u32)i;
@@ -184,7 +195,7 @@ __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const
 		}
 		wave_sync();
 		for (int k = n - 1; k >= 0; --k) {
-			bwagpu_seed_t s = seeds[(u32)srt[k]];
+			bwagpu_seed_t s = uni_seed(seeds[(u32)srt[k]]);
 			// "is the seed already covered by an earlier alignment of this read?" (bwamem.c:697-713) is an existence query --
 			// the reference only uses whether its scan stopped early -- so 64 earlier regions are tested per step
 			bool covered = false;
