@@ -61,10 +61,10 @@ struct bwagpu_s {
 	bool have_batch = false, ran = false;
 	int stats_on = 0, taps_on = 1;
 	bwagpu_stats_t stats = {};
-	DevBuf d_seq, d_off, d_ctr, d_tmp_intv, d_tmp_mem, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
+	DevBuf d_seq, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
 	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_blob;
 	DevBuf d_order, d_bin_cnt, d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
-	i64 intv_cap = 0, slot_cap = 0, node_cap = 0, reg_cap = 0; int mem_cap = 0;
+	i64 slot_cap = 0, node_cap = 0, reg_cap = 0; int mem_cap = 0;
 	std::vector<i64> h_off;
 };
 
@@ -155,7 +155,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 		delete h->ibuf;
 	}
 	DevBuf *all[] = { &h->d_seq, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
-		&h->d_tmp_mem, &h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
+		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
 	for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -335,7 +335,6 @@ extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, cons
 	}
 	// first guess of the arena sizes (grown on overflow)
 	i64 nb = h->n_bases > 1024 ? h->n_bases : 1024;
-	h->intv_cap = nb / 6 + 4096;
 	h->slot_cap = nb / 4 + 4096;
 	h->node_cap = h->slot_cap / 4 + 2 * (i64)n + 64;
 	h->reg_cap = nb / 8 + 4096;
@@ -350,9 +349,8 @@ static int alloc_batch(bwagpu_t *h, int n_threads)
 	int bad = 0;
 	bad |= h->d_ctr.ensure(sizeof(Counters));
 	bad |= h->d_tmp_intv.ensure((size_t)n_threads * 2 * (h->max_len + 1) * sizeof(BiIntv));
-	bad |= h->d_tmp_mem.ensure((size_t)n_threads * h->mem_cap * sizeof(Intv3));
 	bad |= h->d_intv_n.ensure((size_t)n * 4 + 16); bad |= h->d_intv_off.ensure((size_t)n * 8 + 16);
-	bad |= h->d_intv.ensure((size_t)h->intv_cap * sizeof(Intv3));
+	bad |= h->d_intv.ensure(((size_t)n * h->mem_cap + 16) * sizeof(Intv3));
 	bad |= h->d_seed_n.ensure((size_t)n * 4 + 16); bad |= h->d_seed_off.ensure((size_t)n * 8 + 16);
 	bad |= h->d_slot_pos.ensure(sc * 8); bad |= h->d_slot_qbeg.ensure(sc * 4); bad |= h->d_slot_len.ensure(sc * 4); bad |= h->d_slot_rid.ensure(sc * 4); bad |= h->d_slot_blob.ensure(sc * SLOT_BLOB_BYTES);
 	bad |= h->d_chain_n.ensure((size_t)n * 4 + 16); bad |= h->d_node_off.ensure((size_t)n * 8 + 16);
@@ -393,7 +391,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 	if (h->n_reads == 0) { h->ran = true; return BWAGPU_OK; }
 	int n = h->n_reads;
 	// resident lanes: enough to fill the chip, bounded by the seeding scratch budget (2 interval stacks per lane)
-	size_t per_lane = (size_t)2 * (h->max_len + 1) * sizeof(BiIntv) + (size_t)h->mem_cap * sizeof(Intv3) + (size_t)2 * (h->max_len + 2) * 4;
+	size_t per_lane = (size_t)2 * (h->max_len + 1) * sizeof(BiIntv) + (size_t)2 * (h->max_len + 2) * 4;
 	size_t budget = (size_t)12 << 30;
 	i64 max_thr = (i64)(budget / per_lane);
 	if (max_thr > MAX_RESIDENT_THREADS) max_thr = MAX_RESIDENT_THREADS;
@@ -415,8 +413,8 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		Batch B; memset(&B, 0, sizeof B);
 		B.n_reads = n; B.max_len = h->max_len; B.stats = h->stats_on;
 		B.seq = h->d_seq.as<u8>(); B.off = h->d_off.as<i64>(); B.ctr = h->d_ctr.as<Counters>();
-		B.tmp_intv = h->d_tmp_intv.as<BiIntv>(); B.tmp_mem = h->d_tmp_mem.as<Intv3>(); B.mem_cap = h->mem_cap;
-		B.intv_n = h->d_intv_n.as<i32>(); B.intv_off = h->d_intv_off.as<i64>(); B.intv = h->d_intv.as<Intv3>(); B.intv_cap = h->intv_cap;
+		B.tmp_intv = h->d_tmp_intv.as<BiIntv>(); B.mem_cap = h->mem_cap;
+		B.intv_n = h->d_intv_n.as<i32>(); B.intv_off = h->d_intv_off.as<i64>(); B.intv = h->d_intv.as<Intv3>();
 		B.seed_n = h->d_seed_n.as<i32>(); B.seed_off = h->d_seed_off.as<i64>(); B.slot_cap = h->slot_cap;
 		B.slot_pos = h->d_slot_pos.as<u64>(); B.slot_qbeg = h->d_slot_qbeg.as<i32>(); B.slot_len = h->d_slot_len.as<i32>(); B.slot_rid = h->d_slot_rid.as<i32>(); B.slot_blob = h->d_slot_blob.as<u8>();
 		B.chain_n = h->d_chain_n.as<i32>(); B.node_off = h->d_node_off.as<i64>(); B.nodes = h->d_nodes.as<i32>(); B.node_cap = h->node_cap;
@@ -429,6 +427,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
 		HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
 		hipLaunchKernelGGL(k_seed, grid, block, 0, h->stream, h->ix, *opt, B);
+		hipLaunchKernelGGL(k_publish, grid, block, 0, h->stream, *opt, B);
 		hipLaunchKernelGGL(k_expand, grid, block, 0, h->stream, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
 		i64 sa_blocks = (h->slot_cap + BLOCK - 1) / BLOCK;
@@ -456,7 +455,6 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		HIPCHK(h, hipMemcpyAsync(&c, h->d_ctr.p, sizeof c, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(h, hipStreamSynchronize(h->stream));
 		if (c.overflow) {   // grow what overflowed and redo the batch; nothing of the failed attempt is kept
-			if (c.overflow & 1) h->intv_cap = h->intv_cap * 2;
 			if (c.overflow & 2) h->slot_cap = h->slot_cap * 2;
 			if (c.overflow & 6) h->node_cap = h->slot_cap / 4 + 2 * (i64)n + 64 > h->node_cap * 2 ? h->slot_cap / 4 + 2 * (i64)n + 64 : h->node_cap * 2;
 			if (c.overflow & 8) h->reg_cap = h->reg_cap * 2;
@@ -469,7 +467,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		h->stats.ms_seed = ms[0]; h->stats.ms_sa = ms[1]; h->stats.ms_chain = ms[2]; h->stats.ms_seedsw = ms[3]; h->stats.ms_extend = ms[4]; h->stats.ms_dedup = ms[5];
 		HIPCHK(h, hipEventElapsedTime(&h->stats.ms_total, h->ev[0], h->ev[6]));
 		h->stats.n_seeds = (i64)c.seed_used;
-		h->stats.n_intv = (i64)c.intv_used;
+		h->stats.n_intv = (i64)c.n_intv;
 		h->stats.n_chains = (i64)c.n_chains; h->stats.n_regs_raw = (i64)c.n_regs_raw; h->stats.n_regs = (i64)c.n_regs;
 		h->stats.n_occ_blocks = (i64)c.occ_blocks; h->stats.n_lf_steps = (i64)c.lf_steps;
 		h->stats.n_ext_calls = (i64)c.ext_calls; h->stats.n_ext_cells = (i64)c.ext_cells;
@@ -567,7 +565,7 @@ extern "C" int bwagpu_tap_intervals(bwagpu_t *h, int32_t *counts, bwagpu_intv_t 
 {
 	if (!h || !h->ran || !out || !n_out) return BWAGPU_EINVAL;
 	static_assert(sizeof(bwagpu_intv_t) == sizeof(Intv3), "layout");
-	return gather<bwagpu_intv_t>(h, h->d_intv_n, h->d_intv_off, h->d_intv, h->intv_cap, counts, out, n_out);
+	return gather<bwagpu_intv_t>(h, h->d_intv_n, h->d_intv_off, h->d_intv, (i64)h->n_reads * h->mem_cap, counts, out, n_out);
 }
 
 extern "C" int bwagpu_tap_chains(bwagpu_t *h, int32_t *counts, bwagpu_chain_t **chains, int64_t *n_chains, bwagpu_seed_t **seeds, int64_t *n_seeds)

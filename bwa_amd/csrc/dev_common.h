@@ -97,12 +97,11 @@ struct Batch {
 	Counters *ctr;
 	// --- seeding scratch: per resident thread, two interval stacks of (max_len+1) entries each + a MEM list
 	BiIntv *tmp_intv;          // [n_seed_threads][2*(max_len+1)]
-	Intv3 *tmp_mem;            // [n_seed_threads][mem_cap]
-	int mem_cap;
+	int mem_cap;               // capacity of one read's interval list
 	// --- seeding results
 	i32 *intv_n;               // per read
 	i64 *intv_off;             // per read, into intv[]
-	Intv3 *intv; i64 intv_cap;
+	Intv3 *intv;               // [n_reads][mem_cap]: read r's SA intervals at intv + r * mem_cap (intv_off[r] = r * mem_cap)
 	// --- slot space (one slot per SA lookup / seed)
 	i32 *seed_n;               // per read
 	i64 *seed_off;             // per read

@@ -149,31 +149,35 @@ DEVFN void smem_start(const DevIndex &ix, SeedLane &L, int x, u64 min_intv, int 
 	} else L.st = SS_FWD;
 }
 
-// publish one finished read: sort its intervals, copy them out, reserve slot space / B-tree nodes / seed slots
-__device__ void seed_publish(const bwagpu_opt_t &opt, const Batch &B, SeedLane &L)
+// After seeding: per read, sort the intervals (bwamem.c:187; equal keys are identical intervals, so tie order is immaterial),
+// count its SA lookups (mem_chain's inner loop bounds, bwamem.c:304-305) and reserve its slot range and B-tree nodes.  Kept out
+// of k_seed so that no lane of the seeding state machine ever waits for another lane's sort.
+__global__ void __launch_bounds__(256) k_publish(bwagpu_opt_t opt, Batch B)
 {
-	const int r = L.r;
-	if (L.em.overflow) { atomicOr(&B.ctr->overflow, 16ull); return; }
-	int n = L.em.n;
-	if (n == 0) return;
-	dev_introsort(L.em.mem, n, IntvInfoLess());   // equal keys are identical intervals: tie order is immaterial
-	u64 ioff = atomicAdd(&B.ctr->intv_used, (unsigned long long)n);
-	if (ioff + n > (u64)B.intv_cap) { atomicOr(&B.ctr->overflow, 1ull); return; }
-	i64 ns = 0;
-	for (int i = 0; i < n; ++i) {   // number of SA lookups per interval (mem_chain's inner loop bounds, bwamem.c:304-305)
-		Intv3 p = L.em.mem[i];
-		B.intv[ioff + i] = p;
-		u64 step = p.x2 > (u64)opt.max_occ ? p.x2 / opt.max_occ : 1;
-		u64 cnt = (p.x2 + step - 1) / step;
-		ns += (i64)(cnt < (u64)opt.max_occ ? cnt : (u64)opt.max_occ);
+	u64 nintv = 0;
+	for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < B.n_reads; r += gridDim.x * blockDim.x) {
+		const int n = B.intv_n[r];
+		B.intv_off[r] = (i64)r * B.mem_cap;
+		B.seed_n[r] = 0; B.seed_off[r] = 0; B.node_off[r] = 0;
+		if (n == 0) continue;
+		Intv3 *iv = B.intv + (size_t)r * B.mem_cap;
+		dev_introsort(iv, n, IntvInfoLess());
+		i64 ns = 0;
+		for (int i = 0; i < n; ++i) {
+			const u64 x2 = iv[i].x2;
+			u64 step = x2 > (u64)opt.max_occ ? x2 / opt.max_occ : 1;
+			u64 cnt = (x2 + step - 1) / step;
+			ns += (i64)(cnt < (u64)opt.max_occ ? cnt : (u64)opt.max_occ);
+		}
+		u64 soff = atomicAdd(&B.ctr->seed_used, (unsigned long long)ns);
+		u64 nnode = (u64)ns / 4 + 2;
+		u64 noff = atomicAdd(&B.ctr->node_used, (unsigned long long)nnode);
+		if (soff + ns > (u64)B.slot_cap) { atomicOr(&B.ctr->overflow, 2ull); B.intv_n[r] = 0; continue; }
+		if (noff + nnode > (u64)B.node_cap) { atomicOr(&B.ctr->overflow, 4ull); B.intv_n[r] = 0; continue; }
+		B.seed_n[r] = (i32)ns; B.seed_off[r] = (i64)soff; B.node_off[r] = (i64)noff;
+		nintv += (u64)n;
 	}
-	u64 soff = atomicAdd(&B.ctr->seed_used, (unsigned long long)ns);
-	u64 nnode = (u64)ns / 4 + 2;
-	u64 noff = atomicAdd(&B.ctr->node_used, (unsigned long long)nnode);
-	if (soff + ns > (u64)B.slot_cap) { atomicOr(&B.ctr->overflow, 2ull); return; }
-	if (noff + nnode > (u64)B.node_cap) { atomicOr(&B.ctr->overflow, 4ull); return; }
-	B.intv_n[r] = n; B.intv_off[r] = (i64)ioff;
-	B.seed_n[r] = (i32)ns; B.seed_off[r] = (i64)soff; B.node_off[r] = (i64)noff;
+	if (B.stats) atomicAdd(&B.ctr->n_intv, (unsigned long long)nintv);
 }
 
 __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, Batch B)
@@ -183,9 +187,9 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 	const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
 	SeedLane L;
 	L.s0 = B.tmp_intv + (size_t)tid * 2 * cap; L.s1 = L.s0 + cap;
-	L.em.mem = B.tmp_mem + (size_t)tid * B.mem_cap; L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len;
+	L.em.mem = B.intv; L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len;
 	L.st = SS_FETCH; L.r = -1; L.len = 0; L.q = B.seq;
-	u32 nblk = 0; u64 nintv = 0;
+	u32 nblk = 0;
 	while (L.st != SS_DONE) {
 		// ---- advance the lane's state up to its next extension -----------------------------------------------------
 		switch (L.st) {
@@ -193,7 +197,8 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			int r = (int)atomicAdd(&B.ctr->next_read, 1ull);
 			if (r >= B.n_reads) { L.st = SS_DONE; break; }
 			L.r = r; L.q = B.seq + B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
-			B.intv_n[r] = 0; B.intv_off[r] = 0; B.seed_n[r] = 0; B.seed_off[r] = 0; B.node_off[r] = 0;
+			B.intv_n[r] = 0;
+			L.em.mem = B.intv + (size_t)r * B.mem_cap;      // the read's own interval list (sorted and consumed by k_publish)
 			L.em.n = 0; L.em.overflow = false;
 			if (L.len < opt.min_seed_len) break;                  // mem_chain returns at once (bwamem.c:286); fetch the next read
 			L.x = 0; L.st = SS_PASS1;
@@ -222,8 +227,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			}
 			break;
 		case SS_FINAL:
-			seed_publish(opt, B, L);
-			nintv += B.intv_n[L.r];
+			if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull); else B.intv_n[L.r] = L.em.n;
 			L.st = SS_FETCH;
 			break;
 		default: break;
@@ -272,10 +276,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			}
 		}
 	}
-	if (B.stats) {
-		atomicAdd(&B.ctr->occ_blocks, (unsigned long long)nblk);
-		atomicAdd(&B.ctr->n_intv, (unsigned long long)nintv);
-	}
+	if (B.stats) atomicAdd(&B.ctr->occ_blocks, (unsigned long long)nblk);
 }
 
 // One lane per SA interval: expand it into its SA rows (mem_chain's k-loop, bwamem.c:304-305) in the read's slot range.
