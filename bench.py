@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=512.0)
     ap.add_argument("--cache", default=os.environ.get("BWA_AMD_CACHE", "/tmp/bwa_amd_bench"))
     ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU (handles sharing the index)")
-    ap.add_argument("--dense-sa", type=int, default=0, help="densify the SA on the device to this interval (0 = keep the reference's 32)")
+    ap.add_argument("--dense-sa", type=int, default=4, help="densify the SA on the device to this interval (0 = keep the reference's 32)")
     ap.add_argument("--cpu-sample", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
