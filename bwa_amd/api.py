@@ -43,7 +43,7 @@ EXPORTS = [
     "bwagpu_create", "bwagpu_create_from_files", "bwagpu_destroy", "bwagpu_strerror", "bwagpu_last_error", "bwagpu_version",
     "bwagpu_index_info", "bwagpu_densify_sa", "bwagpu_set_stats", "bwagpu_get_stats", "bwagpu_align_bseq", "bwagpu_align_flat",
     "bwagpu_free", "bwagpu_batch_upload", "bwagpu_batch_run", "bwagpu_batch_download", "bwagpu_set_taps", "bwagpu_tap_intervals",
-    "bwagpu_tap_chains", "bwagpu_tap_regs_raw", "bwagpu_index_buffers", "bwagpu_index_export", "bwagpu_clone",
+    "bwagpu_tap_chains", "bwagpu_tap_regs_raw", "bwagpu_index_buffers", "bwagpu_index_export", "bwagpu_clone", "bwagpu_index_ready",
 ]
 
 
@@ -83,6 +83,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.bwagpu_free.argtypes = [C.c_void_p]
     L.bwagpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
     L.bwagpu_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.bwagpu_index_ready.argtypes = [C.c_void_p]
     L.bwagpu_index_buffers.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     L.bwagpu_index_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
@@ -117,6 +118,9 @@ class BwaGpu:
         if rc != 0:
             raise BwaGpuError(f"bwagpu_create(empty) failed: {self.L.bwagpu_strerror(rc).decode()}")
         return self
+
+    def index_ready(self):
+        self._chk(self.L.bwagpu_index_ready(self.h))
 
     def clone(self):
         """A second handle sharing this one's resident index, with its own stream and arenas (for a second host thread)."""

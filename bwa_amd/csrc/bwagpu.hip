@@ -51,7 +51,7 @@ struct bwagpu_s {
 	std::string err;
 	// index
 	DevIndex ix = {};
-	struct IndexBufs { DevBuf d_bwt, d_sa, d_pac, d_ctg_off, d_ctg_len, d_ctg_alt; int refs = 1; };
+	struct IndexBufs { DevBuf d_bwt, d_sa, d_pac, d_ctg_off, d_ctg_len, d_ctg_alt, d_ptab; int refs = 1; };
 	IndexBufs *ibuf = nullptr;      // shared by bwagpu_clone()d handles
 	i64 l_pac = 0; int n_seqs = 0; u64 seq_len = 0; int sa_intv = 0;
 	u64 bwt_blocks = 0, bwt_bytes = 0, sa_bytes = 0, pac_bytes = 0, bwt_size = 0, n_sa = 0;
@@ -92,6 +92,43 @@ static int upload(bwagpu_t *h, DevBuf &b, const void *src, size_t bytes)
 {
 	if (b.ensure(bytes ? bytes : 16)) { h->err = "hipMalloc failed"; return BWAGPU_ENOMEM; }
 	if (bytes) HIPCHK(h, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+	return 0;
+}
+
+// ---- prefix tables (DevIndex::ptab): level j from level j-1 with the sweep's own extension ----------------------------------
+__global__ void __launch_bounds__(256) k_ptab_level(DevIndex ix, u64 *tab, int j)
+{
+	const u64 n = (u64)1 << (2 * j);
+	for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (u64)gridDim.x * blockDim.x) {
+		BiIntv out;
+		if (j == 1) fm_init(ix, (int)c, out);                          // bwt_set_intv (bwt.h:82)
+		else {
+			const u64 *pe = tab + ((((u64)1 << (2 * (j - 1))) - 4) / 3 + (c >> 2)) * 3;
+			BiIntv par; par.x0 = pe[0]; par.x1 = pe[1]; par.x2 = pe[2]; par.info = 0;
+			// forward extension by base c&3 (bwt.c:307-308).  Empty parents are extended too, by the same arithmetic:
+			// bwt_seed_strategy1 keeps extending an interval that has become empty until min_seed_len is reached (bwt.c:364-377)
+			fm_extend1(ix, par, 3 - (int)(c & 3), 0, out);
+		}
+		u64 *e = tab + ((n - 4) / 3 + c) * 3;
+		e[0] = out.x0; e[1] = out.x1; e[2] = out.x2;
+	}
+}
+
+static int build_prefix_tables(bwagpu_t *h, int m)
+{
+	if (m < 2) { h->ix.ptab = nullptr; h->ix.ptab_m = 0; return 0; }
+	if (m > PTAB_MAX) m = PTAB_MAX;
+	size_t entries = ((((size_t)1 << (2 * (m + 1))) - 4) / 3);
+	if (h->ibuf->d_ptab.ensure(entries * 24)) { h->err = "hipMalloc failed (prefix tables)"; return BWAGPU_ENOMEM; }
+	DevIndex ix = h->ix; ix.ptab = nullptr; ix.ptab_m = 0;
+	for (int j = 1; j <= m; ++j) {
+		u64 n = (u64)1 << (2 * j);
+		unsigned nb = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+		hipLaunchKernelGGL(k_ptab_level, dim3(nb), dim3(256), 0, h->stream, ix, h->ibuf->d_ptab.as<u64>(), j);
+	}
+	HIPCHK(h, hipGetLastError());
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	h->ix.ptab = h->ibuf->d_ptab.as<u64>(); h->ix.ptab_m = m;
 	return 0;
 }
 
@@ -139,6 +176,11 @@ extern "C" int bwagpu_create(bwagpu_t **out, const bwagpu_index_desc_t *d, int d
 	h->h_ctg_off.assign(d->ctg_offset, d->ctg_offset + d->n_seqs);
 	h->h_ctg_len.assign(d->ctg_len, d->ctg_len + d->n_seqs);
 	h->h_ctg_alt.assign(d->ctg_is_alt, d->ctg_is_alt + d->n_seqs);
+	h->ix.ptab = nullptr; h->ix.ptab_m = 0;
+	if (!alloc_only) {   // (a handle that receives its index by broadcast builds them in bwagpu_index_ready)
+		int m = getenv("BWAGPU_PTAB_M") ? atoi(getenv("BWAGPU_PTAB_M")) : 10;
+		if ((rc = build_prefix_tables(h, m))) goto fail;
+	}
 	*out = h;
 	return BWAGPU_OK;
 fail:
@@ -150,7 +192,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 {
 	if (!h) return;
 	if (h->ibuf && --h->ibuf->refs == 0) {
-		DevBuf *ib[] = { &h->ibuf->d_bwt, &h->ibuf->d_sa, &h->ibuf->d_pac, &h->ibuf->d_ctg_off, &h->ibuf->d_ctg_len, &h->ibuf->d_ctg_alt };
+		DevBuf *ib[] = { &h->ibuf->d_bwt, &h->ibuf->d_sa, &h->ibuf->d_pac, &h->ibuf->d_ctg_off, &h->ibuf->d_ctg_len, &h->ibuf->d_ctg_alt, &h->ibuf->d_ptab };
 		for (DevBuf *b : ib) b->release();
 		delete h->ibuf;
 	}
@@ -253,6 +295,15 @@ extern "C" int bwagpu_index_buffers(bwagpu_t *h, void **bwt, uint64_t *bwt_bytes
 	if (!h || !bwt || !bwt_bytes || !sa || !sa_bytes || !pac || !pac_bytes) return BWAGPU_EINVAL;
 	*bwt = h->ibuf->d_bwt.p; *bwt_bytes = h->bwt_bytes; *sa = h->ibuf->d_sa.p; *sa_bytes = h->sa_bytes; *pac = h->ibuf->d_pac.p; *pac_bytes = h->pac_bytes;
 	return BWAGPU_OK;
+}
+
+// call on a handle created with NULL arrays once its buffers have been filled by the broadcast
+extern "C" int bwagpu_index_ready(bwagpu_t *h)
+{
+	if (!h) return BWAGPU_EINVAL;
+	HIPCHK(h, hipSetDevice(h->device));
+	int m = getenv("BWAGPU_PTAB_M") ? atoi(getenv("BWAGPU_PTAB_M")) : 10;
+	return build_prefix_tables(h, m);
 }
 
 extern "C" int bwagpu_index_export(const bwagpu_t *h, bwagpu_index_desc_t *d, int64_t *ctg_offset, int32_t *ctg_len, int32_t *ctg_is_alt)

@@ -33,6 +33,9 @@ struct DevIndex {
 	const i64 *ctg_off;
 	const i32 *ctg_len;
 	const i32 *ctg_alt;
+	// prefix tables: bi-interval of every j-mer, j = 1..ptab_m, level j at entry offset (4^j - 4) / 3, three u64 per entry
+	const u64 *ptab;
+	int ptab_m;
 };
 
 // SA interval kept by the seeding stage: {x0, x2, info}; the reverse-strand start x[1] of bwtintv_t (bwt.h:62)

@@ -137,14 +137,45 @@ DEVFN void fwd_finish(SeedLane &L, int cap)
 	bwd_begin_row(L);
 }
 
+// Bi-interval of the j-mer with 2-bit code `code` (first base most significant) from the prefix tables.  The tables are
+// filled at start-up by the same fm_extend1 the sweep uses (k_ptab_level), so the values are those the reference's
+// step-by-step extension would produce; they replace the first ptab_m steps of a forward sweep -- dependent pairs of index
+// block reads -- by independent 24-byte loads.
+DEVFN void ptab_load(const DevIndex &ix, int j, u32 code, BiIntv &out)
+{
+	const u64 *e = ix.ptab + ((((u64)1 << (2 * j)) - 4) / 3 + code) * 3;
+	out.x0 = e[0]; out.x1 = e[1]; out.x2 = e[2];
+}
+
+#define PTAB_MAX 12
+
 DEVFN void smem_start(const DevIndex &ix, SeedLane &L, int x, u64 min_intv, int pass, int cap)
 {
 	L.pass = pass; L.sx = x; L.min_intv = min_intv < 1 ? 1 : min_intv;
 	if (L.q[x] > 3) { L.ret = x + 1; smem_finish(L); return; }   // bwt.c:296
 	fm_init(ix, L.q[x], L.ik); L.ik.info = (u64)(x + 1);
 	L.i = x + 1; L.n0 = 0;
-	if (L.i >= L.len || L.q[L.i] > 3) {                          // nothing to extend: push and go backward
-		L.s0[cap - 1] = L.ik; L.n0 = 1; L.ret = (int)L.ik.info;
+	// number of leading bases the tables can cover: q[x .. x+w) all A/C/G/T and inside the read
+	int w = 1;
+	while (w < ix.ptab_m && x + w < L.len && L.q[x + w] < 4) ++w;
+	if (w >= 2) {   // the first w-1 forward steps of bwt_smem1a (bwt.c:304-320) from table look-ups
+		BiIntv t[PTAB_MAX];
+		u32 code = L.q[x];
+		for (int j = 2; j <= w; ++j) { code = code << 2 | L.q[x + j - 1]; ptab_load(ix, j, code, t[j - 1]); }   // independent loads
+		bool stop = false;
+		for (int j = 2; j <= w; ++j) {
+			const BiIntv &ok = t[j - 1];
+			if (ok.x2 != L.ik.x2) {
+				L.s0[cap - 1 - L.n0] = L.ik; ++L.n0; L.ret = (int)L.ik.info;
+				if (ok.x2 < L.min_intv) { stop = true; break; }
+			}
+			L.ik.x0 = ok.x0; L.ik.x1 = ok.x1; L.ik.x2 = ok.x2; L.ik.info = (u64)(x + j);
+		}
+		if (stop) { fwd_finish(L, cap); return; }
+		L.i = x + w;
+	}
+	if (L.i >= L.len || L.q[L.i] > 3) {                          // nothing (more) to extend: push and go backward
+		L.s0[cap - 1 - L.n0] = L.ik; ++L.n0; L.ret = (int)L.ik.info;
 		fwd_finish(L, cap);
 	} else L.st = SS_FWD;
 }
@@ -221,6 +252,17 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			else if (L.q[L.x] > 3) ++L.x;
 			else {
 				fm_init(ix, L.q[L.x], L.ik); L.sx = L.x; L.i = L.x + 1;
+				// bwt_seed_strategy1 can only stop after min_seed_len steps (bwt.c:368), so its first steps need no test at
+				// all: jump to the longest table-covered prefix (kept shorter than min_seed_len)
+				int w = 1;
+				const int wmax = ix.ptab_m < opt.min_seed_len ? ix.ptab_m : opt.min_seed_len;
+				while (w < wmax && L.x + w < L.len && L.q[L.x + w] < 4) ++w;
+				if (w >= 2) {
+					u32 code = 0;
+					for (int j = 0; j < w; ++j) code = code << 2 | L.q[L.x + j];
+					ptab_load(ix, w, code, L.ik);
+					L.i = L.x + w;
+				}
 				if (L.i >= L.len) { L.x = L.len; }
 				else if (L.q[L.i] > 3) { L.x = L.i + 1; }
 				else L.st = SS_STRAT;

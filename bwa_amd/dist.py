@@ -53,6 +53,8 @@ def broadcast_index(prefix: str, device: int = 0, src: int = 0, lib_path: str | 
             dist.broadcast(t[o:o + chunk], src=src)
     if on_gpu:
         torch.cuda.synchronize()
+    if rank != src:
+        gpu.index_ready()      # derive the prefix tables from the received index
     return gpu
 
 

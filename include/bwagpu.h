@@ -167,6 +167,8 @@ int bwagpu_create(bwagpu_t **h, const bwagpu_index_desc_t *idx, int device);
  * table of a loaded handle so that they can be sent to the other ranks. */
 int bwagpu_index_buffers(bwagpu_t *h, void **bwt, uint64_t *bwt_bytes, void **sa, uint64_t *sa_bytes, void **pac, uint64_t *pac_bytes);
 int bwagpu_index_export(const bwagpu_t *h, bwagpu_index_desc_t *scalars, int64_t *ctg_offset, int32_t *ctg_len, int32_t *ctg_is_alt);
+/* After the broadcast has filled a receiving handle's buffers: derive the device-side acceleration tables from them. */
+int bwagpu_index_ready(bwagpu_t *h);
 
 /* Same, reading <prefix>.bwt/.sa/.pac/.ann/.amb/.alt from disk in the reference's on-disk formats
  * (replaces bwa_idx_load_from_disk(hint, BWA_IDX_ALL), bwa.c:289-321, for a stand-alone host). */

@@ -180,6 +180,7 @@ def test_index_broadcast_over_rccl_single_rank(small):
         for (dp, dn), (sp, sn) in zip(e.index_buffers(), g2.index_buffers()):
             bdist._as_tensor(dp, dn, True).copy_(bdist._as_tensor(sp, sn, True))
         torch.cuda.synchronize()
+        e.index_ready()
         seqs, off = testdata.flat(simdata.make_reads_se(g, 3000, seed=81))
         want = gpu.align(default_opt(), seqs, off)
         assert_regs_equal(*want, *g2.align(default_opt(), seqs, off), "broadcast handle")
