@@ -107,6 +107,7 @@ struct SeedLane {
 	int sx, i, n0, nprev, nc, j, c, ret, last_start;
 	bool any;
 	BiIntv ik, p;
+	u32 code;                 // 2-bit code of q[sx..i) while it is short enough for the prefix tables
 	BiIntv *s0, *s1, *prev, *curr;
 	SeedEmit em;
 };
@@ -139,8 +140,8 @@ DEVFN void fwd_finish(SeedLane &L, int cap)
 
 // Bi-interval of the j-mer with 2-bit code `code` (first base most significant) from the prefix tables.  The tables are
 // filled at start-up by the same fm_extend1 the sweep uses (k_ptab_level), so the values are those the reference's
-// step-by-step extension would produce; they replace the first ptab_m steps of a forward sweep -- dependent pairs of index
-// block reads -- by independent 24-byte loads.
+// step-by-step extension would produce; for the first ptab_m steps of a forward search one 24-byte entry replaces the two
+// 64-byte index blocks of an extension.
 DEVFN void ptab_load(const DevIndex &ix, int j, u32 code, BiIntv &out)
 {
 	const u64 *e = ix.ptab + ((((u64)1 << (2 * j)) - 4) / 3 + code) * 3;
@@ -155,27 +156,9 @@ DEVFN void smem_start(const DevIndex &ix, SeedLane &L, int x, u64 min_intv, int 
 	if (L.q[x] > 3) { L.ret = x + 1; smem_finish(L); return; }   // bwt.c:296
 	fm_init(ix, L.q[x], L.ik); L.ik.info = (u64)(x + 1);
 	L.i = x + 1; L.n0 = 0;
-	// number of leading bases the tables can cover: q[x .. x+w) all A/C/G/T and inside the read
-	int w = 1;
-	while (w < ix.ptab_m && x + w < L.len && L.q[x + w] < 4) ++w;
-	if (w >= 2) {   // the first w-1 forward steps of bwt_smem1a (bwt.c:304-320) from table look-ups
-		BiIntv t[PTAB_MAX];
-		u32 code = L.q[x];
-		for (int j = 2; j <= w; ++j) { code = code << 2 | L.q[x + j - 1]; ptab_load(ix, j, code, t[j - 1]); }   // independent loads
-		bool stop = false;
-		for (int j = 2; j <= w; ++j) {
-			const BiIntv &ok = t[j - 1];
-			if (ok.x2 != L.ik.x2) {
-				L.s0[cap - 1 - L.n0] = L.ik; ++L.n0; L.ret = (int)L.ik.info;
-				if (ok.x2 < L.min_intv) { stop = true; break; }
-			}
-			L.ik.x0 = ok.x0; L.ik.x1 = ok.x1; L.ik.x2 = ok.x2; L.ik.info = (u64)(x + j);
-		}
-		if (stop) { fwd_finish(L, cap); return; }
-		L.i = x + w;
-	}
+	L.code = L.q[x];
 	if (L.i >= L.len || L.q[L.i] > 3) {                          // nothing (more) to extend: push and go backward
-		L.s0[cap - 1 - L.n0] = L.ik; ++L.n0; L.ret = (int)L.ik.info;
+		L.s0[cap - 1] = L.ik; L.n0 = 1; L.ret = (int)L.ik.info;
 		fwd_finish(L, cap);
 	} else L.st = SS_FWD;
 }
@@ -252,17 +235,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			else if (L.q[L.x] > 3) ++L.x;
 			else {
 				fm_init(ix, L.q[L.x], L.ik); L.sx = L.x; L.i = L.x + 1;
-				// bwt_seed_strategy1 can only stop after min_seed_len steps (bwt.c:368), so its first steps need no test at
-				// all: jump to the longest table-covered prefix (kept shorter than min_seed_len)
-				int w = 1;
-				const int wmax = ix.ptab_m < opt.min_seed_len ? ix.ptab_m : opt.min_seed_len;
-				while (w < wmax && L.x + w < L.len && L.q[L.x + w] < 4) ++w;
-				if (w >= 2) {
-					u32 code = 0;
-					for (int j = 0; j < w; ++j) code = code << 2 | L.q[L.x + j];
-					ptab_load(ix, w, code, L.ik);
-					L.i = L.x + w;
-				}
+				L.code = L.q[L.x];
 				if (L.i >= L.len) { L.x = L.len; }
 				else if (L.q[L.i] > 3) { L.x = L.i + 1; }
 				else L.st = SS_STRAT;
@@ -282,7 +255,10 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			if (back) L.p = L.prev[L.j];
 			src.x0 = back ? L.p.x0 : L.ik.x0; src.x1 = back ? L.p.x1 : L.ik.x1; src.x2 = back ? L.p.x2 : L.ik.x2; src.info = 0;
 			const int cb = back ? L.c : 3 - (int)L.q[L.i];
-			nblk += fm_extend1(ix, src, cb, back, ok);       // the only extension site of the kernel
+			if (!back && L.i - L.sx < ix.ptab_m) {            // the first steps of a forward search: one 24-byte table entry
+				L.code = L.code << 2 | L.q[L.i];              // instead of two index blocks (same values, see k_ptab_level)
+				ptab_load(ix, L.i - L.sx + 1, L.code, ok);
+			} else nblk += fm_extend1(ix, src, cb, back, ok);   // the only extension site of the kernel
 			if (st == SS_FWD) {           // forward sweep of bwt_smem1a (bwt.c:304-320)
 				bool stop = false;
 				if (ok.x2 != L.ik.x2) {
