@@ -214,7 +214,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": roof_k, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "alg_bytes_per_launch": alg[roof_k], "kernel_ms": round(dur[roof_k], 3),
-                         "blocks_64B_per_s": round(alg[roof_k] / 64.0 / (dur[roof_k] * 1e-3), 0)},
+                         "blocks_64B_per_s": round(alg[roof_k] / 64.0 / (dur[roof_k] * 1e-3), 0),
+                         "random_64B_ceiling": {"GB/s": 1670.0, "blocks_per_s": 26.0e9, "frac": round(achieved / 1670.0, 4),
+                                                "source": "tools/randbw.hip on MI355X, profiles/r01_randbw_microbench.md: random 64-byte reads from HBM saturate at 26e9/s"}},
             "stage_ms_solo": {k: round(v, 3) for k, v in stage_ms.items()},
             "work_per_read": {"N_blk": round(work["n_occ_blocks"] / work["n_reads"], 1), "N_lf": round(work["n_lf_steps"] / work["n_reads"], 1),
                               "N_sa": round(work["n_seeds"] / work["n_reads"], 2), "ext_cells": round(work["n_ext_cells"] / work["n_reads"], 0),
