@@ -389,7 +389,9 @@ extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, cons
 	h->slot_cap = nb / 4 + 4096;
 	h->node_cap = h->slot_cap / 4 + 2 * (i64)n + 64;
 	h->reg_cap = nb / 8 + 4096;
-	h->mem_cap = h->max_len < 64 ? 64 : h->max_len;
+	// capacity of one read's interval list: reads keep ~10-30 intervals whatever their length class; grown x4 on overflow
+	h->mem_cap = h->max_len / 3 < 64 ? 64 : h->max_len / 3;
+	if (getenv("BWAGPU_MEM_CAP")) h->mem_cap = atoi(getenv("BWAGPU_MEM_CAP"));   // test hook: force the overflow/retry path
 	h->have_batch = true;
 	return BWAGPU_OK;
 }

@@ -98,3 +98,17 @@ def test_hostsim_cloned_handle_shares_index(sim):
     assert_regs_equal(*a, *b, "clone")
     other.close()
     assert_regs_equal(*a, *sim.align(opt, seqs, off), "original after the clone is destroyed")
+
+
+def test_hostsim_interval_list_overflow_retries(monkeypatch):
+    """A deliberately tiny per-read interval capacity: the seeding kernel flags the overflow and the batch is re-run with a
+    larger capacity; results are unchanged."""
+    import hostsim_build
+    prefix, g = testdata.small_index()
+    monkeypatch.setenv("BWAGPU_MEM_CAP", "3")
+    s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+    seqs, off = testdata.flat(simdata.make_reads_se(g, 24, seed=92))
+    orc = orcapi.OrcIndex(prefix)
+    assert_regs_equal(*orc.align(default_opt(), seqs, off), *s2.align(default_opt(), seqs, off), "interval overflow")
+    assert s2.stats()["n_retries"] >= 1
+    s2.close(); orc.close()
