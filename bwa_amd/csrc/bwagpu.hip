@@ -401,7 +401,7 @@ static int alloc_batch(bwagpu_t *h, int n_threads)
 	int n = h->n_reads; size_t sc = (size_t)h->slot_cap + 8;   // +8: chunked readers may touch a few slots past the last read's range
 	int bad = 0;
 	bad |= h->d_ctr.ensure(sizeof(Counters));
-	bad |= h->d_tmp_intv.ensure((size_t)n_threads * 2 * (h->max_len + 1) * sizeof(BiIntv));
+	bad |= h->d_tmp_intv.ensure((size_t)n_threads * (h->max_len + 1) * sizeof(BiIntv));
 	bad |= h->d_intv_n.ensure((size_t)n * 4 + 16); bad |= h->d_intv_off.ensure((size_t)n * 8 + 16);
 	bad |= h->d_intv.ensure(((size_t)n * h->mem_cap + 16) * sizeof(Intv3));
 	bad |= h->d_seed_n.ensure((size_t)n * 4 + 16); bad |= h->d_seed_off.ensure((size_t)n * 8 + 16);
@@ -444,7 +444,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 	if (h->n_reads == 0) { h->ran = true; return BWAGPU_OK; }
 	int n = h->n_reads;
 	// resident lanes: enough to fill the chip, bounded by the seeding scratch budget (2 interval stacks per lane)
-	size_t per_lane = (size_t)2 * (h->max_len + 1) * sizeof(BiIntv) + (size_t)2 * (h->max_len + 2) * 4;
+	size_t per_lane = (size_t)(h->max_len + 1) * sizeof(BiIntv) + (size_t)2 * (h->max_len + 2) * 4;
 	size_t budget = (size_t)12 << 30;
 	i64 max_thr = (i64)(budget / per_lane);
 	if (max_thr > MAX_RESIDENT_THREADS) max_thr = MAX_RESIDENT_THREADS;
@@ -467,6 +467,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.n_reads = n; B.max_len = h->max_len; B.stats = h->stats_on;
 		B.seq = h->d_seq.as<u8>(); B.off = h->d_off.as<i64>(); B.ctr = h->d_ctr.as<Counters>();
 		B.tmp_intv = h->d_tmp_intv.as<BiIntv>(); B.mem_cap = h->mem_cap;
+		B.seed_lds_ok = (h->seq_len < ((u64)1 << 37) && h->max_len < 65536) ? 1 : 0;
 		B.intv_n = h->d_intv_n.as<i32>(); B.intv_off = h->d_intv_off.as<i64>(); B.intv = h->d_intv.as<Intv3>();
 		B.seed_n = h->d_seed_n.as<i32>(); B.seed_off = h->d_seed_off.as<i64>(); B.slot_cap = h->slot_cap;
 		B.slot_pos = h->d_slot_pos.as<u64>(); B.slot_qbeg = h->d_slot_qbeg.as<i32>(); B.slot_len = h->d_slot_len.as<i32>(); B.slot_rid = h->d_slot_rid.as<i32>(); B.slot_blob = h->d_slot_blob.as<u8>();
@@ -479,7 +480,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>();
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
 		HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-		hipLaunchKernelGGL(k_seed, grid, block, 0, h->stream, h->ix, *opt, B);
+		hipLaunchKernelGGL(k_seed, grid, block, (size_t)SEED_LDS_ENT * BLOCK * sizeof(uint4), h->stream, h->ix, *opt, B);   // 60 KiB: 2 blocks per CU
 		hipLaunchKernelGGL(k_publish, grid, block, 0, h->stream, *opt, B);
 		hipLaunchKernelGGL(k_expand, grid, block, 0, h->stream, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[1], h->stream));

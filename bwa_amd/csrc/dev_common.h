@@ -98,8 +98,9 @@ struct Batch {
 	const u8 *seq;             // concatenated nt4 codes
 	const i64 *off;            // n_reads + 1
 	Counters *ctr;
-	// --- seeding scratch: per resident thread, two interval stacks of (max_len+1) entries each + a MEM list
-	BiIntv *tmp_intv;          // [n_seed_threads][2*(max_len+1)]
+	// --- seeding scratch: per resident lane one interval stack (first entries in LDS, see SeedStack)
+	BiIntv *tmp_intv;          // [n_seed_threads][max_len+1]: spill area of the lanes' interval stacks
+	int seed_lds_ok;           // intervals and read lengths fit the packed LDS entries (seq_len < 2^37, max_len < 2^16)
 	int mem_cap;               // capacity of one read's interval list
 	// --- seeding results
 	i32 *intv_n;               // per read

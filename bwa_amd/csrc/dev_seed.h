@@ -108,14 +108,45 @@ struct SeedLane {
 	bool any;
 	BiIntv ik, p;
 	u32 code;                 // 2-bit code of q[sx..i) while it is short enough for the prefix tables
-	BiIntv *s0, *s1, *prev, *curr;
+	int top;                  // index of the longest match in the interval stack (prev[j] = stack[top - j])
 	SeedEmit em;
+};
+
+// The interval stack of one lane (bwt_smem1a's curr/prev vectors, bwt.c:292-300).  One array suffices: the backward sweep
+// reads prev[j] for increasing j and appends at most one survivor per entry read, so survivors are written in place over the
+// consumed part.  Its first SEED_LDS_ENT entries live in LDS, packed to 16 bytes ({x0,x1,x2} < 2^37, end < 2^16), laid out
+// [entry][lane] so that a wave's accesses are conflict-free; deeper entries (rare: typical depth is 7-17) spill to HBM scratch.
+// Keeping the stack out of HBM matters because the kernel runs at the chip's random-request ceiling (profiles/r01_randbw_*):
+// the ~800 stack reads/writes per read were 40 % of its memory requests.
+#define SEED_LDS_ENT 15
+struct SeedStack {
+	uint4 *lds;       // this lane's column of the block's LDS array (stride blockDim.x entries); null = LDS unusable for this batch
+	BiIntv *glob;     // spill area, indexed by entry
+	int stride;
+	DEVFN void store(int e, const BiIntv &v) const {
+		if (lds && e < SEED_LDS_ENT) {
+			uint4 w;
+			w.x = (u32)v.x0; w.y = (u32)v.x1; w.z = (u32)v.x2;
+			w.w = (u32)(v.x0 >> 32) | (u32)(v.x1 >> 32) << 5 | (u32)(v.x2 >> 32) << 10 | (u32)v.info << 16;
+			lds[e * stride] = w;
+		} else glob[e] = v;
+	}
+	DEVFN BiIntv load(int e) const {
+		if (lds && e < SEED_LDS_ENT) {
+			uint4 w = lds[e * stride];
+			BiIntv v;
+			v.x0 = (u64)(w.w & 31) << 32 | w.x; v.x1 = (u64)(w.w >> 5 & 31) << 32 | w.y; v.x2 = (u64)(w.w >> 10 & 31) << 32 | w.z;
+			v.info = w.w >> 16;
+			return v;
+		}
+		return glob[e];
+	}
 };
 
 DEVFN void smem_finish(SeedLane &L) { if (L.pass == 1) { L.x = L.ret; L.st = SS_PASS1; } else L.st = SS_PASS2; }
 
 // start backward row i (bwt.c:326-345); rows without a usable base (i < 0 or N) need no extension at all
-DEVFN void bwd_begin_row(SeedLane &L)
+DEVFN void bwd_begin_row(SeedLane &L, const SeedStack &S)
 {
 	for (;;) {
 		if (L.i < -1) { smem_finish(L); return; }
@@ -123,19 +154,19 @@ DEVFN void bwd_begin_row(SeedLane &L)
 		L.j = 0; L.nc = 0; L.last_x2 = 0;
 		if (L.c >= 0) { L.st = SS_BWD; return; }
 		// every interval stops here; only the longest one (first in prev[]) can be a new MEM
-		BiIntv p = L.prev[0];
+		BiIntv p = S.load(L.top);
 		if (!L.any || L.i + 1 < L.last_start) { L.em.add(p.x0, p.x2, L.i + 1, (int)p.info); L.any = true; L.last_start = L.i + 1; }
 		smem_finish(L);
 		return;
 	}
 }
 
-DEVFN void fwd_finish(SeedLane &L, int cap)
-{	// forward sweep done: the change points sit top-down in s0, longest match first
-	L.prev = L.s0 + (cap - L.n0); L.nprev = L.n0; L.curr = L.s1;
+DEVFN void fwd_finish(SeedLane &L, const SeedStack &S)
+{	// forward sweep done: stack[0 .. n0) holds the change points, longest match on top
+	L.top = L.n0 - 1; L.nprev = L.n0;
 	L.any = false; L.last_start = 0;
 	L.i = L.sx - 1;
-	bwd_begin_row(L);
+	bwd_begin_row(L, S);
 }
 
 // Bi-interval of the j-mer with 2-bit code `code` (first base most significant) from the prefix tables.  The tables are
@@ -150,7 +181,7 @@ DEVFN void ptab_load(const DevIndex &ix, int j, u32 code, BiIntv &out)
 
 #define PTAB_MAX 12
 
-DEVFN void smem_start(const DevIndex &ix, SeedLane &L, int x, u64 min_intv, int pass, int cap)
+DEVFN void smem_start(const DevIndex &ix, SeedLane &L, const SeedStack &S, int x, u64 min_intv, int pass)
 {
 	L.pass = pass; L.sx = x; L.min_intv = min_intv < 1 ? 1 : min_intv;
 	if (L.q[x] > 3) { L.ret = x + 1; smem_finish(L); return; }   // bwt.c:296
@@ -158,8 +189,8 @@ DEVFN void smem_start(const DevIndex &ix, SeedLane &L, int x, u64 min_intv, int 
 	L.i = x + 1; L.n0 = 0;
 	L.code = L.q[x];
 	if (L.i >= L.len || L.q[L.i] > 3) {                          // nothing (more) to extend: push and go backward
-		L.s0[cap - 1] = L.ik; L.n0 = 1; L.ret = (int)L.ik.info;
-		fwd_finish(L, cap);
+		S.store(0, L.ik); L.n0 = 1; L.ret = (int)L.ik.info;
+		fwd_finish(L, S);
 	} else L.st = SS_FWD;
 }
 
@@ -196,11 +227,14 @@ __global__ void __launch_bounds__(256) k_publish(bwagpu_opt_t opt, Batch B)
 
 __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
+	HIP_DYNAMIC_SHARED(uint4, seed_lds)
 	const int tid = blockIdx.x * blockDim.x + threadIdx.x;
 	const int cap = B.max_len + 1;
 	const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
 	SeedLane L;
-	L.s0 = B.tmp_intv + (size_t)tid * 2 * cap; L.s1 = L.s0 + cap;
+	SeedStack S;
+	S.lds = B.seed_lds_ok ? seed_lds + threadIdx.x : nullptr; S.stride = blockDim.x;
+	S.glob = B.tmp_intv + (size_t)tid * cap;
 	L.em.mem = B.intv; L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len;
 	L.st = SS_FETCH; L.r = -1; L.len = 0; L.q = B.seq;
 	u32 nblk = 0;
@@ -220,14 +254,14 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 		case SS_PASS1:   // pass 1: all SMEMs, left to right (bwamem.c:147-157)
 			if (L.x >= L.len) { L.old_n = L.em.n; L.k2 = 0; L.st = SS_PASS2; }
 			else if (L.q[L.x] > 3) ++L.x;
-			else smem_start(ix, L, L.x, 1, 1, cap);
+			else smem_start(ix, L, S, L.x, 1, 1);
 			break;
 		case SS_PASS2:   // pass 2: re-seed from the middle of long, rare SMEMs (bwamem.c:160-168)
 			if (L.k2 >= L.old_n) { L.x = 0; L.st = opt.max_mem_intv > 0 ? SS_PASS3 : SS_FINAL; }
 			else {
 				Intv3 p = L.em.mem[L.k2++];
 				int start = (int)(p.info >> 32), end = (int)(u32)p.info;
-				if (end - start >= split_len && p.x2 <= (u64)opt.split_width) smem_start(ix, L, (start + end) >> 1, p.x2 + 1, 2, cap);
+				if (end - start >= split_len && p.x2 <= (u64)opt.split_width) smem_start(ix, L, S, (start + end) >> 1, p.x2 + 1, 2);
 			}
 			break;
 		case SS_PASS3:   // pass 3: LAST-like seeds (bwamem.c:170-185, bwt_seed_strategy1 bwt.c:358-379)
@@ -252,7 +286,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 		if (st == SS_FWD || st == SS_BWD || st == SS_STRAT) {
 			BiIntv ok, src;
 			const int back = st == SS_BWD;
-			if (back) L.p = L.prev[L.j];
+			if (back) L.p = S.load(L.top - L.j);
 			src.x0 = back ? L.p.x0 : L.ik.x0; src.x1 = back ? L.p.x1 : L.ik.x1; src.x2 = back ? L.p.x2 : L.ik.x2; src.info = 0;
 			const int cb = back ? L.c : 3 - (int)L.q[L.i];
 			if (!back && L.i - L.sx < ix.ptab_m) {            // the first steps of a forward search: one 24-byte table entry
@@ -262,25 +296,25 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			if (st == SS_FWD) {           // forward sweep of bwt_smem1a (bwt.c:304-320)
 				bool stop = false;
 				if (ok.x2 != L.ik.x2) {
-					L.s0[cap - 1 - L.n0] = L.ik; ++L.n0; L.ret = (int)L.ik.info;
+					S.store(L.n0, L.ik); ++L.n0; L.ret = (int)L.ik.info;
 					if (ok.x2 < L.min_intv) stop = true;
 				}
 				if (!stop) {
 					ok.info = (u64)(L.i + 1); L.ik = ok; ++L.i;
-					if (L.i >= L.len || L.q[L.i] > 3) { L.s0[cap - 1 - L.n0] = L.ik; ++L.n0; L.ret = (int)L.ik.info; stop = true; }
+					if (L.i >= L.len || L.q[L.i] > 3) { S.store(L.n0, L.ik); ++L.n0; L.ret = (int)L.ik.info; stop = true; }
 				}
-				if (stop) fwd_finish(L, cap);
+				if (stop) fwd_finish(L, S);
 			} else if (st == SS_BWD) {    // one interval of one backward row (bwt.c:328-342)
 				if (ok.x2 < L.min_intv) {
 					if (L.nc == 0 && (!L.any || L.i + 1 < L.last_start)) {
 						L.em.add(L.p.x0, L.p.x2, L.i + 1, (int)L.p.info); L.any = true; L.last_start = L.i + 1;
 					}
 				} else if (L.nc == 0 || ok.x2 != L.last_x2) {
-					ok.info = L.p.info; L.curr[L.nc++] = ok; L.last_x2 = ok.x2;
+					ok.info = L.p.info; S.store(L.top - L.nc, ok); ++L.nc; L.last_x2 = ok.x2;   // in place: nc <= j
 				}
 				if (++L.j == L.nprev) {
 					if (L.nc == 0) smem_finish(L);
-					else { L.prev = L.curr; L.nprev = L.nc; L.curr = (L.curr == L.s1) ? L.s0 : L.s1; --L.i; bwd_begin_row(L); }
+					else { L.nprev = L.nc; --L.i; bwd_begin_row(L, S); }
 				}
 			} else {                      // bwt_seed_strategy1 (bwt.c:364-377)
 				if (ok.x2 < opt.max_mem_intv && L.i - L.sx >= opt.min_seed_len) {
