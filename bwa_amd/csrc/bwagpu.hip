@@ -363,7 +363,8 @@ extern "C" int bwagpu_densify_sa(bwagpu_t *h, int new_intv)
 // ---- batches -------------------------------------------------------------------------------------------------
 static const int BLOCK = 256;
 static const int MAX_RESIDENT_THREADS = 256 * 2048;   // 256 CUs x 32 waves x 64 lanes
-static const int WAVE_EXT_MAX_LEN = 1100;               // 4 waves x (8+5) B/column must fit the 64 KiB dynamic-LDS limit
+static const int WAVE_EXT_MAX_LEN = 1100;
+static const int SEED_LDS_ENT = 10;                     // 10 x 16 B x 256 lanes = 40 KiB of LDS per block -> 4 blocks (16 waves) per CU; measured best of {4,7,10,15}               // 4 waves x (8+5) B/column must fit the 64 KiB dynamic-LDS limit
 
 extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, const int64_t *off)
 {
@@ -467,7 +468,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.n_reads = n; B.max_len = h->max_len; B.stats = h->stats_on;
 		B.seq = h->d_seq.as<u8>(); B.off = h->d_off.as<i64>(); B.ctr = h->d_ctr.as<Counters>();
 		B.tmp_intv = h->d_tmp_intv.as<BiIntv>(); B.mem_cap = h->mem_cap;
-		B.seed_lds_ok = (h->seq_len < ((u64)1 << 37) && h->max_len < 65536) ? 1 : 0;
+		B.seed_lds_ent = (h->seq_len < ((u64)1 << 37) && h->max_len < 65536) ? (getenv("BWAGPU_SEED_LDS_ENT") ? atoi(getenv("BWAGPU_SEED_LDS_ENT")) : SEED_LDS_ENT) : 0;
 		B.intv_n = h->d_intv_n.as<i32>(); B.intv_off = h->d_intv_off.as<i64>(); B.intv = h->d_intv.as<Intv3>();
 		B.seed_n = h->d_seed_n.as<i32>(); B.seed_off = h->d_seed_off.as<i64>(); B.slot_cap = h->slot_cap;
 		B.slot_pos = h->d_slot_pos.as<u64>(); B.slot_qbeg = h->d_slot_qbeg.as<i32>(); B.slot_len = h->d_slot_len.as<i32>(); B.slot_rid = h->d_slot_rid.as<i32>(); B.slot_blob = h->d_slot_blob.as<u8>();
@@ -480,7 +481,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>();
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
 		HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-		hipLaunchKernelGGL(k_seed, grid, block, (size_t)SEED_LDS_ENT * BLOCK * sizeof(uint4), h->stream, h->ix, *opt, B);   // 60 KiB: 2 blocks per CU
+		hipLaunchKernelGGL(k_seed, grid, block, (size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * BLOCK * sizeof(uint4), h->stream, h->ix, *opt, B);
 		hipLaunchKernelGGL(k_publish, grid, block, 0, h->stream, *opt, B);
 		hipLaunchKernelGGL(k_expand, grid, block, 0, h->stream, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[1], h->stream));

@@ -100,7 +100,7 @@ struct Batch {
 	Counters *ctr;
 	// --- seeding scratch: per resident lane one interval stack (first entries in LDS, see SeedStack)
 	BiIntv *tmp_intv;          // [n_seed_threads][max_len+1]: spill area of the lanes' interval stacks
-	int seed_lds_ok;           // intervals and read lengths fit the packed LDS entries (seq_len < 2^37, max_len < 2^16)
+	int seed_lds_ent;          // stack entries per lane kept in LDS (0 when seq_len >= 2^37 or max_len >= 2^16: the packing would not fit)
 	int mem_cap;               // capacity of one read's interval list
 	// --- seeding results
 	i32 *intv_n;               // per read

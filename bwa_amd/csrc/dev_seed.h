@@ -114,17 +114,16 @@ struct SeedLane {
 
 // The interval stack of one lane (bwt_smem1a's curr/prev vectors, bwt.c:292-300).  One array suffices: the backward sweep
 // reads prev[j] for increasing j and appends at most one survivor per entry read, so survivors are written in place over the
-// consumed part.  Its first SEED_LDS_ENT entries live in LDS, packed to 16 bytes ({x0,x1,x2} < 2^37, end < 2^16), laid out
+// consumed part.  Its first Batch::seed_lds_ent entries live in LDS, packed to 16 bytes ({x0,x1,x2} < 2^37, end < 2^16), laid out
 // [entry][lane] so that a wave's accesses are conflict-free; deeper entries (rare: typical depth is 7-17) spill to HBM scratch.
 // Keeping the stack out of HBM matters because the kernel runs at the chip's random-request ceiling (profiles/r01_randbw_*):
 // the ~800 stack reads/writes per read were 40 % of its memory requests.
-#define SEED_LDS_ENT 15
 struct SeedStack {
 	uint4 *lds;       // this lane's column of the block's LDS array (stride blockDim.x entries); null = LDS unusable for this batch
 	BiIntv *glob;     // spill area, indexed by entry
-	int stride;
+	int stride, n_lds;
 	DEVFN void store(int e, const BiIntv &v) const {
-		if (lds && e < SEED_LDS_ENT) {
+		if (e < n_lds) {
 			uint4 w;
 			w.x = (u32)v.x0; w.y = (u32)v.x1; w.z = (u32)v.x2;
 			w.w = (u32)(v.x0 >> 32) | (u32)(v.x1 >> 32) << 5 | (u32)(v.x2 >> 32) << 10 | (u32)v.info << 16;
@@ -132,7 +131,7 @@ struct SeedStack {
 		} else glob[e] = v;
 	}
 	DEVFN BiIntv load(int e) const {
-		if (lds && e < SEED_LDS_ENT) {
+		if (e < n_lds) {
 			uint4 w = lds[e * stride];
 			BiIntv v;
 			v.x0 = (u64)(w.w & 31) << 32 | w.x; v.x1 = (u64)(w.w >> 5 & 31) << 32 | w.y; v.x2 = (u64)(w.w >> 10 & 31) << 32 | w.z;
@@ -233,7 +232,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 	const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
 	SeedLane L;
 	SeedStack S;
-	S.lds = B.seed_lds_ok ? seed_lds + threadIdx.x : nullptr; S.stride = blockDim.x;
+	S.lds = seed_lds + threadIdx.x; S.stride = blockDim.x; S.n_lds = B.seed_lds_ent;
 	S.glob = B.tmp_intv + (size_t)tid * cap;
 	L.em.mem = B.intv; L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len;
 	L.st = SS_FETCH; L.r = -1; L.len = 0; L.q = B.seq;
