@@ -157,7 +157,7 @@ def main():
     gpu.set_stats(False)
     gpu.run(opt)
     solo = gpu.stats()
-    stage_keys = ("ms_seed", "ms_sa", "ms_chain", "ms_seedsw", "ms_extend", "ms_dedup", "ms_total")
+    stage_keys = ("ms_seed", "ms_publish", "ms_sa", "ms_chain", "ms_seedsw", "ms_extend", "ms_dedup", "ms_total")
     stage_ms = {k: solo[k] for k in stage_keys}
 
     def worker(hdl, n_pass):

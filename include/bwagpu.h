@@ -150,7 +150,7 @@ typedef struct {
 	/* device time per stage, milliseconds (HIP events on the library's stream) */
 	float ms_seed, ms_sa, ms_chain, ms_seedsw, ms_extend, ms_dedup, ms_total;
 	int32_t n_retries;       /* arena-growth reruns */
-	int32_t reserved_;
+	float ms_publish;        /* k_publish + k_expand (interval sort, slot reservation); ms_seed is the k_seed kernel alone */
 } bwagpu_stats_t;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Fold rocprofv3 --pmc counter_collection CSVs (one pass per counter) into profiles/pmc_latest.json.
+
+usage: pmc_summary.py <note> <fetch_dir> <write_dir> [out.json]
+Per kernel: the launch with the largest FETCH_SIZE (the instrumented solo pass and the timed step run the same
+batch; warm-up-free runs have one or two launches per kernel).  bytes = (FETCH_SIZE + WRITE_SIZE) KiB * 1024.
+"""
+import csv, glob, json, os, sys
+
+
+def load(d, name):
+    out = {}
+    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != name:
+                continue
+            k = r["Kernel_Name"].split("(")[0]
+            out.setdefault(k, []).append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    note, fd, wd = sys.argv[1:4]
+    dst = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(__file__), "..", "profiles", "pmc_latest.json")
+    F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
+    res = {"_note": note}
+    for k in sorted(F, key=lambda k: -max(F[k])):
+        if not k.startswith("k_"):
+            continue
+        f, w = max(F[k]), max(W.get(k, [0.0]))
+        res[k] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "launches_seen": len(F[k]),
+                  "hbm_bytes_per_launch": (f + w) * 1024.0}
+    json.dump(res, open(dst, "w"), indent=1)
+    for k, v in res.items():
+        if k != "_note":
+            print(f"{k:20s} fetch {v['FETCH_SIZE_KB']*1024/1e9:8.2f} GB  write {v['WRITE_SIZE_KB']*1024/1e9:8.2f} GB  x{v['launches_seen']}")
+
+
+if __name__ == "__main__":
+    main()
