@@ -108,37 +108,55 @@ struct SeedLane {
 	bool any;
 	BiIntv ik, p;
 	u32 code;                 // 2-bit code of q[sx..i) while it is short enough for the prefix tables
-	int top;                  // index of the longest match in the interval stack (prev[j] = stack[top - j])
+	int top;                  // index of the longest match in the interval stack (prev[j] = the entry j below the top)
+	int slot;                 // forward sweep: ring position of the next push; backward sweep: ring position of the top entry
 	SeedEmit em;
 };
 
 // The interval stack of one lane (bwt_smem1a's curr/prev vectors, bwt.c:292-300).  One array suffices: the backward sweep
 // reads prev[j] for increasing j and appends at most one survivor per entry read, so survivors are written in place over the
-// consumed part.  Its first Batch::seed_lds_ent entries live in LDS, packed to 16 bytes ({x0,x1,x2} < 2^37, end < 2^16), laid out
-// [entry][lane] so that a wave's accesses are conflict-free; deeper entries (rare: typical depth is 7-17) spill to HBM scratch.
-// Keeping the stack out of HBM matters because the kernel runs at the chip's random-request ceiling (profiles/r01_randbw_*):
-// the ~800 stack reads/writes per read were 40 % of its memory requests.
+// consumed part.  The Batch::seed_lds_ent entries nearest the top (the longest matches: the ones every backward row touches,
+// and after a dozen rows the only ones left) live in LDS, packed to 16 bytes ({x0,x1,x2} < 2^37, end < 2^16) and laid out
+// [slot][lane] so that a wave's accesses are conflict-free.  The forward sweep fills the LDS slots as a ring and evicts the
+// oldest (shortest) entry to HBM scratch when it wraps; the backward sweep addresses entries by their depth below the top.
+// Keeping the stack out of HBM matters because the kernel runs at the chip's random-request ceiling (profiles/r01_randbw_*).
 struct SeedStack {
-	uint4 *lds;       // this lane's column of the block's LDS array (stride blockDim.x entries); null = LDS unusable for this batch
-	BiIntv *glob;     // spill area, indexed by entry
-	int stride, n_lds;
-	DEVFN void store(int e, const BiIntv &v) const {
-		if (e < n_lds) {
-			uint4 w;
-			w.x = (u32)v.x0; w.y = (u32)v.x1; w.z = (u32)v.x2;
-			w.w = (u32)(v.x0 >> 32) | (u32)(v.x1 >> 32) << 5 | (u32)(v.x2 >> 32) << 10 | (u32)v.info << 16;
-			lds[e * stride] = w;
-		} else glob[e] = v;
+	uint4 *lds;       // this lane's column of the block's LDS array (stride blockDim.x entries)
+	BiIntv *glob;     // spill area, indexed by entry; holds packed uint4 records when n_lds > 0
+	int stride, n_lds;   // n_lds == 0: intervals not packable for this batch, everything in glob (unpacked)
+	static DEVFN uint4 pack(const BiIntv &v) {
+		uint4 w;
+		w.x = (u32)v.x0; w.y = (u32)v.x1; w.z = (u32)v.x2;
+		w.w = (u32)(v.x0 >> 32) | (u32)(v.x1 >> 32) << 5 | (u32)(v.x2 >> 32) << 10 | (u32)v.info << 16;
+		return w;
 	}
-	DEVFN BiIntv load(int e) const {
-		if (e < n_lds) {
-			uint4 w = lds[e * stride];
-			BiIntv v;
-			v.x0 = (u64)(w.w & 31) << 32 | w.x; v.x1 = (u64)(w.w >> 5 & 31) << 32 | w.y; v.x2 = (u64)(w.w >> 10 & 31) << 32 | w.z;
-			v.info = w.w >> 16;
-			return v;
+	static DEVFN BiIntv unpack(const uint4 &w) {
+		BiIntv v;
+		v.x0 = (u64)(w.w & 31) << 32 | w.x; v.x1 = (u64)(w.w >> 5 & 31) << 32 | w.y; v.x2 = (u64)(w.w >> 10 & 31) << 32 | w.z;
+		v.info = w.w >> 16;
+		return v;
+	}
+	// forward sweep: append entry number L.n0; L.slot is the ring position it goes to
+	DEVFN void push(SeedLane &L, const BiIntv &v) const {
+		if (n_lds == 0) glob[L.n0] = v;
+		else {
+			if (L.n0 >= n_lds) ((uint4*)glob)[L.n0 - n_lds] = lds[L.slot * stride];   // the ring is full: evict the oldest entry
+			lds[L.slot * stride] = pack(v);
+			L.slot = L.slot + 1 == n_lds ? 0 : L.slot + 1;
 		}
-		return glob[e];
+		++L.n0;
+	}
+	// backward sweep: the entry `d` below the top (L.top = index of the top entry, L.slot = its ring position)
+	DEVFN int ring(const SeedLane &L, int d) const { int s = L.slot - d; return s < 0 ? s + n_lds : s; }
+	DEVFN void store(const SeedLane &L, int d, const BiIntv &v) const {
+		if (d < n_lds) lds[ring(L, d) * stride] = pack(v);
+		else if (n_lds) ((uint4*)glob)[L.top - d] = pack(v);
+		else glob[L.top - d] = v;
+	}
+	DEVFN BiIntv load(const SeedLane &L, int d) const {
+		if (d < n_lds) return unpack(lds[ring(L, d) * stride]);
+		if (n_lds) return unpack(((const uint4*)glob)[L.top - d]);
+		return glob[L.top - d];
 	}
 };
 
@@ -153,7 +171,7 @@ DEVFN void bwd_begin_row(SeedLane &L, const SeedStack &S)
 		L.j = 0; L.nc = 0; L.last_x2 = 0;
 		if (L.c >= 0) { L.st = SS_BWD; return; }
 		// every interval stops here; only the longest one (first in prev[]) can be a new MEM
-		BiIntv p = S.load(L.top);
+		BiIntv p = S.load(L, 0);
 		if (!L.any || L.i + 1 < L.last_start) { L.em.add(p.x0, p.x2, L.i + 1, (int)p.info); L.any = true; L.last_start = L.i + 1; }
 		smem_finish(L);
 		return;
@@ -163,6 +181,7 @@ DEVFN void bwd_begin_row(SeedLane &L, const SeedStack &S)
 DEVFN void fwd_finish(SeedLane &L, const SeedStack &S)
 {	// forward sweep done: stack[0 .. n0) holds the change points, longest match on top
 	L.top = L.n0 - 1; L.nprev = L.n0;
+	L.slot = (L.slot == 0 ? S.n_lds : L.slot) - 1;
 	L.any = false; L.last_start = 0;
 	L.i = L.sx - 1;
 	bwd_begin_row(L, S);
@@ -185,10 +204,10 @@ DEVFN void smem_start(const DevIndex &ix, SeedLane &L, const SeedStack &S, int x
 	L.pass = pass; L.sx = x; L.min_intv = min_intv < 1 ? 1 : min_intv;
 	if (L.q[x] > 3) { L.ret = x + 1; smem_finish(L); return; }   // bwt.c:296
 	fm_init(ix, L.q[x], L.ik); L.ik.info = (u64)(x + 1);
-	L.i = x + 1; L.n0 = 0;
+	L.i = x + 1; L.n0 = 0; L.slot = 0;
 	L.code = L.q[x];
 	if (L.i >= L.len || L.q[L.i] > 3) {                          // nothing (more) to extend: push and go backward
-		S.store(0, L.ik); L.n0 = 1; L.ret = (int)L.ik.info;
+		S.push(L, L.ik); L.ret = (int)L.ik.info;
 		fwd_finish(L, S);
 	} else L.st = SS_FWD;
 }
@@ -285,7 +304,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 		if (st == SS_FWD || st == SS_BWD || st == SS_STRAT) {
 			BiIntv ok, src;
 			const int back = st == SS_BWD;
-			if (back) L.p = S.load(L.top - L.j);
+			if (back) L.p = S.load(L, L.j);
 			src.x0 = back ? L.p.x0 : L.ik.x0; src.x1 = back ? L.p.x1 : L.ik.x1; src.x2 = back ? L.p.x2 : L.ik.x2; src.info = 0;
 			const int cb = back ? L.c : 3 - (int)L.q[L.i];
 			if (!back && L.i - L.sx < ix.ptab_m) {            // the first steps of a forward search: one 24-byte table entry
@@ -295,12 +314,12 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			if (st == SS_FWD) {           // forward sweep of bwt_smem1a (bwt.c:304-320)
 				bool stop = false;
 				if (ok.x2 != L.ik.x2) {
-					S.store(L.n0, L.ik); ++L.n0; L.ret = (int)L.ik.info;
+					S.push(L, L.ik); L.ret = (int)L.ik.info;
 					if (ok.x2 < L.min_intv) stop = true;
 				}
 				if (!stop) {
 					ok.info = (u64)(L.i + 1); L.ik = ok; ++L.i;
-					if (L.i >= L.len || L.q[L.i] > 3) { S.store(L.n0, L.ik); ++L.n0; L.ret = (int)L.ik.info; stop = true; }
+					if (L.i >= L.len || L.q[L.i] > 3) { S.push(L, L.ik); L.ret = (int)L.ik.info; stop = true; }
 				}
 				if (stop) fwd_finish(L, S);
 			} else if (st == SS_BWD) {    // one interval of one backward row (bwt.c:328-342)
@@ -309,7 +328,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 						L.em.add(L.p.x0, L.p.x2, L.i + 1, (int)L.p.info); L.any = true; L.last_start = L.i + 1;
 					}
 				} else if (L.nc == 0 || ok.x2 != L.last_x2) {
-					ok.info = L.p.info; S.store(L.top - L.nc, ok); ++L.nc; L.last_x2 = ok.x2;   // in place: nc <= j
+					ok.info = L.p.info; S.store(L, L.nc, ok); ++L.nc; L.last_x2 = ok.x2;   // in place: nc <= j
 				}
 				if (++L.j == L.nprev) {
 					if (L.nc == 0) smem_finish(L);

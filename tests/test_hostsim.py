@@ -112,3 +112,16 @@ def test_hostsim_interval_list_overflow_retries(monkeypatch):
     assert_regs_equal(*orc.align(default_opt(), seqs, off), *s2.align(default_opt(), seqs, off), "interval overflow")
     assert s2.stats()["n_retries"] >= 1
     s2.close(); orc.close()
+
+
+@pytest.mark.parametrize("ent", ["1", "3"])
+def test_hostsim_lds_stack_ring_eviction(monkeypatch, ent):
+    """A tiny LDS interval stack: the forward sweep's ring wraps and evicts to the HBM spill area, and the backward sweep
+    reads deep entries back from it; the seeds (and everything downstream) are unchanged."""
+    prefix, g = testdata.small_index()
+    monkeypatch.setenv("BWAGPU_SEED_LDS_ENT", ent)
+    s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+    seqs, off = testdata.flat(simdata.make_reads_se(g, 24, seed=93))
+    orc = orcapi.OrcIndex(prefix)
+    assert_regs_equal(*orc.align(default_opt(), seqs, off), *s2.align(default_opt(), seqs, off), f"LDS stack of {ent}")
+    s2.close(); orc.close()
