@@ -61,7 +61,7 @@ struct bwagpu_s {
 	bool have_batch = false, ran = false;
 	int stats_on = 0, taps_on = 1;
 	bwagpu_stats_t stats = {};
-	DevBuf d_seq, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
+	DevBuf d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
 	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_blob;
 	DevBuf d_order, d_bin_cnt, d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
 	i64 slot_cap = 0, node_cap = 0, reg_cap = 0; int mem_cap = 0;
@@ -196,7 +196,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 		for (DevBuf *b : ib) b->release();
 		delete h->ibuf;
 	}
-	DevBuf *all[] = { &h->d_seq, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
+	DevBuf *all[] = { &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
@@ -379,10 +379,15 @@ extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, cons
 		if (l > h->max_len) h->max_len = (int)l;
 	}
 	h->h_off.assign(off, off + n + 1);
-	if (h->d_seq.ensure((size_t)h->n_bases + 16) || h->d_off.ensure((size_t)(n + 1) * 8)) { h->err = "hipMalloc failed (reads)"; return BWAGPU_ENOMEM; }
+	const u64 n_words = ((u64)h->n_bases + 15) / 16;
+	if (h->d_seq.ensure((size_t)h->n_bases + 16) || h->d_seq_nib.ensure((size_t)(n_words + 1) * 8) || h->d_off.ensure((size_t)(n + 1) * 8)) { h->err = "hipMalloc failed (reads)"; return BWAGPU_ENOMEM; }
 	if (n) {
 		HIPCHK(h, hipMemcpyAsync(h->d_seq.p, seqs, (size_t)h->n_bases, hipMemcpyHostToDevice, h->stream));
 		HIPCHK(h, hipMemcpyAsync(h->d_off.p, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, h->stream));
+		Batch P = {}; P.seq = h->d_seq.as<u8>(); P.seq_nib = h->d_seq_nib.as<u64>();
+		u64 pb = (n_words + BLOCK - 1) / BLOCK;
+		hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)(pb < 65536 ? pb : 65536)), dim3(BLOCK), 0, h->stream, P, n_words);
+		HIPCHK(h, hipGetLastError());
 		HIPCHK(h, hipStreamSynchronize(h->stream));
 	}
 	// first guess of the arena sizes (grown on overflow)
@@ -466,7 +471,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
 		Batch B; memset(&B, 0, sizeof B);
 		B.n_reads = n; B.max_len = h->max_len; B.stats = h->stats_on;
-		B.seq = h->d_seq.as<u8>(); B.off = h->d_off.as<i64>(); B.ctr = h->d_ctr.as<Counters>();
+		B.seq = h->d_seq.as<u8>(); B.seq_nib = h->d_seq_nib.as<u64>(); B.off = h->d_off.as<i64>(); B.ctr = h->d_ctr.as<Counters>();
 		B.tmp_intv = h->d_tmp_intv.as<BiIntv>(); B.mem_cap = h->mem_cap;
 		B.seed_lds_ent = (h->seq_len < ((u64)1 << 37) && h->max_len < 65536) ? (getenv("BWAGPU_SEED_LDS_ENT") ? atoi(getenv("BWAGPU_SEED_LDS_ENT")) : SEED_LDS_ENT) : 0;
 		B.intv_n = h->d_intv_n.as<i32>(); B.intv_off = h->d_intv_off.as<i64>(); B.intv = h->d_intv.as<Intv3>();

@@ -42,48 +42,6 @@ DEVFN void block_occ4(const OccBlock &b, int o, u64 cnt[4])
 	cnt[3] = ((u64)b.c23.w << 32 | b.c23.z) + c3;
 }
 
-// bwt_2occ4 (bwt.c:189-218): ranks at k and l (k <= l as used by bwt_extend).  Returns the number of distinct
-// 64-byte blocks touched (the N_blk unit of SURVEY.md 8d).
-DEVFN int occ4_pair(const DevIndex &ix, u64 k, u64 l, u64 ck[4], u64 cl[4])
-{
-	const u64 NEG1 = ~0ull;
-	int nblk = 0;
-	u64 kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
-	if (k == NEG1) { ck[0] = ck[1] = ck[2] = ck[3] = 0; }
-	if (l == NEG1) { cl[0] = cl[1] = cl[2] = cl[3] = 0; }
-	if (k != NEG1 && l != NEG1 && (kk >> 7) == (ll >> 7)) {
-		OccBlock b = load_block(ix, kk >> 7);
-		block_occ4(b, (int)(kk & 127), ck);
-		block_occ4(b, (int)(ll & 127), cl);
-		return 1;
-	}
-	if (k != NEG1) { OccBlock b = load_block(ix, kk >> 7); block_occ4(b, (int)(kk & 127), ck); ++nblk; }
-	if (l != NEG1) { OccBlock b = load_block(ix, ll >> 7); block_occ4(b, (int)(ll & 127), cl); ++nblk; }
-	return nblk;
-}
-
-// bwt_extend (bwt.c:262-275).  is_back = 1 prepends a base to the match (the FM-index's native direction),
-// is_back = 0 appends the complement on the other strand.  ok[c] for all four c.
-DEVFN int fm_extend(const DevIndex &ix, const BiIntv &ik, BiIntv ok[4], int is_back)
-{
-	u64 tk[4], tl[4];
-	u64 a = is_back ? ik.x0 : ik.x1, other = is_back ? ik.x1 : ik.x0;
-	int nblk = occ4_pair(ix, a - 1, a - 1 + ik.x2, tk, tl);
-	u64 s3 = tl[3] - tk[3], s2 = tl[2] - tk[2], s1 = tl[1] - tk[1], s0 = tl[0] - tk[0];
-	u64 o3 = other + (a <= ix.primary && a + ik.x2 - 1 >= ix.primary);
-	u64 o2 = o3 + s3, o1 = o2 + s2, o0 = o1 + s1;
-	u64 n0 = ix.L2[0] + 1 + tk[0], n1 = ix.L2[1] + 1 + tk[1], n2 = ix.L2[2] + 1 + tk[2], n3 = ix.L2[3] + 1 + tk[3];
-	ok[0].x2 = s0; ok[1].x2 = s1; ok[2].x2 = s2; ok[3].x2 = s3;
-	if (is_back) {
-		ok[0].x0 = n0; ok[1].x0 = n1; ok[2].x0 = n2; ok[3].x0 = n3;
-		ok[0].x1 = o0; ok[1].x1 = o1; ok[2].x1 = o2; ok[3].x1 = o3;
-	} else {
-		ok[0].x1 = n0; ok[1].x1 = n1; ok[2].x1 = n2; ok[3].x1 = n3;
-		ok[0].x0 = o0; ok[1].x0 = o1; ok[2].x0 = o2; ok[3].x0 = o3;
-	}
-	return nblk;
-}
-
 // symbols 1,2,3 among the top n bases of a 32-base pair, branch-free (n may be <= 0 or >= 32)
 DEVFN void count_pair_bf(u32 whi, u32 wlo, int n, u32 &c1, u32 &c2, u32 &c3)
 {

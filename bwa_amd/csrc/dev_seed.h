@@ -19,72 +19,6 @@ struct SeedEmit {        // the MEM list of the read being seeded (lane-private 
 	}
 };
 
-// bwt_smem1a with max_intv = 0 (bwt.c:289-351).  s0/s1: two lane-private stacks of `cap` entries.
-// Forward sweep: remember the interval each time its size is about to change (stored top-down in s0 so that the
-// longest match comes first without a reversal).  Backward sweep: extend every surviving interval by q[i];
-// an interval that can no longer be extended is a MEM iff nothing longer survived this step and it is not
-// contained in the previously emitted MEM.
-__device__ int dev_smem1(const DevIndex &ix, const u8 *q, int len, int x, u64 min_intv, BiIntv *s0, BiIntv *s1, int cap,
-						 SeedEmit &em, u32 &nblk)
-{
-	if (q[x] > 3) return x + 1;
-	if (min_intv < 1) min_intv = 1;
-	BiIntv ik; fm_init(ix, q[x], ik); ik.info = (u64)(x + 1);
-	int n0 = 0, i;
-	for (i = x + 1; i < len; ++i) {
-		int b = q[i];
-		if (b < 4) {
-			BiIntv ok; nblk += fm_extend1(ix, ik, 3 - b, 0, ok);
-			if (ok.x2 != ik.x2) {
-				s0[cap - 1 - n0] = ik; ++n0;
-				if (ok.x2 < min_intv) break;
-			}
-			ok.info = (u64)(i + 1); ik = ok;
-		} else { s0[cap - 1 - n0] = ik; ++n0; break; }
-	}
-	if (i == len) { s0[cap - 1 - n0] = ik; ++n0; }
-	BiIntv *prev = s0 + (cap - n0), *curr = s1;
-	int nprev = n0, ret = (int)prev[0].info;
-	bool any = false; int last_start = 0;
-	for (i = x - 1; i >= -1; --i) {
-		int c = i < 0 ? -1 : (q[i] < 4 ? (int)q[i] : -1);
-		int nc = 0; u64 last_x2 = 0;
-		for (int j = 0; j < nprev; ++j) {
-			BiIntv p = prev[j], ok; ok.x0 = ok.x1 = ok.x2 = 0;
-			if (c >= 0) nblk += fm_extend1(ix, p, c, 1, ok);
-			if (c < 0 || ok.x2 < min_intv) {
-				if (nc == 0 && (!any || i + 1 < last_start)) {
-					em.add(p.x0, p.x2, i + 1, (int)p.info);
-					any = true; last_start = i + 1;
-				}
-			} else if (nc == 0 || ok.x2 != last_x2) {
-				ok.info = p.info; curr[nc++] = ok; last_x2 = ok.x2;
-			}
-		}
-		if (nc == 0) break;
-		prev = curr; nprev = nc; curr = (curr == s1) ? s0 : s1;
-	}
-	return ret;
-}
-
-// bwt_seed_strategy1 (bwt.c:358-379)
-__device__ int dev_seed_strategy1(const DevIndex &ix, const u8 *q, int len, int x, int min_len, u64 max_intv, SeedEmit &em, u32 &nblk)
-{
-	if (q[x] > 3) return x + 1;
-	BiIntv ik; fm_init(ix, q[x], ik);
-	for (int i = x + 1; i < len; ++i) {
-		int b = q[i];
-		if (b > 3) return i + 1;
-		BiIntv ok; nblk += fm_extend1(ix, ik, 3 - b, 0, ok);
-		if (ok.x2 < max_intv && i - x >= min_len) {
-			if (ok.x2 > 0) em.add(ok.x0, ok.x2, x, i + 1); // caller keeps it only if x[2] > 0 (bwamem.c:177)
-			return i + 1;
-		}
-		ik = ok;
-	}
-	return len;
-}
-
 struct IntvInfoLess { DEVFN bool operator()(const Intv3 &a, const Intv3 &b) const { return a.info < b.info; } };
 
 #define BT_NODE_INTS 40   // n, internal, 9 chain indices, 10 children, (pad), 9 x i64 positions = 160 bytes
@@ -101,7 +35,8 @@ enum { SS_FETCH = 0, SS_PASS1, SS_PASS2, SS_PASS3, SS_FWD, SS_BWD, SS_STRAT, SS_
 
 struct SeedLane {
 	int st, r, len, x, k2, old_n, pass;
-	const u8 *q;
+	u64 qoff, win;            // the read's offset in the packed base array; the 16-base window last fetched from it
+	u32 win_w;                // index of that window (~0u: none)
 	// current SMEM search (bwt_smem1a, bwt.c:289-351)
 	u64 min_intv, last_x2;
 	int sx, i, n0, nprev, nc, j, c, ret, last_start;
@@ -160,14 +95,43 @@ struct SeedStack {
 	}
 };
 
+// Base i of the lane's read (0..3, 4 = N).  A lane walks its read sequentially, forward from x and backward from x-1, and asks
+// for a base at every step; byte loads from the raw read (a different 64-byte line per lane, ~2 MB per XCD of resident
+// lanes against a 4 MB L2 that the index blocks stream through) showed up as memory requests of their own.  k_pack_reads
+// packs the batch to 4 bits per base and each lane keeps the 16-base word it is in; a sweep reloads it every 16 steps.
+DEVFN int seed_q(SeedLane &L, const u64 *nib, int i)
+{
+	const u64 g = L.qoff + (u64)i;
+	const u32 w = (u32)(g >> 4);
+	if (w != L.win_w) { L.win = nib[w]; L.win_w = w; }
+	return (int)(L.win >> (((u32)g & 15) << 2)) & 15;
+}
+
+// 4-bit packing of the batch's bases for seed_q: word w holds bases [16w, 16w+16) of the flat read array, codes > 3 become 4
+__global__ void __launch_bounds__(256) k_pack_reads(Batch B, u64 n_words)
+{
+	for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (u64)gridDim.x * blockDim.x) {
+		const uint4 v = ((const uint4*)B.seq)[w];      // B.seq is padded to a multiple of 16 bytes
+		const u32 d[4] = { v.x, v.y, v.z, v.w };
+		u64 o = 0;
+		for (int k = 0; k < 4; ++k)
+			for (int b = 0; b < 4; ++b) {
+				u32 c = d[k] >> (8 * b) & 255;
+				o |= (u64)(c > 3 ? 4 : c) << ((k * 4 + b) * 4);
+			}
+		B.seq_nib[w] = o;
+	}
+}
+
 DEVFN void smem_finish(SeedLane &L) { if (L.pass == 1) { L.x = L.ret; L.st = SS_PASS1; } else L.st = SS_PASS2; }
 
 // start backward row i (bwt.c:326-345); rows without a usable base (i < 0 or N) need no extension at all
-DEVFN void bwd_begin_row(SeedLane &L, const SeedStack &S)
+DEVFN void bwd_begin_row(SeedLane &L, const SeedStack &S, const u64 *nib)
 {
 	for (;;) {
 		if (L.i < -1) { smem_finish(L); return; }
-		L.c = L.i < 0 ? -1 : (L.q[L.i] < 4 ? (int)L.q[L.i] : -1);
+		L.c = L.i < 0 ? -1 : seed_q(L, nib, L.i);
+		if (L.c > 3) L.c = -1;
 		L.j = 0; L.nc = 0; L.last_x2 = 0;
 		if (L.c >= 0) { L.st = SS_BWD; return; }
 		// every interval stops here; only the longest one (first in prev[]) can be a new MEM
@@ -178,13 +142,13 @@ DEVFN void bwd_begin_row(SeedLane &L, const SeedStack &S)
 	}
 }
 
-DEVFN void fwd_finish(SeedLane &L, const SeedStack &S)
+DEVFN void fwd_finish(SeedLane &L, const SeedStack &S, const u64 *nib)
 {	// forward sweep done: stack[0 .. n0) holds the change points, longest match on top
 	L.top = L.n0 - 1; L.nprev = L.n0;
 	L.slot = (L.slot == 0 ? S.n_lds : L.slot) - 1;
 	L.any = false; L.last_start = 0;
 	L.i = L.sx - 1;
-	bwd_begin_row(L, S);
+	bwd_begin_row(L, S, nib);
 }
 
 // Bi-interval of the j-mer with 2-bit code `code` (first base most significant) from the prefix tables.  The tables are
@@ -199,16 +163,17 @@ DEVFN void ptab_load(const DevIndex &ix, int j, u32 code, BiIntv &out)
 
 #define PTAB_MAX 12
 
-DEVFN void smem_start(const DevIndex &ix, SeedLane &L, const SeedStack &S, int x, u64 min_intv, int pass)
+DEVFN void smem_start(const DevIndex &ix, SeedLane &L, const SeedStack &S, const u64 *nib, int x, u64 min_intv, int pass)
 {
 	L.pass = pass; L.sx = x; L.min_intv = min_intv < 1 ? 1 : min_intv;
-	if (L.q[x] > 3) { L.ret = x + 1; smem_finish(L); return; }   // bwt.c:296
-	fm_init(ix, L.q[x], L.ik); L.ik.info = (u64)(x + 1);
+	const int c0 = seed_q(L, nib, x);
+	if (c0 > 3) { L.ret = x + 1; smem_finish(L); return; }   // bwt.c:296
+	fm_init(ix, c0, L.ik); L.ik.info = (u64)(x + 1);
 	L.i = x + 1; L.n0 = 0; L.slot = 0;
-	L.code = L.q[x];
-	if (L.i >= L.len || L.q[L.i] > 3) {                          // nothing (more) to extend: push and go backward
+	L.code = (u32)c0;
+	if (L.i >= L.len || seed_q(L, nib, L.i) > 3) {                          // nothing (more) to extend: push and go backward
 		S.push(L, L.ik); L.ret = (int)L.ik.info;
-		fwd_finish(L, S);
+		fwd_finish(L, S, nib);
 	} else L.st = SS_FWD;
 }
 
@@ -254,7 +219,8 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 	S.lds = seed_lds + threadIdx.x; S.stride = blockDim.x; S.n_lds = B.seed_lds_ent;
 	S.glob = B.tmp_intv + (size_t)tid * cap;
 	L.em.mem = B.intv; L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len;
-	L.st = SS_FETCH; L.r = -1; L.len = 0; L.q = B.seq;
+	L.st = SS_FETCH; L.r = -1; L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u;
+	const u64 *nib = B.seq_nib;
 	u32 nblk = 0;
 	while (L.st != SS_DONE) {
 		// ---- advance the lane's state up to its next extension -----------------------------------------------------
@@ -262,7 +228,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 		case SS_FETCH: {
 			int r = (int)atomicAdd(&B.ctr->next_read, 1ull);
 			if (r >= B.n_reads) { L.st = SS_DONE; break; }
-			L.r = r; L.q = B.seq + B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
+			L.r = r; L.qoff = (u64)B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
 			B.intv_n[r] = 0;
 			L.em.mem = B.intv + (size_t)r * B.mem_cap;      // the read's own interval list (sorted and consumed by k_publish)
 			L.em.n = 0; L.em.overflow = false;
@@ -271,25 +237,26 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			break; }
 		case SS_PASS1:   // pass 1: all SMEMs, left to right (bwamem.c:147-157)
 			if (L.x >= L.len) { L.old_n = L.em.n; L.k2 = 0; L.st = SS_PASS2; }
-			else if (L.q[L.x] > 3) ++L.x;
-			else smem_start(ix, L, S, L.x, 1, 1);
+			else if (seed_q(L, nib, L.x) > 3) ++L.x;
+			else smem_start(ix, L, S, nib, L.x, 1, 1);
 			break;
 		case SS_PASS2:   // pass 2: re-seed from the middle of long, rare SMEMs (bwamem.c:160-168)
 			if (L.k2 >= L.old_n) { L.x = 0; L.st = opt.max_mem_intv > 0 ? SS_PASS3 : SS_FINAL; }
 			else {
 				Intv3 p = L.em.mem[L.k2++];
 				int start = (int)(p.info >> 32), end = (int)(u32)p.info;
-				if (end - start >= split_len && p.x2 <= (u64)opt.split_width) smem_start(ix, L, S, (start + end) >> 1, p.x2 + 1, 2);
+				if (end - start >= split_len && p.x2 <= (u64)opt.split_width) smem_start(ix, L, S, nib, (start + end) >> 1, p.x2 + 1, 2);
 			}
 			break;
 		case SS_PASS3:   // pass 3: LAST-like seeds (bwamem.c:170-185, bwt_seed_strategy1 bwt.c:358-379)
 			if (L.x >= L.len) L.st = SS_FINAL;
-			else if (L.q[L.x] > 3) ++L.x;
+			else if (seed_q(L, nib, L.x) > 3) ++L.x;
 			else {
-				fm_init(ix, L.q[L.x], L.ik); L.sx = L.x; L.i = L.x + 1;
-				L.code = L.q[L.x];
+				const int c0 = seed_q(L, nib, L.x);
+				fm_init(ix, c0, L.ik); L.sx = L.x; L.i = L.x + 1;
+				L.code = (u32)c0;
 				if (L.i >= L.len) { L.x = L.len; }
-				else if (L.q[L.i] > 3) { L.x = L.i + 1; }
+				else if (seed_q(L, nib, L.i) > 3) { L.x = L.i + 1; }
 				else L.st = SS_STRAT;
 			}
 			break;
@@ -306,9 +273,10 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			const int back = st == SS_BWD;
 			if (back) L.p = S.load(L, L.j);
 			src.x0 = back ? L.p.x0 : L.ik.x0; src.x1 = back ? L.p.x1 : L.ik.x1; src.x2 = back ? L.p.x2 : L.ik.x2; src.info = 0;
-			const int cb = back ? L.c : 3 - (int)L.q[L.i];
+			const int qi = back ? 0 : seed_q(L, nib, L.i);
+			const int cb = back ? L.c : 3 - qi;
 			if (!back && L.i - L.sx < ix.ptab_m) {            // the first steps of a forward search: one 24-byte table entry
-				L.code = L.code << 2 | L.q[L.i];              // instead of two index blocks (same values, see k_ptab_level)
+				L.code = L.code << 2 | (u32)qi;              // instead of two index blocks (same values, see k_ptab_level)
 				ptab_load(ix, L.i - L.sx + 1, L.code, ok);
 			} else nblk += fm_extend1(ix, src, cb, back, ok);   // the only extension site of the kernel
 			if (st == SS_FWD) {           // forward sweep of bwt_smem1a (bwt.c:304-320)
@@ -319,9 +287,9 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 				}
 				if (!stop) {
 					ok.info = (u64)(L.i + 1); L.ik = ok; ++L.i;
-					if (L.i >= L.len || L.q[L.i] > 3) { S.push(L, L.ik); L.ret = (int)L.ik.info; stop = true; }
+					if (L.i >= L.len || seed_q(L, nib, L.i) > 3) { S.push(L, L.ik); L.ret = (int)L.ik.info; stop = true; }
 				}
-				if (stop) fwd_finish(L, S);
+				if (stop) fwd_finish(L, S, nib);
 			} else if (st == SS_BWD) {    // one interval of one backward row (bwt.c:328-342)
 				if (ok.x2 < L.min_intv) {
 					if (L.nc == 0 && (!L.any || L.i + 1 < L.last_start)) {
@@ -332,7 +300,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 				}
 				if (++L.j == L.nprev) {
 					if (L.nc == 0) smem_finish(L);
-					else { L.nprev = L.nc; --L.i; bwd_begin_row(L, S); }
+					else { L.nprev = L.nc; --L.i; bwd_begin_row(L, S, nib); }
 				}
 			} else {                      // bwt_seed_strategy1 (bwt.c:364-377)
 				if (ok.x2 < opt.max_mem_intv && L.i - L.sx >= opt.min_seed_len) {
@@ -341,7 +309,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 				} else {
 					L.ik = ok; ++L.i;
 					if (L.i >= L.len) { L.x = L.len; L.st = SS_PASS3; }
-					else if (L.q[L.i] > 3) { L.x = L.i + 1; L.st = SS_PASS3; }
+					else if (seed_q(L, nib, L.i) > 3) { L.x = L.i + 1; L.st = SS_PASS3; }
 				}
 			}
 		}
