@@ -307,8 +307,13 @@ __global__ void __launch_bounds__(256) k_order_fill(Batch B, const i32 *weight, 
 
 __global__ void __launch_bounds__(256) k_chain(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
-	int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
 	u64 nch = 0;
-	for (int r = tid; r < B.n_reads; r += nth) { chain_read(ix, opt, B, r); nch += B.chain_n[r]; }
+	// reads are drawn from a counter (in input order): the grid need not match the number of resident lanes, and a lane
+	// that finishes a light read takes the next one instead of idling behind its wave's heaviest
+	for (;;) {
+		const int r = (int)atomicAdd(&B.ctr->next_chain, 1ull);
+		if (r >= B.n_reads) break;
+		chain_read(ix, opt, B, r); nch += B.chain_n[r];
+	}
 	if (B.stats) atomicAdd(&B.ctr->n_chains, (unsigned long long)nch);
 }

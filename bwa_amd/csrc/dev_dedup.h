@@ -138,12 +138,16 @@ __device__ void dedup_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Ba
 
 __global__ void __launch_bounds__(256) k_dedup(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
-	int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+	int tid = blockIdx.x * blockDim.x + threadIdx.x;
 	int wave = tid >> 6, lane = tid & 63;
 	i32 *H = B.dp_h + (size_t)wave * (B.max_len + 2) * DPS + lane;
 	i32 *E = B.dp_e + (size_t)wave * (B.max_len + 2) * DPS + lane;
 	u64 calls = 0, cells = 0, nreg = 0;
-	for (int r = tid; r < B.n_reads; r += nth) { dedup_read(ix, opt, B, r, H, E, calls, cells); nreg += B.reg_n[r]; }
+	for (;;) {
+		const int r = (int)atomicAdd(&B.ctr->next_dedup, 1ull);
+		if (r >= B.n_reads) break;
+		dedup_read(ix, opt, B, r, H, E, calls, cells); nreg += B.reg_n[r];
+	}
 	if (B.stats) {
 		atomicAdd(&B.ctr->glb_calls, (unsigned long long)calls);
 		atomicAdd(&B.ctr->glb_cells, (unsigned long long)cells);

@@ -297,14 +297,19 @@ __global__ void __launch_bounds__(256) k_extend_wave(DevIndex ix, bwagpu_opt_t o
 {
 	HIP_DYNAMIC_SHARED(unsigned char, dyn_lds)
 	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_blk, n_waves = gridDim.x * (blockDim.x >> 6);
 	WaveLds L;
 	unsigned char *base = dyn_lds + (size_t)wave_in_blk * lds_per_wave;
 	L.eh = (int2*)base;                                      // max_len + 2 columns + 64 of read-only padding
 	L.qstride = (B.max_len + 64 + 3) & ~3;
 	L.qp = (int8_t*)(base + (size_t)8 * (B.max_len + 2 + 64));
 	u64 calls = 0, cells = 0, refb = 0, nraw = 0;
-	for (int k = wave; k < B.n_reads; k += n_waves) {
+	// Reads are handed out heaviest first from a global counter: a wave that drew light reads simply draws more of them, and
+	// the launch needs no particular relation between its grid and the number of resident workgroups.
+	for (;;) {
+		int k = 0;
+		if (lane == 0) k = (int)atomicAdd(&B.ctr->next_ext, 1ull);
+		k = __builtin_amdgcn_readlane(k, 0);
+		if (k >= B.n_reads) break;
 		const int r = B.order[k];
 		ext_read_wave(ix, opt, B, r, L, calls, cells, refb);
 		wave_sync();
