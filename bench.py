@@ -189,7 +189,7 @@ def main():
         # algorithmic bytes per launch of each index-bound kernel: one 64-byte block per Occ lookup /
         # LF step, 8 bytes per SA sample, plus the read bases the seeding kernel consumes
         alg = {
-            "k_seed": 64.0 * work["n_occ_blocks"] + work["n_bases"],
+            "k_seed": 64.0 * work["n_occ_blocks"] + 24.0 * work["n_tab_lookups"] + work["n_bases"] / 2,
             "k_sa": 64.0 * work["n_lf_steps"] + 8.0 * work["n_seeds"],
         }
         dur = {"k_seed": stage_ms["ms_seed"], "k_sa": stage_ms["ms_sa"]}
@@ -218,7 +218,7 @@ def main():
                          "random_64B_ceiling": {"GB/s": 1670.0, "blocks_per_s": 26.0e9, "frac": round(achieved / 1670.0, 4),
                                                 "source": "tools/randbw.hip on MI355X, profiles/r01_randbw_microbench.md: random 64-byte reads from HBM saturate at 26e9/s"}},
             "stage_ms_solo": {k: round(v, 3) for k, v in stage_ms.items()},
-            "work_per_read": {"N_blk": round(work["n_occ_blocks"] / work["n_reads"], 1), "N_lf": round(work["n_lf_steps"] / work["n_reads"], 1),
+            "work_per_read": {"N_blk": round(work["n_occ_blocks"] / work["n_reads"], 1), "N_tab": round(work["n_tab_lookups"] / work["n_reads"], 1), "N_lf": round(work["n_lf_steps"] / work["n_reads"], 1),
                               "N_sa": round(work["n_seeds"] / work["n_reads"], 2), "ext_cells": round(work["n_ext_cells"] / work["n_reads"], 0),
                               "regs": round(work["n_regs"] / work["n_reads"], 3)},
         }

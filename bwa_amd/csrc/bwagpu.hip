@@ -532,6 +532,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		h->stats.n_seeds = (i64)c.seed_used;
 		h->stats.n_intv = (i64)c.n_intv;
 		h->stats.n_chains = (i64)c.n_chains; h->stats.n_regs_raw = (i64)c.n_regs_raw; h->stats.n_regs = (i64)c.n_regs;
+		h->stats.n_tab_lookups = (i64)c.tab_lookups;
 		h->stats.n_occ_blocks = (i64)c.occ_blocks; h->stats.n_lf_steps = (i64)c.lf_steps;
 		h->stats.n_ext_calls = (i64)c.ext_calls; h->stats.n_ext_cells = (i64)c.ext_cells;
 		h->stats.n_glb_calls = (i64)c.glb_calls; h->stats.n_glb_cells = (i64)c.glb_cells; h->stats.ref_bases = (i64)c.ref_bases;

@@ -70,7 +70,7 @@ struct Counters {          // device-side bump allocators + flags
 	unsigned long long overflow;   // bit0 intv, bit1 seed, bit2 node, bit3 reg, bit4 tmp-intv scratch
 	// algorithmic work counters (bwagpu_stats_t)
 	unsigned long long n_intv, n_chains, n_regs_raw, n_regs;
-	unsigned long long occ_blocks, lf_steps, ext_calls, ext_cells, glb_calls, glb_cells, ref_bases, sw_calls, sw_cells;
+	unsigned long long occ_blocks, lf_steps, ext_calls, ext_cells, glb_calls, glb_cells, ref_bases, sw_calls, sw_cells, tab_lookups;
 };
 
 // Sub-arrays of one read's private region (n = its number of seed slots); offsets keep every array naturally aligned.

@@ -43,6 +43,7 @@ struct SeedLane {
 	bool any;
 	BiIntv ik, p;
 	u32 code;                 // 2-bit code of q[sx..i) while it is short enough for the prefix tables
+	u32 rcode;                // backward sweep: 2-bit code of q[i..i+ptab_m), first base most significant (bases past a match's end are don't-care)
 	int top;                  // index of the longest match in the interval stack (prev[j] = the entry j below the top)
 	int slot;                 // forward sweep: ring position of the next push; backward sweep: ring position of the top entry
 	SeedEmit em;
@@ -126,14 +127,14 @@ __global__ void __launch_bounds__(256) k_pack_reads(Batch B, u64 n_words)
 DEVFN void smem_finish(SeedLane &L) { if (L.pass == 1) { L.x = L.ret; L.st = SS_PASS1; } else L.st = SS_PASS2; }
 
 // start backward row i (bwt.c:326-345); rows without a usable base (i < 0 or N) need no extension at all
-DEVFN void bwd_begin_row(SeedLane &L, const SeedStack &S, const u64 *nib)
+DEVFN void bwd_begin_row(SeedLane &L, const SeedStack &S, const u64 *nib, int m)
 {
 	for (;;) {
 		if (L.i < -1) { smem_finish(L); return; }
 		L.c = L.i < 0 ? -1 : seed_q(L, nib, L.i);
 		if (L.c > 3) L.c = -1;
 		L.j = 0; L.nc = 0; L.last_x2 = 0;
-		if (L.c >= 0) { L.st = SS_BWD; return; }
+		if (L.c >= 0) { if (m > 0) L.rcode = (u32)L.c << (2 * (m - 1)) | L.rcode >> 2; L.st = SS_BWD; return; }
 		// every interval stops here; only the longest one (first in prev[]) can be a new MEM
 		BiIntv p = S.load(L, 0);
 		if (!L.any || L.i + 1 < L.last_start) { L.em.add(p.x0, p.x2, L.i + 1, (int)p.info); L.any = true; L.last_start = L.i + 1; }
@@ -142,13 +143,16 @@ DEVFN void bwd_begin_row(SeedLane &L, const SeedStack &S, const u64 *nib)
 	}
 }
 
-DEVFN void fwd_finish(SeedLane &L, const SeedStack &S, const u64 *nib)
+DEVFN void fwd_finish(SeedLane &L, const SeedStack &S, const u64 *nib, int m)
 {	// forward sweep done: stack[0 .. n0) holds the change points, longest match on top
 	L.top = L.n0 - 1; L.nprev = L.n0;
 	L.slot = (L.slot == 0 ? S.n_lds : L.slot) - 1;
 	L.any = false; L.last_start = 0;
 	L.i = L.sx - 1;
-	bwd_begin_row(L, S, nib);
+	u32 rc = 0;              // code of q[sx..sx+m) for the table look-ups of the first backward rows (see the extension site)
+	for (int k = 0; k < m; ++k) { const int g = L.sx + k; rc = rc << 2 | (u32)((g < L.len ? seed_q(L, nib, g) : 0) & 3); }
+	L.rcode = rc;
+	bwd_begin_row(L, S, nib, m);
 }
 
 // Bi-interval of the j-mer with 2-bit code `code` (first base most significant) from the prefix tables.  The tables are
@@ -173,7 +177,7 @@ DEVFN void smem_start(const DevIndex &ix, SeedLane &L, const SeedStack &S, const
 	L.code = (u32)c0;
 	if (L.i >= L.len || seed_q(L, nib, L.i) > 3) {                          // nothing (more) to extend: push and go backward
 		S.push(L, L.ik); L.ret = (int)L.ik.info;
-		fwd_finish(L, S, nib);
+		fwd_finish(L, S, nib, ix.ptab_m);
 	} else L.st = SS_FWD;
 }
 
@@ -221,7 +225,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 	L.em.mem = B.intv; L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len;
 	L.st = SS_FETCH; L.r = -1; L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u;
 	const u64 *nib = B.seq_nib;
-	u32 nblk = 0;
+	u32 nblk = 0, ntab = 0;
 	while (L.st != SS_DONE) {
 		// ---- advance the lane's state up to its next extension -----------------------------------------------------
 		switch (L.st) {
@@ -275,9 +279,15 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			src.x0 = back ? L.p.x0 : L.ik.x0; src.x1 = back ? L.p.x1 : L.ik.x1; src.x2 = back ? L.p.x2 : L.ik.x2; src.info = 0;
 			const int qi = back ? 0 : seed_q(L, nib, L.i);
 			const int cb = back ? L.c : 3 - qi;
-			if (!back && L.i - L.sx < ix.ptab_m) {            // the first steps of a forward search: one 24-byte table entry
-				L.code = L.code << 2 | (u32)qi;              // instead of two index blocks (same values, see k_ptab_level)
-				ptab_load(ix, L.i - L.sx + 1, L.code, ok);
+			// A match no longer than ptab_m bases has its bi-interval in the prefix tables (filled by the same fm_extend1 at
+			// start-up, k_ptab_level; a bi-interval is a function of the string, whichever way it was extended): one 24-byte
+			// entry instead of two index blocks.  That covers the first steps of every forward search and, in the first
+			// backward rows, the short change-point intervals, whose match q[i..end) is still short.
+			const int tl = back ? (int)L.p.info - L.i : L.i - L.sx + 1;    // length of the extended match
+			if (tl <= ix.ptab_m) {
+				if (!back) L.code = L.code << 2 | (u32)qi;
+				ptab_load(ix, tl, back ? L.rcode >> (2 * (ix.ptab_m - tl)) : L.code, ok);
+				++ntab;
 			} else nblk += fm_extend1(ix, src, cb, back, ok);   // the only extension site of the kernel
 			if (st == SS_FWD) {           // forward sweep of bwt_smem1a (bwt.c:304-320)
 				bool stop = false;
@@ -289,7 +299,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 					ok.info = (u64)(L.i + 1); L.ik = ok; ++L.i;
 					if (L.i >= L.len || seed_q(L, nib, L.i) > 3) { S.push(L, L.ik); L.ret = (int)L.ik.info; stop = true; }
 				}
-				if (stop) fwd_finish(L, S, nib);
+				if (stop) fwd_finish(L, S, nib, ix.ptab_m);
 			} else if (st == SS_BWD) {    // one interval of one backward row (bwt.c:328-342)
 				if (ok.x2 < L.min_intv) {
 					if (L.nc == 0 && (!L.any || L.i + 1 < L.last_start)) {
@@ -300,7 +310,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 				}
 				if (++L.j == L.nprev) {
 					if (L.nc == 0) smem_finish(L);
-					else { L.nprev = L.nc; --L.i; bwd_begin_row(L, S, nib); }
+					else { L.nprev = L.nc; --L.i; bwd_begin_row(L, S, nib, ix.ptab_m); }
 				}
 			} else {                      // bwt_seed_strategy1 (bwt.c:364-377)
 				if (ok.x2 < opt.max_mem_intv && L.i - L.sx >= opt.min_seed_len) {
@@ -314,7 +324,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			}
 		}
 	}
-	if (B.stats) atomicAdd(&B.ctr->occ_blocks, (unsigned long long)nblk);
+	if (B.stats) { atomicAdd(&B.ctr->occ_blocks, (unsigned long long)nblk); atomicAdd(&B.ctr->tab_lookups, (unsigned long long)ntab); }
 }
 
 // One lane per SA interval: expand it into its SA rows (mem_chain's k-loop, bwamem.c:304-305) in the read's slot range.

@@ -151,6 +151,7 @@ typedef struct {
 	float ms_seed, ms_sa, ms_chain, ms_seedsw, ms_extend, ms_dedup, ms_total;
 	int32_t n_retries;       /* arena-growth reruns */
 	float ms_publish;        /* k_publish + k_expand (interval sort, slot reservation); ms_seed is the k_seed kernel alone */
+	int64_t n_tab_lookups;   /* 24-byte prefix-table entries read by seeding in place of index blocks (stats only) */
 } bwagpu_stats_t;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */

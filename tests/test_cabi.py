@@ -33,7 +33,7 @@ def test_header_functions_are_exported(lib):
 def test_struct_sizes_in_header_match_python_mirrors():
     from bwa_amd.structs import MemOpt, ALNREG_DTYPE
     assert C.sizeof(MemOpt) == 168 and ALNREG_DTYPE.itemsize == 88
-    assert C.sizeof(api.Stats) == 168   # 16 x i64 + 7 x f32 + 2 x i32, padded to 8
+    assert C.sizeof(api.Stats) == 176   # 16 x i64 + 7 x f32 + i32 + f32 (padded to 8) + i64
 
 
 def test_no_cpu_fallback_without_gpu(lib):
