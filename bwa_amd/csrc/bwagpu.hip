@@ -114,21 +114,37 @@ __global__ void __launch_bounds__(256) k_ptab_level(DevIndex ix, u64 *tab, int j
 	}
 }
 
+// records: for every m-mer W the packed bi-intervals of its m prefixes, gathered from the level tables
+__global__ void __launch_bounds__(256) k_ptab_records(const u64 *tab, uint4 *rec, int m)
+{
+	const u64 n = ((u64)1 << (2 * m)) * (u64)m;
+	for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (u64)gridDim.x * blockDim.x) {
+		const u64 w = t / (u64)m; const int j = (int)(t % (u64)m) + 1;
+		const u64 *e = tab + ((((u64)1 << (2 * j)) - 4) / 3 + (w >> (2 * (m - j)))) * 3;
+		BiIntv v; v.x0 = e[0]; v.x1 = e[1]; v.x2 = e[2]; v.info = 0;
+		rec[t] = SeedStack::pack(v);
+	}
+}
+
 static int build_prefix_tables(bwagpu_t *h, int m)
 {
-	if (m < 2) { h->ix.ptab = nullptr; h->ix.ptab_m = 0; return 0; }
+	// the packed entries hold 37-bit interval bounds (as do the LDS interval stacks)
+	if (m < 2 || h->ix.seq_len >= ((u64)1 << 36)) { h->ix.ptab = nullptr; h->ix.ptab_m = 0; return 0; }
 	if (m > PTAB_MAX) m = PTAB_MAX;
 	size_t entries = ((((size_t)1 << (2 * (m + 1))) - 4) / 3);
-	if (h->ibuf->d_ptab.ensure(entries * 24)) { h->err = "hipMalloc failed (prefix tables)"; return BWAGPU_ENOMEM; }
+	DevBuf levels;
+	if (levels.ensure(entries * 24) || h->ibuf->d_ptab.ensure(((size_t)1 << (2 * m)) * m * sizeof(uint4))) { levels.release(); h->err = "hipMalloc failed (prefix tables)"; return BWAGPU_ENOMEM; }
 	DevIndex ix = h->ix; ix.ptab = nullptr; ix.ptab_m = 0;
 	for (int j = 1; j <= m; ++j) {
 		u64 n = (u64)1 << (2 * j);
 		unsigned nb = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-		hipLaunchKernelGGL(k_ptab_level, dim3(nb), dim3(256), 0, h->stream, ix, h->ibuf->d_ptab.as<u64>(), j);
+		hipLaunchKernelGGL(k_ptab_level, dim3(nb), dim3(256), 0, h->stream, ix, levels.as<u64>(), j);
 	}
-	HIPCHK(h, hipGetLastError());
-	HIPCHK(h, hipStreamSynchronize(h->stream));
-	h->ix.ptab = h->ibuf->d_ptab.as<u64>(); h->ix.ptab_m = m;
+	hipLaunchKernelGGL(k_ptab_records, dim3(8192), dim3(256), 0, h->stream, levels.as<u64>(), h->ibuf->d_ptab.as<uint4>(), m);
+	hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(h->stream);
+	levels.release();
+	HIPCHK(h, e1); HIPCHK(h, e2);
+	h->ix.ptab = h->ibuf->d_ptab.as<uint4>(); h->ix.ptab_m = m;
 	return 0;
 }
 

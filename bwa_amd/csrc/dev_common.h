@@ -33,8 +33,10 @@ struct DevIndex {
 	const i64 *ctg_off;
 	const i32 *ctg_len;
 	const i32 *ctg_alt;
-	// prefix tables: bi-interval of every j-mer, j = 1..ptab_m, level j at entry offset (4^j - 4) / 3, three u64 per entry
-	const u64 *ptab;
+	// prefix tables: one record per ptab_m-mer W, holding the bi-intervals of W's prefixes of length 1..ptab_m as packed
+	// 16-byte entries (SeedStack::pack layout) -- every look-up a search makes while its window q[x..x+m) stays the same hits
+	// the same 16*m-byte record
+	const uint4 *ptab;
 	int ptab_m;
 };
 

@@ -42,8 +42,7 @@ struct SeedLane {
 	int sx, i, n0, nprev, nc, j, c, ret, last_start;
 	bool any;
 	BiIntv ik, p;
-	u32 code;                 // 2-bit code of q[sx..i) while it is short enough for the prefix tables
-	u32 rcode;                // backward sweep: 2-bit code of q[i..i+ptab_m), first base most significant (bases past a match's end are don't-care)
+	u32 code;                 // prefix-table window: forward sweep, q[sx..sx+ptab_m); backward sweep, q[i..i+ptab_m) (window_code)
 	int top;                  // index of the longest match in the interval stack (prev[j] = the entry j below the top)
 	int slot;                 // forward sweep: ring position of the next push; backward sweep: ring position of the top entry
 	SeedEmit em;
@@ -134,7 +133,7 @@ DEVFN void bwd_begin_row(SeedLane &L, const SeedStack &S, const u64 *nib, int m)
 		L.c = L.i < 0 ? -1 : seed_q(L, nib, L.i);
 		if (L.c > 3) L.c = -1;
 		L.j = 0; L.nc = 0; L.last_x2 = 0;
-		if (L.c >= 0) { if (m > 0) L.rcode = (u32)L.c << (2 * (m - 1)) | L.rcode >> 2; L.st = SS_BWD; return; }
+		if (L.c >= 0) { if (m > 0) L.code = (u32)L.c << (2 * (m - 1)) | L.code >> 2; L.st = SS_BWD; return; }
 		// every interval stops here; only the longest one (first in prev[]) can be a new MEM
 		BiIntv p = S.load(L, 0);
 		if (!L.any || L.i + 1 < L.last_start) { L.em.add(p.x0, p.x2, L.i + 1, (int)p.info); L.any = true; L.last_start = L.i + 1; }
@@ -149,20 +148,25 @@ DEVFN void fwd_finish(SeedLane &L, const SeedStack &S, const u64 *nib, int m)
 	L.slot = (L.slot == 0 ? S.n_lds : L.slot) - 1;
 	L.any = false; L.last_start = 0;
 	L.i = L.sx - 1;
-	u32 rc = 0;              // code of q[sx..sx+m) for the table look-ups of the first backward rows (see the extension site)
-	for (int k = 0; k < m; ++k) { const int g = L.sx + k; rc = rc << 2 | (u32)((g < L.len ? seed_q(L, nib, g) : 0) & 3); }
-	L.rcode = rc;
 	bwd_begin_row(L, S, nib, m);
 }
 
-// Bi-interval of the j-mer with 2-bit code `code` (first base most significant) from the prefix tables.  The tables are
-// filled at start-up by the same fm_extend1 the sweep uses (k_ptab_level), so the values are those the reference's
-// step-by-step extension would produce; for the first ptab_m steps of a forward search one 24-byte entry replaces the two
-// 64-byte index blocks of an extension.
-DEVFN void ptab_load(const DevIndex &ix, int j, u32 code, BiIntv &out)
+// Bi-interval of the first j bases of the m-mer with 2-bit code `w` (first base most significant) from the prefix tables.
+// The tables are filled at start-up by the same fm_extend1 the sweep uses (k_ptab_level), so the values are those the
+// reference's step-by-step extension would produce.  A look-up is one 16-byte entry instead of the two 64-byte index
+// blocks of an extension, and the look-ups of consecutive steps fall into the same 16*m-byte record.
+DEVFN void ptab_load(const DevIndex &ix, int j, u32 w, BiIntv &out)
 {
-	const u64 *e = ix.ptab + ((((u64)1 << (2 * j)) - 4) / 3 + code) * 3;
-	out.x0 = e[0]; out.x1 = e[1]; out.x2 = e[2];
+	out = SeedStack::unpack(ix.ptab[(u64)w * (u32)ix.ptab_m + (u32)(j - 1)]);
+}
+
+// 2-bit code of q[x..x+m), first base most significant; N and positions past the read's end read as 0 (no match that the
+// tables are asked about extends over them)
+DEVFN u32 window_code(SeedLane &L, const u64 *nib, int x, int m)
+{
+	u32 rc = 0;
+	for (int k = 0; k < m; ++k) { const int g = x + k; rc = rc << 2 | (u32)((g < L.len ? seed_q(L, nib, g) : 0) & 3); }
+	return rc;
 }
 
 #define PTAB_MAX 12
@@ -174,7 +178,7 @@ DEVFN void smem_start(const DevIndex &ix, SeedLane &L, const SeedStack &S, const
 	if (c0 > 3) { L.ret = x + 1; smem_finish(L); return; }   // bwt.c:296
 	fm_init(ix, c0, L.ik); L.ik.info = (u64)(x + 1);
 	L.i = x + 1; L.n0 = 0; L.slot = 0;
-	L.code = (u32)c0;
+	L.code = window_code(L, nib, x, ix.ptab_m);
 	if (L.i >= L.len || seed_q(L, nib, L.i) > 3) {                          // nothing (more) to extend: push and go backward
 		S.push(L, L.ik); L.ret = (int)L.ik.info;
 		fwd_finish(L, S, nib, ix.ptab_m);
@@ -258,7 +262,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			else {
 				const int c0 = seed_q(L, nib, L.x);
 				fm_init(ix, c0, L.ik); L.sx = L.x; L.i = L.x + 1;
-				L.code = (u32)c0;
+				L.code = window_code(L, nib, L.x, ix.ptab_m);
 				if (L.i >= L.len) { L.x = L.len; }
 				else if (seed_q(L, nib, L.i) > 3) { L.x = L.i + 1; }
 				else L.st = SS_STRAT;
@@ -280,13 +284,12 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			const int qi = back ? 0 : seed_q(L, nib, L.i);
 			const int cb = back ? L.c : 3 - qi;
 			// A match no longer than ptab_m bases has its bi-interval in the prefix tables (filled by the same fm_extend1 at
-			// start-up, k_ptab_level; a bi-interval is a function of the string, whichever way it was extended): one 24-byte
+			// start-up, k_ptab_level; a bi-interval is a function of the string, whichever way it was extended): one 16-byte
 			// entry instead of two index blocks.  That covers the first steps of every forward search and, in the first
 			// backward rows, the short change-point intervals, whose match q[i..end) is still short.
 			const int tl = back ? (int)L.p.info - L.i : L.i - L.sx + 1;    // length of the extended match
 			if (tl <= ix.ptab_m) {
-				if (!back) L.code = L.code << 2 | (u32)qi;
-				ptab_load(ix, tl, back ? L.rcode >> (2 * (ix.ptab_m - tl)) : L.code, ok);
+				ptab_load(ix, tl, L.code, ok);
 				++ntab;
 			} else nblk += fm_extend1(ix, src, cb, back, ok);   // the only extension site of the kernel
 			if (st == SS_FWD) {           // forward sweep of bwt_smem1a (bwt.c:304-320)
