@@ -9,9 +9,15 @@
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+#include <atomic>
 #include <chrono>
-#include <future>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "bwamem_host.h"
 
@@ -58,30 +64,48 @@ struct Seq { std::string name, comment, seq, qual; bool has_comment = false, has
 
 struct Reader {
 	gzFile fp = nullptr; std::vector<char> buf; int pos = 0, len = 0; int last = 0; bool eof = false;
-	bool open(const char *fn) { fp = strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(fileno(stdin), "r"); buf.resize(1 << 16); return fp != nullptr; }
-	int getc_() { if (pos >= len) { if (eof) return -1; len = gzread(fp, buf.data(), (unsigned)buf.size()); pos = 0; if (len <= 0) { eof = true; return -1; } } return (unsigned char)buf[pos++]; }
+	bool open(const char *fn) { fp = strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(fileno(stdin), "r"); if (fp) gzbuffer(fp, 1 << 20); buf.resize(1 << 20); return fp != nullptr; }
+	bool fill() { if (eof) return false; len = gzread(fp, buf.data(), (unsigned)buf.size()); pos = 0; if (len <= 0) { len = 0; eof = true; return false; } return true; }
+	int getc_() { if (pos >= len && !fill()) return -1; return (unsigned char)buf[pos++]; }
+	// append the bytes up to the next delimiter (newline, or any white space when `space`) to `out` and consume the delimiter;
+	// returns the delimiter, or -1 at end of input.  Whole buffer spans are copied at once.
+	int until(bool space, std::string *out) {
+		for (;;) {
+			if (pos >= len && !fill()) return -1;
+			const char *b = buf.data() + pos; const int n = len - pos; int k;
+			if (space) { for (k = 0; k < n && !isspace((unsigned char)b[k]); ++k) {} }
+			else { const char *q = (const char*)memchr(b, '\n', (size_t)n); k = q ? (int)(q - b) : n; }
+			if (out) out->append(b, (size_t)k);
+			pos += k;
+			if (k < n) return (unsigned char)buf[pos++];
+		}
+	}
+	static void strip_cr(std::string &t) { while (!t.empty() && t.back() == '\r') t.pop_back(); }
 	bool read(Seq &s) {
 		int c;
 		if (last == 0) { while ((c = getc_()) != -1 && c != '>' && c != '@') {} if (c == -1) return false; last = c; }
 		s.name.clear(); s.comment.clear(); s.seq.clear(); s.qual.clear(); s.has_comment = s.has_qual = false;
-		while ((c = getc_()) != -1 && !isspace(c)) s.name += (char)c;
-		if (c != '\n' && c != -1) { s.has_comment = true; while ((c = getc_()) != -1 && c != '\n') s.comment += (char)c; while (!s.comment.empty() && s.comment.back() == '\r') s.comment.pop_back(); }
-		if (!s.has_comment) while (!s.name.empty() && s.name.back() == '\r') s.name.pop_back();
+		c = until(true, &s.name);
+		if (c != '\n' && c != -1) { s.has_comment = true; until(false, &s.comment); strip_cr(s.comment); }
+		if (!s.has_comment) strip_cr(s.name);
 		while ((c = getc_()) != -1 && c != '>' && c != '+' && c != '@') {
 			if (c == '\n') continue;
 			s.seq += (char)c;
-			while ((c = getc_()) != -1 && c != '\n') s.seq += (char)c;
+			until(false, &s.seq);
 		}
 		while (!s.seq.empty() && isspace((unsigned char)s.seq.back())) s.seq.pop_back();
-		{ std::string t; for (char ch : s.seq) if (!isspace((unsigned char)ch)) t += ch; s.seq.swap(t); }
+		bool ws = false;
+		for (char ch : s.seq) if (isspace((unsigned char)ch)) { ws = true; break; }
+		if (ws) { std::string t; for (char ch : s.seq) if (!isspace((unsigned char)ch)) t += ch; s.seq.swap(t); }
 		if (c == '>' || c == '@') last = c; else last = 0;
 		if (c != '+') return true;
-		while ((c = getc_()) != -1 && c != '\n') {}          // skip the rest of the '+' line
-		if (c == -1) return true;
+		if (until(false, nullptr) == -1) return true;          // skip the rest of the '+' line
 		s.has_qual = true;
 		while (s.qual.size() < s.seq.size()) {
-			bool got = false;
-			while ((c = getc_()) != -1 && c != '\n') { if (c != '\r') s.qual += (char)c; got = true; }
+			const size_t before = s.qual.size();
+			c = until(false, &s.qual);
+			const bool got = s.qual.size() > before;
+			if (memchr(s.qual.data() + before, '\r', s.qual.size() - before)) { std::string t(s.qual, 0, before); for (size_t i = before; i < s.qual.size(); ++i) if (s.qual[i] != '\r') t += s.qual[i]; s.qual.swap(t); }
 			if (c == -1 && !got) break;
 		}
 		last = 0;
@@ -110,32 +134,67 @@ static inline uint8_t nt4(unsigned char c)
 	switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
 }
 
-// ---- one batch: == mem_process_seqs (bwamem.c:1235-1264) ----------------------------------------------------------------
-static void process_seqs(bwagpu_t *gpu, const RefSeqs &ref, const bwagpu_opt_t &opt, int64_t n_processed, std::vector<Seq*> &seqs, const Pestat *pes0,
-						 const char *rg_id, bool copy_comment, std::vector<std::string> &sam)
-{
-	auto t0 = std::chrono::steady_clock::now();
-	const int n = (int)seqs.size();
-	std::vector<int64_t> off((size_t)n + 1, 0);
-	for (int i = 0; i < n; ++i) off[i + 1] = off[i] + (int64_t)seqs[i]->seq.size();
-	std::vector<uint8_t> flat((size_t)off[n] + 1);
-	for (int i = 0; i < n; ++i) { const std::string &s = seqs[i]->seq; uint8_t *d = flat.data() + off[i]; for (size_t j = 0; j < s.size(); ++j) d[j] = nt4((unsigned char)s[j]); }
-	std::vector<int32_t> counts((size_t)n);
+// ---- batches flow through a four-stage pipeline: read+encode | device (hot path) | finalize (host threads) | write -------------
+// (the reference overlaps input, compute and output the same way with kt_pipeline, kthread.c:119; here the compute step is
+// split once more so that the GPU works on batch i+1 while the host cores turn batch i's regions into SAM text)
+struct Sub {      // one mem_process_seqs call (bwamem.c:1235-1264) on the reads `idx` of its batch
+	std::vector<int> idx; bwagpu_opt_t opt; int64_t n_processed = 0;
+	std::vector<uint8_t> flat; std::vector<int64_t> off; std::vector<int32_t> counts;
 	bwagpu_alnreg_t *all = nullptr; int64_t tot = 0;
-	int rc = bwagpu_align_flat(gpu, &opt, n, flat.data(), off.data(), counts.data(), &all, &tot);   // was: kt_for(worker1) (bwamem.c:1252)
+	double t_dev = 0;
+};
+struct Work { long no = 0; std::vector<Seq> seqs; std::vector<Sub> subs; std::vector<std::string> out; };
+typedef std::unique_ptr<Work> WorkP;
+
+struct Chan {     // bounded FIFO between two stages
+	std::mutex m; std::condition_variable cv; std::deque<WorkP> q; size_t cap; bool closed = false;
+	explicit Chan(size_t c) : cap(c) {}
+	void push(WorkP w) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return q.size() < cap; }); q.push_back(std::move(w)); cv.notify_all(); }
+	bool pop(WorkP &w) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; w = std::move(q.front()); q.pop_front(); cv.notify_all(); return true; }
+	void close() { std::lock_guard<std::mutex> l(m); closed = true; cv.notify_all(); }
+};
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static void encode_sub(const std::vector<Seq> &seqs, Sub &u)
+{
+	const int n = (int)u.idx.size();
+	u.off.assign((size_t)n + 1, 0);
+	for (int i = 0; i < n; ++i) u.off[i + 1] = u.off[i] + (int64_t)seqs[u.idx[i]].seq.size();
+	u.flat.resize((size_t)u.off[n] + 1);
+	for (int i = 0; i < n; ++i) { const std::string &q = seqs[u.idx[i]].seq; uint8_t *d = u.flat.data() + u.off[i]; for (size_t j = 0; j < q.size(); ++j) d[j] = nt4((unsigned char)q[j]); }
+	u.counts.assign((size_t)n, 0);
+}
+
+// stage 2: the kt_for(worker1) of mem_process_seqs (bwamem.c:1252) on the device
+static void device_sub(bwagpu_t *gpu, Sub &u)
+{
+	const double t0 = now_s();
+	int rc = bwagpu_align_flat(gpu, &u.opt, (int)u.idx.size(), u.flat.data(), u.off.data(), u.counts.data(), &u.all, &u.tot);
 	if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu)); exit(EXIT_FAILURE); }
+	u.t_dev = now_s() - t0;
+}
+
+// stage 3: mem_pestat + kt_for(worker2) (bwamem.c:1254-1260) on the host cores
+static void finalize_sub(const RefSeqs &ref, Work &w, Sub &u, const Pestat *pes0, const char *rg_id, bool copy_comment)
+{
+	const double t0 = now_s();
+	const int n = (int)u.idx.size();
 	std::vector<Regs> regs((size_t)n); std::vector<Read> reads((size_t)n);
 	int64_t k = 0;
 	for (int i = 0; i < n; ++i) {
-		regs[i].assign(all + k, all + k + counts[i]); k += counts[i];
-		reads[i].name = seqs[i]->name.c_str();
-		reads[i].comment = copy_comment && seqs[i]->has_comment ? seqs[i]->comment.c_str() : nullptr;
-		reads[i].seq = flat.data() + off[i]; reads[i].qual = seqs[i]->has_qual ? seqs[i]->qual.c_str() : nullptr; reads[i].l_seq = (int)seqs[i]->seq.size();
+		const Seq &q = w.seqs[u.idx[i]];
+		regs[i].assign(u.all + k, u.all + k + u.counts[i]); k += u.counts[i];
+		reads[i].name = q.name.c_str();
+		reads[i].comment = copy_comment && q.has_comment ? q.comment.c_str() : nullptr;
+		reads[i].seq = u.flat.data() + u.off[i]; reads[i].qual = q.has_qual ? q.qual.c_str() : nullptr; reads[i].l_seq = (int)q.seq.size();
 	}
-	bwagpu_free(all);
-	if (opt.flag & F_PE) for (int i = 0; i + 1 < n; i += 2) if (seqs[i]->name != seqs[i + 1]->name) { fprintf(stderr, "[mem_sam_pe] paired reads have different names: \"%s\", \"%s\"\n", seqs[i]->name.c_str(), seqs[i + 1]->name.c_str()); exit(EXIT_FAILURE); }
-	finalize_batch(opt, ref, n_processed, n, reads.data(), regs, pes0, opt.n_threads, rg_id, sam, g_verbose >= 3);
-	if (g_verbose >= 3) fprintf(stderr, "[M::%s] Processed %d reads in %.3f real sec\n", "mem_process_seqs", n, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+	bwagpu_free(u.all); u.all = nullptr;
+	if (u.opt.flag & F_PE) for (int i = 0; i + 1 < n; i += 2) if (w.seqs[u.idx[i]].name != w.seqs[u.idx[i + 1]].name) { fprintf(stderr, "[mem_sam_pe] paired reads have different names: \"%s\", \"%s\"\n", w.seqs[u.idx[i]].name.c_str(), w.seqs[u.idx[i + 1]].name.c_str()); exit(EXIT_FAILURE); }
+	std::vector<std::string> sam;
+	finalize_batch(u.opt, ref, u.n_processed, n, reads.data(), regs, (u.opt.flag & F_PE) ? pes0 : nullptr, u.opt.n_threads, rg_id, sam, g_verbose >= 3);
+	for (int i = 0; i < n; ++i) w.out[u.idx[i]].swap(sam[i]);
+	if (g_verbose >= 3) fprintf(stderr, "[M::%s] Processed %d reads in %.3f real sec\n", "mem_process_seqs", n, u.t_dev + (now_s() - t0));
 }
 
 static bool slurp(const std::string &fn, std::vector<char> &out)
@@ -296,39 +355,88 @@ int main(int argc, char *argv[])
 		printf("%s\n", pg.c_str());
 	}
 	const int chunk = fixed_chunk > 0 ? fixed_chunk : opt.chunk_size * opt.n_threads;
-	int64_t n_processed = 0;
-	std::vector<Seq> cur, nxt;
-	bool have = read_batch(r1, pr2, chunk, cur);
-	while (have) {
-		// overlap the next batch's input with this batch's compute (the role of kt_pipeline's step 0, kthread.c:119)
-		std::future<bool> fut = std::async(std::launch::async, [&]() { return read_batch(r1, pr2, chunk, nxt); });
-		long bp = 0; for (auto &s : cur) bp += (long)s.seq.size();
-		if (g_verbose >= 3) fprintf(stderr, "[M::%s] read %d sequences (%ld bp)...\n", "process", (int)cur.size(), bp);
-		const int n = (int)cur.size();
-		std::vector<std::string> out((size_t)n);
-		if (opt.flag & F_SMARTPE) {   // -p: adjacent records with equal names are pairs (bseq_classify, bwa.c:114-130)
-			std::vector<Seq*> se, pe; std::vector<int> ise, ipe;
-			bool has_last = true; int i;
-			for (i = 1; i < n; ++i) {
-				if (has_last) {
-					if (cur[i].name == cur[i - 1].name) { pe.push_back(&cur[i - 1]); pe.push_back(&cur[i]); ipe.push_back(i - 1); ipe.push_back(i); has_last = false; }
-					else { se.push_back(&cur[i - 1]); ise.push_back(i - 1); }
-				} else has_last = true;
+	const double t_start = now_s();
+	int n_dev = getenv("BWAGPU_CLI_STREAMS") ? atoi(getenv("BWAGPU_CLI_STREAMS")) : 2;      // batches in flight on the device
+	if (n_dev < 1) n_dev = 1;
+	std::vector<bwagpu_t*> handles(1, gpu);
+	for (int i = 1; i < n_dev; ++i) { bwagpu_t *h2 = nullptr; int rc = bwagpu_clone(gpu, &h2); if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s\n", "main_mem", bwagpu_strerror(rc)); return 1; } bwagpu_set_taps(h2, 0); handles.push_back(h2); }
+	Chan to_dev(2), to_out(2);
+	std::mutex dm; std::condition_variable dcv; std::map<long, WorkP> done; long next_fin = 0;   // device -> finalize, re-ordered
+	std::atomic<long> n_works(-1), n_reads_total(0);
+
+	std::thread reader([&] {      // stage 1: input, pairing classes, 2-bit encoding
+		int64_t n_processed = 0; long no = 0;
+		for (;;) {
+			WorkP w(new Work()); w->no = no;
+			if (!read_batch(r1, pr2, chunk, w->seqs)) break;
+			const int n = (int)w->seqs.size();
+			long bp = 0; for (auto &q : w->seqs) bp += (long)q.seq.size();
+			if (g_verbose >= 3) fprintf(stderr, "[M::%s] read %d sequences (%ld bp)...\n", "process", n, bp);
+			w->out.assign((size_t)n, std::string());
+			if (opt.flag & F_SMARTPE) {   // -p: adjacent records with equal names are pairs (bseq_classify, bwa.c:114-130)
+				Sub se, pe; bool has_last = true; int i;
+				for (i = 1; i < n; ++i) {
+					if (has_last) {
+						if (w->seqs[i].name == w->seqs[i - 1].name) { pe.idx.push_back(i - 1); pe.idx.push_back(i); has_last = false; }
+						else se.idx.push_back(i - 1);
+					} else has_last = true;
+				}
+				if (has_last) se.idx.push_back(i - 1);
+				se.opt = opt; se.opt.flag &= ~F_PE; se.n_processed = n_processed;
+				pe.opt = opt; pe.opt.flag |= F_PE; pe.n_processed = n_processed + (int64_t)se.idx.size();
+				if (!se.idx.empty()) w->subs.push_back(std::move(se));
+				if (!pe.idx.empty()) w->subs.push_back(std::move(pe));
+			} else {
+				Sub u; u.idx.resize((size_t)n); for (int i = 0; i < n; ++i) u.idx[i] = i;
+				u.opt = opt; u.n_processed = n_processed;
+				w->subs.push_back(std::move(u));
 			}
-			if (has_last) { se.push_back(&cur[i - 1]); ise.push_back(i - 1); }
-			bwagpu_opt_t tmp = opt; std::vector<std::string> sam;
-			if (!se.empty()) { tmp.flag &= ~F_PE; process_seqs(gpu, ref, tmp, n_processed, se, nullptr, rg_id.c_str(), copy_comment, sam); for (size_t k = 0; k < se.size(); ++k) out[ise[k]].swap(sam[k]); }
-			if (!pe.empty()) { tmp.flag |= F_PE; process_seqs(gpu, ref, tmp, n_processed + (int64_t)se.size(), pe, pes0, rg_id.c_str(), copy_comment, sam); for (size_t k = 0; k < pe.size(); ++k) out[ipe[k]].swap(sam[k]); }
-		} else {
-			std::vector<Seq*> all((size_t)n);
-			for (int i = 0; i < n; ++i) all[i] = &cur[i];
-			process_seqs(gpu, ref, opt, n_processed, all, pes0, rg_id.c_str(), copy_comment, out);
+			for (Sub &u : w->subs) encode_sub(w->seqs, u);
+			n_processed += n; ++no;
+			to_dev.push(std::move(w));
 		}
-		n_processed += n;
-		for (auto &s : out) fwrite(s.data(), 1, s.size(), stdout);
-		have = fut.get();
-		cur.swap(nxt);
+		n_works = no; n_reads_total = (long)n_processed;
+		to_dev.close();
+		{ std::lock_guard<std::mutex> l(dm); dcv.notify_all(); }
+	});
+
+	std::vector<std::thread> devs;
+	for (int d = 0; d < n_dev; ++d) devs.emplace_back([&, d] {      // stage 2: one host thread per device handle
+		WorkP w;
+		while (to_dev.pop(w)) {
+			{ std::unique_lock<std::mutex> l(dm); dcv.wait(l, [&] { return w->no - next_fin <= (long)n_dev; }); }   // do not run ahead of the host
+			for (Sub &u : w->subs) device_sub(handles[d], u);
+			std::lock_guard<std::mutex> l(dm);
+			const long no = w->no;
+			done[no] = std::move(w);
+			dcv.notify_all();
+		}
+	});
+
+	std::thread writer([&] {      // stage 4: output in input order
+		WorkP w;
+		while (to_out.pop(w)) for (auto &t : w->out) fwrite(t.data(), 1, t.size(), stdout);
+	});
+
+	for (;;) {                    // stage 3 (this thread drives the worker pool of finalize_batch)
+		WorkP w;
+		{
+			std::unique_lock<std::mutex> l(dm);
+			dcv.wait(l, [&] { return done.count(next_fin) || (n_works.load() >= 0 && next_fin >= n_works.load()); });
+			if (!done.count(next_fin)) break;
+			w = std::move(done[next_fin]); done.erase(next_fin);
+		}
+		for (Sub &u : w->subs) finalize_sub(ref, *w, u, pes0, rg_id.c_str(), copy_comment != 0);
+		w->seqs.clear(); w->subs.clear();
+		to_out.push(std::move(w));
+		{ std::lock_guard<std::mutex> l(dm); ++next_fin; dcv.notify_all(); }
 	}
+	reader.join();
+	for (auto &t : devs) t.join();
+	to_out.close();
+	writer.join();
+	if (g_verbose >= 3) { const double dt = now_s() - t_start; fprintf(stderr, "[M::%s] %ld reads in %.3f sec after the index was loaded: %.0f reads/s\n", "main_mem", n_reads_total.load(), dt, dt > 0 ? n_reads_total.load() / dt : 0.); }
+	for (size_t i = 1; i < handles.size(); ++i) bwagpu_destroy(handles[i]);
 	fflush(stdout);
 	bwagpu_destroy(gpu);
 	return 0;
