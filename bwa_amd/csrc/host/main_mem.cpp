@@ -60,7 +60,10 @@ static std::string unescape(const char *s)
 }
 
 // ---- FASTA/FASTQ input (what kseq_read + bseq_read deliver, kseq.h:175-220, bwa.c:79-112) ----------------------------
-struct Seq { std::string name, comment, seq, qual; bool has_comment = false, has_qual = false; };
+// One record = four NUL-terminated strings in its batch's text arena (no per-record allocation: the reader is a single
+// thread and sets the pace of the whole pipeline).
+struct Seq { size_t name = 0, comment = 0, seq = 0, qual = 0; int l_name = 0, l_seq = 0, l_qual = 0; bool has_comment = false, has_qual = false; };
+typedef std::vector<char> Arena;
 
 struct Reader {
 	gzFile fp = nullptr; std::vector<char> buf; int pos = 0, len = 0; int last = 0; bool eof = false;
@@ -69,70 +72,85 @@ struct Reader {
 	int getc_() { if (pos >= len && !fill()) return -1; return (unsigned char)buf[pos++]; }
 	// append the bytes up to the next delimiter (newline, or any white space when `space`) to `out` and consume the delimiter;
 	// returns the delimiter, or -1 at end of input.  Whole buffer spans are copied at once.
-	int until(bool space, std::string *out) {
+	int until(bool space, Arena *out) {
 		for (;;) {
 			if (pos >= len && !fill()) return -1;
 			const char *b = buf.data() + pos; const int n = len - pos; int k;
 			if (space) { for (k = 0; k < n && !isspace((unsigned char)b[k]); ++k) {} }
 			else { const char *q = (const char*)memchr(b, '\n', (size_t)n); k = q ? (int)(q - b) : n; }
-			if (out) out->append(b, (size_t)k);
+			if (out) out->insert(out->end(), b, b + k);
 			pos += k;
 			if (k < n) return (unsigned char)buf[pos++];
 		}
 	}
-	static void strip_cr(std::string &t) { while (!t.empty() && t.back() == '\r') t.pop_back(); }
-	bool read(Seq &s) {
+	// drop the characters of A[from..) for which `drop` holds
+	template <class P> static void squeeze(Arena &A, size_t from, P drop) { size_t w = from; for (size_t i = from; i < A.size(); ++i) if (!drop((unsigned char)A[i])) A[w++] = A[i]; A.resize(w); }
+	bool read(Seq &s, Arena &A) {
 		int c;
 		if (last == 0) { while ((c = getc_()) != -1 && c != '>' && c != '@') {} if (c == -1) return false; last = c; }
-		s.name.clear(); s.comment.clear(); s.seq.clear(); s.qual.clear(); s.has_comment = s.has_qual = false;
-		c = until(true, &s.name);
-		if (c != '\n' && c != -1) { s.has_comment = true; until(false, &s.comment); strip_cr(s.comment); }
-		if (!s.has_comment) strip_cr(s.name);
+		s = Seq();
+		s.name = A.size();
+		c = until(true, &A);
+		size_t name_end = A.size();
+		A.push_back(0);
+		s.comment = A.size();
+		if (c != '\n' && c != -1) { s.has_comment = true; until(false, &A); while (A.size() > s.comment && A.back() == '\r') A.pop_back(); }
+		else while (name_end > s.name && A[name_end - 1] == '\r') A[--name_end] = 0;
+		s.l_name = (int)(name_end - s.name);
+		A.push_back(0);
+		s.seq = A.size();
 		while ((c = getc_()) != -1 && c != '>' && c != '+' && c != '@') {
 			if (c == '\n') continue;
-			s.seq += (char)c;
-			until(false, &s.seq);
+			A.push_back((char)c);
+			until(false, &A);
 		}
-		while (!s.seq.empty() && isspace((unsigned char)s.seq.back())) s.seq.pop_back();
 		bool ws = false;
-		for (char ch : s.seq) if (isspace((unsigned char)ch)) { ws = true; break; }
-		if (ws) { std::string t; for (char ch : s.seq) if (!isspace((unsigned char)ch)) t += ch; s.seq.swap(t); }
+		for (size_t i = s.seq; i < A.size(); ++i) if (isspace((unsigned char)A[i])) { ws = true; break; }
+		if (ws) squeeze(A, s.seq, [](unsigned char ch) { return isspace(ch) != 0; });
+		s.l_seq = (int)(A.size() - s.seq);
+		A.push_back(0);
+		s.qual = A.size();
 		if (c == '>' || c == '@') last = c; else last = 0;
-		if (c != '+') return true;
-		if (until(false, nullptr) == -1) return true;          // skip the rest of the '+' line
+		if (c != '+') { A.push_back(0); return true; }
+		if (until(false, nullptr) == -1) { A.push_back(0); return true; }          // skip the rest of the '+' line
 		s.has_qual = true;
-		while (s.qual.size() < s.seq.size()) {
-			const size_t before = s.qual.size();
-			c = until(false, &s.qual);
-			const bool got = s.qual.size() > before;
-			if (memchr(s.qual.data() + before, '\r', s.qual.size() - before)) { std::string t(s.qual, 0, before); for (size_t i = before; i < s.qual.size(); ++i) if (s.qual[i] != '\r') t += s.qual[i]; s.qual.swap(t); }
+		while (A.size() - s.qual < (size_t)s.l_seq) {
+			const size_t before = A.size();
+			c = until(false, &A);
+			const bool got = A.size() > before;
+			if (memchr(A.data() + before, '\r', A.size() - before)) squeeze(A, before, [](unsigned char ch) { return ch == '\r'; });
 			if (c == -1 && !got) break;
 		}
+		s.l_qual = (int)(A.size() - s.qual);
+		A.push_back(0);
 		last = 0;
 		return true;
 	}
 };
 
-static void trim_readno(std::string &s) { if (s.size() > 2 && s[s.size() - 2] == '/' && isdigit((unsigned char)s.back())) s.resize(s.size() - 2); }
+// "/1" and "/2" name suffixes are dropped (trim_readno, bwa.c:66-71)
+static void trim_readno(Seq &s, Arena &A) { if (s.l_name > 2 && A[s.name + s.l_name - 2] == '/' && isdigit((unsigned char)A[s.name + s.l_name - 1])) { s.l_name -= 2; A[s.name + s.l_name] = 0; } }
 
-static bool read_batch(Reader &r1, Reader *r2, int chunk, std::vector<Seq> &out)
+struct Batch { Arena text; std::vector<Seq> seqs; };
+
+static bool read_batch(Reader &r1, Reader *r2, int chunk, Batch &out)
 {
-	out.clear();
-	long size = 0; Seq s;
-	while (r1.read(s)) {
-		Seq s2;
-		if (r2 && !r2->read(s2)) { fprintf(stderr, "[W::%s] the 2nd file has fewer sequences.\n", "bseq_read"); break; }
-		trim_readno(s.name); size += (long)s.seq.size(); out.push_back(s);
-		if (r2) { trim_readno(s2.name); size += (long)s2.seq.size(); out.push_back(s2); }
-		if (size >= chunk && (out.size() & 1) == 0) break;
+	out.seqs.clear(); out.text.clear();
+	long size = 0; Seq s, s2;
+	while (r1.read(s, out.text)) {
+		if (r2 && !r2->read(s2, out.text)) { fprintf(stderr, "[W::%s] the 2nd file has fewer sequences.\n", "bseq_read"); break; }
+		trim_readno(s, out.text); size += s.l_seq; out.seqs.push_back(s);
+		if (r2) { trim_readno(s2, out.text); size += s2.l_seq; out.seqs.push_back(s2); }
+		if (size >= chunk && (out.seqs.size() & 1) == 0) break;
 	}
-	return !out.empty();
+	return !out.seqs.empty();
 }
 
-static inline uint8_t nt4(unsigned char c)
-{	// nst_nt4_table (bntseq.c:46-63)
-	switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
-}
+struct Nt4 {   // nst_nt4_table (bntseq.c:46-63)
+	uint8_t t[256];
+	Nt4() { memset(t, 4, sizeof t); t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3; }
+};
+static const Nt4 g_nt4;
 
 // ---- batches flow through a four-stage pipeline: read+encode | device (hot path) | finalize (host threads) | write -------------
 // (the reference overlaps input, compute and output the same way with kt_pipeline, kthread.c:119; here the compute step is
@@ -143,7 +161,7 @@ struct Sub {      // one mem_process_seqs call (bwamem.c:1235-1264) on the reads
 	bwagpu_alnreg_t *all = nullptr; int64_t tot = 0;
 	double t_dev = 0;
 };
-struct Work { long no = 0; std::vector<Seq> seqs; std::vector<Sub> subs; std::vector<std::string> out; };
+struct Work { long no = 0; Batch in; std::vector<Sub> subs; std::vector<std::string> out; };
 typedef std::unique_ptr<Work> WorkP;
 
 struct Chan {     // bounded FIFO between two stages
@@ -156,13 +174,17 @@ struct Chan {     // bounded FIFO between two stages
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-static void encode_sub(const std::vector<Seq> &seqs, Sub &u)
+static void encode_sub(const Batch &in, Sub &u)
 {
 	const int n = (int)u.idx.size();
 	u.off.assign((size_t)n + 1, 0);
-	for (int i = 0; i < n; ++i) u.off[i + 1] = u.off[i] + (int64_t)seqs[u.idx[i]].seq.size();
+	for (int i = 0; i < n; ++i) u.off[i + 1] = u.off[i] + (int64_t)in.seqs[u.idx[i]].l_seq;
 	u.flat.resize((size_t)u.off[n] + 1);
-	for (int i = 0; i < n; ++i) { const std::string &q = seqs[u.idx[i]].seq; uint8_t *d = u.flat.data() + u.off[i]; for (size_t j = 0; j < q.size(); ++j) d[j] = nt4((unsigned char)q[j]); }
+	for (int i = 0; i < n; ++i) {
+		const Seq &q = in.seqs[u.idx[i]];
+		const unsigned char *src = (const unsigned char*)in.text.data() + q.seq; uint8_t *d = u.flat.data() + u.off[i];
+		for (int j = 0; j < q.l_seq; ++j) d[j] = g_nt4.t[src[j]];
+	}
 	u.counts.assign((size_t)n, 0);
 }
 
@@ -183,14 +205,15 @@ static void finalize_sub(const RefSeqs &ref, Work &w, Sub &u, const Pestat *pes0
 	std::vector<Regs> regs((size_t)n); std::vector<Read> reads((size_t)n);
 	int64_t k = 0;
 	for (int i = 0; i < n; ++i) {
-		const Seq &q = w.seqs[u.idx[i]];
+		const Seq &q = w.in.seqs[u.idx[i]];
+		const char *T = w.in.text.data();
 		regs[i].assign(u.all + k, u.all + k + u.counts[i]); k += u.counts[i];
-		reads[i].name = q.name.c_str();
-		reads[i].comment = copy_comment && q.has_comment ? q.comment.c_str() : nullptr;
-		reads[i].seq = u.flat.data() + u.off[i]; reads[i].qual = q.has_qual ? q.qual.c_str() : nullptr; reads[i].l_seq = (int)q.seq.size();
+		reads[i].name = T + q.name;
+		reads[i].comment = copy_comment && q.has_comment ? T + q.comment : nullptr;
+		reads[i].seq = u.flat.data() + u.off[i]; reads[i].qual = q.has_qual ? T + q.qual : nullptr; reads[i].l_seq = q.l_seq;
 	}
 	bwagpu_free(u.all); u.all = nullptr;
-	if (u.opt.flag & F_PE) for (int i = 0; i + 1 < n; i += 2) if (w.seqs[u.idx[i]].name != w.seqs[u.idx[i + 1]].name) { fprintf(stderr, "[mem_sam_pe] paired reads have different names: \"%s\", \"%s\"\n", w.seqs[u.idx[i]].name.c_str(), w.seqs[u.idx[i + 1]].name.c_str()); exit(EXIT_FAILURE); }
+	if (u.opt.flag & F_PE) for (int i = 0; i + 1 < n; i += 2) if (strcmp(reads[i].name, reads[i + 1].name) != 0) { fprintf(stderr, "[mem_sam_pe] paired reads have different names: \"%s\", \"%s\"\n", reads[i].name, reads[i + 1].name); exit(EXIT_FAILURE); }
 	std::vector<std::string> sam;
 	finalize_batch(u.opt, ref, u.n_processed, n, reads.data(), regs, (u.opt.flag & F_PE) ? pes0 : nullptr, u.opt.n_threads, rg_id, sam, g_verbose >= 3);
 	for (int i = 0; i < n; ++i) w.out[u.idx[i]].swap(sam[i]);
@@ -363,21 +386,23 @@ int main(int argc, char *argv[])
 	Chan to_dev(2), to_out(2);
 	std::mutex dm; std::condition_variable dcv; std::map<long, WorkP> done; long next_fin = 0;   // device -> finalize, re-ordered
 	std::atomic<long> n_works(-1), n_reads_total(0);
+	double busy_read = 0, busy_fin = 0, busy_write = 0; std::atomic<long> busy_dev_us(0);   // per-stage busy time (-v 3 summary)
 
 	std::thread reader([&] {      // stage 1: input, pairing classes, 2-bit encoding
 		int64_t n_processed = 0; long no = 0;
 		for (;;) {
 			WorkP w(new Work()); w->no = no;
-			if (!read_batch(r1, pr2, chunk, w->seqs)) break;
-			const int n = (int)w->seqs.size();
-			long bp = 0; for (auto &q : w->seqs) bp += (long)q.seq.size();
+			const double tr = now_s();
+			if (!read_batch(r1, pr2, chunk, w->in)) break;
+			const int n = (int)w->in.seqs.size();
+			long bp = 0; for (auto &q : w->in.seqs) bp += (long)q.l_seq;
 			if (g_verbose >= 3) fprintf(stderr, "[M::%s] read %d sequences (%ld bp)...\n", "process", n, bp);
 			w->out.assign((size_t)n, std::string());
 			if (opt.flag & F_SMARTPE) {   // -p: adjacent records with equal names are pairs (bseq_classify, bwa.c:114-130)
 				Sub se, pe; bool has_last = true; int i;
 				for (i = 1; i < n; ++i) {
 					if (has_last) {
-						if (w->seqs[i].name == w->seqs[i - 1].name) { pe.idx.push_back(i - 1); pe.idx.push_back(i); has_last = false; }
+						if (strcmp(w->in.text.data() + w->in.seqs[i].name, w->in.text.data() + w->in.seqs[i - 1].name) == 0) { pe.idx.push_back(i - 1); pe.idx.push_back(i); has_last = false; }
 						else se.idx.push_back(i - 1);
 					} else has_last = true;
 				}
@@ -391,8 +416,9 @@ int main(int argc, char *argv[])
 				u.opt = opt; u.n_processed = n_processed;
 				w->subs.push_back(std::move(u));
 			}
-			for (Sub &u : w->subs) encode_sub(w->seqs, u);
+			for (Sub &u : w->subs) encode_sub(w->in, u);
 			n_processed += n; ++no;
+			busy_read += now_s() - tr;
 			to_dev.push(std::move(w));
 		}
 		n_works = no; n_reads_total = (long)n_processed;
@@ -405,7 +431,7 @@ int main(int argc, char *argv[])
 		WorkP w;
 		while (to_dev.pop(w)) {
 			{ std::unique_lock<std::mutex> l(dm); dcv.wait(l, [&] { return w->no - next_fin <= (long)n_dev; }); }   // do not run ahead of the host
-			for (Sub &u : w->subs) device_sub(handles[d], u);
+			for (Sub &u : w->subs) { device_sub(handles[d], u); busy_dev_us += (long)(u.t_dev * 1e6); }
 			std::lock_guard<std::mutex> l(dm);
 			const long no = w->no;
 			done[no] = std::move(w);
@@ -415,7 +441,7 @@ int main(int argc, char *argv[])
 
 	std::thread writer([&] {      // stage 4: output in input order
 		WorkP w;
-		while (to_out.pop(w)) for (auto &t : w->out) fwrite(t.data(), 1, t.size(), stdout);
+		while (to_out.pop(w)) { const double tw = now_s(); for (auto &t : w->out) fwrite(t.data(), 1, t.size(), stdout); busy_write += now_s() - tw; }
 	});
 
 	for (;;) {                    // stage 3 (this thread drives the worker pool of finalize_batch)
@@ -426,8 +452,10 @@ int main(int argc, char *argv[])
 			if (!done.count(next_fin)) break;
 			w = std::move(done[next_fin]); done.erase(next_fin);
 		}
+		const double tf = now_s();
 		for (Sub &u : w->subs) finalize_sub(ref, *w, u, pes0, rg_id.c_str(), copy_comment != 0);
-		w->seqs.clear(); w->subs.clear();
+		busy_fin += now_s() - tf;
+		w->in = Batch(); w->subs.clear();
 		to_out.push(std::move(w));
 		{ std::lock_guard<std::mutex> l(dm); ++next_fin; dcv.notify_all(); }
 	}
@@ -435,7 +463,8 @@ int main(int argc, char *argv[])
 	for (auto &t : devs) t.join();
 	to_out.close();
 	writer.join();
-	if (g_verbose >= 3) { const double dt = now_s() - t_start; fprintf(stderr, "[M::%s] %ld reads in %.3f sec after the index was loaded: %.0f reads/s\n", "main_mem", n_reads_total.load(), dt, dt > 0 ? n_reads_total.load() / dt : 0.); }
+	if (g_verbose >= 3) { const double dt = now_s() - t_start; fprintf(stderr, "[M::%s] %ld reads in %.3f sec after the index was loaded: %.0f reads/s\n", "main_mem", n_reads_total.load(), dt, dt > 0 ? n_reads_total.load() / dt : 0.);
+		fprintf(stderr, "[M::%s] stage busy time: read+encode %.3f s, device %.3f s (over %d handles), finalize %.3f s, write %.3f s\n", "main_mem", busy_read, busy_dev_us.load() * 1e-6, n_dev, busy_fin, busy_write); }
 	for (size_t i = 1; i < handles.size(); ++i) bwagpu_destroy(handles[i]);
 	fflush(stdout);
 	bwagpu_destroy(gpu);

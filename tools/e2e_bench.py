@@ -41,6 +41,9 @@ def main():
             p = subprocess.run([cli, "mem", "-t", th, "-K", a.chunk, "-v", "3", fa] + files, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=env)
             m = re.search(r"\[M::main_mem\] (\d+) reads in ([\d.]+) sec .*: (\d+) reads/s", p.stderr)
             print(f"[e2e] {'PE' if a.pe else 'SE'} -t {th} streams {st} -K {a.chunk}: rc={p.returncode} {m.group(0) if m else p.stderr[-300:]}  (process wall {time.time() - t:.1f}s)", flush=True)
+            m2 = re.search(r"stage busy time: .*", p.stderr)
+            if m2:
+                print("[e2e]    " + m2.group(0), flush=True)
 
 
 if __name__ == "__main__":
