@@ -61,7 +61,7 @@ struct bwagpu_s {
 	bool have_batch = false, ran = false;
 	int stats_on = 0, taps_on = 1;
 	bwagpu_stats_t stats = {};
-	DevBuf d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
+	DevBuf d_pack_off, d_regs_packed, d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
 	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_blob;
 	DevBuf d_order, d_bin_cnt, d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
 	i64 slot_cap = 0, node_cap = 0, reg_cap = 0; int mem_cap = 0;
@@ -212,7 +212,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 		for (DevBuf *b : ib) b->release();
 		delete h->ibuf;
 	}
-	DevBuf *all[] = { &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
+	DevBuf *all[] = { &h->d_pack_off, &h->d_regs_packed, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
@@ -587,12 +587,46 @@ static int gather(bwagpu_t *h, const DevBuf &d_n, const DevBuf &d_off, const Dev
 	return BWAGPU_OK;
 }
 
+// The region arena is sparse (every read owns a range sized for its worst case); pack the used records on the device so
+// that only they cross PCIe.  One lane per read, 88-byte records copied as 11 x u64.
+__global__ void __launch_bounds__(256) k_pack_regs(int n, const i32 *reg_n, const i64 *reg_off, const bwagpu_alnreg_t *regs, const i64 *dst_off, bwagpu_alnreg_t *dst)
+{
+	static_assert(sizeof(bwagpu_alnreg_t) == 88, "layout");
+	for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+		const int c = reg_n[r];
+		const u64 *src = (const u64*)(regs + reg_off[r]); u64 *d = (u64*)(dst + dst_off[r]);
+		for (int k = 0; k < c * 11; ++k) d[k] = src[k];
+	}
+}
+
 extern "C" int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg_t **regs_out, int64_t *n_regs_out)
 {
 	if (!h || !h->ran || !regs_out || !n_regs_out) return BWAGPU_EINVAL;
 	HIPCHK(h, hipSetDevice(h->device));
-	if (h->n_reads == 0) { *regs_out = (bwagpu_alnreg_t*)malloc(sizeof(bwagpu_alnreg_t)); *n_regs_out = 0; return BWAGPU_OK; }
-	return gather<bwagpu_alnreg_t>(h, h->d_reg_n, h->d_reg_off, h->d_regs, h->reg_cap, counts, regs_out, n_regs_out);
+	const int n = h->n_reads;
+	if (n == 0) { *regs_out = (bwagpu_alnreg_t*)malloc(sizeof(bwagpu_alnreg_t)); *n_regs_out = 0; return BWAGPU_OK; }
+	std::vector<i32> cnt((size_t)n); std::vector<i64> dst((size_t)n);
+	HIPCHK(h, hipMemcpyAsync(cnt.data(), h->d_reg_n.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, hipStreamSynchronize(h->stream));
+	i64 tot = 0;
+	for (int i = 0; i < n; ++i) { dst[i] = tot; tot += cnt[i]; if (counts) counts[i] = cnt[i]; }
+	bwagpu_alnreg_t *res = (bwagpu_alnreg_t*)malloc((size_t)(tot ? tot : 1) * sizeof(bwagpu_alnreg_t));
+	if (!res) return BWAGPU_ENOMEM;
+	if (tot) {
+		if (h->d_pack_off.ensure((size_t)n * 8) || h->d_regs_packed.ensure((size_t)tot * sizeof(bwagpu_alnreg_t))) { free(res); h->err = "hipMalloc failed (packed regions)"; return BWAGPU_ENOMEM; }
+		hipError_t e = hipMemcpyAsync(h->d_pack_off.p, dst.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream);
+		if (e == hipSuccess) {
+			int nb = (n + BLOCK - 1) / BLOCK; if (nb > 8192) nb = 8192;
+			hipLaunchKernelGGL(k_pack_regs, dim3(nb), dim3(BLOCK), 0, h->stream, n, h->d_reg_n.as<i32>(), h->d_reg_off.as<i64>(), h->d_regs.as<bwagpu_alnreg_t>(),
+							   h->d_pack_off.as<i64>(), h->d_regs_packed.as<bwagpu_alnreg_t>());
+			e = hipGetLastError();
+		}
+		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_regs_packed.p, (size_t)tot * sizeof(bwagpu_alnreg_t), hipMemcpyDeviceToHost, h->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+		if (e != hipSuccess) { free(res); HIPCHK(h, e); }
+	}
+	*regs_out = res; *n_regs_out = tot;
+	return BWAGPU_OK;
 }
 
 extern "C" int bwagpu_align_flat(bwagpu_t *h, const bwagpu_opt_t *opt, int n, const uint8_t *seqs, const int64_t *off,

@@ -12,6 +12,8 @@
 #pragma once
 #include <stdint.h>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include "../../../include/bwagpu.h"
 
@@ -46,6 +48,17 @@ struct Read {   // == bseq1_t as the finalize code needs it
 };
 
 typedef std::vector<bwagpu_alnreg_t> Regs;
+
+// kt_for-like (kthread.c:49): the per-read outputs are independent, so any work split gives the same result
+template <class F> static inline void parallel_for(int n_threads, long n, F f)
+{
+	if (n_threads <= 1 || n <= 1) { for (long i = 0; i < n; ++i) f(i); return; }
+	std::atomic<long> next(0);
+	std::vector<std::thread> th;
+	for (int t = 0; t < n_threads; ++t)
+		th.emplace_back([&]() { for (;;) { long i = next.fetch_add(16); if (i >= n) break; long e = i + 16 < n ? i + 16 : n; for (; i < e; ++i) f(i); } });
+	for (auto &t : th) t.join();
+}
 
 uint64_t hash_64(uint64_t key);                                     // utils.h:98-109
 int mark_primary_se(const bwagpu_opt_t &opt, Regs &a, int64_t id);  // bwamem.c:547-584

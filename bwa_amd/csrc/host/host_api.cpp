@@ -9,17 +9,6 @@
 
 namespace hostmem {
 
-// kt_for-like (kthread.c:49): the per-read outputs are independent, so any work split gives the same result
-template <class F> static void parallel_for(int n_threads, long n, F f)
-{
-	if (n_threads <= 1 || n <= 1) { for (long i = 0; i < n; ++i) f(i); return; }
-	std::atomic<long> next(0);
-	std::vector<std::thread> th;
-	for (int t = 0; t < n_threads; ++t)
-		th.emplace_back([&]() { for (;;) { long i = next.fetch_add(16); if (i >= n) break; long e = i + 16 < n ? i + 16 : n; for (; i < e; ++i) f(i); } });
-	for (auto &t : th) t.join();
-}
-
 // regs[i] for all reads of a batch -> SAM text per read (sam[i]); PE when opt.flag & F_PE (mates interleaved)
 void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_processed, int n, const Read *reads, std::vector<Regs> &regs,
 					const Pestat *pes0, int n_threads, const char *rg_id, std::vector<std::string> &sam, bool verbose)
@@ -32,12 +21,14 @@ void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_proce
 			std::string out[2];
 			sam_pe(opt, ref, pes, (uint64_t)((n_processed >> 1) + i), &reads[i << 1], &regs[i << 1], out, rg_id);
 			sam[i << 1].swap(out[0]); sam[i << 1 | 1].swap(out[1]);
+			Regs().swap(regs[i << 1]); Regs().swap(regs[i << 1 | 1]);
 		});
 	} else {
 		parallel_for(n_threads, n, [&](long i) {
 			mark_primary_se(opt, regs[i], n_processed + i);
 			if (opt.flag & F_PRIMARY5) reorder_primary5(opt.T, regs[i]);
 			reg2sam(opt, ref, sam[i], reads[i], regs[i], 0, 0, rg_id);
+			Regs().swap(regs[i]);      // release in the worker: the caller would otherwise free a million small blocks serially
 		});
 	}
 }

@@ -203,15 +203,16 @@ static void finalize_sub(const RefSeqs &ref, Work &w, Sub &u, const Pestat *pes0
 	const double t0 = now_s();
 	const int n = (int)u.idx.size();
 	std::vector<Regs> regs((size_t)n); std::vector<Read> reads((size_t)n);
-	int64_t k = 0;
-	for (int i = 0; i < n; ++i) {
+	std::vector<int64_t> roff((size_t)n + 1, 0);
+	for (int i = 0; i < n; ++i) roff[i + 1] = roff[i] + u.counts[i];
+	parallel_for(u.opt.n_threads, n, [&](long i) {
 		const Seq &q = w.in.seqs[u.idx[i]];
 		const char *T = w.in.text.data();
-		regs[i].assign(u.all + k, u.all + k + u.counts[i]); k += u.counts[i];
+		regs[i].assign(u.all + roff[i], u.all + roff[i + 1]);
 		reads[i].name = T + q.name;
 		reads[i].comment = copy_comment && q.has_comment ? T + q.comment : nullptr;
 		reads[i].seq = u.flat.data() + u.off[i]; reads[i].qual = q.has_qual ? T + q.qual : nullptr; reads[i].l_seq = q.l_seq;
-	}
+	});
 	bwagpu_free(u.all); u.all = nullptr;
 	if (u.opt.flag & F_PE) for (int i = 0; i + 1 < n; i += 2) if (strcmp(reads[i].name, reads[i + 1].name) != 0) { fprintf(stderr, "[mem_sam_pe] paired reads have different names: \"%s\", \"%s\"\n", reads[i].name, reads[i + 1].name); exit(EXIT_FAILURE); }
 	std::vector<std::string> sam;
