@@ -28,6 +28,10 @@ GSEED_DTYPE = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4"), ("scor
 assert GCHAIN_DTYPE.itemsize == 32 and GSEED_DTYPE.itemsize == 24
 
 
+CIGAR_DTYPE = np.dtype([("score", "<i4"), ("n_cigar", "<i4"), ("cigar", "<u4", (6,))])   # bwagpu_cigar_t
+assert CIGAR_DTYPE.itemsize == 32
+
+
 class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "n_reads", "n_bases", "n_intv", "n_seeds", "n_chains", "n_regs_raw", "n_regs", "n_occ_blocks", "n_lf_steps",
@@ -44,6 +48,7 @@ EXPORTS = [
     "bwagpu_index_info", "bwagpu_densify_sa", "bwagpu_set_stats", "bwagpu_get_stats", "bwagpu_align_bseq", "bwagpu_align_flat",
     "bwagpu_free", "bwagpu_batch_upload", "bwagpu_batch_run", "bwagpu_batch_download", "bwagpu_set_taps", "bwagpu_tap_intervals",
     "bwagpu_tap_chains", "bwagpu_tap_regs_raw", "bwagpu_index_buffers", "bwagpu_index_export", "bwagpu_clone", "bwagpu_index_ready",
+    "bwagpu_batch_cigars",
 ]
 
 
@@ -77,6 +82,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.bwagpu_batch_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.bwagpu_batch_run.argtypes = [C.c_void_p, C.c_void_p]
     L.bwagpu_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bwagpu_batch_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwagpu_tap_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwagpu_tap_chains.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwagpu_tap_regs_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -189,6 +195,12 @@ class BwaGpu:
         n = C.c_int64()
         self._chk(self.L.bwagpu_batch_download(self.h, counts.ctypes.data, C.byref(p), C.byref(n)))
         return counts, self._take(p, n.value, ALNREG_DTYPE)
+
+    def cigars(self, opt: MemOpt):
+        """bwagpu_batch_cigars: one CIGAR_DTYPE record per region of the last download(), in its order."""
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.bwagpu_batch_cigars(self.h, C.byref(opt), C.byref(p), C.byref(n)))
+        return self._take(p, n.value, CIGAR_DTYPE)
 
     def align(self, opt: MemOpt, seqs: np.ndarray, off: np.ndarray):
         self.upload(seqs, off)

@@ -27,6 +27,7 @@
 #include "dev_extw.h"
 #include "dev_dedup.h"
 #include "dev_seedsw.h"
+#include "dev_cigar.h"
 
 #define BWAGPU_VERSION "bwagpu 0.1 (gfx950)"
 
@@ -61,7 +62,8 @@ struct bwagpu_s {
 	bool have_batch = false, ran = false;
 	int stats_on = 0, taps_on = 1;
 	bwagpu_stats_t stats = {};
-	DevBuf d_pack_off, d_regs_packed, d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
+	i64 packed_tot = -1;          // regions packed by the last bwagpu_batch_download (-1: none)
+	DevBuf d_pack_off, d_regs_packed, d_pack_read, d_cigs, d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
 	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_blob;
 	DevBuf d_order, d_bin_cnt, d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
 	i64 slot_cap = 0, node_cap = 0, reg_cap = 0; int mem_cap = 0;
@@ -212,7 +214,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 		for (DevBuf *b : ib) b->release();
 		delete h->ibuf;
 	}
-	DevBuf *all[] = { &h->d_pack_off, &h->d_regs_packed, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
+	DevBuf *all[] = { &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
@@ -386,7 +388,7 @@ extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, cons
 {
 	if (!h || n < 0 || (n > 0 && (!seqs || !off))) return BWAGPU_EINVAL;
 	HIPCHK(h, hipSetDevice(h->device));
-	h->have_batch = false; h->ran = false;
+	h->have_batch = false; h->ran = false; h->packed_tot = -1;
 	h->n_reads = n; h->max_len = 0; h->n_bases = n ? off[n] - off[0] : 0;
 	if (n && off[0] != 0) return BWAGPU_EINVAL;
 	for (int i = 0; i < n; ++i) {
@@ -589,13 +591,14 @@ static int gather(bwagpu_t *h, const DevBuf &d_n, const DevBuf &d_off, const Dev
 
 // The region arena is sparse (every read owns a range sized for its worst case); pack the used records on the device so
 // that only they cross PCIe.  One lane per read, 88-byte records copied as 11 x u64.
-__global__ void __launch_bounds__(256) k_pack_regs(int n, const i32 *reg_n, const i64 *reg_off, const bwagpu_alnreg_t *regs, const i64 *dst_off, bwagpu_alnreg_t *dst)
+__global__ void __launch_bounds__(256) k_pack_regs(int n, const i32 *reg_n, const i64 *reg_off, const bwagpu_alnreg_t *regs, const i64 *dst_off, bwagpu_alnreg_t *dst, i32 *dst_read)
 {
 	static_assert(sizeof(bwagpu_alnreg_t) == 88, "layout");
 	for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
 		const int c = reg_n[r];
 		const u64 *src = (const u64*)(regs + reg_off[r]); u64 *d = (u64*)(dst + dst_off[r]);
 		for (int k = 0; k < c * 11; ++k) d[k] = src[k];
+		for (int k = 0; k < c; ++k) dst_read[dst_off[r] + k] = r;
 	}
 }
 
@@ -613,19 +616,49 @@ extern "C" int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg
 	bwagpu_alnreg_t *res = (bwagpu_alnreg_t*)malloc((size_t)(tot ? tot : 1) * sizeof(bwagpu_alnreg_t));
 	if (!res) return BWAGPU_ENOMEM;
 	if (tot) {
-		if (h->d_pack_off.ensure((size_t)n * 8) || h->d_regs_packed.ensure((size_t)tot * sizeof(bwagpu_alnreg_t))) { free(res); h->err = "hipMalloc failed (packed regions)"; return BWAGPU_ENOMEM; }
+		if (h->d_pack_off.ensure((size_t)n * 8) || h->d_regs_packed.ensure((size_t)tot * sizeof(bwagpu_alnreg_t)) || h->d_pack_read.ensure((size_t)tot * 4)) { free(res); h->err = "hipMalloc failed (packed regions)"; return BWAGPU_ENOMEM; }
 		hipError_t e = hipMemcpyAsync(h->d_pack_off.p, dst.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream);
 		if (e == hipSuccess) {
 			int nb = (n + BLOCK - 1) / BLOCK; if (nb > 8192) nb = 8192;
 			hipLaunchKernelGGL(k_pack_regs, dim3(nb), dim3(BLOCK), 0, h->stream, n, h->d_reg_n.as<i32>(), h->d_reg_off.as<i64>(), h->d_regs.as<bwagpu_alnreg_t>(),
-							   h->d_pack_off.as<i64>(), h->d_regs_packed.as<bwagpu_alnreg_t>());
+							   h->d_pack_off.as<i64>(), h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_pack_read.as<i32>());
 			e = hipGetLastError();
 		}
 		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_regs_packed.p, (size_t)tot * sizeof(bwagpu_alnreg_t), hipMemcpyDeviceToHost, h->stream);
 		if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
 		if (e != hipSuccess) { free(res); HIPCHK(h, e); }
 	}
+	h->packed_tot = tot;
 	*regs_out = res; *n_regs_out = tot;
+	return BWAGPU_OK;
+}
+
+extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_cigar_t **out, int64_t *n_out)
+{
+	if (!h || !opt || !h->ran || h->packed_tot < 0 || !out || !n_out) return BWAGPU_EINVAL;
+	if (opt->e_del <= 0 || opt->e_ins <= 0) return BWAGPU_EINVAL;
+	HIPCHK(h, hipSetDevice(h->device));
+	const i64 tot = h->packed_tot;
+	static_assert(sizeof(bwagpu_cigar_t) == 32, "layout");
+	bwagpu_cigar_t *res = (bwagpu_cigar_t*)malloc((size_t)(tot ? tot : 1) * sizeof(bwagpu_cigar_t));
+	if (!res) return BWAGPU_ENOMEM;
+	if (tot) {
+		if (h->d_cigs.ensure((size_t)tot * sizeof(bwagpu_cigar_t)) || h->d_ctr.ensure(sizeof(Counters))) { free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
+		Batch B = {}; B.seq = h->d_seq.as<u8>(); B.off = h->d_off.as<i64>(); B.n_reads = h->n_reads; B.max_len = h->max_len;
+		unsigned long long *next = &h->d_ctr.as<Counters>()->next_ext;
+		hipError_t e = hipMemsetAsync(next, 0, sizeof(unsigned long long), h->stream);
+		if (e == hipSuccess) {
+			const int lds_wave = CIG_LDS_BYTES;
+			i64 nblk = (tot + 3) / 4, cap = 256 * 6;
+			hipLaunchKernelGGL(k_cigar, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(BLOCK), (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, tot,
+							   h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_pack_read.as<i32>(), h->d_cigs.as<bwagpu_cigar_t>(), next);
+			e = hipGetLastError();
+		}
+		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_cigs.p, (size_t)tot * sizeof(bwagpu_cigar_t), hipMemcpyDeviceToHost, h->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+		if (e != hipSuccess) { free(res); HIPCHK(h, e); }
+	}
+	*out = res; *n_out = tot;
 	return BWAGPU_OK;
 }
 

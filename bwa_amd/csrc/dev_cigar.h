@@ -1,0 +1,192 @@
+// dev_cigar.h -- banded global alignment with traceback for the final regions: what mem_reg2aln (bwamem.c:1119-1152)
+// obtains from bwa_gen_cigar2 (bwa.c:148-234) / ksw_global2 (ksw.c:540-642), one wavefront per region.
+//
+// ksw_global2 opens gaps from the diagonal term M as ksw_extend2 does, so a DP row is again a max-plus prefix scan over
+// M(i,.): lanes own the columns of the band (at most 64, i.e. w <= 31), rows are sequential.  The per-column state
+// {H(i-1,j-1), E(i,j)}, the query profile and the direction bytes live in LDS; lane 0 walks the direction bytes back.
+// All integers are those of the scalar recurrence (including the -2^30 "minus infinity" terms), so direction bytes,
+// score and CIGAR are identical to the host's.  Regions outside the kernel's limits (band wider than 64 columns, more
+// than CIG_Z_CELLS direction bytes, more than CIG_MAX_OPS operations, windows spanning the forward/reverse boundary) are
+// flagged n_cigar = -1 and left to the caller's own bwa_gen_cigar2.
+#pragma once
+#include "dev_extw.h"
+
+#define CIG_NEG_INF (-0x40000000)
+#define CIG_MAX_LEN 320        // longest query / target segment handled here
+#define CIG_Z_CELLS 10240      // DP cells whose direction nibbles fit one wave's LDS region (two rows per byte)
+#define CIG_MAX_OPS 6          // operations kept per record (bwagpu_cigar_t)
+#define CIG_TMP_OPS 64
+
+struct CigLds { i32 *hd, *e; int8_t *qp; u8 *z; u32 *ops; int qstride; };
+#define CIG_LDS_BYTES ((2 * (CIG_MAX_LEN + 2 + 64) * 4 + 5 * (CIG_MAX_LEN + 64) + CIG_Z_CELLS / 2 + 64 + CIG_TMP_OPS * 4 + 15) & ~15)   // per wave
+
+// ksw_global2 (ksw.c:540-642).  Returns the score; *n_ops < 0 when the traceback does not fit CIG_TMP_OPS.  Operations are
+// left in L.ops in traceback (reversed) order, run-length merged.
+__device__ int wave_ksw_global2(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen, i64 t0, int tdir, int tlen,
+								int w, const CigLds &L, int *n_ops)
+{
+	const int lane = threadIdx.x & 63;
+	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+	const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+	i32 *hd = L.hd, *e_ = L.e; int8_t *qp = L.qp; u8 *z = L.z; const int qs = L.qstride;
+	for (int k = 0; k < 5; ++k)
+		for (int j = lane; j < qlen; j += 64) qp[k * qs + j] = opt.mat[k * 5 + q[q0 + j * qdir]];
+	for (int j = lane; j <= qlen; j += 64) {      // first row (ksw.c:566-570)
+		hd[j] = j == 0 ? 0 : (j <= w ? -(o_ins + e_ins * j) : CIG_NEG_INF);
+		e_[j] = CIG_NEG_INF;
+	}
+	wave_sync();
+	int treg = 0;
+	for (int i = 0; i < tlen; ++i) {
+		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
+		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
+		const int beg = i > w ? i - w : 0, end = i + w + 1 < qlen ? i + w + 1 : qlen;
+		const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : CIG_NEG_INF;
+		const int j = beg + lane; const bool act = j < end;
+		const int dg = hd[j], ec = e_[j];                 // padded arrays: inactive lanes read, never write
+		const int sc = qp[tb * qs + j];
+		wave_sync();
+		const int m = dg + sc;
+		// F(i,j) = max( -inf - (j-beg) e_ins , max_{beg<=k<j} m_k - oe_ins - (j-1-k) e_ins ): the scalar chain f <- max(f - e, m - oe)
+		const int a = act ? m - oe_ins + j * e_ins : I32_MIN;
+		const int inc = wave_incl_scan_max(a);
+		const int exc = wave_shift_up1(inc, I32_MIN);
+		int f = CIG_NEG_INF - (j - beg) * e_ins;
+		if (lane > 0 && exc != I32_MIN) f = imax(f, exc - (j - 1) * e_ins);
+		int d = m >= ec ? 0 : 1, h = m >= ec ? m : ec;
+		if (h < f) { d = 2; h = f; }
+		int t = m - oe_del, en = ec - e_del;
+		if (en > t) d |= 1 << 2; else en = t;
+		t = m - oe_ins; const int fn = f - e_ins;
+		if (fn > t) d |= 2 << 4;
+		if (act) {
+			e_[j] = en;
+			hd[j + 1] = h;
+			// direction nibble {H source (2 bits), E continues, F continues}; rows 2r and 2r+1 of a band column share a byte and
+			// are written by the same lane
+			const u32 nib = (u32)(d & 7) | (u32)(d >> 5 & 1) << 3;
+			u8 *zb = z + (i >> 1) * n_col + lane;
+			*zb = (i & 1) ? (u8)(*zb | nib << 4) : (u8)nib;
+		}
+		if (lane == 0) { hd[beg] = h1_init; }
+		wave_sync();
+		if (lane == 0) e_[end] = CIG_NEG_INF;            // hd[end] = H(i,end-1) was written by the last active lane
+		wave_sync();
+	}
+	const int score = hd[qlen];
+	// traceback (ksw.c:624-639), lane 0; the other lanes wait at the barrier below
+	int n = 0;
+	if (lane == 0) {
+		u32 *ops = L.ops;
+		int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, which = 0;
+		auto push = [&](int op, int len) {
+			if (n > 0 && (int)(ops[n - 1] & 0xf) == op) ops[n - 1] += (u32)len << 4;
+			else if (n < CIG_TMP_OPS) ops[n++] = (u32)len << 4 | (u32)op;
+			else n = CIG_TMP_OPS + 1;
+		};
+		while (i >= 0 && k >= 0 && n <= CIG_TMP_OPS) {
+			const u32 nib = z[(i >> 1) * n_col + (k - (i > w ? i - w : 0))] >> ((i & 1) << 2) & 15;
+			// states: 0 = in H (take its source), 1 = in E (continue the deletion?), 2 = in F (continue the insertion?)
+			which = which == 0 ? (int)(nib & 3) : which == 1 ? (int)(nib >> 2 & 1) : (int)(nib >> 3 & 1) << 1;
+			if (which == 0) { push(0, 1); --i; --k; }
+			else if (which == 1) { push(2, 1); --i; }
+			else { push(1, 1); --k; }
+		}
+		if (n <= CIG_TMP_OPS && i >= 0) push(2, i + 1);
+		if (n <= CIG_TMP_OPS && k >= 0) push(1, k + 1);
+	}
+	n = __builtin_amdgcn_readlane(n, 0);
+	wave_sync();
+	*n_ops = n > CIG_TMP_OPS ? -1 : n;
+	return score;
+}
+
+DEVFN int dev_infer_bw(int l1, int l2, int score, int a, int q, int r)
+{	// infer_bw (bwamem.c:818-825)
+	if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
+	int w = (int)((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.);
+	const int d = l1 > l2 ? l1 - l2 : l2 - l1;
+	if (w < d) w = d;
+	return w;
+}
+
+// One region: the band-doubling loop of mem_reg2aln (bwamem.c:1143-1152) around bwa_gen_cigar2 (bwa.c:148-195).
+__device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *query, const bwagpu_alnreg_t &p, const CigLds &L, bwagpu_cigar_t *out)
+{
+	const int lane = threadIdx.x & 63;
+	const i64 rb = uni64(p.rb), re = uni64(p.re), l_pac = ix.l_pac;
+	const int qb = uni(p.qb), qe = uni(p.qe), truesc = uni(p.truesc), pw = uni(p.w);
+	const int l_query = qe - qb;
+	int res_score = 0, res_n = -1;
+	const bool ok_shape = l_query > 0 && rb < re && !(rb < l_pac && re > l_pac) && l_query <= CIG_MAX_LEN && re - rb <= CIG_MAX_LEN;
+	if (ok_shape) {
+		const int rlen = (int)(re - rb);
+		const bool rev = rb >= l_pac;            // both sequences reversed so that gaps are left-aligned on the forward strand (bwa.c:163-170)
+		const int q0 = rev ? qe - 1 : qb, qdir = rev ? -1 : 1;
+		const i64 t0 = rev ? re - 1 : rb; const int tdir = rev ? -1 : 1;
+		int tmp = dev_infer_bw(l_query, rlen, truesc, opt.a, opt.o_del, opt.e_del);
+		int w2 = dev_infer_bw(l_query, rlen, truesc, opt.a, opt.o_ins, opt.e_ins);
+		w2 = w2 > tmp ? w2 : tmp;
+		if (w2 > opt.w) w2 = w2 < pw ? w2 : pw;
+		int i = 0, score = 0, last_sc = -(1 << 30), n_ops = -1;
+		bool give_up = false;
+		do {
+			w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+			if (l_query == rlen && w2 == 0) {     // no gap possible: one M run, score by direct comparison (bwa.c:171-174)
+				int s = 0;
+				for (int j = lane; j < l_query; j += 64) s += opt.mat[ref_base(ix, t0 + (i64)j * tdir) * 5 + query[q0 + j * qdir]];
+				for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+				score = s; n_ops = 1;
+				if (lane == 0) L.ops[0] = (u32)l_query << 4;
+				wave_sync();
+			} else {
+				int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+				int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+				int max_gap = max_ins > max_del ? max_ins : max_del;
+				const int dl = rlen > l_query ? rlen - l_query : l_query - rlen;
+				max_gap = max_gap > 1 ? max_gap : 1;
+				int w = (max_gap + dl + 1) >> 1; w = w < w2 ? w : w2;
+				const int min_w = dl + 3; w = w > min_w ? w : min_w;
+				const int n_col = l_query < 2 * w + 1 ? l_query : 2 * w + 1;
+				if (n_col > 64 || n_col * rlen > CIG_Z_CELLS) { give_up = true; break; }
+				score = wave_ksw_global2(ix, opt, query, q0, qdir, l_query, t0, tdir, rlen, w, L, &n_ops);
+				if (n_ops < 0) { give_up = true; break; }
+			}
+			if (score == last_sc || w2 == opt.w << 2) break;
+			last_sc = score;
+			w2 <<= 1;
+		} while (++i < 3 && score < truesc - opt.a);
+		if (!give_up && n_ops <= CIG_MAX_OPS) { res_score = score; res_n = n_ops; }
+	}
+	if (lane == 0) {
+		out->score = res_score; out->n_cigar = res_n;
+		for (int k = 0; k < CIG_MAX_OPS; ++k) out->cigar[k] = k < res_n ? L.ops[res_n - 1 - k] : 0;   // traceback order reversed
+	}
+	wave_sync();
+}
+
+// One wavefront per packed region (bwagpu_batch_download's order); regions below the output threshold T are skipped.
+__global__ void __launch_bounds__(256) k_cigar(DevIndex ix, bwagpu_opt_t opt, Batch B, i64 n_regs, const bwagpu_alnreg_t *regs, const i32 *reg_read, bwagpu_cigar_t *out,
+											   unsigned long long *next)
+{
+	HIP_DYNAMIC_SHARED(unsigned char, cig_lds)
+	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	unsigned char *base = cig_lds + (size_t)wave_in_blk * CIG_LDS_BYTES;
+	CigLds L;
+	L.hd = (i32*)base; L.e = L.hd + (CIG_MAX_LEN + 2 + 64);
+	L.qstride = CIG_MAX_LEN + 64;
+	L.qp = (int8_t*)(L.e + (CIG_MAX_LEN + 2 + 64));
+	L.z = (u8*)(L.qp + 5 * L.qstride);
+	L.ops = (u32*)(L.z + CIG_Z_CELLS / 2 + 64);
+	for (;;) {
+		long long g = 0;
+		if (lane == 0) g = (long long)atomicAdd(next, 1ull);
+		g = (long long)lane0_i64((i64)g);
+		if (g >= n_regs) break;
+		const bwagpu_alnreg_t p = regs[g];
+		if (p.score < opt.T) { if (lane == 0) { out[g].score = 0; out[g].n_cigar = -1; for (int k = 0; k < CIG_MAX_OPS; ++k) out[g].cigar[k] = 0; } continue; }
+		const int r = reg_read[g];
+		cigar_region(ix, opt, B.seq + B.off[r], p, L, out + g);
+	}
+}

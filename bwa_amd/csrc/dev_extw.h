@@ -50,6 +50,11 @@ DEVFN i64 uni64(i64 v)
 	int lo = __builtin_amdgcn_readfirstlane((int)(u32)(u64)v), hi = __builtin_amdgcn_readfirstlane((int)(u32)((u64)v >> 32));
 	return (i64)((u64)(u32)hi << 32 | (u32)lo);
 }
+DEVFN i64 lane0_i64(i64 v)       // broadcast lane 0's value
+{
+	int lo = __builtin_amdgcn_readlane((int)(u32)(u64)v, 0), hi = __builtin_amdgcn_readlane((int)(u32)((u64)v >> 32), 0);
+	return (i64)((u64)(u32)hi << 32 | (u32)lo);
+}
 DEVFN bwagpu_seed_t uni_seed(bwagpu_seed_t s) { s.rbeg = uni64(s.rbeg); s.qbeg = uni(s.qbeg); s.len = uni(s.len); s.score = uni(s.score); return s; }
 
 struct WaveLds { int2 *eh; int8_t *qp; int qstride; };

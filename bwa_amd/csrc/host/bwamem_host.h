@@ -43,8 +43,14 @@ struct Aln {   // == the information of mem_aln_t (bwamem.h:114-126)
 	int score = 0, sub = 0, alt_sc = 0;
 };
 
+// Device-computed global alignments of a read's regions (bwagpu_batch_cigars): regs[k] as downloaded, cigs[k] its result.
+// reg2aln looks a region up by the fields its band-doubling loop depends on and skips the DP when it finds a usable entry;
+// the result is the same either way.
+struct CigHints { const bwagpu_alnreg_t *regs; const bwagpu_cigar_t *cigs; int n; };
+
 struct Read {   // == bseq1_t as the finalize code needs it
 	const char *name; const char *comment; const uint8_t *seq /* nt4 codes */; const char *qual; int l_seq;
+	const CigHints *hints = nullptr;
 };
 
 typedef std::vector<bwagpu_alnreg_t> Regs;
@@ -64,7 +70,7 @@ uint64_t hash_64(uint64_t key);                                     // utils.h:9
 int mark_primary_se(const bwagpu_opt_t &opt, Regs &a, int64_t id);  // bwamem.c:547-584
 void reorder_primary5(int T, Regs &a);                              // bwamem.c:1008-1030
 int approx_mapq_se(const bwagpu_opt_t &opt, const bwagpu_alnreg_t &a);   // bwamem.c:982-1006
-Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint8_t *query, const bwagpu_alnreg_t *ar);   // bwamem.c:1119-1189
+Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint8_t *query, const bwagpu_alnreg_t *ar, const CigHints *hints = nullptr);   // bwamem.c:1119-1189
 void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, const Read &s, const std::vector<Aln> &list, int which, const Aln *mate, const char *rg_id);   // bwamem.c:851-976
 void reg2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, const Read &s, Regs &a, int extra_flag, const Aln *mate, const char *rg_id);   // bwamem.c:1033-1079
 void pestat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const std::vector<Regs> &regs, Pestat pes[4], bool verbose);   // bwamem_pair.c:72-135

@@ -51,14 +51,16 @@ void bwamem_host_set_alt(void *h, int rid, int flag) { ((RefSeqs*)h)->ctg[rid].i
 
 // same shape as refshim_regs2sam (oracle/ref_shim.c): names NUL-separated, seqs are nt4 codes, regs flat in read order
 char *bwamem_host_regs2sam(void *h, const bwagpu_opt_t *opt, int64_t n_processed, int n, const char *names, const uint8_t *seqs, const char *quals,
-						   const int64_t *off, const int32_t *counts, const bwagpu_alnreg_t *regs, const Pestat *pes0, int n_threads, int64_t *out_len)
+						   const int64_t *off, const int32_t *counts, const bwagpu_alnreg_t *regs, const Pestat *pes0, int n_threads, int64_t *out_len,
+						   const bwagpu_cigar_t *cigs /* optional: bwagpu_batch_cigars output, parallel to regs */)
 {
 	const RefSeqs &ref = *(RefSeqs*)h;
-	std::vector<Read> reads(n); std::vector<Regs> rv(n);
+	std::vector<Read> reads(n); std::vector<Regs> rv(n); std::vector<CigHints> hints(n);
 	const char *nm = names; int64_t roff = 0;
 	for (int i = 0; i < n; ++i) {
 		reads[i].name = nm; nm += strlen(nm) + 1;
 		reads[i].comment = 0; reads[i].seq = seqs + off[i]; reads[i].qual = quals ? quals + off[i] : 0; reads[i].l_seq = (int)(off[i + 1] - off[i]);
+		if (cigs) { hints[i].regs = regs + roff; hints[i].cigs = cigs + roff; hints[i].n = counts[i]; reads[i].hints = &hints[i]; }
 		rv[i].assign(regs + roff, regs + roff + counts[i]); roff += counts[i];
 	}
 	std::vector<std::string> sam;

@@ -133,6 +133,33 @@ int approx_mapq_se(const bwagpu_opt_t &opt, const bwagpu_alnreg_t &a)
 	return mapq;
 }
 
+// NM and MD from a CIGAR over the (possibly reversed) query and reference segments (bwa.c:196-226)
+static void nm_md(bool fwd, const uint8_t *query, const uint8_t *rseq, const std::vector<uint32_t> &cigar, int *NM, std::string &md)
+{
+	const char *int2base = fwd ? "ACGTN" : "TGCAN";
+	int x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0, n_cigar = (int)cigar.size();
+	md.clear();
+	for (int k = 0; k < n_cigar; ++k) {
+		int op = cigar[k] & 0xf, len = cigar[k] >> 4;
+		if (op == 0) {
+			for (int i = 0; i < len; ++i) {
+				if (query[x + i] != rseq[y + i]) { put_int(md, u); md += int2base[rseq[y + i]]; ++n_mm; u = 0; }
+				else ++u;
+			}
+			x += len; y += len;
+		} else if (op == 2) {
+			if (k > 0 && k < n_cigar - 1) {
+				put_int(md, u); md += '^';
+				for (int i = 0; i < len; ++i) md += int2base[rseq[y + i]];
+				u = 0; n_gap += len;
+			}
+			y += len;
+		} else if (op == 1) { x += len; n_gap += len; }
+	}
+	put_int(md, u);
+	*NM = n_mm + n_gap;
+}
+
 // ---- CIGAR + NM + MD (bwa_gen_cigar2, bwa.c:148-234) -------------------------------------------------------------------
 // returns false when the reference would return a NULL cigar; *score is set whenever DP/ungapped scoring ran
 static bool gen_cigar2(const bwagpu_opt_t &opt, const RefSeqs &ref, int w_, int l_query, const uint8_t *query_, int64_t rb, int64_t re,
@@ -160,29 +187,7 @@ static bool gen_cigar2(const bwagpu_opt_t &opt, const RefSeqs &ref, int w_, int 
 		min_w = dl + 3; w = w > min_w ? w : min_w;
 		*score = ksw_global2(l_query, query.data(), rlen, rseq.data(), opt.mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, w, &cigar);
 	}
-	{	// NM and MD (bwa.c:196-226)
-		const char *int2base = rb < l_pac ? "ACGTN" : "TGCAN";
-		int x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0, n_cigar = (int)cigar.size();
-		for (int k = 0; k < n_cigar; ++k) {
-			int op = cigar[k] & 0xf, len = cigar[k] >> 4;
-			if (op == 0) {
-				for (int i = 0; i < len; ++i) {
-					if (query[x + i] != rseq[y + i]) { put_int(md, u); md += int2base[rseq[y + i]]; ++n_mm; u = 0; }
-					else ++u;
-				}
-				x += len; y += len;
-			} else if (op == 2) {
-				if (k > 0 && k < n_cigar - 1) {
-					put_int(md, u); md += '^';
-					for (int i = 0; i < len; ++i) md += int2base[rseq[y + i]];
-					u = 0; n_gap += len;
-				}
-				y += len;
-			} else if (op == 1) { x += len; n_gap += len; }
-		}
-		put_int(md, u);
-		*NM = n_mm + n_gap;
-	}
+	nm_md(rb < l_pac, query.data(), rseq.data(), cigar, NM, md);
 	return true;
 }
 
@@ -196,7 +201,18 @@ static inline int infer_bw(int l1, int l2, int score, int a, int q, int r)
 }
 
 // ---- region -> alignment (mem_reg2aln, bwamem.c:1119-1189) -------------------------------------------------------------
-Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint8_t *query, const bwagpu_alnreg_t *ar)
+// a usable device result for this region, if any (see CigHints)
+static const bwagpu_cigar_t *find_hint(const CigHints *h, const bwagpu_alnreg_t &a)
+{
+	if (!h) return nullptr;
+	for (int k = 0; k < h->n; ++k) {
+		const bwagpu_alnreg_t &r = h->regs[k];
+		if (r.rb == a.rb && r.re == a.re && r.qb == a.qb && r.qe == a.qe && r.truesc == a.truesc && r.w == a.w) return h->cigs[k].n_cigar >= 0 ? &h->cigs[k] : nullptr;
+	}
+	return nullptr;
+}
+
+Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint8_t *query, const bwagpu_alnreg_t *ar, const CigHints *hints)
 {
 	Aln a;
 	if (ar == 0 || ar->rb < 0 || ar->re < 0) { a.rid = -1; a.pos = -1; a.flag |= 0x4; return a; }
@@ -208,7 +224,13 @@ Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint
 	int w2 = infer_bw(qe - qb, (int)(re - rb), ar->truesc, opt.a, opt.o_ins, opt.e_ins);
 	w2 = w2 > tmp ? w2 : tmp;
 	if (w2 > opt.w) w2 = w2 < ar->w ? w2 : ar->w;
-	do {
+	if (const bwagpu_cigar_t *pc = find_hint(hints, *ar)) {   // the loop below already ran on the device: only NM/MD are left
+		a.cigar.assign(pc->cigar, pc->cigar + pc->n_cigar);
+		std::vector<uint8_t> rseq, qs(query + qb, query + qe);
+		ref.get_seq(rb, re, rseq);
+		if (rb >= ref.l_pac) { std::reverse(qs.begin(), qs.end()); std::reverse(rseq.begin(), rseq.end()); }
+		nm_md(rb < ref.l_pac, qs.data(), rseq.data(), a.cigar, &NM, a.md);
+	} else do {
 		w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
 		gen_cigar2(opt, ref, w2, qe - qb, query + qb, rb, re, &score, a.cigar, &NM, a.md);
 		if (score == last_sc || w2 == opt.w << 2) break;
@@ -245,7 +267,7 @@ static inline int pri_idx(double ratio, const bwagpu_alnreg_t *a, int i)
 }
 
 // returns false when no XA exists for any region (the reference's NULL)
-static bool gen_alt(const bwagpu_opt_t &opt, const RefSeqs &ref, const Regs &av, int l_query, const uint8_t *query, std::vector<std::string> &xa, std::vector<char> &has)
+static bool gen_alt(const bwagpu_opt_t &opt, const RefSeqs &ref, const Regs &av, int l_query, const uint8_t *query, std::vector<std::string> &xa, std::vector<char> &has, const CigHints *hints)
 {
 	int n = (int)av.size(), tot = 0;
 	const bwagpu_alnreg_t *a = av.data();
@@ -260,7 +282,7 @@ static bool gen_alt(const bwagpu_opt_t &opt, const RefSeqs &ref, const Regs &av,
 		int r = pri_idx(opt.XA_drop_ratio, a, i);
 		if (r < 0) continue;
 		if (cnt[r] > opt.max_XA_hits_alt || (!has_alt[r] && cnt[r] > opt.max_XA_hits)) continue;
-		Aln t = reg2aln(opt, ref, l_query, query, &a[i]);
+		Aln t = reg2aln(opt, ref, l_query, query, &a[i], hints);
 		std::string &s = xa[r];
 		s += ref.ctg[t.rid].name; s += ','; s += "+-"[t.is_rev]; put_int(s, t.pos + 1); s += ',';
 		for (uint32_t c : t.cigar) { put_int(s, c >> 4); s += "MIDSHN"[c & 0xf]; }
@@ -272,9 +294,9 @@ static bool gen_alt(const bwagpu_opt_t &opt, const RefSeqs &ref, const Regs &av,
 	return true;
 }
 
-bool gen_alt_for_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Regs &av, int l_query, const uint8_t *query, std::vector<std::string> &xa, std::vector<char> &has)
+bool gen_alt_for_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Regs &av, int l_query, const uint8_t *query, std::vector<std::string> &xa, std::vector<char> &has, const CigHints *hints)
 {
-	return gen_alt(opt, ref, av, l_query, query, xa, has);
+	return gen_alt(opt, ref, av, l_query, query, xa, has, hints);
 }
 
 // ---- SAM record (mem_aln2sam, bwamem.c:851-976) ------------------------------------------------------------------------
@@ -386,7 +408,7 @@ void reg2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, cons
 {
 	std::vector<std::string> xa; std::vector<char> has;
 	bool have_xa = false;
-	if (!(opt.flag & F_ALL)) have_xa = gen_alt(opt, ref, av, s.l_seq, s.seq, xa, has);
+	if (!(opt.flag & F_ALL)) have_xa = gen_alt(opt, ref, av, s.l_seq, s.seq, xa, has, s.hints);
 	std::vector<Aln> aa;
 	int l = 0;
 	const int n = (int)av.size();
@@ -395,7 +417,7 @@ void reg2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, cons
 		if (p.score < opt.T) continue;
 		if (p.secondary >= 0 && (p.is_alt || !(opt.flag & F_ALL))) continue;
 		if (p.secondary >= 0 && p.secondary < INT_MAX && p.score < av[p.secondary].score * opt.drop_ratio) continue;
-		Aln q = reg2aln(opt, ref, s.l_seq, s.seq, &p);
+		Aln q = reg2aln(opt, ref, s.l_seq, s.seq, &p, s.hints);
 		if (have_xa && has[k]) { q.has_xa = true; q.xa = xa[k]; }
 		q.flag |= extra_flag;
 		if (p.secondary >= 0) q.sub = -1;

@@ -252,7 +252,7 @@ static int pair_ends(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat p
 }
 
 // from host_finalize.cpp
-bool gen_alt_for_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Regs &av, int l_query, const uint8_t *query, std::vector<std::string> &xa, std::vector<char> &has);
+bool gen_alt_for_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Regs &av, int l_query, const uint8_t *query, std::vector<std::string> &xa, std::vector<char> &has, const CigHints *hints);
 
 static inline int raw_mapq(int diff, int a) { return (int)(6.02 * diff / a + .499); }
 
@@ -315,10 +315,10 @@ int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uin
 					}
 				}
 				std::vector<std::string> xa[2]; std::vector<char> has[2]; bool have[2] = {false, false};
-				if (!(opt.flag & F_ALL)) for (int i = 0; i < 2; ++i) have[i] = gen_alt_for_pe(opt, ref, a[i], s[i].l_seq, s[i].seq, xa[i], has[i]);
+				if (!(opt.flag & F_ALL)) for (int i = 0; i < 2; ++i) have[i] = gen_alt_for_pe(opt, ref, a[i], s[i].l_seq, s[i].seq, xa[i], has[i], s[i].hints);
 				std::vector<Aln> aa[2];
 				for (int i = 0; i < 2; ++i) {
-					h[i] = reg2aln(opt, ref, s[i].l_seq, s[i].seq, &a[i][z[i]]);
+					h[i] = reg2aln(opt, ref, s[i].l_seq, s[i].seq, &a[i][z[i]], s[i].hints);
 					h[i].mapq = q_se[i];
 					h[i].flag |= 0x40 << i | extra_flag;
 					if (have[i] && has[i][z[i]]) { h[i].has_xa = true; h[i].xa = xa[i][z[i]]; }
@@ -326,7 +326,7 @@ int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uin
 					if (n_pri[i] < (int)a[i].size()) {   // the read has ALT hits
 						const bwagpu_alnreg_t &p = a[i][n_pri[i]];
 						if (p.score < opt.T || p.secondary >= 0 || !p.is_alt) continue;
-						Aln g = reg2aln(opt, ref, s[i].l_seq, s[i].seq, &p);
+						Aln g = reg2aln(opt, ref, s[i].l_seq, s[i].seq, &p, s[i].hints);
 						g.flag |= 0x800 | 0x40 << i | extra_flag;
 						if (have[i] && has[i][n_pri[i]]) { g.has_xa = true; g.xa = xa[i][n_pri[i]]; }
 						aa[i].push_back(g);
@@ -345,7 +345,7 @@ int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uin
 			if (a[i][0].score >= opt.T) which = 0;
 			else if (n_pri[i] < (int)a[i].size() && a[i][n_pri[i]].score >= opt.T) which = n_pri[i];
 		}
-		h[i] = which >= 0 ? reg2aln(opt, ref, s[i].l_seq, s[i].seq, &a[i][which]) : reg2aln(opt, ref, s[i].l_seq, s[i].seq, 0);
+		h[i] = which >= 0 ? reg2aln(opt, ref, s[i].l_seq, s[i].seq, &a[i][which], s[i].hints) : reg2aln(opt, ref, s[i].l_seq, s[i].seq, 0);
 	}
 	if (!(opt.flag & F_NOPAIRING) && h[0].rid == h[1].rid && h[0].rid >= 0) {
 		int64_t dist;

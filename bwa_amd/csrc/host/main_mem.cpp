@@ -28,6 +28,7 @@ void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_proce
 using namespace hostmem;
 
 static int g_verbose = 3;
+static int g_device_cigars = 1;   // BWAGPU_CLI_CIGARS=0: the host computes every CIGAR itself (same output)
 
 // ---- options -----------------------------------------------------------------------------------------------------------
 static void fill_scmat(int a, int b, int8_t mat[25])
@@ -159,6 +160,7 @@ struct Sub {      // one mem_process_seqs call (bwamem.c:1235-1264) on the reads
 	std::vector<int> idx; bwagpu_opt_t opt; int64_t n_processed = 0;
 	std::vector<uint8_t> flat; std::vector<int64_t> off; std::vector<int32_t> counts;
 	bwagpu_alnreg_t *all = nullptr; int64_t tot = 0;
+	bwagpu_cigar_t *cigs = nullptr;           // device-side global alignments of the regions (bwagpu_batch_cigars)
 	double t_dev = 0;
 };
 struct Work { long no = 0; Batch in; std::vector<Sub> subs; std::vector<std::string> out; };
@@ -194,6 +196,11 @@ static void device_sub(bwagpu_t *gpu, Sub &u)
 	const double t0 = now_s();
 	int rc = bwagpu_align_flat(gpu, &u.opt, (int)u.idx.size(), u.flat.data(), u.off.data(), u.counts.data(), &u.all, &u.tot);
 	if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu)); exit(EXIT_FAILURE); }
+	if (g_device_cigars && u.tot > 0) {       // the DP of mem_reg2aln on the device as well; the host keeps NM/MD and the text
+		int64_t nc = 0;
+		rc = bwagpu_batch_cigars(gpu, &u.opt, &u.cigs, &nc);
+		if (rc != BWAGPU_OK || nc != u.tot) { fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu)); exit(EXIT_FAILURE); }
+	}
 	u.t_dev = now_s() - t0;
 }
 
@@ -202,21 +209,22 @@ static void finalize_sub(const RefSeqs &ref, Work &w, Sub &u, const Pestat *pes0
 {
 	const double t0 = now_s();
 	const int n = (int)u.idx.size();
-	std::vector<Regs> regs((size_t)n); std::vector<Read> reads((size_t)n);
+	std::vector<Regs> regs((size_t)n); std::vector<Read> reads((size_t)n); std::vector<CigHints> hints(u.cigs ? (size_t)n : 0);
 	std::vector<int64_t> roff((size_t)n + 1, 0);
 	for (int i = 0; i < n; ++i) roff[i + 1] = roff[i] + u.counts[i];
 	parallel_for(u.opt.n_threads, n, [&](long i) {
 		const Seq &q = w.in.seqs[u.idx[i]];
 		const char *T = w.in.text.data();
 		regs[i].assign(u.all + roff[i], u.all + roff[i + 1]);
+		if (u.cigs) { hints[i].regs = u.all + roff[i]; hints[i].cigs = u.cigs + roff[i]; hints[i].n = u.counts[i]; reads[i].hints = &hints[i]; }
 		reads[i].name = T + q.name;
 		reads[i].comment = copy_comment && q.has_comment ? T + q.comment : nullptr;
 		reads[i].seq = u.flat.data() + u.off[i]; reads[i].qual = q.has_qual ? T + q.qual : nullptr; reads[i].l_seq = q.l_seq;
 	});
-	bwagpu_free(u.all); u.all = nullptr;
 	if (u.opt.flag & F_PE) for (int i = 0; i + 1 < n; i += 2) if (strcmp(reads[i].name, reads[i + 1].name) != 0) { fprintf(stderr, "[mem_sam_pe] paired reads have different names: \"%s\", \"%s\"\n", reads[i].name, reads[i + 1].name); exit(EXIT_FAILURE); }
 	std::vector<std::string> sam;
 	finalize_batch(u.opt, ref, u.n_processed, n, reads.data(), regs, (u.opt.flag & F_PE) ? pes0 : nullptr, u.opt.n_threads, rg_id, sam, g_verbose >= 3);
+	bwagpu_free(u.all); u.all = nullptr; bwagpu_free(u.cigs); u.cigs = nullptr;
 	for (int i = 0; i < n; ++i) w.out[u.idx[i]].swap(sam[i]);
 	if (g_verbose >= 3) fprintf(stderr, "[M::%s] Processed %d reads in %.3f real sec\n", "mem_process_seqs", n, u.t_dev + (now_s() - t0));
 }
@@ -380,6 +388,7 @@ int main(int argc, char *argv[])
 	}
 	const int chunk = fixed_chunk > 0 ? fixed_chunk : opt.chunk_size * opt.n_threads;
 	const double t_start = now_s();
+	if (getenv("BWAGPU_CLI_CIGARS")) g_device_cigars = atoi(getenv("BWAGPU_CLI_CIGARS"));
 	int n_dev = getenv("BWAGPU_CLI_STREAMS") ? atoi(getenv("BWAGPU_CLI_STREAMS")) : 2;      // batches in flight on the device
 	if (n_dev < 1) n_dev = 1;
 	std::vector<bwagpu_t*> handles(1, gpu);

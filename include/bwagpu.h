@@ -97,6 +97,16 @@ typedef struct {
 	uint64_t hash;
 } bwagpu_alnreg_t;
 
+/* Banded global alignment of one region as mem_reg2aln's band-doubling loop around bwa_gen_cigar2 leaves it
+ * (bwamem.c:1143-1152, bwa.c:148-195): score and BAM-style CIGAR (len << 4 | op, op M=0 I=1 D=2) before clipping and before
+ * the leading/trailing-deletion squeeze.  n_cigar == -1: not computed on the device (region below opt->T, outside the
+ * kernel's limits, or more than 6 operations) -- the caller runs bwa_gen_cigar2 itself. */
+typedef struct {
+	int32_t score;
+	int32_t n_cigar;
+	uint32_t cigar[6];
+} bwagpu_cigar_t;
+
 /* == mem_alnreg_v, reference bwamem.h:106 */
 typedef struct { size_t n, m; bwagpu_alnreg_t *a; } bwagpu_alnreg_v;
 
@@ -153,6 +163,12 @@ typedef struct {
 	float ms_publish;        /* k_publish + k_expand (interval sort, slot reservation); ms_seed is the k_seed kernel alone */
 	int64_t n_tab_lookups;   /* 24-byte prefix-table entries read by seeding in place of index blocks (stats only) */
 } bwagpu_stats_t;
+
+/* ---- optional widening past mem_process_seqs' first loop ---- */
+/* After bwagpu_batch_download: one bwagpu_cigar_t per downloaded region, in the same order, computed on the device.  They
+ * are what worker2's mem_reg2aln (bwamem.c:1119-1152) would compute on the host for that region; a finalize stage can use
+ * them instead of calling bwa_gen_cigar2 (NM/MD are still derived on the host from the CIGAR).  Free with bwagpu_free. */
+int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_cigar_t **out, int64_t *n_out);
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
 

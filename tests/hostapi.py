@@ -28,7 +28,7 @@ def lib():
         L.bwamem_host_destroy.argtypes = [C.c_void_p]
         L.bwamem_host_set_alt.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.bwamem_host_regs2sam.restype = C.c_void_p
-        L.bwamem_host_regs2sam.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.bwamem_host_regs2sam.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.bwamem_host_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
@@ -42,14 +42,15 @@ class HostFinalize:
     def set_alt(self, rid, flag=1):
         lib().bwamem_host_set_alt(self.h, rid, flag)
 
-    def regs2sam(self, opt, names, seqs_nt4: np.ndarray, quals: bytes, off, counts, regs, n_processed=0, pes0=None, n_threads=4) -> bytes:
+    def regs2sam(self, opt, names, seqs_nt4: np.ndarray, quals: bytes, off, counts, regs, n_processed=0, pes0=None, n_threads=4, cigs=None) -> bytes:
         n = off.shape[0] - 1
         nm = b"".join(x.encode() + b"\0" for x in names)
         ln = C.c_int64(0)
         regs = np.ascontiguousarray(regs)
         counts = np.ascontiguousarray(counts, dtype=np.int32)
         seqs_nt4 = np.ascontiguousarray(seqs_nt4, dtype=np.uint8)
-        p = lib().bwamem_host_regs2sam(self.h, C.byref(opt), n_processed, n, nm, seqs_nt4.ctypes.data, quals, off.ctypes.data, counts.ctypes.data, regs.ctypes.data, pes0, n_threads, C.byref(ln))
+        p = lib().bwamem_host_regs2sam(self.h, C.byref(opt), n_processed, n, nm, seqs_nt4.ctypes.data, quals, off.ctypes.data, counts.ctypes.data, regs.ctypes.data, pes0, n_threads, C.byref(ln),
+                                       None if cigs is None else np.ascontiguousarray(cigs).ctypes.data)
         s = C.string_at(p, ln.value)
         lib().bwamem_host_free(p)
         return s

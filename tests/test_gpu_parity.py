@@ -157,6 +157,41 @@ def test_properties_at_scale(medium):
     assert ((r["rb"] < r["re"]) & (r["qb"] < r["qe"]) & (r["re"] <= 2 * l_pac) & ~((r["rb"] < l_pac) & (r["re"] > l_pac))).all()
 
 
+def test_device_cigars_match_the_reference_sam(medium):
+    """bwagpu_batch_cigars (mem_reg2aln's banded global alignment + traceback on the device).  Fed to the host
+    finalize code as hints, the SAM text must equal the compiled reference's mem_process_seqs output byte for byte, for
+    single-end and paired-end input with indels on both strands; most regions must be served by the device."""
+    import hostapi
+    gpu, orc, ref, g = medium
+    host = hostapi.HostFinalize(testdata.medium_index()[0])
+    ascii_ = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for pe in (False, True):
+        opt = default_opt()
+        if pe:
+            opt.flag |= 2
+            r1, r2 = simdata.make_reads_pe(g, 10000, seed=611, sub=0.02, dele=0.003, ins=0.003)
+            reads = np.empty((2 * r1.shape[0], r1.shape[1]), dtype=np.uint8); reads[0::2], reads[1::2] = r1, r2
+        else:
+            reads = simdata.make_reads_se(g, 20000, seed=610, sub=0.03, dele=0.004, ins=0.004)
+        seqs, off = testdata.flat(reads)
+        n = off.shape[0] - 1
+        names = [f"q{i >> 1}" if pe else f"q{i}" for i in range(n)]
+        quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
+        counts, regs = gpu.align(opt, seqs, off)
+        cigs = gpu.cigars(opt)
+        assert cigs.shape[0] == regs.shape[0]
+        want = ref.process_seqs(opt, names, ascii_[seqs].tobytes(), quals, off)
+        got = host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs)
+        if got != want:
+            for a, b in zip(want.split(b"\n"), got.split(b"\n")):
+                assert a == b, f"first differing SAM line (pe={pe})\nwant {a[:300]!r}\ngot  {b[:300]!r}"
+        assert got == want
+        ok = regs["score"] >= opt.T
+        assert (cigs["n_cigar"][ok] >= 0).mean() > 0.9, "device served too few regions"
+        assert (cigs["n_cigar"] > 1).sum() > 100, "too few gapped alignments to exercise the traceback"
+    host.close()
+
+
 def test_index_broadcast_over_rccl_single_rank(small):
     """The multi-GPU start-up path on one GPU: a world_size-1 RCCL group, the index buffers wrapped as device tensors
     (CUDA array interface) and broadcast; the handle must align exactly like one created directly."""

@@ -125,3 +125,29 @@ def test_hostsim_lds_stack_ring_eviction(monkeypatch, ent):
     orc = orcapi.OrcIndex(prefix)
     assert_regs_equal(*orc.align(default_opt(), seqs, off), *s2.align(default_opt(), seqs, off), f"LDS stack of {ent}")
     s2.close(); orc.close()
+
+
+def test_hostsim_device_cigars_give_the_same_sam(sim):
+    """bwagpu_batch_cigars (banded global alignment + traceback on the device): feeding its records to the
+    host finalize code as hints yields exactly the SAM text the host produces when it runs every DP itself, and a good
+    share of the regions is actually served by the device."""
+    import hostapi
+    from bwa_amd.api import CIGAR_DTYPE
+    prefix, g = testdata.small_index()
+    host = hostapi.HostFinalize(prefix)
+    reads = simdata.make_reads_se(g, 40, seed=95, sub=0.03, dele=0.004, ins=0.004)
+    seqs, off = testdata.flat(reads)
+    opt = default_opt()
+    counts, regs = sim.align(opt, seqs, off)
+    cigs = sim.cigars(opt)
+    assert cigs.dtype == CIGAR_DTYPE and cigs.shape[0] == regs.shape[0]
+    names = [f"q{i}" for i in range(off.shape[0] - 1)]
+    quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
+    plain = host.regs2sam(opt, names, seqs, quals, off, counts, regs)
+    hinted = host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs)
+    assert hinted == plain
+    served = int((cigs["n_cigar"] >= 0).sum())
+    assert served >= regs.shape[0] // 2, (served, regs.shape[0])
+    gapped = int(((cigs["n_cigar"] > 1)).sum())
+    assert gapped > 0, "no gapped alignment exercised the traceback"
+    host.close()
