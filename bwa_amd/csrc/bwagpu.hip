@@ -646,12 +646,16 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		if (h->d_cigs.ensure((size_t)tot * sizeof(bwagpu_cigar_t)) || h->d_ctr.ensure(sizeof(Counters))) { free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
 		Batch B = {}; B.seq = h->d_seq.as<u8>(); B.off = h->d_off.as<i64>(); B.n_reads = h->n_reads; B.max_len = h->max_len;
 		unsigned long long *next = &h->d_ctr.as<Counters>()->next_ext;
-		hipError_t e = hipMemsetAsync(next, 0, sizeof(unsigned long long), h->stream);
-		if (e == hipSuccess) {
-			const int lds_wave = CIG_LDS_BYTES;
-			i64 nblk = (tot + 3) / 4, cap = 256 * 6;
-			hipLaunchKernelGGL(k_cigar, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(BLOCK), (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, tot,
-							   h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_pack_read.as<i32>(), h->d_cigs.as<bwagpu_cigar_t>(), next);
+		hipError_t e = hipSuccess;
+		const int zc[2] = { CIG_Z_SMALL, CIG_Z_BIG };
+		for (int tier = 0; tier < 2 && e == hipSuccess; ++tier) {   // narrow bands at high occupancy, then the deferred wide ones
+			e = hipMemsetAsync(next, 0, sizeof(unsigned long long), h->stream);
+			if (e != hipSuccess) break;
+			const int lds_wave = CIG_LDS_BYTES(zc[tier]);
+			const int wpb = tier == 0 ? 4 : 2;                 // waves per workgroup: the wide tier stays below 64 KiB of LDS per group
+			i64 nblk = (tot + wpb - 1) / wpb, cap = 256 * 6;
+			hipLaunchKernelGGL(k_cigar, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, tot,
+							   h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_pack_read.as<i32>(), h->d_cigs.as<bwagpu_cigar_t>(), next, zc[tier], tier);
 			e = hipGetLastError();
 		}
 		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_cigs.p, (size_t)tot * sizeof(bwagpu_cigar_t), hipMemcpyDeviceToHost, h->stream);

@@ -2,23 +2,27 @@
 // obtains from bwa_gen_cigar2 (bwa.c:148-234) / ksw_global2 (ksw.c:540-642), one wavefront per region.
 //
 // ksw_global2 opens gaps from the diagonal term M as ksw_extend2 does, so a DP row is again a max-plus prefix scan over
-// M(i,.): lanes own the columns of the band (at most 64, i.e. w <= 31), rows are sequential.  The per-column state
+// M(i,.): lanes own the columns of the band (64 per pass, up to CIG_MAX_COLS), rows are sequential.  The per-column state
 // {H(i-1,j-1), E(i,j)}, the query profile and the direction bytes live in LDS; lane 0 walks the direction bytes back.
 // All integers are those of the scalar recurrence (including the -2^30 "minus infinity" terms), so direction bytes,
-// score and CIGAR are identical to the host's.  Regions outside the kernel's limits (band wider than 64 columns, more
-// than CIG_Z_CELLS direction bytes, more than CIG_MAX_OPS operations, windows spanning the forward/reverse boundary) are
-// flagged n_cigar = -1 and left to the caller's own bwa_gen_cigar2.
+// score and CIGAR are identical to the host's.  The kernel runs in two tiers that differ in the LDS they reserve for
+// direction nibbles: most regions need a narrow band and run at high occupancy, the few with a wide band are redone by a
+// second launch.  Regions outside the limits (band wider than CIG_MAX_COLS, more than CIG_Z_BIG cells, more than
+// CIG_MAX_OPS operations, windows spanning the forward/reverse boundary) are flagged n_cigar = -1 and left to the caller's
+// own bwa_gen_cigar2.
 #pragma once
 #include "dev_extw.h"
 
 #define CIG_NEG_INF (-0x40000000)
 #define CIG_MAX_LEN 320        // longest query / target segment handled here
-#define CIG_Z_CELLS 10240      // DP cells whose direction nibbles fit one wave's LDS region (two rows per byte)
+#define CIG_Z_SMALL 6144       // DP cells (direction nibbles, two rows per byte) per wave: first tier ...
+#define CIG_Z_BIG 28672        // ... and second tier
+#define CIG_MAX_COLS 192       // widest band (columns per row)
 #define CIG_MAX_OPS 6          // operations kept per record (bwagpu_cigar_t)
 #define CIG_TMP_OPS 64
 
-struct CigLds { i32 *hd, *e; int8_t *qp; u8 *z; u32 *ops; int qstride; };
-#define CIG_LDS_BYTES ((2 * (CIG_MAX_LEN + 2 + 64) * 4 + 5 * (CIG_MAX_LEN + 64) + CIG_Z_CELLS / 2 + 64 + CIG_TMP_OPS * 4 + 15) & ~15)   // per wave
+struct CigLds { i32 *hd, *e; int8_t *qp; u8 *z; u32 *ops; int qstride, z_cells; };
+#define CIG_LDS_BYTES(zc) ((2 * (CIG_MAX_LEN + 2 + 64) * 4 + 5 * (CIG_MAX_LEN + 64) + (zc) / 2 + CIG_MAX_COLS + CIG_TMP_OPS * 4 + 15) & ~15)   // per wave
 
 // ksw_global2 (ksw.c:540-642).  Returns the score; *n_ops < 0 when the traceback does not fit CIG_TMP_OPS.  Operations are
 // left in L.ops in traceback (reversed) order, run-length merged.
@@ -43,34 +47,41 @@ __device__ int wave_ksw_global2(const DevIndex &ix, const bwagpu_opt_t &opt, con
 		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
 		const int beg = i > w ? i - w : 0, end = i + w + 1 < qlen ? i + w + 1 : qlen;
 		const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : CIG_NEG_INF;
-		const int j = beg + lane; const bool act = j < end;
-		const int dg = hd[j], ec = e_[j];                 // padded arrays: inactive lanes read, never write
-		const int sc = qp[tb * qs + j];
-		wave_sync();
-		const int m = dg + sc;
-		// F(i,j) = max( -inf - (j-beg) e_ins , max_{beg<=k<j} m_k - oe_ins - (j-1-k) e_ins ): the scalar chain f <- max(f - e, m - oe)
-		const int a = act ? m - oe_ins + j * e_ins : I32_MIN;
-		const int inc = wave_incl_scan_max(a);
-		const int exc = wave_shift_up1(inc, I32_MIN);
-		int f = CIG_NEG_INF - (j - beg) * e_ins;
-		if (lane > 0 && exc != I32_MIN) f = imax(f, exc - (j - 1) * e_ins);
-		int d = m >= ec ? 0 : 1, h = m >= ec ? m : ec;
-		if (h < f) { d = 2; h = f; }
-		int t = m - oe_del, en = ec - e_del;
-		if (en > t) d |= 1 << 2; else en = t;
-		t = m - oe_ins; const int fn = f - e_ins;
-		if (fn > t) d |= 2 << 4;
-		if (act) {
-			e_[j] = en;
-			hd[j + 1] = h;
-			// direction nibble {H source (2 bits), E continues, F continues}; rows 2r and 2r+1 of a band column share a byte and
-			// are written by the same lane
-			const u32 nib = (u32)(d & 7) | (u32)(d >> 5 & 1) << 3;
-			u8 *zb = z + (i >> 1) * n_col + lane;
-			*zb = (i & 1) ? (u8)(*zb | nib << 4) : (u8)nib;
+		int carry = I32_MIN, bnd = 0;
+		for (int b = beg; b < end; b += 64) {
+			const int j = b + lane; const bool act = j < end;
+			int dg = hd[j]; const int ec = e_[j];          // padded arrays: inactive lanes read, never write
+			const int sc = qp[tb * qs + j];
+			const int bnd_next = hd[b + 64];                // the next pass's first diagonal, before this pass's lane 63 overwrites it
+			if (b != beg && lane == 0) dg = bnd;
+			wave_sync();
+			const int m = dg + sc;
+			// F(i,j) = max( -inf - (j-beg) e_ins , max_{beg<=k<j} m_k - oe_ins - (j-1-k) e_ins ): the scalar chain f <- max(f - e, m - oe)
+			const int a = act ? m - oe_ins + j * e_ins : I32_MIN;
+			const int inc = wave_incl_scan_max(a);
+			const int exc = imax(wave_shift_up1(inc, I32_MIN), carry);
+			int f = CIG_NEG_INF - (j - beg) * e_ins;
+			if (j > beg && act) f = imax(f, exc - (j - 1) * e_ins);
+			int d = m >= ec ? 0 : 1, h = m >= ec ? m : ec;
+			if (h < f) { d = 2; h = f; }
+			int t = m - oe_del, en = ec - e_del;
+			if (en > t) d |= 1 << 2; else en = t;
+			t = m - oe_ins; const int fn = f - e_ins;
+			if (fn > t) d |= 2 << 4;
+			if (act) {
+				e_[j] = en;
+				hd[j + 1] = h;
+				// direction nibble {H source (2 bits), E continues, F continues}; rows 2r and 2r+1 of a band column share a byte and
+				// are written by the same lane
+				const u32 nib = (u32)(d & 7) | (u32)(d >> 5 & 1) << 3;
+				u8 *zb = z + (i >> 1) * n_col + (j - beg);
+				*zb = (i & 1) ? (u8)(*zb | nib << 4) : (u8)nib;
+			}
+			if (b == beg && lane == 0) hd[beg] = h1_init;
+			carry = imax(carry, __builtin_amdgcn_readlane(inc, 63));
+			bnd = bnd_next;
+			wave_sync();
 		}
-		if (lane == 0) { hd[beg] = h1_init; }
-		wave_sync();
 		if (lane == 0) e_[end] = CIG_NEG_INF;            // hd[end] = H(i,end-1) was written by the last active lane
 		wave_sync();
 	}
@@ -118,7 +129,7 @@ __device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const 
 	const i64 rb = uni64(p.rb), re = uni64(p.re), l_pac = ix.l_pac;
 	const int qb = uni(p.qb), qe = uni(p.qe), truesc = uni(p.truesc), pw = uni(p.w);
 	const int l_query = qe - qb;
-	int res_score = 0, res_n = -1;
+	int res_score = 2, res_n = -1;          // unserved records carry a reason in `score`: 1 below T, 2 shape/limits, 3 too many operations
 	const bool ok_shape = l_query > 0 && rb < re && !(rb < l_pac && re > l_pac) && l_query <= CIG_MAX_LEN && re - rb <= CIG_MAX_LEN;
 	if (ok_shape) {
 		const int rlen = (int)(re - rb);
@@ -130,7 +141,7 @@ __device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const 
 		w2 = w2 > tmp ? w2 : tmp;
 		if (w2 > opt.w) w2 = w2 < pw ? w2 : pw;
 		int i = 0, score = 0, last_sc = -(1 << 30), n_ops = -1;
-		bool give_up = false;
+		bool give_up = false, defer = false;
 		do {
 			w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
 			if (l_query == rlen && w2 == 0) {     // no gap possible: one M run, score by direct comparison (bwa.c:171-174)
@@ -149,7 +160,8 @@ __device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const 
 				int w = (max_gap + dl + 1) >> 1; w = w < w2 ? w : w2;
 				const int min_w = dl + 3; w = w > min_w ? w : min_w;
 				const int n_col = l_query < 2 * w + 1 ? l_query : 2 * w + 1;
-				if (n_col > 64 || n_col * rlen > CIG_Z_CELLS) { give_up = true; break; }
+				if (n_col > CIG_MAX_COLS || n_col * ((rlen + 1) & ~1) > CIG_Z_BIG) { give_up = true; break; }
+				if (n_col * ((rlen + 1) & ~1) > L.z_cells) { defer = true; break; }     // needs the second tier's LDS
 				score = wave_ksw_global2(ix, opt, query, q0, qdir, l_query, t0, tdir, rlen, w, L, &n_ops);
 				if (n_ops < 0) { give_up = true; break; }
 			}
@@ -157,7 +169,9 @@ __device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const 
 			last_sc = score;
 			w2 <<= 1;
 		} while (++i < 3 && score < truesc - opt.a);
-		if (!give_up && n_ops <= CIG_MAX_OPS) { res_score = score; res_n = n_ops; }
+		if (defer) res_n = -2;
+		else if (!give_up && n_ops <= CIG_MAX_OPS) { res_score = score; res_n = n_ops; }
+		else if (!give_up) res_score = 3;
 	}
 	if (lane == 0) {
 		out->score = res_score; out->n_cigar = res_n;
@@ -167,26 +181,31 @@ __device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const 
 }
 
 // One wavefront per packed region (bwagpu_batch_download's order); regions below the output threshold T are skipped.
+// tier 0 visits every region and defers (n_cigar = -2) those whose band needs more LDS than z_cells; tier 1 redoes exactly those.
 __global__ void __launch_bounds__(256) k_cigar(DevIndex ix, bwagpu_opt_t opt, Batch B, i64 n_regs, const bwagpu_alnreg_t *regs, const i32 *reg_read, bwagpu_cigar_t *out,
-											   unsigned long long *next)
+											   unsigned long long *next, int z_cells, int tier)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, cig_lds)
 	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	unsigned char *base = cig_lds + (size_t)wave_in_blk * CIG_LDS_BYTES;
+	unsigned char *base = cig_lds + (size_t)wave_in_blk * CIG_LDS_BYTES(z_cells);
 	CigLds L;
 	L.hd = (i32*)base; L.e = L.hd + (CIG_MAX_LEN + 2 + 64);
-	L.qstride = CIG_MAX_LEN + 64;
+	L.qstride = CIG_MAX_LEN + 64; L.z_cells = z_cells;
 	L.qp = (int8_t*)(L.e + (CIG_MAX_LEN + 2 + 64));
 	L.z = (u8*)(L.qp + 5 * L.qstride);
-	L.ops = (u32*)(L.z + CIG_Z_CELLS / 2 + 64);
+	L.ops = (u32*)(L.z + z_cells / 2 + CIG_MAX_COLS);
 	for (;;) {
 		long long g = 0;
 		if (lane == 0) g = (long long)atomicAdd(next, 1ull);
 		g = (long long)lane0_i64((i64)g);
 		if (g >= n_regs) break;
+		if (tier > 0) {
+			if (__builtin_amdgcn_readlane(out[g].n_cigar, 0) != -2) continue;
+		}
 		const bwagpu_alnreg_t p = regs[g];
-		if (p.score < opt.T) { if (lane == 0) { out[g].score = 0; out[g].n_cigar = -1; for (int k = 0; k < CIG_MAX_OPS; ++k) out[g].cigar[k] = 0; } continue; }
+		if (p.score < opt.T) { if (lane == 0) { out[g].score = 1; out[g].n_cigar = -1; for (int k = 0; k < CIG_MAX_OPS; ++k) out[g].cigar[k] = 0; } continue; }
 		const int r = reg_read[g];
 		cigar_region(ix, opt, B.seq + B.off[r], p, L, out + g);
+		if (tier > 0 && lane == 0 && out[g].n_cigar == -2) out[g].n_cigar = -1;
 	}
 }

@@ -100,7 +100,7 @@ typedef struct {
 /* Banded global alignment of one region as mem_reg2aln's band-doubling loop around bwa_gen_cigar2 leaves it
  * (bwamem.c:1143-1152, bwa.c:148-195): score and BAM-style CIGAR (len << 4 | op, op M=0 I=1 D=2) before clipping and before
  * the leading/trailing-deletion squeeze.  n_cigar == -1: not computed on the device (region below opt->T, outside the
- * kernel's limits, or more than 6 operations) -- the caller runs bwa_gen_cigar2 itself. */
+ * kernel's limits, or more than 6 operations; `score` then holds the reason 1/2/3) -- the caller runs bwa_gen_cigar2 itself. */
 typedef struct {
 	int32_t score;
 	int32_t n_cigar;

@@ -165,14 +165,15 @@ def test_device_cigars_match_the_reference_sam(medium):
     gpu, orc, ref, g = medium
     host = hostapi.HostFinalize(testdata.medium_index()[0])
     ascii_ = np.frombuffer(b"ACGTN", dtype=np.uint8)
-    for pe in (False, True):
+    for pe, noisy in ((False, True), (True, True), (False, False)):
         opt = default_opt()
+        kw = dict(sub=0.03, dele=0.004, ins=0.004) if noisy else {}
         if pe:
             opt.flag |= 2
-            r1, r2 = simdata.make_reads_pe(g, 10000, seed=611, sub=0.02, dele=0.003, ins=0.003)
+            r1, r2 = simdata.make_reads_pe(g, 10000, seed=611, **kw)
             reads = np.empty((2 * r1.shape[0], r1.shape[1]), dtype=np.uint8); reads[0::2], reads[1::2] = r1, r2
         else:
-            reads = simdata.make_reads_se(g, 20000, seed=610, sub=0.03, dele=0.004, ins=0.004)
+            reads = simdata.make_reads_se(g, 20000, seed=610, **kw)
         seqs, off = testdata.flat(reads)
         n = off.shape[0] - 1
         names = [f"q{i >> 1}" if pe else f"q{i}" for i in range(n)]
@@ -187,7 +188,8 @@ def test_device_cigars_match_the_reference_sam(medium):
                 assert a == b, f"first differing SAM line (pe={pe})\nwant {a[:300]!r}\ngot  {b[:300]!r}"
         assert got == want
         ok = regs["score"] >= opt.T
-        assert (cigs["n_cigar"][ok] >= 0).mean() > 0.9, "device served too few regions"
+        served = (cigs["n_cigar"][ok] >= 0).mean()      # the rest has more than 6 CIGAR operations and stays on the host
+        assert served > (0.7 if noisy else 0.95), f"device served too few regions: {served:.3f}"
         assert (cigs["n_cigar"] > 1).sum() > 100, "too few gapped alignments to exercise the traceback"
     host.close()
 
