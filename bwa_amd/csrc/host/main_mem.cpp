@@ -191,8 +191,13 @@ static void encode_sub(const Batch &in, Sub &u)
 }
 
 // stage 2: the kt_for(worker1) of mem_process_seqs (bwamem.c:1252) on the device
+static std::mutex g_dev_mutex;
+static bool g_dev_serialize = false;   // BWAGPU_CLI_SERIALIZE=1: one device call at a time (the mock HIP runtime of the CPU tests is not thread-safe)
+
 static void device_sub(bwagpu_t *gpu, Sub &u)
 {
+	std::unique_lock<std::mutex> serial(g_dev_mutex, std::defer_lock);
+	if (g_dev_serialize) serial.lock();
 	const double t0 = now_s();
 	int rc = bwagpu_align_flat(gpu, &u.opt, (int)u.idx.size(), u.flat.data(), u.off.data(), u.counts.data(), &u.all, &u.tot);
 	if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu)); exit(EXIT_FAILURE); }
@@ -388,6 +393,7 @@ int main(int argc, char *argv[])
 	}
 	const int chunk = fixed_chunk > 0 ? fixed_chunk : opt.chunk_size * opt.n_threads;
 	const double t_start = now_s();
+	if (getenv("BWAGPU_CLI_SERIALIZE")) g_dev_serialize = atoi(getenv("BWAGPU_CLI_SERIALIZE")) != 0;
 	if (getenv("BWAGPU_CLI_CIGARS")) g_device_cigars = atoi(getenv("BWAGPU_CLI_CIGARS"));
 	int n_dev = getenv("BWAGPU_CLI_STREAMS") ? atoi(getenv("BWAGPU_CLI_STREAMS")) : 2;      // batches in flight on the device
 	if (n_dev < 1) n_dev = 1;
