@@ -62,6 +62,7 @@ struct bwagpu_s {
 	bool have_batch = false, ran = false;
 	int stats_on = 0, taps_on = 1;
 	bwagpu_stats_t stats = {};
+	volatile int phase = 0;       // progress marker for bwagpu_debug_phase (diagnostics of a stuck call)
 	i64 packed_tot = -1;          // regions packed by the last bwagpu_batch_download (-1: none)
 	DevBuf d_pack_off, d_regs_packed, d_pack_read, d_cigs, d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
 	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_blob;
@@ -346,6 +347,8 @@ extern "C" int bwagpu_index_info(const bwagpu_t *h, int64_t *l_pac, int32_t *n_s
 	return BWAGPU_OK;
 }
 
+extern "C" int bwagpu_debug_phase(const bwagpu_t *h) { return h ? h->phase : -1; }
+
 extern "C" int bwagpu_set_stats(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->stats_on = enable ? 1 : 0; return BWAGPU_OK; }
 extern "C" int bwagpu_set_taps(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->taps_on = enable ? 1 : 0; return BWAGPU_OK; }
 extern "C" int bwagpu_get_stats(const bwagpu_t *h, bwagpu_stats_t *out) { if (!h || !out) return BWAGPU_EINVAL; *out = h->stats; return BWAGPU_OK; }
@@ -388,7 +391,7 @@ extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, cons
 {
 	if (!h || n < 0 || (n > 0 && (!seqs || !off))) return BWAGPU_EINVAL;
 	HIPCHK(h, hipSetDevice(h->device));
-	h->have_batch = false; h->ran = false; h->packed_tot = -1;
+	h->have_batch = false; h->ran = false; h->packed_tot = -1; h->phase = 10;
 	h->n_reads = n; h->max_len = 0; h->n_bases = n ? off[n] - off[0] : 0;
 	if (n && off[0] != 0) return BWAGPU_EINVAL;
 	for (int i = 0; i < n; ++i) {
@@ -398,10 +401,12 @@ extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, cons
 	}
 	h->h_off.assign(off, off + n + 1);
 	const u64 n_words = ((u64)h->n_bases + 15) / 16;
+	h->phase = 11;
 	if (h->d_seq.ensure((size_t)h->n_bases + 16) || h->d_seq_nib.ensure((size_t)(n_words + 1) * 8) || h->d_off.ensure((size_t)(n + 1) * 8)) { h->err = "hipMalloc failed (reads)"; return BWAGPU_ENOMEM; }
 	if (n) {
 		HIPCHK(h, hipMemcpyAsync(h->d_seq.p, seqs, (size_t)h->n_bases, hipMemcpyHostToDevice, h->stream));
 		HIPCHK(h, hipMemcpyAsync(h->d_off.p, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, h->stream));
+		h->phase = 12;
 		Batch P = {}; P.seq = h->d_seq.as<u8>(); P.seq_nib = h->d_seq_nib.as<u64>();
 		u64 pb = (n_words + BLOCK - 1) / BLOCK;
 		hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)(pb < 65536 ? pb : 65536)), dim3(BLOCK), 0, h->stream, P, n_words);
@@ -483,6 +488,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		if (!(min_l > 0.05f * l)) { minhsp[l] = (int)(opt->a * min_l + .499); any_seedsw = true; }
 	}
 	for (int attempt = 0; attempt < 12; ++attempt) {
+		h->phase = 20 + attempt * 100;
 		int rc = alloc_batch(h, n_threads);
 		if (rc) return rc;
 		HIPCHK(h, hipMemcpyAsync(h->d_minhsp.p, minhsp.data(), minhsp.size() * 4, hipMemcpyHostToDevice, h->stream));
@@ -530,6 +536,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		hipLaunchKernelGGL(k_dedup, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
 		HIPCHK(h, hipGetLastError());
+		h->phase = 22 + attempt * 100;
 		Counters c;
 		HIPCHK(h, hipMemcpyAsync(&c, h->d_ctr.p, sizeof c, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -608,6 +615,7 @@ extern "C" int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg
 	HIPCHK(h, hipSetDevice(h->device));
 	const int n = h->n_reads;
 	if (n == 0) { *regs_out = (bwagpu_alnreg_t*)malloc(sizeof(bwagpu_alnreg_t)); *n_regs_out = 0; return BWAGPU_OK; }
+	h->phase = 30;
 	std::vector<i32> cnt((size_t)n); std::vector<i64> dst((size_t)n);
 	HIPCHK(h, hipMemcpyAsync(cnt.data(), h->d_reg_n.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -615,8 +623,10 @@ extern "C" int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg
 	for (int i = 0; i < n; ++i) { dst[i] = tot; tot += cnt[i]; if (counts) counts[i] = cnt[i]; }
 	bwagpu_alnreg_t *res = (bwagpu_alnreg_t*)malloc((size_t)(tot ? tot : 1) * sizeof(bwagpu_alnreg_t));
 	if (!res) return BWAGPU_ENOMEM;
+	h->phase = 31;
 	if (tot) {
 		if (h->d_pack_off.ensure((size_t)n * 8) || h->d_regs_packed.ensure((size_t)tot * sizeof(bwagpu_alnreg_t)) || h->d_pack_read.ensure((size_t)tot * 4)) { free(res); h->err = "hipMalloc failed (packed regions)"; return BWAGPU_ENOMEM; }
+		h->phase = 32;
 		hipError_t e = hipMemcpyAsync(h->d_pack_off.p, dst.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream);
 		if (e == hipSuccess) {
 			int nb = (n + BLOCK - 1) / BLOCK; if (nb > 8192) nb = 8192;
@@ -628,7 +638,7 @@ extern "C" int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg
 		if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
 		if (e != hipSuccess) { free(res); HIPCHK(h, e); }
 	}
-	h->packed_tot = tot;
+	h->packed_tot = tot; h->phase = 39;
 	*regs_out = res; *n_regs_out = tot;
 	return BWAGPU_OK;
 }
@@ -639,6 +649,7 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 	if (opt->e_del <= 0 || opt->e_ins <= 0) return BWAGPU_EINVAL;
 	HIPCHK(h, hipSetDevice(h->device));
 	const i64 tot = h->packed_tot;
+	h->phase = 40;
 	static_assert(sizeof(bwagpu_cigar_t) == 32, "layout");
 	bwagpu_cigar_t *res = (bwagpu_cigar_t*)malloc((size_t)(tot ? tot : 1) * sizeof(bwagpu_cigar_t));
 	if (!res) return BWAGPU_ENOMEM;
@@ -651,6 +662,7 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		for (int tier = 0; tier < 2 && e == hipSuccess; ++tier) {   // narrow bands at high occupancy, then the deferred wide ones
 			e = hipMemsetAsync(next, 0, sizeof(unsigned long long), h->stream);
 			if (e != hipSuccess) break;
+			h->phase = 41 + tier;
 			const int lds_wave = CIG_LDS_BYTES(zc[tier]);
 			const int wpb = tier == 0 ? 4 : 2;                 // waves per workgroup: the wide tier stays below 64 KiB of LDS per group
 			i64 nblk = (tot + wpb - 1) / wpb, cap = 256 * 6;
@@ -658,6 +670,7 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 							   h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_pack_read.as<i32>(), h->d_cigs.as<bwagpu_cigar_t>(), next, zc[tier], tier);
 			e = hipGetLastError();
 		}
+		h->phase = 45;
 		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_cigs.p, (size_t)tot * sizeof(bwagpu_cigar_t), hipMemcpyDeviceToHost, h->stream);
 		if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
 		if (e != hipSuccess) { free(res); HIPCHK(h, e); }

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <zlib.h>
 #include <atomic>
 #include <chrono>
@@ -404,6 +405,23 @@ int main(int argc, char *argv[])
 	std::atomic<long> n_works(-1), n_reads_total(0);
 	double busy_read = 0, busy_fin = 0, busy_write = 0; std::atomic<long> busy_dev_us(0);   // per-stage busy time (-v 3 summary)
 
+	// watchdog (BWAGPU_CLI_WATCHDOG=<seconds>): if no stage makes progress for that long, say where everything is and give up
+	std::atomic<long> progress(0); std::atomic<int> dev_no[16]; std::atomic<bool> all_done(false);
+	for (auto &x : dev_no) x = -1;
+	const int wd_secs = getenv("BWAGPU_CLI_WATCHDOG") ? atoi(getenv("BWAGPU_CLI_WATCHDOG")) : 0;
+	std::thread watchdog([&] {
+		long last = -1; int idle = 0;
+		while (wd_secs > 0 && !all_done.load()) {
+			std::this_thread::sleep_for(std::chrono::milliseconds(250));
+			const long p = progress.load();
+			if (p != last) { last = p; idle = 0; continue; }
+			if (++idle < wd_secs * 4) continue;
+			fprintf(stderr, "[E::%s] no progress for %d s: next batch to finalize %ld, batches read %ld, done-but-waiting %zu\n", "main_mem", wd_secs, next_fin, n_works.load(), done.size());
+			for (int d = 0; d < n_dev && d < 16; ++d) fprintf(stderr, "[E::%s]   device thread %d: batch %d, library phase %d\n", "main_mem", d, dev_no[d].load(), bwagpu_debug_phase(handles[d]));
+			_exit(3);
+		}
+	});
+
 	std::thread reader([&] {      // stage 1: input, pairing classes, 2-bit encoding
 		int64_t n_processed = 0; long no = 0;
 		for (;;) {
@@ -433,7 +451,7 @@ int main(int argc, char *argv[])
 				w->subs.push_back(std::move(u));
 			}
 			for (Sub &u : w->subs) encode_sub(w->in, u);
-			n_processed += n; ++no;
+			n_processed += n; ++no; ++progress;
 			busy_read += now_s() - tr;
 			to_dev.push(std::move(w));
 		}
@@ -447,7 +465,9 @@ int main(int argc, char *argv[])
 		WorkP w;
 		while (to_dev.pop(w)) {
 			{ std::unique_lock<std::mutex> l(dm); dcv.wait(l, [&] { return w->no - next_fin <= (long)n_dev; }); }   // do not run ahead of the host
-			for (Sub &u : w->subs) { device_sub(handles[d], u); busy_dev_us += (long)(u.t_dev * 1e6); }
+			if (d < 16) dev_no[d] = (int)w->no;
+			++progress;
+			for (Sub &u : w->subs) { device_sub(handles[d], u); ++progress; busy_dev_us += (long)(u.t_dev * 1e6); }
 			std::lock_guard<std::mutex> l(dm);
 			const long no = w->no;
 			done[no] = std::move(w);
@@ -473,12 +493,13 @@ int main(int argc, char *argv[])
 		busy_fin += now_s() - tf;
 		w->in = Batch(); w->subs.clear();
 		to_out.push(std::move(w));
-		{ std::lock_guard<std::mutex> l(dm); ++next_fin; dcv.notify_all(); }
+		{ std::lock_guard<std::mutex> l(dm); ++next_fin; ++progress; dcv.notify_all(); }
 	}
 	reader.join();
 	for (auto &t : devs) t.join();
 	to_out.close();
 	writer.join();
+	all_done = true; watchdog.join();
 	if (g_verbose >= 3) { const double dt = now_s() - t_start; fprintf(stderr, "[M::%s] %ld reads in %.3f sec after the index was loaded: %.0f reads/s\n", "main_mem", n_reads_total.load(), dt, dt > 0 ? n_reads_total.load() / dt : 0.);
 		fprintf(stderr, "[M::%s] stage busy time: read+encode %.3f s, device %.3f s (over %d handles), finalize %.3f s, write %.3f s\n", "main_mem", busy_read, busy_dev_us.load() * 1e-6, n_dev, busy_fin, busy_write); }
 	for (size_t i = 1; i < handles.size(); ++i) bwagpu_destroy(handles[i]);

@@ -164,6 +164,11 @@ typedef struct {
 	int64_t n_tab_lookups;   /* 24-byte prefix-table entries read by seeding in place of index blocks (stats only) */
 } bwagpu_stats_t;
 
+/* Diagnostics: a marker of the step the handle's current (or last) batch call has reached; safe to call from another
+ * thread while a call is in progress.  10-12 upload, 20+100*attempt run launched, 22+100*attempt run waiting, 30-39 download,
+ * 40-45 cigars. */
+int bwagpu_debug_phase(const bwagpu_t *h);
+
 /* ---- optional widening past mem_process_seqs' first loop ---- */
 /* After bwagpu_batch_download: one bwagpu_cigar_t per downloaded region, in the same order, computed on the device.  They
  * are what worker2's mem_reg2aln (bwamem.c:1119-1152) would compute on the host for that region; a finalize stage can use
