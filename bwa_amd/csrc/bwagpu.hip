@@ -659,7 +659,8 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		unsigned long long *next = &h->d_ctr.as<Counters>()->next_ext;
 		hipError_t e = hipSuccess;
 		const int zc[2] = { CIG_Z_SMALL, CIG_Z_BIG };
-		for (int tier = 0; tier < 2 && e == hipSuccess; ++tier) {   // narrow bands at high occupancy, then the deferred wide ones
+		const int n_tier = getenv("BWAGPU_CIG_TIERS") ? atoi(getenv("BWAGPU_CIG_TIERS")) : 2;   // diagnostics
+		for (int tier = 0; tier < n_tier && e == hipSuccess; ++tier) {   // narrow bands at high occupancy, then the deferred wide ones
 			e = hipMemsetAsync(next, 0, sizeof(unsigned long long), h->stream);
 			if (e != hipSuccess) break;
 			h->phase = 41 + tier;

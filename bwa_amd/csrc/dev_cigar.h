@@ -195,13 +195,9 @@ __global__ void __launch_bounds__(256) k_cigar(DevIndex ix, bwagpu_opt_t opt, Ba
 	L.z = (u8*)(L.qp + 5 * L.qstride);
 	L.ops = (u32*)(L.z + z_cells / 2 + CIG_MAX_COLS);
 	for (;;) {
-		long long g = 0;
-		if (lane == 0) g = (long long)atomicAdd(next, 1ull);
-		g = (long long)lane0_i64((i64)g);
+		const long long g = wave_fetch(next);
 		if (g >= n_regs) break;
-		if (tier > 0) {
-			if (__builtin_amdgcn_readlane(out[g].n_cigar, 0) != -2) continue;
-		}
+		if (tier > 0 && uni(out[g].n_cigar) != -2) continue;
 		const bwagpu_alnreg_t p = regs[g];
 		if (p.score < opt.T) { if (lane == 0) { out[g].score = 1; out[g].n_cigar = -1; for (int k = 0; k < CIG_MAX_OPS; ++k) out[g].cigar[k] = 0; } continue; }
 		const int r = reg_read[g];

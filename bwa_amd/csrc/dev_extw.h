@@ -55,6 +55,15 @@ DEVFN i64 lane0_i64(i64 v)       // broadcast lane 0's value
 	int lo = __builtin_amdgcn_readlane((int)(u32)(u64)v, 0), hi = __builtin_amdgcn_readlane((int)(u32)((u64)v >> 32), 0);
 	return (i64)((u64)(u32)hi << 32 | (u32)lo);
 }
+// Wave-wide work fetch: the wave draws the next item from a global counter and every lane receives it.  Every lane takes
+// part in the atomic (lane 0 adds one, the others zero) instead of guarding it with `if (lane == 0)`: with the guard, the
+// optimizer unswitched the work loop on the (loop-invariant, but lane-dependent) test, lanes 1..63 got a loop copy of their
+// own without the atomic, and a wave whose item took a `continue` spun in it forever.
+DEVFN long long wave_fetch(unsigned long long *ctr)
+{
+	const unsigned long long old = atomicAdd(ctr, (unsigned long long)((threadIdx.x & 63) == 0));
+	return (long long)lane0_i64((i64)old);
+}
 DEVFN bwagpu_seed_t uni_seed(bwagpu_seed_t s) { s.rbeg = uni64(s.rbeg); s.qbeg = uni(s.qbeg); s.len = uni(s.len); s.score = uni(s.score); return s; }
 
 struct WaveLds { int2 *eh; int8_t *qp; int qstride; };
@@ -311,9 +320,7 @@ __global__ void __launch_bounds__(256) k_extend_wave(DevIndex ix, bwagpu_opt_t o
 	// Reads are handed out heaviest first from a global counter: a wave that drew light reads simply draws more of them, and
 	// the launch needs no particular relation between its grid and the number of resident workgroups.
 	for (;;) {
-		int k = 0;
-		if (lane == 0) k = (int)atomicAdd(&B.ctr->next_ext, 1ull);
-		k = __builtin_amdgcn_readlane(k, 0);
+		const long long k = wave_fetch(&B.ctr->next_ext);
 		if (k >= B.n_reads) break;
 		const int r = B.order[k];
 		ext_read_wave(ix, opt, B, r, L, calls, cells, refb);

@@ -202,6 +202,7 @@ static void device_sub(bwagpu_t *gpu, Sub &u)
 	const double t0 = now_s();
 	int rc = bwagpu_align_flat(gpu, &u.opt, (int)u.idx.size(), u.flat.data(), u.off.data(), u.counts.data(), &u.all, &u.tot);
 	if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu)); exit(EXIT_FAILURE); }
+	if (getenv("BWAGPU_CLI_TRACE")) fprintf(stderr, "[D::device_sub] %d reads -> %ld regions (flag 0x%x)\n", (int)u.idx.size(), (long)u.tot, u.opt.flag);
 	if (g_device_cigars && u.tot > 0) {       // the DP of mem_reg2aln on the device as well; the host keeps NM/MD and the text
 		int64_t nc = 0;
 		rc = bwagpu_batch_cigars(gpu, &u.opt, &u.cigs, &nc);
