@@ -20,7 +20,14 @@ uint64_t hash_64(uint64_t key)
 	return key;
 }
 
-static inline void put_int(std::string &s, long long v) { char buf[24]; snprintf(buf, sizeof buf, "%lld", v); s += buf; }
+static inline void put_int(std::string &s, long long v)
+{	// decimal text of v (what kputw/kputl/ksprintf("%d") emit), without a trip through snprintf
+	char buf[24]; int k = 24;
+	unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+	do { buf[--k] = (char)('0' + u % 10); u /= 10; } while (u);
+	if (v < 0) buf[--k] = '-';
+	s.append(buf + k, (size_t)(24 - k));
+}
 
 // ---- primary / secondary marking (bwamem.c:519-584) -------------------------------------------------------------------
 static void mark_core(const bwagpu_opt_t &opt, int n, bwagpu_alnreg_t *a, std::vector<int> &z)
@@ -408,6 +415,7 @@ void reg2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, cons
 {
 	std::vector<std::string> xa; std::vector<char> has;
 	bool have_xa = false;
+	out.reserve(out.size() + 2 * (size_t)s.l_seq + 320);
 	if (!(opt.flag & F_ALL)) have_xa = gen_alt(opt, ref, av, s.l_seq, s.seq, xa, has, s.hints);
 	std::vector<Aln> aa;
 	int l = 0;
