@@ -49,6 +49,7 @@ struct bwagpu_s {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[8] = {};
+	hipEvent_t ev_wait = nullptr;    // blocking-sync event: waiting for the stream must not spin on a host core (see wait_stream)
 	std::string err;
 	// index
 	DevIndex ix = {};
@@ -70,6 +71,10 @@ struct bwagpu_s {
 	i64 slot_cap = 0, node_cap = 0, reg_cap = 0; int mem_cap = 0;
 	std::vector<i64> h_off;
 };
+
+// Wait for the handle's stream without burning a host core: hipStreamSynchronize busy-waits, and a process that keeps several
+// batches in flight from several host threads would spend that many cores spinning -- cores the finalize stage needs.
+#define wait_stream(h) ((h)->ev_wait ? (hipEventRecord((h)->ev_wait, (h)->stream) == hipSuccess ? hipEventSynchronize((h)->ev_wait) : hipStreamSynchronize((h)->stream)) : hipStreamSynchronize((h)->stream))
 
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return BWAGPU_EHIP; } } while (0)
 
@@ -166,6 +171,7 @@ extern "C" int bwagpu_create(bwagpu_t **out, const bwagpu_index_desc_t *d, int d
 	int rc;
 	if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return BWAGPU_ENODEV; }
 	for (int i = 0; i < 8; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return BWAGPU_ENODEV; }
+	if (hipEventCreateWithFlags(&h->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) h->ev_wait = nullptr;
 	// the last Occ record of the .bwt is a trailing 32-byte half block; pad the upload to whole 64-byte blocks
 	u64 nblk = (d->bwt_size + 15) / 16;
 	std::vector<uint32_t> padded;
@@ -220,6 +226,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 		&h->d_order, &h->d_bin_cnt, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
 	for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+	if (h->ev_wait) (void)hipEventDestroy(h->ev_wait);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -299,6 +306,7 @@ extern "C" int bwagpu_clone(bwagpu_t *src, bwagpu_t **out)
 	h->device = src->device;
 	if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return BWAGPU_ENODEV; }
 	for (int i = 0; i < 8; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return BWAGPU_ENODEV; }
+	if (hipEventCreateWithFlags(&h->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) h->ev_wait = nullptr;
 	h->ibuf = src->ibuf; ++h->ibuf->refs;
 	h->ix = src->ix; h->l_pac = src->l_pac; h->n_seqs = src->n_seqs; h->seq_len = src->seq_len; h->sa_intv = src->sa_intv;
 	h->bwt_blocks = src->bwt_blocks; h->bwt_bytes = src->bwt_bytes; h->sa_bytes = src->sa_bytes; h->pac_bytes = src->pac_bytes;
@@ -411,7 +419,7 @@ extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, cons
 		u64 pb = (n_words + BLOCK - 1) / BLOCK;
 		hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)(pb < 65536 ? pb : 65536)), dim3(BLOCK), 0, h->stream, P, n_words);
 		HIPCHK(h, hipGetLastError());
-		HIPCHK(h, hipStreamSynchronize(h->stream));
+		HIPCHK(h, wait_stream(h));
 	}
 	// first guess of the arena sizes (grown on overflow)
 	i64 nb = h->n_bases > 1024 ? h->n_bases : 1024;
@@ -539,7 +547,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		h->phase = 22 + attempt * 100;
 		Counters c;
 		HIPCHK(h, hipMemcpyAsync(&c, h->d_ctr.p, sizeof c, hipMemcpyDeviceToHost, h->stream));
-		HIPCHK(h, hipStreamSynchronize(h->stream));
+		HIPCHK(h, wait_stream(h));
 		if (c.overflow) {   // grow what overflowed and redo the batch; nothing of the failed attempt is kept
 			if (c.overflow & 2) h->slot_cap = h->slot_cap * 2;
 			if (c.overflow & 6) h->node_cap = h->slot_cap / 4 + 2 * (i64)n + 64 > h->node_cap * 2 ? h->slot_cap / 4 + 2 * (i64)n + 64 : h->node_cap * 2;
@@ -618,7 +626,7 @@ extern "C" int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg
 	h->phase = 30;
 	std::vector<i32> cnt((size_t)n); std::vector<i64> dst((size_t)n);
 	HIPCHK(h, hipMemcpyAsync(cnt.data(), h->d_reg_n.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
-	HIPCHK(h, hipStreamSynchronize(h->stream));
+	HIPCHK(h, wait_stream(h));
 	i64 tot = 0;
 	for (int i = 0; i < n; ++i) { dst[i] = tot; tot += cnt[i]; if (counts) counts[i] = cnt[i]; }
 	bwagpu_alnreg_t *res = (bwagpu_alnreg_t*)malloc((size_t)(tot ? tot : 1) * sizeof(bwagpu_alnreg_t));
@@ -635,7 +643,7 @@ extern "C" int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg
 			e = hipGetLastError();
 		}
 		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_regs_packed.p, (size_t)tot * sizeof(bwagpu_alnreg_t), hipMemcpyDeviceToHost, h->stream);
-		if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+		if (e == hipSuccess) e = wait_stream(h);
 		if (e != hipSuccess) { free(res); HIPCHK(h, e); }
 	}
 	h->packed_tot = tot; h->phase = 39;
@@ -673,7 +681,7 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		}
 		h->phase = 45;
 		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_cigs.p, (size_t)tot * sizeof(bwagpu_cigar_t), hipMemcpyDeviceToHost, h->stream);
-		if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+		if (e == hipSuccess) e = wait_stream(h);
 		if (e != hipSuccess) { free(res); HIPCHK(h, e); }
 	}
 	*out = res; *n_out = tot;

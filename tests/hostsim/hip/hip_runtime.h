@@ -48,6 +48,10 @@ static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return 
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new mock_event_s(); return hipSuccess; }
+#define hipEventBlockingSync 1
+#define hipEventDisableTiming 2
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new mock_event_s(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
