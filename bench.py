@@ -200,7 +200,7 @@ def main():
         # algorithmic bytes per launch of each index-bound kernel: one 64-byte block per Occ lookup /
         # LF step, 8 bytes per SA sample, plus the read bases the seeding kernel consumes
         alg = {
-            "k_seed": 64.0 * work["n_occ_blocks"] + 24.0 * work["n_tab_lookups"] + work["n_bases"] / 2,
+            "k_seed": 64.0 * work["n_occ_blocks"] + 16.0 * work["n_tab_lookups"] + work["n_bases"] / 2,
             "k_sa": 64.0 * work["n_lf_steps"] + 8.0 * work["n_seeds"],
         }
         dur = {"k_seed": stage_ms["ms_seed"], "k_sa": stage_ms["ms_sa"]}

@@ -121,7 +121,7 @@ def test_hostsim_lds_stack_ring_eviction(monkeypatch, ent):
     prefix, g = testdata.small_index()
     monkeypatch.setenv("BWAGPU_SEED_LDS_ENT", ent)
     s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
-    seqs, off = testdata.flat(simdata.make_reads_se(g, 24, seed=93))
+    seqs, off = testdata.flat(simdata.make_reads_se(g, 14, seed=93))
     orc = orcapi.OrcIndex(prefix)
     assert_regs_equal(*orc.align(default_opt(), seqs, off), *s2.align(default_opt(), seqs, off), f"LDS stack of {ent}")
     s2.close(); orc.close()
