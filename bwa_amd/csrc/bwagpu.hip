@@ -517,10 +517,6 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.seedsw_minhsp = h->d_minhsp.as<i32>();
 		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>();
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
-		// processing order of the seeding kernel: predicted-heavy reads first (k_seed_weight); weights live in reg_cap_r until k_chain fills it
-		B.n_prio = getenv("BWAGPU_SEED_PRIO") ? atoi(getenv("BWAGPU_SEED_PRIO")) : n / 64;
-		hipLaunchKernelGGL(k_seed_weight, dim3((unsigned)((n + BLOCK - 1) / BLOCK < 4096 ? (n + BLOCK - 1) / BLOCK : 4096)), dim3(BLOCK), 0, h->stream, h->ix, B, B.reg_cap_r);
-		if (int rc2 = order_reads(h, B, B.reg_cap_r)) return rc2;
 		HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
 		hipLaunchKernelGGL(k_seed, grid, block, (size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * BLOCK * sizeof(uint4), h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[7], h->stream));

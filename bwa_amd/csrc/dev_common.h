@@ -100,7 +100,6 @@ struct Batch {
 	int max_len;               // longest read of the batch
 	int stats;                 // collect work counters
 	const u8 *seq;             // concatenated nt4 codes
-	int n_prio;                // k_seed: reads at order positions below this are predicted heavy (issue priority)
 	u64 *seq_nib;              // the same bases at 4 bits each, 16 per word (k_pack_reads; read by the seeding kernel)
 	const i64 *off;            // n_reads + 1
 	Counters *ctr;

@@ -43,7 +43,6 @@ struct SeedLane {
 	bool any;
 	BiIntv ik, p;
 	u32 code;                 // prefix-table window: forward sweep, q[sx..sx+ptab_m); backward sweep, q[i..i+ptab_m) (window_code)
-	bool heavy;               // this lane's read came from the predicted-heavy head of the processing order
 	int top;                  // index of the longest match in the interval stack (prev[j] = the entry j below the top)
 	int slot;                 // forward sweep: ring position of the next push; backward sweep: ring position of the top entry
 	SeedEmit em;
@@ -217,29 +216,6 @@ __global__ void __launch_bounds__(256) k_publish(bwagpu_opt_t opt, Batch B)
 	if (B.stats) atomicAdd(&B.ctr->n_intv, (unsigned long long)nintv);
 }
 
-// Seeding cost predictor: a read from repetitive sequence takes many more extension steps (up to ~18x the average), and the
-// kernel ends when the lane that drew the heaviest read finishes -- so predicted-heavy reads should start first.  The
-// occurrence counts of a few of the read's m-mers are one prefix-table look-up each; weight = 2^(sum of their log2 / 15),
-// which k_order_* turn into roughly linear bins of the log-sum.  (Measured offline: 89 % of the 1000 heaviest reads of a
-// 1 M-read batch fall into the predicted top 5 %.)
-__global__ void __launch_bounds__(256) k_seed_weight(DevIndex ix, Batch B, i32 *weight)
-{
-	const int m = ix.ptab_m;
-	for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < B.n_reads; r += gridDim.x * blockDim.x) {
-		const u64 qoff = (u64)B.off[r]; const int len = (int)(B.off[r + 1] - B.off[r]);
-		int sum = 0, ns = 0;
-		if (m > 0)
-			for (int p = 0; p + m <= len && ns < 15; p += (len >= 150 ? len / 15 : 10), ++ns) {
-				u32 code = 0;
-				for (int k = 0; k < m; ++k) { const u64 g = qoff + (u64)(p + k); code = code << 2 | (u32)(B.seq_nib[g >> 4] >> ((g & 15) << 2) & 3); }
-				const u64 occ = SeedStack::unpack(ix.ptab[(u64)code * (u32)m + (u32)(m - 1)]).x2;
-				sum += 64 - __clzll((long long)(occ + 1));
-			}
-		const int b = ns ? sum * 15 / ns / 15 : 0;          // mean log2 count, scaled as if 15 samples had been taken, / 15
-		weight[r] = 1 << (b > 30 ? 30 : b);
-	}
-}
-
 __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
 	HIP_DYNAMIC_SHARED(uint4, seed_lds)
@@ -253,18 +229,13 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 	L.em.mem = B.intv; L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len;
 	L.st = SS_FETCH; L.r = -1; L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u;
 	const u64 *nib = B.seq_nib;
-	u32 nblk = 0, ntab = 0, it = 0;
-	L.heavy = false;
+	u32 nblk = 0, ntab = 0;
 	while (L.st != SS_DONE) {
-		// a wave that holds a predicted-heavy read gets issue priority: that read is the kernel's critical path
-		if ((it++ & 63) == 0) { if (__any(L.heavy)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
 		// ---- advance the lane's state up to its next extension -----------------------------------------------------
 		switch (L.st) {
 		case SS_FETCH: {
 			int r = (int)atomicAdd(&B.ctr->next_read, 1ull);
-			if (r >= B.n_reads) { L.st = SS_DONE; L.heavy = false; break; }
-			L.heavy = r < B.n_prio;                             // drawn from the predicted-heavy head of the order
-			r = B.order[r];
+			if (r >= B.n_reads) { L.st = SS_DONE; break; }
 			L.r = r; L.qoff = (u64)B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
 			B.intv_n[r] = 0;
 			L.em.mem = B.intv + (size_t)r * B.mem_cap;      // the read's own interval list (sorted and consumed by k_publish)

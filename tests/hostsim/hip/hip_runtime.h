@@ -84,7 +84,6 @@ static inline int __shfl_xor(int v, int x) { uint64_t o[64], m; mock_exchange((u
 static inline unsigned long long __ballot(int p) { uint64_t o[64], m; mock_exchange(p ? 1 : 0, o, &m); unsigned long long r = 0; for (int i = 0; i < 64; ++i) if ((m >> i & 1) && o[i]) r |= 1ull << i; return r; }
 void mock_block_barrier();
 #define __syncthreads() mock_block_barrier()
-static inline int __any(int p) { return __ballot(p) != 0; }
 static inline void mock_wave_barrier() { uint64_t o[64], m; mock_exchange(0, o, &m); }
 // DPP / readlane emulation (gfx9 semantics; bound_ctrl = 0 keeps `old` where the source lane is invalid or masked off)
 static inline int mock_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
@@ -103,7 +102,6 @@ static inline int mock_update_dpp(int old, int src, int ctrl, int row_mask, int 
 static inline int mock_readlane(int v, int src) { uint64_t o[64], m; mock_exchange((uint32_t)v, o, &m); return (int)(uint32_t)o[src & 63]; }
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) mock_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_readlane(v, l) mock_readlane((v), (l))
-#define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define __builtin_amdgcn_readfirstlane(v) (v)   /* used only on wave-uniform values */
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_wave_barrier() mock_wave_barrier()
