@@ -534,11 +534,17 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		if (int rc2 = order_reads(h, B, B.reg_cap_r)) return rc2;   // heaviest reads (most seeds in kept chains) first
 		// wave-per-read extension with the DP columns in LDS; its row-max scan packs (score << 6 | lane) into 31 bits
 		i64 max_score = (i64)h->max_len * (opt->a > 0 ? opt->a : 1) * 2 + 1024;
+		int ring_cols = 256;                     // long reads: ring of {H,E} columns wide enough for the widest band (2 * opt.w, bwamem.c:742)
+		while (ring_cols < 4 * opt->w + 4 + 128) ring_cols <<= 1;
 		if (h->max_len <= WAVE_EXT_MAX_LEN && max_score < (1 << 24)) {
 			int lds_wave = (8 * (h->max_len + 2 + 64) + 5 * ((h->max_len + 64 + 3) & ~3) + 15) & ~15;
 			i64 nblk = ((i64)n + 3) / 4, cap = 256 * 8;
-			hipLaunchKernelGGL(k_extend_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave);
-		} else                                  // long reads: lane-per-read scalar DP with the columns in HBM scratch
+			hipLaunchKernelGGL(k_extend_wave<false>, dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
+		} else if (max_score < (1 << 24) && ring_cols <= 2048) {
+			int lds_wave = 8 * ring_cols + 32;   // the band's columns only: independent of the read length
+			i64 nblk = ((i64)n + 3) / 4, cap = 256 * 8;
+			hipLaunchKernelGGL(k_extend_wave<true>, dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, ring_cols);
+		} else                                  // very wide bands: lane-per-read scalar DP with the columns in HBM scratch
 			hipLaunchKernelGGL(k_extend, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
 		hipLaunchKernelGGL(k_dedup, grid, block, 0, h->stream, h->ix, *opt, B);

@@ -66,9 +66,13 @@ DEVFN long long wave_fetch(unsigned long long *ctr)
 }
 DEVFN bwagpu_seed_t uni_seed(bwagpu_seed_t s) { s.rbeg = uni64(s.rbeg); s.qbeg = uni(s.qbeg); s.len = uni(s.len); s.score = uni(s.score); return s; }
 
-struct WaveLds { int2 *eh; int8_t *qp; int qstride; };
+// LDS of one wave.  Short reads: eh[] holds every query column and qp[] the 5 x qlen query profile.  Long reads (RING): a row of
+// ksw_extend2 only touches columns i-w .. i+w+1, columns left of the band are dead and columns right of it still hold their
+// first-row values, so eh[] is a ring of ring_mask+1 columns that is initialised lazily as the band advances, and scores come
+// from a 25-entry copy of the matrix (mat) and the query bases in global memory.
+struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t *mat; };
 
-__device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, int mat_max, const u8 *q, int q0, const int qdir, int qlen,
+template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, int mat_max, const u8 *q, int q0, const int qdir, int qlen,
 								   i64 t0, const int tdir, int tlen, int w, int end_bonus, int h0, const WaveLds &L, u64 &cells)
 {
 	const int lane = threadIdx.x & 63;
@@ -78,14 +82,18 @@ __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, 
 	// every argument is wave-uniform: keep it in SGPRs so that the row loop's control flow and address arithmetic are scalar
 	q0 = uni(q0); qlen = uni(qlen); tlen = uni(tlen); w = uni(w); h0 = uni(h0); end_bonus = uni(end_bonus); t0 = uni64(t0);
 	// query profile (ksw.c:425-428) and first row (ksw.c:430-433: H(-1,-1) = h0, then an insertion ramp)
-	for (int k = 0; k < 5; ++k)
-		for (int j = lane; j < qlen; j += 64) qp[k * qs + j] = opt.mat[k * 5 + q[q0 + j * qdir]];
+	#define EHI(j) (RING ? ((j) & L.ring_mask) : (j))
 	const int v1 = h0 > oe_ins ? h0 - oe_ins : 0;
-	for (int j = lane; j <= qlen; j += 64) {
-		int hv = j == 0 ? h0 : v1 - (j - 1) * e_ins;
-		eh[j] = make_int2(hv > 0 ? hv : 0, 0);
+	if (!RING) {
+		for (int k = 0; k < 5; ++k)
+			for (int j = lane; j < qlen; j += 64) qp[k * qs + j] = opt.mat[k * 5 + q[q0 + j * qdir]];
+		for (int j = lane; j <= qlen; j += 64) {
+			int hv = j == 0 ? h0 : v1 - (j - 1) * e_ins;
+			eh[j] = make_int2(hv > 0 ? hv : 0, 0);
+		}
+		wave_sync();
 	}
-	wave_sync();
+	int init_hi = -1;                                  // RING: columns 0..init_hi hold valid (initial or computed) values
 	int lim = (int)((double)(qlen * mat_max + end_bonus - o_ins) / e_ins + 1.); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	lim = (int)((double)(qlen * mat_max + end_bonus - o_del) / e_del + 1.); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	int beg = 0, end = qlen, max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, treg = 0;
@@ -97,6 +105,17 @@ __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, 
 		if (end > i + w + 1) end = i + w + 1;
 		if (end > qlen) end = qlen;
 		beg = uni(beg); end = uni(end);
+		if (RING) {      // first-row values (ksw.c:430-433) for the columns this row can reach for the first time
+			int hi = i + w + 2 < qlen ? i + w + 2 : qlen;
+			if (hi > init_hi) {
+				for (int j = init_hi + 1 + lane; j <= hi; j += 64) {
+					int hv = j == 0 ? h0 : v1 - (j - 1) * e_ins;
+					eh[EHI(j)] = make_int2(hv > 0 ? hv : 0, 0);
+				}
+				init_hi = hi;
+				wave_sync();
+			}
+		}
 		int h1_init = 0;
 		if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
 		int m = 0, mj = -1, carry = W_NEG, hprev = h1_init, first_nz = -1, last_nz = -1, bnd = 0;
@@ -104,9 +123,11 @@ __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, 
 		for (int b = beg; b < end; b += 64) {
 			const int j = b + lane; const bool act = j < end;
 			// the LDS region is padded by 64 columns, so inactive lanes may read (never write) past `end`
-			int2 old = eh[j];
-			const int sc = qrow[j];
-			const int bnd_next = eh[b + 64].x;             // next pass's diagonal for its lane 0, before lane 63 overwrites it
+			int2 old = eh[EHI(j)];
+			int sc;
+			if (RING) { const int qc = j < qlen ? (int)q[q0 + j * qdir] : 4; sc = L.mat[tb * 5 + qc]; }
+			else sc = qrow[j];
+			const int bnd_next = eh[EHI(b + 64)].x;             // next pass's diagonal for its lane 0, before lane 63 overwrites it
 			if (b != beg && lane == 0) old.x = bnd;
 			wave_sync();
 			const int M = old.x ? old.x + sc : 0;          // ksw.c:469: a dead diagonal cell stays dead
@@ -117,10 +138,10 @@ __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, 
 			const int h = imax(imax(M, old.y), f);                    // H(i,j) = max(M, E, F), ksw.c:470-471
 			const int e_new = imax(imax(old.y - e_del, M - oe_del), 0); // E(i+1,j), ksw.c:475-479
 			if (act) {
-				eh[j].y = e_new;
-				eh[j + 1].x = h;                                       // becomes the diagonal of column j+1 in row i+1
+				eh[EHI(j)].y = e_new;
+				eh[EHI(j + 1)].x = h;                                  // becomes the diagonal of column j+1 in row i+1
 			}
-			if (j == beg) eh[j].x = h1_init;
+			if (j == beg) eh[EHI(j)].x = h1_init;
 			const int hleft = wave_shift_up1(h, hprev);               // eh[j].h after this row = H(i,j-1)
 			const u64 nzm = __ballot(act && (hleft | e_new) != 0);
 			if (nzm) { if (first_nz < 0) first_nz = b + __ffsll((unsigned long long)nzm) - 1; last_nz = b + 63 - __clzll((long long)nzm); }
@@ -135,7 +156,7 @@ __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, 
 		}
 		const int h1 = beg < end ? hprev : h1_init;      // H(i, end-1) as left in h1 by the reference's column loop
 		const int jfin = beg < end ? end : beg;
-		if (lane == 0) { eh[end].x = h1; eh[end].y = 0; }
+		if (lane == 0) { eh[EHI(end)].x = h1; eh[EHI(end)].y = 0; }
 		wave_sync();
 		if (jfin == qlen) { if (h1 >= gscore) max_ie = i; if (h1 > gscore) gscore = h1; }
 		if (m == 0) break;
@@ -154,12 +175,13 @@ __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, 
 		beg = nbeg;
 		end = jl + 2 < qlen ? jl + 2 : qlen;
 	}
+	#undef EHI
 	ExtRes r; r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
 	return r;
 }
 
 // mem_chain2aln for all chains of one read, executed by one wavefront.
-__device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const WaveLds &L,
+template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const WaveLds &L,
 							  u64 &n_calls, u64 &n_cells, u64 &n_refb)
 {
 	const int lane = threadIdx.x & 63;
@@ -264,7 +286,7 @@ __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const
 				for (int i = 0; i < 2; ++i) {
 					int prev = a.score;
 					aw0 = opt.w << i;
-					x = wave_ksw_extend2(ix, opt, mat_max, query, s.qbeg - 1, -1, s.qbeg, s.rbeg - 1, -1, tl, aw0, opt.pen_clip5, s.len * opt.a, L, n_cells);
+					x = wave_ksw_extend2<RING>(ix, opt, mat_max, query, s.qbeg - 1, -1, s.qbeg, s.rbeg - 1, -1, tl, aw0, opt.pen_clip5, s.len * opt.a, L, n_cells);
 					++n_calls;
 					a.score = x.score;
 					if (a.score == prev || x.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
@@ -279,7 +301,7 @@ __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const
 				for (int i = 0; i < 2; ++i) {
 					int prev = a.score;
 					aw1 = opt.w << i;
-					x = wave_ksw_extend2(ix, opt, mat_max, query, qe, 1, l_query - qe, re, 1, (int)(rmax1 - re), aw1, opt.pen_clip3, sc0, L, n_cells);
+					x = wave_ksw_extend2<RING>(ix, opt, mat_max, query, qe, 1, l_query - qe, re, 1, (int)(rmax1 - re), aw1, opt.pen_clip3, sc0, L, n_cells);
 					++n_calls;
 					a.score = x.score;
 					if (a.score == prev || x.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
@@ -306,16 +328,24 @@ __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const
 }
 
 // One wavefront per read, 4 waves per workgroup; dynamic LDS = 4 private regions of
-// 8*(max_len+2+64) bytes of {H,E} columns + 5*qstride bytes of query profile.
-__global__ void __launch_bounds__(256) k_extend_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int lds_per_wave)
+// 8*(max_len+2+64) bytes of {H,E} columns + 5*qstride bytes of query profile, or (RING, long reads) of ring_cols*8 + 32 bytes.
+template <bool RING> __global__ void __launch_bounds__(256) k_extend_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int lds_per_wave, int ring_cols)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, dyn_lds)
 	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	WaveLds L;
 	unsigned char *base = dyn_lds + (size_t)wave_in_blk * lds_per_wave;
 	L.eh = (int2*)base;                                      // max_len + 2 columns + 64 of read-only padding
-	L.qstride = (B.max_len + 64 + 3) & ~3;
-	L.qp = (int8_t*)(base + (size_t)8 * (B.max_len + 2 + 64));
+	if (RING) {
+		int8_t *m = (int8_t*)(base + (size_t)8 * ring_cols);
+		if (lane < 25) m[lane] = opt.mat[lane];
+		L.mat = m; L.ring_mask = ring_cols - 1; L.qp = nullptr; L.qstride = 0;
+		wave_sync();
+	} else {
+		L.qstride = (B.max_len + 64 + 3) & ~3;
+		L.qp = (int8_t*)(base + (size_t)8 * (B.max_len + 2 + 64));
+		L.mat = nullptr; L.ring_mask = 0;
+	}
 	u64 calls = 0, cells = 0, refb = 0, nraw = 0;
 	// Reads are handed out heaviest first from a global counter: a wave that drew light reads simply draws more of them, and
 	// the launch needs no particular relation between its grid and the number of resident workgroups.
@@ -323,7 +353,7 @@ __global__ void __launch_bounds__(256) k_extend_wave(DevIndex ix, bwagpu_opt_t o
 		const long long k = wave_fetch(&B.ctr->next_ext);
 		if (k >= B.n_reads) break;
 		const int r = B.order[k];
-		ext_read_wave(ix, opt, B, r, L, calls, cells, refb);
+		ext_read_wave<RING>(ix, opt, B, r, L, calls, cells, refb);
 		wave_sync();
 		nraw += B.reg_n_raw[r];
 	}

@@ -11,7 +11,7 @@ import testdata
 from cmputil import assert_regs_equal, golden_opts, golden_sets
 from bwa_amd import simdata
 from bwa_amd.api import BwaGpu
-from bwa_amd.structs import ALNREG_DTYPE, default_opt
+from bwa_amd.structs import ALNREG_DTYPE, default_opt, pacbio_opt
 
 
 @pytest.fixture(scope="module")
@@ -151,3 +151,14 @@ def test_hostsim_device_cigars_give_the_same_sam(sim):
     gapped = int(((cigs["n_cigar"] > 1)).sum())
     assert gapped > 0, "no gapped alignment exercised the traceback"
     host.close()
+
+
+def test_hostsim_long_reads_ring_extension(sim):
+    """Reads beyond the short-read limit take the wave extension kernel in ring mode ({H,E} columns of the band only, lazily
+    initialised) -- same regions as the oracle for noisy 1.8 kb reads with the pacbio preset and a 1.5 kb read with defaults (the GPU suite runs 4-5 kb)."""
+    prefix, g = testdata.small_index()
+    orc = orcapi.OrcIndex(prefix)
+    for n, opt, kw in ((2, pacbio_opt(), dict(length=1800, sub=0.05, dele=0.04, ins=0.04)), (1, default_opt(), dict(length=1500, sub=0.02, dele=0.005, ins=0.005))):
+        seqs, off = testdata.flat(simdata.make_reads_se(g, n, seed=97, **kw))
+        assert_regs_equal(*orc.align(opt, seqs, off), *sim.align(opt, seqs, off), f"long reads {kw}")
+    orc.close()

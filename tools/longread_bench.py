@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""GPU-box measurement of the long-read path (BASELINE configs[4] shape: 10 kb reads, -x pacbio) -- a parity-test
+configuration, not the bench line; prints reads/s and the stage times of one batch."""
+import argparse, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from bwa_amd import simdata
+from bwa_amd.api import BwaGpu
+from bwa_amd.structs import pacbio_opt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genome-mbp", type=float, default=512.0)
+    ap.add_argument("--reads", type=int, default=20000)
+    ap.add_argument("--read-len", type=int, default=10000)
+    ap.add_argument("--cache", default=os.environ.get("BWA_AMD_CACHE", "/tmp/bwa_amd_bench"))
+    a = ap.parse_args()
+    import torch
+    fa, g = bench.build_or_load_index(a.genome_mbp, a.cache, 0, lambda: torch.cuda.synchronize())
+    gpu = BwaGpu(fa); gpu.densify_sa(4); gpu.set_taps(False)
+    rd = simdata.make_reads_se(g, a.reads, length=a.read_len, seed=5, sub=0.04, dele=0.04, ins=0.04)
+    off = np.arange(0, a.reads + 1, dtype=np.int64) * a.read_len
+    opt = pacbio_opt()
+    gpu.upload(np.ascontiguousarray(rd.reshape(-1)), off)
+    t = time.time(); gpu.run(opt); dt0 = time.time() - t
+    t = time.time(); gpu.run(opt); dt = time.time() - t
+    st = gpu.stats()
+    counts, regs = gpu.download()
+    print(f"[longread] {a.reads} x {a.read_len} bp -x pacbio: first pass {dt0:.2f}s, second {dt:.2f}s -> {a.reads / dt:.0f} reads/s ({a.reads * a.read_len / dt / 1e6:.1f} Mbp/s); "
+          f"regions {regs.shape[0]}, retries {st['n_retries']}, stage ms: " + ", ".join(f"{k[3:]} {st[k]:.0f}" for k in ("ms_seed", "ms_sa", "ms_chain", "ms_seedsw", "ms_extend", "ms_dedup")), flush=True)
+
+
+if __name__ == "__main__":
+    main()
