@@ -28,6 +28,7 @@
 #include "dev_dedup.h"
 #include "dev_seedsw.h"
 #include "dev_cigar.h"
+#include "dev_dedupw.h"
 
 #define BWAGPU_VERSION "bwagpu 0.1 (gfx950)"
 
@@ -529,7 +530,10 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
 		hipLaunchKernelGGL(k_chain, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
-		if (any_seedsw) hipLaunchKernelGGL(k_seedsw, grid, block, 0, h->stream, h->ix, *opt, B);
+		if (any_seedsw && h->max_len > WAVE_EXT_MAX_LEN) {   // long reads: one wavefront per read, one lane per seed
+			i64 nblk = ((i64)n + 3) / 4, cap = n_threads / BLOCK;
+			hipLaunchKernelGGL(k_seedsw_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), block, 0, h->stream, h->ix, *opt, B);
+		} else if (any_seedsw) hipLaunchKernelGGL(k_seedsw, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
 		if (int rc2 = order_reads(h, B, B.reg_cap_r)) return rc2;   // heaviest reads (most seeds in kept chains) first
 		// wave-per-read extension with the DP columns in LDS; its row-max scan packs (score << 6 | lane) into 31 bits
@@ -547,7 +551,12 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		} else                                  // very wide bands: lane-per-read scalar DP with the columns in HBM scratch
 			hipLaunchKernelGGL(k_extend, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
-		hipLaunchKernelGGL(k_dedup, grid, block, 0, h->stream, h->ix, *opt, B);
+		if (h->max_len > WAVE_EXT_MAX_LEN) {     // long reads: few reads, long patch alignments -> one wavefront per read
+			int rc_ = 256; while (rc_ < 8 * opt->w + 4 + 128 && rc_ < 2048) rc_ <<= 1;
+			i64 nblk = ((i64)n + 3) / 4, cap = n_threads / BLOCK;   // dp_h/dp_e hold one scratch region per wave of the standard grid
+			hipLaunchKernelGGL(k_dedup_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)(8 * rc_ + 32) * 4, h->stream, h->ix, *opt, B, rc_);
+		} else
+			hipLaunchKernelGGL(k_dedup, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
 		HIPCHK(h, hipGetLastError());
 		h->phase = 22 + attempt * 100;

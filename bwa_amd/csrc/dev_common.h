@@ -68,6 +68,7 @@ struct Counters {          // device-side bump allocators + flags
 	unsigned long long intv_used, seed_used, node_used, reg_used;
 	unsigned long long next_read;  // work counter of the seeding kernel
 	unsigned long long next_ext;   // work counter of the wave extension kernel (position in Batch::order)
+	unsigned long long next_seedsw;                // work counter of the wave-per-read seed re-scoring kernel (long reads)
 	unsigned long long next_chain, next_dedup;   // work counters of the lane-per-read chaining and de-duplication kernels
 	unsigned long long overflow;   // bit0 intv, bit1 seed, bit2 node, bit3 reg, bit4 tmp-intv scratch
 	// algorithmic work counters (bwagpu_stats_t)

@@ -1,0 +1,314 @@
+// dev_dedupw.h -- mem_sort_dedup_patch for long reads, one wavefront per read.
+//
+// Same decisions as dedup_read (dev_dedup.h), but the score-only global alignments of mem_patch_reg span thousands of
+// bases for 10 kb reads and there are only as many reads as a few hundred wavefronts have lanes, so the DP runs
+// row-parallel over the wave (ksw_global2 opens gaps from M, dev_cigar.h) with the band's {H, E} columns in an LDS ring;
+// the order-dependent control logic runs wave-uniformly and lane 0 performs the sorts and the stores.
+#pragma once
+#include "dev_dedup.h"
+#include "dev_extw.h"
+
+struct DedupLds { i32 *hd, *e; const int8_t *mat; int ring_mask; i32 *H, *E; /* lane 0's HBM scratch columns (dev_ksw_global2_score) for bands wider than the ring */ };
+
+// ksw_global2 without traceback (ksw.c:540-619), columns in a ring of ring_mask+1 entries, lazily initialised
+__device__ int wave_global2_score_ring(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen, i64 t0, int tdir, int tlen,
+									   int w, const DedupLds &L, u64 &cells)
+{
+	const int lane = threadIdx.x & 63;
+	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+	i32 *hd = L.hd, *e_ = L.e; const int rm = L.ring_mask;
+	int init_hi = -1, treg = 0;
+	for (int i = 0; i < tlen; ++i) {
+		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
+		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
+		const int beg = i > w ? i - w : 0, end = i + w + 1 < qlen ? i + w + 1 : qlen;
+		{	// first-row values (ksw.c:566-570) of the columns this row can reach for the first time
+			const int hi = i + w + 2 < qlen ? i + w + 2 : qlen;
+			if (hi > init_hi) {
+				for (int j = init_hi + 1 + lane; j <= hi; j += 64) {
+					hd[j & rm] = j == 0 ? 0 : (j <= w ? -(o_ins + e_ins * j) : DEV_NEG_INF);
+					e_[j & rm] = DEV_NEG_INF;
+				}
+				init_hi = hi;
+				wave_sync();
+			}
+		}
+		const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : DEV_NEG_INF;
+		int carry = I32_MIN, bnd = 0;
+		cells += (u64)(end > beg ? end - beg : 0);
+		for (int b = beg; b < end; b += 64) {
+			const int j = b + lane; const bool act = j < end;
+			int dg = hd[j & rm]; const int ec = e_[j & rm];
+			const int qc = j < qlen ? (int)q[q0 + j * qdir] : 4;
+			const int sc = L.mat[tb * 5 + qc];
+			const int bnd_next = hd[(b + 64) & rm];
+			if (b != beg && lane == 0) dg = bnd;
+			wave_sync();
+			const int m = dg + sc;
+			const int a = act ? m - oe_ins + j * e_ins : I32_MIN;
+			const int inc = wave_incl_scan_max(a);
+			const int exc = imax(wave_shift_up1(inc, I32_MIN), carry);
+			int f = DEV_NEG_INF - (j - beg) * e_ins;
+			if (j > beg && act) f = imax(f, exc - (j - 1) * e_ins);
+			int h = m >= ec ? m : ec;
+			if (h < f) h = f;
+			const int t = m - oe_del; int en = ec - e_del; if (en < t) en = t;
+			if (act) { e_[j & rm] = en; hd[(j + 1) & rm] = h; }
+			if (b == beg && lane == 0) hd[beg & rm] = h1_init;
+			carry = imax(carry, __builtin_amdgcn_readlane(inc, 63));
+			bnd = bnd_next;
+			wave_sync();
+		}
+		if (lane == 0) e_[end & rm] = DEV_NEG_INF;
+		wave_sync();
+	}
+	const int score = hd[qlen & rm];
+	wave_sync();
+	return score;
+}
+
+// bwa_gen_cigar2 in score-only mode (bwa.c:148-194).  A band that does not fit the ring (rare: the length difference of the two
+// segments exceeds 4 * opt.w) is computed by lane 0 alone with its columns in HBM scratch.
+__device__ int wave_global_score(const DevIndex &ix, const bwagpu_opt_t &opt, int w_, int l_query, const u8 *query, i64 rb, i64 re,
+								 const DedupLds &L, u64 &calls, u64 &cells)
+{
+	const int lane = threadIdx.x & 63;
+	const i64 l_pac = ix.l_pac;
+	if (l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac)) return 0;
+	const int rlen = (int)(re - rb), rev = rb >= l_pac;
+	const int q0 = rev ? l_query - 1 : 0, qdir = rev ? -1 : 1; const i64 t0 = rev ? re - 1 : rb; const int tdir = rev ? -1 : 1;
+	if (l_query == rlen && w_ == 0) {
+		int s = 0;
+		for (int i = lane; i < l_query; i += 64) s += opt.mat[ref_base(ix, t0 + (i64)i * tdir) * 5 + query[q0 + i * qdir]];
+		for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+		return s;
+	}
+	int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+	int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+	int mg = max_ins > max_del ? max_ins : max_del, dl = rlen - l_query;
+	if (dl < 0) dl = -dl;
+	if (mg < 1) mg = 1;
+	int w = (mg + dl + 1) >> 1; if (w > w_) w = w_;
+	if (w < dl + 3) w = dl + 3;
+	++calls;
+	if (2 * w + 4 + 128 > L.ring_mask + 1) {
+		int sc = 0;
+		if (lane == 0) sc = dev_ksw_global2_score(ix, opt, query, q0, qdir, l_query, t0, tdir, rlen, w, L.H, L.E, cells);
+		sc = __builtin_amdgcn_readlane(sc, 0);
+		wave_sync();
+		return sc;
+	}
+	return wave_global2_score_ring(ix, opt, query, q0, qdir, l_query, t0, tdir, rlen, w, L, cells);
+}
+
+// mem_patch_reg (bwamem.c:432-461); all arguments wave-uniform
+__device__ int wave_patch_reg(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *query, const bwagpu_alnreg_t &a, const bwagpu_alnreg_t &b,
+							  int *w_out, const DedupLds &L, u64 &calls, u64 &cells)
+{
+	if (a.rb < ix.l_pac && b.rb >= ix.l_pac) return 0;
+	if (a.qb >= b.qb || a.qe >= b.qe || a.re >= b.re) return 0;
+	int w = (int)((a.re - b.rb) - (a.qe - b.qb)); if (w < 0) w = -w;
+	double r = (double)(a.re - b.rb) / (b.re - a.rb) - (double)(a.qe - b.qb) / (b.qe - a.qb); if (r < 0.) r = -r;
+	if (a.re < b.rb || a.qe < b.qb) { if (w > opt.w << 1 || r >= 0.05f) return 0; }
+	else if (w > opt.w << 2 || r >= 0.05f * 2) return 0;
+	w += a.w + b.w;
+	if (w > opt.w << 2) w = opt.w << 2;
+	int score = wave_global_score(ix, opt, w, b.qe - a.qb, query + a.qb, a.rb, b.re, L, calls, cells);
+	int q_s = (int)((double)(b.qe - a.qb) / ((b.qe - b.qb) + (a.qe - a.qb)) * (b.score + a.score) + .499);
+	int r_s = (int)((double)(b.re - a.rb) / ((b.re - b.rb) + (a.re - a.rb)) * (b.score + a.score) + .499);
+	if ((double)score / (q_s > r_s ? q_s : r_s) < 0.90f) return 0;
+	*w_out = w;
+	return score;
+}
+
+// a wave-uniform copy of a region record (every lane loads the same address)
+DEVFN bwagpu_alnreg_t uni_reg(const bwagpu_alnreg_t *p)
+{
+	bwagpu_alnreg_t r = *p;
+	r.rb = uni64(r.rb); r.re = uni64(r.re); r.qb = uni(r.qb); r.qe = uni(r.qe); r.rid = uni(r.rid); r.score = uni(r.score); r.w = uni(r.w);
+	return r;
+}
+
+// mem_sort_dedup_patch (bwamem.c:463-515) for one read.  Every store by lane 0 is bracketed by wave_sync: the other lanes read
+// the same records to take the same branches.
+__device__ void dedup_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const DedupLds &L, u64 &calls, u64 &cells)
+{
+	const int lane = threadIdx.x & 63;
+	int n = uni(B.reg_n_raw[r]);
+	bwagpu_alnreg_t *a = B.regs + uni64(B.reg_off[r]);
+	const u8 *query = B.seq + uni64(B.off[r]);
+	if (B.regs_raw) { for (int i = lane; i < n; i += 64) B.regs_raw[B.reg_off[r] + i] = a[i]; }
+	if (n > 1) {
+		wave_sync();
+		if (lane == 0) {
+			dev_introsort(a, n, RegEndLess());
+			for (int i = 0; i < n; ++i) a[i].n_comp = 1;
+		}
+		wave_sync();
+		for (int i = 1; i < n; ++i) {
+			bwagpu_alnreg_t p = uni_reg(&a[i]);
+			{
+				const bwagpu_alnreg_t pr = uni_reg(&a[i - 1]);
+				if (p.rid != pr.rid || p.rb >= pr.re + opt.max_chain_gap) continue;
+			}
+			bool p_dirty = false;
+			for (int j = i - 1; j >= 0; --j) {
+				bwagpu_alnreg_t q = uni_reg(&a[j]);
+				if (!(p.rid == q.rid && p.rb < q.re + opt.max_chain_gap)) break;
+				i64 orr, oq, mr, mq; int score, w = 0;
+				if (q.qe == q.qb) continue;
+				orr = q.re - p.rb;
+				oq = q.qb < p.qb ? q.qe - p.qb : p.qe - q.qb;
+				mr = q.re - q.rb < p.re - p.rb ? q.re - q.rb : p.re - p.rb;
+				mq = q.qe - q.qb < p.qe - p.qb ? q.qe - q.qb : p.qe - p.qb;
+				if (orr > opt.mask_level_redun * mr && oq > opt.mask_level_redun * mq) {
+					if (p.score < q.score) { p.qe = p.qb; p_dirty = true; break; }
+					else { wave_sync(); if (lane == 0) a[j].qe = q.qb; wave_sync(); }
+				} else if (q.rb < p.rb) {
+					score = wave_patch_reg(ix, opt, query, q, p, &w, L, calls, cells);
+					if (score > 0) {
+						p.n_comp += q.n_comp + 1;
+						if (q.seedcov > p.seedcov) p.seedcov = q.seedcov;
+						if (q.sub > p.sub) p.sub = q.sub;
+						if (q.csub > p.csub) p.csub = q.csub;
+						p.qb = q.qb; p.rb = q.rb;
+						p.truesc = p.score = score;
+						p.w = w;
+						p_dirty = true;
+						wave_sync();
+						if (lane == 0) a[j].qb = q.qe;
+						wave_sync();
+					}
+				}
+			}
+			if (p_dirty) { wave_sync(); if (lane == 0) a[i] = p; wave_sync(); }
+		}
+		wave_sync();
+		if (lane == 0) {
+			int m = 0;
+			for (int i = 0; i < n; ++i) if (a[i].qe > a[i].qb) { if (m != i) a[m] = a[i]; ++m; }
+			n = m;
+			dev_introsort(a, n, RegBestLess());
+			for (int i = 1; i < n; ++i)
+				if (a[i].score == a[i - 1].score && a[i].rb == a[i - 1].rb && a[i].qb == a[i - 1].qb) a[i].qe = a[i].qb;
+			m = n > 0 ? 1 : 0;
+			for (int i = 1; i < n; ++i) if (a[i].qe > a[i].qb) { if (m != i) a[m] = a[i]; ++m; }
+			n = m;
+		}
+		n = __builtin_amdgcn_readlane(n, 0);
+		wave_sync();
+	}
+	if (lane == 0) {
+		for (int i = 0; i < n; ++i)   // bwamem.c:1111-1115
+			if (a[i].rid >= 0 && ix.ctg_alt[a[i].rid]) a[i].is_alt = 1;
+		B.reg_n[r] = n;
+	}
+	wave_sync();
+}
+
+// One wavefront per read.
+__global__ void __launch_bounds__(256) k_dedup_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int ring_cols)
+{
+	HIP_DYNAMIC_SHARED(unsigned char, ddw_lds)
+	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	unsigned char *base = ddw_lds + (size_t)wave_in_blk * (8 * ring_cols + 32);
+	DedupLds L;
+	L.hd = (i32*)base; L.e = L.hd + ring_cols; L.ring_mask = ring_cols - 1;
+	int8_t *m = (int8_t*)(base + (size_t)8 * ring_cols);
+	if (lane < 25) m[lane] = opt.mat[lane];
+	L.mat = m;
+	{
+		const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_blk;
+		L.H = B.dp_h + wave * (B.max_len + 2) * DPS; L.E = B.dp_e + wave * (B.max_len + 2) * DPS;
+	}
+	wave_sync();
+	u64 calls = 0, cells = 0, nreg = 0;
+	for (;;) {
+		const long long k = wave_fetch(&B.ctr->next_dedup);
+		if (k >= B.n_reads) break;
+		const int r = (int)k;
+		dedup_read_wave(ix, opt, B, r, L, calls, cells);
+		nreg += B.reg_n[r];
+	}
+	if (B.stats && lane == 0) {
+		atomicAdd(&B.ctr->glb_calls, (unsigned long long)calls);
+		atomicAdd(&B.ctr->glb_cells, (unsigned long long)cells);
+		atomicAdd(&B.ctr->n_regs, (unsigned long long)nreg);
+	}
+}
+
+// ---- mem_flt_chained_seeds (bwamem.c:624-645) for long reads: one wavefront per read, one lane per seed --------------------
+// The local re-alignments of a read's seeds are independent of each other; only the compaction that follows is ordered.
+// (seedsw_read, dev_seedsw.h, is the lane-per-read form of the same logic.)
+__device__ void seedsw_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, i32 *H, i32 *E, u64 &calls, u64 &cells)
+{
+	const int lane = threadIdx.x & 63;
+	const int n_ch = uni(B.chain_n[r]);
+	if (n_ch == 0) return;
+	const int l_query = uni((int)(B.off[r + 1] - B.off[r]));
+	const int min_hsp = uni(B.seedsw_minhsp[l_query]);
+	if (min_hsp < 0) return;
+	const u8 *query = B.seq + uni64(B.off[r]);
+	const i64 so = uni64(B.seed_off[r]), l_pac = ix.l_pac;
+	const RegionView R = region_of(B.slot_blob, so, uni(B.seed_n[r]));
+	bwagpu_chain_t *chains = R.cchain;
+	bwagpu_seed_t *seeds = R.cseed;
+	int S = 0;
+	for (int ci = 0; ci < n_ch; ++ci) S += uni(chains[ci].n_seeds);
+	for (int t = lane; t < S; t += 64) {
+		bwagpu_seed_t s = seeds[t];
+		int sc = -1;
+		if (s.len < 200) {
+			int qb = s.qbeg - 50, qe = s.qbeg + s.len + 50;
+			i64 rb = s.rbeg - 50, re = s.rbeg + s.len + 50, mid = (s.rbeg + s.rbeg + s.len) >> 1;
+			if (qb < 0) qb = 0;
+			if (qe > l_query) qe = l_query;
+			if (rb < 0) rb = 0;
+			if (re > l_pac << 1) re = l_pac << 1;
+			if (rb < l_pac && l_pac < re) { if (mid < l_pac) re = l_pac; else rb = l_pac; }
+			if (qe - qb < 200 && re - rb < 200) {
+				int is_rev; int rid = dev_pos2rid(ix, dev_depos(ix, mid, &is_rev));   // bns_fetch_seq clamp
+				i64 fb = ix.ctg_off[rid], fe = fb + ix.ctg_len[rid];
+				if (is_rev) { i64 t2 = fb; fb = (l_pac << 1) - fe; fe = (l_pac << 1) - t2; }
+				if (rb < fb) rb = fb;
+				if (re > fe) re = fe;
+				sc = dev_local_score(ix, opt, query + qb, qe - qb, rb, (int)(re - rb), H, E, cells);
+				++calls;
+			}
+		}
+		seeds[t].score = sc;
+	}
+	wave_sync();
+	if (lane == 0) {
+		int sbeg = 0, m = 0;
+		for (int ci = 0; ci < n_ch; ++ci) {
+			const int n = chains[ci].n_seeds; int k = 0;
+			for (int j = 0; j < n; ++j) {
+				bwagpu_seed_t s = seeds[sbeg + j];
+				if (s.score < 0 || s.score >= min_hsp) {
+					if (s.score < 0) s.score = s.len * opt.a;
+					seeds[m + k] = s; ++k;
+				}
+			}
+			sbeg += n; m += k;
+			chains[ci].n_seeds = k;
+		}
+	}
+	wave_sync();
+}
+
+__global__ void __launch_bounds__(256) k_seedsw_wave(DevIndex ix, bwagpu_opt_t opt, Batch B)
+{
+	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_blk;
+	i32 *H = B.dp_h + wave * (B.max_len + 2) * DPS + lane;
+	i32 *E = B.dp_e + wave * (B.max_len + 2) * DPS + lane;
+	u64 calls = 0, cells = 0;
+	for (;;) {
+		const long long k = wave_fetch(&B.ctr->next_seedsw);
+		if (k >= B.n_reads) break;
+		seedsw_read_wave(ix, opt, B, (int)k, H, E, calls, cells);
+	}
+	if (B.stats) { atomicAdd(&B.ctr->sw_calls, (unsigned long long)calls); atomicAdd(&B.ctr->sw_cells, (unsigned long long)cells); }
+}
