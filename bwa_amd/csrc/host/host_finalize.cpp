@@ -314,12 +314,12 @@ static int get_rlen(const std::vector<uint32_t> &c)
 	return l;
 }
 
-static void add_cigar(const bwagpu_opt_t &opt, const Aln &p, std::string &s, int which)
+static void add_cigar(const bwagpu_opt_t &opt, const std::vector<uint32_t> &cigar, bool is_alt, std::string &s, int which)
 {	// bwamem.c:838-849
-	if (!p.cigar.empty()) {
-		for (uint32_t x : p.cigar) {
+	if (!cigar.empty()) {
+		for (uint32_t x : cigar) {
 			int c = x & 0xf;
-			if (!(opt.flag & F_SOFTCLIP) && !p.is_alt && (c == 3 || c == 4)) c = which ? 4 : 3;
+			if (!(opt.flag & F_SOFTCLIP) && !is_alt && (c == 3 || c == 4)) c = which ? 4 : 3;
 			put_int(s, x >> 4); s += "MIDSH"[c];
 		}
 	} else s += '*';
@@ -327,14 +327,21 @@ static void add_cigar(const bwagpu_opt_t &opt, const Aln &p, std::string &s, int
 
 void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &str, const Read &s, const std::vector<Aln> &list, int which, const Aln *m_, const char *rg_id)
 {
-	Aln p = list[which], mtmp; Aln *m = 0;
+	// The reference works on copies of the record and of the mate (bwamem.c:859-872) because it borrows coordinates from the
+	// mapped end for an unmapped one; only a few scalars and "has no CIGAR any more" change, so those are copied here.
+	const Aln &src = list[which];
+	struct View { int flag, rid, mapq, NM, score, sub, alt_sc; int64_t pos; bool is_rev, is_alt, has_xa; const std::vector<uint32_t> *cigar; const std::string *md, *xa; };
+	static const std::vector<uint32_t> no_cigar;
+	auto view = [](const Aln &a) { View v; v.flag = a.flag; v.rid = a.rid; v.mapq = a.mapq; v.NM = a.NM; v.score = a.score; v.sub = a.sub; v.alt_sc = a.alt_sc; v.pos = a.pos;
+		v.is_rev = a.is_rev; v.is_alt = a.is_alt; v.has_xa = a.has_xa; v.cigar = &a.cigar; v.md = &a.md; v.xa = &a.xa; return v; };
+	View p = view(src), mtmp; View *m = 0;
 	const int n = (int)list.size();
-	if (m_) { mtmp = *m_; m = &mtmp; }
+	if (m_) { mtmp = view(*m_); m = &mtmp; }
 	p.flag |= m ? 0x1 : 0;
 	p.flag |= p.rid < 0 ? 0x4 : 0;
 	p.flag |= m && m->rid < 0 ? 0x8 : 0;
-	if (p.rid < 0 && m && m->rid >= 0) { p.rid = m->rid; p.pos = m->pos; p.is_rev = m->is_rev; p.cigar.clear(); }
-	if (m && m->rid < 0 && p.rid >= 0) { m->rid = p.rid; m->pos = p.pos; m->is_rev = p.is_rev; m->cigar.clear(); }
+	if (p.rid < 0 && m && m->rid >= 0) { p.rid = m->rid; p.pos = m->pos; p.is_rev = m->is_rev; p.cigar = &no_cigar; }
+	if (m && m->rid < 0 && p.rid >= 0) { m->rid = p.rid; m->pos = p.pos; m->is_rev = p.is_rev; m->cigar = &no_cigar; }
 	p.flag |= p.is_rev ? 0x10 : 0;
 	p.flag |= m && m->is_rev ? 0x20 : 0;
 	str += s.name; str += '\t';
@@ -343,7 +350,7 @@ void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &str, cons
 		str += ref.ctg[p.rid].name; str += '\t';
 		put_int(str, p.pos + 1); str += '\t';
 		put_int(str, p.mapq); str += '\t';
-		add_cigar(opt, p, str, which);
+		add_cigar(opt, *p.cigar, p.is_alt, str, which);
 	} else str += "*\t0\t0\t*";
 	str += '\t';
 	if (m && m->rid >= 0) {
@@ -351,9 +358,9 @@ void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &str, cons
 		str += '\t';
 		put_int(str, m->pos + 1); str += '\t';
 		if (p.rid == m->rid) {
-			int64_t p0 = p.pos + (p.is_rev ? get_rlen(p.cigar) - 1 : 0);
-			int64_t p1 = m->pos + (m->is_rev ? get_rlen(m->cigar) - 1 : 0);
-			if (m->cigar.empty() || p.cigar.empty()) str += '0';
+			int64_t p0 = p.pos + (p.is_rev ? get_rlen(*p.cigar) - 1 : 0);
+			int64_t p1 = m->pos + (m->is_rev ? get_rlen(*m->cigar) - 1 : 0);
+			if (m->cigar->empty() || p.cigar->empty()) str += '0';
 			else put_int(str, -(p0 - p1 + (p0 > p1 ? 1 : p0 < p1 ? -1 : 0)));
 		} else str += '0';
 	} else str += "*\t0\t0";
@@ -361,27 +368,27 @@ void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &str, cons
 	if (p.flag & 0x100) str += "*\t*";
 	else {
 		int qb = 0, qe = s.l_seq;
-		const bool trim = !p.cigar.empty() && which && !(opt.flag & F_SOFTCLIP) && !p.is_alt;
+		const bool trim = !p.cigar->empty() && which && !(opt.flag & F_SOFTCLIP) && !p.is_alt;
 		if (!p.is_rev) {
 			if (trim) {
-				if ((p.cigar[0] & 0xf) == 4 || (p.cigar[0] & 0xf) == 3) qb += p.cigar[0] >> 4;
-				if ((p.cigar.back() & 0xf) == 4 || (p.cigar.back() & 0xf) == 3) qe -= p.cigar.back() >> 4;
+				if (((*p.cigar)[0] & 0xf) == 4 || ((*p.cigar)[0] & 0xf) == 3) qb += (*p.cigar)[0] >> 4;
+				if ((p.cigar->back() & 0xf) == 4 || (p.cigar->back() & 0xf) == 3) qe -= p.cigar->back() >> 4;
 			}
 			for (int i = qb; i < qe; ++i) str += "ACGTN"[s.seq[i]];
 			str += '\t';
 			if (s.qual) str.append(s.qual + qb, s.qual + qe); else str += '*';
 		} else {
 			if (trim) {
-				if ((p.cigar[0] & 0xf) == 4 || (p.cigar[0] & 0xf) == 3) qe -= p.cigar[0] >> 4;
-				if ((p.cigar.back() & 0xf) == 4 || (p.cigar.back() & 0xf) == 3) qb += p.cigar.back() >> 4;
+				if (((*p.cigar)[0] & 0xf) == 4 || ((*p.cigar)[0] & 0xf) == 3) qe -= (*p.cigar)[0] >> 4;
+				if ((p.cigar->back() & 0xf) == 4 || (p.cigar->back() & 0xf) == 3) qb += p.cigar->back() >> 4;
 			}
 			for (int i = qe - 1; i >= qb; --i) str += "TGCAN"[s.seq[i]];
 			str += '\t';
 			if (s.qual) for (int i = qe - 1; i >= qb; --i) str += s.qual[i]; else str += '*';
 		}
 	}
-	if (!p.cigar.empty()) { str += "\tNM:i:"; put_int(str, p.NM); str += "\tMD:Z:"; str += p.md; }
-	if (m && !m->cigar.empty()) { str += "\tMC:Z:"; add_cigar(opt, *m, str, which); }
+	if (!p.cigar->empty()) { str += "\tNM:i:"; put_int(str, p.NM); str += "\tMD:Z:"; str += *p.md; }
+	if (m && !m->cigar->empty()) { str += "\tMC:Z:"; add_cigar(opt, *m->cigar, m->is_alt, str, which); }
 	if (m) { str += "\tMQ:i:"; put_int(str, m->mapq); }
 	if (p.score >= 0) { str += "\tAS:i:"; put_int(str, p.score); }
 	if (p.sub >= 0) { str += "\tXS:i:"; put_int(str, p.sub); }
@@ -401,7 +408,7 @@ void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &str, cons
 		}
 		if (p.alt_sc > 0) { char buf[64]; snprintf(buf, sizeof buf, "\tpa:f:%.3f", (double)p.score / p.alt_sc); str += buf; }
 	}
-	if (p.has_xa) { str += (opt.flag & F_XB) ? "\tXB:Z:" : "\tXA:Z:"; str += p.xa; }
+	if (p.has_xa) { str += (opt.flag & F_XB) ? "\tXB:Z:" : "\tXA:Z:"; str += *p.xa; }
 	if (s.comment) { str += '\t'; str += s.comment; }
 	if ((opt.flag & F_REF_HDR) && p.rid >= 0 && !ref.ctg[p.rid].anno.empty()) {
 		str += "\tXR:Z:";
@@ -431,7 +438,7 @@ void reg2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, cons
 		if (p.secondary >= 0) q.sub = -1;
 		if (l && p.secondary < 0) q.flag |= (opt.flag & F_NO_MULTI) ? 0x10000 : 0x800;
 		if (!(opt.flag & F_KEEP_SUPP_MAPQ) && l && !p.is_alt && q.mapq > aa[0].mapq) q.mapq = aa[0].mapq;
-		aa.push_back(q);
+		aa.push_back(std::move(q));
 		++l;
 	}
 	if (aa.empty()) {

@@ -87,7 +87,36 @@ struct Reader {
 	}
 	// drop the characters of A[from..) for which `drop` holds
 	template <class P> static void squeeze(Arena &A, size_t from, P drop) { size_t w = from; for (size_t i = from; i < A.size(); ++i) if (!drop((unsigned char)A[i])) A[w++] = A[i]; A.resize(w); }
+	// The common case -- a four-line FASTQ record that lies completely in the buffer, without '\r' or blanks in the sequence --
+	// located with four memchr calls and appended in bulk; anything else goes through the general reader below.
+	bool read_fast(Seq &s, Arena &A) {
+		if (last != 0 || pos >= len) return false;
+		const char *b = buf.data() + pos, *e = buf.data() + len;
+		if (*b != '@') return false;
+		const char *n1 = (const char*)memchr(b, '\n', (size_t)(e - b)); if (!n1 || n1 + 1 >= e) return false;
+		const char *n2 = (const char*)memchr(n1 + 1, '\n', (size_t)(e - n1 - 1)); if (!n2 || n2 + 1 >= e || n2[1] != '+') return false;
+		const char *n3 = (const char*)memchr(n2 + 1, '\n', (size_t)(e - n2 - 1)); if (!n3 || n3 + 1 >= e) return false;
+		const char *n4 = (const char*)memchr(n3 + 1, '\n', (size_t)(e - n3 - 1)); if (!n4) return false;
+		const char *sq = n1 + 1, *ql = n3 + 1;
+		const size_t ls = (size_t)(n2 - sq), lq = (size_t)(n4 - ql);
+		if (ls == 0 || ls != lq || n1[-1] == '\r' || n2[-1] == '\r' || n4[-1] == '\r') return false;
+		if (sq[0] == '>' || sq[0] == '+' || sq[0] == '@') return false;              // the general reader treats these as record structure
+		for (size_t i = 0; i < ls; ++i) if ((unsigned char)sq[i] <= ' ') return false;   // blanks / control characters: general path
+		const char *h = b + 1, *he = n1, *ne = h;
+		while (ne < he && !isspace((unsigned char)*ne)) ++ne;
+		s = Seq();
+		s.name = A.size(); s.l_name = (int)(ne - h);
+		A.insert(A.end(), h, ne); A.push_back(0);
+		s.comment = A.size();
+		if (ne < he) { s.has_comment = true; A.insert(A.end(), ne + 1, he); }
+		A.push_back(0);
+		s.seq = A.size(); s.l_seq = (int)ls; A.insert(A.end(), sq, sq + ls); A.push_back(0);
+		s.qual = A.size(); s.l_qual = (int)lq; s.has_qual = true; A.insert(A.end(), ql, ql + lq); A.push_back(0);
+		pos = (int)(n4 + 1 - buf.data());
+		return true;
+	}
 	bool read(Seq &s, Arena &A) {
+		if (read_fast(s, A)) return true;
 		int c;
 		if (last == 0) { while ((c = getc_()) != -1 && c != '>' && c != '@') {} if (c == -1) return false; last = c; }
 		s = Seq();
@@ -138,6 +167,7 @@ struct Batch { Arena text; std::vector<Seq> seqs; };
 static bool read_batch(Reader &r1, Reader *r2, int chunk, Batch &out)
 {
 	out.seqs.clear(); out.text.clear();
+	if (out.text.capacity() == 0) { out.text.reserve((size_t)chunk * 5 / 2 + (1 << 20)); out.seqs.reserve((size_t)chunk / 64 + 1024); }   // ~2.3 text bytes per base
 	long size = 0; Seq s, s2;
 	while (r1.read(s, out.text)) {
 		if (r2 && !r2->read(s2, out.text)) { fprintf(stderr, "[W::%s] the 2nd file has fewer sequences.\n", "bseq_read"); break; }
@@ -395,6 +425,12 @@ int main(int argc, char *argv[])
 	}
 	const int chunk = fixed_chunk > 0 ? fixed_chunk : opt.chunk_size * opt.n_threads;
 	const double t_start = now_s();
+	if (getenv("BWAGPU_CLI_PARSE_ONLY")) {   // diagnostics: speed of the input stage alone
+		Batch b; long n = 0, bp = 0;
+		while (read_batch(r1, pr2, chunk, b)) { n += (long)b.seqs.size(); for (auto &q : b.seqs) bp += q.l_seq; }
+		fprintf(stderr, "[M::%s] parsed %ld records (%ld bp) in %.3f s\n", "main_mem", n, bp, now_s() - t_start);
+		return 0;
+	}
 	if (getenv("BWAGPU_CLI_SERIALIZE")) g_dev_serialize = atoi(getenv("BWAGPU_CLI_SERIALIZE")) != 0;
 	if (getenv("BWAGPU_CLI_CIGARS")) g_device_cigars = atoi(getenv("BWAGPU_CLI_CIGARS"));
 	int n_dev = getenv("BWAGPU_CLI_STREAMS") ? atoi(getenv("BWAGPU_CLI_STREAMS")) : 2;      // batches in flight on the device
@@ -402,6 +438,9 @@ int main(int argc, char *argv[])
 	std::vector<bwagpu_t*> handles(1, gpu);
 	for (int i = 1; i < n_dev; ++i) { bwagpu_t *h2 = nullptr; int rc = bwagpu_clone(gpu, &h2); if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s\n", "main_mem", bwagpu_strerror(rc)); return 1; } bwagpu_set_taps(h2, 0); handles.push_back(h2); }
 	Chan to_dev(2), to_out(2);
+	// text arenas and base arrays of finished batches are handed back to the reader: re-using them saves a few hundred MB of
+	// first-touch page faults per batch on the one thread that paces the pipeline
+	std::mutex pool_m; std::vector<Batch> batch_pool; std::vector<std::vector<uint8_t>> flat_pool;
 	std::mutex dm; std::condition_variable dcv; std::map<long, WorkP> done; long next_fin = 0;   // device -> finalize, re-ordered
 	std::atomic<long> n_works(-1), n_reads_total(0);
 	double busy_read = 0, busy_fin = 0, busy_write = 0; std::atomic<long> busy_dev_us(0);   // per-stage busy time (-v 3 summary)
@@ -427,6 +466,7 @@ int main(int argc, char *argv[])
 		int64_t n_processed = 0; long no = 0;
 		for (;;) {
 			WorkP w(new Work()); w->no = no;
+			{ std::lock_guard<std::mutex> l(pool_m); if (!batch_pool.empty()) { w->in = std::move(batch_pool.back()); batch_pool.pop_back(); } }
 			const double tr = now_s();
 			if (!read_batch(r1, pr2, chunk, w->in)) break;
 			const int n = (int)w->in.seqs.size();
@@ -451,7 +491,10 @@ int main(int argc, char *argv[])
 				u.opt = opt; u.n_processed = n_processed;
 				w->subs.push_back(std::move(u));
 			}
-			for (Sub &u : w->subs) encode_sub(w->in, u);
+			for (Sub &u : w->subs) {
+				{ std::lock_guard<std::mutex> l(pool_m); if (!flat_pool.empty()) { u.flat = std::move(flat_pool.back()); flat_pool.pop_back(); } }
+				encode_sub(w->in, u);
+			}
 			n_processed += n; ++no; ++progress;
 			busy_read += now_s() - tr;
 			to_dev.push(std::move(w));
@@ -492,6 +535,11 @@ int main(int argc, char *argv[])
 		const double tf = now_s();
 		for (Sub &u : w->subs) finalize_sub(ref, *w, u, pes0, rg_id.c_str(), copy_comment != 0);
 		busy_fin += now_s() - tf;
+		{
+			std::lock_guard<std::mutex> l(pool_m);
+			if (batch_pool.size() < 4) batch_pool.push_back(std::move(w->in));
+			for (Sub &u : w->subs) if (flat_pool.size() < 6) flat_pool.push_back(std::move(u.flat));
+		}
 		w->in = Batch(); w->subs.clear();
 		to_out.push(std::move(w));
 		{ std::lock_guard<std::mutex> l(dm); ++next_fin; ++progress; dcv.notify_all(); }
