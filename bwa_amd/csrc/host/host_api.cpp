@@ -75,6 +75,15 @@ char *bwamem_host_regs2sam(void *h, const bwagpu_opt_t *opt, int64_t n_processed
 
 void bwamem_host_free(void *p) { free(p); }
 
+// one bwagpu_cigar_t per region, computed by the host code (reference for bwagpu_batch_cigars; see host_region_cigar)
+void bwamem_host_region_cigars(void *h, const bwagpu_opt_t *opt, int n, const uint8_t *seqs, const int64_t *off, const int32_t *counts, const bwagpu_alnreg_t *regs, bwagpu_cigar_t *out)
+{
+	const RefSeqs &ref = *(RefSeqs*)h;
+	int64_t k = 0;
+	for (int i = 0; i < n; ++i)
+		for (int j = 0; j < counts[i]; ++j, ++k) host_region_cigar(*opt, ref, seqs + off[i], regs[k], out + k);
+}
+
 void bwamem_host_ksw_align2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins, int xtra, int out[7])
 {
 	KswResult r = ksw_align2(qlen, query, tlen, target, mat, o_del, e_del, o_ins, e_ins, xtra);

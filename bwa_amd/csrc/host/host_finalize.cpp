@@ -219,6 +219,32 @@ static const bwagpu_cigar_t *find_hint(const CigHints *h, const bwagpu_alnreg_t 
 	return nullptr;
 }
 
+// What bwagpu_batch_cigars delivers for one region, computed here on the host (tests: the device records must equal these;
+// they also let the CPU suite exercise the hint path on thousands of reads).
+void host_region_cigar(const bwagpu_opt_t &opt, const RefSeqs &ref, const uint8_t *query, const bwagpu_alnreg_t &ar, bwagpu_cigar_t *out)
+{
+	out->score = 2; out->n_cigar = -1; for (int k = 0; k < 6; ++k) out->cigar[k] = 0;
+	if (ar.score < opt.T) { out->score = 1; return; }
+	const int qb = ar.qb, qe = ar.qe; const int64_t rb = ar.rb, re = ar.re;
+	if (qe - qb <= 0 || rb >= re || (rb < ref.l_pac && re > ref.l_pac)) return;
+	int score = 0, last_sc = -(1 << 30), NM = -1, i = 0;
+	int tmp = infer_bw(qe - qb, (int)(re - rb), ar.truesc, opt.a, opt.o_del, opt.e_del);
+	int w2 = infer_bw(qe - qb, (int)(re - rb), ar.truesc, opt.a, opt.o_ins, opt.e_ins);
+	w2 = w2 > tmp ? w2 : tmp;
+	if (w2 > opt.w) w2 = w2 < ar.w ? w2 : ar.w;
+	std::vector<uint32_t> cigar; std::string md;
+	do {
+		w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+		gen_cigar2(opt, ref, w2, qe - qb, query + qb, rb, re, &score, cigar, &NM, md);
+		if (score == last_sc || w2 == opt.w << 2) break;
+		last_sc = score;
+		w2 <<= 1;
+	} while (++i < 3 && score < ar.truesc - opt.a);
+	if (cigar.size() > 6) { out->score = 3; return; }
+	out->score = score; out->n_cigar = (int)cigar.size();
+	for (size_t k = 0; k < cigar.size(); ++k) out->cigar[k] = cigar[k];
+}
+
 Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint8_t *query, const bwagpu_alnreg_t *ar, const CigHints *hints)
 {
 	Aln a;

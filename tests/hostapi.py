@@ -30,6 +30,7 @@ def lib():
         L.bwamem_host_regs2sam.restype = C.c_void_p
         L.bwamem_host_regs2sam.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.bwamem_host_free.argtypes = [C.c_void_p]
+        L.bwamem_host_region_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -54,6 +55,14 @@ class HostFinalize:
         s = C.string_at(p, ln.value)
         lib().bwamem_host_free(p)
         return s
+
+    def region_cigars(self, opt, seqs_nt4, off, counts, regs):
+        """Host-computed bwagpu_cigar_t records (the reference for the device's bwagpu_batch_cigars)."""
+        from bwa_amd.api import CIGAR_DTYPE
+        regs = np.ascontiguousarray(regs); counts = np.ascontiguousarray(counts, dtype=np.int32); seqs_nt4 = np.ascontiguousarray(seqs_nt4, dtype=np.uint8)
+        out = np.zeros(regs.shape[0], dtype=CIGAR_DTYPE)
+        lib().bwamem_host_region_cigars(self.h, C.byref(opt), off.shape[0] - 1, seqs_nt4.ctypes.data, off.ctypes.data, counts.ctypes.data, regs.ctypes.data, out.ctypes.data)
+        return out
 
     def close(self):
         if self.h:

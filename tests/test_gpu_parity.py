@@ -181,6 +181,7 @@ def test_device_cigars_match_the_reference_sam(medium):
         counts, regs = gpu.align(opt, seqs, off)
         cigs = gpu.cigars(opt)
         assert cigs.shape[0] == regs.shape[0]
+        assert cigs.tobytes() == host.region_cigars(opt, seqs, off, counts, regs).tobytes(), "device records differ from the host's"
         want = ref.process_seqs(opt, names, ascii_[seqs].tobytes(), quals, off)
         got = host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs)
         if got != want:

@@ -107,6 +107,29 @@ def test_paired_end_mixed_orientations_and_chimeras(pair):
     _check(ref, host, opt, _interleave(r1, r2), "PE mixed")
 
 
+def test_cigar_hints_do_not_change_the_sam(pair):
+    """The finalize code may be handed precomputed region alignments (bwagpu_cigar_t records, normally from the device).  With
+    host-computed records for every region the SAM text is the reference's, SE and PE; most regions are served by a record."""
+    ref, host, g = pair
+    for pe in (False, True):
+        opt = default_opt()
+        if pe:
+            opt.flag |= 2
+            r1, r2 = simdata.make_reads_pe(g, 3000, seed=331, sub=0.02, dele=0.003, ins=0.003)
+            reads = _interleave(r1, r2)
+        else:
+            reads = simdata.make_reads_se(g, 6000, seed=330, sub=0.02, dele=0.003, ins=0.003)
+        seqs, off = testdata.flat(reads)
+        n = off.shape[0] - 1
+        names = [f"q{i >> 1}" if pe else f"q{i}" for i in range(n)]
+        quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
+        want = ref.process_seqs(opt, names, ASCII[seqs].tobytes(), quals, off)
+        counts, regs = ref.align(opt, seqs, off)
+        cigs = host.region_cigars(opt, seqs, off, counts, regs)
+        assert (cigs["n_cigar"][regs["score"] >= opt.T] >= 0).mean() > 0.8
+        assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs) == want
+
+
 def test_ksw_align2_fuzz():
     """ksw_align2 (striped SSE2 in the reference) vs the host restatement: score, te, qe, score2, te2, tb, qb."""
     import hostapi

@@ -143,6 +143,8 @@ def test_hostsim_device_cigars_give_the_same_sam(sim):
     assert cigs.dtype == CIGAR_DTYPE and cigs.shape[0] == regs.shape[0]
     names = [f"q{i}" for i in range(off.shape[0] - 1)]
     quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
+    want = host.region_cigars(opt, seqs, off, counts, regs)
+    assert cigs.tobytes() == want.tobytes(), "device records differ from the host's"
     plain = host.regs2sam(opt, names, seqs, quals, off, counts, regs)
     hinted = host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs)
     assert hinted == plain
