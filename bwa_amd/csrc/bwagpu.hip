@@ -70,6 +70,7 @@ struct bwagpu_s {
 	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_blob;
 	DevBuf d_order, d_bin_cnt, d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
 	i64 slot_cap = 0, node_cap = 0, reg_cap = 0; int mem_cap = 0;
+	double need_slot = 0, need_node = 0, need_reg = 0; int need_mem = 0;   // per-base arena needs learnt from earlier batches of this handle
 	std::vector<i64> h_off;
 };
 
@@ -426,9 +427,14 @@ extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, cons
 	i64 nb = h->n_bases > 1024 ? h->n_bases : 1024;
 	h->slot_cap = nb / 4 + 4096;
 	h->node_cap = h->slot_cap / 4 + 2 * (i64)n + 64;
-	h->reg_cap = nb / 8 + 4096;
+	h->reg_cap = nb / 6 + 4096;
 	// capacity of one read's interval list: reads keep ~10-30 intervals whatever their length class; grown x4 on overflow
 	h->mem_cap = h->max_len / 3 < 64 ? 64 : h->max_len / 3;
+	// what earlier batches turned out to need (after overflow re-runs) carries over: a re-run doubles a batch's device time
+	if ((i64)(h->need_slot * nb) > h->slot_cap) h->slot_cap = (i64)(h->need_slot * nb);
+	if ((i64)(h->need_node * nb) > h->node_cap) h->node_cap = (i64)(h->need_node * nb);
+	if ((i64)(h->need_reg * nb) > h->reg_cap) h->reg_cap = (i64)(h->need_reg * nb);
+	if (h->need_mem > h->mem_cap) h->mem_cap = h->need_mem;
 	if (getenv("BWAGPU_MEM_CAP")) h->mem_cap = atoi(getenv("BWAGPU_MEM_CAP"));   // test hook: force the overflow/retry path
 	h->have_batch = true;
 	return BWAGPU_OK;
@@ -570,6 +576,13 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			if (c.overflow & 16) h->mem_cap = h->mem_cap * 4;
 			++h->stats.n_retries;
 			continue;
+		}
+		{	// remember the sizes that sufficed, per base
+			const double nbd = (double)(h->n_bases > 1024 ? h->n_bases : 1024);
+			if (h->slot_cap / nbd > h->need_slot) h->need_slot = h->slot_cap / nbd;
+			if (h->node_cap / nbd > h->need_node) h->need_node = h->node_cap / nbd;
+			if (h->reg_cap / nbd > h->need_reg) h->need_reg = h->reg_cap / nbd;
+			if (h->mem_cap > h->need_mem && !getenv("BWAGPU_MEM_CAP")) h->need_mem = h->mem_cap;
 		}
 		float ms[6];
 		for (int i = 0; i < 6; ++i) HIPCHK(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));

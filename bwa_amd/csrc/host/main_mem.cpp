@@ -407,6 +407,10 @@ int main(int argc, char *argv[])
 		if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s\n", "main_mem", bwagpu_strerror(rc)); return 1; }
 	}
 	bwagpu_set_taps(gpu, 0);
+	{	// SA look-ups walk ~31 LF steps with the reference's interval of 32; HBM has room for a denser array (same values)
+		const int dense = getenv("BWAGPU_CLI_DENSE_SA") ? atoi(getenv("BWAGPU_CLI_DENSE_SA")) : 4;
+		if (dense > 0) { int rc = bwagpu_densify_sa(gpu, dense); if (rc != BWAGPU_OK && g_verbose >= 2) fprintf(stderr, "[W::%s] SA not densified: %s\n", "main_mem", bwagpu_strerror(rc)); }
+	}
 
 	Reader r1, r2; Reader *pr2 = nullptr;
 	if (!r1.open(argv[optind + 1])) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", "main_mem", argv[optind + 1]); return 1; }
