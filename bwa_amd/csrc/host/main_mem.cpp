@@ -1,7 +1,7 @@
 // main_mem.cpp -- `bwa-amd mem`: the stand-alone command line around libbwagpu.so + the host finalize code.
 // Mirrors the reference's `bwa mem` (fastmap.c:141-406): same option letters and meaning, same batching rule
 // (chunk_size * n_threads bases per batch unless -K, fastmap.c:394), same SAM header (bwa.c:407-439), so that for the same
-// input and the same -K the output equals `bwa mem`'s except for the @PG line.  Not implemented: -H from a file, -o/-f.
+// input and the same -K the output equals `bwa mem`'s except for the @PG line.
 #include <ctype.h>
 #include <getopt.h>
 #include <math.h>
@@ -297,7 +297,7 @@ int main(int argc, char *argv[])
 	const char *mode = nullptr; char *p;
 	int c, fixed_chunk = -1, ignore_alt = 0, copy_comment = 0, device = getenv("BWAGPU_DEVICE") ? atoi(getenv("BWAGPU_DEVICE")) : 0;
 	std::string hdr_line, rg_line, rg_id;
-	while ((c = getopt(argc, argv, "51qpaMCSPVYjuk:c:v:s:r:t:R:A:B:O:E:U:w:L:d:T:Q:D:m:I:N:W:x:G:h:y:K:X:H:z:")) >= 0) {
+	while ((c = getopt(argc, argv, "51qpaMCSPVYjuk:c:v:s:r:t:R:A:B:O:E:U:w:L:d:T:Q:D:m:I:N:o:f:W:x:G:h:y:K:X:H:z:")) >= 0) {
 		if (c == 'k') opt.min_seed_len = atoi(optarg), opt0.min_seed_len = 1;
 		else if (c == '1') {}
 		else if (c == 'x') mode = optarg;
@@ -350,7 +350,16 @@ int main(int argc, char *argv[])
 			if (q == std::string::npos) { fprintf(stderr, "[E::bwa_set_rg] no ID within the read group line\n"); return 1; }
 			for (q += 4; q < rg_line.size() && rg_line[q] != '\t' && rg_line[q] != '\n'; ++q) rg_id += rg_line[q];
 		}
-		else if (c == 'H') { if (optarg[0] == '@') { if (!hdr_line.empty()) hdr_line += '\n'; hdr_line += unescape(optarg); } }
+		else if (c == 'H') {   // header lines given literally or in a file (fastmap.c:224-239; bwa_insert_header, bwa.c:490-505)
+			auto add = [&](const char *line) { if (line[0] == '@') { if (!hdr_line.empty()) hdr_line += '\n'; hdr_line += unescape(line); } };
+			if (optarg[0] == '@') add(optarg);
+			else if (FILE *fp = fopen(optarg, "r")) {
+				std::string line; int ch;
+				while ((ch = fgetc(fp)) != EOF) { if (ch == '\n') { add(line.c_str()); line.clear(); } else line += (char)ch; }
+				fclose(fp);
+			}
+		}
+		else if (c == 'o' || c == 'f') { if (!freopen(optarg, "wb", stdout)) { fprintf(stderr, "[E::%s] fail to open '%s' for writing\n", "main_mem", optarg); return 1; } }
 		else if (c == 'I') {
 			pes0 = pes; pes[1].failed = 0; pes[1].avg = strtod(optarg, &p); pes[1].std = pes[1].avg * .1;
 			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes[1].std = strtod(p + 1, &p);

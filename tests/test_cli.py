@@ -71,6 +71,17 @@ def _compare_all(cli, fa, f1, f2, inter, fasta, env=None):
     y = ["-a", "-k", "17", "-A", "2", "-T", "40", "-h", "3,10", "-I", "400,50", "-5"]
     assert _run(refapi.REF_BWA, K + y + [fa, f1, f2]) == _run(cli, K + y + [fa, f1, f2], env), "scaled scores (-A 2), -I, -a, -5"
     assert _run(refapi.REF_BWA, K + [fa, fasta]) == _run(cli, K + [fa, fasta], env), "multi-line FASTA input"
+    # header lines from a file (-H), output to a file (-o)
+    hdr = os.path.join(os.path.dirname(f1), "hdr.txt")
+    with open(hdr, "w") as f:
+        f.write("@CO\tfirst comment\nnot a header line\n@CO\tsecond\\tcomment\n")
+    outs = []
+    for binary, e in ((refapi.REF_BWA, None), (cli, env)):
+        o = os.path.join(os.path.dirname(f1), "out.sam")
+        p = subprocess.run([binary, "mem"] + K + ["-H", hdr, "-o", o, fa, fasta], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+        assert p.returncode == 0 and p.stdout == b"", p.stderr.decode()[-500:]
+        outs.append(_body(open(o, "rb").read()))
+    assert outs[0] == outs[1], "-H <file> and -o <file>"
     assert _run(refapi.REF_BWA, ["-K", "3000", "-t", "2", fa, f1, f2]) == _run(cli, ["-K", "3000", "-t", "2", fa, f1, f2], env), "many small batches (-K 3000)"
 
 
