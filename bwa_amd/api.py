@@ -28,6 +28,10 @@ GSEED_DTYPE = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4"), ("scor
 assert GCHAIN_DTYPE.itemsize == 32 and GSEED_DTYPE.itemsize == 24
 
 
+MATESW_DTYPE = np.dtype([("read", "<i4"), ("r", "<i4"), ("anchor_rb", "<i8"), ("anchor_rid", "<i4"), ("score", "<i4"), ("te", "<i4"), ("qe", "<i4"),
+                         ("score2", "<i4"), ("te2", "<i4"), ("tb", "<i4"), ("qb", "<i4"), ("pad_", "<i4"), ("pad2_", "<i4")])   # bwagpu_matesw_t (56 bytes with its tail padding)
+assert MATESW_DTYPE.itemsize == 56
+PES_DTYPE = np.dtype([("low", "<i4"), ("high", "<i4"), ("failed", "<i4"), ("pad_", "<i4")])               # bwagpu_pes_t
 CIGAR_DTYPE = np.dtype([("score", "<i4"), ("n_cigar", "<i4"), ("cigar", "<u4", (6,))])   # bwagpu_cigar_t
 assert CIGAR_DTYPE.itemsize == 32
 
@@ -48,7 +52,7 @@ EXPORTS = [
     "bwagpu_index_info", "bwagpu_densify_sa", "bwagpu_set_stats", "bwagpu_get_stats", "bwagpu_align_bseq", "bwagpu_align_flat",
     "bwagpu_free", "bwagpu_batch_upload", "bwagpu_batch_run", "bwagpu_batch_download", "bwagpu_set_taps", "bwagpu_tap_intervals",
     "bwagpu_tap_chains", "bwagpu_tap_regs_raw", "bwagpu_index_buffers", "bwagpu_index_export", "bwagpu_clone", "bwagpu_index_ready",
-    "bwagpu_batch_cigars", "bwagpu_debug_phase",
+    "bwagpu_batch_cigars", "bwagpu_debug_phase", "bwagpu_batch_matesw",
 ]
 
 
@@ -82,6 +86,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.bwagpu_batch_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.bwagpu_batch_run.argtypes = [C.c_void_p, C.c_void_p]
     L.bwagpu_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bwagpu_batch_matesw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwagpu_batch_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwagpu_tap_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwagpu_tap_chains.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -201,6 +206,14 @@ class BwaGpu:
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.L.bwagpu_batch_cigars(self.h, C.byref(opt), C.byref(p), C.byref(n)))
         return self._take(p, n.value, CIGAR_DTYPE)
+
+    def matesw(self, opt: MemOpt, pes: np.ndarray):
+        """bwagpu_batch_matesw: precomputed mate-rescue alignments (MATESW_DTYPE) for the last download(); pes = PES_DTYPE[4]."""
+        pes = np.ascontiguousarray(pes, dtype=PES_DTYPE)
+        assert pes.shape == (4,)
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.bwagpu_batch_matesw(self.h, C.byref(opt), pes.ctypes.data, C.byref(p), C.byref(n)))
+        return self._take(p, n.value, MATESW_DTYPE)
 
     def align(self, opt: MemOpt, seqs: np.ndarray, off: np.ndarray):
         self.upload(seqs, off)

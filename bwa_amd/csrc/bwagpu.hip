@@ -29,6 +29,7 @@
 #include "dev_seedsw.h"
 #include "dev_cigar.h"
 #include "dev_dedupw.h"
+#include "dev_matesw.h"
 
 #define BWAGPU_VERSION "bwagpu 0.1 (gfx950)"
 
@@ -66,6 +67,7 @@ struct bwagpu_s {
 	bwagpu_stats_t stats = {};
 	volatile int phase = 0;       // progress marker for bwagpu_debug_phase (diagnostics of a stuck call)
 	i64 packed_tot = -1;          // regions packed by the last bwagpu_batch_download (-1: none)
+	DevBuf d_msw_tasks, d_msw_out, d_msw_pes, d_msw_scratch;
 	DevBuf d_pack_off, d_regs_packed, d_pack_read, d_cigs, d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
 	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_blob;
 	DevBuf d_order, d_bin_cnt, d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
@@ -223,7 +225,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 		for (DevBuf *b : ib) b->release();
 		delete h->ibuf;
 	}
-	DevBuf *all[] = { &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
+	DevBuf *all[] = { &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
@@ -713,6 +715,48 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		if (e != hipSuccess) { free(res); HIPCHK(h, e); }
 	}
 	*out = res; *n_out = tot;
+	return BWAGPU_OK;
+}
+
+extern "C" int bwagpu_batch_matesw(bwagpu_t *h, const bwagpu_opt_t *opt, const bwagpu_pes_t pes[4], bwagpu_matesw_t **out, int64_t *n_out)
+{
+	if (!h || !opt || !pes || !h->ran || h->packed_tot < 0 || !out || !n_out) return BWAGPU_EINVAL;
+	if (opt->e_del <= 0 || opt->e_ins <= 0 || (h->n_reads & 1)) return BWAGPU_EINVAL;
+	static_assert(sizeof(bwagpu_matesw_t) == 56 && sizeof(MateTask) == 24 && sizeof(bwagpu_pes_t) == 16, "layout");
+	HIPCHK(h, hipSetDevice(h->device));
+	const int n = h->n_reads;
+	*out = nullptr; *n_out = 0;
+	if (n == 0 || h->packed_tot == 0) { *out = (bwagpu_matesw_t*)malloc(sizeof(bwagpu_matesw_t)); return *out ? BWAGPU_OK : BWAGPU_ENOMEM; }
+	const i64 task_cap = (i64)n * 2 + 1024;          // more candidates than this are simply left to the host
+	const int waves = 1024;
+	if (h->d_msw_tasks.ensure((size_t)task_cap * sizeof(MateTask)) || h->d_msw_out.ensure((size_t)task_cap * sizeof(bwagpu_matesw_t)) ||
+		h->d_msw_pes.ensure(4 * sizeof(bwagpu_pes_t)) || h->d_msw_scratch.ensure((size_t)waves * MSW_LANE_INTS * 64 * 4) || h->d_ctr.ensure(sizeof(Counters))) {
+		h->err = "hipMalloc failed (mate rescue)"; return BWAGPU_ENOMEM;
+	}
+	unsigned long long *n_tasks = &h->d_ctr.as<Counters>()->next_chain, *next = &h->d_ctr.as<Counters>()->next_dedup;   // idle counters at this point
+	HIPCHK(h, hipMemsetAsync(n_tasks, 0, 8, h->stream));
+	HIPCHK(h, hipMemsetAsync(next, 0, 8, h->stream));
+	HIPCHK(h, hipMemcpyAsync(h->d_msw_pes.p, pes, 4 * sizeof(bwagpu_pes_t), hipMemcpyHostToDevice, h->stream));
+	int nb = (n / 2 + BLOCK - 1) / BLOCK; if (nb > 8192) nb = 8192; if (nb < 1) nb = 1;
+	hipLaunchKernelGGL(k_matesw_tasks, dim3(nb), dim3(BLOCK), 0, h->stream, h->ix, *opt, n, h->d_reg_n.as<i32>(), h->d_pack_off.as<i64>(), h->d_regs_packed.as<bwagpu_alnreg_t>(),
+					   h->d_msw_pes.as<bwagpu_pes_t>(), h->d_msw_tasks.as<MateTask>(), n_tasks, task_cap);
+	HIPCHK(h, hipGetLastError());
+	unsigned long long nt = 0;
+	HIPCHK(h, hipMemcpyAsync(&nt, n_tasks, 8, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(h, wait_stream(h));
+	if ((i64)nt > task_cap) nt = (unsigned long long)task_cap;
+	bwagpu_matesw_t *res = (bwagpu_matesw_t*)malloc((size_t)(nt ? nt : 1) * sizeof(bwagpu_matesw_t));
+	if (!res) return BWAGPU_ENOMEM;
+	if (nt) {
+		Batch B = {}; B.seq = h->d_seq.as<u8>(); B.off = h->d_off.as<i64>(); B.n_reads = n; B.max_len = h->max_len;
+		hipLaunchKernelGGL(k_matesw_sw, dim3(waves / 4), dim3(BLOCK), 0, h->stream, h->ix, *opt, B, h->d_msw_pes.as<bwagpu_pes_t>(), h->d_msw_tasks.as<MateTask>(), (i64)nt,
+						   h->d_msw_out.as<bwagpu_matesw_t>(), next, h->d_msw_scratch.as<i32>());
+		hipError_t e = hipGetLastError();
+		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_msw_out.p, (size_t)nt * sizeof(bwagpu_matesw_t), hipMemcpyDeviceToHost, h->stream);
+		if (e == hipSuccess) e = wait_stream(h);
+		if (e != hipSuccess) { free(res); HIPCHK(h, e); }
+	}
+	*out = res; *n_out = (int64_t)nt;
 	return BWAGPU_OK;
 }
 

@@ -51,6 +51,7 @@ struct CigHints { const bwagpu_alnreg_t *regs; const bwagpu_cigar_t *cigs; int n
 struct Read {   // == bseq1_t as the finalize code needs it
 	const char *name; const char *comment; const uint8_t *seq /* nt4 codes */; const char *qual; int l_seq;
 	const CigHints *hints = nullptr;
+	const bwagpu_matesw_t *msw = nullptr; int n_msw = 0;   // device-computed mate-rescue alignments of this read (bwagpu_batch_matesw)
 };
 
 typedef std::vector<bwagpu_alnreg_t> Regs;
@@ -74,7 +75,11 @@ void host_region_cigar(const bwagpu_opt_t &opt, const RefSeqs &ref, const uint8_
 Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint8_t *query, const bwagpu_alnreg_t *ar, const CigHints *hints = nullptr);   // bwamem.c:1119-1189
 void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, const Read &s, const std::vector<Aln> &list, int which, const Aln *mate, const char *rg_id);   // bwamem.c:851-976
 void reg2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, const Read &s, Regs &a, int extra_flag, const Aln *mate, const char *rg_id);   // bwamem.c:1033-1079
-void pestat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const std::vector<Regs> &regs, Pestat pes[4], bool verbose);   // bwamem_pair.c:72-135
+void pestat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const std::vector<Regs> &regs, Pestat pes[4], bool verbose);
+void pestat_flat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const bwagpu_alnreg_t *all, const int64_t *roff, Pestat pes[4], bool verbose);
+void attach_matesw(int n, Read *reads, const bwagpu_matesw_t *recs, int64_t n_recs, std::vector<bwagpu_matesw_t> &sorted);
+int64_t host_matesw_records(const bwagpu_opt_t &opt, const RefSeqs &ref, int n, const uint8_t *seqs, const int64_t *off, const bwagpu_alnreg_t *all, const int64_t *roff,
+							const Pestat pes[4], bwagpu_matesw_t *out, int64_t cap);   // == bwagpu_batch_matesw, on the host   // bwamem_pair.c:72-135
 int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uint64_t id, const Read s[2], Regs a[2], std::string out[2], const char *rg_id);   // bwamem_pair.c:276-419
 
 // DP kernels of the finalize stage

@@ -33,6 +33,18 @@ void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_proce
 	}
 }
 
+// group bwagpu_batch_matesw records by the read they align and attach the slices to the reads
+void attach_matesw(int n, Read *reads, const bwagpu_matesw_t *recs, int64_t n_recs, std::vector<bwagpu_matesw_t> &sorted)
+{
+	std::vector<int64_t> start((size_t)n + 1, 0);
+	for (int64_t k = 0; k < n_recs; ++k) if (recs[k].r >= 0 && recs[k].read >= 0 && recs[k].read < n) ++start[recs[k].read + 1];
+	for (int i = 0; i < n; ++i) start[i + 1] += start[i];
+	sorted.resize((size_t)start[n]);
+	std::vector<int64_t> fill(start.begin(), start.end() - 1);
+	for (int64_t k = 0; k < n_recs; ++k) if (recs[k].r >= 0 && recs[k].read >= 0 && recs[k].read < n) sorted[(size_t)fill[recs[k].read]++] = recs[k];
+	for (int i = 0; i < n; ++i) { reads[i].msw = sorted.data() + start[i]; reads[i].n_msw = (int)(start[i + 1] - start[i]); }
+}
+
 }  // namespace hostmem
 
 using namespace hostmem;
@@ -52,7 +64,8 @@ void bwamem_host_set_alt(void *h, int rid, int flag) { ((RefSeqs*)h)->ctg[rid].i
 // same shape as refshim_regs2sam (oracle/ref_shim.c): names NUL-separated, seqs are nt4 codes, regs flat in read order
 char *bwamem_host_regs2sam(void *h, const bwagpu_opt_t *opt, int64_t n_processed, int n, const char *names, const uint8_t *seqs, const char *quals,
 						   const int64_t *off, const int32_t *counts, const bwagpu_alnreg_t *regs, const Pestat *pes0, int n_threads, int64_t *out_len,
-						   const bwagpu_cigar_t *cigs /* optional: bwagpu_batch_cigars output, parallel to regs */)
+						   const bwagpu_cigar_t *cigs /* optional: bwagpu_batch_cigars output, parallel to regs */,
+						   const bwagpu_matesw_t *msw /* optional: bwagpu_batch_matesw output */, int64_t n_msw)
 {
 	const RefSeqs &ref = *(RefSeqs*)h;
 	std::vector<Read> reads(n); std::vector<Regs> rv(n); std::vector<CigHints> hints(n);
@@ -63,6 +76,8 @@ char *bwamem_host_regs2sam(void *h, const bwagpu_opt_t *opt, int64_t n_processed
 		if (cigs) { hints[i].regs = regs + roff; hints[i].cigs = cigs + roff; hints[i].n = counts[i]; reads[i].hints = &hints[i]; }
 		rv[i].assign(regs + roff, regs + roff + counts[i]); roff += counts[i];
 	}
+	std::vector<bwagpu_matesw_t> msw_sorted;
+	if (msw) attach_matesw(n, reads.data(), msw, n_msw, msw_sorted);
 	std::vector<std::string> sam;
 	finalize_batch(*opt, ref, n_processed, n, reads.data(), rv, pes0, n_threads, 0, sam, false);
 	size_t tot = 0;
@@ -74,6 +89,23 @@ char *bwamem_host_regs2sam(void *h, const bwagpu_opt_t *opt, int64_t n_processed
 }
 
 void bwamem_host_free(void *p) { free(p); }
+
+// mem_pestat of a batch given as flat regions (the insert-size windows bwagpu_batch_matesw needs); pes = Pestat[4]
+void bwamem_host_pestat(void *h, const bwagpu_opt_t *opt, int n, const int32_t *counts, const bwagpu_alnreg_t *regs, Pestat *pes)
+{
+	std::vector<int64_t> roff((size_t)n + 1, 0);
+	for (int i = 0; i < n; ++i) roff[i + 1] = roff[i] + counts[i];
+	pestat_flat(*opt, ((RefSeqs*)h)->l_pac, n, regs, roff.data(), pes, false);
+}
+
+// the records bwagpu_batch_matesw should produce, computed on the host (order: by pair, end, anchor, orientation)
+int64_t bwamem_host_matesw_records(void *h, const bwagpu_opt_t *opt, int n, const uint8_t *seqs, const int64_t *off, const int32_t *counts, const bwagpu_alnreg_t *regs,
+								   const Pestat *pes, bwagpu_matesw_t *out, int64_t cap)
+{
+	std::vector<int64_t> roff((size_t)n + 1, 0);
+	for (int i = 0; i < n; ++i) roff[i + 1] = roff[i] + counts[i];
+	return host_matesw_records(*opt, *(RefSeqs*)h, n, seqs, off, regs, roff.data(), pes, out, cap);
+}
 
 // one bwagpu_cigar_t per region, computed by the host code (reference for bwagpu_batch_cigars; see host_region_cigar)
 void bwamem_host_region_cigars(void *h, const bwagpu_opt_t *opt, int n, const uint8_t *seqs, const int64_t *off, const int32_t *counts, const bwagpu_alnreg_t *regs, bwagpu_cigar_t *out)

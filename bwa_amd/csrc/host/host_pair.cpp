@@ -22,7 +22,13 @@ static inline int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist
 	return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
 }
 
-static int cal_sub(const bwagpu_opt_t &opt, const Regs &r)
+struct RegSpan {   // a read's regions inside a flat array
+	const bwagpu_alnreg_t *a; size_t n;
+	size_t size() const { return n; } bool empty() const { return n == 0; }
+	const bwagpu_alnreg_t &operator[](size_t i) const { return a[i]; }
+};
+
+template <class R> static int cal_sub(const bwagpu_opt_t &opt, const R &r)
 {	// bwamem_pair.c:58-70
 	size_t j;
 	for (j = 1; j < r.size(); ++j) {
@@ -37,12 +43,12 @@ static int cal_sub(const bwagpu_opt_t &opt, const Regs &r)
 
 struct U64Less { bool operator()(uint64_t a, uint64_t b) const { return a < b; } };
 
-void pestat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const std::vector<Regs> &regs, Pestat pes[4], bool verbose)
+template <class Get> static void pestat_impl(const bwagpu_opt_t &opt, int64_t l_pac, int n, Get get, Pestat pes[4], bool verbose)
 {
 	std::vector<uint64_t> isize[4];
 	memset(pes, 0, 4 * sizeof(Pestat));
 	for (int i = 0; i < n >> 1; ++i) {
-		const Regs &r0 = regs[i << 1], &r1 = regs[i << 1 | 1];
+		const auto r0 = get(i << 1), r1 = get(i << 1 | 1);
 		int64_t is;
 		if (r0.empty() || r1.empty()) continue;
 		if (cal_sub(opt, r0) > 0.8 * r0[0].score) continue;
@@ -92,6 +98,17 @@ void pestat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const std::vector<Reg
 		}
 }
 
+void pestat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const std::vector<Regs> &regs, Pestat pes[4], bool verbose)
+{
+	pestat_impl(opt, l_pac, n, [&](int i) { return RegSpan{regs[i].data(), regs[i].size()}; }, pes, verbose);
+}
+
+// the same on a batch's flat region array (regions of read i at all[roff[i] .. roff[i+1]))
+void pestat_flat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const bwagpu_alnreg_t *all, const int64_t *roff, Pestat pes[4], bool verbose)
+{
+	pestat_impl(opt, l_pac, n, [&](int i) { return RegSpan{all + roff[i], (size_t)(roff[i + 1] - roff[i])}; }, pes, verbose);
+}
+
 // ---- mem_sort_dedup_patch with bns == 0: no patching, only redundancy removal and the final sort (bwamem.c:463-515) ----
 struct RegEndLess { bool operator()(const bwagpu_alnreg_t &a, const bwagpu_alnreg_t &b) const { return a.re < b.re; } };
 struct RegBestLess {
@@ -134,7 +151,8 @@ int sort_dedup_nopatch(const bwagpu_opt_t &opt, Regs &av)
 }
 
 // ---- mate rescue (mem_matesw, bwamem_pair.c:137-206) ----------------------------------------------------------------------
-static int matesw(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], const bwagpu_alnreg_t &a, int l_ms, const uint8_t *ms, Regs &ma)
+static int matesw(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], const bwagpu_alnreg_t &a, int l_ms, const uint8_t *ms, Regs &ma,
+				  const bwagpu_matesw_t *msw, int n_msw)   // msw: device-computed alignments of this mate (bwagpu_batch_matesw), or none
 {
 	const int64_t l_pac = ref.l_pac;
 	int skip[4], n = 0;
@@ -168,7 +186,11 @@ static int matesw(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[
 		if (rb < re) { ref.fetch_seq(rb, (rb + re) >> 1, re, rid, refseq); fetched = true; }
 		if (fetched && a.rid == rid && re - rb >= opt.min_seed_len) {
 			int xtra = XSUBO | XSTART | (l_ms * opt.a < 250 ? XBYTE : 0) | (opt.min_seed_len * opt.a);
-			KswResult aln = ksw_align2(l_ms, seq, (int)(re - rb), refseq.data(), opt.mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra);
+			KswResult aln;
+			const bwagpu_matesw_t *hm = nullptr;
+			for (int k = 0; k < n_msw; ++k) if (msw[k].r == r && msw[k].anchor_rb == a.rb && msw[k].anchor_rid == a.rid) { hm = &msw[k]; break; }
+			if (hm) { aln.score = hm->score; aln.te = hm->te; aln.qe = hm->qe; aln.score2 = hm->score2; aln.te2 = hm->te2; aln.tb = hm->tb; aln.qb = hm->qb; }
+			else aln = ksw_align2(l_ms, seq, (int)(re - rb), refseq.data(), opt.mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra);
 			if (aln.score >= opt.min_seed_len && aln.qb >= 0) {
 				bwagpu_alnreg_t b; memset(&b, 0, sizeof b);
 				b.rid = a.rid; b.is_alt = a.is_alt;
@@ -190,6 +212,54 @@ static int matesw(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[
 		if (n) sort_dedup_nopatch(opt, ma);
 	}
 	return n;
+}
+
+// What bwagpu_batch_matesw computes, on the host (tests): tasks enumerated from the initial region lists in read order, results by
+// ksw_align2.  Returns the number of records written (at most cap).
+int64_t host_matesw_records(const bwagpu_opt_t &opt, const RefSeqs &ref, int n, const uint8_t *seqs, const int64_t *off, const bwagpu_alnreg_t *all, const int64_t *roff,
+							const Pestat pes[4], bwagpu_matesw_t *out, int64_t cap)
+{
+	const int64_t l_pac = ref.l_pac;
+	int64_t nout = 0;
+	for (int p = 0; p < n / 2; ++p)
+		for (int i = 0; i < 2; ++i) {
+			const int ri = 2 * p + i, rm = 2 * p + (1 - i);
+			const int ni = (int)(roff[ri + 1] - roff[ri]), nm = (int)(roff[rm + 1] - roff[rm]);
+			if (ni == 0) continue;
+			const bwagpu_alnreg_t *a = all + roff[ri], *ma = all + roff[rm];
+			int taken = 0;
+			for (int j = 0; j < ni && taken < opt.max_matesw; ++j) {
+				if (a[j].score < a[0].score - opt.pen_unpaired) continue;
+				++taken;
+				int skip[4];
+				for (int r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
+				for (int k = 0; k < nm; ++k) { int64_t dist; int r = infer_dir(l_pac, a[j].rb, ma[k].rb, &dist); if (dist >= pes[r].low && dist <= pes[r].high) skip[r] = 1; }
+				for (int r = 0; r < 4; ++r) {
+					if (skip[r] || nout >= cap) continue;
+					bwagpu_matesw_t o; memset(&o, 0, sizeof o);
+					o.read = rm; o.r = -1; o.anchor_rb = a[j].rb; o.anchor_rid = a[j].rid; o.te = o.qe = o.score2 = o.te2 = o.tb = o.qb = -1;
+					const int l_ms = (int)(off[rm + 1] - off[rm]); const uint8_t *ms = seqs + off[rm];
+					const int is_rev = (r >> 1) != (r & 1), is_larger = !(r >> 1);
+					std::vector<uint8_t> rev, refseq; const uint8_t *seq = ms;
+					if (is_rev) { rev.resize(l_ms); for (int q = 0; q < l_ms; ++q) rev[l_ms - 1 - q] = ms[q] < 4 ? 3 - ms[q] : 4; seq = rev.data(); }
+					int64_t rb, re; int rid = -1;
+					if (!is_rev) { rb = is_larger ? a[j].rb + pes[r].low : a[j].rb - pes[r].high; re = (is_larger ? a[j].rb + pes[r].high : a[j].rb - pes[r].low) + l_ms; }
+					else { rb = (is_larger ? a[j].rb + pes[r].low : a[j].rb - pes[r].high) - l_ms; re = is_larger ? a[j].rb + pes[r].high : a[j].rb - pes[r].low; }
+					if (rb < 0) rb = 0;
+					if (re > l_pac << 1) re = l_pac << 1;
+					if (rb < re && l_ms <= 512) {
+						ref.fetch_seq(rb, (rb + re) >> 1, re, rid, refseq);
+						if (a[j].rid == rid && re - rb >= opt.min_seed_len && re - rb <= 2048) {
+							int xtra = XSUBO | XSTART | (l_ms * opt.a < 250 ? XBYTE : 0) | (opt.min_seed_len * opt.a);
+							KswResult aln = ksw_align2(l_ms, seq, (int)(re - rb), refseq.data(), opt.mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra);
+							o.r = r; o.score = aln.score; o.te = aln.te; o.qe = aln.qe; o.score2 = aln.score2; o.te2 = aln.te2; o.tb = aln.tb; o.qb = aln.qb;
+						}
+					}
+					out[nout++] = o;
+				}
+			}
+		}
+	return nout;
 }
 
 // ---- pairing (mem_pair, bwamem_pair.c:208-274) --------------------------------------------------------------------------------
@@ -268,7 +338,7 @@ int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uin
 				if (a[i][j].score >= a[i][0].score - opt.pen_unpaired) b[i].push_back(a[i][j]);
 		for (int i = 0; i < 2; ++i)
 			for (int j = 0; j < (int)b[i].size() && j < opt.max_matesw; ++j)
-				n += matesw(opt, ref, pes, b[i][j], s[!i].l_seq, s[!i].seq, a[!i]);
+				n += matesw(opt, ref, pes, b[i][j], s[!i].l_seq, s[!i].seq, a[!i], s[!i].msw, s[!i].n_msw);
 	}
 	n_pri[0] = mark_primary_se(opt, a[0], (int64_t)(id << 1 | 0));
 	n_pri[1] = mark_primary_se(opt, a[1], (int64_t)(id << 1 | 1));

@@ -29,6 +29,7 @@ void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_proce
 using namespace hostmem;
 
 static int g_verbose = 3;
+static int g_device_matesw = 0;   // BWAGPU_CLI_MATESW=1: mate-rescue alignments precomputed on the device (same output; off until measured on hardware)
 static int g_device_cigars = 1;   // BWAGPU_CLI_CIGARS=0: the host computes every CIGAR itself (same output)
 
 // ---- options -----------------------------------------------------------------------------------------------------------
@@ -192,6 +193,8 @@ struct Sub {      // one mem_process_seqs call (bwamem.c:1235-1264) on the reads
 	std::vector<uint8_t> flat; std::vector<int64_t> off; std::vector<int32_t> counts;
 	bwagpu_alnreg_t *all = nullptr; int64_t tot = 0;
 	bwagpu_cigar_t *cigs = nullptr;           // device-side global alignments of the regions (bwagpu_batch_cigars)
+	bwagpu_matesw_t *msw = nullptr; int64_t n_msw = 0;   // device-side mate-rescue alignments (bwagpu_batch_matesw)
+	Pestat pes[4]; bool have_pes = false;     // insert-size windows, when they had to be computed before the finalize stage
 	double t_dev = 0;
 };
 struct Work { long no = 0; Batch in; std::vector<Sub> subs; std::vector<std::string> out; };
@@ -225,7 +228,7 @@ static void encode_sub(const Batch &in, Sub &u)
 static std::mutex g_dev_mutex;
 static bool g_dev_serialize = false;   // BWAGPU_CLI_SERIALIZE=1: one device call at a time (the mock HIP runtime of the CPU tests is not thread-safe)
 
-static void device_sub(bwagpu_t *gpu, Sub &u)
+static void device_sub(bwagpu_t *gpu, Sub &u, const RefSeqs &ref, const Pestat *pes0)
 {
 	std::unique_lock<std::mutex> serial(g_dev_mutex, std::defer_lock);
 	if (g_dev_serialize) serial.lock();
@@ -237,6 +240,20 @@ static void device_sub(bwagpu_t *gpu, Sub &u)
 		int64_t nc = 0;
 		rc = bwagpu_batch_cigars(gpu, &u.opt, &u.cigs, &nc);
 		if (rc != BWAGPU_OK || nc != u.tot) { fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu)); exit(EXIT_FAILURE); }
+	}
+	if (g_device_matesw && (u.opt.flag & F_PE) && !(u.opt.flag & F_NO_RESCUE) && u.tot > 0) {
+		const int n = (int)u.idx.size();
+		if (pes0) memcpy(u.pes, pes0, sizeof u.pes);
+		else {   // mem_pestat needs the whole batch's regions (bwamem.c:1258): they have just arrived
+			std::vector<int64_t> roff((size_t)n + 1, 0);
+			for (int i = 0; i < n; ++i) roff[i + 1] = roff[i] + u.counts[i];
+			pestat_flat(u.opt, ref.l_pac, n, u.all, roff.data(), u.pes, g_verbose >= 3);
+		}
+		u.have_pes = true;
+		bwagpu_pes_t dp[4];
+		for (int d = 0; d < 4; ++d) { dp[d].low = u.pes[d].low; dp[d].high = u.pes[d].high; dp[d].failed = u.pes[d].failed; dp[d].pad_ = 0; }
+		rc = bwagpu_batch_matesw(gpu, &u.opt, dp, &u.msw, &u.n_msw);
+		if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu)); exit(EXIT_FAILURE); }
 	}
 	u.t_dev = now_s() - t0;
 }
@@ -259,9 +276,11 @@ static void finalize_sub(const RefSeqs &ref, Work &w, Sub &u, const Pestat *pes0
 		reads[i].seq = u.flat.data() + u.off[i]; reads[i].qual = q.has_qual ? T + q.qual : nullptr; reads[i].l_seq = q.l_seq;
 	});
 	if (u.opt.flag & F_PE) for (int i = 0; i + 1 < n; i += 2) if (strcmp(reads[i].name, reads[i + 1].name) != 0) { fprintf(stderr, "[mem_sam_pe] paired reads have different names: \"%s\", \"%s\"\n", reads[i].name, reads[i + 1].name); exit(EXIT_FAILURE); }
+	std::vector<bwagpu_matesw_t> msw_sorted;
+	if (u.msw) attach_matesw(n, reads.data(), u.msw, u.n_msw, msw_sorted);
 	std::vector<std::string> sam;
-	finalize_batch(u.opt, ref, u.n_processed, n, reads.data(), regs, (u.opt.flag & F_PE) ? pes0 : nullptr, u.opt.n_threads, rg_id, sam, g_verbose >= 3);
-	bwagpu_free(u.all); u.all = nullptr; bwagpu_free(u.cigs); u.cigs = nullptr;
+	finalize_batch(u.opt, ref, u.n_processed, n, reads.data(), regs, (u.opt.flag & F_PE) ? (u.have_pes ? u.pes : pes0) : nullptr, u.opt.n_threads, rg_id, sam, g_verbose >= 3);
+	bwagpu_free(u.all); u.all = nullptr; bwagpu_free(u.cigs); u.cigs = nullptr; bwagpu_free(u.msw); u.msw = nullptr;
 	for (int i = 0; i < n; ++i) w.out[u.idx[i]].swap(sam[i]);
 	if (g_verbose >= 3) fprintf(stderr, "[M::%s] Processed %d reads in %.3f real sec\n", "mem_process_seqs", n, u.t_dev + (now_s() - t0));
 }
@@ -445,6 +464,7 @@ int main(int argc, char *argv[])
 		return 0;
 	}
 	if (getenv("BWAGPU_CLI_SERIALIZE")) g_dev_serialize = atoi(getenv("BWAGPU_CLI_SERIALIZE")) != 0;
+	if (getenv("BWAGPU_CLI_MATESW")) g_device_matesw = atoi(getenv("BWAGPU_CLI_MATESW"));
 	if (getenv("BWAGPU_CLI_CIGARS")) g_device_cigars = atoi(getenv("BWAGPU_CLI_CIGARS"));
 	int n_dev = getenv("BWAGPU_CLI_STREAMS") ? atoi(getenv("BWAGPU_CLI_STREAMS")) : 2;      // batches in flight on the device
 	if (n_dev < 1) n_dev = 1;
@@ -524,7 +544,7 @@ int main(int argc, char *argv[])
 			{ std::unique_lock<std::mutex> l(dm); dcv.wait(l, [&] { return w->no - next_fin <= (long)n_dev; }); }   // do not run ahead of the host
 			if (d < 16) dev_no[d] = (int)w->no;
 			++progress;
-			for (Sub &u : w->subs) { device_sub(handles[d], u); ++progress; busy_dev_us += (long)(u.t_dev * 1e6); }
+			for (Sub &u : w->subs) { device_sub(handles[d], u, ref, pes0); ++progress; busy_dev_us += (long)(u.t_dev * 1e6); }
 			std::lock_guard<std::mutex> l(dm);
 			const long no = w->no;
 			done[no] = std::move(w);

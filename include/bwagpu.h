@@ -107,6 +107,21 @@ typedef struct {
 	uint32_t cigar[6];
 } bwagpu_cigar_t;
 
+/* Insert-size window of one orientation as mem_matesw uses it: mem_pestat_t::low/high/failed (bwamem.h:108-112). */
+typedef struct { int32_t low, high, failed, pad_; } bwagpu_pes_t;
+
+/* One precomputed mate-rescue alignment: the kswr_t that mem_matesw's ksw_align2 call (bwamem_pair.c:170) returns for
+ * aligning read `read` (or its reverse complement) inside the window that anchor position `anchor_rb` on contig
+ * `anchor_rid` and orientation r imply.  r == -1: no alignment was due for this task (empty window, other contig, window
+ * shorter than min_seed_len or beyond the kernel's limits). */
+typedef struct {
+	int32_t read, r;
+	int64_t anchor_rb;
+	int32_t anchor_rid;
+	int32_t score, te, qe, score2, te2, tb, qb;
+	int32_t pad_;
+} bwagpu_matesw_t;
+
 /* == mem_alnreg_v, reference bwamem.h:106 */
 typedef struct { size_t n, m; bwagpu_alnreg_t *a; } bwagpu_alnreg_v;
 
@@ -174,6 +189,12 @@ int bwagpu_debug_phase(const bwagpu_t *h);
  * are what worker2's mem_reg2aln (bwamem.c:1119-1152) would compute on the host for that region; a finalize stage can use
  * them instead of calling bwa_gen_cigar2 (NM/MD are still derived on the host from the CIGAR).  Free with bwagpu_free. */
 int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_cigar_t **out, int64_t *n_out);
+
+/* After bwagpu_batch_download of a paired batch (mates interleaved 2i, 2i+1): the local alignments mem_matesw
+ * (bwamem_pair.c:137-206) would run for every (anchor region, orientation) that the downloaded region lists do not already
+ * satisfy, given the batch's insert-size windows.  A finalize stage looks results up by (read, anchor_rb, anchor_rid, r)
+ * and runs ksw_align2 itself where there is none.  Free with bwagpu_free. */
+int bwagpu_batch_matesw(bwagpu_t *h, const bwagpu_opt_t *opt, const bwagpu_pes_t pes[4], bwagpu_matesw_t **out, int64_t *n_out);
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
 

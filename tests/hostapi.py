@@ -28,7 +28,10 @@ def lib():
         L.bwamem_host_destroy.argtypes = [C.c_void_p]
         L.bwamem_host_set_alt.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.bwamem_host_regs2sam.restype = C.c_void_p
-        L.bwamem_host_regs2sam.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.bwamem_host_regs2sam.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.bwamem_host_pestat.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bwamem_host_matesw_records.restype = C.c_int64
+        L.bwamem_host_matesw_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.bwamem_host_free.argtypes = [C.c_void_p]
         L.bwamem_host_region_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -43,7 +46,7 @@ class HostFinalize:
     def set_alt(self, rid, flag=1):
         lib().bwamem_host_set_alt(self.h, rid, flag)
 
-    def regs2sam(self, opt, names, seqs_nt4: np.ndarray, quals: bytes, off, counts, regs, n_processed=0, pes0=None, n_threads=4, cigs=None) -> bytes:
+    def regs2sam(self, opt, names, seqs_nt4: np.ndarray, quals: bytes, off, counts, regs, n_processed=0, pes0=None, n_threads=4, cigs=None, msw=None) -> bytes:
         n = off.shape[0] - 1
         nm = b"".join(x.encode() + b"\0" for x in names)
         ln = C.c_int64(0)
@@ -51,7 +54,8 @@ class HostFinalize:
         counts = np.ascontiguousarray(counts, dtype=np.int32)
         seqs_nt4 = np.ascontiguousarray(seqs_nt4, dtype=np.uint8)
         p = lib().bwamem_host_regs2sam(self.h, C.byref(opt), n_processed, n, nm, seqs_nt4.ctypes.data, quals, off.ctypes.data, counts.ctypes.data, regs.ctypes.data, pes0, n_threads, C.byref(ln),
-                                       None if cigs is None else np.ascontiguousarray(cigs).ctypes.data)
+                                       None if cigs is None else np.ascontiguousarray(cigs).ctypes.data,
+                                       None if msw is None else np.ascontiguousarray(msw).ctypes.data, 0 if msw is None else int(msw.shape[0]))
         s = C.string_at(p, ln.value)
         lib().bwamem_host_free(p)
         return s
@@ -63,6 +67,25 @@ class HostFinalize:
         out = np.zeros(regs.shape[0], dtype=CIGAR_DTYPE)
         lib().bwamem_host_region_cigars(self.h, C.byref(opt), off.shape[0] - 1, seqs_nt4.ctypes.data, off.ctypes.data, counts.ctypes.data, regs.ctypes.data, out.ctypes.data)
         return out
+
+    PESTAT_DTYPE = np.dtype([("low", "<i4"), ("high", "<i4"), ("failed", "<i4"), ("pad_", "<i4"), ("avg", "<f8"), ("std", "<f8")])   # hostmem::Pestat
+
+    def pestat(self, opt, counts, regs):
+        """mem_pestat of the batch: Pestat[4] (low, high, failed, avg, std)."""
+        regs = np.ascontiguousarray(regs); counts = np.ascontiguousarray(counts, dtype=np.int32)
+        pes = np.zeros(4, dtype=self.PESTAT_DTYPE)
+        lib().bwamem_host_pestat(self.h, C.byref(opt), counts.shape[0], counts.ctypes.data, regs.ctypes.data, pes.ctypes.data)
+        return pes
+
+    def matesw_records(self, opt, seqs_nt4, off, counts, regs, pes):
+        """Host-computed bwagpu_matesw_t records (the reference for the device's bwagpu_batch_matesw)."""
+        from bwa_amd.api import MATESW_DTYPE
+        regs = np.ascontiguousarray(regs); counts = np.ascontiguousarray(counts, dtype=np.int32); seqs_nt4 = np.ascontiguousarray(seqs_nt4, dtype=np.uint8)
+        cap = 2 * counts.shape[0] + 1024
+        out = np.zeros(cap, dtype=MATESW_DTYPE)
+        n = lib().bwamem_host_matesw_records(self.h, C.byref(opt), counts.shape[0], seqs_nt4.ctypes.data, off.ctypes.data, counts.ctypes.data, regs.ctypes.data,
+                                             np.ascontiguousarray(pes).ctypes.data, out.ctypes.data, cap)
+        return out[:n]
 
     def close(self):
         if self.h:

@@ -130,6 +130,36 @@ def test_cigar_hints_do_not_change_the_sam(pair):
         assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs) == want
 
 
+def _noisy_mate_pairs(g, n_pairs, seed):
+    """Pairs whose second mate carries ~9 % substitutions: it often has no acceptable hit of its own and must be rescued."""
+    r1, r2 = simdata.make_reads_pe(g, n_pairs, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    hit = rng.random(r2.shape) < 0.09
+    r2 = np.where(hit, (r2 + rng.integers(1, 4, r2.shape)) % 4, r2).astype(np.uint8)
+    return _interleave(r1, r2)
+
+
+def test_matesw_hints_do_not_change_the_sam(pair):
+    """mem_matesw may be handed precomputed ksw_align2 results (bwagpu_matesw_t records, normally from the device).  With the
+    host-computed records of every task the initial region lists call for, the SAM text is the reference's; the data make
+    rescue frequent."""
+    ref, host, g = pair
+    opt = default_opt(); opt.flag |= 2
+    reads = _noisy_mate_pairs(g, 3000, seed=341)
+    seqs, off = testdata.flat(reads)
+    n = off.shape[0] - 1
+    names = [f"q{i >> 1}" for i in range(n)]
+    quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
+    want = ref.process_seqs(opt, names, ASCII[seqs].tobytes(), quals, off)
+    counts, regs = ref.align(opt, seqs, off)
+    pes = host.pestat(opt, counts, regs)
+    recs = host.matesw_records(opt, seqs, off, counts, regs, pes)
+    assert (recs["r"] >= 0).sum() > 300, "too few rescue alignments to mean anything"
+    assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, msw=recs) == want
+    cigs = host.region_cigars(opt, seqs, off, counts, regs)
+    assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs, msw=recs) == want
+
+
 def test_ksw_align2_fuzz():
     """ksw_align2 (striped SSE2 in the reference) vs the host restatement: score, te, qe, score2, te2, tb, qb."""
     import hostapi

@@ -164,3 +164,39 @@ def test_hostsim_long_reads_ring_extension(sim):
         seqs, off = testdata.flat(simdata.make_reads_se(g, n, seed=97, **kw))
         assert_regs_equal(*orc.align(opt, seqs, off), *sim.align(opt, seqs, off), f"long reads {kw}")
     orc.close()
+
+
+def test_hostsim_device_matesw_records_match_the_host(sim):
+    """bwagpu_batch_matesw: for a paired batch whose second mates are too noisy to map on their own, the
+    device's task list and ksw_align2 results equal the host code's (same records, any order), and feeding them to the
+    finalize stage leaves the SAM text unchanged."""
+    import hostapi
+    from bwa_amd.api import MATESW_DTYPE, PES_DTYPE
+    prefix, g = testdata.small_index()
+    host = hostapi.HostFinalize(prefix)
+    r1, r2 = simdata.make_reads_pe(g, 60, seed=98)
+    rng = np.random.default_rng(99)
+    r2 = np.where(rng.random(r2.shape) < 0.14, (r2 + rng.integers(1, 4, r2.shape)) % 4, r2).astype(np.uint8)
+    reads = np.empty((2 * r1.shape[0], r1.shape[1]), dtype=np.uint8); reads[0::2], reads[1::2] = r1, r2
+    seqs, off = testdata.flat(reads)
+    opt = default_opt(); opt.flag |= 2
+    counts, regs = sim.align(opt, seqs, off)
+    pes = host.pestat(opt, counts, regs)
+    if (pes["failed"] != 0).all():          # tiny batch: give the FR orientation the simulated library's window
+        pes["failed"][1] = 0; pes["low"][1] = 200; pes["high"][1] = 600
+    dpes = np.zeros(4, dtype=PES_DTYPE)
+    for k in ("low", "high", "failed"):
+        dpes[k] = pes[k]
+    got = sim.matesw(opt, dpes)
+    want = host.matesw_records(opt, seqs, off, counts, regs, pes)
+    assert got.dtype == MATESW_DTYPE and got.shape == want.shape
+    key = lambda a: np.sort(np.frombuffer(a.tobytes(), dtype=f"V{MATESW_DTYPE.itemsize}"))
+    assert (key(got) == key(want)).all(), "device mate-rescue records differ from the host's"
+    assert (got["r"] >= 0).sum() >= 8, "too few rescue alignments to mean anything"
+    names = [f"q{i >> 1}" for i in range(off.shape[0] - 1)]
+    quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
+    import ctypes as C
+    p0 = pes.ctypes.data_as(C.c_void_p)
+    plain = host.regs2sam(opt, names, seqs, quals, off, counts, regs, pes0=p0)
+    assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, pes0=p0, msw=got) == plain
+    host.close()
