@@ -29,7 +29,7 @@ void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_proce
 using namespace hostmem;
 
 static int g_verbose = 3;
-static int g_device_matesw = 0;   // BWAGPU_CLI_MATESW=1: mate-rescue alignments precomputed on the device (same output; off until measured on hardware)
+static int g_device_matesw = 1;   // BWAGPU_CLI_MATESW=0: the host runs every mate-rescue alignment itself (same output)
 static int g_device_cigars = 1;   // BWAGPU_CLI_CIGARS=0: the host computes every CIGAR itself (same output)
 
 // ---- options -----------------------------------------------------------------------------------------------------------

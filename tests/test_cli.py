@@ -89,9 +89,8 @@ def test_cli_hostsim(tmp_path):
     prefix, g = testdata.small_index()
     # the reference binary wants <prefix>.bwt etc.; both programs take the same prefix
     f1, f2, inter, fasta = _write_inputs(tmp_path, g, 26, seed=401)
-    # the mock HIP runtime keeps its lane/block state in globals: two device threads, but one device call at a time;
-    # device-side mate-rescue alignments on (off by default until measured on hardware)
-    _compare_all(_sim_cli(), prefix, f1, f2, inter, fasta, env=dict(os.environ, BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1", BWAGPU_CLI_MATESW="1"))
+    # the mock HIP runtime keeps its lane/block state in globals: two device threads, but one device call at a time
+    _compare_all(_sim_cli(), prefix, f1, f2, inter, fasta, env=dict(os.environ, BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1"))
 
 
 @pytest.mark.gpu

@@ -195,6 +195,37 @@ def test_device_cigars_match_the_reference_sam(medium):
     host.close()
 
 
+def test_device_matesw_records_match_the_host(medium):
+    """bwagpu_batch_matesw on pairs whose second mate is too noisy to map on its own -- the device's task list and
+    ksw_align2 results equal the host code's (same records, any order), and the SAM text produced with them is the reference's."""
+    import ctypes as C
+    import hostapi
+    from bwa_amd.api import MATESW_DTYPE, PES_DTYPE
+    gpu, orc, ref, g = medium
+    host = hostapi.HostFinalize(testdata.medium_index()[0])
+    r1, r2 = simdata.make_reads_pe(g, 10000, seed=98)
+    rng = np.random.default_rng(99)
+    r2 = np.where(rng.random(r2.shape) < 0.10, (r2 + rng.integers(1, 4, r2.shape)) % 4, r2).astype(np.uint8)
+    reads = np.empty((2 * r1.shape[0], r1.shape[1]), dtype=np.uint8); reads[0::2], reads[1::2] = r1, r2
+    seqs, off = testdata.flat(reads)
+    opt = default_opt(); opt.flag |= 2
+    counts, regs = gpu.align(opt, seqs, off)
+    pes = host.pestat(opt, counts, regs)
+    dpes = np.zeros(4, dtype=PES_DTYPE)
+    for k in ("low", "high", "failed"):
+        dpes[k] = pes[k]
+    got = gpu.matesw(opt, dpes)
+    want = host.matesw_records(opt, seqs, off, counts, regs, pes)
+    key = lambda a: np.sort(np.frombuffer(a.tobytes(), dtype=f"V{MATESW_DTYPE.itemsize}"))
+    assert got.shape == want.shape and (key(got) == key(want)).all(), "device mate-rescue records differ from the host's"
+    assert (got["r"] >= 0).sum() > 1000
+    names = [f"q{i >> 1}" for i in range(off.shape[0] - 1)]
+    quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
+    ascii_ = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, msw=got, cigs=gpu.cigars(opt)) == ref.process_seqs(opt, names, ascii_[seqs].tobytes(), quals, off)
+    host.close()
+
+
 def test_index_broadcast_over_rccl_single_rank(small):
     """The multi-GPU start-up path on one GPU: a world_size-1 RCCL group, the index buffers wrapped as device tensors
     (CUDA array interface) and broadcast; the handle must align exactly like one created directly."""
