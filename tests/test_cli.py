@@ -88,7 +88,7 @@ def _compare_all(cli, fa, f1, f2, inter, fasta, env=None):
 def test_cli_hostsim(tmp_path):
     prefix, g = testdata.small_index()
     # the reference binary wants <prefix>.bwt etc.; both programs take the same prefix
-    f1, f2, inter, fasta = _write_inputs(tmp_path, g, 26, seed=401)
+    f1, f2, inter, fasta = _write_inputs(tmp_path, g, 18, seed=401)
     # the mock HIP runtime keeps its lane/block state in globals: two device threads, but one device call at a time
     _compare_all(_sim_cli(), prefix, f1, f2, inter, fasta, env=dict(os.environ, BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1"))
 
