@@ -260,7 +260,7 @@ def main():
             e2e = end_to_end(fa, [f1, f2], threads, streams=2)
             if e2e:
                 out["end_to_end_pe"] = {"value": round(e2e / 1e6, 4), "unit": "Mreads/s",
-                                        "what": f"same, {n_pairs} pairs of 2x{args.read_len} bp (BASELINE metric's read layout): adds mem_pestat, mate rescue and pairing on the host"}
+                                        "what": f"same, {n_pairs} pairs of 2x{args.read_len} bp (BASELINE metric's read layout): adds mem_pestat and pairing on the host, mate-rescue alignments on the device"}
         print(json.dumps(out), flush=True)
     gpu.close()
     if dist is not None:
