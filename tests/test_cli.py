@@ -59,6 +59,22 @@ def _write_inputs(tmp_path, g, n_pairs, seed):
         for i in range(min(n_pairs, 40)):
             s = simdata._ASCII[r1[i]].tobytes()
             f.write(f">fa{i}\n".encode() + s[:70] + b"\n" + s[70:] + b"\n")
+    # awkward but legal input: CRLF line ends, multi-line FASTQ records, lower case and IUPAC codes, blank lines, a record
+    # without qualities in between, a comment after the name
+    weird = str(tmp_path / "weird.fq")
+    with open(weird, "wb") as f:
+        a = simdata._ASCII
+        for i in range(min(n_pairs, 12)):
+            s = a[r1[i]].tobytes()
+            q = bytes(33 + (j * 7 + i) % 40 for j in range(len(s)))
+            if i % 4 == 0:
+                f.write(f"@w{i} some comment\r\n".encode() + s + b"\r\n+\r\n" + q + b"\r\n")
+            elif i % 4 == 1:
+                f.write(f"@w{i}\n".encode() + s[:60] + b"\n" + s[60:] + b"\n+w\n" + q[:100] + b"\n" + q[100:] + b"\n\n")
+            elif i % 4 == 2:
+                f.write(f">w{i}\n".encode() + s.lower()[:75] + b"\n" + s[75:].replace(b"A", b"R", 1) + b"\n")
+            else:
+                f.write(f"@w{i}\n".encode() + s + b"\n+\n" + q + b"\n")
     return f1, f2, inter, fasta
 
 
@@ -71,6 +87,8 @@ def _compare_all(cli, fa, f1, f2, inter, fasta, env=None):
     y = ["-a", "-k", "17", "-A", "2", "-T", "40", "-h", "3,10", "-I", "400,50", "-5"]
     assert _run(refapi.REF_BWA, K + y + [fa, f1, f2]) == _run(cli, K + y + [fa, f1, f2], env), "scaled scores (-A 2), -I, -a, -5"
     assert _run(refapi.REF_BWA, K + [fa, fasta]) == _run(cli, K + [fa, fasta], env), "multi-line FASTA input"
+    weird = os.path.join(os.path.dirname(f1), "weird.fq")
+    assert _run(refapi.REF_BWA, K + ["-C", fa, weird]) == _run(cli, K + ["-C", fa, weird], env), "CRLF, multi-line FASTQ, lower case / IUPAC, mixed FASTA records"
     # header lines from a file (-H), output to a file (-o)
     hdr = os.path.join(os.path.dirname(f1), "hdr.txt")
     with open(hdr, "w") as f:
