@@ -495,7 +495,7 @@ int main(int argc, char *argv[])
 		}
 	});
 
-	std::thread reader([&] {      // stage 1: input, pairing classes, 2-bit encoding
+	std::thread reader([&] {      // stage 1: input, pairing classes
 		int64_t n_processed = 0; long no = 0;
 		for (;;) {
 			WorkP w(new Work()); w->no = no;
@@ -524,10 +524,6 @@ int main(int argc, char *argv[])
 				u.opt = opt; u.n_processed = n_processed;
 				w->subs.push_back(std::move(u));
 			}
-			for (Sub &u : w->subs) {
-				{ std::lock_guard<std::mutex> l(pool_m); if (!flat_pool.empty()) { u.flat = std::move(flat_pool.back()); flat_pool.pop_back(); } }
-				encode_sub(w->in, u);
-			}
 			n_processed += n; ++no; ++progress;
 			busy_read += now_s() - tr;
 			to_dev.push(std::move(w));
@@ -544,6 +540,12 @@ int main(int argc, char *argv[])
 			{ std::unique_lock<std::mutex> l(dm); dcv.wait(l, [&] { return w->no - next_fin <= (long)n_dev; }); }   // do not run ahead of the host
 			if (d < 16) dev_no[d] = (int)w->no;
 			++progress;
+			const double te = now_s();
+			for (Sub &u : w->subs) {   // 2-bit encoding here rather than on the reader thread, which paces the pipeline
+				{ std::lock_guard<std::mutex> l(pool_m); if (!flat_pool.empty()) { u.flat = std::move(flat_pool.back()); flat_pool.pop_back(); } }
+				encode_sub(w->in, u);
+			}
+			busy_dev_us += (long)((now_s() - te) * 1e6);
 			for (Sub &u : w->subs) { device_sub(handles[d], u, ref, pes0); ++progress; busy_dev_us += (long)(u.t_dev * 1e6); }
 			std::lock_guard<std::mutex> l(dm);
 			const long no = w->no;
@@ -583,7 +585,7 @@ int main(int argc, char *argv[])
 	writer.join();
 	all_done = true; watchdog.join();
 	if (g_verbose >= 3) { const double dt = now_s() - t_start; fprintf(stderr, "[M::%s] %ld reads in %.3f sec after the index was loaded: %.0f reads/s\n", "main_mem", n_reads_total.load(), dt, dt > 0 ? n_reads_total.load() / dt : 0.);
-		fprintf(stderr, "[M::%s] stage busy time: read+encode %.3f s, device %.3f s (over %d handles), finalize %.3f s, write %.3f s\n", "main_mem", busy_read, busy_dev_us.load() * 1e-6, n_dev, busy_fin, busy_write); }
+		fprintf(stderr, "[M::%s] stage busy time: read %.3f s, encode+device %.3f s (over %d handles), finalize %.3f s, write %.3f s\n", "main_mem", busy_read, busy_dev_us.load() * 1e-6, n_dev, busy_fin, busy_write); }
 	for (size_t i = 1; i < handles.size(); ++i) bwagpu_destroy(handles[i]);
 	fflush(stdout);
 	bwagpu_destroy(gpu);
