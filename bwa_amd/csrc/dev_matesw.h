@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) k_matesw_sw(DevIndex ix, bwagpu_opt_t opt
 		const MateTask k = tasks[t];
 		bwagpu_matesw_t o;
 		o.read = k.read; o.r = -1; o.anchor_rb = k.anchor_rb; o.anchor_rid = k.anchor_rid;
-		o.score = 0; o.te = o.qe = o.score2 = o.te2 = o.tb = o.qb = -1; o.pad_ = 0;
+		o.score = 0; o.te = o.qe = o.score2 = o.te2 = o.tb = o.qb = -1; o.pad_ = 0; o.pad2_ = 0;
 		const u8 *ms = Bt.seq + Bt.off[k.read];
 		const int l_ms = (int)(Bt.off[k.read + 1] - Bt.off[k.read]);
 		const int r = k.r, is_rev = (r >> 1) != (r & 1), is_larger = !(r >> 1);

@@ -119,7 +119,7 @@ typedef struct {
 	int64_t anchor_rb;
 	int32_t anchor_rid;
 	int32_t score, te, qe, score2, te2, tb, qb;
-	int32_t pad_;
+	int32_t pad_, pad2_;     /* zero */
 } bwagpu_matesw_t;
 
 /* == mem_alnreg_v, reference bwamem.h:106 */
