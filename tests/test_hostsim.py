@@ -25,7 +25,7 @@ def sim():
 # The mock runs every lane as a fiber and every wave collective as a rendezvous, so the wave-cooperative extension
 # kernel costs ~0.1 s per read here; the CPU suite therefore checks a prefix of each golden set (the GPU suite
 # checks all of it).
-N_SIM = {"se150": 48, "se150_N": 32, "se100_noisy": 32, "se250_odd": 16, "se40": 48, "se17": 50, "long2k_pacbio": 2, "long1500_default": 2}
+N_SIM = {"se150": 48, "se150_N": 32, "se100_noisy": 32, "se250_odd": 16, "se40": 48, "se17": 50, "long2k_pacbio": 1, "long1500_default": 1}
 
 
 def test_hostsim_regs_match_golden(sim):
