@@ -110,7 +110,7 @@ typedef struct {
 /* Insert-size window of one orientation as mem_matesw uses it: mem_pestat_t::low/high/failed (bwamem.h:108-112). */
 typedef struct { int32_t low, high, failed, pad_; } bwagpu_pes_t;
 
-/* One precomputed mate-rescue alignment: the kswr_t that mem_matesw's ksw_align2 call (bwamem_pair.c:170) returns for
+/* One precomputed mate-rescue alignment: the kswr_t that mem_matesw's ksw_align2 call (bwamem_pair.c:177) returns for
  * aligning read `read` (or its reverse complement) inside the window that anchor position `anchor_rb` on contig
  * `anchor_rid` and orientation r imply.  r == -1: no alignment was due for this task (empty window, other contig, window
  * shorter than min_seed_len or beyond the kernel's limits). */
