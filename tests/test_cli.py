@@ -89,6 +89,11 @@ def _compare_all(cli, fa, f1, f2, inter, fasta, env=None):
     assert _run(refapi.REF_BWA, K + [fa, fasta]) == _run(cli, K + [fa, fasta], env), "multi-line FASTA input"
     weird = os.path.join(os.path.dirname(f1), "weird.fq")
     assert _run(refapi.REF_BWA, K + ["-C", fa, weird]) == _run(cli, K + ["-C", fa, weird], env), "CRLF, multi-line FASTQ, lower case / IUPAC, mixed FASTA records"
+    # the second file ends early: both programs stop at the last complete pair (bseq_read warns, bwa.c:96-99)
+    short2 = os.path.join(os.path.dirname(f1), "r2_short.fq")
+    with open(f2, "rb") as fi, open(short2, "wb") as fo:
+        fo.write(b"".join(fi.readlines()[: 4 * 7]))
+    assert _run(refapi.REF_BWA, K + [fa, f1, short2]) == _run(cli, K + [fa, f1, short2], env), "second file shorter than the first"
     # header lines from a file (-H), output to a file (-o)
     hdr = os.path.join(os.path.dirname(f1), "hdr.txt")
     with open(hdr, "w") as f:
