@@ -21,7 +21,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
     srcs = sources()
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in srcs):
         return OUT
-    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, "bwagpu.hip"), "-o", OUT]
+    # two translation units (the index builder pulls in rocPRIM's sort templates and rarely changes): objects are rebuilt
+    # only when one of their own sources is newer
+    objs = []
+    for tu, deps in (("bwagpu.hip", [s for s in srcs if not s.endswith("bwagpu_index.hip")]), ("bwagpu_index.hip", [os.path.join(CSRC, "bwagpu_index.hip"), srcs[-1]])):
+        obj = os.path.join(CSRC, tu.replace(".hip", ".o"))
+        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in deps):
+            cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", os.path.join(CSRC, tu), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

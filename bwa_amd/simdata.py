@@ -58,6 +58,60 @@ def make_genome(total_len: int, n_contigs: int = 4, seed: int = 42, n_interspers
     return g, [int(x) for x in lens]
 
 
+def make_genome_large(total_len: int, n_contigs: int = 24, seed: int = 42, divergence: float = 0.10, threads: int = 8):
+    """GRCh38-scale stand-in: the recipe of make_genome (uniform-random contigs + 4 families of 300 bp interspersed repeats,
+    one copy per 1400 bp, + one tandem array per 40 kb), restructured so that 3.1 Gbp take tens of seconds: the random
+    background is drawn in 16 MB chunks, each from its own PCG64 stream spawned from `seed` (so the result does not depend
+    on the number of threads), and copy mutations come from byte draws.  Contig lengths fall off linearly (the longest is
+    ~8 % of the genome, like chr1); every contig stays below 2^31 (bntann1_t::len is int32).
+    Not byte-compatible with make_genome for the same seed: fixtures keep using make_genome."""
+    from concurrent.futures import ThreadPoolExecutor
+    CH = 1 << 24
+    n_ch = (total_len + CH - 1) // CH
+    ss = np.random.SeedSequence(seed)
+    kids = ss.spawn(n_ch + 1)
+    g = np.empty(total_len, dtype=np.uint8)
+
+    def fill(k):
+        lo, hi = k * CH, min(total_len, (k + 1) * CH)
+        g[lo:hi] = np.frombuffer(np.random.Generator(np.random.PCG64(kids[k])).bytes(hi - lo), dtype=np.uint8) & 3
+
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        list(ex.map(fill, range(n_ch)))
+    rng = np.random.Generator(np.random.PCG64(kids[n_ch]))
+    w = np.linspace(1.0, 0.2, n_contigs)
+    lens = np.maximum((w / w.sum() * total_len).astype(np.int64), 1000)
+    lens[0] += total_len - lens.sum()
+    assert lens.sum() == total_len and (lens > 0).all() and lens.max() < (1 << 31)
+    n_fam = 4
+    fams = rng.integers(0, 4, size=(n_fam, 300), dtype=np.uint8)
+    n_inter = max(8, total_len // 1400)
+    thr = int(round(divergence * 256))
+    for lo in range(0, n_inter, 200_000):                 # chunks bound the temporaries (200k copies x 300 bases)
+        c = min(200_000, n_inter - lo)
+        pos = rng.integers(0, total_len - 400, size=c)
+        e = fams[rng.integers(0, n_fam, size=c)]
+        m = rng.integers(0, 256, size=(c, 300), dtype=np.uint8) < thr
+        e = np.where(m, (e + rng.integers(1, 4, size=(c, 300), dtype=np.uint8)) & 3, e).astype(np.uint8)
+        rev = rng.integers(0, 2, size=c).astype(bool)
+        e[rev] = (3 - e[rev])[:, ::-1]
+        for p, row in zip(pos.tolist(), e):               # slice copies (~0.6 us each) beat a 60 M-element fancy-index scatter
+            g[p:p + 300] = row
+    n_tandem = max(2, total_len // 40000)
+    ulen = rng.integers(20, 61, size=n_tandem).tolist(); ncopy = rng.integers(5, 41, size=n_tandem).tolist()
+    tpos = rng.integers(0, total_len - 60 * 41 - 1, size=n_tandem).tolist()
+    units = rng.integers(0, 4, size=(n_tandem, 60), dtype=np.uint8)
+    mut = rng.integers(0, 256, size=(n_tandem, 64), dtype=np.uint8)     # per array: up to 32 (offset, delta) mutation draws
+    for k in range(n_tandem):
+        arr = np.tile(units[k, : ulen[k]], ncopy[k])
+        n_mut = arr.size // 50                                           # ~2 % of the array's bases
+        for j in range(min(n_mut, 32)):
+            o = (int(mut[k, 2 * j]) * 257 + j * 7919) % arr.size
+            arr[o] = (arr[o] + 1 + (mut[k, 2 * j + 1] % 3)) & 3
+        g[tpos[k]: tpos[k] + arr.size] = arr
+    return g, [int(x) for x in lens]
+
+
 def write_fasta(path: str, g: np.ndarray, lens, prefix: str = "chr"):
     off = 0
     with open(path, "wb") as f:

@@ -196,6 +196,26 @@ int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_cigar_t **o
  * and runs ksw_align2 itself where there is none.  Free with bwagpu_free. */
 int bwagpu_batch_matesw(bwagpu_t *h, const bwagpu_opt_t *opt, const bwagpu_pes_t pes[4], bwagpu_matesw_t **out, int64_t *n_out);
 
+/* ---- index construction on the device -------------------------------------------------------- */
+/* The arrays `bwa index` leaves in bwt_t after bwt_bwtgen2/bwt_pac2bwt + bwt_bwtupdate_core + bwt_cal_sa
+ * (bwtindex.c:64-120, 150-172; bwt.c:62-84), built from the 2-bit packed forward strand by a suffix sort in HBM
+ * (bwagpu_index.hip).  bwt/sa are malloc()ed; free with bwagpu_built_free.  Written with the 40/56-byte headers of
+ * bwt_dump_bwt / bwt_dump_sa (bwt.c:385-407) they are byte-identical to the reference's .bwt/.sa files. */
+typedef struct {
+	uint32_t *bwt;           /* bwt_t::bwt: Occ checkpoints interleaved with 2-bit symbols, bwt_size words */
+	uint64_t bwt_size;
+	uint64_t *sa;            /* bwt_t::sa: n_sa entries, sa[0] = (uint64_t)-1 */
+	uint64_t n_sa;
+	int sa_intv;
+	uint64_t primary, L2[5], seq_len;
+	float build_ms;          /* device time of the whole construction (HIP events) */
+} bwagpu_built_t;
+/* pac: the reference's .pac layout (bntseq.c:229-230), forward strand, l_pac bases, no ambiguity codes (bns_fasta2bntseq
+ * replaces them before packing, bntseq.c:266,295-296).  sa_intv: power of two (the reference uses 32, bwtindex.c:316).
+ * On failure a message is copied to errbuf (may be NULL). */
+int bwagpu_index_build(const uint8_t *pac, int64_t l_pac, int sa_intv, int device, bwagpu_built_t *out, char *errbuf, size_t errlen);
+void bwagpu_built_free(bwagpu_built_t *b);
+
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
 
 /* Create a handle on HIP device `device` and upload the index once (replaces nothing in the reference; it is

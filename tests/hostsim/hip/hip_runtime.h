@@ -63,6 +63,7 @@ static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMem
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __popc(unsigned int x) { return __builtin_popcount(x); }
 static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
 static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }

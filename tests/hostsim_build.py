@@ -12,9 +12,10 @@ OUT = os.path.join(SIM, "libbwagpu_hostsim.so")
 def build():
     csrc = os.path.join(ROOT, "bwa_amd", "csrc")
     srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))] + [
-        os.path.join(SIM, "hip", "hip_runtime.h"), os.path.join(SIM, "mock_globals.cpp"), os.path.join(ROOT, "include", "bwagpu.h")]
+        os.path.join(SIM, "hip", "hip_runtime.h"), os.path.join(SIM, "mock_globals.cpp"), os.path.join(ROOT, "include", "bwagpu.h"),
+        os.path.join(SIM, "rocprim", "functional.hpp")]
     if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in srcs):
         return OUT
     subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-x", "c++", "-I", SIM,
-                    os.path.join(csrc, "bwagpu.hip"), os.path.join(SIM, "mock_globals.cpp"), "-o", OUT], check=True)
+                    os.path.join(csrc, "bwagpu.hip"), os.path.join(csrc, "bwagpu_index.hip"), os.path.join(SIM, "mock_globals.cpp"), "-o", OUT], check=True)
     return OUT

@@ -1,10 +1,12 @@
-"""The device-side index builder (bwa_amd/index.py, torch prefix-doubling suffix array) must write the same five files as the
-reference's `bwa index` (CPU here; the same code runs on the GPU in bench.py)."""
+"""The device-side index builder (bwagpu_index_build in bwa_amd/csrc/bwagpu_index.hip, bound by bwa_amd/index.py) must write
+the same five files as the reference's `bwa index`.  CPU here: the unmodified HIP source under the mock runtime of
+tests/hostsim (rocPRIM's sort/scan replaced by std:: stand-ins); the same code on the GPU in tests/test_gpu_index.py."""
 import filecmp
 import os
 import numpy as np
 import pytest
 
+import hostsim_build
 import refapi
 import testdata
 from bwa_amd import simdata
@@ -14,7 +16,7 @@ from bwa_amd.index import build_index
 def test_small_index_equals_committed_reference_index(tmp_path):
     g, lens = testdata.small_genome()
     prefix = str(tmp_path / "mine")
-    build_index(prefix, g, [(f"chr{i + 1}", l) for i, l in enumerate(lens)], device="cpu")
+    build_index(prefix, g, [(f"chr{i + 1}", l) for i, l in enumerate(lens)], lib_path=hostsim_build.build())
     for ext in ("bwt", "sa", "pac", "ann", "amb"):
         assert filecmp.cmp(prefix + "." + ext, os.path.join(testdata.GOLDEN, "g200k." + ext), shallow=False), ext
 
@@ -30,6 +32,25 @@ def test_index_equals_bwa_index(tmp_path, total, seed):
     simdata.write_fasta(fa, g, lens)
     refapi.build_index(fa)
     prefix = str(tmp_path / "mine")
-    build_index(prefix, g, [(f"chr{i + 1}", l) for i, l in enumerate(lens)], device="cpu")
+    build_index(prefix, g, [(f"chr{i + 1}", l) for i, l in enumerate(lens)], lib_path=hostsim_build.build())
+    for ext in ("bwt", "sa", "pac", "ann", "amb"):
+        assert filecmp.cmp(prefix + "." + ext, fa + "." + ext, shallow=False), ext
+
+
+@pytest.mark.skipif(not refapi.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("env", [{"BWAGPU_INDEX_BUCKET_BASES": "2"}, {"BWAGPU_INDEX_BUCKET_BASES": "3", "BWAGPU_INDEX_SPLIT_SORT": "1"}])
+def test_index_bucketed_and_split_sort_paths(tmp_path, monkeypatch, env):
+    """Large-genome code paths forced on a small genome: several first-pass buckets, and the two-sort form of a doubling
+    round (used when group number + rank exceed 64 bits)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g, lens = simdata.make_genome(50_000, n_contigs=2, seed=11)
+    g[7000:9000] = np.tile(g[7000:7050], 40)          # long exact tandem repeat
+    g[-300:] = 0                                       # poly-A up to the end of the text: exercises the terminator ordering
+    fa = str(tmp_path / "ref.fa")
+    simdata.write_fasta(fa, g, lens)
+    refapi.build_index(fa)
+    prefix = str(tmp_path / "mine")
+    build_index(prefix, g, [(f"chr{i + 1}", l) for i, l in enumerate(lens)], lib_path=hostsim_build.build())
     for ext in ("bwt", "sa", "pac", "ann", "amb"):
         assert filecmp.cmp(prefix + "." + ext, fa + "." + ext, shallow=False), ext
