@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the MI355X BWA-MEM hot path (mem_align1_core for every read of a batch).
+"""bench.py -- throughput of the MI355X BWA-MEM hot path on BASELINE.json's metric: 2x150 bp paired-end reads against a
+GRCh38-scale index, SAM bit-identical to `bwa mem`.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by torch.distributed.run
-with one rank per GPU.  One "step" = one pass of the hot path (seed -> SA -> chain -> extend -> dedup) over one batch
-of synthetic reads that is already resident in HBM.  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by torch.distributed.run with one
+rank per GPU.  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1]): `--reads` (default 1 M) synthetic 150 bp single-end reads per GPU against a
-seeded synthetic stand-in for GRCh38 (`--genome-mbp`, default below; no genome data exists offline and a 3.1 Gbp
-index cannot be built inside the GPU-time budget -- see DESIGN.md section 6).  Reads shard across ranks with no
-data-path collective ("weak" scaling: every rank aligns its own `--reads`).
+Workload (BASELINE.json configs[2] layout, the configuration the metric is quoted on): per GPU and step one batch of
+`--reads` (default 1 M = 500 k pairs, mates interleaved as mem_process_seqs takes them, bwamem.h:146-150) synthetic 2x150 bp
+reads against a seeded synthetic stand-in for GRCh38 of `--genome-mbp` (default 3100 -> seq_len = 6.2e9 > 2^32; no genome
+data exists offline).  The index is built on the GPU at start-up by our own builder (bwagpu_index_build, byte-identical to
+`bwa index`, ~5 s for 3.1 Gbp).  One "step" = one pass of the hot path (mem_align1_core for every read: seed -> SA -> chain ->
+extend -> dedup) over a batch that is already resident in HBM: `value` is the RESIDENT HOT PATH rate and excludes PCIe and the
+host finalize; the end-to-end `bwa-amd mem` rates (FASTQ in -> SAM out) are reported beside it.  Reads shard across ranks with
+no data-path collective ("weak" scaling: every rank aligns its own `--reads`); the index reaches ranks > 0 by RCCL broadcast.
+
+Parity gate: the unmodified reference (`oracle/_ref/bwa mem`, also the CPU baseline) and the product command line
+(`bwa-amd mem`) align the same single-end and paired-end samples with the same -K; their SAM must be byte-identical apart from
+@PG, otherwise the run exits non-zero.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel's algorithmic bytes / its measured duration (HIP events on the library's stream)
-  cpu_baseline the unmodified reference (`oracle/_ref/bwa mem -t C`) on a bounded sample of the same reads
+  roofline     the longest kernel's algorithmic bytes / its measured duration (HIP events on the library's stream)
+  cpu_baseline the reference on the paired-end sample (and the single-end one under "se"), on this box's host cores
+  parity       result of the gate
 """
 import argparse
 import hashlib
@@ -37,38 +46,72 @@ def log(*a):
 
 
 def build_or_load_index(genome_mbp: float, cache: str, rank: int, barrier):
-    """Seeded synthetic genome + reference-format index, built on the GPU by bwa_amd.index (byte-identical to `bwa index`
-    output, tests/test_index_build.py) and cached on the box."""
+    """Seeded synthetic genome + reference-format index files, built on the GPU by bwagpu_index_build and cached on the box.
+    Rank 0 builds; the genome's base codes are shared with the other ranks through a memory-mapped file."""
     from bwa_amd import simdata
     total = int(genome_mbp * 1_000_000)
     prefix = os.path.join(cache, f"g{total}_s42")
-    g, lens = simdata.make_genome(total, n_contigs=8, seed=42)
-    if rank == 0 and not os.path.exists(prefix + ".sa"):
+    info = {}
+    if rank == 0 and not (os.path.exists(prefix + ".sa") and os.path.exists(prefix + ".codes.npy")):
         from bwa_amd.index import build_index
         os.makedirs(cache, exist_ok=True)
         t = time.time()
-        build_index(prefix, g, [(f"chr{i + 1}", l) for i, l in enumerate(lens)])
-        import torch
-        torch.cuda.empty_cache()
-        log(f"[bench] built {genome_mbp} Mbp index on the device in {time.time() - t:.1f}s")
+        g, lens = simdata.make_genome_large(total, n_contigs=24, seed=42, threads=4)
+        t_gen = time.time() - t
+        t = time.time()
+        info = build_index(prefix, g, [(f"chr{i + 1}", l) for i, l in enumerate(lens)])
+        t_idx = time.time() - t
+        np.save(prefix + ".codes.npy", g)
+        del g
+        log(f"[bench] {genome_mbp:g} Mbp genome generated in {t_gen:.1f}s; index built on the device in {info['build_ms'] / 1e3:.2f}s "
+            f"({t_idx:.1f}s with packing, D2H and file output)")
     barrier()
-    return prefix, g
+    return prefix, np.load(prefix + ".codes.npy", mmap_mode="r"), info
 
 
-def cpu_baseline(fa: str, reads: np.ndarray, threads: int):
-    """Unmodified reference `bwa mem -t threads` on a bounded sample; reads/s from its own per-batch timing lines
-    (bwamem.c:1263: '[M::mem_process_seqs] Processed N reads in X CPU sec, Y real sec')."""
-    from bwa_amd import simdata
+def sam_body_digest(path: str):
+    """sha256 over a SAM file without its @PG lines (the only lines allowed to differ: program name and command line)."""
+    h = hashlib.sha256()
+    n = 0
+    with open(path, "rb") as f:
+        for line in f:
+            if line.startswith(b"@PG"):
+                continue
+            h.update(line)
+            n += line[:1] != b"@"
+    return h.hexdigest(), n
+
+
+def run_reference(prefix: str, files, threads: int, out_sam: str):
+    """Unmodified reference `bwa mem -t threads -K 100000000`; reads/s from its own per-batch timing lines
+    (bwamem.c:1263: '[M::mem_process_seqs] Processed N reads in X CPU sec, Y real sec') and the whole-run real time (main.c:126)."""
     bwa = os.path.join(ROOT, "oracle", "_ref", "bwa")
-    fq = os.path.join(os.path.dirname(fa), f"sample_{reads.shape[0]}.fq")
-    simdata.write_fastq(fq, reads)
-    p = subprocess.run([bwa, "mem", "-t", str(threads), "-K", "100000000", "-v", "3", fa, fq], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    t = time.time()
+    with open(out_sam, "wb") as fo:
+        p = subprocess.run([bwa, "mem", "-t", str(threads), "-K", "100000000", "-v", "3", prefix] + list(files), stdout=fo, stderr=subprocess.PIPE, text=True)
+    wall = time.time() - t
     n = tot = 0.0
     for m in re.finditer(r"Processed (\d+) reads in ([\d.]+) CPU sec, ([\d.]+) real sec", p.stderr):
         n += int(m.group(1)); tot += float(m.group(3))
     if p.returncode != 0 or tot <= 0:
+        log("[bench] reference bwa mem failed:", p.stderr[-500:])
         return None
-    return n / tot
+    return {"reads_per_s": n / tot, "n": int(n), "wall_s": wall}
+
+
+def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: int = 2):
+    """The stand-alone `bwa-amd mem` (FASTQ in -> device hot path + device CIGARs / mate rescue -> host finalize -> SAM text)."""
+    cli = os.path.join(ROOT, "bwa_amd", "bwa-amd")
+    cmd = [cli, "mem", "-t", str(threads), "-K", "100000000", "-v", "3"] + (["-o", out_sam] if out_sam else []) + [prefix] + list(files)
+    t = time.time()
+    p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=dict(os.environ, BWAGPU_CLI_STREAMS=str(streams)))
+    wall = time.time() - t
+    m = re.search(r"\[M::main_mem\] (\d+) reads in ([\d.]+) sec .*: (\d+) reads/s", p.stderr)
+    if p.returncode != 0 or not m:
+        log("[bench] bwa-amd mem failed:", p.stderr[-800:])
+        return None
+    busy = re.search(r"stage busy time: (.*)", p.stderr)
+    return {"reads_per_s": float(m.group(3)), "n": int(m.group(1)), "wall_s": wall, "stages": busy.group(1) if busy else ""}
 
 
 def effective_cpus() -> int:
@@ -84,33 +127,28 @@ def effective_cpus() -> int:
     return n
 
 
-def end_to_end(fa: str, files, threads: int, streams: int = 3):
-    """The stand-alone `bwa-amd mem` (FASTQ in -> device hot path + device CIGARs -> host finalize -> SAM text out) on FASTQ
-    files; whole-run reads/s as the program reports it after the index is loaded (input parsing and output included)."""
-    cli = os.path.join(ROOT, "bwa_amd", "bwa-amd")
-    if not (os.path.exists(cli) and all(os.path.exists(f) for f in files)):
-        return None
-    p = subprocess.run([cli, "mem", "-t", str(threads), "-K", "100000000", "-v", "3", fa] + list(files), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
-                       env=dict(os.environ, BWAGPU_CLI_STREAMS=str(streams)))
-    m = re.search(r"\[M::main_mem\] (\d+) reads in ([\d.]+) sec .*: (\d+) reads/s", p.stderr)
-    if p.returncode != 0 or not m:
-        return None
-    return float(m.group(3))
+def interleave(r1: np.ndarray, r2: np.ndarray) -> np.ndarray:
+    out = np.empty((2 * r1.shape[0], r1.shape[1]), dtype=np.uint8)
+    out[0::2] = r1; out[1::2] = r2
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step (pairs x 2 when --layout pe)")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--genome-mbp", type=float, default=512.0)
+    ap.add_argument("--layout", choices=("pe", "se"), default="pe", help="pe: BASELINE configs[2] (2x150 bp pairs, the metric's layout); se: configs[1]")
+    ap.add_argument("--genome-mbp", type=float, default=3100.0)
     ap.add_argument("--cache", default=os.environ.get("BWA_AMD_CACHE", "/tmp/bwa_amd_bench"))
     ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU (handles sharing the index)")
     ap.add_argument("--dense-sa", type=int, default=4, help="densify the SA on the device to this interval (0 = keep the reference's 32)")
-    ap.add_argument("--cpu-sample", type=int, default=200_000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads of the single-end parity / CPU-baseline sample; the paired-end one has this many reads too")
+    ap.add_argument("--e2e-reads", type=int, default=6_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference runs (and with them the parity gate)")
+    ap.add_argument("--no-e2e", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -134,19 +172,32 @@ def main():
     from bwa_amd.api import BwaGpu
     from bwa_amd.structs import default_opt
 
-    fa, g = build_or_load_index(args.genome_mbp, args.cache, rank, barrier)
+    t_all = time.time()
+    prefix, g, idx_info = build_or_load_index(args.genome_mbp, args.cache, rank, barrier)
+    bcast_s = None
     if dist is not None:                     # rank 0 loads + uploads, the others receive the index over RCCL/xGMI
         from bwa_amd import dist as bdist
         t_b = time.perf_counter()
-        gpu = bdist.broadcast_index(fa, device=local, src=0)
+        gpu = bdist.broadcast_index(prefix, device=local, src=0)
+        barrier()
+        bcast_s = time.perf_counter() - t_b
         if rank == 0:
-            log(f"[bench] index broadcast to {world} GPUs in {time.perf_counter() - t_b:.2f}s")
+            log(f"[bench] index loaded on rank 0 and broadcast to {world} ranks over RCCL in {bcast_s:.2f}s")
     else:
-        gpu = BwaGpu(fa, device=local)       # index resident in this GPU's HBM (no CPU fallback: raises without a GPU)
+        gpu = BwaGpu(prefix, device=local)   # index resident in this GPU's HBM (no CPU fallback: raises without a GPU)
     if args.dense_sa:
         gpu.densify_sa(args.dense_sa)
     gpu.set_taps(False)
     opt = default_opt()
+    pe = args.layout == "pe"
+    if pe:
+        opt.flag |= 0x2                      # MEM_F_PE (bwamem.h:43): mates interleaved; the hot path aligns them independently (bwamem.c:1209-1213)
+
+    def make_batch(seed):
+        if pe:
+            r1, r2 = simdata.make_reads_pe(g, args.reads // 2, length=args.read_len, seed=seed)
+            return interleave(r1, r2)
+        return simdata.make_reads_se(g, args.reads, length=args.read_len, seed=seed)
 
     # S batches in flight per GPU: S handles share the resident index (bwagpu_clone), each with its own stream and arenas and
     # driven by its own host thread, so the latency-bound tails of one batch overlap the throughput-bound kernels of another.
@@ -155,11 +206,11 @@ def main():
     handles = [gpu] + [gpu.clone() for _ in range(S - 1)]
     batches = []
     for si, hdl in enumerate(handles):
-        rd = simdata.make_reads_se(g, args.reads, length=args.read_len, seed=1000 + rank * 64 + si)   # this rank's shard(s)
+        rd = make_batch(1000 + rank * 64 + si)            # this rank's shard(s)
         hdl.set_taps(False)
-        hdl.upload(np.ascontiguousarray(rd.reshape(-1)), np.arange(0, args.reads + 1, dtype=np.int64) * args.read_len)   # resident in HBM
+        hdl.upload(np.ascontiguousarray(rd.reshape(-1)), np.arange(0, rd.shape[0] + 1, dtype=np.int64) * args.read_len)   # resident in HBM
         batches.append(rd)
-    reads = batches[0]
+    n_batch = batches[0].shape[0]
 
     # one untimed instrumented solo pass: algorithmic work counters of batch 0 (roofline numerator) and solo kernel times
     gpu.set_stats(True)
@@ -194,18 +245,23 @@ def main():
     for hdl in handles[1:]:
         hdl.close()
 
+    rc_exit = 0
     if rank == 0:
-        total_reads = args.reads * world * args.steps
+        total_reads = n_batch * world * args.steps
         value = total_reads / dt / 1e6
-        # algorithmic bytes per launch of each index-bound kernel: one 64-byte block per Occ lookup /
-        # LF step, 8 bytes per SA sample, plus the read bases the seeding kernel consumes
+        nr = float(work["n_reads"])
+        # algorithmic bytes per launch: one 64-byte block per Occ lookup / LF step, 16 bytes per prefix-table entry,
+        # 8 bytes per SA sample, the read bases; chaining: the slot records it reads (20 B) and the 160-byte B-tree nodes and
+        # 64-byte chain records it touches (counted by the instrumented pass); extension: packed reference window + read + regions
         alg = {
             "k_seed": 64.0 * work["n_occ_blocks"] + 16.0 * work["n_tab_lookups"] + work["n_bases"] / 2,
             "k_sa": 64.0 * work["n_lf_steps"] + 8.0 * work["n_seeds"],
+            "k_chain": 20.0 * work["n_seeds"] + 160.0 * work.get("n_bt_nodes", 0) + 64.0 * work.get("n_chain_recs", 0),
+            "k_extend_wave": work["ref_bases"] / 4 + work["n_bases"] + 88.0 * work["n_regs_raw"],
+            "k_dedup": 2 * 88.0 * work["n_regs_raw"],
         }
-        dur = {"k_seed": stage_ms["ms_seed"], "k_sa": stage_ms["ms_sa"]}
-        dom = max(("k_seed", "k_sa", "k_extend", "k_chain", "k_dedup"), key=lambda k: {"k_extend": stage_ms["ms_extend"], "k_chain": stage_ms["ms_chain"], "k_dedup": stage_ms["ms_dedup"], **dur}[k])
-        roof_k = dom if dom in alg else "k_seed"
+        dur = {"k_seed": stage_ms["ms_seed"], "k_sa": stage_ms["ms_sa"], "k_chain": stage_ms["ms_chain"], "k_extend_wave": stage_ms["ms_extend"], "k_dedup": stage_ms["ms_dedup"]}
+        roof_k = max(dur, key=lambda k: dur[k])           # the longest kernel, whatever it is
         achieved = alg[roof_k] / (dur[roof_k] * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -214,57 +270,95 @@ def main():
                 traffic = json.load(open(pmc)).get(roof_k, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        layout = f"{n_batch // 2} pairs of 2x{args.read_len} bp (mates interleaved)" if pe else f"{n_batch} single-end {args.read_len} bp reads"
         out = {
-            "metric": "Mreads/s (whole job), hot path mem_align1_core, regs bit-identical to bwa mem",
+            "metric": "Mreads/s (whole job), 2x150 bp vs GRCh38-scale index, resident hot path (mem_align1_core of every read); SAM parity gate vs bwa mem",
             "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32/u64 (integer DP + FM-index ranks)", "data": "synthetic",
-            "config": {"workload": f"{args.reads} synthetic {args.read_len}bp SE reads per GPU vs seeded synthetic {args.genome_mbp} Mbp genome (GRCh38 stand-in, BASELINE configs[1])",
-                       "reads_per_gpu": args.reads, "read_len": args.read_len, "genome_mbp": args.genome_mbp, "sa_intv": args.dense_sa or 32,
-                       "sharding": f"reads x{world}, no collective", "batches_in_flight": S, "result_sha256_16": digest},
+            "config": {"workload": f"{layout} per GPU per step vs seeded synthetic {args.genome_mbp:g} Mbp genome (GRCh38 stand-in, seq_len {2 * int(args.genome_mbp * 1e6):.3g}; BASELINE configs[{2 if pe else 1}] layout)",
+                       "reads_per_gpu": n_batch, "read_len": args.read_len, "layout": args.layout, "genome_mbp": args.genome_mbp, "sa_intv": args.dense_sa or 32,
+                       "sharding": f"reads x{world}, no collective", "batches_in_flight": S, "result_sha256_16": digest,
+                       "timed": "kernels of the hot path on batches resident in HBM (no PCIe, no host finalize); see end_to_end_* for FASTQ->SAM"},
             "roofline": {"bound": "hbm", "kernel": roof_k, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "alg_bytes_per_launch": alg[roof_k], "kernel_ms": round(dur[roof_k], 3),
-                         "blocks_64B_per_s": round(alg[roof_k] / 64.0 / (dur[roof_k] * 1e-3), 0),
-                         "random_64B_ceiling": {"GB/s": 1670.0, "blocks_per_s": 26.0e9, "frac": round(achieved / 1670.0, 4),
-                                                "source": "tools/randbw.hip on MI355X, profiles/r01_randbw_microbench.md: random 64-byte reads from HBM saturate at 26e9/s"}},
+                         "per_kernel": {k: {"ms": round(dur[k], 3), "alg_GB": round(alg[k] / 1e9, 3), "GB/s": round(alg[k] / (dur[k] * 1e-3) / 1e9, 1) if dur[k] > 0 else None} for k in dur},
+                         "random_64B_ceiling": {"GB/s": 1670.0, "blocks_per_s": 26.0e9,
+                                                "source": "tools/randbw.hip on MI355X, profiles/r01_randbw_microbench.md: random 64-byte reads from HBM saturate at 26e9/s"},
+                         "ext_gcups": round(work["n_ext_cells"] / (stage_ms["ms_extend"] * 1e-3) / 1e9, 1) if stage_ms["ms_extend"] > 0 else None},
             "stage_ms_solo": {k: round(v, 3) for k, v in stage_ms.items()},
-            "work_per_read": {"N_blk": round(work["n_occ_blocks"] / work["n_reads"], 1), "N_tab": round(work["n_tab_lookups"] / work["n_reads"], 1), "N_lf": round(work["n_lf_steps"] / work["n_reads"], 1),
-                              "N_sa": round(work["n_seeds"] / work["n_reads"], 2), "ext_cells": round(work["n_ext_cells"] / work["n_reads"], 0),
-                              "regs": round(work["n_regs"] / work["n_reads"], 3)},
+            "work_per_read": {"N_blk": round(work["n_occ_blocks"] / nr, 1), "N_tab": round(work["n_tab_lookups"] / nr, 1), "N_lf": round(work["n_lf_steps"] / nr, 1),
+                              "N_sa": round(work["n_seeds"] / nr, 2), "ext_cells": round(work["n_ext_cells"] / nr, 0),
+                              "regs": round(work["n_regs"] / nr, 3)},
+            "index_build": {"device_s": round(idx_info.get("build_ms", 0) / 1e3, 3) if idx_info else None,
+                            "what": "bwagpu_index_build: suffix sort of forward+reverse text in HBM, BWT/Occ/SA in the reference's layout (byte-identical to bwa index)"},
         }
+        if bcast_s is not None:
+            out["index_broadcast"] = {"ranks": world, "seconds": round(bcast_s, 3), "what": "rank 0 loads the index files and uploads; RCCL broadcast of .bwt/.sa/.pac buffers over xGMI; every rank then builds its prefix tables"}
+        gpu.close()
         if world == 1 and not args.no_cpu_baseline:
             threads = effective_cpus()
-            n_s = min(args.cpu_sample, args.reads)
-            t = time.time()
-            rps = cpu_baseline(fa, reads[:n_s], threads)
-            if rps:
-                out["cpu_baseline"] = {"value": round(rps / 1e6, 4), "unit": "Mreads/s", "cores": threads, "kind": "reference",
-                                       "sample": f"first {n_s} reads of the same batch, `bwa mem -t {threads} -K 100000000` (whole mem_process_seqs incl. SAM text; "
-                                                 f"the box exposes {os.cpu_count()} hardware threads but its cgroup quota is {threads} CPUs), {time.time() - t:.1f}s wall"}
-            gpu.close()
-            cache = os.path.dirname(fa)
-            fq = os.path.join(cache, "e2e_se.fq")
-            # a few million reads, so that the figure reflects the pipeline's steady state rather than its fill and drain
-            all_reads = np.concatenate(batches + [simdata.make_reads_se(g, max(0, 6 * args.reads - len(batches) * args.reads), length=args.read_len, seed=4242)])
-            simdata.write_fastq(fq, all_reads)
-            e2e = end_to_end(fa, [fq], threads, streams=2)
-            if e2e:
-                out["end_to_end"] = {"value": round(e2e / 1e6, 4), "unit": "Mreads/s",
-                                     "what": f"`bwa-amd mem -t {threads}` on {all_reads.shape[0]} reads as FASTQ: parsing + H2D + device hot path + device CIGARs + D2H + "
-                                             f"host finalize + SAM text, pipelined over batches of 100 Mbp with 2 in flight; wall time after the index is loaded"}
-            n_pairs = 2 * args.reads
-            r1, r2 = simdata.make_reads_pe(g, n_pairs, length=args.read_len, seed=77)
-            f1, f2 = os.path.join(cache, "e2e_1.fq"), os.path.join(cache, "e2e_2.fq")
-            simdata.write_fastq(f1, r1); simdata.write_fastq(f2, r2)
-            e2e = end_to_end(fa, [f1, f2], threads, streams=2)
-            if e2e:
-                out["end_to_end_pe"] = {"value": round(e2e / 1e6, 4), "unit": "Mreads/s",
-                                        "what": f"same, {n_pairs} pairs of 2x{args.read_len} bp (BASELINE metric's read layout): adds mem_pestat and pairing on the host, mate-rescue alignments on the device"}
+            cache = os.path.dirname(prefix)
+            n_s = min(args.cpu_sample, n_batch) // 2 * 2
+            # ---- single-end sample: reference vs product, same reads, same -K ----
+            se_reads = batches[0][:n_s] if not pe else simdata.make_reads_se(g, n_s, length=args.read_len, seed=4001)
+            fq = os.path.join(cache, "sample_se.fq")
+            simdata.write_fastq(fq, se_reads)
+            ref_se = run_reference(prefix, [fq], threads, os.path.join(cache, "ref_se.sam"))
+            our_se = run_product(prefix, [fq], threads, os.path.join(cache, "our_se.sam"))
+            # ---- paired-end sample ----
+            if pe:
+                p1, p2 = batches[0][0:n_s:2], batches[0][1:n_s:2]
+            else:
+                p1, p2 = simdata.make_reads_pe(g, n_s // 2, length=args.read_len, seed=4002)
+            f1, f2 = os.path.join(cache, "sample_1.fq"), os.path.join(cache, "sample_2.fq")
+            simdata.write_fastq(f1, p1, suffix="/1"); simdata.write_fastq(f2, p2, suffix="/2")
+            ref_pe = run_reference(prefix, [f1, f2], threads, os.path.join(cache, "ref_pe.sam"))
+            our_pe = run_product(prefix, [f1, f2], threads, os.path.join(cache, "our_pe.sam"))
+            par = {"se": False, "pe": False, "n_se": n_s, "n_pairs": n_s // 2,
+                   "how": "sha256 of the SAM text minus @PG lines: oracle/_ref/bwa mem vs bwa-amd mem, same FASTQ, -K 100000000"}
+            if ref_se and our_se:
+                a, b = sam_body_digest(os.path.join(cache, "ref_se.sam")), sam_body_digest(os.path.join(cache, "our_se.sam"))
+                par["se"] = a == b and a[1] >= n_s
+                par["se_records"] = a[1]
+            if ref_pe and our_pe:
+                a, b = sam_body_digest(os.path.join(cache, "ref_pe.sam")), sam_body_digest(os.path.join(cache, "our_pe.sam"))
+                par["pe"] = a == b and a[1] >= n_s
+                par["pe_records"] = a[1]
+            out["parity"] = par
+            if not (par["se"] and par["pe"]):
+                rc_exit = 3
+                log("[bench] PARITY GATE FAILED:", par)
+            note = f"`bwa mem -t {threads} -K 100000000`, whole mem_process_seqs incl. SAM text, rate from its own per-batch real-time lines; the box exposes {os.cpu_count()} hardware threads but its cgroup quota is {threads} CPUs"
+            if ref_pe:
+                out["cpu_baseline"] = {"value": round(ref_pe["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "cores": threads, "kind": "reference",
+                                       "sample": f"{n_s // 2} pairs of 2x{args.read_len} bp of the benchmark's read model ({'first pairs of batch 0' if pe else 'seed 4002'}); {note}; {ref_pe['wall_s']:.1f}s wall incl. index load"}
+                if ref_se:
+                    out["cpu_baseline"]["se"] = {"value": round(ref_se["reads_per_s"] / 1e6, 4), "sample": f"{n_s} single-end reads, same command"}
+            if not args.no_e2e:
+                # a few million reads, so that the figure reflects the pipeline's steady state rather than its fill and drain
+                n_e = max(args.e2e_reads, n_batch) // 2 * 2
+                r1, r2 = simdata.make_reads_pe(g, n_e // 2, length=args.read_len, seed=77)
+                simdata.write_fastq(f1, r1, suffix="/1"); simdata.write_fastq(f2, r2, suffix="/2")
+                e2e = run_product(prefix, [f1, f2], threads, None)
+                if e2e:
+                    out["end_to_end_pe"] = {"value": round(e2e["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "stages": e2e["stages"],
+                                            "what": f"`bwa-amd mem -t {threads}` on {n_e // 2} pairs as two FASTQ files (the BASELINE metric's layout): parsing + H2D + device hot path + device CIGARs and "
+                                                    f"mate-rescue alignments + D2H + mem_pestat/pairing/SAM text on the host, batches of 100 Mbp, 2 in flight; wall time after the index is loaded"}
+                    if ref_pe:
+                        out["end_to_end_pe"]["vs_cpu_baseline"] = round(e2e["reads_per_s"] / ref_pe["reads_per_s"], 1)
+                simdata.write_fastq(fq, np.concatenate([r1, r2]))
+                e2e = run_product(prefix, [fq], threads, None)
+                if e2e:
+                    out["end_to_end_se"] = {"value": round(e2e["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "stages": e2e["stages"], "what": f"same reads as {n_e} single-end reads"}
+        out["bench_wall_s"] = round(time.time() - t_all, 1)
         print(json.dumps(out), flush=True)
-    gpu.close()
+    else:
+        gpu.close()
     if dist is not None:
         dist.destroy_process_group()
+    sys.exit(rc_exit)
 
 
 if __name__ == "__main__":
