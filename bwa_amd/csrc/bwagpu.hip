@@ -23,6 +23,7 @@
 #include "dev_sort.h"
 #include "dev_seed.h"
 #include "dev_chain.h"
+#include "dev_chainw.h"
 #include "dev_ext.h"
 #include "dev_extw.h"
 #include "dev_dedup.h"
@@ -70,7 +71,7 @@ struct bwagpu_s {
 	DevBuf d_msw_tasks, d_msw_out, d_msw_pes, d_msw_scratch;
 	DevBuf d_pack_off, d_regs_packed, d_pack_read, d_cigs, d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
 	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_blob;
-	DevBuf d_order, d_bin_cnt, d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
+	DevBuf d_order, d_bin_cnt, d_chain_todo, d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
 	i64 slot_cap = 0, node_cap = 0, reg_cap = 0; int mem_cap = 0;
 	double need_slot = 0, need_node = 0, need_reg = 0; int need_mem = 0;   // per-base arena needs learnt from earlier batches of this handle
 	std::vector<i64> h_off;
@@ -227,7 +228,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 	}
 	DevBuf *all[] = { &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
-		&h->d_order, &h->d_bin_cnt, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
+		&h->d_order, &h->d_bin_cnt, &h->d_chain_todo, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
 	for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
 	if (h->ev_wait) (void)hipEventDestroy(h->ev_wait);
@@ -360,6 +361,15 @@ extern "C" int bwagpu_index_info(const bwagpu_t *h, int64_t *l_pac, int32_t *n_s
 }
 
 extern "C" int bwagpu_debug_phase(const bwagpu_t *h) { return h ? h->phase : -1; }
+// cycle counters of the last batch_run in a -DBWAGPU_PROFILE build (all zero otherwise); diagnostics only
+extern "C" int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16])
+{
+	if (!h || !out || !h->d_ctr.p) return BWAGPU_EINVAL;
+	Counters c;
+	if (hipMemcpy(&c, h->d_ctr.p, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return BWAGPU_EHIP;
+	for (int i = 0; i < 16; ++i) out[i] = c.prof[i];
+	return BWAGPU_OK;
+}
 
 extern "C" int bwagpu_set_stats(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->stats_on = enable ? 1 : 0; return BWAGPU_OK; }
 extern "C" int bwagpu_set_taps(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->taps_on = enable ? 1 : 0; return BWAGPU_OK; }
@@ -462,7 +472,7 @@ static int alloc_batch(bwagpu_t *h, int n_threads)
 	bad |= h->d_dp_h.ensure((size_t)n_waves * (h->max_len + 2) * DPS * 4);
 	bad |= h->d_dp_e.ensure((size_t)n_waves * (h->max_len + 2) * DPS * 4);
 	bad |= h->d_minhsp.ensure((size_t)(h->max_len + 2) * 4);
-	bad |= h->d_order.ensure((size_t)n * 4 + 16); bad |= h->d_bin_cnt.ensure(2 * ORDER_BINS * 4);
+	bad |= h->d_order.ensure((size_t)n * 4 + 16); bad |= h->d_bin_cnt.ensure(2 * ORDER_BINS * 4); bad |= h->d_chain_todo.ensure((size_t)n * 8 + 32);
 	if (bad) { h->err = "hipMalloc failed (batch arenas)"; return BWAGPU_ENOMEM; }
 	return 0;
 }
@@ -524,7 +534,9 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.regs_raw = h->taps_on ? h->d_regs_raw.as<bwagpu_alnreg_t>() : nullptr;
 		B.dp_h = h->d_dp_h.as<i32>(); B.dp_e = h->d_dp_e.as<i32>(); B.dp_waves = (n_threads + 63) / 64;
 		B.seedsw_minhsp = h->d_minhsp.as<i32>();
-		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>();
+		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>(); B.chain_todo = h->d_chain_todo.as<i32>(); B.chain_todo2 = B.chain_todo + n + 4;
+		B.chain_stop = getenv("BWAGPU_CHAIN_STOP") ? atoi(getenv("BWAGPU_CHAIN_STOP")) : 0;
+		B.chain_lds_off = getenv("BWAGPU_CHAIN_LDS") && atoi(getenv("BWAGPU_CHAIN_LDS")) == 0;
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
 		HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
 		hipLaunchKernelGGL(k_seed, grid, block, (size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * BLOCK * sizeof(uint4), h->stream, h->ix, *opt, B);
@@ -536,7 +548,14 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		if (sa_blocks > MAX_RESIDENT_THREADS / BLOCK) sa_blocks = MAX_RESIDENT_THREADS / BLOCK;
 		hipLaunchKernelGGL(k_sa, dim3((unsigned)sa_blocks), block, 0, h->stream, h->ix, B);
 		HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
-		hipLaunchKernelGGL(k_chain, grid, block, 0, h->stream, h->ix, *opt, B);
+		if (getenv("BWAGPU_CHAIN_LANE")) hipLaunchKernelGGL(k_chain, grid, block, 0, h->stream, h->ix, *opt, B);   // round-1 lane-per-read kernel (A/B measurements)
+		else {	// wave per read, heaviest reads (most seeds) first; reads that outgrow the LDS tier are redone by the HBM tier
+			if (int rc2 = order_reads(h, B, B.seed_n)) return rc2;
+			i64 nblk = ((i64)n + 3) / 4, cap = 256 * 8;
+			hipLaunchKernelGGL((k_chain_wave<0, 10, 32, 128>), dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)CW_LDS_BYTES(10, 32, 128) * 4, h->stream, h->ix, *opt, B);
+			hipLaunchKernelGGL((k_chain_wave<1, 16, 64, 0>), dim3(256 * 5), block, (size_t)CW_LDS_BYTES(16, 64, 0) * 4, h->stream, h->ix, *opt, B);
+			hipLaunchKernelGGL((k_chain_wave<2, 0, 0, 0>), dim3(256 * 7), block, (size_t)CW_LDS_BYTES(0, 0, 0) * 4, h->stream, h->ix, *opt, B);
+		}
 		HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
 		if (any_seedsw && h->max_len > WAVE_EXT_MAX_LEN) {   // long reads: one wavefront per read, one lane per seed
 			i64 nblk = ((i64)n + 3) / 4, cap = n_threads / BLOCK;
@@ -595,7 +614,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		h->stats.n_seeds = (i64)c.seed_used;
 		h->stats.n_intv = (i64)c.n_intv;
 		h->stats.n_chains = (i64)c.n_chains; h->stats.n_regs_raw = (i64)c.n_regs_raw; h->stats.n_regs = (i64)c.n_regs;
-		h->stats.n_tab_lookups = (i64)c.tab_lookups;
+		h->stats.n_tab_lookups = (i64)c.tab_lookups; h->stats.n_bt_nodes = (i64)c.bt_nodes; h->stats.n_chain_recs = (i64)c.chain_recs; h->stats.n_chain_deferred = (i64)c.n_chain_todo; h->stats.n_chain_deferred2 = (i64)c.n_chain_todo2;
 		h->stats.n_occ_blocks = (i64)c.occ_blocks; h->stats.n_lf_steps = (i64)c.lf_steps;
 		h->stats.n_ext_calls = (i64)c.ext_calls; h->stats.n_ext_cells = (i64)c.ext_cells;
 		h->stats.n_glb_calls = (i64)c.glb_calls; h->stats.n_glb_cells = (i64)c.glb_cells; h->stats.ref_bases = (i64)c.ref_bases;

@@ -194,9 +194,10 @@ __global__ void __launch_bounds__(256) k_cigar(DevIndex ix, bwagpu_opt_t opt, Ba
 	L.qp = (int8_t*)(L.e + (CIG_MAX_LEN + 2 + 64));
 	L.z = (u8*)(L.qp + 5 * L.qstride);
 	L.ops = (u32*)(L.z + z_cells / 2 + CIG_MAX_COLS);
+	WaveQueue wq; wq_init(wq);
 	for (;;) {
-		const long long g = wave_fetch(next);
-		if (g >= n_regs) break;
+		long long g;
+		if (!wq_next(wq, next, n_regs, g)) break;
 		if (tier > 0 && uni(out[g].n_cigar) != -2) continue;
 		const bwagpu_alnreg_t p = regs[g];
 		if (p.score < opt.T) { if (lane == 0) { out[g].score = 1; out[g].n_cigar = -1; for (int k = 0; k < CIG_MAX_OPS; ++k) out[g].cigar[k] = 0; } continue; }

@@ -64,17 +64,38 @@ struct ChainRec {
 #define ORDER_BINS 32
 #define SLOT_BLOB_BYTES 160   // 64 chain record + 16 packed kept-chain record + 32 kept chain header + 24 seed + 8 sort key + 3 x 4 ints (+4 pad)
 
+// Every wave of a kernel draws its work from these counters, and same-address atomics complete at only ~75 M/s on this chip
+// (measured: 10^6 fetches = 13 ms, most of the round-1 chaining kernel's "bulk").  Hence: the hot counters sit on cache lines of
+// their own (atomics of different counters then go to different L2 channels), and kernels draw reads in chunks (wave_fetch_n).
+struct alignas(128) HotCounter { unsigned long long v; unsigned long long pad_[15]; };
 struct Counters {          // device-side bump allocators + flags
-	unsigned long long intv_used, seed_used, node_used, reg_used;
-	unsigned long long next_read;  // work counter of the seeding kernel
-	unsigned long long next_ext;   // work counter of the wave extension kernel (position in Batch::order)
-	unsigned long long next_seedsw;                // work counter of the wave-per-read seed re-scoring kernel (long reads)
-	unsigned long long next_chain, next_dedup;   // work counters of the lane-per-read chaining and de-duplication kernels
+	HotCounter seed_used_, node_used_, reg_used_;
+	HotCounter next_read_;   // work counter of the seeding kernel
+	HotCounter next_ext_;    // work counter of the wave extension kernel (position in Batch::order)
+	HotCounter next_seedsw_; // work counter of the wave-per-read seed re-scoring kernel (long reads)
+	HotCounter next_chain_, next_dedup_;       // work counters of the chaining and de-duplication kernels
+	HotCounter next_chain_b_, n_chain_todo_;   // second tier of the wave-per-read chaining kernel: its work counter and the length of its work list
+	HotCounter next_chain_c_, n_chain_todo2_;  // third tier
+	unsigned long long intv_used;
 	unsigned long long overflow;   // bit0 intv, bit1 seed, bit2 node, bit3 reg, bit4 tmp-intv scratch
 	// algorithmic work counters (bwagpu_stats_t)
 	unsigned long long n_intv, n_chains, n_regs_raw, n_regs;
 	unsigned long long occ_blocks, lf_steps, ext_calls, ext_cells, glb_calls, glb_cells, ref_bases, sw_calls, sw_cells, tab_lookups;
+	unsigned long long prof[16];                   // cycle counters of a -DBWAGPU_PROFILE build (bwagpu_debug_prof), zero otherwise
+	unsigned long long bt_nodes, chain_recs;       // B-tree nodes visited by look-ups / chain records touched (k_chain's algorithmic bytes)
 };
+#define seed_used seed_used_.v
+#define node_used node_used_.v
+#define reg_used reg_used_.v
+#define next_read next_read_.v
+#define next_ext next_ext_.v
+#define next_seedsw next_seedsw_.v
+#define next_chain next_chain_.v
+#define next_dedup next_dedup_.v
+#define next_chain_b next_chain_b_.v
+#define n_chain_todo n_chain_todo_.v
+#define next_chain_c next_chain_c_.v
+#define n_chain_todo2 n_chain_todo2_.v
 
 // Sub-arrays of one read's private region (n = its number of seed slots); offsets keep every array naturally aligned.
 struct RegionView {
@@ -125,6 +146,9 @@ struct Batch {
 	// per read, and the next read of the lane starts in a fresh region).
 	u8 *slot_blob;
 	i32 *chain_n;              // per read: chains after filtering
+	i32 *chain_todo, *chain_todo2; // reads deferred by tier 0 / tier 1 of k_chain_wave to the next tier
+	int chain_stop;            // diagnostics (BWAGPU_CHAIN_STOP=k): k_chain_wave returns after phase k of every read (timing only, results invalid)
+	int chain_lds_off;         // test hook (BWAGPU_CHAIN_LDS=0): the LDS tiers defer every read
 	// --- B-tree nodes
 	i64 *node_off;             // per read
 	i32 *nodes; i64 node_cap;  // 21 ints per node

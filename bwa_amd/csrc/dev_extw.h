@@ -64,6 +64,29 @@ DEVFN long long wave_fetch(unsigned long long *ctr)
 	const unsigned long long old = atomicAdd(ctr, (unsigned long long)((threadIdx.x & 63) == 0));
 	return (long long)lane0_i64((i64)old);
 }
+// The same for n consecutive items.
+DEVFN long long wave_fetch_n(unsigned long long *ctr, int n)
+{
+	const unsigned long long old = atomicAdd(ctr, (unsigned long long)((threadIdx.x & 63) == 0 ? n : 0));
+	return (long long)lane0_i64((i64)old);
+}
+// Work queue of one wave over items [0, n) of a heaviest-first list: the first WQ_SINGLE items are drawn one at a time (a wave should
+// not sit on several of the heaviest reads), the rest in chunks of WQ_CHUNK, which cuts the atomics on the counter eightfold.
+#define WQ_SINGLE 16384
+#define WQ_CHUNK 8
+struct WaveQueue { long long cur, end; int step; };
+DEVFN void wq_init(WaveQueue &q) { q.cur = q.end = 0; q.step = 1; }
+DEVFN bool wq_next(WaveQueue &q, unsigned long long *ctr, long long n, long long &k)
+{
+	if (q.cur >= q.end) {
+		const long long b = wave_fetch_n(ctr, q.step);
+		if (b >= n) return false;
+		q.cur = b; q.end = b + q.step < n ? b + q.step : n;
+		if (b >= WQ_SINGLE) q.step = WQ_CHUNK;
+	}
+	k = q.cur++;
+	return true;
+}
 DEVFN bwagpu_seed_t uni_seed(bwagpu_seed_t s) { s.rbeg = uni64(s.rbeg); s.qbeg = uni(s.qbeg); s.len = uni(s.len); s.score = uni(s.score); return s; }
 
 // LDS of one wave.  Short reads: eh[] holds every query column and qp[] the 5 x qlen query profile.  Long reads (RING): a row of

@@ -230,19 +230,38 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 	L.st = SS_FETCH; L.r = -1; L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u;
 	const u64 *nib = B.seq_nib;
 	u32 nblk = 0, ntab = 0;
+	// Reads are drawn from the batch counter 64 at a time into a pool of the wave, and lanes that finish a read take the pool's
+	// next one: a per-lane atomicAdd would be 10^6 same-address atomics per batch, which alone take ~13 ms on this chip.
+	int pool_base = 0, pool_cnt = 0;
 	while (L.st != SS_DONE) {
+		{
+			const bool want = L.st == SS_FETCH;
+			const u64 wm = __ballot(want);
+			if (wm) {
+				if (pool_cnt == 0) {
+					const int first = __ffsll((unsigned long long)__ballot(1)) - 1;        // lane 0 may already have left the loop
+					const unsigned long long old = atomicAdd(&B.ctr->next_read, (threadIdx.x & 63) == first ? 64ull : 0ull);
+					pool_base = __shfl((int)old, first); pool_cnt = 64;
+				}
+				const int rank = __popcll(wm & ((1ull << (threadIdx.x & 63)) - 1));
+				if (want && rank < pool_cnt) {
+					const int r = pool_base + rank;
+					if (r >= B.n_reads) L.st = SS_DONE;
+					else {
+						L.r = r; L.qoff = (u64)B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
+						B.intv_n[r] = 0;
+						L.em.mem = B.intv + (size_t)r * B.mem_cap;      // the read's own interval list (sorted and consumed by k_publish)
+						L.em.n = 0; L.em.overflow = false;
+						if (L.len >= opt.min_seed_len) { L.x = 0; L.st = SS_PASS1; }   // else mem_chain returns at once (bwamem.c:286): draw the next read
+					}
+				}
+				const int took = __popcll(wm) < pool_cnt ? __popcll(wm) : pool_cnt;
+				pool_base += took; pool_cnt -= took;
+			}
+		}
 		// ---- advance the lane's state up to its next extension -----------------------------------------------------
 		switch (L.st) {
-		case SS_FETCH: {
-			int r = (int)atomicAdd(&B.ctr->next_read, 1ull);
-			if (r >= B.n_reads) { L.st = SS_DONE; break; }
-			L.r = r; L.qoff = (u64)B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
-			B.intv_n[r] = 0;
-			L.em.mem = B.intv + (size_t)r * B.mem_cap;      // the read's own interval list (sorted and consumed by k_publish)
-			L.em.n = 0; L.em.overflow = false;
-			if (L.len < opt.min_seed_len) break;                  // mem_chain returns at once (bwamem.c:286); fetch the next read
-			L.x = 0; L.st = SS_PASS1;
-			break; }
+		case SS_FETCH: break;    // handled above (wave-level pool)
 		case SS_PASS1:   // pass 1: all SMEMs, left to right (bwamem.c:147-157)
 			if (L.x >= L.len) { L.old_n = L.em.n; L.k2 = 0; L.st = SS_PASS2; }
 			else if (seed_q(L, nib, L.x) > 3) ++L.x;

@@ -176,7 +176,11 @@ typedef struct {
 	float ms_seed, ms_sa, ms_chain, ms_seedsw, ms_extend, ms_dedup, ms_total;
 	int32_t n_retries;       /* arena-growth reruns */
 	float ms_publish;        /* k_publish + k_expand (interval sort, slot reservation); ms_seed is the k_seed kernel alone */
-	int64_t n_tab_lookups;   /* 24-byte prefix-table entries read by seeding in place of index blocks (stats only) */
+	int64_t n_tab_lookups;   /* 16-byte prefix-table entries read by seeding in place of index blocks (stats only) */
+	int64_t n_bt_nodes;      /* B-tree nodes (160 B) visited by chaining's look-ups (stats only)               */
+	int64_t n_chain_recs;    /* chain records (64 B) read or created by chaining (stats only)                  */
+	int64_t n_chain_deferred;/* reads whose chaining outgrew tier 0 of k_chain_wave (LDS-resident seeds, 32 chains) */
+	int64_t n_chain_deferred2;/* ... and tier 1 (96 chains in LDS): chained in the read's HBM region           */
 } bwagpu_stats_t;
 
 /* Diagnostics: a marker of the step the handle's current (or last) batch call has reached; safe to call from another

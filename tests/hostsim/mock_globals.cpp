@@ -3,6 +3,9 @@
 #include <ucontext.h>
 #include <stdio.h>
 #include <vector>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 
 dim3 threadIdx, blockIdx, blockDim, gridDim;
 static unsigned char g_lds[160 * 1024] __attribute__((aligned(64)));
@@ -93,4 +96,25 @@ void mock_launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()
 		}
 	}
 	cur = -1; cur_body = nullptr;
+}
+
+// a crash inside emulated device code should say where: print the native backtrace (build with -g; addr2line resolves it)
+static void mock_segv(int sig)
+{
+	void *bt[64];
+	int n = backtrace(bt, 64);
+	const char msg[] = "mock HIP runtime: fatal signal in emulated device code; backtrace:\n";
+	(void)!write(2, msg, sizeof msg - 1);
+	backtrace_symbols_fd(bt, n, 2);
+	_exit(128 + sig);
+}
+__attribute__((constructor)) static void mock_install_handlers()
+{
+	if (!getenv("MOCK_HIP_BACKTRACE")) return;
+	static char alt[1 << 16];
+	stack_t ss; ss.ss_sp = alt; ss.ss_size = sizeof alt; ss.ss_flags = 0;
+	sigaltstack(&ss, nullptr);
+	struct sigaction sa; memset(&sa, 0, sizeof sa);
+	sa.sa_handler = mock_segv; sa.sa_flags = SA_ONSTACK;
+	sigaction(SIGSEGV, &sa, nullptr); sigaction(SIGBUS, &sa, nullptr); sigaction(SIGABRT, &sa, nullptr);
 }

@@ -200,3 +200,53 @@ def test_hostsim_device_matesw_records_match_the_host(sim):
     plain = host.regs2sam(opt, names, seqs, quals, off, counts, regs, pes0=p0)
     assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, pes0=p0, msw=got) == plain
     host.close()
+
+
+@pytest.mark.parametrize("lds", ["1", "0"])
+def test_hostsim_wave_chaining_heavy_reads(monkeypatch, lds):
+    """k_chain_wave on reads with many chains (repeat-rich 2 Mb genome): multi-level B-trees with splits, duplicate keys, the
+    64-wide chain filter and the flattening of hundreds of chains must reproduce the oracle's chains exactly -- with the tree in
+    LDS (reads that outgrow it fall through to the HBM tier) and with the LDS tier switched off (every read in the HBM tier)."""
+    import refapi
+    if not refapi.have_ref():
+        pytest.skip("oracle/_ref not built (needed to index the 2 Mb genome)")
+    import tempfile
+    d = tempfile.mkdtemp()
+    g, lens = simdata.make_genome(500_000, n_contigs=2, seed=5, n_interspersed=2000, divergence=0.04)   # 500 copies per repeat family
+    fa = os.path.join(d, "rep.fa")
+    simdata.write_fasta(fa, g, lens)
+    refapi.build_index(fa)
+    orc = orcapi.OrcIndex(fa)
+    opt = default_opt()
+    cand = simdata.make_reads_se(g, 1200, seed=97, sub=0.05)        # noisy reads: the home copy of a repeat is not much better than the others
+    n_chains = np.array([orc.chains(opt, r, 0)[0].shape[0] for r in cand])
+    top = np.argsort(n_chains)[::-1][:30]
+    n_kept = np.array([orc.chains(opt, cand[i], 1)[0].shape[0] for i in top])
+    pick = list(top[:3]) + [int(top[i]) for i in np.argsort(n_kept)[::-1][:3]]
+    assert n_chains[pick[0]] > 200 and n_kept.max() > 100, (n_chains[top], n_kept)
+    mid = [int(i) for i in np.nonzero((n_chains >= 36) & (n_chains <= 60))[0][:2]]    # more than tier 0 holds, fewer than tier 1's limit
+    assert len(mid) == 2
+    reads = np.concatenate([cand[pick], cand[mid], cand[:6]])
+    monkeypatch.setenv("BWAGPU_CHAIN_LDS", lds)
+    s2 = BwaGpu(fa, lib_path=hostsim_build.build())
+    s2.set_taps(True); s2.set_stats(True)
+    seqs, off = testdata.flat(reads)
+    c, r = s2.align(opt, seqs, off)
+    st = s2.stats()
+    if lds == "0":
+        assert st["n_chain_deferred"] == st["n_chain_deferred2"] == len(reads)
+    else:   # some reads stay in tier 0, some run in tier 1 (LDS tree, seeds in HBM), the heaviest in tier 2
+        assert 1 <= st["n_chain_deferred2"] < st["n_chain_deferred"] < len(reads), st
+    cn, ch, cs = s2.tap_chains()
+    kc = ks = 0
+    for i, rd in enumerate(reads):
+        hdr, seeds = orc.chains(opt, rd, 1)
+        assert cn[i] == hdr.shape[0], i
+        got_h, got_s = ch[kc:kc + cn[i]], cs[ks:ks + int(hdr["n"].sum())]
+        for f, gname in (("n_seeds", "n"), ("rid", "rid"), ("w", "w"), ("kept", "kept"), ("is_alt", "is_alt"), ("frac_rep", "frac_rep"), ("pos", "pos")):
+            assert np.array_equal(got_h[f], hdr[gname]), (i, f)
+        for f in ("rbeg", "qbeg", "len"):
+            assert np.array_equal(got_s[f], seeds[f]), (i, f)
+        kc += cn[i]; ks += int(hdr["n"].sum())
+    assert_regs_equal(*orc.align(opt, seqs, off), c, r, "heavy chaining")
+    s2.close(); orc.close()
