@@ -110,6 +110,7 @@ class BwaGpu:
         rc = self.L.bwagpu_create_from_files(C.byref(self.h), prefix.encode(), device)
         if rc != 0:
             raise BwaGpuError(f"bwagpu_create_from_files({prefix}) failed: {self.L.bwagpu_strerror(rc).decode()}")
+        self.set_taps(True)     # the library's default is off (a second region arena per batch); the tests read the stage taps, bench.py turns them off
 
     @classmethod
     def empty(cls, meta: dict, device: int = 0, lib_path: str | None = None):

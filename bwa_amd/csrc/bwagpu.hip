@@ -64,7 +64,7 @@ struct bwagpu_s {
 	// batch
 	int n_reads = 0, max_len = 0; i64 n_bases = 0;
 	bool have_batch = false, ran = false;
-	int stats_on = 0, taps_on = 1;
+	int stats_on = 0, taps_on = 0;       // stage taps cost a second region arena and a copy per batch: off unless a test asks (bwagpu_set_taps)
 	bwagpu_stats_t stats = {};
 	volatile int phase = 0;       // progress marker for bwagpu_debug_phase (diagnostics of a stuck call)
 	i64 packed_tot = -1;          // regions packed by the last bwagpu_batch_download (-1: none)
@@ -174,8 +174,8 @@ extern "C" int bwagpu_create(bwagpu_t **out, const bwagpu_index_desc_t *d, int d
 	h->device = device;
 	h->ibuf = new bwagpu_s::IndexBufs();
 	int rc;
-	if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return BWAGPU_ENODEV; }
-	for (int i = 0; i < 8; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return BWAGPU_ENODEV; }
+	if (hipStreamCreate(&h->stream) != hipSuccess) { h->stream = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
+	for (int i = 0; i < 8; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { h->ev[i] = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
 	if (hipEventCreateWithFlags(&h->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) h->ev_wait = nullptr;
 	// the last Occ record of the .bwt is a trailing 32-byte half block; pad the upload to whole 64-byte blocks
 	u64 nblk = (d->bwt_size + 15) / 16;
@@ -285,12 +285,14 @@ extern "C" int bwagpu_create_from_files(bwagpu_t **out, const char *prefix, int 
 		coff[i] = xx; clen[i] = len;
 	}
 	fclose(fa);
-	if (FILE *fl = fopen((pre + ".alt").c_str(), "r")) {   // first column of each non-@ line names an ALT contig
-		char line[8192];
-		while (fgets(line, sizeof line, fl)) {
-			if (line[0] == '@') continue;
-			char *e = line; while (*e && *e != '\t' && *e != '\n' && *e != '\r') ++e; *e = 0;
-			for (int i = 0; i < n_seqs; ++i) if (names[i] == line) calt[i] = 1;
+	if (FILE *fl = fopen((pre + ".alt").c_str(), "r")) {   // first column of each non-@ line names an ALT contig (bns_restore, bntseq.c:185-205)
+		std::string name; int ch;
+		while ((ch = fgetc(fl)) != EOF) {            // lines of any length; like the reference, a last line without a line end is not seen
+			if (ch == '\t' || ch == '\n' || ch == '\r') {
+				if (!name.empty() && name[0] != '@') for (int i = 0; i < n_seqs; ++i) if (names[i] == name) calt[i] = 1;
+				while (ch != '\n' && ch != EOF) ch = fgetc(fl);
+				name.clear();
+			} else name += (char)ch;
 		}
 		fclose(fl);
 	}
@@ -309,10 +311,10 @@ extern "C" int bwagpu_clone(bwagpu_t *src, bwagpu_t **out)
 	if (hipSetDevice(src->device) != hipSuccess) return BWAGPU_ENODEV;
 	bwagpu_t *h = new bwagpu_s();
 	h->device = src->device;
-	if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return BWAGPU_ENODEV; }
-	for (int i = 0; i < 8; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return BWAGPU_ENODEV; }
+	h->ibuf = src->ibuf; ++h->ibuf->refs;     // (bwagpu_destroy drops the reference again on every failure path below)
+	if (hipStreamCreate(&h->stream) != hipSuccess) { h->stream = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
+	for (int i = 0; i < 8; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { h->ev[i] = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
 	if (hipEventCreateWithFlags(&h->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) h->ev_wait = nullptr;
-	h->ibuf = src->ibuf; ++h->ibuf->refs;
 	h->ix = src->ix; h->l_pac = src->l_pac; h->n_seqs = src->n_seqs; h->seq_len = src->seq_len; h->sa_intv = src->sa_intv;
 	h->bwt_blocks = src->bwt_blocks; h->bwt_bytes = src->bwt_bytes; h->sa_bytes = src->sa_bytes; h->pac_bytes = src->pac_bytes;
 	h->bwt_size = src->bwt_size; h->n_sa = src->n_sa;
@@ -496,7 +498,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 	HIPCHK(h, hipSetDevice(h->device));
 	memset(&h->stats, 0, sizeof h->stats);
 	h->stats.n_reads = h->n_reads; h->stats.n_bases = h->n_bases;
-	h->ran = false;
+	h->ran = false; h->packed_tot = -1;      // regions packed by an earlier download belong to the previous run
 	if (h->n_reads == 0) { h->ran = true; return BWAGPU_OK; }
 	int n = h->n_reads;
 	// resident lanes: enough to fill the chip, bounded by the seeding scratch budget (2 interval stacks per lane)
@@ -788,11 +790,12 @@ extern "C" int bwagpu_align_flat(bwagpu_t *h, const bwagpu_opt_t *opt, int n, co
 	return bwagpu_batch_download(h, counts, regs_out, n_regs_out);
 }
 
-// nst_nt4_table (bntseq.c:46-63) as a function: A/a C/c G/g T/t -> 0..3, everything else 4
+// nst_nt4_table (bntseq.c:46-63) as a function: A/a C/c G/g T/t -> 0..3, '-' -> 5, everything else 4
 static inline uint8_t nt4(unsigned char c)
 {
 	switch (c) {
 	case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3;
+	case '-': return 5;
 	default: return 4;
 	}
 }
@@ -816,7 +819,12 @@ extern "C" int bwagpu_align_bseq(bwagpu_t *h, const bwagpu_opt_t *opt, int n, bw
 	for (int i = 0; i < n; ++i) {
 		regs[i].n = regs[i].m = (size_t)counts[i];
 		regs[i].a = (bwagpu_alnreg_t*)malloc((size_t)(counts[i] ? counts[i] : 1) * sizeof(bwagpu_alnreg_t));
-		if (!regs[i].a) { free(all); return BWAGPU_ENOMEM; }
+		if (!regs[i].a) {   // leave no half-filled output behind
+			for (int j = 0; j < i; ++j) { free(regs[j].a); regs[j].a = nullptr; regs[j].n = regs[j].m = 0; }
+			regs[i].n = regs[i].m = 0;
+			free(all);
+			return BWAGPU_ENOMEM;
+		}
 		memcpy(regs[i].a, all + k, (size_t)counts[i] * sizeof(bwagpu_alnreg_t));
 		k += counts[i];
 	}

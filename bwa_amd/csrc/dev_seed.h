@@ -233,8 +233,28 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 	// Reads are drawn from the batch counter 64 at a time into a pool of the wave, and lanes that finish a read take the pool's
 	// next one: a per-lane atomicAdd would be 10^6 same-address atomics per batch, which alone take ~13 ms on this chip.
 	int pool_base = 0, pool_cnt = 0;
+	// The bookkeeping between extensions (next read, next search of a pass, publishing a read's intervals) is a few hundred
+	// instructions that a wave executes whenever ANY of its lanes needs them -- with 64 lanes, in nine iterations out of ten, for one
+	// or two lanes each time (measured: 700 VALU instructions per iteration, 280 of them the extension).  Lanes therefore wait in
+	// their bookkeeping state until eight of them have gathered (or three iterations have passed, or nobody can extend), and the
+	// wave then runs that code once for all of them.
+	int deferred = 0;
+	u32 n_iter = 0, n_slow = 0, n_ext_lanes = 0;
 	while (L.st != SS_DONE) {
-		{
+		++n_iter;
+		const bool slow = L.st < SS_FWD || L.st == SS_FINAL;
+		const u64 sm = __ballot(slow);
+		bool run_slow = false;
+		if (sm) {
+			const u64 am = __ballot(1);
+			run_slow = __popcll(sm) >= 8 || sm == am || ++deferred >= 3;
+		}
+		if (run_slow) {
+			deferred = 0; ++n_slow;
+			if (L.st == SS_FINAL) {
+				if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull); else B.intv_n[L.r] = L.em.n;
+				L.st = SS_FETCH;
+			}
 			const bool want = L.st == SS_FETCH;
 			const u64 wm = __ballot(want);
 			if (wm) {
@@ -258,43 +278,42 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 				const int took = __popcll(wm) < pool_cnt ? __popcll(wm) : pool_cnt;
 				pool_base += took; pool_cnt -= took;
 			}
-		}
-		// ---- advance the lane's state up to its next extension -----------------------------------------------------
-		switch (L.st) {
-		case SS_FETCH: break;    // handled above (wave-level pool)
-		case SS_PASS1:   // pass 1: all SMEMs, left to right (bwamem.c:147-157)
-			if (L.x >= L.len) { L.old_n = L.em.n; L.k2 = 0; L.st = SS_PASS2; }
-			else if (seed_q(L, nib, L.x) > 3) ++L.x;
-			else smem_start(ix, L, S, nib, L.x, 1, 1);
-			break;
-		case SS_PASS2:   // pass 2: re-seed from the middle of long, rare SMEMs (bwamem.c:160-168)
-			if (L.k2 >= L.old_n) { L.x = 0; L.st = opt.max_mem_intv > 0 ? SS_PASS3 : SS_FINAL; }
-			else {
-				Intv3 p = L.em.mem[L.k2++];
-				int start = (int)(p.info >> 32), end = (int)(u32)p.info;
-				if (end - start >= split_len && p.x2 <= (u64)opt.split_width) smem_start(ix, L, S, nib, (start + end) >> 1, p.x2 + 1, 2);
+			// ---- advance the lane's state up to its next extension (a few steps: skipped bases, searches that end at once) ----
+			for (int rep = 0; rep < 3; ++rep) {
+				switch (L.st) {
+				case SS_PASS1:   // pass 1: all SMEMs, left to right (bwamem.c:147-157)
+					while (L.x < L.len && seed_q(L, nib, L.x) > 3) ++L.x;
+					if (L.x >= L.len) { L.old_n = L.em.n; L.k2 = 0; L.st = SS_PASS2; }
+					else smem_start(ix, L, S, nib, L.x, 1, 1);
+					break;
+				case SS_PASS2: { // pass 2: re-seed from the middle of long, rare SMEMs (bwamem.c:160-168)
+					bool started = false;
+					while (L.k2 < L.old_n && !started) {
+						Intv3 p = L.em.mem[L.k2++];
+						int start = (int)(p.info >> 32), end = (int)(u32)p.info;
+						if (end - start >= split_len && p.x2 <= (u64)opt.split_width) { smem_start(ix, L, S, nib, (start + end) >> 1, p.x2 + 1, 2); started = true; }
+					}
+					if (!started) { L.x = 0; L.st = opt.max_mem_intv > 0 ? SS_PASS3 : SS_FINAL; }
+					break; }
+				case SS_PASS3:   // pass 3: LAST-like seeds (bwamem.c:170-185, bwt_seed_strategy1 bwt.c:358-379)
+					while (L.x < L.len && seed_q(L, nib, L.x) > 3) ++L.x;
+					if (L.x >= L.len) L.st = SS_FINAL;
+					else {
+						const int c0 = seed_q(L, nib, L.x);
+						fm_init(ix, c0, L.ik); L.sx = L.x; L.i = L.x + 1;
+						L.code = window_code(L, nib, L.x, ix.ptab_m);
+						if (L.i >= L.len) { L.x = L.len; }
+						else if (seed_q(L, nib, L.i) > 3) { L.x = L.i + 1; }
+						else L.st = SS_STRAT;
+					}
+					break;
+				default: break;
+				}
 			}
-			break;
-		case SS_PASS3:   // pass 3: LAST-like seeds (bwamem.c:170-185, bwt_seed_strategy1 bwt.c:358-379)
-			if (L.x >= L.len) L.st = SS_FINAL;
-			else if (seed_q(L, nib, L.x) > 3) ++L.x;
-			else {
-				const int c0 = seed_q(L, nib, L.x);
-				fm_init(ix, c0, L.ik); L.sx = L.x; L.i = L.x + 1;
-				L.code = window_code(L, nib, L.x, ix.ptab_m);
-				if (L.i >= L.len) { L.x = L.len; }
-				else if (seed_q(L, nib, L.i) > 3) { L.x = L.i + 1; }
-				else L.st = SS_STRAT;
-			}
-			break;
-		case SS_FINAL:
-			if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull); else B.intv_n[L.r] = L.em.n;
-			L.st = SS_FETCH;
-			break;
-		default: break;
 		}
 		// ---- the one expensive, convergent step: an FM extension ---------------------------------------------------------
 		const int st = L.st;
+		if (B.stats) n_ext_lanes += (u32)__popcll(__ballot(st == SS_FWD || st == SS_BWD || st == SS_STRAT));
 		if (st == SS_FWD || st == SS_BWD || st == SS_STRAT) {
 			BiIntv ok, src;
 			const int back = st == SS_BWD;
@@ -346,7 +365,10 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			}
 		}
 	}
-	if (B.stats) { atomicAdd(&B.ctr->occ_blocks, (unsigned long long)nblk); atomicAdd(&B.ctr->tab_lookups, (unsigned long long)ntab); }
+	if (B.stats) {
+		atomicAdd(&B.ctr->occ_blocks, (unsigned long long)nblk); atomicAdd(&B.ctr->tab_lookups, (unsigned long long)ntab);
+		if ((threadIdx.x & 63) == 0) { atomicAdd(&B.ctr->prof[13], (unsigned long long)n_iter); atomicAdd(&B.ctr->prof[14], (unsigned long long)n_slow); atomicAdd(&B.ctr->prof[15], (unsigned long long)n_ext_lanes); }
+	}
 }
 
 // One lane per SA interval: expand it into its SA rows (mem_chain's k-loop, bwamem.c:304-305) in the read's slot range.

@@ -26,12 +26,14 @@ bool load_refseqs(const std::string &prefix, RefSeqs &out, std::string &err)
 		c.offset = xx; c.is_alt = 0;
 	}
 	fclose(fa);
-	if (FILE *fl = fopen((prefix + ".alt").c_str(), "r")) {
-		char line[8192];
-		while (fgets(line, sizeof line, fl)) {
-			if (line[0] == '@') continue;
-			char *e = line; while (*e && *e != '\t' && *e != '\n' && *e != '\r') ++e; *e = 0;
-			for (auto &c : out.ctg) if (c.name == line) c.is_alt = 1;
+	if (FILE *fl = fopen((prefix + ".alt").c_str(), "r")) {   // bns_restore (bntseq.c:185-205): first column of every non-@ line
+		std::string name; int ch;
+		while ((ch = fgetc(fl)) != EOF) {            // lines of any length; like the reference, a last line without a line end is not seen
+			if (ch == '\t' || ch == '\n' || ch == '\r') {
+				if (!name.empty() && name[0] != '@') for (auto &c : out.ctg) if (c.name == name) c.is_alt = 1;
+				while (ch != '\n' && ch != EOF) ch = fgetc(fl);
+				name.clear();
+			} else name += (char)ch;
 		}
 		fclose(fl);
 	}

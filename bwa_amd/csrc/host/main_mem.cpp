@@ -144,7 +144,7 @@ struct Reader {
 		s.qual = A.size();
 		if (c == '>' || c == '@') last = c; else last = 0;
 		if (c != '+') { A.push_back(0); return true; }
-		if (until(false, nullptr) == -1) { A.push_back(0); return true; }          // skip the rest of the '+' line
+		if (until(false, nullptr) == -1) { A.push_back(0); last = 0; return false; } // '+' line, then end of input: kseq_read's "no quality string" error (-2), the record is dropped
 		s.has_qual = true;
 		while (A.size() - s.qual < (size_t)s.l_seq) {
 			const size_t before = A.size();
@@ -156,6 +156,10 @@ struct Reader {
 		s.l_qual = (int)(A.size() - s.qual);
 		A.push_back(0);
 		last = 0;
+		// kseq_read returns -2 when the quality string and the sequence differ in length (kseq.h:219): bseq_read's loop ends there
+		// (bwa.c:88), the record is dropped and the batch closed; the next batch resumes scanning for a header after the text the
+		// quality loop has consumed.  Passing such a record on would also let the SAM writer read qual[0..l_seq) out of bounds.
+		if (s.l_qual != s.l_seq) return false;
 		return true;
 	}
 };
