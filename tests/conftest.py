@@ -11,3 +11,21 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    """On a box with a GPU the compiled reference (oracle/_ref) must be there: it is git-ignored but travels with the gpurun
+    snapshot, and most -m gpu parity tests compare against it.  A skip for its absence would leave a green suite of four tests,
+    so for gpu-marked tests such a skip is turned into a failure."""
+    outcome = yield
+    rep = outcome.get_result()
+    if rep.skipped and item.get_closest_marker("gpu") is not None and "oracle/_ref" in str(rep.longrepr):
+        try:
+            import torch
+            has_gpu = torch.cuda.is_available()
+        except Exception:
+            has_gpu = False
+        if has_gpu:
+            rep.outcome = "failed"
+            rep.longrepr = f"{item.nodeid}: skipped for a missing oracle/_ref on a GPU box -- the compiled reference did not travel with the snapshot ({rep.longrepr})"

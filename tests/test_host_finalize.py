@@ -91,6 +91,17 @@ def test_paired_end_sam(pair, flag, kw):
     _check(ref, host, opt, _interleave(*simdata.make_reads_pe(g, 4000, **kw)), f"PE flag {flag:#x}", n_processed=8000)
 
 
+@pytest.mark.parametrize("n_processed", [(1 << 24) - 2000, (1 << 24) + 6, (1 << 25) + (1 << 24) + 1000, 20_000_000])
+def test_paired_end_pair_ids_beyond_2_to_23(pair, n_processed):
+    """BASELINE configs[2]/[3] hold 10-100 M pairs: mem_pair hashes `id << 8` with a 32-bit int id (bwamem_pair.c:208,248), which
+    overflows -- and is sign-extended into the 64-bit XOR -- from pair id 2^23 on.  Batches that start just below, at, and far
+    beyond that id (bit 31 of id << 8 set and clear) must give the reference's SAM: the tie-breaking hash decides between
+    equally good pairings, which the repeat-rich genome provides."""
+    ref, host, g = pair
+    opt = default_opt(); opt.flag |= 0x2
+    _check(ref, host, opt, _interleave(*simdata.make_reads_pe(g, 3000, seed=351, sub=0.02)), f"PE, n_processed {n_processed}", n_processed=n_processed)
+
+
 def test_paired_end_mixed_orientations_and_chimeras(pair):
     """Pairs whose second mate is not reverse-complemented (FF), swapped, or taken from elsewhere: exercises the four
     orientation branches of mate rescue and the no-pairing fallback."""

@@ -250,3 +250,37 @@ def test_hostsim_wave_chaining_heavy_reads(monkeypatch, lds):
         kc += cn[i]; ks += int(hdr["n"].sum())
     assert_regs_equal(*orc.align(opt, seqs, off), c, r, "heavy chaining")
     s2.close(); orc.close()
+
+
+def _alt_prefix(tmp_path, prefix, alt_names):
+    """The same index under a new prefix, plus a .alt file (first column = contig name, bntseq.c:185-205)."""
+    new = str(tmp_path / "alt_idx")
+    for ext in ("bwt", "sa", "pac", "ann", "amb"):
+        os.symlink(os.path.abspath(prefix + "." + ext), new + "." + ext)
+    with open(new + ".alt", "w") as f:
+        f.write("@SQ\tSN:ignored header line\n")
+        for nme in alt_names:
+            f.write(f"{nme}\t0\tchr1\t1\t60\t100M\t*\t0\t0\t*\t*\n")
+    return new
+
+
+def test_hostsim_alt_contigs(tmp_path):
+    """ALT contigs on the device path (is_alt from the .alt file -> mem_chain's chain records, mem_chain_flt's ALT-aware overlap rule
+    bwamem.c:377, mem_sort_dedup_patch, the regions' is_alt, bwamem.c:1113-1114): regions equal the oracle's with the same contig
+    flagged, and differ from the run without the .alt file (so the flag demonstrably reaches the kernels)."""
+    prefix, g = testdata.small_index()
+    alt = _alt_prefix(tmp_path, prefix, ["chr3"])
+    orc = orcapi.OrcIndex(prefix); orc.set_alt(2, 1)
+    s_alt, s_plain = BwaGpu(alt, lib_path=hostsim_build.build()), BwaGpu(prefix, lib_path=hostsim_build.build())
+    # reads from the ALT contig and from the repeats the contigs share
+    lens = testdata.small_genome()[1]
+    lo = sum(lens[:2])
+    reads = np.concatenate([simdata.make_reads_se(g[lo:], 30, seed=98), simdata.make_reads_se(g, 30, seed=99)])
+    seqs, off = testdata.flat(reads)
+    opt = default_opt()
+    c, r = s_alt.align(opt, seqs, off)
+    assert_regs_equal(*orc.align(opt, seqs, off), c, r, "ALT contig")
+    assert int((r["ncomp_isalt"] >> 30).sum()) > 0, "no region on the ALT contig"
+    c0, r0 = s_plain.align(opt, seqs, off)
+    assert r.tobytes() != r0.tobytes()
+    s_alt.close(); s_plain.close(); orc.close()
