@@ -42,7 +42,7 @@ class Stats(C.Structure):
         "n_ext_calls", "n_ext_cells", "n_glb_calls", "n_glb_cells", "ref_bases", "n_sw_calls", "n_sw_cells")] + [
         (n, C.c_float) for n in ("ms_seed", "ms_sa", "ms_chain", "ms_seedsw", "ms_extend", "ms_dedup", "ms_total")] + [
         ("n_retries", C.c_int32), ("ms_publish", C.c_float), ("n_tab_lookups", C.c_int64), ("n_bt_nodes", C.c_int64), ("n_chain_recs", C.c_int64),
-        ("n_chain_deferred", C.c_int64), ("n_chain_deferred2", C.c_int64)]
+        ("n_chain_deferred", C.c_int64), ("n_ext_fast", C.c_int64), ("n_chain_deferred2", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved_"}
@@ -53,7 +53,7 @@ EXPORTS = [
     "bwagpu_index_info", "bwagpu_densify_sa", "bwagpu_set_stats", "bwagpu_get_stats", "bwagpu_align_bseq", "bwagpu_align_flat",
     "bwagpu_free", "bwagpu_batch_upload", "bwagpu_batch_run", "bwagpu_batch_download", "bwagpu_set_taps", "bwagpu_tap_intervals",
     "bwagpu_tap_chains", "bwagpu_tap_regs_raw", "bwagpu_index_buffers", "bwagpu_index_export", "bwagpu_clone", "bwagpu_index_ready",
-    "bwagpu_batch_cigars", "bwagpu_debug_phase", "bwagpu_batch_matesw",
+    "bwagpu_batch_cigars", "bwagpu_debug_phase", "bwagpu_batch_matesw", "bwagpu_clone_to_device", "bwagpu_index_build", "bwagpu_built_free", "bwagpu_abi_sizes", "bwagpu_debug_prof",
 ]
 
 

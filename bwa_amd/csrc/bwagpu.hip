@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -56,7 +57,12 @@ struct bwagpu_s {
 	std::string err;
 	// index
 	DevIndex ix = {};
-	struct IndexBufs { DevBuf d_bwt, d_sa, d_pac, d_ctg_off, d_ctg_len, d_ctg_alt, d_ptab; int refs = 1; };
+	struct IndexBufs {
+		DevBuf d_bwt, d_sa, d_pac, d_ctg_off, d_ctg_len, d_ctg_alt, d_ptab; int refs = 1;
+		// per-base arena needs learnt by any handle on this index (a re-run for arena growth doubles a batch's device time, so a
+		// cloned handle should not have to learn them again); written and read under `m`
+		std::mutex m; double need_slot = 0, need_node = 0, need_reg = 0; int need_mem = 0;
+	};
 	IndexBufs *ibuf = nullptr;      // shared by bwagpu_clone()d handles
 	i64 l_pac = 0; int n_seqs = 0; u64 seq_len = 0; int sa_intv = 0;
 	u64 bwt_blocks = 0, bwt_bytes = 0, sa_bytes = 0, pac_bytes = 0, bwt_size = 0, n_sa = 0;
@@ -84,6 +90,12 @@ struct bwagpu_s {
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return BWAGPU_EHIP; } } while (0)
 
 extern "C" const char *bwagpu_version(void) { return BWAGPU_VERSION; }
+// sizeof of the public structs as this library was compiled (bindings check their mirrors against it)
+extern "C" void bwagpu_abi_sizes(int32_t out[8])
+{
+	out[0] = (int32_t)sizeof(bwagpu_opt_t); out[1] = (int32_t)sizeof(bwagpu_alnreg_t); out[2] = (int32_t)sizeof(bwagpu_stats_t); out[3] = (int32_t)sizeof(bwagpu_index_desc_t);
+	out[4] = (int32_t)sizeof(bwagpu_cigar_t); out[5] = (int32_t)sizeof(bwagpu_matesw_t); out[6] = (int32_t)sizeof(bwagpu_bseq1_t); out[7] = (int32_t)sizeof(bwagpu_built_t);
+}
 
 extern "C" const char *bwagpu_strerror(int code)
 {
@@ -324,6 +336,46 @@ extern "C" int bwagpu_clone(bwagpu_t *src, bwagpu_t **out)
 	return BWAGPU_OK;
 }
 
+// A handle on ANOTHER device of the node holding a copy of src's resident index: the three index buffers, the
+// (possibly densified) SA, the contig table and the prefix tables travel device to device with hipMemcpyPeer -- point to point
+// over xGMI, the single-process counterpart of the RCCL broadcast that bwa_amd/dist.py does between processes.  The new handle
+// owns its copy; bwagpu_clone() on it gives further streams on that device.
+extern "C" int bwagpu_clone_to_device(bwagpu_t *src, int device, bwagpu_t **out)
+{
+	if (!src || !out) return BWAGPU_EINVAL;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return BWAGPU_ENODEV;
+	if (device == src->device) return bwagpu_clone(src, out);
+	if (hipSetDevice(device) != hipSuccess) return BWAGPU_ENODEV;
+	bwagpu_t *h = new bwagpu_s();
+	h->device = device;
+	h->ibuf = new bwagpu_s::IndexBufs();
+	if (hipStreamCreate(&h->stream) != hipSuccess) { h->stream = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
+	for (int i = 0; i < 8; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { h->ev[i] = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
+	if (hipEventCreateWithFlags(&h->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) h->ev_wait = nullptr;
+	struct { DevBuf *dst; const DevBuf *from; size_t bytes; } parts[] = {
+		{ &h->ibuf->d_bwt, &src->ibuf->d_bwt, (size_t)src->bwt_bytes }, { &h->ibuf->d_sa, &src->ibuf->d_sa, (size_t)src->sa_bytes },
+		{ &h->ibuf->d_pac, &src->ibuf->d_pac, (size_t)src->pac_bytes }, { &h->ibuf->d_ctg_off, &src->ibuf->d_ctg_off, (size_t)src->n_seqs * 8 },
+		{ &h->ibuf->d_ctg_len, &src->ibuf->d_ctg_len, (size_t)src->n_seqs * 4 }, { &h->ibuf->d_ctg_alt, &src->ibuf->d_ctg_alt, (size_t)src->n_seqs * 4 },
+		{ &h->ibuf->d_ptab, &src->ibuf->d_ptab, src->ix.ptab ? ((size_t)1 << (2 * src->ix.ptab_m)) * src->ix.ptab_m * sizeof(uint4) : 0 } };
+	for (auto &pt : parts) {
+		if (pt.bytes == 0) continue;
+		if (pt.dst->ensure(pt.bytes)) { h->err = "hipMalloc failed (index copy)"; bwagpu_destroy(h); return BWAGPU_ENOMEM; }
+		if (hipMemcpyPeer(pt.dst->p, device, pt.from->p, src->device, pt.bytes) != hipSuccess) { bwagpu_destroy(h); return BWAGPU_EHIP; }
+	}
+	h->ix = src->ix;
+	h->ix.bwt = h->ibuf->d_bwt.as<uint4>(); h->ix.sa = h->ibuf->d_sa.as<u64>(); h->ix.pac = h->ibuf->d_pac.as<u8>();
+	h->ix.ctg_off = h->ibuf->d_ctg_off.as<i64>(); h->ix.ctg_len = h->ibuf->d_ctg_len.as<i32>(); h->ix.ctg_alt = h->ibuf->d_ctg_alt.as<i32>();
+	h->ix.ptab = src->ix.ptab ? h->ibuf->d_ptab.as<uint4>() : nullptr;
+	h->l_pac = src->l_pac; h->n_seqs = src->n_seqs; h->seq_len = src->seq_len; h->sa_intv = src->sa_intv;
+	h->bwt_blocks = src->bwt_blocks; h->bwt_bytes = src->bwt_bytes; h->sa_bytes = src->sa_bytes; h->pac_bytes = src->pac_bytes;
+	h->bwt_size = src->bwt_size; h->n_sa = src->n_sa;
+	h->h_ctg_off = src->h_ctg_off; h->h_ctg_len = src->h_ctg_len; h->h_ctg_alt = src->h_ctg_alt;
+	h->stats_on = src->stats_on; h->taps_on = src->taps_on;
+	*out = h;
+	return BWAGPU_OK;
+}
+
 extern "C" int bwagpu_index_buffers(bwagpu_t *h, void **bwt, uint64_t *bwt_bytes, void **sa, uint64_t *sa_bytes, void **pac, uint64_t *pac_bytes)
 {
 	if (!h || !bwt || !bwt_bytes || !sa || !sa_bytes || !pac || !pac_bytes) return BWAGPU_EINVAL;
@@ -439,12 +491,19 @@ extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, cons
 	}
 	// first guess of the arena sizes (grown on overflow)
 	i64 nb = h->n_bases > 1024 ? h->n_bases : 1024;
-	h->slot_cap = nb / 4 + 4096;
+	h->slot_cap = nb / 3 + 4096;     // (a 3.1 Gbp repeat-rich genome needs ~0.26 slots and ~0.15 region records per base)
 	h->node_cap = h->slot_cap / 4 + 2 * (i64)n + 64;
-	h->reg_cap = nb / 6 + 4096;
+	h->reg_cap = nb / 5 + 4096;
 	// capacity of one read's interval list: reads keep ~10-30 intervals whatever their length class; grown x4 on overflow
 	h->mem_cap = h->max_len / 3 < 64 ? 64 : h->max_len / 3;
-	// what earlier batches turned out to need (after overflow re-runs) carries over: a re-run doubles a batch's device time
+	// what earlier batches -- of this handle or of another handle on the same index -- turned out to need carries over
+	{
+		std::lock_guard<std::mutex> l(h->ibuf->m);
+		if (h->ibuf->need_slot > h->need_slot) h->need_slot = h->ibuf->need_slot;
+		if (h->ibuf->need_node > h->need_node) h->need_node = h->ibuf->need_node;
+		if (h->ibuf->need_reg > h->need_reg) h->need_reg = h->ibuf->need_reg;
+		if (h->ibuf->need_mem > h->need_mem) h->need_mem = h->ibuf->need_mem;
+	}
 	if ((i64)(h->need_slot * nb) > h->slot_cap) h->slot_cap = (i64)(h->need_slot * nb);
 	if ((i64)(h->need_node * nb) > h->node_cap) h->node_cap = (i64)(h->need_node * nb);
 	if ((i64)(h->need_reg * nb) > h->reg_cap) h->reg_cap = (i64)(h->need_reg * nb);
@@ -593,9 +652,14 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		HIPCHK(h, hipMemcpyAsync(&c, h->d_ctr.p, sizeof c, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(h, wait_stream(h));
 		if (c.overflow) {   // grow what overflowed and redo the batch; nothing of the failed attempt is kept
-			if (c.overflow & 2) h->slot_cap = h->slot_cap * 2;
-			if (c.overflow & 6) h->node_cap = h->slot_cap / 4 + 2 * (i64)n + 64 > h->node_cap * 2 ? h->slot_cap / 4 + 2 * (i64)n + 64 : h->node_cap * 2;
-			if (c.overflow & 8) h->reg_cap = h->reg_cap * 2;
+			// the bump counters kept counting past the arenas' ends: grow to what was asked for (+10 %) in one step rather than by doubling
+			if (c.overflow & 2) { const i64 want = (i64)(c.seed_used + c.seed_used / 10) + 4096; h->slot_cap = want > h->slot_cap * 5 / 4 ? want : h->slot_cap * 2; }
+			if (c.overflow & 6) {
+				i64 want = h->slot_cap / 4 + 2 * (i64)n + 64; const i64 asked = (i64)(c.node_used + c.node_used / 10) + 64;
+				if (asked > want) want = asked;
+				h->node_cap = want > h->node_cap * 5 / 4 ? want : h->node_cap * 2;
+			}
+			if (c.overflow & 8) { const i64 want = (i64)(c.reg_used + c.reg_used / 10) + 4096; h->reg_cap = (c.overflow & 2) || want <= h->reg_cap * 5 / 4 ? h->reg_cap * 2 : want; }
 			if (c.overflow & 16) h->mem_cap = h->mem_cap * 4;
 			++h->stats.n_retries;
 			continue;
@@ -606,6 +670,11 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			if (h->node_cap / nbd > h->need_node) h->need_node = h->node_cap / nbd;
 			if (h->reg_cap / nbd > h->need_reg) h->need_reg = h->reg_cap / nbd;
 			if (h->mem_cap > h->need_mem && !getenv("BWAGPU_MEM_CAP")) h->need_mem = h->mem_cap;
+			std::lock_guard<std::mutex> l(h->ibuf->m);
+			if (h->need_slot > h->ibuf->need_slot) h->ibuf->need_slot = h->need_slot;
+			if (h->need_node > h->ibuf->need_node) h->ibuf->need_node = h->need_node;
+			if (h->need_reg > h->ibuf->need_reg) h->ibuf->need_reg = h->need_reg;
+			if (h->need_mem > h->ibuf->need_mem) h->ibuf->need_mem = h->need_mem;
 		}
 		float ms[6];
 		for (int i = 0; i < 6; ++i) HIPCHK(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
@@ -618,7 +687,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		h->stats.n_chains = (i64)c.n_chains; h->stats.n_regs_raw = (i64)c.n_regs_raw; h->stats.n_regs = (i64)c.n_regs;
 		h->stats.n_tab_lookups = (i64)c.tab_lookups; h->stats.n_bt_nodes = (i64)c.bt_nodes; h->stats.n_chain_recs = (i64)c.chain_recs; h->stats.n_chain_deferred = (i64)c.n_chain_todo; h->stats.n_chain_deferred2 = (i64)c.n_chain_todo2;
 		h->stats.n_occ_blocks = (i64)c.occ_blocks; h->stats.n_lf_steps = (i64)c.lf_steps;
-		h->stats.n_ext_calls = (i64)c.ext_calls; h->stats.n_ext_cells = (i64)c.ext_cells;
+		h->stats.n_ext_calls = (i64)c.ext_calls; h->stats.n_ext_cells = (i64)c.ext_cells; h->stats.n_ext_fast = (i64)c.ext_fast;
 		h->stats.n_glb_calls = (i64)c.glb_calls; h->stats.n_glb_cells = (i64)c.glb_cells; h->stats.ref_bases = (i64)c.ref_bases;
 		h->stats.n_sw_calls = (i64)c.sw_calls; h->stats.n_sw_cells = (i64)c.sw_cells;
 		h->ran = true;

@@ -82,6 +82,7 @@ struct Counters {          // device-side bump allocators + flags
 	unsigned long long n_intv, n_chains, n_regs_raw, n_regs;
 	unsigned long long occ_blocks, lf_steps, ext_calls, ext_cells, glb_calls, glb_cells, ref_bases, sw_calls, sw_cells, tab_lookups;
 	unsigned long long prof[16];                   // cycle counters of a -DBWAGPU_PROFILE build (bwagpu_debug_prof), zero otherwise
+	unsigned long long ext_fast;                   // ksw_extend2 calls answered by the diagonal rule (no DP)
 	unsigned long long bt_nodes, chain_recs;       // B-tree nodes visited by look-ups / chain records touched (k_chain's algorithmic bytes)
 };
 #define seed_used seed_used_.v

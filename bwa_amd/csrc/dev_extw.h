@@ -96,7 +96,7 @@ DEVFN bwagpu_seed_t uni_seed(bwagpu_seed_t s) { s.rbeg = uni64(s.rbeg); s.qbeg =
 struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t *mat; };
 
 template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, int mat_max, const u8 *q, int q0, const int qdir, int qlen,
-								   i64 t0, const int tdir, int tlen, int w, int end_bonus, int h0, const WaveLds &L, u64 &cells)
+								   i64 t0, const int tdir, int tlen, int w, int end_bonus, int h0, const WaveLds &L, u64 &cells, u64 &fast)
 {
 	const int lane = threadIdx.x & 63;
 	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
@@ -104,6 +104,48 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 	int2 *eh = L.eh; int8_t *qp = L.qp; const int qs = L.qstride;
 	// every argument is wave-uniform: keep it in SGPRs so that the row loop's control flow and address arithmetic are scalar
 	q0 = uni(q0); qlen = uni(qlen); tlen = uni(tlen); w = uni(w); h0 = uni(h0); end_bonus = uni(end_bonus); t0 = uni64(t0);
+	// ---- the extension that stays on the diagonal needs no DP ------------------------------------------------------------
+	// Let P be the score the first qlen diagonal cells lose against an all-match diagonal (mismatches, Ns).  Any cell (i,j) off
+	// the diagonal lies on a path with a gap, hence H(i,j) <= h0 + mat_max * (min(i,j)+1) - (o + e*|i-j|), while the diagonal
+	// cell of the same row has H(i,i) >= h0 + mat_max * (i+1) - P.  With P < o_del+e_del and P < o_ins+e_ins every diagonal
+	// cell is therefore the strict maximum of its row and equals h0 + its prefix sum of scores (E and F, which come out of
+	// gaps, cannot reach it; it stays positive, so the band's zero-trimming never cuts it off).  Everything ksw_extend2 returns
+	// then follows from the prefix sums V_i: score = max(h0, max V_i) at the first i that attains it (strict update, ksw.c:491),
+	// qle = tle = that i + 1, max_off = 0; rows beyond the diagonal's end only hold gapped cells, all below it, so the
+	// to-end score is gscore = V_{qlen-1} at gtle = qlen (ksw.c:486-489), and neither m == 0 nor the z-drop test (which
+	// would need max - m > zdrop > P) ends the loop before that row.  Needs tlen >= qlen.  At 1 % substitutions this covers
+	// most extensions of a read's true locus: a couple of wave steps instead of ~60 rows.
+	if (tlen >= qlen && qlen > 0) {
+		const int oe_min = oe_del < oe_ins ? oe_del : oe_ins;
+		int P = 0;
+		for (int b = 0; b < qlen && P < oe_min; b += 64) {
+			const int j = b + lane;
+			int loss = 0;
+			if (j < qlen) loss = mat_max - (int)opt.mat[ref_base(ix, t0 + (i64)j * tdir) * 5 + q[q0 + j * qdir]];
+			for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o);
+			P += loss;
+		}
+		if (P < oe_min && (zdrop <= 0 || P < zdrop) && h0 > P) {
+			int best = h0, best_i = -1, run = h0;
+			for (int b = 0; b < qlen; b += 64) {
+				const int j = b + lane;
+				int sc = 0;
+				if (j < qlen) sc = (int)opt.mat[ref_base(ix, t0 + (i64)j * tdir) * 5 + q[q0 + j * qdir]];
+				int inc = sc;                                  // inclusive prefix sum over the wave
+				for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+				const int v = run + inc;
+				// first lane of this chunk whose value exceeds everything before it: maximum of (v << 6 | 63 - lane)
+				const int key = wave_incl_scan_max(j < qlen ? (v << 6 | (63 - lane)) : I32_MIN);
+				const int kmax = __builtin_amdgcn_readlane(key, 63);
+				if ((kmax >> 6) > best) { best = kmax >> 6; best_i = b + 63 - (kmax & 63); }
+				const int nact = qlen - b < 64 ? qlen - b : 64;
+				run = __builtin_amdgcn_readlane(v, nact - 1);
+			}
+			ExtRes r; r.score = best; r.qle = best_i + 1; r.tle = best_i + 1; r.gtle = qlen; r.gscore = run; r.max_off = 0;
+			++fast;
+			return r;
+		}
+	}
 	// query profile (ksw.c:425-428) and first row (ksw.c:430-433: H(-1,-1) = h0, then an insertion ramp)
 	#define EHI(j) (RING ? ((j) & L.ring_mask) : (j))
 	const int v1 = h0 > oe_ins ? h0 - oe_ins : 0;
@@ -120,6 +162,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 	int lim = (int)((double)(qlen * mat_max + end_bonus - o_ins) / e_ins + 1.); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	lim = (int)((double)(qlen * mat_max + end_bonus - o_del) / e_del + 1.); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	int beg = 0, end = qlen, max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, treg = 0;
+	u32 cells32 = 0;
 	for (int i = 0; i < tlen; ++i) {
 		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
 		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
@@ -142,45 +185,72 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		int h1_init = 0;
 		if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
 		int m = 0, mj = -1, carry = W_NEG, hprev = h1_init, first_nz = -1, last_nz = -1, bnd = 0;
-		cells += (u64)(end > beg ? end - beg : 0);
-		for (int b = beg; b < end; b += 64) {
-			const int j = b + lane; const bool act = j < end;
-			// the LDS region is padded by 64 columns, so inactive lanes may read (never write) past `end`
-			int2 old = eh[EHI(j)];
-			int sc;
-			if (RING) { const int qc = j < qlen ? (int)q[q0 + j * qdir] : 4; sc = L.mat[tb * 5 + qc]; }
-			else sc = qrow[j];
-			const int bnd_next = eh[EHI(b + 64)].x;             // next pass's diagonal for its lane 0, before lane 63 overwrites it
-			if (b != beg && lane == 0) old.x = bnd;
+		cells32 += (u32)(end > beg ? end - beg : 0);
+		if (!RING && end - beg <= 64) {
+			// The band fits one pass of the wave (always, for 150 bp reads): the same arithmetic without the pass loop and its carries
+			// -- the kernel is bound by scalar instructions (one scalar unit per CU), and the loop's control was half of them.
+			const int nact = end - beg;
+			const int j = beg + lane; const bool act = lane < nact;
+			const int2 old = eh[j];                           // (the LDS region is padded by 64 columns)
+			const int sc = qrow[j];
 			wave_sync();
 			const int M = old.x ? old.x + sc : 0;          // ksw.c:469: a dead diagonal cell stays dead
 			const int a = act ? imax(M - oe_ins, 0) + j * e_ins : W_NEG;
 			const int inc = wave_incl_scan_max(a);
-			const int exc = imax(wave_shift_up1(inc, W_NEG), carry);
-			const int f = j == beg ? 0 : exc - (j - 1) * e_ins;       // F(i,j): best insertion ending left of column j
+			const int exc = wave_shift_up1(inc, W_NEG);
+			const int f = lane == 0 ? 0 : exc - (j - 1) * e_ins;       // F(i,j): best insertion ending left of column j
 			const int h = imax(imax(M, old.y), f);                    // H(i,j) = max(M, E, F), ksw.c:470-471
 			const int e_new = imax(imax(old.y - e_del, M - oe_del), 0); // E(i+1,j), ksw.c:475-479
-			if (act) {
-				eh[EHI(j)].y = e_new;
-				eh[EHI(j + 1)].x = h;                                  // becomes the diagonal of column j+1 in row i+1
-			}
-			if (j == beg) eh[EHI(j)].x = h1_init;
-			const int hleft = wave_shift_up1(h, hprev);               // eh[j].h after this row = H(i,j-1)
+			if (act) { eh[j].y = e_new; eh[j + 1].x = h; }            // H(i,j) becomes the diagonal of column j+1 in row i+1; the last lane's is eh[end].h = h1 (ksw.c:485)
+			if (lane == 0) eh[beg].x = h1_init;
+			if (lane == (nact ? nact - 1 : 0)) eh[end].y = 0;
+			const int hleft = wave_shift_up1(h, h1_init);             // eh[j].h after this row = H(i,j-1)
 			const u64 nzm = __ballot(act && (hleft | e_new) != 0);
-			if (nzm) { if (first_nz < 0) first_nz = b + __ffsll((unsigned long long)nzm) - 1; last_nz = b + 63 - __clzll((long long)nzm); }
-			// row maximum with "last column wins ties" (ksw.c:473-474): one scan over (h << 6 | lane)
-			const int key = __builtin_amdgcn_readlane(wave_incl_scan_max(act ? (h << 6 | lane) : -1), 63);
-			if ((key >> 6) >= m) { m = key >> 6; mj = b + (key & 63); }
-			carry = imax(carry, __builtin_amdgcn_readlane(inc, 63));
-			const int nact = end - b < 64 ? end - b : 64;
-			hprev = __builtin_amdgcn_readlane(h, nact - 1);
-			bnd = bnd_next;
+			if (nzm) { first_nz = beg + __builtin_ctzll(nzm); last_nz = beg + 63 - __builtin_clzll(nzm); }
+			const int key = __builtin_amdgcn_readlane(wave_incl_scan_max(act ? (h << 6 | lane) : -1), 63);   // last column wins ties (ksw.c:473-474)
+			if (key >= 0) { m = key >> 6; mj = beg + (key & 63); }
+			if (nact) hprev = __builtin_amdgcn_readlane(h, nact - 1);
+			wave_sync();
+		} else {
+			for (int b = beg; b < end; b += 64) {
+				const int j = b + lane; const bool act = j < end;
+				// the LDS region is padded by 64 columns, so inactive lanes may read (never write) past `end`
+				int2 old = eh[EHI(j)];
+				int sc;
+				if (RING) { const int qc = j < qlen ? (int)q[q0 + j * qdir] : 4; sc = L.mat[tb * 5 + qc]; }
+				else sc = qrow[j];
+				const int bnd_next = eh[EHI(b + 64)].x;             // next pass's diagonal for its lane 0, before lane 63 overwrites it
+				if (b != beg && lane == 0) old.x = bnd;
+				wave_sync();
+				const int M = old.x ? old.x + sc : 0;          // ksw.c:469: a dead diagonal cell stays dead
+				const int a = act ? imax(M - oe_ins, 0) + j * e_ins : W_NEG;
+				const int inc = wave_incl_scan_max(a);
+				const int exc = imax(wave_shift_up1(inc, W_NEG), carry);
+				const int f = j == beg ? 0 : exc - (j - 1) * e_ins;       // F(i,j): best insertion ending left of column j
+				const int h = imax(imax(M, old.y), f);                    // H(i,j) = max(M, E, F), ksw.c:470-471
+				const int e_new = imax(imax(old.y - e_del, M - oe_del), 0); // E(i+1,j), ksw.c:475-479
+				if (act) {
+					eh[EHI(j)].y = e_new;
+					eh[EHI(j + 1)].x = h;                                  // becomes the diagonal of column j+1 in row i+1
+				}
+				if (j == beg) eh[EHI(j)].x = h1_init;
+				const int hleft = wave_shift_up1(h, hprev);               // eh[j].h after this row = H(i,j-1)
+				const u64 nzm = __ballot(act && (hleft | e_new) != 0);
+				if (nzm) { if (first_nz < 0) first_nz = b + __ffsll((unsigned long long)nzm) - 1; last_nz = b + 63 - __clzll((long long)nzm); }
+				// row maximum with "last column wins ties" (ksw.c:473-474): one scan over (h << 6 | lane)
+				const int key = __builtin_amdgcn_readlane(wave_incl_scan_max(act ? (h << 6 | lane) : -1), 63);
+				if ((key >> 6) >= m) { m = key >> 6; mj = b + (key & 63); }
+				carry = imax(carry, __builtin_amdgcn_readlane(inc, 63));
+				const int nact = end - b < 64 ? end - b : 64;
+				hprev = __builtin_amdgcn_readlane(h, nact - 1);
+				bnd = bnd_next;
+				wave_sync();
+			}
+			if (lane == 0) { eh[EHI(end)].x = beg < end ? hprev : h1_init; eh[EHI(end)].y = 0; }
 			wave_sync();
 		}
 		const int h1 = beg < end ? hprev : h1_init;      // H(i, end-1) as left in h1 by the reference's column loop
 		const int jfin = beg < end ? end : beg;
-		if (lane == 0) { eh[EHI(end)].x = h1; eh[EHI(end)].y = 0; }
-		wave_sync();
 		if (jfin == qlen) { if (h1 >= gscore) max_ie = i; if (h1 > gscore) gscore = h1; }
 		if (m == 0) break;
 		if (m > max) {
@@ -199,13 +269,14 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		end = jl + 2 < qlen ? jl + 2 : qlen;
 	}
 	#undef EHI
+	cells += cells32;
 	ExtRes r; r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
 	return r;
 }
 
 // mem_chain2aln for all chains of one read, executed by one wavefront.
 template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const WaveLds &L,
-							  u64 &n_calls, u64 &n_cells, u64 &n_refb)
+							  u64 &n_calls, u64 &n_cells, u64 &n_refb, u64 &n_fast)
 {
 	const int lane = threadIdx.x & 63;
 	r = uni(r);
@@ -309,7 +380,7 @@ template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwa
 				for (int i = 0; i < 2; ++i) {
 					int prev = a.score;
 					aw0 = opt.w << i;
-					x = wave_ksw_extend2<RING>(ix, opt, mat_max, query, s.qbeg - 1, -1, s.qbeg, s.rbeg - 1, -1, tl, aw0, opt.pen_clip5, s.len * opt.a, L, n_cells);
+					x = wave_ksw_extend2<RING>(ix, opt, mat_max, query, s.qbeg - 1, -1, s.qbeg, s.rbeg - 1, -1, tl, aw0, opt.pen_clip5, s.len * opt.a, L, n_cells, n_fast);
 					++n_calls;
 					a.score = x.score;
 					if (a.score == prev || x.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
@@ -324,7 +395,7 @@ template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwa
 				for (int i = 0; i < 2; ++i) {
 					int prev = a.score;
 					aw1 = opt.w << i;
-					x = wave_ksw_extend2<RING>(ix, opt, mat_max, query, qe, 1, l_query - qe, re, 1, (int)(rmax1 - re), aw1, opt.pen_clip3, sc0, L, n_cells);
+					x = wave_ksw_extend2<RING>(ix, opt, mat_max, query, qe, 1, l_query - qe, re, 1, (int)(rmax1 - re), aw1, opt.pen_clip3, sc0, L, n_cells, n_fast);
 					++n_calls;
 					a.score = x.score;
 					if (a.score == prev || x.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
@@ -369,20 +440,21 @@ template <bool RING> __global__ void __launch_bounds__(256) k_extend_wave(DevInd
 		L.qp = (int8_t*)(base + (size_t)8 * (B.max_len + 2 + 64));
 		L.mat = nullptr; L.ring_mask = 0;
 	}
-	u64 calls = 0, cells = 0, refb = 0, nraw = 0;
+	u64 calls = 0, cells = 0, refb = 0, nraw = 0, fast = 0;
 	// Reads are handed out heaviest first from a global counter: a wave that drew light reads simply draws more of them, and
 	// the launch needs no particular relation between its grid and the number of resident workgroups.
 	for (;;) {
 		const long long k = wave_fetch(&B.ctr->next_ext);
 		if (k >= B.n_reads) break;
 		const int r = B.order[k];
-		ext_read_wave<RING>(ix, opt, B, r, L, calls, cells, refb);
+		ext_read_wave<RING>(ix, opt, B, r, L, calls, cells, refb, fast);
 		wave_sync();
 		nraw += B.reg_n_raw[r];
 	}
 	if (B.stats && lane == 0) {
 		atomicAdd(&B.ctr->ext_calls, (unsigned long long)calls);
 		atomicAdd(&B.ctr->ext_cells, (unsigned long long)cells);
+		atomicAdd(&B.ctr->ext_fast, (unsigned long long)fast);
 		atomicAdd(&B.ctr->ref_bases, (unsigned long long)refb);
 		atomicAdd(&B.ctr->n_regs_raw, (unsigned long long)nraw);
 	}

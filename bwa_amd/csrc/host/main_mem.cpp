@@ -19,6 +19,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <functional>
 #include <vector>
 #include "bwamem_host.h"
 
@@ -232,21 +233,70 @@ static void encode_sub(const Batch &in, Sub &u)
 static std::mutex g_dev_mutex;
 static bool g_dev_serialize = false;   // BWAGPU_CLI_SERIALIZE=1: one device call at a time (the mock HIP runtime of the CPU tests is not thread-safe)
 
-static void device_sub(bwagpu_t *gpu, Sub &u, const RefSeqs &ref, const Pestat *pes0)
+static void device_fail(bwagpu_t *gpu, int rc) { fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu)); exit(EXIT_FAILURE); }
+
+// One mem_process_seqs call's device work on the GPUs of `gpus` (one handle per device).  With several devices
+// the reads are split into contiguous ranges of whole pairs, every device runs the hot path -- and the device-side CIGARs and
+// mate-rescue alignments -- on its range, and the results are concatenated in read order.  The one step that needs the whole
+// batch, mem_pestat (bwamem.c:1258), runs on the host over the gathered regions between the two device phases, so the SAM is the
+// single-device SAM whatever the number of devices.
+static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs &ref, const Pestat *pes0)
 {
 	std::unique_lock<std::mutex> serial(g_dev_mutex, std::defer_lock);
 	if (g_dev_serialize) serial.lock();
 	const double t0 = now_s();
-	int rc = bwagpu_align_flat(gpu, &u.opt, (int)u.idx.size(), u.flat.data(), u.off.data(), u.counts.data(), &u.all, &u.tot);
-	if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu)); exit(EXIT_FAILURE); }
-	if (getenv("BWAGPU_CLI_TRACE")) fprintf(stderr, "[D::device_sub] %d reads -> %ld regions (flag 0x%x)\n", (int)u.idx.size(), (long)u.tot, u.opt.flag);
-	if (g_device_cigars && u.tot > 0) {       // the DP of mem_reg2aln on the device as well; the host keeps NM/MD and the text
-		int64_t nc = 0;
-		rc = bwagpu_batch_cigars(gpu, &u.opt, &u.cigs, &nc);
-		if (rc != BWAGPU_OK || nc != u.tot) { fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu)); exit(EXIT_FAILURE); }
+	const bool trace = getenv("BWAGPU_CLI_TRACE") != nullptr;
+	const int n = (int)u.idx.size();
+	const bool pe = (u.opt.flag & F_PE) != 0;
+	int D = (int)gpus.size();
+	const int units = pe ? n / 2 : n, per = pe ? 2 : 1;
+	if (D > units) D = units > 0 ? units : 1;
+	struct Shard { int lo = 0, hi = 0; std::vector<int64_t> off; bwagpu_alnreg_t *all = nullptr; int64_t tot = 0; bwagpu_cigar_t *cigs = nullptr; bwagpu_matesw_t *msw = nullptr; int64_t n_msw = 0; };
+	std::vector<Shard> sh((size_t)D);
+	for (int d = 0; d < D; ++d) {
+		sh[d].lo = (int)((int64_t)units * d / D) * per; sh[d].hi = d + 1 == D ? n : (int)((int64_t)units * (d + 1) / D) * per;
+		sh[d].off.resize((size_t)(sh[d].hi - sh[d].lo) + 1);
+		for (int i = sh[d].lo; i <= sh[d].hi; ++i) sh[d].off[(size_t)(i - sh[d].lo)] = u.off[i] - u.off[sh[d].lo];
 	}
-	if (g_device_matesw && (u.opt.flag & F_PE) && !(u.opt.flag & F_NO_RESCUE) && u.tot > 0) {
-		const int n = (int)u.idx.size();
+	auto on_devices = [&](const std::function<void(int)> &f) {   // f(d) for every device, concurrently (the calls block on their streams)
+		if (D == 1 || g_dev_serialize) { for (int d = 0; d < D; ++d) f(d); return; }
+		std::vector<std::thread> th;
+		for (int d = 1; d < D; ++d) th.emplace_back(f, d);
+		f(0);
+		for (auto &t : th) t.join();
+	};
+	double t1 = t0, t2 = t0, t3 = t0, t4 = t0, t5 = t0;
+	on_devices([&](int d) {
+		Shard &s = sh[d];
+		int rc = bwagpu_batch_upload(gpus[d], s.hi - s.lo, u.flat.data() + u.off[s.lo], s.off.data());
+		if (d == 0) t1 = now_s();
+		if (rc == BWAGPU_OK) rc = bwagpu_batch_run(gpus[d], &u.opt);
+		if (d == 0) t2 = now_s();
+		if (rc == BWAGPU_OK) rc = bwagpu_batch_download(gpus[d], u.counts.data() + s.lo, &s.all, &s.tot);
+		if (rc != BWAGPU_OK) device_fail(gpus[d], rc);
+		if (g_device_cigars && s.tot > 0) {       // the DP of mem_reg2aln on the device as well; the host keeps NM/MD and the text
+			int64_t nc = 0;
+			rc = bwagpu_batch_cigars(gpus[d], &u.opt, &s.cigs, &nc);
+			if (rc != BWAGPU_OK || nc != s.tot) device_fail(gpus[d], rc);
+		}
+	});
+	t3 = t4 = now_s();
+	if (D == 1) { u.all = sh[0].all; u.tot = sh[0].tot; u.cigs = sh[0].cigs; }
+	else {   // gather in read order
+		u.tot = 0; for (auto &s : sh) u.tot += s.tot;
+		u.all = (bwagpu_alnreg_t*)malloc((size_t)(u.tot ? u.tot : 1) * sizeof(bwagpu_alnreg_t));
+		const bool have_cigs = g_device_cigars && u.tot > 0;
+		u.cigs = have_cigs ? (bwagpu_cigar_t*)malloc((size_t)u.tot * sizeof(bwagpu_cigar_t)) : nullptr;
+		if (!u.all || (have_cigs && !u.cigs)) { fprintf(stderr, "[E::%s] out of memory\n", "mem_process_seqs"); exit(EXIT_FAILURE); }
+		int64_t k = 0;
+		for (auto &s : sh) {
+			if (s.tot) memcpy(u.all + k, s.all, (size_t)s.tot * sizeof(bwagpu_alnreg_t));
+			if (have_cigs && s.tot) memcpy(u.cigs + k, s.cigs, (size_t)s.tot * sizeof(bwagpu_cigar_t));   // (a shard without regions has no records)
+			k += s.tot;
+			bwagpu_free(s.all); s.all = nullptr; bwagpu_free(s.cigs); s.cigs = nullptr;
+		}
+	}
+	if (g_device_matesw && pe && !(u.opt.flag & F_NO_RESCUE) && u.tot > 0) {
 		if (pes0) memcpy(u.pes, pes0, sizeof u.pes);
 		else {   // mem_pestat needs the whole batch's regions (bwamem.c:1258): they have just arrived
 			std::vector<int64_t> roff((size_t)n + 1, 0);
@@ -256,10 +306,27 @@ static void device_sub(bwagpu_t *gpu, Sub &u, const RefSeqs &ref, const Pestat *
 		u.have_pes = true;
 		bwagpu_pes_t dp[4];
 		for (int d = 0; d < 4; ++d) { dp[d].low = u.pes[d].low; dp[d].high = u.pes[d].high; dp[d].failed = u.pes[d].failed; dp[d].pad_ = 0; }
-		rc = bwagpu_batch_matesw(gpu, &u.opt, dp, &u.msw, &u.n_msw);
-		if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu)); exit(EXIT_FAILURE); }
+		on_devices([&](int d) {
+			if (sh[d].tot == 0) return;
+			int rc = bwagpu_batch_matesw(gpus[d], &u.opt, dp, &sh[d].msw, &sh[d].n_msw);
+			if (rc != BWAGPU_OK) device_fail(gpus[d], rc);
+		});
+		if (D == 1) { u.msw = sh[0].msw; u.n_msw = sh[0].n_msw; }
+		else {
+			u.n_msw = 0; for (auto &s : sh) u.n_msw += s.n_msw;
+			u.msw = (bwagpu_matesw_t*)malloc((size_t)(u.n_msw ? u.n_msw : 1) * sizeof(bwagpu_matesw_t));
+			if (!u.msw) { fprintf(stderr, "[E::%s] out of memory\n", "mem_process_seqs"); exit(EXIT_FAILURE); }
+			int64_t k = 0;
+			for (auto &s : sh) {
+				for (int64_t i = 0; i < s.n_msw; ++i) { u.msw[k] = s.msw[i]; u.msw[k].read += s.lo; ++k; }   // read indices are relative to the device's range
+				bwagpu_free(s.msw); s.msw = nullptr;
+			}
+		}
 	}
-	u.t_dev = now_s() - t0;
+	t5 = now_s();
+	u.t_dev = t5 - t0;
+	if (trace) fprintf(stderr, "[D::device_sub] %d reads on %d device(s) -> %ld regions (flag 0x%x): upload %.3f run %.3f download+cigars %.3f pestat+matesw %.3f s\n", n, D, (long)u.tot, u.opt.flag,
+					   t1 - t0, t2 - t1, t3 - t2, t5 - t4);
 }
 
 // stage 3: mem_pestat + kt_for(worker2) (bwamem.c:1254-1260) on the host cores
@@ -472,8 +539,22 @@ int main(int argc, char *argv[])
 	if (getenv("BWAGPU_CLI_CIGARS")) g_device_cigars = atoi(getenv("BWAGPU_CLI_CIGARS"));
 	int n_dev = getenv("BWAGPU_CLI_STREAMS") ? atoi(getenv("BWAGPU_CLI_STREAMS")) : 2;      // batches in flight on the device
 	if (n_dev < 1) n_dev = 1;
-	std::vector<bwagpu_t*> handles(1, gpu);
-	for (int i = 1; i < n_dev; ++i) { bwagpu_t *h2 = nullptr; int rc = bwagpu_clone(gpu, &h2); if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s\n", "main_mem", bwagpu_strerror(rc)); return 1; } bwagpu_set_taps(h2, 0); handles.push_back(h2); }
+	// devices: BWAGPU_DEVICES=0,1,... (default: the one of BWAGPU_DEVICE); every batch is split over all of them.  The index reaches
+	// the other devices by device-to-device copies (bwagpu_clone_to_device); handles[slot][device], one slot per batch in flight.
+	std::vector<int> dev_ids(1, device);
+	if (const char *dl = getenv("BWAGPU_DEVICES")) {
+		dev_ids.clear();
+		for (const char *q = dl; *q;) { dev_ids.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+		if (dev_ids.empty() || dev_ids[0] != device) { fprintf(stderr, "[E::%s] BWAGPU_DEVICES must start with the device the index was loaded on (%d)\n", "main_mem", device); return 1; }
+	}
+	std::vector<std::vector<bwagpu_t*>> handles((size_t)n_dev);
+	for (size_t di = 0; di < dev_ids.size(); ++di) {
+		bwagpu_t *base = gpu;
+		if (di > 0) { int rc = bwagpu_clone_to_device(gpu, dev_ids[di], &base); if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] device %d: %s\n", "main_mem", dev_ids[di], bwagpu_strerror(rc)); return 1; } bwagpu_set_taps(base, 0); }
+		handles[0].push_back(base);
+		for (int i = 1; i < n_dev; ++i) { bwagpu_t *h2 = nullptr; int rc = bwagpu_clone(base, &h2); if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s\n", "main_mem", bwagpu_strerror(rc)); return 1; } bwagpu_set_taps(h2, 0); handles[(size_t)i].push_back(h2); }
+	}
+	if (g_verbose >= 3 && dev_ids.size() > 1) fprintf(stderr, "[M::%s] index copied to %zu devices; batches are split over them\n", "main_mem", dev_ids.size());
 	Chan to_dev(2), to_out(2);
 	// text arenas and base arrays of finished batches are handed back to the reader: re-using them saves a few hundred MB of
 	// first-touch page faults per batch on the one thread that paces the pipeline
@@ -494,7 +575,7 @@ int main(int argc, char *argv[])
 			if (p != last) { last = p; idle = 0; continue; }
 			if (++idle < wd_secs * 4) continue;
 			fprintf(stderr, "[E::%s] no progress for %d s: next batch to finalize %ld, batches read %ld, done-but-waiting %zu\n", "main_mem", wd_secs, next_fin, n_works.load(), done.size());
-			for (int d = 0; d < n_dev && d < 16; ++d) fprintf(stderr, "[E::%s]   device thread %d: batch %d, library phase %d\n", "main_mem", d, dev_no[d].load(), bwagpu_debug_phase(handles[d]));
+			for (int d = 0; d < n_dev && d < 16; ++d) fprintf(stderr, "[E::%s]   device thread %d: batch %d, library phase %d\n", "main_mem", d, dev_no[d].load(), bwagpu_debug_phase(handles[d][0]));
 			_exit(3);
 		}
 	});
@@ -590,8 +671,8 @@ int main(int argc, char *argv[])
 	all_done = true; watchdog.join();
 	if (g_verbose >= 3) { const double dt = now_s() - t_start; fprintf(stderr, "[M::%s] %ld reads in %.3f sec after the index was loaded: %.0f reads/s\n", "main_mem", n_reads_total.load(), dt, dt > 0 ? n_reads_total.load() / dt : 0.);
 		fprintf(stderr, "[M::%s] stage busy time: read %.3f s, encode+device %.3f s (over %d handles), finalize %.3f s, write %.3f s\n", "main_mem", busy_read, busy_dev_us.load() * 1e-6, n_dev, busy_fin, busy_write); }
-	for (size_t i = 1; i < handles.size(); ++i) bwagpu_destroy(handles[i]);
 	fflush(stdout);
+	for (auto &slot : handles) for (bwagpu_t *hh : slot) if (hh != gpu) bwagpu_destroy(hh);
 	bwagpu_destroy(gpu);
 	return 0;
 }

@@ -180,6 +180,7 @@ typedef struct {
 	int64_t n_bt_nodes;      /* B-tree nodes (160 B) visited by chaining's look-ups (stats only)               */
 	int64_t n_chain_recs;    /* chain records (64 B) read or created by chaining (stats only)                  */
 	int64_t n_chain_deferred;/* reads whose chaining outgrew tier 0 of k_chain_wave (LDS-resident seeds, 32 chains) */
+	int64_t n_ext_fast;      /* ksw_extend2 calls answered without DP (diagonal rule, dev_extw.h)              */
 	int64_t n_chain_deferred2;/* ... and tier 1 (96 chains in LDS): chained in the read's HBM region           */
 } bwagpu_stats_t;
 
@@ -187,6 +188,9 @@ typedef struct {
  * thread while a call is in progress.  10-12 upload, 20+100*attempt run launched, 22+100*attempt run waiting, 30-39 download,
  * 40-45 cigars. */
 int bwagpu_debug_phase(const bwagpu_t *h);
+/* Diagnostics: sixteen cycle / event counters of the last batch_run (wave iterations of the seeding kernel in [13..15]; the rest
+ * only in a -DBWAGPU_PROFILE build of the library, zero otherwise). */
+int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16]);
 
 /* ---- optional widening past mem_process_seqs' first loop ---- */
 /* After bwagpu_batch_download: one bwagpu_cigar_t per downloaded region, in the same order, computed on the device.  They
@@ -245,10 +249,15 @@ int bwagpu_create_from_files(bwagpu_t **h, const char *prefix, int device);
  * driven from two host threads keep two batches in flight (the kt_pipeline of the reference overlaps I/O the same way,
  * kthread.c:119).  Clone after bwagpu_densify_sa, not before.  Each handle is destroyed separately. */
 int bwagpu_clone(bwagpu_t *src, bwagpu_t **out);
+/* A handle on another device of the node with its own copy of src's index, copied device to device over xGMI (hipMemcpyPeer): the
+ * single-process counterpart of the RCCL index broadcast between processes.  Densify the SA on src first. */
+int bwagpu_clone_to_device(bwagpu_t *src, int device, bwagpu_t **out);
 void bwagpu_destroy(bwagpu_t *h);
 const char *bwagpu_strerror(int code);
 const char *bwagpu_last_error(const bwagpu_t *h);
 const char *bwagpu_version(void);
+/* sizeof of bwagpu_opt_t, _alnreg_t, _stats_t, _index_desc_t, _cigar_t, _matesw_t, _bseq1_t, _built_t in this build of the library */
+void bwagpu_abi_sizes(int32_t out[8]);
 
 /* Index facts (for callers that loaded from files). */
 int bwagpu_index_info(const bwagpu_t *h, int64_t *l_pac, int32_t *n_seqs, uint64_t *seq_len, int *sa_intv);

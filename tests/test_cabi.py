@@ -33,7 +33,12 @@ def test_header_functions_are_exported(lib):
 def test_struct_sizes_in_header_match_python_mirrors():
     from bwa_amd.structs import MemOpt, ALNREG_DTYPE
     assert C.sizeof(MemOpt) == 168 and ALNREG_DTYPE.itemsize == 88
-    assert C.sizeof(api.Stats) == 176   # 16 x i64 + 7 x f32 + i32 + f32 (padded to 8) + i64
+    # the ctypes mirrors against what the library itself was compiled with
+    from bwa_amd.index import Built
+    L = C.CDLL(api.DEFAULT_LIB)
+    sz = (C.c_int32 * 8)()
+    L.bwagpu_abi_sizes(sz)
+    assert list(sz) == [C.sizeof(MemOpt), ALNREG_DTYPE.itemsize, C.sizeof(api.Stats), C.sizeof(api.IndexDesc), api.CIGAR_DTYPE.itemsize, api.MATESW_DTYPE.itemsize, 48, C.sizeof(Built)], list(sz)
 
 
 def test_no_cpu_fallback_without_gpu(lib):

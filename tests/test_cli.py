@@ -134,3 +134,26 @@ def test_cli_gpu(tmp_path):
     fa, g = testdata.medium_index()
     f1, f2, inter, fasta = _write_inputs(tmp_path, g, 20000, seed=402)
     _compare_all(cli, fa, f1, f2, inter, fasta)
+
+
+@pytest.mark.skipif(not refapi.have_ref(), reason="oracle/_ref not built")
+def test_cli_hostsim_two_devices(tmp_path):
+    """Multi-GPU in the product: with BWAGPU_DEVICES=0,1 every batch is split into two contiguous ranges of whole
+    pairs, each range runs on its own device (hot path, device CIGARs, mate-rescue alignments), regions are gathered on the host and
+    ONE mem_pestat covers the whole batch (bwamem.c:1258) -- the SAM must be the reference's, hence the single-device SAM, for
+    single-end, paired-end, smart-pairing and many-small-batches input.  Two devices of the mock runtime on the CPU."""
+    prefix, g = testdata.small_index()
+    f1, f2, inter, fasta = _write_inputs(tmp_path, g, 18, seed=403)
+    cli = _sim_cli()
+    env = dict(os.environ, BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1", MOCK_HIP_DEVICES="2", BWAGPU_DEVICES="0,1")
+    K = ["-K", "100000000", "-t", "4", "-v", "3"]
+    p = subprocess.run([cli, "mem"] + K + [prefix, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0 and b"index copied to 2 devices" in p.stderr, p.stderr.decode()[-800:]
+    K = ["-K", "100000000", "-t", "4"]
+    assert _run(refapi.REF_BWA, K + [prefix, f1]) == _run(cli, K + [prefix, f1], env), "single-end, 2 devices"
+    assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], env), "paired-end, 2 devices"
+    x = ["-p", "-C"]
+    assert _run(refapi.REF_BWA, K + x + [prefix, inter]) == _run(cli, K + x + [prefix, inter], env), "smart pairing, 2 devices"
+    assert _run(refapi.REF_BWA, ["-K", "3000", "-t", "2", prefix, f1, f2]) == _run(cli, ["-K", "3000", "-t", "2", prefix, f1, f2], env), "small batches, 2 devices"
+    env3 = dict(env, MOCK_HIP_DEVICES="3", BWAGPU_DEVICES="0,1,2")
+    assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], env3), "paired-end, 3 devices"
