@@ -121,7 +121,7 @@ def _compare_all(cli, fa, f1, f2, inter, fasta, env=None):
 def test_cli_hostsim(tmp_path):
     prefix, g = testdata.small_index()
     # the reference binary wants <prefix>.bwt etc.; both programs take the same prefix
-    f1, f2, inter, fasta = _write_inputs(tmp_path, g, 18, seed=401)
+    f1, f2, inter, fasta = _write_inputs(tmp_path, g, 14, seed=401)
     # the mock HIP runtime keeps its lane/block state in globals: two device threads, but one device call at a time
     _compare_all(_sim_cli(), prefix, f1, f2, inter, fasta, env=dict(os.environ, BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1"))
 
@@ -154,6 +154,6 @@ def test_cli_hostsim_two_devices(tmp_path):
     assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], env), "paired-end, 2 devices"
     x = ["-p", "-C"]
     assert _run(refapi.REF_BWA, K + x + [prefix, inter]) == _run(cli, K + x + [prefix, inter], env), "smart pairing, 2 devices"
-    assert _run(refapi.REF_BWA, ["-K", "3000", "-t", "2", prefix, f1, f2]) == _run(cli, ["-K", "3000", "-t", "2", prefix, f1, f2], env), "small batches, 2 devices"
+    assert _run(refapi.REF_BWA, ["-K", "9000", "-t", "2", prefix, f1, f2]) == _run(cli, ["-K", "9000", "-t", "2", prefix, f1, f2], env), "small batches, 2 devices"
     env3 = dict(env, MOCK_HIP_DEVICES="3", BWAGPU_DEVICES="0,1,2")
     assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], env3), "paired-end, 3 devices"

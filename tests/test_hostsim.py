@@ -222,11 +222,11 @@ def test_hostsim_wave_chaining_heavy_reads(monkeypatch, lds):
     n_chains = np.array([orc.chains(opt, r, 0)[0].shape[0] for r in cand])
     top = np.argsort(n_chains)[::-1][:30]
     n_kept = np.array([orc.chains(opt, cand[i], 1)[0].shape[0] for i in top])
-    pick = list(top[:3]) + [int(top[i]) for i in np.argsort(n_kept)[::-1][:3]]
+    pick = list(top[:2]) + [int(top[i]) for i in np.argsort(n_kept)[::-1][:2]]
     assert n_chains[pick[0]] > 200 and n_kept.max() > 100, (n_chains[top], n_kept)
     mid = [int(i) for i in np.nonzero((n_chains >= 36) & (n_chains <= 60))[0][:2]]    # more than tier 0 holds, fewer than tier 1's limit
     assert len(mid) == 2
-    reads = np.concatenate([cand[pick], cand[mid], cand[:6]])
+    reads = np.concatenate([cand[pick], cand[mid], cand[:3]])
     monkeypatch.setenv("BWAGPU_CHAIN_LDS", lds)
     s2 = BwaGpu(fa, lib_path=hostsim_build.build())
     s2.set_taps(True); s2.set_stats(True)
