@@ -15,6 +15,8 @@ def load(d, name):
             if r["Counter_Name"] != name:
                 continue
             k = r["Kernel_Name"].split("(")[0]
+            if k.startswith("void "):
+                k = k[5:]
             out.setdefault(k, []).append(float(r["Counter_Value"]))
     return out
 
@@ -30,6 +32,14 @@ def main():
         f, w = max(F[k]), max(W.get(k, [0.0]))
         res[k] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "launches_seen": len(F[k]),
                   "hbm_bytes_per_launch": (f + w) * 1024.0}
+    # the three tiers of the chaining kernel are one stage: k_chain = their sum
+    tiers = [k for k in res if k.startswith("k_chain_wave<")]
+    if tiers:
+        res["k_chain"] = {"FETCH_SIZE_KB": sum(res[k]["FETCH_SIZE_KB"] for k in tiers), "WRITE_SIZE_KB": sum(res[k]["WRITE_SIZE_KB"] for k in tiers),
+                          "launches_seen": min(res[k]["launches_seen"] for k in tiers), "hbm_bytes_per_launch": sum(res[k]["hbm_bytes_per_launch"] for k in tiers)}
+    for k in list(res):
+        if k.startswith("k_extend_wave<"):
+            res["k_extend_wave"] = res[k]
     json.dump(res, open(dst, "w"), indent=1)
     for k, v in res.items():
         if k != "_note":
