@@ -99,6 +99,21 @@ def run_reference(prefix: str, files, threads: int, out_sam: str):
     return {"reads_per_s": n / tot, "n": int(n), "wall_s": wall}
 
 
+def run_instrumented(prefix: str, files, threads: int):
+    """The counter-instrumented reference build (oracle/_ref/bwa_instr, oracle/make_instr.py): SURVEY.md 8(d)'s N_blk, N_lf, N_sa,
+    W_ref and DP cells, counted by the reference's own bwt_2occ4 / bwt_sa / mem_chain2aln / ksw_* on the same reads."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "bwa_instr")
+    if not os.path.exists(exe):
+        return None
+    p = subprocess.run([exe, "mem", "-t", str(threads), "-K", "100000000", "-v", "3", prefix] + list(files), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    m = re.search(r"\[orc_instr\] n_2occ4 (\d+) N_blk (\d+) N_sa (\d+) N_lf (\d+) W_ref (\d+) ext_calls (\d+) ext_cells (\d+) glb_cells (\d+)", p.stderr)
+    n = sum(int(x) for x in re.findall(r"Processed (\d+) reads", p.stderr))
+    if p.returncode != 0 or not m or n == 0:
+        return None
+    k = [int(x) for x in m.groups()]
+    return {"n_reads": n, "n_2occ4": k[0] / n, "N_blk": k[1] / n, "N_sa": k[2] / n, "N_lf": k[3] / n, "W_ref": k[4] / n, "ext_calls": k[5] / n, "ext_cells": k[6] / n, "glb_cells": k[7] / n}
+
+
 def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: int = 2):
     """The stand-alone `bwa-amd mem` (FASTQ in -> device hot path + device CIGARs / mate rescue -> host finalize -> SAM text)."""
     cli = os.path.join(ROOT, "bwa_amd", "bwa-amd")
@@ -327,6 +342,20 @@ def main():
                 par["pe"] = a == b and a[1] >= n_s
                 par["pe_records"] = a[1]
             out["parity"] = par
+            # B_alg per read: the reference's own counts on the paired-end sample next to what the device path does for
+            # the same result (prefix tables replace short-match steps: N_blk falls, 16-byte look-ups appear; the SA is denser: N_lf falls)
+            ins = run_instrumented(prefix, [f1, f2], threads)
+            l_seq = args.read_len
+            regs_pr = work["n_regs"] / nr
+            dev_b = (alg["k_seed"] + alg["k_sa"]) / nr + (work["ref_bases"] / 4 + work["n_bases"] + 88.0 * work["n_regs"]) / nr
+            out["b_alg_per_read"] = {"device": {"bytes": round(dev_b, 0), "N_blk": round(work["n_occ_blocks"] / nr, 1), "N_tab_16B": round(work["n_tab_lookups"] / nr, 1),
+                                                "N_lf": round(work["n_lf_steps"] / nr, 1), "N_sa": round(work["n_seeds"] / nr, 2), "W_ref": round(work["ref_bases"] / nr, 0),
+                                                "ext_cells": round(work["n_ext_cells"] / nr, 0), "sa_intv": args.dense_sa or 32}}
+            if ins:
+                ref_b = 64.0 * ins["N_blk"] + 64.0 * ins["N_lf"] + 8.0 * ins["N_sa"] + ins["W_ref"] / 4 + l_seq + 88.0 * regs_pr
+                out["b_alg_per_read"]["reference"] = {"bytes": round(ref_b, 0), **{k_: round(v_, 2) for k_, v_ in ins.items() if k_ != "n_reads"}, "sa_intv": 32,
+                                                      "how": f"oracle/_ref/bwa_instr (counters patched into a scratch copy of bwt.c/ksw.c/bwamem.c at build time) on the {ins['n_reads']}-read paired-end sample; "
+                                                             "B_alg = 64 N_blk + 64 N_lf + 8 N_sa + W_ref/4 + l_seq + 88 n_regs"}
             if not (par["se"] and par["pe"]):
                 rc_exit = 3
                 log("[bench] PARITY GATE FAILED:", par)

@@ -1,3 +1,9 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_cli.py tests/test_sam_via_reference.py -m gpu -x -q 2>&1 | tail -2
-MBP=3100 PAIRS=3000000 STREAMS=2,3 python tools/e2e_probe.py 2>&1 | grep -v "amdgpu.ids"
+for s in 2 4 6; do
+python bench.py --no-e2e --no-cpu-baseline --streams $s --steps 12 > gpurun_out/r02_bench_s$s.json 2> gpurun_out/r02_bench_s$s.err
+python - <<PY
+import json
+d=json.load(open('gpurun_out/r02_bench_s$s.json'))
+print('streams',$s, d['value'], d['ms_per_step'])
+PY
+done
