@@ -77,7 +77,7 @@ struct bwagpu_s {
 	DevBuf d_msw_tasks, d_msw_out, d_msw_pes, d_msw_scratch;
 	DevBuf d_pack_off, d_regs_packed, d_pack_read, d_cigs, d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
 	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_blob;
-	DevBuf d_order, d_bin_cnt, d_chain_todo, d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
+	DevBuf d_order, d_bin_cnt, d_chain_todo, d_seed_w, d_seed_order, d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
 	i64 slot_cap = 0, node_cap = 0, reg_cap = 0; int mem_cap = 0;
 	double need_slot = 0, need_node = 0, need_reg = 0; int need_mem = 0;   // per-base arena needs learnt from earlier batches of this handle
 	std::vector<i64> h_off;
@@ -240,7 +240,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 	}
 	DevBuf *all[] = { &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
-		&h->d_order, &h->d_bin_cnt, &h->d_chain_todo, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
+		&h->d_order, &h->d_bin_cnt, &h->d_chain_todo, &h->d_seed_w, &h->d_seed_order, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
 	for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
 	if (h->ev_wait) (void)hipEventDestroy(h->ev_wait);
@@ -533,7 +533,7 @@ static int alloc_batch(bwagpu_t *h, int n_threads)
 	bad |= h->d_dp_h.ensure((size_t)n_waves * (h->max_len + 2) * DPS * 4);
 	bad |= h->d_dp_e.ensure((size_t)n_waves * (h->max_len + 2) * DPS * 4);
 	bad |= h->d_minhsp.ensure((size_t)(h->max_len + 2) * 4);
-	bad |= h->d_order.ensure((size_t)n * 4 + 16); bad |= h->d_bin_cnt.ensure(2 * ORDER_BINS * 4); bad |= h->d_chain_todo.ensure((size_t)n * 8 + 32);
+	bad |= h->d_order.ensure((size_t)n * 4 + 16); bad |= h->d_bin_cnt.ensure(2 * ORDER_BINS * 4); bad |= h->d_chain_todo.ensure((size_t)n * 8 + 32); bad |= h->d_seed_w.ensure((size_t)n * 4 + 16); bad |= h->d_seed_order.ensure((size_t)n * 4 + 16);
 	if (bad) { h->err = "hipMalloc failed (batch arenas)"; return BWAGPU_ENOMEM; }
 	return 0;
 }
@@ -595,11 +595,21 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.regs_raw = h->taps_on ? h->d_regs_raw.as<bwagpu_alnreg_t>() : nullptr;
 		B.dp_h = h->d_dp_h.as<i32>(); B.dp_e = h->d_dp_e.as<i32>(); B.dp_waves = (n_threads + 63) / 64;
 		B.seedsw_minhsp = h->d_minhsp.as<i32>();
-		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>(); B.chain_todo = h->d_chain_todo.as<i32>(); B.chain_todo2 = B.chain_todo + n + 4;
+		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>(); B.chain_todo = h->d_chain_todo.as<i32>(); B.chain_todo2 = B.chain_todo + n + 4; B.seed_w = h->d_seed_w.as<i32>(); B.seed_order = nullptr;
+		B.seed_prio = !(getenv("BWAGPU_SEED_PRIO") && atoi(getenv("BWAGPU_SEED_PRIO")) == 0);
+		B.seed_pass3_inline = getenv("BWAGPU_SEED_PASS3_INLINE") && atoi(getenv("BWAGPU_SEED_PASS3_INLINE")) != 0;
 		B.chain_stop = getenv("BWAGPU_CHAIN_STOP") ? atoi(getenv("BWAGPU_CHAIN_STOP")) : 0;
 		B.chain_lds_off = getenv("BWAGPU_CHAIN_LDS") && atoi(getenv("BWAGPU_CHAIN_LDS")) == 0;
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
 		HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+		if (!B.seed_pass3_inline) {   // pass 3 first (cheap), then passes 1-2 on the reads ordered by the repetitiveness it measured
+			hipLaunchKernelGGL(k_seed3, grid, block, 0, h->stream, h->ix, *opt, B);
+			if (!getenv("BWAGPU_SEED_INPUT_ORDER")) {
+				i32 *keep = B.order; B.order = h->d_seed_order.as<i32>();
+				if (int rc2 = order_reads(h, B, B.seed_w)) return rc2;
+				B.seed_order = B.order; B.order = keep;
+			}
+		}
 		hipLaunchKernelGGL(k_seed, grid, block, (size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * BLOCK * sizeof(uint4), h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
 		hipLaunchKernelGGL(k_publish, grid, block, 0, h->stream, *opt, B);

@@ -70,7 +70,7 @@ struct ChainRec {
 struct alignas(128) HotCounter { unsigned long long v; unsigned long long pad_[15]; };
 struct Counters {          // device-side bump allocators + flags
 	HotCounter seed_used_, node_used_, reg_used_;
-	HotCounter next_read_;   // work counter of the seeding kernel
+	HotCounter next_read_, next_read3_;   // work counters of the seeding kernels (passes 1-2, pass 3)
 	HotCounter next_ext_;    // work counter of the wave extension kernel (position in Batch::order)
 	HotCounter next_seedsw_; // work counter of the wave-per-read seed re-scoring kernel (long reads)
 	HotCounter next_chain_, next_dedup_;       // work counters of the chaining and de-duplication kernels
@@ -89,6 +89,7 @@ struct Counters {          // device-side bump allocators + flags
 #define node_used node_used_.v
 #define reg_used reg_used_.v
 #define next_read next_read_.v
+#define next_read3 next_read3_.v
 #define next_ext next_ext_.v
 #define next_seedsw next_seedsw_.v
 #define next_chain next_chain_.v
@@ -131,6 +132,8 @@ struct Batch {
 	int seed_lds_ent;          // stack entries per lane kept in LDS (0 when seq_len >= 2^37 or max_len >= 2^16: the packing would not fit)
 	int mem_cap;               // capacity of one read's interval list
 	// --- seeding results
+	i32 *seed_w;               // per read: repetitiveness weight left by k_seed3 (sum of seed-length match occurrences)
+	const i32 *seed_order;     // processing order of k_seed (heaviest first by seed_w), or null: input order
 	i32 *intv_n;               // per read
 	i64 *intv_off;             // per read, into intv[]
 	Intv3 *intv;               // [n_reads][mem_cap]: read r's SA intervals at intv + r * mem_cap (intv_off[r] = r * mem_cap)
@@ -148,6 +151,8 @@ struct Batch {
 	u8 *slot_blob;
 	i32 *chain_n;              // per read: chains after filtering
 	i32 *chain_todo, *chain_todo2; // reads deferred by tier 0 / tier 1 of k_chain_wave to the next tier
+	int seed_prio;             // waves holding the heaviest 3 % of k_seed's reads run at raised issue priority (BWAGPU_SEED_PRIO=0 turns it off)
+	int seed_pass3_inline;     // A/B switch (BWAGPU_SEED_PASS3_INLINE=1): pass 3 inside k_seed's state machine as in round 1, instead of k_seed3
 	int chain_stop;            // diagnostics (BWAGPU_CHAIN_STOP=k): k_chain_wave returns after phase k of every read (timing only, results invalid)
 	int chain_lds_off;         // test hook (BWAGPU_CHAIN_LDS=0): the LDS tiers defer every read
 	// --- B-tree nodes

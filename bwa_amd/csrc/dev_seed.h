@@ -34,7 +34,7 @@ struct IntvInfoLess { DEVFN bool operator()(const Intv3 &a, const Intv3 &b) cons
 enum { SS_FETCH = 0, SS_PASS1, SS_PASS2, SS_PASS3, SS_FWD, SS_BWD, SS_STRAT, SS_FINAL, SS_DONE };
 
 struct SeedLane {
-	int st, r, len, x, k2, old_n, pass;
+	int st, r, len, x, k2, old_n, pass, n3;
 	u64 qoff, win;            // the read's offset in the packed base array; the 16-base window last fetched from it
 	u32 win_w;                // index of that window (~0u: none)
 	// current SMEM search (bwt_smem1a, bwt.c:289-351)
@@ -262,16 +262,23 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 					const int first = __ffsll((unsigned long long)__ballot(1)) - 1;        // lane 0 may already have left the loop
 					const unsigned long long old = atomicAdd(&B.ctr->next_read, (threadIdx.x & 63) == first ? 64ull : 0ull);
 					pool_base = __shfl((int)old, first); pool_cnt = 64;
+					// the waves holding the (predicted) heaviest reads get issue priority: a lane's long chain of dependent extensions then
+					// advances at the pace of the wave alone on its SIMD instead of a quarter of it
+					if (B.seed_order && B.seed_prio) { if (pool_base < B.n_reads / 32) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
 				}
 				const int rank = __popcll(wm & ((1ull << (threadIdx.x & 63)) - 1));
 				if (want && rank < pool_cnt) {
-					const int r = pool_base + rank;
-					if (r >= B.n_reads) L.st = SS_DONE;
+					const int idx = pool_base + rank;
+					if (idx >= B.n_reads) L.st = SS_DONE;
 					else {
+						// k_seed3 ran first: it left the read's LAST-like seeds in the list and a repetitiveness weight by which the
+						// reads were ordered heaviest first (a read inside a repeat family is a chain of 10-20 k dependent blocks --
+						// started last, it alone kept the kernel running for another 15 ms)
+						const int r = B.seed_order ? B.seed_order[idx] : idx;
 						L.r = r; L.qoff = (u64)B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
-						B.intv_n[r] = 0;
+						if (B.seed_pass3_inline) B.intv_n[r] = 0;
 						L.em.mem = B.intv + (size_t)r * B.mem_cap;      // the read's own interval list (sorted and consumed by k_publish)
-						L.em.n = 0; L.em.overflow = false;
+						L.em.n = B.seed_pass3_inline ? 0 : B.intv_n[r]; L.n3 = L.em.n; L.em.overflow = false;
 						if (L.len >= opt.min_seed_len) { L.x = 0; L.st = SS_PASS1; }   // else mem_chain returns at once (bwamem.c:286): draw the next read
 					}
 				}
@@ -283,7 +290,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 				switch (L.st) {
 				case SS_PASS1:   // pass 1: all SMEMs, left to right (bwamem.c:147-157)
 					while (L.x < L.len && seed_q(L, nib, L.x) > 3) ++L.x;
-					if (L.x >= L.len) { L.old_n = L.em.n; L.k2 = 0; L.st = SS_PASS2; }
+					if (L.x >= L.len) { L.old_n = L.em.n; L.k2 = L.n3; L.st = SS_PASS2; }   // pass 2 re-seeds pass 1's SMEMs (the entries after pass 3's)
 					else smem_start(ix, L, S, nib, L.x, 1, 1);
 					break;
 				case SS_PASS2: { // pass 2: re-seed from the middle of long, rare SMEMs (bwamem.c:160-168)
@@ -293,7 +300,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 						int start = (int)(p.info >> 32), end = (int)(u32)p.info;
 						if (end - start >= split_len && p.x2 <= (u64)opt.split_width) { smem_start(ix, L, S, nib, (start + end) >> 1, p.x2 + 1, 2); started = true; }
 					}
-					if (!started) { L.x = 0; L.st = opt.max_mem_intv > 0 ? SS_PASS3 : SS_FINAL; }
+					if (!started) { L.x = 0; L.st = (opt.max_mem_intv > 0 && B.seed_pass3_inline) ? SS_PASS3 : SS_FINAL; }
 					break; }
 				case SS_PASS3:   // pass 3: LAST-like seeds (bwamem.c:170-185, bwt_seed_strategy1 bwt.c:358-379)
 					while (L.x < L.len && seed_q(L, nib, L.x) > 3) ++L.x;
@@ -369,6 +376,78 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 		atomicAdd(&B.ctr->occ_blocks, (unsigned long long)nblk); atomicAdd(&B.ctr->tab_lookups, (unsigned long long)ntab);
 		if ((threadIdx.x & 63) == 0) { atomicAdd(&B.ctr->prof[13], (unsigned long long)n_iter); atomicAdd(&B.ctr->prof[14], (unsigned long long)n_slow); atomicAdd(&B.ctr->prof[15], (unsigned long long)n_ext_lanes); }
 	}
+}
+
+// Pass 3 of mem_collect_intv (bwamem.c:170-185) -- the LAST-like seeds of bwt_seed_strategy1 (bwt.c:358-379) -- as a kernel of its
+// own, run BEFORE passes 1-2 (k_seed): besides its seeds it leaves, per read, the summed occurrence counts of the seed-length matches it
+// walked through -- a measure of how repetitive the read is, by which k_seed's reads are then ordered heaviest first.  The pass does not depend on passes 1-2 (it only appends to the read's interval list, which k_publish sorts afterwards), and it
+// is a plain forward extension loop: run inside k_seed's state machine each of its steps paid for that machine's whole divergent
+// iteration (~1060 VALU instructions); here an iteration is the extension plus a dozen instructions of control.  One lane per
+// read, reads drawn from a per-wave pool.
+__global__ void __launch_bounds__(256) k_seed3(DevIndex ix, bwagpu_opt_t opt, Batch B)
+{
+	SeedLane L;                   // only the read window (qoff, win, win_w, len), x, sx, i, ik, code and the emitter are used
+	L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len; L.em.mem = B.intv; L.em.n = 0; L.em.overflow = false;
+	L.r = -1; L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u; L.x = 0; L.sx = 0; L.i = 0; L.code = 0;
+	L.ik.x0 = L.ik.x1 = L.ik.x2 = L.ik.info = 0;
+	const u64 *nib = B.seq_nib;
+	const int lane = threadIdx.x & 63;
+	enum { T_FETCH = 0, T_START, T_EXT, T_DONE };
+	int st = T_FETCH, pool_base = 0, pool_cnt = 0;
+	u32 nblk = 0, ntab = 0, weight = 0;
+	while (st != T_DONE) {
+		const u64 wm = __ballot(st == T_FETCH);
+		if (wm) {
+			if (pool_cnt == 0) {
+				const int first = __ffsll((unsigned long long)__ballot(1)) - 1;
+				const unsigned long long old = atomicAdd(&B.ctr->next_read3, lane == first ? 64ull : 0ull);
+				pool_base = __shfl((int)old, first); pool_cnt = 64;
+			}
+			const int rank = __popcll(wm & ((1ull << lane) - 1));
+			if (st == T_FETCH && rank < pool_cnt) {
+				const int r = pool_base + rank;
+				if (r >= B.n_reads) st = T_DONE;
+				else {
+					L.r = r; L.qoff = (u64)B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
+					L.em.mem = B.intv + (size_t)r * B.mem_cap; L.em.n = 0; L.em.overflow = false;
+					B.intv_n[r] = 0; B.seed_w[r] = 0; weight = 0;
+					if (L.len >= opt.min_seed_len && opt.max_mem_intv > 0) { L.x = 0; st = T_START; }   // mem_chain returns at once for shorter reads (bwamem.c:286)
+				}
+			}
+			const int took = __popcll(wm) < pool_cnt ? __popcll(wm) : pool_cnt;
+			pool_base += took; pool_cnt -= took;
+		}
+		if (st == T_START) {
+			while (L.x < L.len && seed_q(L, nib, L.x) > 3) ++L.x;
+			if (L.x >= L.len) {
+				if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull); else B.intv_n[L.r] = L.em.n;
+				B.seed_w[L.r] = (i32)(weight > 0x3fffffffu ? 0x3fffffffu : weight);
+				st = T_FETCH;
+			} else {
+				fm_init(ix, seed_q(L, nib, L.x), L.ik); L.sx = L.x; L.i = L.x + 1;
+				L.code = window_code(L, nib, L.x, ix.ptab_m);
+				if (L.i >= L.len) L.x = L.len;
+				else if (seed_q(L, nib, L.i) > 3) L.x = L.i + 1;
+				else st = T_EXT;
+			}
+		}
+		if (st == T_EXT) {        // one forward extension (bwt.c:364-377)
+			BiIntv ok;
+			const int tl = L.i - L.sx + 1;
+			if (tl <= ix.ptab_m) { ptab_load(ix, tl, L.code, ok); ++ntab; }
+			else nblk += fm_extend1(ix, L.ik, 3 - seed_q(L, nib, L.i), 0, ok);
+			if (tl == opt.min_seed_len) weight += (u32)(ok.x2 > 65535 ? 65535 : ok.x2);   // occurrences of the seed-length match: the read's repetitiveness
+			if (ok.x2 < opt.max_mem_intv && L.i - L.sx >= opt.min_seed_len) {
+				if (ok.x2 > 0) L.em.add(ok.x0, ok.x2, L.sx, L.i + 1);
+				L.x = L.i + 1; st = T_START;
+			} else {
+				L.ik = ok; ++L.i;
+				if (L.i >= L.len) { L.x = L.len; st = T_START; }
+				else if (seed_q(L, nib, L.i) > 3) { L.x = L.i + 1; st = T_START; }
+			}
+		}
+	}
+	if (B.stats) { atomicAdd(&B.ctr->occ_blocks, (unsigned long long)nblk); atomicAdd(&B.ctr->tab_lookups, (unsigned long long)ntab); }
 }
 
 // One lane per SA interval: expand it into its SA rows (mem_chain's k-loop, bwamem.c:304-305) in the read's slot range.
