@@ -282,7 +282,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(roof_k, {}).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get(roof_k, {}).get("hbm_bytes_per_launch")
+                if roof_k == "k_seed" and traffic and "k_seed3" in pj:     # the seeding stage is two kernels since round 2 (pass 3 runs first)
+                    traffic += pj["k_seed3"].get("hbm_bytes_per_launch", 0.0)
             except Exception:
                 traffic = None
         layout = f"{n_batch // 2} pairs of 2x{args.read_len} bp (mates interleaved)" if pe else f"{n_batch} single-end {args.read_len} bp reads"
