@@ -298,7 +298,7 @@ def main():
                        "reads_per_gpu": n_batch, "read_len": args.read_len, "layout": args.layout, "genome_mbp": args.genome_mbp, "sa_intv": args.dense_sa or 32,
                        "sharding": f"reads x{world}, no collective", "batches_in_flight": S, "result_sha256_16": digest,
                        "timed": "kernels of the hot path on batches resident in HBM (no PCIe, no host finalize); see end_to_end_* for FASTQ->SAM"},
-            "roofline": {"bound": "hbm", "kernel": roof_k, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": roof_k + (" (+ k_seed3: the seeding stage)" if roof_k == "k_seed" else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "alg_bytes_per_launch": alg[roof_k], "kernel_ms": round(dur[roof_k], 3),
                          "per_kernel": {k: {"ms": round(dur[k], 3), "alg_GB": round(alg[k] / 1e9, 3), "GB/s": round(alg[k] / (dur[k] * 1e-3) / 1e9, 1) if dur[k] > 0 else None} for k in dur},
