@@ -385,11 +385,13 @@ def main():
                 if e2e:
                     out["end_to_end_se"] = {"value": round(e2e["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "stages": e2e["stages"], "what": f"same reads as {n_e} single-end reads"}
         out["bench_wall_s"] = round(time.time() - t_all, 1)
-        print(json.dumps(out), flush=True)
     else:
         gpu.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)      # the one JSON line, last thing on stdout (RCCL prints a version banner of its own at start-up)
     sys.exit(rc_exit)
 
 
