@@ -415,7 +415,7 @@ extern "C" int bwagpu_index_info(const bwagpu_t *h, int64_t *l_pac, int32_t *n_s
 }
 
 extern "C" int bwagpu_debug_phase(const bwagpu_t *h) { return h ? h->phase : -1; }
-// cycle counters of the last batch_run in a -DBWAGPU_PROFILE build (all zero otherwise); diagnostics only
+// diagnostic counters of the last batch_run (Counters::prof)
 extern "C" int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16])
 {
 	if (!h || !out || !h->d_ctr.p) return BWAGPU_EINVAL;
@@ -598,7 +598,6 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>(); B.chain_todo = h->d_chain_todo.as<i32>(); B.chain_todo2 = B.chain_todo + n + 4; B.seed_w = h->d_seed_w.as<i32>(); B.seed_order = nullptr;
 		B.seed_prio = !(getenv("BWAGPU_SEED_PRIO") && atoi(getenv("BWAGPU_SEED_PRIO")) == 0);
 		B.seed_pass3_inline = getenv("BWAGPU_SEED_PASS3_INLINE") && atoi(getenv("BWAGPU_SEED_PASS3_INLINE")) != 0;
-		B.chain_stop = getenv("BWAGPU_CHAIN_STOP") ? atoi(getenv("BWAGPU_CHAIN_STOP")) : 0;
 		B.chain_lds_off = getenv("BWAGPU_CHAIN_LDS") && atoi(getenv("BWAGPU_CHAIN_LDS")) == 0;
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
 		HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
@@ -649,7 +648,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		} else                                  // very wide bands: lane-per-read scalar DP with the columns in HBM scratch
 			hipLaunchKernelGGL(k_extend, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
-		if (h->max_len > WAVE_EXT_MAX_LEN) {     // long reads: few reads, long patch alignments -> one wavefront per read
+		if (h->max_len > WAVE_EXT_MAX_LEN || getenv("BWAGPU_DEDUP_WAVE")) {     // long reads: few reads, long patch alignments -> one wavefront per read
 			int rc_ = 256; while (rc_ < 8 * opt->w + 4 + 128 && rc_ < 2048) rc_ <<= 1;
 			i64 nblk = ((i64)n + 3) / 4, cap = n_threads / BLOCK;   // dp_h/dp_e hold one scratch region per wave of the standard grid
 			hipLaunchKernelGGL(k_dedup_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)(8 * rc_ + 32) * 4, h->stream, h->ix, *opt, B, rc_);

@@ -21,21 +21,6 @@
 #include "dev_chain.h"
 #include "dev_extw.h"
 
-#ifdef CW_DEBUG
-#define CW_DBG(rid, s, t, base, ns, qbeg, slen, nseq) do { if ((rid) >= (nseq) && lane == 0) fprintf(stderr, "bad rid %d s=%d t=%d base=%d ns=%d qbeg=%d len=%d\n", rid, s, t, base, ns, qbeg, slen); } while (0)
-#else
-#define CW_DBG(...)
-#endif
-#ifdef BWAGPU_PROFILE
-#define CW_T0() const unsigned long long t0_ = __builtin_readcyclecounter()
-#define CW_T(k) do { const unsigned long long t1_ = __builtin_readcyclecounter(); prof_[k] += t1_ - tl_; tl_ = t1_; } while (0)
-#define CW_TDECL() unsigned long long prof_[16] = {0}, tl_ = __builtin_readcyclecounter()
-#define CW_TFLUSH() do { if (lane == 0) for (int q_ = 0; q_ < 16; ++q_) if (prof_[q_]) atomicAdd(&B.ctr->prof[q_], prof_[q_]); } while (0)
-#else
-#define CW_T(k)
-#define CW_TDECL()
-#define CW_TFLUSH()
-#endif
 #define CW_STACK_INTS 32
 // LDS bytes of one wave: nodes, chain records, sort pairs, filter records {int4 kinfo, i32 kept, i32 ord}, seeds {i64 pos, i32 qbeg, len, next}, stack
 #define CW_PW_HBM_TIER 512       // HBM tier: chains whose {weight, index} pairs are sorted in LDS (a serial sort in HBM costs ~1 us per step)
@@ -209,7 +194,6 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 {
 	out_k = 0; out_m = 0;
 	const int lane = threadIdx.x & 63;
-	CW_TDECL();
 	r = uni(r);
 	const i64 off0 = B.off[r], off1 = B.off[r + 1];
 	const int ns_ = B.seed_n[r], niv_ = B.intv_n[r];
@@ -221,8 +205,6 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 		return true;
 	}
 	if (NC > 0 && SC > 0 && ns > SC) return false;            // tier 0 takes the reads whose seeds fit its LDS cache
-	CW_T(0);
-	if (B.chain_stop == 1) { CW_TFLUSH(); return true; }
 	const RegionView R = region_of(B.slot_blob, so, ns);
 	// ---- storage of this tier ----
 	i32 *nd; ChainRec *ch; int2 *pw; int4 *kinfo; i32 *kept, *ord, *stk;
@@ -253,14 +235,12 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 	int n_nodes = 1, root = 0, n_ch = 0, height = 1;
 	if (lane == 0) { nd[0] = 0; nd[1] = 0; }
 	wave_sync();
-	CW_T(1);
 	u32 visits = 0, recs = 0;
 	for (int base = 0; base < ns; base += 64) {
 		const int li = base + lane;
 		i64 v_rbeg = 0; int v_qb = 0, v_len = 0, v_rid = -1;
 		if (li < ns) { v_rbeg = pos[li]; v_qb = sqb[li]; v_len = sln[li]; v_rid = srid[li]; }
 		const int cnt = ns - base < 64 ? ns - base : 64;
-		CW_T(2);
 		for (int t = 0; t < cnt; ++t) {
 			const int s = base + t;
 			const int rid = __builtin_amdgcn_readlane(v_rid, t);
@@ -269,10 +249,8 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 			const i64 rbeg = readlane_i64(v_rbeg, t);
 			bool add = true;
 			LowerPath path; path.direct = false;
-			CW_T(3);
 			if (n_ch) {
 				const int lo = cw_lower(nd, root, rbeg, lane, visits, path);
-				CW_T(4);
 				if (lo >= 0) {   // test_and_merge (bwamem.c:216-237)
 					ChainRec *c = ch + lo;
 					++recs;
@@ -297,9 +275,7 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 					}
 				}
 			}
-			CW_T(5);
 			if (add) {
-				CW_DBG(rid, s, t, base, ns, qbeg, slen, ix.n_seqs);
 				// an insertion allocates at most two nodes for a root split plus one per level below the (new) root
 				if (NC > 0 && (n_ch >= CC || n_nodes + height + 2 > NC)) return false;   // outgrew this tier
 				if (lane == 0) {
@@ -313,12 +289,10 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 				if (path.direct) cw_insert_at(nd, path, n_ch, rbeg, lane);
 				else cw_insert(nd, n_nodes, root, height, n_ch, rbeg, lane);
 				++n_ch; ++recs;
-				CW_T(6);
 			}
 		}
 	}
 	n_visits += visits; n_recs += recs;
-	if (B.chain_stop == 2) { CW_TFLUSH(); return true; }
 	if (lane == 0) { B.chain_n[r] = 0; B.reg_off[r] = 0; B.reg_cap_r[r] = 0; B.reg_n_raw[r] = 0; B.reg_n[r] = 0; }
 	if (n_ch == 0) return true;
 	// Fraction of the read covered by over-abundant seeds (bwamem.c:291-298).  The reference merges the intervals -- sorted by
@@ -342,10 +316,7 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 		}
 		frac_rep = (float)l_rep / len;
 	}
-	CW_T(7);
 	int n = cw_inorder(nd, root, ord, stk, lane);
-	CW_T(8);
-	if (B.chain_stop == 3) return true;
 	// ---- mem_chain_flt (bwamem.c:353-411): weights (lane per chain), drop light chains keeping the order ----
 	int k = 0;
 	for (int base = 0; base < n; base += 64) {
@@ -377,8 +348,7 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 		k += __popcll(m);
 	}
 	n = k;
-	CW_T(9);
-	if (n == 0 || B.chain_stop == 4) { CW_TFLUSH(); return true; }
+	if (n == 0) return true;
 	wave_sync();
 	// ks_introsort by weight (bwamem.c:367): {weight, index} pairs, literal comparison sequence, one lane
 	for (int i = lane; i < n; i += 64) pw[i] = make_int2(ch[ord[i]].w, ord[i]);
@@ -452,8 +422,6 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 		for (int i = cut + lane; i < n; i += 64) if (ch[ord[i]].kept < 3) ch[ord[i]].kept = 0;
 		wave_sync();
 	}
-	CW_T(10);
-	if (B.chain_stop == 5) { CW_TFLUSH(); return true; }
 	// ---- publish the kept chains: headers + seeds flattened chain by chain, in sorted order ----
 	bwagpu_chain_t *oc = R.cchain;
 	bwagpu_seed_t *os = R.cseed;
@@ -481,12 +449,9 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 		m_tot = __shfl(my_m + cn, 63);
 	}
 	wave_sync();
-	CW_T(11);
 	// the caller reserves the read's range of the region arena (one atomic per chunk of reads) and sets reg_off
 	if (k && lane == 0) { B.chain_n[r] = k; B.reg_cap_r[r] = m_tot; }
 	out_k = k; out_m = m_tot;
-	CW_T(12);
-	CW_TFLUSH();
 	return true;
 }
 

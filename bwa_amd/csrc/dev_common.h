@@ -81,7 +81,7 @@ struct Counters {          // device-side bump allocators + flags
 	// algorithmic work counters (bwagpu_stats_t)
 	unsigned long long n_intv, n_chains, n_regs_raw, n_regs;
 	unsigned long long occ_blocks, lf_steps, ext_calls, ext_cells, glb_calls, glb_cells, ref_bases, sw_calls, sw_cells, tab_lookups;
-	unsigned long long prof[16];                   // cycle counters of a -DBWAGPU_PROFILE build (bwagpu_debug_prof), zero otherwise
+	unsigned long long prof[16];                   // diagnostics (bwagpu_debug_prof): [13..15] k_seed's wave iterations, bookkeeping iterations, extending lanes (stats runs)
 	unsigned long long ext_fast;                   // ksw_extend2 calls answered by the diagonal rule (no DP)
 	unsigned long long bt_nodes, chain_recs;       // B-tree nodes visited by look-ups / chain records touched (k_chain's algorithmic bytes)
 };
@@ -153,7 +153,6 @@ struct Batch {
 	i32 *chain_todo, *chain_todo2; // reads deferred by tier 0 / tier 1 of k_chain_wave to the next tier
 	int seed_prio;             // waves holding the heaviest 3 % of k_seed's reads run at raised issue priority (BWAGPU_SEED_PRIO=0 turns it off)
 	int seed_pass3_inline;     // A/B switch (BWAGPU_SEED_PASS3_INLINE=1): pass 3 inside k_seed's state machine as in round 1, instead of k_seed3
-	int chain_stop;            // diagnostics (BWAGPU_CHAIN_STOP=k): k_chain_wave returns after phase k of every read (timing only, results invalid)
 	int chain_lds_off;         // test hook (BWAGPU_CHAIN_LDS=0): the LDS tiers defer every read
 	// --- B-tree nodes
 	i64 *node_off;             // per read

@@ -188,8 +188,8 @@ typedef struct {
  * thread while a call is in progress.  10-12 upload, 20+100*attempt run launched, 22+100*attempt run waiting, 30-39 download,
  * 40-45 cigars. */
 int bwagpu_debug_phase(const bwagpu_t *h);
-/* Diagnostics: sixteen cycle / event counters of the last batch_run (wave iterations of the seeding kernel in [13..15]; the rest
- * only in a -DBWAGPU_PROFILE build of the library, zero otherwise). */
+/* Diagnostics: sixteen event counters of the last batch_run; with stats on, [13..15] = wave iterations of the seeding kernel, those that
+ * ran its bookkeeping code, and the lanes extending summed over iterations (tools/seed_iter_probe.py). */
 int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16]);
 
 /* ---- optional widening past mem_process_seqs' first loop ---- */

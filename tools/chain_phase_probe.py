@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostics (GPU): time of k_chain_wave when every read returns after phase k (BWAGPU_CHAIN_STOP)."""
+"""Diagnostics (GPU): one solo batch of the benchmark workload (two passes); run as `chain_phase_probe.py x` under rocprofv3 for per-kernel
+times and counters (tools/profile_round.sh uses bench.py instead)."""
 import os, sys, subprocess
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +22,6 @@ if len(sys.argv) > 1:
         except Exception as e:
             print("run failed", e); break
     s = gpu.stats()
-    print(f"stop={os.environ.get('BWAGPU_CHAIN_STOP', '0')} lane={os.environ.get('BWAGPU_CHAIN_LANE', '-')}: chain {s['ms_chain']:.2f} ms  (seed {s['ms_seed']:.1f})", flush=True)
+    print(f"seed {s['ms_seed']:.1f} chain {s['ms_chain']:.2f} extend {s['ms_extend']:.1f} dedup {s['ms_dedup']:.1f} ms", flush=True)
 else:
-    for stop in ("1", "2", "3", "4", "5", "0"):
-        subprocess.run([sys.executable, __file__, "x"], env=dict(os.environ, BWAGPU_CHAIN_STOP=stop))
+    subprocess.run([sys.executable, __file__, "x"])
