@@ -56,16 +56,33 @@ int RefSeqs::pos2rid(int64_t pos_f) const
 
 static inline int pac_at(const uint8_t *pac, int64_t l) { return pac[l >> 2] >> ((~l & 3) << 1) & 3; }
 
+// bns_get_seq (bntseq.c:403-423): bases [beg, end) of the forward + reverse-complement coordinate space; empty when the range
+// bridges the two strands.  Four bases per packed byte are unpacked at a time through a 256-entry table (the per-base form --
+// one shift/mask and a push_back per base -- was 15 % of the finalize stage).
+struct PacLut { uint8_t f[256][4], r[256][4]; PacLut() { for (int b = 0; b < 256; ++b) for (int k = 0; k < 4; ++k) { f[b][k] = (uint8_t)(b >> ((3 - k) << 1) & 3); r[b][k] = (uint8_t)(3 - (b >> (k << 1) & 3)); } } };
+static const PacLut g_paclut;
+
 void RefSeqs::get_seq(int64_t beg, int64_t end, std::vector<uint8_t> &out) const
 {
 	out.clear();
 	if (end < beg) std::swap(beg, end);
 	if (end > l_pac << 1) end = l_pac << 1;
 	if (beg < 0) beg = 0;
-	if (beg >= l_pac || end <= l_pac) {
-		out.reserve((size_t)(end - beg));
-		if (beg >= l_pac) for (int64_t k = (l_pac << 1) - 1 - beg; k > (l_pac << 1) - 1 - end; --k) out.push_back((uint8_t)(3 - pac_at(pac.data(), k)));
-		else for (int64_t k = beg; k < end; ++k) out.push_back((uint8_t)pac_at(pac.data(), k));
+	if (!(beg >= l_pac || end <= l_pac)) return;
+	const size_t n = (size_t)(end - beg);
+	out.resize(n);
+	uint8_t *o = out.data();
+	const uint8_t *p = pac.data();
+	if (beg < l_pac) {          // forward strand: bases beg .. end-1
+		int64_t k = beg; size_t i = 0;
+		for (; i < n && (k & 3); ++i, ++k) o[i] = (uint8_t)pac_at(p, k);
+		for (; i + 4 <= n; i += 4, k += 4) memcpy(o + i, g_paclut.f[p[k >> 2]], 4);
+		for (; i < n; ++i, ++k) o[i] = (uint8_t)pac_at(p, k);
+	} else {                    // reverse strand: complement of forward bases 2 l_pac - 1 - beg downwards
+		int64_t k = (l_pac << 1) - 1 - beg; size_t i = 0;
+		for (; i < n && (k & 3) != 3; ++i, --k) o[i] = (uint8_t)(3 - pac_at(p, k));
+		for (; i + 4 <= n; i += 4, k -= 4) memcpy(o + i, g_paclut.r[p[k >> 2]], 4);    // byte k>>2 holds bases k-3 .. k; reversed and complemented
+		for (; i < n; ++i, --k) o[i] = (uint8_t)(3 - pac_at(p, k));
 	}
 }
 
