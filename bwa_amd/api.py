@@ -53,7 +53,7 @@ EXPORTS = [
     "bwagpu_index_info", "bwagpu_densify_sa", "bwagpu_set_stats", "bwagpu_get_stats", "bwagpu_align_bseq", "bwagpu_align_flat",
     "bwagpu_free", "bwagpu_batch_upload", "bwagpu_batch_run", "bwagpu_batch_download", "bwagpu_set_taps", "bwagpu_tap_intervals",
     "bwagpu_tap_chains", "bwagpu_tap_regs_raw", "bwagpu_index_buffers", "bwagpu_index_export", "bwagpu_clone", "bwagpu_index_ready",
-    "bwagpu_batch_cigars", "bwagpu_debug_phase", "bwagpu_batch_matesw", "bwagpu_clone_to_device", "bwagpu_index_build", "bwagpu_built_free", "bwagpu_abi_sizes", "bwagpu_debug_prof",
+    "bwagpu_batch_cigars", "bwagpu_batch_cigar_ops", "bwagpu_debug_phase", "bwagpu_batch_matesw", "bwagpu_clone_to_device", "bwagpu_index_build", "bwagpu_built_free", "bwagpu_abi_sizes", "bwagpu_debug_prof",
 ]
 
 
@@ -89,6 +89,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.bwagpu_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwagpu_batch_matesw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwagpu_batch_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bwagpu_batch_cigar_ops.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwagpu_tap_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwagpu_tap_chains.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwagpu_tap_regs_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -208,6 +209,12 @@ class BwaGpu:
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.L.bwagpu_batch_cigars(self.h, C.byref(opt), C.byref(p), C.byref(n)))
         return self._take(p, n.value, CIGAR_DTYPE)
+
+    def cigar_ops(self):
+        """bwagpu_batch_cigar_ops: the operation array of the last cigars() call (records with 7..64 operations point into it)."""
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.bwagpu_batch_cigar_ops(self.h, C.byref(p), C.byref(n)))
+        return self._take(p, n.value, np.dtype("<u4"))
 
     def matesw(self, opt: MemOpt, pes: np.ndarray):
         """bwagpu_batch_matesw: precomputed mate-rescue alignments (MATESW_DTYPE) for the last download(); pes = PES_DTYPE[4]."""

@@ -75,6 +75,7 @@ struct bwagpu_s {
 	volatile int phase = 0;       // progress marker for bwagpu_debug_phase (diagnostics of a stuck call)
 	i64 packed_tot = -1;          // regions packed by the last bwagpu_batch_download (-1: none)
 	DevBuf d_msw_tasks, d_msw_out, d_msw_pes, d_msw_scratch;
+	DevBuf d_cig_ext; i64 cig_ext_n = -1;   // operation array of the last bwagpu_batch_cigars (records with 7..64 operations point into it)
 	DevBuf d_pack_off, d_regs_packed, d_pack_read, d_cigs, d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
 	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_blob;
 	DevBuf d_order, d_bin_cnt, d_chain_todo, d_seed_w, d_seed_order, d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
@@ -238,7 +239,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 		for (DevBuf *b : ib) b->release();
 		delete h->ibuf;
 	}
-	DevBuf *all[] = { &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
+	DevBuf *all[] = { &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_chain_todo, &h->d_seed_w, &h->d_seed_order, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
@@ -467,7 +468,7 @@ extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, cons
 {
 	if (!h || n < 0 || (n > 0 && (!seqs || !off))) return BWAGPU_EINVAL;
 	HIPCHK(h, hipSetDevice(h->device));
-	h->have_batch = false; h->ran = false; h->packed_tot = -1; h->phase = 10;
+	h->have_batch = false; h->ran = false; h->packed_tot = -1; h->cig_ext_n = -1; h->phase = 10;
 	h->n_reads = n; h->max_len = 0; h->n_bases = n ? off[n] - off[0] : 0;
 	if (n && off[0] != 0) return BWAGPU_EINVAL;
 	for (int i = 0; i < n; ++i) {
@@ -793,27 +794,55 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 	if (tot) {
 		if (h->d_cigs.ensure((size_t)tot * sizeof(bwagpu_cigar_t)) || h->d_ctr.ensure(sizeof(Counters))) { free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
 		Batch B = {}; B.seq = h->d_seq.as<u8>(); B.off = h->d_off.as<i64>(); B.n_reads = h->n_reads; B.max_len = h->max_len;
-		unsigned long long *next = &h->d_ctr.as<Counters>()->next_ext;
-		hipError_t e = hipSuccess;
+		unsigned long long *next = &h->d_ctr.as<Counters>()->next_ext, *ext_used = &h->d_ctr.as<Counters>()->cig_ext_used;
 		const int zc[2] = { CIG_Z_SMALL, CIG_Z_BIG };
 		const int n_tier = getenv("BWAGPU_CIG_TIERS") ? atoi(getenv("BWAGPU_CIG_TIERS")) : 2;   // diagnostics
-		for (int tier = 0; tier < n_tier && e == hipSuccess; ++tier) {   // narrow bands at high occupancy, then the deferred wide ones
-			e = hipMemsetAsync(next, 0, sizeof(unsigned long long), h->stream);
-			if (e != hipSuccess) break;
-			h->phase = 41 + tier;
-			const int lds_wave = CIG_LDS_BYTES(zc[tier]);
-			const int wpb = tier == 0 ? 4 : 2;                 // waves per workgroup: the wide tier stays below 64 KiB of LDS per group
-			i64 nblk = (tot + wpb - 1) / wpb, cap = 256 * 6;
-			hipLaunchKernelGGL(k_cigar, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, tot,
-							   h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_pack_read.as<i32>(), h->d_cigs.as<bwagpu_cigar_t>(), next, zc[tier], tier);
-			e = hipGetLastError();
+		// operation array: sized for a typical batch; one that needs more (gap-rich reads) reports the total it reserved and is
+		// redone once with exactly that much
+		i64 ext_cap = getenv("BWAGPU_CIG_OPS_CAP") ? atoll(getenv("BWAGPU_CIG_OPS_CAP")) : tot * 4 + 65536;   // (the variable: tests of the second attempt)
+		if (ext_cap < 1) ext_cap = 1;
+		unsigned long long used = 0;
+		hipError_t e = hipSuccess;
+		for (int attempt = 0; attempt < 2; ++attempt) {
+			if (h->d_cig_ext.ensure((size_t)ext_cap * 4)) { free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
+			e = hipMemsetAsync(ext_used, 0, sizeof(unsigned long long), h->stream);
+			for (int tier = 0; tier < n_tier && e == hipSuccess; ++tier) {   // narrow bands at high occupancy, then the deferred wide ones
+				e = hipMemsetAsync(next, 0, sizeof(unsigned long long), h->stream);
+				if (e != hipSuccess) break;
+				h->phase = 41 + tier;
+				const int lds_wave = CIG_LDS_BYTES(zc[tier]);
+				const int wpb = tier == 0 ? 4 : 2;                 // waves per workgroup: the wide tier stays below 64 KiB of LDS per group
+				i64 nblk = (tot + wpb - 1) / wpb, cap = 256 * 6;
+				hipLaunchKernelGGL(k_cigar, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, tot,
+								   h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_pack_read.as<i32>(), h->d_cigs.as<bwagpu_cigar_t>(), next, zc[tier], tier,
+								   h->d_cig_ext.as<u32>(), ext_used, ext_cap);
+				e = hipGetLastError();
+			}
+			if (e == hipSuccess) e = hipMemcpyAsync(&used, ext_used, sizeof used, hipMemcpyDeviceToHost, h->stream);
+			if (e == hipSuccess) e = wait_stream(h);
+			if (e != hipSuccess || (i64)used <= ext_cap) break;
+			ext_cap = (i64)used;
 		}
 		h->phase = 45;
 		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_cigs.p, (size_t)tot * sizeof(bwagpu_cigar_t), hipMemcpyDeviceToHost, h->stream);
 		if (e == hipSuccess) e = wait_stream(h);
+		h->cig_ext_n = (i64)used < ext_cap ? (i64)used : ext_cap;
 		if (e != hipSuccess) { free(res); HIPCHK(h, e); }
 	}
+	if (tot == 0) h->cig_ext_n = 0;
 	*out = res; *n_out = tot;
+	return BWAGPU_OK;
+}
+
+extern "C" int bwagpu_batch_cigar_ops(bwagpu_t *h, uint32_t **ops, int64_t *n_ops)
+{
+	if (!h || !ops || !n_ops || h->cig_ext_n < 0) return BWAGPU_EINVAL;
+	HIPCHK(h, hipSetDevice(h->device));
+	const i64 n = h->cig_ext_n;
+	uint32_t *res = (uint32_t*)malloc((size_t)(n ? n : 1) * 4);
+	if (!res) return BWAGPU_ENOMEM;
+	if (n) { hipError_t e = hipMemcpyAsync(res, h->d_cig_ext.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream); if (e == hipSuccess) e = wait_stream(h); if (e != hipSuccess) { free(res); HIPCHK(h, e); } }
+	*ops = res; *n_ops = n;
 	return BWAGPU_OK;
 }
 

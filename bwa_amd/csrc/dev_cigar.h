@@ -123,7 +123,8 @@ DEVFN int dev_infer_bw(int l1, int l2, int score, int a, int q, int r)
 }
 
 // One region: the band-doubling loop of mem_reg2aln (bwamem.c:1143-1152) around bwa_gen_cigar2 (bwa.c:148-195).
-__device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *query, const bwagpu_alnreg_t &p, const CigLds &L, bwagpu_cigar_t *out)
+__device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *query, const bwagpu_alnreg_t &p, const CigLds &L, bwagpu_cigar_t *out,
+							 u32 *ext, unsigned long long *ext_used, i64 ext_cap)
 {
 	const int lane = threadIdx.x & 63;
 	const i64 rb = uni64(p.rb), re = uni64(p.re), l_pac = ix.l_pac;
@@ -171,7 +172,18 @@ __device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const 
 		} while (++i < 3 && score < truesc - opt.a);
 		if (defer) res_n = -2;
 		else if (!give_up && n_ops <= CIG_MAX_OPS) { res_score = score; res_n = n_ops; }
-		else if (!give_up) res_score = 3;
+		else if (!give_up) {   // 7 .. CIG_TMP_OPS operations: they go to the batch's operation array, the record holds their offset
+			unsigned long long at = 0;
+			if (lane == 0) at = atomicAdd(ext_used, (unsigned long long)n_ops);
+			at = (unsigned long long)lane0_i64((i64)at);
+			if (ext && (i64)(at + n_ops) <= ext_cap) {
+				for (int k = lane; k < n_ops; k += 64) ext[at + k] = L.ops[n_ops - 1 - k];   // traceback order reversed
+				if (lane == 0) { out->score = score; out->n_cigar = n_ops; out->cigar[0] = (u32)at; out->cigar[1] = (u32)(at >> 32); for (int k = 2; k < CIG_MAX_OPS; ++k) out->cigar[k] = 0; }
+				wave_sync();
+				return;
+			}
+			res_score = 3;
+		}
 	}
 	if (lane == 0) {
 		out->score = res_score; out->n_cigar = res_n;
@@ -183,7 +195,7 @@ __device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const 
 // One wavefront per packed region (bwagpu_batch_download's order); regions below the output threshold T are skipped.
 // tier 0 visits every region and defers (n_cigar = -2) those whose band needs more LDS than z_cells; tier 1 redoes exactly those.
 __global__ void __launch_bounds__(256) k_cigar(DevIndex ix, bwagpu_opt_t opt, Batch B, i64 n_regs, const bwagpu_alnreg_t *regs, const i32 *reg_read, bwagpu_cigar_t *out,
-											   unsigned long long *next, int z_cells, int tier)
+											   unsigned long long *next, int z_cells, int tier, u32 *ext, unsigned long long *ext_used, i64 ext_cap)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, cig_lds)
 	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -202,7 +214,7 @@ __global__ void __launch_bounds__(256) k_cigar(DevIndex ix, bwagpu_opt_t opt, Ba
 		const bwagpu_alnreg_t p = regs[g];
 		if (p.score < opt.T) { if (lane == 0) { out[g].score = 1; out[g].n_cigar = -1; for (int k = 0; k < CIG_MAX_OPS; ++k) out[g].cigar[k] = 0; } continue; }
 		const int r = reg_read[g];
-		cigar_region(ix, opt, B.seq + B.off[r], p, L, out + g);
+		cigar_region(ix, opt, B.seq + B.off[r], p, L, out + g, ext, ext_used, ext_cap);
 		if (tier > 0 && lane == 0 && out[g].n_cigar == -2) out[g].n_cigar = -1;
 	}
 }

@@ -76,6 +76,7 @@ struct Counters {          // device-side bump allocators + flags
 	HotCounter next_chain_, next_dedup_;       // work counters of the chaining and de-duplication kernels
 	HotCounter next_chain_b_, n_chain_todo_;   // second tier of the wave-per-read chaining kernel: its work counter and the length of its work list
 	HotCounter next_chain_c_, n_chain_todo2_;  // third tier
+	HotCounter cig_ext_used_;                  // operations written to the batch's CIGAR operation array (records with more than 6 operations)
 	unsigned long long intv_used;
 	unsigned long long overflow;   // bit0 intv, bit1 seed, bit2 node, bit3 reg, bit4 tmp-intv scratch
 	// algorithmic work counters (bwagpu_stats_t)
@@ -98,6 +99,7 @@ struct Counters {          // device-side bump allocators + flags
 #define n_chain_todo n_chain_todo_.v
 #define next_chain_c next_chain_c_.v
 #define n_chain_todo2 n_chain_todo2_.v
+#define cig_ext_used cig_ext_used_.v
 
 // Sub-arrays of one read's private region (n = its number of seed slots); offsets keep every array naturally aligned.
 struct RegionView {

@@ -46,7 +46,7 @@ struct Aln {   // == the information of mem_aln_t (bwamem.h:114-126)
 // Device-computed global alignments of a read's regions (bwagpu_batch_cigars): regs[k] as downloaded, cigs[k] its result.
 // reg2aln looks a region up by the fields its band-doubling loop depends on and skips the DP when it finds a usable entry;
 // the result is the same either way.
-struct CigHints { const bwagpu_alnreg_t *regs; const bwagpu_cigar_t *cigs; int n; };
+struct CigHints { const bwagpu_alnreg_t *regs; const bwagpu_cigar_t *cigs; int n; const uint32_t *ops = nullptr; /* the batch's operation array: records with 7..64 operations (bwagpu_batch_cigar_ops) */ };
 
 struct Read {   // == bseq1_t as the finalize code needs it
 	const char *name; const char *comment; const uint8_t *seq /* nt4 codes */; const char *qual; int l_seq;
@@ -71,7 +71,7 @@ uint64_t hash_64(uint64_t key);                                     // utils.h:9
 int mark_primary_se(const bwagpu_opt_t &opt, Regs &a, int64_t id);  // bwamem.c:547-584
 void reorder_primary5(int T, Regs &a);                              // bwamem.c:1008-1030
 int approx_mapq_se(const bwagpu_opt_t &opt, const bwagpu_alnreg_t &a);   // bwamem.c:982-1006
-void host_region_cigar(const bwagpu_opt_t &opt, const RefSeqs &ref, const uint8_t *query, const bwagpu_alnreg_t &ar, bwagpu_cigar_t *out);   // == one bwagpu_batch_cigars record
+void host_region_cigar(const bwagpu_opt_t &opt, const RefSeqs &ref, const uint8_t *query, const bwagpu_alnreg_t &ar, bwagpu_cigar_t *out, std::vector<uint32_t> *ext);   // == one bwagpu_batch_cigars record (+ its entries of the operation array)
 Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint8_t *query, const bwagpu_alnreg_t *ar, const CigHints *hints = nullptr);   // bwamem.c:1119-1189
 void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, const Read &s, const std::vector<Aln> &list, int which, const Aln *mate, const char *rg_id);   // bwamem.c:851-976
 void reg2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, const Read &s, Regs &a, int extra_flag, const Aln *mate, const char *rg_id);   // bwamem.c:1033-1079

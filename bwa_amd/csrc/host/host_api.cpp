@@ -65,7 +65,8 @@ void bwamem_host_set_alt(void *h, int rid, int flag) { ((RefSeqs*)h)->ctg[rid].i
 char *bwamem_host_regs2sam(void *h, const bwagpu_opt_t *opt, int64_t n_processed, int n, const char *names, const uint8_t *seqs, const char *quals,
 						   const int64_t *off, const int32_t *counts, const bwagpu_alnreg_t *regs, const Pestat *pes0, int n_threads, int64_t *out_len,
 						   const bwagpu_cigar_t *cigs /* optional: bwagpu_batch_cigars output, parallel to regs */,
-						   const bwagpu_matesw_t *msw /* optional: bwagpu_batch_matesw output */, int64_t n_msw)
+						   const bwagpu_matesw_t *msw /* optional: bwagpu_batch_matesw output */, int64_t n_msw,
+						   const uint32_t *cig_ops /* optional: bwagpu_batch_cigar_ops output (records with more than 6 operations) */)
 {
 	const RefSeqs &ref = *(RefSeqs*)h;
 	std::vector<Read> reads(n); std::vector<Regs> rv(n); std::vector<CigHints> hints(n);
@@ -73,7 +74,7 @@ char *bwamem_host_regs2sam(void *h, const bwagpu_opt_t *opt, int64_t n_processed
 	for (int i = 0; i < n; ++i) {
 		reads[i].name = nm; nm += strlen(nm) + 1;
 		reads[i].comment = 0; reads[i].seq = seqs + off[i]; reads[i].qual = quals ? quals + off[i] : 0; reads[i].l_seq = (int)(off[i + 1] - off[i]);
-		if (cigs) { hints[i].regs = regs + roff; hints[i].cigs = cigs + roff; hints[i].n = counts[i]; reads[i].hints = &hints[i]; }
+		if (cigs) { hints[i].regs = regs + roff; hints[i].cigs = cigs + roff; hints[i].n = counts[i]; hints[i].ops = cig_ops; reads[i].hints = &hints[i]; }
 		rv[i].assign(regs + roff, regs + roff + counts[i]); roff += counts[i];
 	}
 	std::vector<bwagpu_matesw_t> msw_sorted;
@@ -108,12 +109,18 @@ int64_t bwamem_host_matesw_records(void *h, const bwagpu_opt_t *opt, int n, cons
 }
 
 // one bwagpu_cigar_t per region, computed by the host code (reference for bwagpu_batch_cigars; see host_region_cigar)
-void bwamem_host_region_cigars(void *h, const bwagpu_opt_t *opt, int n, const uint8_t *seqs, const int64_t *off, const int32_t *counts, const bwagpu_alnreg_t *regs, bwagpu_cigar_t *out)
+// ops/ops_cap: optional operation array for records with 7..64 operations (returns the number of entries used; without it such
+// regions are reported unserved, reason 3)
+int64_t bwamem_host_region_cigars(void *h, const bwagpu_opt_t *opt, int n, const uint8_t *seqs, const int64_t *off, const int32_t *counts, const bwagpu_alnreg_t *regs, bwagpu_cigar_t *out,
+								  uint32_t *ops, int64_t ops_cap)
 {
 	const RefSeqs &ref = *(RefSeqs*)h;
+	std::vector<uint32_t> ext;
 	int64_t k = 0;
 	for (int i = 0; i < n; ++i)
-		for (int j = 0; j < counts[i]; ++j, ++k) host_region_cigar(*opt, ref, seqs + off[i], regs[k], out + k);
+		for (int j = 0; j < counts[i]; ++j, ++k) host_region_cigar(*opt, ref, seqs + off[i], regs[k], out + k, ops ? &ext : nullptr);
+	if (ops && (int64_t)ext.size() <= ops_cap && !ext.empty()) memcpy(ops, ext.data(), ext.size() * 4);
+	return (int64_t)ext.size();
 }
 
 void bwamem_host_ksw_align2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins, int xtra, int out[7])

@@ -214,14 +214,15 @@ static const bwagpu_cigar_t *find_hint(const CigHints *h, const bwagpu_alnreg_t 
 	if (!h) return nullptr;
 	for (int k = 0; k < h->n; ++k) {
 		const bwagpu_alnreg_t &r = h->regs[k];
-		if (r.rb == a.rb && r.re == a.re && r.qb == a.qb && r.qe == a.qe && r.truesc == a.truesc && r.w == a.w) return h->cigs[k].n_cigar >= 0 ? &h->cigs[k] : nullptr;
+		if (r.rb == a.rb && r.re == a.re && r.qb == a.qb && r.qe == a.qe && r.truesc == a.truesc && r.w == a.w)
+			return h->cigs[k].n_cigar >= 0 && (h->cigs[k].n_cigar <= 6 || h->ops) ? &h->cigs[k] : nullptr;
 	}
 	return nullptr;
 }
 
 // What bwagpu_batch_cigars delivers for one region, computed here on the host (tests: the device records must equal these;
 // they also let the CPU suite exercise the hint path on thousands of reads).
-void host_region_cigar(const bwagpu_opt_t &opt, const RefSeqs &ref, const uint8_t *query, const bwagpu_alnreg_t &ar, bwagpu_cigar_t *out)
+void host_region_cigar(const bwagpu_opt_t &opt, const RefSeqs &ref, const uint8_t *query, const bwagpu_alnreg_t &ar, bwagpu_cigar_t *out, std::vector<uint32_t> *ext)
 {
 	out->score = 2; out->n_cigar = -1; for (int k = 0; k < 6; ++k) out->cigar[k] = 0;
 	if (ar.score < opt.T) { out->score = 1; return; }
@@ -240,7 +241,13 @@ void host_region_cigar(const bwagpu_opt_t &opt, const RefSeqs &ref, const uint8_
 		last_sc = score;
 		w2 <<= 1;
 	} while (++i < 3 && score < ar.truesc - opt.a);
-	if (cigar.size() > 6) { out->score = 3; return; }
+	if (cigar.size() > 6) {   // 7..64 operations go to the operation array, like the device's records
+		if (!ext || cigar.size() > 64) { out->score = 3; return; }
+		const uint64_t at = ext->size();
+		ext->insert(ext->end(), cigar.begin(), cigar.end());
+		out->score = score; out->n_cigar = (int)cigar.size(); out->cigar[0] = (uint32_t)at; out->cigar[1] = (uint32_t)(at >> 32);
+		return;
+	}
 	out->score = score; out->n_cigar = (int)cigar.size();
 	for (size_t k = 0; k < cigar.size(); ++k) out->cigar[k] = cigar[k];
 }
@@ -258,7 +265,8 @@ Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint
 	w2 = w2 > tmp ? w2 : tmp;
 	if (w2 > opt.w) w2 = w2 < ar->w ? w2 : ar->w;
 	if (const bwagpu_cigar_t *pc = find_hint(hints, *ar)) {   // the loop below already ran on the device: only NM/MD are left
-		a.cigar.assign(pc->cigar, pc->cigar + pc->n_cigar);
+		if (pc->n_cigar <= 6) a.cigar.assign(pc->cigar, pc->cigar + pc->n_cigar);
+		else { const uint32_t *o = hints->ops + ((uint64_t)pc->cigar[1] << 32 | pc->cigar[0]); a.cigar.assign(o, o + pc->n_cigar); }
 		std::vector<uint8_t> rseq, qs(query + qb, query + qe);
 		ref.get_seq(rb, re, rseq);
 		if (rb >= ref.l_pac) { std::reverse(qs.begin(), qs.end()); std::reverse(rseq.begin(), rseq.end()); }

@@ -198,6 +198,7 @@ struct Sub {      // one mem_process_seqs call (bwamem.c:1235-1264) on the reads
 	std::vector<uint8_t> flat; std::vector<int64_t> off; std::vector<int32_t> counts;
 	bwagpu_alnreg_t *all = nullptr; int64_t tot = 0;
 	bwagpu_cigar_t *cigs = nullptr;           // device-side global alignments of the regions (bwagpu_batch_cigars)
+	uint32_t *cig_ops = nullptr;              // ... and the operation array its records with more than 6 operations point into
 	bwagpu_matesw_t *msw = nullptr; int64_t n_msw = 0;   // device-side mate-rescue alignments (bwagpu_batch_matesw)
 	Pestat pes[4]; bool have_pes = false;     // insert-size windows, when they had to be computed before the finalize stage
 	double t_dev = 0;
@@ -251,7 +252,7 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 	int D = (int)gpus.size();
 	const int units = pe ? n / 2 : n, per = pe ? 2 : 1;
 	if (D > units) D = units > 0 ? units : 1;
-	struct Shard { int lo = 0, hi = 0; std::vector<int64_t> off; bwagpu_alnreg_t *all = nullptr; int64_t tot = 0; bwagpu_cigar_t *cigs = nullptr; bwagpu_matesw_t *msw = nullptr; int64_t n_msw = 0; };
+	struct Shard { int lo = 0, hi = 0; std::vector<int64_t> off; bwagpu_alnreg_t *all = nullptr; int64_t tot = 0; bwagpu_cigar_t *cigs = nullptr; uint32_t *ops = nullptr; int64_t n_ops = 0; bwagpu_matesw_t *msw = nullptr; int64_t n_msw = 0; };
 	std::vector<Shard> sh((size_t)D);
 	for (int d = 0; d < D; ++d) {
 		sh[d].lo = (int)((int64_t)units * d / D) * per; sh[d].hi = d + 1 == D ? n : (int)((int64_t)units * (d + 1) / D) * per;
@@ -278,22 +279,33 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 			int64_t nc = 0;
 			rc = bwagpu_batch_cigars(gpus[d], &u.opt, &s.cigs, &nc);
 			if (rc != BWAGPU_OK || nc != s.tot) device_fail(gpus[d], rc);
+			rc = bwagpu_batch_cigar_ops(gpus[d], &s.ops, &s.n_ops);
+			if (rc != BWAGPU_OK) device_fail(gpus[d], rc);
 		}
 	});
 	t3 = t4 = now_s();
-	if (D == 1) { u.all = sh[0].all; u.tot = sh[0].tot; u.cigs = sh[0].cigs; }
+	if (D == 1) { u.all = sh[0].all; u.tot = sh[0].tot; u.cigs = sh[0].cigs; u.cig_ops = sh[0].ops; }
 	else {   // gather in read order
 		u.tot = 0; for (auto &s : sh) u.tot += s.tot;
 		u.all = (bwagpu_alnreg_t*)malloc((size_t)(u.tot ? u.tot : 1) * sizeof(bwagpu_alnreg_t));
 		const bool have_cigs = g_device_cigars && u.tot > 0;
 		u.cigs = have_cigs ? (bwagpu_cigar_t*)malloc((size_t)u.tot * sizeof(bwagpu_cigar_t)) : nullptr;
 		if (!u.all || (have_cigs && !u.cigs)) { fprintf(stderr, "[E::%s] out of memory\n", "mem_process_seqs"); exit(EXIT_FAILURE); }
-		int64_t k = 0;
+		int64_t n_ops = 0; for (auto &s : sh) n_ops += s.n_ops;
+		u.cig_ops = have_cigs ? (uint32_t*)malloc((size_t)(n_ops ? n_ops : 1) * 4) : nullptr;
+		int64_t k = 0, ko = 0;
 		for (auto &s : sh) {
 			if (s.tot) memcpy(u.all + k, s.all, (size_t)s.tot * sizeof(bwagpu_alnreg_t));
-			if (have_cigs && s.tot) memcpy(u.cigs + k, s.cigs, (size_t)s.tot * sizeof(bwagpu_cigar_t));   // (a shard without regions has no records)
-			k += s.tot;
-			bwagpu_free(s.all); s.all = nullptr; bwagpu_free(s.cigs); s.cigs = nullptr;
+			if (have_cigs && s.tot) {   // (a shard without regions has no records); offsets into the operation array move with the shard's part of it
+				memcpy(u.cigs + k, s.cigs, (size_t)s.tot * sizeof(bwagpu_cigar_t));
+				if (s.n_ops) memcpy(u.cig_ops + ko, s.ops, (size_t)s.n_ops * 4);
+				if (ko) for (int64_t i = 0; i < s.tot; ++i) if (u.cigs[k + i].n_cigar > 6) {
+					const uint64_t at = ((uint64_t)u.cigs[k + i].cigar[1] << 32 | u.cigs[k + i].cigar[0]) + (uint64_t)ko;
+					u.cigs[k + i].cigar[0] = (uint32_t)at; u.cigs[k + i].cigar[1] = (uint32_t)(at >> 32);
+				}
+			}
+			k += s.tot; ko += s.n_ops;
+			bwagpu_free(s.all); s.all = nullptr; bwagpu_free(s.cigs); s.cigs = nullptr; bwagpu_free(s.ops); s.ops = nullptr;
 		}
 	}
 	if (g_device_matesw && pe && !(u.opt.flag & F_NO_RESCUE) && u.tot > 0) {
@@ -341,7 +353,7 @@ static void finalize_sub(const RefSeqs &ref, Work &w, Sub &u, const Pestat *pes0
 		const Seq &q = w.in.seqs[u.idx[i]];
 		const char *T = w.in.text.data();
 		regs[i].assign(u.all + roff[i], u.all + roff[i + 1]);
-		if (u.cigs) { hints[i].regs = u.all + roff[i]; hints[i].cigs = u.cigs + roff[i]; hints[i].n = u.counts[i]; reads[i].hints = &hints[i]; }
+		if (u.cigs) { hints[i].regs = u.all + roff[i]; hints[i].cigs = u.cigs + roff[i]; hints[i].n = u.counts[i]; hints[i].ops = u.cig_ops; reads[i].hints = &hints[i]; }
 		reads[i].name = T + q.name;
 		reads[i].comment = copy_comment && q.has_comment ? T + q.comment : nullptr;
 		reads[i].seq = u.flat.data() + u.off[i]; reads[i].qual = q.has_qual ? T + q.qual : nullptr; reads[i].l_seq = q.l_seq;
@@ -351,7 +363,7 @@ static void finalize_sub(const RefSeqs &ref, Work &w, Sub &u, const Pestat *pes0
 	if (u.msw) attach_matesw(n, reads.data(), u.msw, u.n_msw, msw_sorted);
 	std::vector<std::string> sam;
 	finalize_batch(u.opt, ref, u.n_processed, n, reads.data(), regs, (u.opt.flag & F_PE) ? (u.have_pes ? u.pes : pes0) : nullptr, u.opt.n_threads, rg_id, sam, g_verbose >= 3);
-	bwagpu_free(u.all); u.all = nullptr; bwagpu_free(u.cigs); u.cigs = nullptr; bwagpu_free(u.msw); u.msw = nullptr;
+	bwagpu_free(u.all); u.all = nullptr; bwagpu_free(u.cigs); u.cigs = nullptr; bwagpu_free(u.cig_ops); u.cig_ops = nullptr; bwagpu_free(u.msw); u.msw = nullptr;
 	for (int i = 0; i < n; ++i) w.out[u.idx[i]].swap(sam[i]);
 	if (g_verbose >= 3) fprintf(stderr, "[M::%s] Processed %d reads in %.3f real sec\n", "mem_process_seqs", n, u.t_dev + (now_s() - t0));
 }

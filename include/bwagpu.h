@@ -99,8 +99,10 @@ typedef struct {
 
 /* Banded global alignment of one region as mem_reg2aln's band-doubling loop around bwa_gen_cigar2 leaves it
  * (bwamem.c:1143-1152, bwa.c:148-195): score and BAM-style CIGAR (len << 4 | op, op M=0 I=1 D=2) before clipping and before
- * the leading/trailing-deletion squeeze.  n_cigar == -1: not computed on the device (region below opt->T, outside the
- * kernel's limits, or more than 6 operations; `score` then holds the reason 1/2/3) -- the caller runs bwa_gen_cigar2 itself. */
+ * the leading/trailing-deletion squeeze.  n_cigar 1..6: the operations are in cigar[]; n_cigar 7..64: they are entries
+ * [at, at + n_cigar) of the batch's operation array (bwagpu_batch_cigar_ops), at = cigar[1] << 32 | cigar[0].
+ * n_cigar == -1: not computed on the device (region below opt->T, outside the kernel's limits, or more than 64
+ * operations; `score` then holds the reason 1/2/3) -- the caller runs bwa_gen_cigar2 itself. */
 typedef struct {
 	int32_t score;
 	int32_t n_cigar;
@@ -197,6 +199,8 @@ int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16]);
  * are what worker2's mem_reg2aln (bwamem.c:1119-1152) would compute on the host for that region; a finalize stage can use
  * them instead of calling bwa_gen_cigar2 (NM/MD are still derived on the host from the CIGAR).  Free with bwagpu_free. */
 int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_cigar_t **out, int64_t *n_out);
+/* The operation array of the last bwagpu_batch_cigars call (records with more than 6 operations point into it).  Free with bwagpu_free. */
+int bwagpu_batch_cigar_ops(bwagpu_t *h, uint32_t **ops, int64_t *n_ops);
 
 /* After bwagpu_batch_download of a paired batch (mates interleaved 2i, 2i+1): the local alignments mem_matesw
  * (bwamem_pair.c:137-206) would run for every (anchor region, orientation) that the downloaded region lists do not already

@@ -28,12 +28,13 @@ def lib():
         L.bwamem_host_destroy.argtypes = [C.c_void_p]
         L.bwamem_host_set_alt.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.bwamem_host_regs2sam.restype = C.c_void_p
-        L.bwamem_host_regs2sam.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.bwamem_host_regs2sam.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.bwamem_host_pestat.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.bwamem_host_matesw_records.restype = C.c_int64
         L.bwamem_host_matesw_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.bwamem_host_free.argtypes = [C.c_void_p]
-        L.bwamem_host_region_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bwamem_host_region_cigars.restype = C.c_int64
+        L.bwamem_host_region_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         _lib = L
     return _lib
 
@@ -46,7 +47,7 @@ class HostFinalize:
     def set_alt(self, rid, flag=1):
         lib().bwamem_host_set_alt(self.h, rid, flag)
 
-    def regs2sam(self, opt, names, seqs_nt4: np.ndarray, quals: bytes, off, counts, regs, n_processed=0, pes0=None, n_threads=4, cigs=None, msw=None) -> bytes:
+    def regs2sam(self, opt, names, seqs_nt4: np.ndarray, quals: bytes, off, counts, regs, n_processed=0, pes0=None, n_threads=4, cigs=None, msw=None, cig_ops=None) -> bytes:
         n = off.shape[0] - 1
         nm = b"".join(x.encode() + b"\0" for x in names)
         ln = C.c_int64(0)
@@ -55,18 +56,23 @@ class HostFinalize:
         seqs_nt4 = np.ascontiguousarray(seqs_nt4, dtype=np.uint8)
         p = lib().bwamem_host_regs2sam(self.h, C.byref(opt), n_processed, n, nm, seqs_nt4.ctypes.data, quals, off.ctypes.data, counts.ctypes.data, regs.ctypes.data, pes0, n_threads, C.byref(ln),
                                        None if cigs is None else np.ascontiguousarray(cigs).ctypes.data,
-                                       None if msw is None else np.ascontiguousarray(msw).ctypes.data, 0 if msw is None else int(msw.shape[0]))
+                                       None if msw is None else np.ascontiguousarray(msw).ctypes.data, 0 if msw is None else int(msw.shape[0]),
+                                       None if cig_ops is None else np.ascontiguousarray(cig_ops, dtype=np.uint32).ctypes.data)
         s = C.string_at(p, ln.value)
         lib().bwamem_host_free(p)
         return s
 
-    def region_cigars(self, opt, seqs_nt4, off, counts, regs):
-        """Host-computed bwagpu_cigar_t records (the reference for the device's bwagpu_batch_cigars)."""
+    def region_cigars(self, opt, seqs_nt4, off, counts, regs, with_ops=False):
+        """Host-computed bwagpu_cigar_t records (the reference for the device's bwagpu_batch_cigars); with_ops: also the operation
+        array that records with 7..64 operations point into (else such regions are reported unserved)."""
         from bwa_amd.api import CIGAR_DTYPE
         regs = np.ascontiguousarray(regs); counts = np.ascontiguousarray(counts, dtype=np.int32); seqs_nt4 = np.ascontiguousarray(seqs_nt4, dtype=np.uint8)
         out = np.zeros(regs.shape[0], dtype=CIGAR_DTYPE)
-        lib().bwamem_host_region_cigars(self.h, C.byref(opt), off.shape[0] - 1, seqs_nt4.ctypes.data, off.ctypes.data, counts.ctypes.data, regs.ctypes.data, out.ctypes.data)
-        return out
+        cap = 64 * regs.shape[0] + 64
+        ops = np.zeros(cap, dtype=np.uint32) if with_ops else None
+        n = lib().bwamem_host_region_cigars(self.h, C.byref(opt), off.shape[0] - 1, seqs_nt4.ctypes.data, off.ctypes.data, counts.ctypes.data, regs.ctypes.data, out.ctypes.data,
+                                            ops.ctypes.data if with_ops else None, cap)
+        return (out, ops[:n]) if with_ops else out
 
     PESTAT_DTYPE = np.dtype([("low", "<i4"), ("high", "<i4"), ("failed", "<i4"), ("pad_", "<i4"), ("avg", "<f8"), ("std", "<f8")])   # hostmem::Pestat
 
@@ -91,3 +97,19 @@ class HostFinalize:
         if self.h:
             lib().bwamem_host_destroy(self.h)
             self.h = None
+
+
+def decode_cigars(cigs, ops):
+    """bwagpu_cigar_t records as [(score, n_cigar, (op, ...))]: records with more than 6 operations are looked up in the operation
+    array, whose order differs between producers (the device appends in the order its waves finish)."""
+    out = []
+    for c in cigs:
+        n = int(c["n_cigar"])
+        if n > 6:
+            at = int(c["cigar"][1]) << 32 | int(c["cigar"][0])
+            assert at + n <= ops.shape[0], (at, n, ops.shape[0])
+            body = tuple(int(x) for x in ops[at:at + n])
+        else:
+            body = tuple(int(x) for x in c["cigar"][:max(n, 0)])
+        out.append((int(c["score"]), n, body))
+    return out

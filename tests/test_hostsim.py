@@ -127,7 +127,7 @@ def test_hostsim_lds_stack_ring_eviction(monkeypatch, ent):
     s2.close(); orc.close()
 
 
-def test_hostsim_device_cigars_give_the_same_sam(sim):
+def test_hostsim_device_cigars_give_the_same_sam(sim, monkeypatch):
     """bwagpu_batch_cigars (banded global alignment + traceback on the device): feeding its records to the
     host finalize code as hints yields exactly the SAM text the host produces when it runs every DP itself, and a good
     share of the regions is actually served by the device."""
@@ -143,15 +143,32 @@ def test_hostsim_device_cigars_give_the_same_sam(sim):
     assert cigs.dtype == CIGAR_DTYPE and cigs.shape[0] == regs.shape[0]
     names = [f"q{i}" for i in range(off.shape[0] - 1)]
     quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
-    want = host.region_cigars(opt, seqs, off, counts, regs)
-    assert cigs.tobytes() == want.tobytes(), "device records differ from the host's"
+    ops = sim.cigar_ops()
+    want, want_ops = host.region_cigars(opt, seqs, off, counts, regs, with_ops=True)
+    assert hostapi.decode_cigars(cigs, ops) == hostapi.decode_cigars(want, want_ops), "device records differ from the host's"
+    assert ops.shape[0] == want_ops.shape[0]
     plain = host.regs2sam(opt, names, seqs, quals, off, counts, regs)
-    hinted = host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs)
+    hinted = host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs, cig_ops=ops)
     assert hinted == plain
     served = int((cigs["n_cigar"] >= 0).sum())
     assert served >= regs.shape[0] // 2, (served, regs.shape[0])
     gapped = int(((cigs["n_cigar"] > 1)).sum())
     assert gapped > 0, "no gapped alignment exercised the traceback"
+    # gap-rich reads: alignments of 7..64 operations go through the operation array
+    reads = simdata.make_reads_se(g, 12, seed=96, sub=0.02, dele=0.03, ins=0.03)
+    seqs, off = testdata.flat(reads)
+    counts, regs = sim.align(opt, seqs, off)
+    cigs, ops = sim.cigars(opt), sim.cigar_ops()
+    want, want_ops = host.region_cigars(opt, seqs, off, counts, regs, with_ops=True)
+    assert hostapi.decode_cigars(cigs, ops) == hostapi.decode_cigars(want, want_ops)
+    assert int((cigs["n_cigar"] > 6).sum()) >= 4, cigs["n_cigar"]
+    monkeypatch.setenv("BWAGPU_CIG_OPS_CAP", "10")       # an operation array that is too small: the pass is redone with the size it asked for
+    cigs2, ops2 = sim.cigars(opt), sim.cigar_ops()
+    assert hostapi.decode_cigars(cigs2, ops2) == hostapi.decode_cigars(want, want_ops) and ops2.shape[0] == want_ops.shape[0]
+    monkeypatch.delenv("BWAGPU_CIG_OPS_CAP")
+    names = [f"q{i}" for i in range(off.shape[0] - 1)]
+    quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
+    assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs, cig_ops=ops) == host.regs2sam(opt, names, seqs, quals, off, counts, regs)
     host.close()
 
 
