@@ -166,7 +166,8 @@ static int build_prefix_tables(bwagpu_t *h, int m)
 		unsigned nb = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
 		hipLaunchKernelGGL(k_ptab_level, dim3(nb), dim3(256), 0, h->stream, ix, levels.as<u64>(), j);
 	}
-	hipLaunchKernelGGL(k_ptab_records, dim3(8192), dim3(256), 0, h->stream, levels.as<u64>(), h->ibuf->d_ptab.as<uint4>(), m);
+	const u64 n_rec = ((u64)1 << (2 * m)) * (u64)m;
+	hipLaunchKernelGGL(k_ptab_records, dim3((unsigned)((n_rec + 255) / 256 < 8192 ? (n_rec + 255) / 256 : 8192)), dim3(256), 0, h->stream, levels.as<u64>(), h->ibuf->d_ptab.as<uint4>(), m);
 	hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(h->stream);
 	levels.release();
 	HIPCHK(h, e1); HIPCHK(h, e2);
@@ -448,7 +449,7 @@ extern "C" int bwagpu_densify_sa(bwagpu_t *h, int new_intv)
 	u64 n_out = (h->seq_len + new_intv) / new_intv;
 	DevBuf nb;
 	if (nb.ensure(n_out * 8)) { h->err = "hipMalloc failed (dense SA)"; return BWAGPU_ENOMEM; }
-	hipLaunchKernelGGL(k_densify, dim3(8192), dim3(256), 0, h->stream, h->ix, nb.as<u64>(), n_out, sh);
+	hipLaunchKernelGGL(k_densify, dim3((unsigned)((n_out + 255) / 256 < 8192 ? (n_out + 255) / 256 : 8192)), dim3(256), 0, h->stream, h->ix, nb.as<u64>(), n_out, sh);
 	HIPCHK(h, hipGetLastError());
 	HIPCHK(h, hipStreamSynchronize(h->stream));
 	h->ibuf->d_sa.release();
@@ -624,8 +625,9 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			if (int rc2 = order_reads(h, B, B.seed_n)) return rc2;
 			i64 nblk = ((i64)n + 3) / 4, cap = 256 * 8;
 			hipLaunchKernelGGL((k_chain_wave<0, 10, 32, 128>), dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)CW_LDS_BYTES(10, 32, 128) * 4, h->stream, h->ix, *opt, B);
-			hipLaunchKernelGGL((k_chain_wave<1, 16, 64, 0>), dim3(256 * 5), block, (size_t)CW_LDS_BYTES(16, 64, 0) * 4, h->stream, h->ix, *opt, B);
-			hipLaunchKernelGGL((k_chain_wave<2, 0, 0, 0>), dim3(256 * 7), block, (size_t)CW_LDS_BYTES(0, 0, 0) * 4, h->stream, h->ix, *opt, B);
+			// (the deferred reads are known on the device only: the grids of tiers 1 and 2 are sized for a full chip, or for every read of a small batch)
+			hipLaunchKernelGGL((k_chain_wave<1, 16, 64, 0>), dim3((unsigned)(nblk < 256 * 5 ? nblk : 256 * 5)), block, (size_t)CW_LDS_BYTES(16, 64, 0) * 4, h->stream, h->ix, *opt, B);
+			hipLaunchKernelGGL((k_chain_wave<2, 0, 0, 0>), dim3((unsigned)(nblk < 256 * 7 ? nblk : 256 * 7)), block, (size_t)CW_LDS_BYTES(0, 0, 0) * 4, h->stream, h->ix, *opt, B);
 		}
 		HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
 		if (any_seedsw && h->max_len > WAVE_EXT_MAX_LEN) {   // long reads: one wavefront per read, one lane per seed

@@ -77,7 +77,9 @@ def _write_inputs(tmp_path, g, n_pairs, seed):
     return f1, f2, inter, fasta
 
 
-def _compare_all(cli, fa, f1, f2, inter, fasta, env=None):
+def _compare_all(cli, fa, f1, f2, inter, fasta, env=None, full=True):
+    """full=False (the mock runtime, seconds per invocation): the option sets that only change host-side behaviour already covered
+    by another run are left to the GPU test."""
     K = ["-K", "100000000", "-t", "4"]
     assert _run(refapi.REF_BWA, K + [fa, f1]) == _run(cli, K + [fa, f1], env), "single-end"
     assert _run(refapi.REF_BWA, K + [fa, f1, f2]) == _run(cli, K + [fa, f1, f2], env), "paired-end, two files"
@@ -85,18 +87,20 @@ def _compare_all(cli, fa, f1, f2, inter, fasta, env=None):
     assert _run(refapi.REF_BWA, K + x + [fa, inter]) == _run(cli, K + x + [fa, inter], env), "smart pairing, comments, read group"
     y = ["-a", "-k", "17", "-A", "2", "-T", "40", "-h", "3,10", "-I", "400,50", "-5"]
     assert _run(refapi.REF_BWA, K + y + [fa, f1, f2]) == _run(cli, K + y + [fa, f1, f2], env), "scaled scores (-A 2), -I, -a, -5"
-    assert _run(refapi.REF_BWA, K + [fa, fasta]) == _run(cli, K + [fa, fasta], env), "multi-line FASTA input"
+    if full:   # (the -H/-o run below reads the same file)
+        assert _run(refapi.REF_BWA, K + [fa, fasta]) == _run(cli, K + [fa, fasta], env), "multi-line FASTA input"
     weird = os.path.join(os.path.dirname(f1), "weird.fq")
     assert _run(refapi.REF_BWA, K + ["-C", fa, weird]) == _run(cli, K + ["-C", fa, weird], env), "CRLF, multi-line FASTQ, lower case / IUPAC, mixed FASTA records"
     # the second file ends early: both programs stop at the last complete pair (bseq_read warns, bwa.c:96-99)
     short2 = os.path.join(os.path.dirname(f1), "r2_short.fq")
     with open(f2, "rb") as fi, open(short2, "wb") as fo:
         fo.write(b"".join(fi.readlines()[: 4 * 7]))
-    assert _run(refapi.REF_BWA, K + [fa, f1, short2]) == _run(cli, K + [fa, f1, short2], env), "second file shorter than the first"
+    if full:
+        assert _run(refapi.REF_BWA, K + [fa, f1, short2]) == _run(cli, K + [fa, f1, short2], env), "second file shorter than the first"
     # a record whose quality string is shorter than its sequence (kseq_read returns -2, kseq.h:219): the record is dropped, the
     # batch ends there, and reading resumes after whatever the quality loop consumed -- in the middle of the file and at its end
     lines = open(f1, "rb").read().split(b"\n")
-    for name, rec in (("trunc_mid.fq", 3), ("trunc_last.fq", len(lines) // 4 - 1)):
+    for name, rec in (("trunc_mid.fq", 3), ("trunc_last.fq", len(lines) // 4 - 1))[: 2 if full else 1]:
         t = os.path.join(os.path.dirname(f1), name)
         ll = list(lines[: 4 * (rec + 1 if name == "trunc_last.fq" else len(lines) // 4)])
         ll[4 * rec + 3] = ll[4 * rec + 3][:60]
@@ -123,7 +127,7 @@ def test_cli_hostsim(tmp_path):
     # the reference binary wants <prefix>.bwt etc.; both programs take the same prefix
     f1, f2, inter, fasta = _write_inputs(tmp_path, g, 14, seed=401)
     # the mock HIP runtime keeps its lane/block state in globals: two device threads, but one device call at a time
-    _compare_all(_sim_cli(), prefix, f1, f2, inter, fasta, env=dict(os.environ, BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1"))
+    _compare_all(_sim_cli(), prefix, f1, f2, inter, fasta, env=dict(os.environ, BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1", BWAGPU_PTAB_M="6"), full=False)   # (small prefix tables: a million emulated lanes per handle otherwise)
 
 
 @pytest.mark.gpu
@@ -145,13 +149,12 @@ def test_cli_hostsim_two_devices(tmp_path):
     prefix, g = testdata.small_index()
     f1, f2, inter, fasta = _write_inputs(tmp_path, g, 18, seed=403)
     cli = _sim_cli()
-    env = dict(os.environ, BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1", MOCK_HIP_DEVICES="2", BWAGPU_DEVICES="0,1")
-    K = ["-K", "100000000", "-t", "4", "-v", "3"]
-    p = subprocess.run([cli, "mem"] + K + [prefix, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
-    assert p.returncode == 0 and b"index copied to 2 devices" in p.stderr, p.stderr.decode()[-800:]
+    env = dict(os.environ, BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1", MOCK_HIP_DEVICES="2", BWAGPU_DEVICES="0,1", BWAGPU_PTAB_M="6")
     K = ["-K", "100000000", "-t", "4"]
+    p = subprocess.run([cli, "mem"] + K + ["-v", "3", prefix, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0 and b"index copied to 2 devices" in p.stderr, p.stderr.decode()[-800:]
+    assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _body(p.stdout), "paired-end, 2 devices"
     assert _run(refapi.REF_BWA, K + [prefix, f1]) == _run(cli, K + [prefix, f1], env), "single-end, 2 devices"
-    assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], env), "paired-end, 2 devices"
     x = ["-p", "-C"]
     assert _run(refapi.REF_BWA, K + x + [prefix, inter]) == _run(cli, K + x + [prefix, inter], env), "smart pairing, 2 devices"
     assert _run(refapi.REF_BWA, ["-K", "9000", "-t", "2", prefix, f1, f2]) == _run(cli, ["-K", "9000", "-t", "2", prefix, f1, f2], env), "small batches, 2 devices"

@@ -219,17 +219,15 @@ def test_hostsim_device_matesw_records_match_the_host(sim):
     host.close()
 
 
-@pytest.mark.parametrize("lds", ["1", "0"])
-def test_hostsim_wave_chaining_heavy_reads(monkeypatch, lds):
-    """k_chain_wave on reads with many chains (repeat-rich 2 Mb genome): multi-level B-trees with splits, duplicate keys, the
-    64-wide chain filter and the flattening of hundreds of chains must reproduce the oracle's chains exactly -- with the tree in
-    LDS (reads that outgrow it fall through to the HBM tier) and with the LDS tier switched off (every read in the HBM tier)."""
+@pytest.fixture(scope="module")
+def heavy_case():
+    """Repeat-rich 500 kb genome (500 copies per repeat family), its index, and the reads with the most chains."""
     import refapi
     if not refapi.have_ref():
-        pytest.skip("oracle/_ref not built (needed to index the 2 Mb genome)")
+        pytest.skip("oracle/_ref not built (needed to index the genome)")
     import tempfile
     d = tempfile.mkdtemp()
-    g, lens = simdata.make_genome(500_000, n_contigs=2, seed=5, n_interspersed=2000, divergence=0.04)   # 500 copies per repeat family
+    g, lens = simdata.make_genome(500_000, n_contigs=2, seed=5, n_interspersed=2000, divergence=0.04)
     fa = os.path.join(d, "rep.fa")
     simdata.write_fasta(fa, g, lens)
     refapi.build_index(fa)
@@ -244,6 +242,17 @@ def test_hostsim_wave_chaining_heavy_reads(monkeypatch, lds):
     mid = [int(i) for i in np.nonzero((n_chains >= 36) & (n_chains <= 60))[0][:2]]    # more than tier 0 holds, fewer than tier 1's limit
     assert len(mid) == 2
     reads = np.concatenate([cand[pick], cand[mid], cand[:3]])
+    yield fa, orc, reads
+    orc.close()
+
+
+@pytest.mark.parametrize("lds", ["1", "0"])
+def test_hostsim_wave_chaining_heavy_reads(monkeypatch, heavy_case, lds):
+    """k_chain_wave on reads with many chains (repeat-rich genome): multi-level B-trees with splits, duplicate keys, the
+    64-wide chain filter and the flattening of hundreds of chains must reproduce the oracle's chains exactly -- with the tree in
+    LDS (reads that outgrow it fall through to the HBM tier) and with the LDS tier switched off (every read in the HBM tier)."""
+    fa, orc, reads = heavy_case
+    opt = default_opt()
     monkeypatch.setenv("BWAGPU_CHAIN_LDS", lds)
     s2 = BwaGpu(fa, lib_path=hostsim_build.build())
     s2.set_taps(True); s2.set_stats(True)
@@ -266,7 +275,7 @@ def test_hostsim_wave_chaining_heavy_reads(monkeypatch, lds):
             assert np.array_equal(got_s[f], seeds[f]), (i, f)
         kc += cn[i]; ks += int(hdr["n"].sum())
     assert_regs_equal(*orc.align(opt, seqs, off), c, r, "heavy chaining")
-    s2.close(); orc.close()
+    s2.close()
 
 
 def _alt_prefix(tmp_path, prefix, alt_names):
