@@ -76,6 +76,7 @@ struct bwagpu_s {
 	i64 packed_tot = -1;          // regions packed by the last bwagpu_batch_download (-1: none)
 	DevBuf d_msw_tasks, d_msw_out, d_msw_pes, d_msw_scratch;
 	DevBuf d_cig_ext; i64 cig_ext_n = -1;   // operation array of the last bwagpu_batch_cigars (records with 7..64 operations point into it)
+	DevBuf d_seq_2b, d_seq_flags; int rd_words = 0;   // per-read 2-bit copies for k_seed's LDS (k_pack_reads2b)
 	DevBuf d_pack_off, d_regs_packed, d_pack_read, d_cigs, d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
 	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_blob;
 	DevBuf d_order, d_bin_cnt, d_chain_todo, d_seed_w, d_seed_order, d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
@@ -240,7 +241,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 		for (DevBuf *b : ib) b->release();
 		delete h->ibuf;
 	}
-	DevBuf *all[] = { &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
+	DevBuf *all[] = { &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_chain_todo, &h->d_seed_w, &h->d_seed_order, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
@@ -489,6 +490,16 @@ extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, cons
 		u64 pb = (n_words + BLOCK - 1) / BLOCK;
 		hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)(pb < 65536 ? pb : 65536)), dim3(BLOCK), 0, h->stream, P, n_words);
 		HIPCHK(h, hipGetLastError());
+		// reads of up to 256 bases: a 2-bit copy per read for the seeding kernel's LDS
+		h->rd_words = (h->max_len <= 256 && !(getenv("BWAGPU_SEED_RD_LDS") && atoi(getenv("BWAGPU_SEED_RD_LDS")) == 0)) ? (((h->max_len + 15) / 16 + 3) & ~3) : 0;
+		if (h->rd_words) {
+			if (h->d_seq_2b.ensure((size_t)n * h->rd_words * 4 + 64) || h->d_seq_flags.ensure((size_t)n + 16)) { h->err = "hipMalloc failed (reads)"; return BWAGPU_ENOMEM; }
+			HIPCHK(h, hipMemsetAsync(h->d_seq_flags.p, 0, (size_t)n, h->stream));
+			P.off = h->d_off.as<i64>(); P.n_reads = n; P.rd_words = h->rd_words; P.seq_2b = h->d_seq_2b.as<u32>(); P.seq_flags = h->d_seq_flags.as<u8>();
+			const u64 tb = ((u64)n * h->rd_words + BLOCK - 1) / BLOCK;
+			hipLaunchKernelGGL(k_pack_reads2b, dim3((unsigned)(tb < 65536 ? tb : 65536)), dim3(BLOCK), 0, h->stream, P);
+			HIPCHK(h, hipGetLastError());
+		}
 		HIPCHK(h, wait_stream(h));
 	}
 	// first guess of the arena sizes (grown on overflow)
@@ -520,7 +531,7 @@ static int alloc_batch(bwagpu_t *h, int n_threads)
 	int n = h->n_reads; size_t sc = (size_t)h->slot_cap + 8;   // +8: chunked readers may touch a few slots past the last read's range
 	int bad = 0;
 	bad |= h->d_ctr.ensure(sizeof(Counters));
-	bad |= h->d_tmp_intv.ensure((size_t)n_threads * (h->max_len + 1) * sizeof(BiIntv));
+	bad |= h->d_tmp_intv.ensure((size_t)n_threads * (h->max_len + 1 + PTAB_MAX) * sizeof(BiIntv));
 	bad |= h->d_intv_n.ensure((size_t)n * 4 + 16); bad |= h->d_intv_off.ensure((size_t)n * 8 + 16);
 	bad |= h->d_intv.ensure(((size_t)n * h->mem_cap + 16) * sizeof(Intv3));
 	bad |= h->d_seed_n.ensure((size_t)n * 4 + 16); bad |= h->d_seed_off.ensure((size_t)n * 8 + 16);
@@ -563,7 +574,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 	if (h->n_reads == 0) { h->ran = true; return BWAGPU_OK; }
 	int n = h->n_reads;
 	// resident lanes: enough to fill the chip, bounded by the seeding scratch budget (2 interval stacks per lane)
-	size_t per_lane = (size_t)(h->max_len + 1) * sizeof(BiIntv) + (size_t)2 * (h->max_len + 2) * 4;
+	size_t per_lane = (size_t)(h->max_len + 1 + PTAB_MAX) * sizeof(BiIntv) + (size_t)2 * (h->max_len + 2) * 4;
 	size_t budget = (size_t)12 << 30;
 	i64 max_thr = (i64)(budget / per_lane);
 	if (max_thr > MAX_RESIDENT_THREADS) max_thr = MAX_RESIDENT_THREADS;
@@ -587,7 +598,11 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.n_reads = n; B.max_len = h->max_len; B.stats = h->stats_on;
 		B.seq = h->d_seq.as<u8>(); B.seq_nib = h->d_seq_nib.as<u64>(); B.off = h->d_off.as<i64>(); B.ctr = h->d_ctr.as<Counters>();
 		B.tmp_intv = h->d_tmp_intv.as<BiIntv>(); B.mem_cap = h->mem_cap;
-		B.seed_lds_ent = (h->seq_len < ((u64)1 << 37) && h->max_len < 65536) ? (getenv("BWAGPU_SEED_LDS_ENT") ? atoi(getenv("BWAGPU_SEED_LDS_ENT")) : SEED_LDS_ENT) : 0;
+		B.rd_words = h->rd_words; B.seq_2b = h->d_seq_2b.as<u32>(); B.seq_flags = h->d_seq_flags.as<u8>();
+		// LDS per lane: 160 bytes at four blocks per CU -- the read's 2-bit copy first, interval-stack entries with the rest
+		const int lds_ent_dflt = h->rd_words ? ((160 - 4 * h->rd_words) / 16 < SEED_LDS_ENT ? (160 - 4 * h->rd_words) / 16 : SEED_LDS_ENT) : SEED_LDS_ENT;
+		B.seed_lds_ent = (h->seq_len < ((u64)1 << 37) && h->max_len < 65536) ? (getenv("BWAGPU_SEED_LDS_ENT") ? atoi(getenv("BWAGPU_SEED_LDS_ENT")) : lds_ent_dflt) : 0;
+		if (((size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * 16 + (size_t)B.rd_words * 4) * BLOCK > 65536) B.rd_words = 0;   // (an LDS_ENT override too large for both)
 		B.intv_n = h->d_intv_n.as<i32>(); B.intv_off = h->d_intv_off.as<i64>(); B.intv = h->d_intv.as<Intv3>();
 		B.seed_n = h->d_seed_n.as<i32>(); B.seed_off = h->d_seed_off.as<i64>(); B.slot_cap = h->slot_cap;
 		B.slot_pos = h->d_slot_pos.as<u64>(); B.slot_qbeg = h->d_slot_qbeg.as<i32>(); B.slot_len = h->d_slot_len.as<i32>(); B.slot_rid = h->d_slot_rid.as<i32>(); B.slot_blob = h->d_slot_blob.as<u8>();
@@ -599,6 +614,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.seedsw_minhsp = h->d_minhsp.as<i32>();
 		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>(); B.chain_todo = h->d_chain_todo.as<i32>(); B.chain_todo2 = B.chain_todo + n + 4; B.seed_w = h->d_seed_w.as<i32>(); B.seed_order = nullptr;
 		B.seed_prio = !(getenv("BWAGPU_SEED_PRIO") && atoi(getenv("BWAGPU_SEED_PRIO")) == 0);
+		B.seed_no_virt = getenv("BWAGPU_SEED_NO_VIRT") && atoi(getenv("BWAGPU_SEED_NO_VIRT")) != 0;
 		B.seed_pass3_inline = getenv("BWAGPU_SEED_PASS3_INLINE") && atoi(getenv("BWAGPU_SEED_PASS3_INLINE")) != 0;
 		B.chain_lds_off = getenv("BWAGPU_CHAIN_LDS") && atoi(getenv("BWAGPU_CHAIN_LDS")) == 0;
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
@@ -611,7 +627,10 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 				B.seed_order = B.order; B.order = keep;
 			}
 		}
-		hipLaunchKernelGGL(k_seed, grid, block, (size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * BLOCK * sizeof(uint4), h->stream, h->ix, *opt, B);
+		const size_t seed_lds = ((size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * sizeof(uint4) + (size_t)B.rd_words * 4) * BLOCK;
+		// (four instances: with/without the LDS copy of the reads, with/without the work counters, which cost registers)
+		if (B.rd_words) { if (B.stats) hipLaunchKernelGGL((k_seed<true, true>), grid, block, seed_lds, h->stream, h->ix, *opt, B); else hipLaunchKernelGGL((k_seed<true, false>), grid, block, seed_lds, h->stream, h->ix, *opt, B); }
+		else { if (B.stats) hipLaunchKernelGGL((k_seed<false, true>), grid, block, seed_lds, h->stream, h->ix, *opt, B); else hipLaunchKernelGGL((k_seed<false, false>), grid, block, seed_lds, h->stream, h->ix, *opt, B); }
 		HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
 		hipLaunchKernelGGL(k_publish, grid, block, 0, h->stream, *opt, B);
 		hipLaunchKernelGGL(k_expand, grid, block, 0, h->stream, *opt, B);

@@ -82,7 +82,7 @@ struct Counters {          // device-side bump allocators + flags
 	// algorithmic work counters (bwagpu_stats_t)
 	unsigned long long n_intv, n_chains, n_regs_raw, n_regs;
 	unsigned long long occ_blocks, lf_steps, ext_calls, ext_cells, glb_calls, glb_cells, ref_bases, sw_calls, sw_cells, tab_lookups;
-	unsigned long long prof[16];                   // diagnostics (bwagpu_debug_prof): [13..15] k_seed's wave iterations, bookkeeping iterations, extending lanes (stats runs)
+	unsigned long long prof[16];                   // diagnostics (bwagpu_debug_prof): [12] k_seed iterations that read the interval stack from HBM, [13..15] its wave iterations, bookkeeping iterations, extending lanes (stats runs)
 	unsigned long long ext_fast;                   // ksw_extend2 calls answered by the diagonal rule (no DP)
 	unsigned long long bt_nodes, chain_recs;       // B-tree nodes visited by look-ups / chain records touched (k_chain's algorithmic bytes)
 };
@@ -128,10 +128,14 @@ struct Batch {
 	const u8 *seq;             // concatenated nt4 codes
 	u64 *seq_nib;              // the same bases at 4 bits each, 16 per word (k_pack_reads; read by the seeding kernel)
 	const i64 *off;            // n_reads + 1
+	u32 *seq_2b;               // [n_reads][rd_words]: every read's bases at 2 bits each from a word boundary of its own (k_pack_reads2b) ...
+	u8 *seq_flags;             // ... and per read: 1 = the read holds an N (its lane then reads bases from seq_nib)
+	int rd_words;              // words per read in seq_2b (a multiple of 4), 0: reads too long, no LDS copy
 	Counters *ctr;
 	// --- seeding scratch: per resident lane one interval stack (first entries in LDS, see SeedStack)
 	BiIntv *tmp_intv;          // [n_seed_threads][max_len+1]: spill area of the lanes' interval stacks
 	int seed_lds_ent;          // stack entries per lane kept in LDS (0 when seq_len >= 2^37 or max_len >= 2^16: the packing would not fit)
+	int seed_no_virt;          // diagnostics: keep short matches in the stack as well (see SeedLane::smask)
 	int mem_cap;               // capacity of one read's interval list
 	// --- seeding results
 	i32 *seed_w;               // per read: repetitiveness weight left by k_seed3 (sum of seed-length match occurrences)

@@ -8,14 +8,21 @@
 #include "dev_fm.h"
 #include "dev_sort.h"
 
+#define PTAB_MAX 12      // deepest prefix table
+
 struct SeedEmit {        // the MEM list of the read being seeded (lane-private scratch)
-	Intv3 *mem; int n, cap; bool overflow;
+	Intv3 *intv; int r, n, cap; bool overflow;      // the list is intv[r * cap ..] (the address is rebuilt on use: two registers less per lane)
 	int min_seed_len;
+	DEVFN Intv3 *mem() const { return intv + (size_t)r * (size_t)cap; }
+	// pass 2 (bwamem.c:160-168) walks pass 1's SMEMs looking for the long and rare ones; re-reading the list costs a memory round
+	// trip per entry with the whole wave waiting, so the test is made here and remembered: bit k = entry base + k qualifies
+	int split_len, base; u64 split_width, cand;
 	DEVFN void add(u64 x0, u64 x2, int start, int end) {
 		if (end - start < min_seed_len) return;
 		if (n == cap) { overflow = true; return; }
 		Intv3 v; v.x0 = x0; v.x2 = x2; v.info = (u64)start << 32 | (u32)end;
-		mem[n++] = v;
+		if (end - start >= split_len && x2 <= split_width && n - base < 64) cand |= 1ull << (n - base);
+		mem()[n++] = v;
 	}
 };
 
@@ -34,15 +41,25 @@ struct IntvInfoLess { DEVFN bool operator()(const Intv3 &a, const Intv3 &b) cons
 enum { SS_FETCH = 0, SS_PASS1, SS_PASS2, SS_PASS3, SS_FWD, SS_BWD, SS_STRAT, SS_FINAL, SS_DONE };
 
 struct SeedLane {
-	int st, r, len, x, k2, old_n, pass, n3;
+	int st, len, x, k2, old_n, pass;      // (the read's number is em.r)
 	u64 qoff, win;            // the read's offset in the packed base array; the 16-base window last fetched from it
 	u32 win_w;                // index of that window (~0u: none)
+	const u32 *rd;            // k_seed<true>: the block's LDS copy of its lanes' reads (2 bits per base), [word][lane]
+	int rd_on;                // ... in use for the current read (it holds no N)
+	const u8 *raw; const i64 *off;   // ... and where a read with an N finds its bases (Batch::seq, Batch::off)
 	// current SMEM search (bwt_smem1a, bwt.c:289-351)
 	u64 min_intv, last_x2;
 	int sx, i, n0, nprev, nc, j, c, ret, last_start;
 	bool any;
 	BiIntv ik, p;
 	u32 code;                 // prefix-table window: forward sweep, q[sx..sx+ptab_m); backward sweep, q[i..i+ptab_m) (window_code)
+	// Matches shorter than the prefix tables' depth are not kept in the stack at all: whatever is done with such an entry -- extend it
+	// by a base, compare interval sizes -- is answered by the table for the string it stands for, so its end position is all there is to
+	// know about it.  They are the shortest entries (the deep end of the stack): bit k of smask = there is an entry whose match is k+1
+	// bases long.  An entry that grows to the tables' depth in a backward row is written to the stack then.  (Only with min_seed_len
+	// above that depth: no match that short is ever reported.)
+	u32 smask, srem, snew;    // the row's short entries; those not yet visited; those surviving into the next row
+	int ncl;                  // survivors of the row written to the stack (nc counts the short ones too)
 	int top;                  // index of the longest match in the interval stack (prev[j] = the entry j below the top)
 	int slot;                 // forward sweep: ring position of the next push; backward sweep: ring position of the top entry
 	SeedEmit em;
@@ -56,9 +73,18 @@ struct SeedLane {
 // oldest (shortest) entry to HBM scratch when it wraps; the backward sweep addresses entries by their depth below the top.
 // Keeping the stack out of HBM matters because the kernel runs at the chip's random-request ceiling (profiles/r01_randbw_*).
 struct SeedStack {
-	uint4 *lds;       // this lane's column of the block's LDS array (stride blockDim.x entries)
-	BiIntv *glob;     // spill area, indexed by entry; holds packed uint4 records when n_lds > 0
+	uint4 *lds_base;  // the block's LDS array [slot][lane] (stride blockDim.x entries)
+	BiIntv *glob_base; int glob_cap;   // spill areas of all lanes, glob_cap entries each; a lane's is indexed by entry and holds packed uint4 records when n_lds > 0
+	// (per-lane addresses are rebuilt on use instead of being carried in registers)
+	DEVFN uint4 *lds_col() const { return lds_base + threadIdx.x; }
+	DEVFN BiIntv *glob_col() const { return glob_base + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * (size_t)glob_cap + PTAB_MAX; }   // (a backward row may add one entry at the deep end, see SeedLane::smask)
 	int stride, n_lds;   // n_lds == 0: intervals not packable for this batch, everything in glob (unpacked)
+	int virt_m;          // matches of fewer bases live in SeedLane::smask instead (0: none do)
+	// forward sweep: an entry of the change-point list
+	DEVFN void push_fw(SeedLane &L, const BiIntv &v) const {
+		const int len = (int)v.info - L.sx;
+		if (len < virt_m) L.smask |= 1u << (len - 1); else push(L, v);
+	}
 	static DEVFN uint4 pack(const BiIntv &v) {
 		uint4 w;
 		w.x = (u32)v.x0; w.y = (u32)v.x1; w.z = (u32)v.x2;
@@ -73,10 +99,10 @@ struct SeedStack {
 	}
 	// forward sweep: append entry number L.n0; L.slot is the ring position it goes to
 	DEVFN void push(SeedLane &L, const BiIntv &v) const {
-		if (n_lds == 0) glob[L.n0] = v;
+		if (n_lds == 0) glob_col()[L.n0] = v;
 		else {
-			if (L.n0 >= n_lds) ((uint4*)glob)[L.n0 - n_lds] = lds[L.slot * stride];   // the ring is full: evict the oldest entry
-			lds[L.slot * stride] = pack(v);
+			if (L.n0 >= n_lds) ((uint4*)glob_col())[L.n0 - n_lds] = lds_col()[L.slot * stride];   // the ring is full: evict the oldest entry
+			lds_col()[L.slot * stride] = pack(v);
 			L.slot = L.slot + 1 == n_lds ? 0 : L.slot + 1;
 		}
 		++L.n0;
@@ -84,14 +110,14 @@ struct SeedStack {
 	// backward sweep: the entry `d` below the top (L.top = index of the top entry, L.slot = its ring position)
 	DEVFN int ring(const SeedLane &L, int d) const { int s = L.slot - d; return s < 0 ? s + n_lds : s; }
 	DEVFN void store(const SeedLane &L, int d, const BiIntv &v) const {
-		if (d < n_lds) lds[ring(L, d) * stride] = pack(v);
-		else if (n_lds) ((uint4*)glob)[L.top - d] = pack(v);
-		else glob[L.top - d] = v;
+		if (d < n_lds) lds_col()[ring(L, d) * stride] = pack(v);
+		else if (n_lds) ((uint4*)glob_col())[L.top - d] = pack(v);
+		else glob_col()[L.top - d] = v;
 	}
 	DEVFN BiIntv load(const SeedLane &L, int d) const {
-		if (d < n_lds) return unpack(lds[ring(L, d) * stride]);
-		if (n_lds) return unpack(((const uint4*)glob)[L.top - d]);
-		return glob[L.top - d];
+		if (d < n_lds) return unpack(lds_col()[ring(L, d) * stride]);
+		if (n_lds) return unpack(((const uint4*)glob_col())[L.top - d]);
+		return glob_col()[L.top - d];
 	}
 };
 
@@ -99,8 +125,17 @@ struct SeedStack {
 // for a base at every step; byte loads from the raw read (a different 64-byte line per lane, ~2 MB per XCD of resident
 // lanes against a 4 MB L2 that the index blocks stream through) showed up as memory requests of their own.  k_pack_reads
 // packs the batch to 4 bits per base and each lane keeps the 16-base word it is in; a sweep reloads it every 16 steps.
+// In k_seed that reload stalled the wave almost every iteration (with 64 lanes some lane always crosses a word, and the
+// index blocks cannot be requested before the base is known to the compiler's satisfaction): there the read lives in LDS at 2
+// bits per base, copied once when the lane takes it, and only reads holding an N use the 4-bit array.
 DEVFN int seed_q(SeedLane &L, const u64 *nib, int i)
 {
+	if (L.rd_on) {
+		const u32 w = (u32)i >> 4;
+		if (w != L.win_w) { L.win = L.rd[w * blockDim.x + threadIdx.x]; L.win_w = w; }
+		return (int)((u32)L.win >> (((u32)i & 15) << 1)) & 3;
+	}
+	if (nib == nullptr) { const u8 c = L.raw[L.off[L.em.r] + i]; return c > 3 ? 4 : (int)c; }   // k_seed<true>, a read with an N (rare): byte by byte
 	const u64 g = L.qoff + (u64)i;
 	const u32 w = (u32)(g >> 4);
 	if (w != L.win_w) { L.win = nib[w]; L.win_w = w; }
@@ -123,6 +158,24 @@ __global__ void __launch_bounds__(256) k_pack_reads(Batch B, u64 n_words)
 	}
 }
 
+// 2-bit copy of every read from a word boundary of its own: word j of read r holds its bases [16j, 16j+16), N and positions past
+// the end as 0; a read with an N is flagged (its lane uses the 4-bit array instead)
+__global__ void __launch_bounds__(256) k_pack_reads2b(Batch B)
+{
+	const u64 total = (u64)B.n_reads * (u64)B.rd_words;
+	for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (u64)gridDim.x * blockDim.x) {
+		const int r = (int)(t / (u32)B.rd_words), j = (int)(t % (u32)B.rd_words);
+		const i64 b0 = B.off[r] + 16 * (i64)j, left = B.off[r + 1] - b0;
+		u32 o = 0; bool any_n = false;
+		for (int k = 0; k < 16 && k < left; ++k) {
+			const u32 c = B.seq[b0 + k];
+			if (c > 3) any_n = true; else o |= c << (2 * k);
+		}
+		B.seq_2b[t] = o;
+		if (any_n) B.seq_flags[r] = 1;
+	}
+}
+
 DEVFN void smem_finish(SeedLane &L) { if (L.pass == 1) { L.x = L.ret; L.st = SS_PASS1; } else L.st = SS_PASS2; }
 
 // start backward row i (bwt.c:326-345); rows without a usable base (i < 0 or N) need no extension at all
@@ -132,11 +185,13 @@ DEVFN void bwd_begin_row(SeedLane &L, const SeedStack &S, const u64 *nib, int m)
 		if (L.i < -1) { smem_finish(L); return; }
 		L.c = L.i < 0 ? -1 : seed_q(L, nib, L.i);
 		if (L.c > 3) L.c = -1;
-		L.j = 0; L.nc = 0; L.last_x2 = 0;
+		L.j = 0; L.nc = 0; L.ncl = 0; L.last_x2 = 0; L.srem = L.smask; L.snew = 0;
 		if (L.c >= 0) { if (m > 0) L.code = (u32)L.c << (2 * (m - 1)) | L.code >> 2; L.st = SS_BWD; return; }
 		// every interval stops here; only the longest one (first in prev[]) can be a new MEM
-		BiIntv p = S.load(L, 0);
-		if (!L.any || L.i + 1 < L.last_start) { L.em.add(p.x0, p.x2, L.i + 1, (int)p.info); L.any = true; L.last_start = L.i + 1; }
+		if (!L.any || L.i + 1 < L.last_start) {
+			if (L.nprev > 0) { BiIntv p = S.load(L, 0); L.em.add(p.x0, p.x2, L.i + 1, (int)p.info); }   // (a short entry on top: too short to be reported)
+			L.any = true; L.last_start = L.i + 1;
+		}
 		smem_finish(L);
 		return;
 	}
@@ -169,7 +224,6 @@ DEVFN u32 window_code(SeedLane &L, const u64 *nib, int x, int m)
 	return rc;
 }
 
-#define PTAB_MAX 12
 
 DEVFN void smem_start(const DevIndex &ix, SeedLane &L, const SeedStack &S, const u64 *nib, int x, u64 min_intv, int pass)
 {
@@ -177,10 +231,10 @@ DEVFN void smem_start(const DevIndex &ix, SeedLane &L, const SeedStack &S, const
 	const int c0 = seed_q(L, nib, x);
 	if (c0 > 3) { L.ret = x + 1; smem_finish(L); return; }   // bwt.c:296
 	fm_init(ix, c0, L.ik); L.ik.info = (u64)(x + 1);
-	L.i = x + 1; L.n0 = 0; L.slot = 0;
+	L.i = x + 1; L.n0 = 0; L.slot = 0; L.smask = 0;
 	L.code = window_code(L, nib, x, ix.ptab_m);
 	if (L.i >= L.len || seed_q(L, nib, L.i) > 3) {                          // nothing (more) to extend: push and go backward
-		S.push(L, L.ik); L.ret = (int)L.ik.info;
+		S.push_fw(L, L.ik); L.ret = (int)L.ik.info;
 		fwd_finish(L, S, nib, ix.ptab_m);
 	} else L.st = SS_FWD;
 }
@@ -216,32 +270,38 @@ __global__ void __launch_bounds__(256) k_publish(bwagpu_opt_t opt, Batch B)
 	if (B.stats) atomicAdd(&B.ctr->n_intv, (unsigned long long)nintv);
 }
 
+// RD: the batch's reads are short enough for an LDS copy (Batch::rd_words > 0)
+template<bool RD, bool STATS>
 __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
 	HIP_DYNAMIC_SHARED(uint4, seed_lds)
-	const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-	const int cap = B.max_len + 1;
+	const int cap = B.max_len + 1 + PTAB_MAX;
 	const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
 	SeedLane L;
 	SeedStack S;
-	S.lds = seed_lds + threadIdx.x; S.stride = blockDim.x; S.n_lds = B.seed_lds_ent;
-	S.glob = B.tmp_intv + (size_t)tid * cap;
-	L.em.mem = B.intv; L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len;
-	L.st = SS_FETCH; L.r = -1; L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u;
-	const u64 *nib = B.seq_nib;
+	S.lds_base = seed_lds; S.stride = blockDim.x; S.n_lds = B.seed_lds_ent;
+	S.glob_base = B.tmp_intv; S.glob_cap = cap;
+	S.virt_m = (ix.ptab_m >= 2 && opt.min_seed_len > ix.ptab_m && !B.seed_no_virt) ? ix.ptab_m : 0;
+	L.smask = L.srem = L.snew = 0; L.ncl = 0;
+	L.em.intv = B.intv; L.em.r = -1; L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len;
+	L.em.split_len = split_len; L.em.split_width = (u64)opt.split_width; L.em.cand = 0; L.em.base = 0;
+	L.st = SS_FETCH; L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u;
+	u32 *rd_lds = (u32*)(seed_lds + (size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * blockDim.x);   // (after the stacks)
+	L.rd = rd_lds; L.rd_on = 0; L.raw = B.seq; L.off = B.off;
+	const u64 *nib = RD ? nullptr : B.seq_nib;
 	u32 nblk = 0, ntab = 0;
 	// Reads are drawn from the batch counter 64 at a time into a pool of the wave, and lanes that finish a read take the pool's
 	// next one: a per-lane atomicAdd would be 10^6 same-address atomics per batch, which alone take ~13 ms on this chip.
-	int pool_base = 0, pool_cnt = 0;
+	int pool_base = 0, pool_cnt = 0, pool_r = 0;
 	// The bookkeeping between extensions (next read, next search of a pass, publishing a read's intervals) is a few hundred
 	// instructions that a wave executes whenever ANY of its lanes needs them -- with 64 lanes, in nine iterations out of ten, for one
 	// or two lanes each time (measured: 700 VALU instructions per iteration, 280 of them the extension).  Lanes therefore wait in
 	// their bookkeeping state until eight of them have gathered (or three iterations have passed, or nobody can extend), and the
 	// wave then runs that code once for all of them.
 	int deferred = 0;
-	u32 n_iter = 0, n_slow = 0, n_ext_lanes = 0;
+	u32 n_iter = 0, n_slow = 0, n_ext_lanes = 0, n_deep = 0;
 	while (L.st != SS_DONE) {
-		++n_iter;
+		if (STATS) ++n_iter;
 		const bool slow = L.st < SS_FWD || L.st == SS_FINAL;
 		const u64 sm = __ballot(slow);
 		bool run_slow = false;
@@ -250,9 +310,9 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			run_slow = __popcll(sm) >= 8 || sm == am || ++deferred >= 3;
 		}
 		if (run_slow) {
-			deferred = 0; ++n_slow;
+			deferred = 0; if (STATS) ++n_slow;
 			if (L.st == SS_FINAL) {
-				if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull); else B.intv_n[L.r] = L.em.n;
+				if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull); else B.intv_n[L.em.r] = L.em.n;
 				L.st = SS_FETCH;
 			}
 			const bool want = L.st == SS_FETCH;
@@ -262,23 +322,39 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 					const int first = __ffsll((unsigned long long)__ballot(1)) - 1;        // lane 0 may already have left the loop
 					const unsigned long long old = atomicAdd(&B.ctr->next_read, (threadIdx.x & 63) == first ? 64ull : 0ull);
 					pool_base = __shfl((int)old, first); pool_cnt = 64;
+					// lane l looks up the pool's read number l now: a lane taking a read later gets it from a register of the wave
+					// instead of a memory round trip of its own in front of the reads of the read's data
+					{ const int idx = pool_base + (int)(threadIdx.x & 63); pool_r = idx < B.n_reads ? (B.seed_order ? B.seed_order[idx] : idx) : 0; }
 					// the waves holding the (predicted) heaviest reads get issue priority: a lane's long chain of dependent extensions then
 					// advances at the pace of the wave alone on its SIMD instead of a quarter of it
 					if (B.seed_order && B.seed_prio) { if (pool_base < B.n_reads / 32) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
 				}
 				const int rank = __popcll(wm & ((1ull << (threadIdx.x & 63)) - 1));
+				// k_seed3 ran first: it left the read's LAST-like seeds in the list and a repetitiveness weight by which the reads were
+				// ordered heaviest first (a read inside a repeat family is a chain of 10-20 k dependent blocks -- started last, it alone
+				// kept the kernel running for another 15 ms)
+				const int r = __shfl(pool_r, (64 - pool_cnt + rank) & 63);
 				if (want && rank < pool_cnt) {
 					const int idx = pool_base + rank;
 					if (idx >= B.n_reads) L.st = SS_DONE;
 					else {
-						// k_seed3 ran first: it left the read's LAST-like seeds in the list and a repetitiveness weight by which the
-						// reads were ordered heaviest first (a read inside a repeat family is a chain of 10-20 k dependent blocks --
-						// started last, it alone kept the kernel running for another 15 ms)
-						const int r = B.seed_order ? B.seed_order[idx] : idx;
-						L.r = r; L.qoff = (u64)B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
+						L.em.r = r; L.qoff = (u64)B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
+						L.win_w = ~0u;
+						if (RD) {
+							L.rd_on = !B.seq_flags[r];      // the read's bases into LDS (2 bits each; at most four 16-byte pieces)
+							const uint4 *src = (const uint4*)(B.seq_2b + (size_t)r * (u32)B.rd_words);
+							u32 *dst = rd_lds + threadIdx.x;
+							const int n4 = B.rd_words >> 2;
+#pragma unroll
+							for (int q = 0; q < 4; ++q)
+								if (q < n4) {
+									const uint4 v = src[q];
+									dst[(4 * q + 0) * blockDim.x] = v.x; dst[(4 * q + 1) * blockDim.x] = v.y; dst[(4 * q + 2) * blockDim.x] = v.z; dst[(4 * q + 3) * blockDim.x] = v.w;
+								}
+						}
 						if (B.seed_pass3_inline) B.intv_n[r] = 0;
-						L.em.mem = B.intv + (size_t)r * B.mem_cap;      // the read's own interval list (sorted and consumed by k_publish)
-						L.em.n = B.seed_pass3_inline ? 0 : B.intv_n[r]; L.n3 = L.em.n; L.em.overflow = false;
+						L.em.n = B.seed_pass3_inline ? 0 : B.intv_n[r]; L.em.base = L.em.n; L.em.overflow = false;   // (base: the entries after pass 3's)
+						L.em.cand = 0;
 						if (L.len >= opt.min_seed_len) { L.x = 0; L.st = SS_PASS1; }   // else mem_chain returns at once (bwamem.c:286): draw the next read
 					}
 				}
@@ -290,13 +366,20 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 				switch (L.st) {
 				case SS_PASS1:   // pass 1: all SMEMs, left to right (bwamem.c:147-157)
 					while (L.x < L.len && seed_q(L, nib, L.x) > 3) ++L.x;
-					if (L.x >= L.len) { L.old_n = L.em.n; L.k2 = L.n3; L.st = SS_PASS2; }   // pass 2 re-seeds pass 1's SMEMs (the entries after pass 3's)
+					if (L.x >= L.len) { L.old_n = L.em.n; L.k2 = L.em.base; L.st = SS_PASS2; }   // pass 2 re-seeds pass 1's SMEMs (the entries after pass 3's)
 					else smem_start(ix, L, S, nib, L.x, 1, 1);
 					break;
 				case SS_PASS2: { // pass 2: re-seed from the middle of long, rare SMEMs (bwamem.c:160-168)
 					bool started = false;
 					while (L.k2 < L.old_n && !started) {
-						Intv3 p = L.em.mem[L.k2++];
+						const int kk = L.k2 - L.em.base;          // skip the entries the emitter already found not to qualify
+						if (kk < 64) {
+							const u64 rest = L.em.cand >> kk;
+							if (rest == 0) { L.k2 = L.em.base + 64 < L.old_n ? L.em.base + 64 : L.old_n; continue; }
+							L.k2 += __ffsll((unsigned long long)rest) - 1;
+							if (L.k2 >= L.old_n) break;
+						}
+						Intv3 p = L.em.mem()[L.k2++];
 						int start = (int)(p.info >> 32), end = (int)(u32)p.info;
 						if (end - start >= split_len && p.x2 <= (u64)opt.split_width) { smem_start(ix, L, S, nib, (start + end) >> 1, p.x2 + 1, 2); started = true; }
 					}
@@ -320,11 +403,20 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 		}
 		// ---- the one expensive, convergent step: an FM extension ---------------------------------------------------------
 		const int st = L.st;
-		if (B.stats) n_ext_lanes += (u32)__popcll(__ballot(st == SS_FWD || st == SS_BWD || st == SS_STRAT));
+		if (STATS) n_ext_lanes += (u32)__popcll(__ballot(st == SS_FWD || st == SS_BWD || st == SS_STRAT));
+		if (STATS && __ballot(st == SS_BWD && L.j >= S.n_lds && L.j < L.nprev)) ++n_deep;
 		if (st == SS_FWD || st == SS_BWD || st == SS_STRAT) {
 			BiIntv ok, src;
 			const int back = st == SS_BWD;
-			if (back) L.p = S.load(L, L.j);
+			bool short_ent = false;
+			if (back) {
+				if (L.j < L.nprev) L.p = S.load(L, L.j);
+				else {                                   // the stack's entries are done: the short ones, longest first
+					const int len = 32 - __clz((int)L.srem);
+					L.srem &= ~(1u << (len - 1));
+					L.p.x0 = L.p.x1 = L.p.x2 = 0; L.p.info = (u64)(L.i + 1 + len); short_ent = true;
+				}
+			}
 			src.x0 = back ? L.p.x0 : L.ik.x0; src.x1 = back ? L.p.x1 : L.ik.x1; src.x2 = back ? L.p.x2 : L.ik.x2; src.info = 0;
 			const int qi = back ? 0 : seed_q(L, nib, L.i);
 			const int cb = back ? L.c : 3 - qi;
@@ -335,17 +427,17 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			const int tl = back ? (int)L.p.info - L.i : L.i - L.sx + 1;    // length of the extended match
 			if (tl <= ix.ptab_m) {
 				ptab_load(ix, tl, L.code, ok);
-				++ntab;
-			} else nblk += fm_extend1(ix, src, cb, back, ok);   // the only extension site of the kernel
+				if (STATS) ++ntab;
+			} else { const u32 nb = fm_extend1(ix, src, cb, back, ok); if (STATS) nblk += nb; }   // the only extension site of the kernel
 			if (st == SS_FWD) {           // forward sweep of bwt_smem1a (bwt.c:304-320)
 				bool stop = false;
 				if (ok.x2 != L.ik.x2) {
-					S.push(L, L.ik); L.ret = (int)L.ik.info;
+					S.push_fw(L, L.ik); L.ret = (int)L.ik.info;
 					if (ok.x2 < L.min_intv) stop = true;
 				}
 				if (!stop) {
 					ok.info = (u64)(L.i + 1); L.ik = ok; ++L.i;
-					if (L.i >= L.len || seed_q(L, nib, L.i) > 3) { S.push(L, L.ik); L.ret = (int)L.ik.info; stop = true; }
+					if (L.i >= L.len || seed_q(L, nib, L.i) > 3) { S.push_fw(L, L.ik); L.ret = (int)L.ik.info; stop = true; }
 				}
 				if (stop) fwd_finish(L, S, nib, ix.ptab_m);
 			} else if (st == SS_BWD) {    // one interval of one backward row (bwt.c:328-342)
@@ -354,11 +446,16 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 						L.em.add(L.p.x0, L.p.x2, L.i + 1, (int)L.p.info); L.any = true; L.last_start = L.i + 1;
 					}
 				} else if (L.nc == 0 || ok.x2 != L.last_x2) {
-					ok.info = L.p.info; S.store(L, L.nc, ok); ++L.nc; L.last_x2 = ok.x2;   // in place: nc <= j
+					ok.info = L.p.info;
+					const int nl = (int)L.p.info - L.i;      // bases of the extended match
+					if (nl < S.virt_m) L.snew |= 1u << (nl - 1);
+					else { S.store(L, L.ncl, ok); ++L.ncl; }   // in place: ncl <= j, or one past the deep end for a short entry that has grown up
+					++L.nc; L.last_x2 = ok.x2;
 				}
-				if (++L.j == L.nprev) {
+				if (!short_ent) ++L.j;
+				if (L.j >= L.nprev && L.srem == 0) {
 					if (L.nc == 0) smem_finish(L);
-					else { L.nprev = L.nc; --L.i; bwd_begin_row(L, S, nib, ix.ptab_m); }
+					else { L.nprev = L.ncl; L.smask = L.snew; --L.i; bwd_begin_row(L, S, nib, ix.ptab_m); }
 				}
 			} else {                      // bwt_seed_strategy1 (bwt.c:364-377)
 				if (ok.x2 < opt.max_mem_intv && L.i - L.sx >= opt.min_seed_len) {
@@ -372,9 +469,9 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			}
 		}
 	}
-	if (B.stats) {
+	if (STATS) {
 		atomicAdd(&B.ctr->occ_blocks, (unsigned long long)nblk); atomicAdd(&B.ctr->tab_lookups, (unsigned long long)ntab);
-		if ((threadIdx.x & 63) == 0) { atomicAdd(&B.ctr->prof[13], (unsigned long long)n_iter); atomicAdd(&B.ctr->prof[14], (unsigned long long)n_slow); atomicAdd(&B.ctr->prof[15], (unsigned long long)n_ext_lanes); }
+		if ((threadIdx.x & 63) == 0) { atomicAdd(&B.ctr->prof[12], (unsigned long long)n_deep); atomicAdd(&B.ctr->prof[13], (unsigned long long)n_iter); atomicAdd(&B.ctr->prof[14], (unsigned long long)n_slow); atomicAdd(&B.ctr->prof[15], (unsigned long long)n_ext_lanes); }
 	}
 }
 
@@ -387,8 +484,9 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 __global__ void __launch_bounds__(256) k_seed3(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
 	SeedLane L;                   // only the read window (qoff, win, win_w, len), x, sx, i, ik, code and the emitter are used
-	L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len; L.em.mem = B.intv; L.em.n = 0; L.em.overflow = false;
-	L.r = -1; L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u; L.x = 0; L.sx = 0; L.i = 0; L.code = 0;
+	L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len; L.em.intv = B.intv; L.em.r = -1; L.em.n = 0; L.em.overflow = false;
+	L.em.split_len = 0x7fffffff; L.em.split_width = 0; L.em.cand = 0; L.em.base = 0;
+	L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u; L.x = 0; L.sx = 0; L.i = 0; L.code = 0; L.rd = nullptr; L.rd_on = 0; L.raw = nullptr; L.off = nullptr;
 	L.ik.x0 = L.ik.x1 = L.ik.x2 = L.ik.info = 0;
 	const u64 *nib = B.seq_nib;
 	const int lane = threadIdx.x & 63;
@@ -408,8 +506,8 @@ __global__ void __launch_bounds__(256) k_seed3(DevIndex ix, bwagpu_opt_t opt, Ba
 				const int r = pool_base + rank;
 				if (r >= B.n_reads) st = T_DONE;
 				else {
-					L.r = r; L.qoff = (u64)B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
-					L.em.mem = B.intv + (size_t)r * B.mem_cap; L.em.n = 0; L.em.overflow = false;
+					L.em.r = r; L.qoff = (u64)B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
+					L.em.n = 0; L.em.overflow = false;
 					B.intv_n[r] = 0; B.seed_w[r] = 0; weight = 0;
 					if (L.len >= opt.min_seed_len && opt.max_mem_intv > 0) { L.x = 0; st = T_START; }   // mem_chain returns at once for shorter reads (bwamem.c:286)
 				}
@@ -420,8 +518,8 @@ __global__ void __launch_bounds__(256) k_seed3(DevIndex ix, bwagpu_opt_t opt, Ba
 		if (st == T_START) {
 			while (L.x < L.len && seed_q(L, nib, L.x) > 3) ++L.x;
 			if (L.x >= L.len) {
-				if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull); else B.intv_n[L.r] = L.em.n;
-				B.seed_w[L.r] = (i32)(weight > 0x3fffffffu ? 0x3fffffffu : weight);
+				if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull); else B.intv_n[L.em.r] = L.em.n;
+				B.seed_w[L.em.r] = (i32)(weight > 0x3fffffffu ? 0x3fffffffu : weight);
 				st = T_FETCH;
 			} else {
 				fm_init(ix, seed_q(L, nib, L.x), L.ik); L.sx = L.x; L.i = L.x + 1;

@@ -9,16 +9,27 @@ from bwa_amd import simdata
 from bwa_amd.api import BwaGpu
 from bwa_amd.structs import default_opt
 prefix, g, _ = bench.build_or_load_index(float(os.environ.get("MBP", "3100")), "/tmp/bwa_amd_bench", 0, lambda: None)
-gpu = BwaGpu(prefix); gpu.densify_sa(4); gpu.set_taps(False)
 opt = default_opt(); opt.flag |= 2
 r1, r2 = simdata.make_reads_pe(g, 500_000, seed=1000)
 rd = bench.interleave(r1, r2)
-gpu.upload(np.ascontiguousarray(rd.reshape(-1)), np.arange(0, rd.shape[0] + 1, dtype=np.int64) * 150)
-gpu.set_stats(True); gpu.run(opt)
-s = gpu.stats()
-out = (C.c_ulonglong * 16)()
-gpu.L.bwagpu_debug_prof.argtypes = [C.c_void_p, C.c_void_p]
-gpu.L.bwagpu_debug_prof(gpu.h, out)
-it, slow, ext = out[13], out[14], out[15]
-print(f"k_seed {s['ms_seed']:.1f} ms: wave iterations {it:.4g}, with bookkeeping {slow:.4g} ({100.0 * slow / it:.1f}%), lanes extending per iteration {ext / it:.1f} of 64; "
-      f"lane steps {s['n_occ_blocks']} blocks + {s['n_tab_lookups']} table look-ups")
+flat = np.ascontiguousarray(rd.reshape(-1)); off = np.arange(0, rd.shape[0] + 1, dtype=np.int64) * 150
+# every argument is one configuration: space-separated NAME=VALUE environment settings ("" = defaults)
+for cfg in (sys.argv[1:] or [""]):
+    sets = dict(kv.split("=", 1) for kv in cfg.split())
+    for k, v in sets.items():
+        os.environ[k] = v
+    gpu = BwaGpu(prefix); gpu.densify_sa(4); gpu.set_taps(False)
+    gpu.upload(flat, off)
+    gpu.set_stats(False); gpu.run(opt); gpu.run(opt); ms_plain = gpu.stats()
+    gpu.set_stats(True); gpu.run(opt)
+    s = gpu.stats()
+    out = (C.c_ulonglong * 16)()
+    gpu.L.bwagpu_debug_prof.argtypes = [C.c_void_p, C.c_void_p]
+    gpu.L.bwagpu_debug_prof(gpu.h, out)
+    it, slow, ext, deep = out[13], out[14], out[15], out[12]
+    print(f"[{cfg or 'defaults'}] k_seed {ms_plain['ms_seed']:.1f} ms (with counters {s['ms_seed']:.1f}), chain {ms_plain['ms_chain']:.1f} extend {ms_plain['ms_extend']:.1f} dedup {ms_plain['ms_dedup']:.1f} total {ms_plain['ms_total']:.1f}: "
+          f"wave iterations {it:.4g}, reading the stack from HBM {deep:.4g} ({100.0 * deep / max(it, 1):.1f}%), with bookkeeping {slow:.4g} ({100.0 * slow / max(it, 1):.1f}%), "
+          f"lanes extending per iteration {ext / max(it, 1):.1f} of 64; lane steps {s['n_occ_blocks']} blocks + {s['n_tab_lookups']} table look-ups; regs {s['n_regs']}", flush=True)
+    gpu.close()
+    for k in sets:
+        del os.environ[k]
