@@ -660,13 +660,17 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		int ring_cols = 256;                     // long reads: ring of {H,E} columns wide enough for the widest band (2 * opt.w, bwamem.c:742)
 		while (ring_cols < 4 * opt->w + 4 + 128) ring_cols <<= 1;
 		if (h->max_len <= WAVE_EXT_MAX_LEN && max_score < (1 << 24)) {
-			int lds_wave = (8 * (h->max_len + 2 + 64) + 5 * ((h->max_len + 64 + 3) & ~3) + 15) & ~15;
+			int lds_wave = (8 * (h->max_len + 2 + 64) + 5 * ((h->max_len + 64 + 3) & ~3) + 32 + 15) & ~15;   // {H,E} columns, query profile, scoring matrix
 			i64 nblk = ((i64)n + 3) / 4, cap = 256 * 8;
-			hipLaunchKernelGGL(k_extend_wave<false>, dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
+			const int occ = getenv("BWAGPU_EXT_OCC") ? atoi(getenv("BWAGPU_EXT_OCC")) : 6;   // waves per SIMD the register allocation aims at (measured at 3.1 Gbp: 4 -> 63 ms, 5 -> 58 ms, 6 -> 56 ms)
+			const dim3 g((unsigned)(nblk < cap ? nblk : cap));
+			if (occ == 6) hipLaunchKernelGGL((k_extend_wave<false, 6>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
+			else if (occ == 5) hipLaunchKernelGGL((k_extend_wave<false, 5>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
+			else hipLaunchKernelGGL((k_extend_wave<false, 4>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
 		} else if (max_score < (1 << 24) && ring_cols <= 2048) {
 			int lds_wave = 8 * ring_cols + 32;   // the band's columns only: independent of the read length
 			i64 nblk = ((i64)n + 3) / 4, cap = 256 * 8;
-			hipLaunchKernelGGL(k_extend_wave<true>, dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, ring_cols);
+			hipLaunchKernelGGL((k_extend_wave<true, 4>), dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, ring_cols);
 		} else                                  // very wide bands: lane-per-read scalar DP with the columns in HBM scratch
 			hipLaunchKernelGGL(k_extend, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[5], h->stream));

@@ -93,7 +93,7 @@ DEVFN bwagpu_seed_t uni_seed(bwagpu_seed_t s) { s.rbeg = uni64(s.rbeg); s.qbeg =
 // ksw_extend2 only touches columns i-w .. i+w+1, columns left of the band are dead and columns right of it still hold their
 // first-row values, so eh[] is a ring of ring_mask+1 columns that is initialised lazily as the band advances, and scores come
 // from a 25-entry copy of the matrix (mat) and the query bases in global memory.
-struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t *mat; };
+struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t *mat; unsigned long long *prof; };   // prof: stats runs only (Counters::prof)
 
 template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, int mat_max, const u8 *q, int q0, const int qdir, int qlen,
 								   i64 t0, const int tdir, int tlen, int w, int end_bonus, int h0, const WaveLds &L, u64 &cells, u64 &fast)
@@ -115,13 +115,16 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 	// to-end score is gscore = V_{qlen-1} at gtle = qlen (ksw.c:486-489), and neither m == 0 nor the z-drop test (which
 	// would need max - m > zdrop > P) ends the loop before that row.  Needs tlen >= qlen.  At 1 % substitutions this covers
 	// most extensions of a read's true locus: a couple of wave steps instead of ~60 rows.
+	// score of reference base b against column j's query base: the read's profile (built once per read, indexed in the read's own
+	// coordinates whichever way the extension runs), or for long reads the matrix copy and the base itself
+	#define SCORE_AT(b, j) (RING ? (int)L.mat[(b) * 5 + q[q0 + (j) * qdir]] : (int)qp[(b) * qs + q0 + (j) * qdir])
 	if (tlen >= qlen && qlen > 0) {
 		const int oe_min = oe_del < oe_ins ? oe_del : oe_ins;
 		int P = 0;
 		for (int b = 0; b < qlen && P < oe_min; b += 64) {
 			const int j = b + lane;
 			int loss = 0;
-			if (j < qlen) loss = mat_max - (int)opt.mat[ref_base(ix, t0 + (i64)j * tdir) * 5 + q[q0 + j * qdir]];
+			if (j < qlen) loss = mat_max - SCORE_AT(ref_base(ix, t0 + (i64)j * tdir), j);
 			for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o);
 			P += loss;
 		}
@@ -130,7 +133,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			for (int b = 0; b < qlen; b += 64) {
 				const int j = b + lane;
 				int sc = 0;
-				if (j < qlen) sc = (int)opt.mat[ref_base(ix, t0 + (i64)j * tdir) * 5 + q[q0 + j * qdir]];
+				if (j < qlen) sc = SCORE_AT(ref_base(ix, t0 + (i64)j * tdir), j);
 				int inc = sc;                                  // inclusive prefix sum over the wave
 				for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
 				const int v = run + inc;
@@ -146,12 +149,10 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			return r;
 		}
 	}
-	// query profile (ksw.c:425-428) and first row (ksw.c:430-433: H(-1,-1) = h0, then an insertion ramp)
+	// first row (ksw.c:430-433: H(-1,-1) = h0, then an insertion ramp); the query profile (ksw.c:425-428) is the read's, see ext_read_wave
 	#define EHI(j) (RING ? ((j) & L.ring_mask) : (j))
 	const int v1 = h0 > oe_ins ? h0 - oe_ins : 0;
 	if (!RING) {
-		for (int k = 0; k < 5; ++k)
-			for (int j = lane; j < qlen; j += 64) qp[k * qs + j] = opt.mat[k * 5 + q[q0 + j * qdir]];
 		for (int j = lane; j <= qlen; j += 64) {
 			int hv = j == 0 ? h0 : v1 - (j - 1) * e_ins;
 			eh[j] = make_int2(hv > 0 ? hv : 0, 0);
@@ -162,11 +163,12 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 	int lim = (int)((double)(qlen * mat_max + end_bonus - o_ins) / e_ins + 1.); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	lim = (int)((double)(qlen * mat_max + end_bonus - o_del) / e_del + 1.); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	int beg = 0, end = qlen, max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, treg = 0;
-	u32 cells32 = 0;
+	u32 cells32 = 0, rows1 = 0, rows2 = 0, rowsn = 0;
+	const bool two_col_ok = h0 + qlen * mat_max < (1 << 23);      // (score << 7 | column) must fit the scan's 31 bits
 	for (int i = 0; i < tlen; ++i) {
 		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
 		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
-		const int8_t *qrow = qp + tb * qs;
+		const int8_t *qrow = qp + tb * qs + q0;        // column j's score is qrow[j * qdir]
 		if (beg < i - w) beg = i - w;
 		if (end > i + w + 1) end = i + w + 1;
 		if (end > qlen) end = qlen;
@@ -189,10 +191,10 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		if (!RING && end - beg <= 64) {
 			// The band fits one pass of the wave (always, for 150 bp reads): the same arithmetic without the pass loop and its carries
 			// -- the kernel is bound by scalar instructions (one scalar unit per CU), and the loop's control was half of them.
-			const int nact = end - beg;
+			const int nact = end - beg; ++rows1;
 			const int j = beg + lane; const bool act = lane < nact;
 			const int2 old = eh[j];                           // (the LDS region is padded by 64 columns)
-			const int sc = qrow[j];
+			const int sc = qrow[(act ? j : beg) * qdir];
 			wave_sync();
 			const int M = old.x ? old.x + sc : 0;          // ksw.c:469: a dead diagonal cell stays dead
 			const int a = act ? imax(M - oe_ins, 0) + j * e_ins : W_NEG;
@@ -211,14 +213,47 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			if (key >= 0) { m = key >> 6; mj = beg + (key & 63); }
 			if (nact) hprev = __builtin_amdgcn_readlane(h, nact - 1);
 			wave_sync();
+		} else if (!RING && end - beg <= 128 && two_col_ok) {
+			// 65..128 columns (the longer half of a 150 bp read's extensions): each lane owns two adjacent columns, so the row still takes ONE
+			// prefix scan for F and one for the row maximum instead of two passes of the loop below with their carries.  A lane's two
+			// {H,E} slots are read and written by that lane only -- H(i,j) reaches the owner of column j+1 through a lane shift, not LDS.
+			const int nact = end - beg; ++rows2;
+			const int jA = beg + 2 * lane, jB = jA + 1;
+			const bool actA = jA < end, actB = jB < end;
+			const int2 oA = eh[jA], oB = eh[jB];               // (the LDS region is padded by 64 columns past the longest read)
+			const int scA = qrow[(actA ? jA : beg) * qdir], scB = qrow[(actB ? jB : beg) * qdir];
+			const int MA = oA.x ? oA.x + scA : 0, MB = oB.x ? oB.x + scB : 0;      // ksw.c:469
+			const int aA = actA ? imax(MA - oe_ins, 0) + jA * e_ins : W_NEG;
+			const int aB = actB ? imax(MB - oe_ins, 0) + jB * e_ins : W_NEG;
+			const int exc = wave_shift_up1(wave_incl_scan_max(imax(aA, aB)), W_NEG);   // best insertion start among the columns of the lanes below
+			const int fA = lane == 0 ? 0 : exc - (jA - 1) * e_ins;
+			const int fB = imax(exc, aA) - (jB - 1) * e_ins;
+			const int hA = imax(imax(MA, oA.y), fA), hB = imax(imax(MB, oB.y), fB);   // ksw.c:470-471
+			const int eA = imax(imax(oA.y - e_del, MA - oe_del), 0), eB = imax(imax(oB.y - e_del, MB - oe_del), 0);   // ksw.c:475-479
+			const int hleftA = wave_shift_up1(hB, h1_init);                       // H(i, jA-1): the lane below's second column
+			if (jA <= end) eh[jA] = make_int2(hleftA, actA ? eA : 0);                 // (column `end` gets {h1, 0}, ksw.c:485)
+			if (jB <= end) eh[jB] = make_int2(hA, actB ? eB : 0);
+			const u64 nzA = __ballot(actA && (hleftA | eA) != 0), nzB = __ballot(actB && (hA | eB) != 0);
+			if (nzA | nzB) {
+				const int fa = nzA ? 2 * __builtin_ctzll(nzA) : 1 << 20, fb = nzB ? 2 * __builtin_ctzll(nzB) + 1 : 1 << 20;
+				const int la = nzA ? 2 * (63 - __builtin_clzll(nzA)) : -1, lb = nzB ? 2 * (63 - __builtin_clzll(nzB)) + 1 : -1;
+				first_nz = beg + (fa < fb ? fa : fb); last_nz = beg + (la > lb ? la : lb);
+			}
+			const int kA = actA ? (hA << 7 | 2 * lane) : -1, kB = actB ? (hB << 7 | (2 * lane + 1)) : -1;   // last column wins ties (ksw.c:473-474)
+			const int key = __builtin_amdgcn_readlane(wave_incl_scan_max(imax(kA, kB)), 63);
+			if (key >= 0) { m = key >> 7; mj = beg + (key & 127); }
+			const int lastc = nact - 1;
+			hprev = (lastc & 1) ? __builtin_amdgcn_readlane(hB, lastc >> 1) : __builtin_amdgcn_readlane(hA, lastc >> 1);
+			wave_sync();
 		} else {
 			for (int b = beg; b < end; b += 64) {
+				++rowsn;
 				const int j = b + lane; const bool act = j < end;
 				// the LDS region is padded by 64 columns, so inactive lanes may read (never write) past `end`
 				int2 old = eh[EHI(j)];
 				int sc;
 				if (RING) { const int qc = j < qlen ? (int)q[q0 + j * qdir] : 4; sc = L.mat[tb * 5 + qc]; }
-				else sc = qrow[j];
+				else sc = qrow[(act ? j : beg) * qdir];
 				const int bnd_next = eh[EHI(b + 64)].x;             // next pass's diagonal for its lane 0, before lane 63 overwrites it
 				if (b != beg && lane == 0) old.x = bnd;
 				wave_sync();
@@ -269,7 +304,12 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		end = jl + 2 < qlen ? jl + 2 : qlen;
 	}
 	#undef EHI
+	#undef SCORE_AT
 	cells += cells32;
+	if (L.prof && lane == 0) {   // [6] DP calls, [7] their query columns, [8..10] rows of one column per lane / two / passes of the general loop
+		atomicAdd(L.prof + 6, 1ull); atomicAdd(L.prof + 7, (unsigned long long)qlen);
+		atomicAdd(L.prof + 8, (unsigned long long)rows1); atomicAdd(L.prof + 9, (unsigned long long)rows2); atomicAdd(L.prof + 10, (unsigned long long)rowsn);
+	}
 	ExtRes r; r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
 	return r;
 }
@@ -292,6 +332,13 @@ template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwa
 	u64 *srt_all = R.srt;
 	bwagpu_alnreg_t *av = B.regs + uni64(B.reg_off[r]);
 	int n_av = 0, sbeg = 0, mat_max = opt_mat_max(opt);
+	if (!RING) {     // query profile of the whole read (ksw.c:425-428 builds one per call): every extension of the read indexes into it
+		for (int j = lane; j < l_query; j += 64) {
+			const int qc = query[j];
+			for (int k = 0; k < 5; ++k) L.qp[k * L.qstride + j] = L.mat[k * 5 + qc];
+		}
+		wave_sync();
+	}
 	for (int ci = 0; ci < n_ch; ++ci) {
 		const bwagpu_chain_t c = chains[ci];
 		const bwagpu_seed_t *seeds = seeds_all + sbeg;
@@ -423,23 +470,26 @@ template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwa
 
 // One wavefront per read, 4 waves per workgroup; dynamic LDS = 4 private regions of
 // 8*(max_len+2+64) bytes of {H,E} columns + 5*qstride bytes of query profile, or (RING, long reads) of ring_cols*8 + 32 bytes.
-template <bool RING> __global__ void __launch_bounds__(256) k_extend_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int lds_per_wave, int ring_cols)
+template <bool RING, int OCC> __global__ void __launch_bounds__(256, OCC) k_extend_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int lds_per_wave, int ring_cols)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, dyn_lds)
 	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	WaveLds L;
 	unsigned char *base = dyn_lds + (size_t)wave_in_blk * lds_per_wave;
 	L.eh = (int2*)base;                                      // max_len + 2 columns + 64 of read-only padding
+	L.prof = B.stats ? B.ctr->prof : nullptr;
 	if (RING) {
 		int8_t *m = (int8_t*)(base + (size_t)8 * ring_cols);
 		if (lane < 25) m[lane] = opt.mat[lane];
 		L.mat = m; L.ring_mask = ring_cols - 1; L.qp = nullptr; L.qstride = 0;
-		wave_sync();
 	} else {
 		L.qstride = (B.max_len + 64 + 3) & ~3;
 		L.qp = (int8_t*)(base + (size_t)8 * (B.max_len + 2 + 64));
-		L.mat = nullptr; L.ring_mask = 0;
+		int8_t *m = L.qp + 5 * L.qstride;                  // (the scoring matrix: dynamic indexing of the kernel argument would go through scratch memory)
+		if (lane < 25) m[lane] = opt.mat[lane];
+		L.mat = m; L.ring_mask = 0;
 	}
+	wave_sync();
 	u64 calls = 0, cells = 0, refb = 0, nraw = 0, fast = 0;
 	// Reads are handed out heaviest first from a global counter: a wave that drew light reads simply draws more of them, and
 	// the launch needs no particular relation between its grid and the number of resident workgroups.

@@ -20,7 +20,11 @@ for cfg in (sys.argv[1:] or [""]):
         os.environ[k] = v
     gpu = BwaGpu(prefix); gpu.densify_sa(4); gpu.set_taps(False)
     gpu.upload(flat, off)
-    gpu.set_stats(False); gpu.run(opt); gpu.run(opt); ms_plain = gpu.stats()
+    gpu.set_stats(False); gpu.run(opt)
+    runs = []
+    for _ in range(4):
+        gpu.run(opt); runs.append(gpu.stats())
+    ms_plain = {k: min(r[k] for r in runs) for k in ("ms_seed", "ms_chain", "ms_extend", "ms_dedup", "ms_total")}
     gpu.set_stats(True); gpu.run(opt)
     s = gpu.stats()
     out = (C.c_ulonglong * 16)()
@@ -29,7 +33,8 @@ for cfg in (sys.argv[1:] or [""]):
     it, slow, ext, deep = out[13], out[14], out[15], out[12]
     print(f"[{cfg or 'defaults'}] k_seed {ms_plain['ms_seed']:.1f} ms (with counters {s['ms_seed']:.1f}), chain {ms_plain['ms_chain']:.1f} extend {ms_plain['ms_extend']:.1f} dedup {ms_plain['ms_dedup']:.1f} total {ms_plain['ms_total']:.1f}: "
           f"wave iterations {it:.4g}, reading the stack from HBM {deep:.4g} ({100.0 * deep / max(it, 1):.1f}%), with bookkeeping {slow:.4g} ({100.0 * slow / max(it, 1):.1f}%), "
-          f"lanes extending per iteration {ext / max(it, 1):.1f} of 64; lane steps {s['n_occ_blocks']} blocks + {s['n_tab_lookups']} table look-ups; regs {s['n_regs']}", flush=True)
+          f"lanes extending per iteration {ext / max(it, 1):.1f} of 64; lane steps {s['n_occ_blocks']} blocks + {s['n_tab_lookups']} table look-ups; regs {s['n_regs']}; "
+          f"extension calls {s['n_ext_calls']} (diagonal rule {s['n_ext_fast']}), DP calls {out[6]} with {out[7] / max(out[6], 1):.1f} query columns on average, rows: {out[8]} one-column, {out[9]} two-column, {out[10]} general passes; cells {s['n_ext_cells']}", flush=True)
     gpu.close()
     for k in sets:
         del os.environ[k]
