@@ -629,8 +629,10 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		}
 		const size_t seed_lds = ((size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * sizeof(uint4) + (size_t)B.rd_words * 4) * BLOCK;
 		// (four instances: with/without the LDS copy of the reads, with/without the work counters, which cost registers)
-		if (B.rd_words) { if (B.stats) hipLaunchKernelGGL((k_seed<true, true>), grid, block, seed_lds, h->stream, h->ix, *opt, B); else hipLaunchKernelGGL((k_seed<true, false>), grid, block, seed_lds, h->stream, h->ix, *opt, B); }
-		else { if (B.stats) hipLaunchKernelGGL((k_seed<false, true>), grid, block, seed_lds, h->stream, h->ix, *opt, B); else hipLaunchKernelGGL((k_seed<false, false>), grid, block, seed_lds, h->stream, h->ix, *opt, B); }
+		dim3 sgrid = grid;                    // (BWAGPU_SEED_GRID, measurements: fewer resident workgroups of the seeding kernel; it stays within 5 % down to two per CU -- it is bound by memory requests, not by waves -- but step time with three batches in flight did not move either, nor did making the batches' seeding kernels take turns)
+		if (getenv("BWAGPU_SEED_GRID") && atoi(getenv("BWAGPU_SEED_GRID")) > 0 && (unsigned)atoi(getenv("BWAGPU_SEED_GRID")) < grid.x) sgrid = dim3((unsigned)atoi(getenv("BWAGPU_SEED_GRID")));
+		if (B.rd_words) { if (B.stats) hipLaunchKernelGGL((k_seed<true, true>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B); else hipLaunchKernelGGL((k_seed<true, false>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B); }
+		else { if (B.stats) hipLaunchKernelGGL((k_seed<false, true>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B); else hipLaunchKernelGGL((k_seed<false, false>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B); }
 		HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
 		hipLaunchKernelGGL(k_publish, grid, block, 0, h->stream, *opt, B);
 		hipLaunchKernelGGL(k_expand, grid, block, 0, h->stream, *opt, B);
