@@ -93,7 +93,7 @@ DEVFN bwagpu_seed_t uni_seed(bwagpu_seed_t s) { s.rbeg = uni64(s.rbeg); s.qbeg =
 // ksw_extend2 only touches columns i-w .. i+w+1, columns left of the band are dead and columns right of it still hold their
 // first-row values, so eh[] is a ring of ring_mask+1 columns that is initialised lazily as the band advances, and scores come
 // from a 25-entry copy of the matrix (mat) and the query bases in global memory.
-struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t *mat; unsigned long long *prof; };   // prof: stats runs only (Counters::prof)
+struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t *mat; };
 
 template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, int mat_max, const u8 *q, int q0, const int qdir, int qlen,
 								   i64 t0, const int tdir, int tlen, int w, int end_bonus, int h0, const WaveLds &L, u64 &cells, u64 &fast)
@@ -163,7 +163,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 	int lim = (int)((double)(qlen * mat_max + end_bonus - o_ins) / e_ins + 1.); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	lim = (int)((double)(qlen * mat_max + end_bonus - o_del) / e_del + 1.); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	int beg = 0, end = qlen, max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, treg = 0;
-	u32 cells32 = 0, rows1 = 0, rows2 = 0, rowsn = 0;
+	u32 cells32 = 0;
 	const bool two_col_ok = h0 + qlen * mat_max < (1 << 23);      // (score << 7 | column) must fit the scan's 31 bits
 	for (int i = 0; i < tlen; ++i) {
 		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
@@ -191,7 +191,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		if (!RING && end - beg <= 64) {
 			// The band fits one pass of the wave (always, for 150 bp reads): the same arithmetic without the pass loop and its carries
 			// -- the kernel is bound by scalar instructions (one scalar unit per CU), and the loop's control was half of them.
-			const int nact = end - beg; ++rows1;
+			const int nact = end - beg;
 			const int j = beg + lane; const bool act = lane < nact;
 			const int2 old = eh[j];                           // (the LDS region is padded by 64 columns)
 			const int sc = qrow[(act ? j : beg) * qdir];
@@ -217,7 +217,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			// 65..128 columns (the longer half of a 150 bp read's extensions): each lane owns two adjacent columns, so the row still takes ONE
 			// prefix scan for F and one for the row maximum instead of two passes of the loop below with their carries.  A lane's two
 			// {H,E} slots are read and written by that lane only -- H(i,j) reaches the owner of column j+1 through a lane shift, not LDS.
-			const int nact = end - beg; ++rows2;
+			const int nact = end - beg;
 			const int jA = beg + 2 * lane, jB = jA + 1;
 			const bool actA = jA < end, actB = jB < end;
 			const int2 oA = eh[jA], oB = eh[jB];               // (the LDS region is padded by 64 columns past the longest read)
@@ -247,7 +247,6 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			wave_sync();
 		} else {
 			for (int b = beg; b < end; b += 64) {
-				++rowsn;
 				const int j = b + lane; const bool act = j < end;
 				// the LDS region is padded by 64 columns, so inactive lanes may read (never write) past `end`
 				int2 old = eh[EHI(j)];
@@ -306,10 +305,6 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 	#undef EHI
 	#undef SCORE_AT
 	cells += cells32;
-	if (L.prof && lane == 0) {   // [6] DP calls, [7] their query columns, [8..10] rows of one column per lane / two / passes of the general loop
-		atomicAdd(L.prof + 6, 1ull); atomicAdd(L.prof + 7, (unsigned long long)qlen);
-		atomicAdd(L.prof + 8, (unsigned long long)rows1); atomicAdd(L.prof + 9, (unsigned long long)rows2); atomicAdd(L.prof + 10, (unsigned long long)rowsn);
-	}
 	ExtRes r; r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
 	return r;
 }
@@ -477,7 +472,6 @@ template <bool RING, int OCC> __global__ void __launch_bounds__(256, OCC) k_exte
 	WaveLds L;
 	unsigned char *base = dyn_lds + (size_t)wave_in_blk * lds_per_wave;
 	L.eh = (int2*)base;                                      // max_len + 2 columns + 64 of read-only padding
-	L.prof = B.stats ? B.ctr->prof : nullptr;
 	if (RING) {
 		int8_t *m = (int8_t*)(base + (size_t)8 * ring_cols);
 		if (lane < 25) m[lane] = opt.mat[lane];

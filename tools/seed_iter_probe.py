@@ -34,7 +34,7 @@ for cfg in (sys.argv[1:] or [""]):
     print(f"[{cfg or 'defaults'}] k_seed {ms_plain['ms_seed']:.1f} ms (with counters {s['ms_seed']:.1f}), chain {ms_plain['ms_chain']:.1f} extend {ms_plain['ms_extend']:.1f} dedup {ms_plain['ms_dedup']:.1f} total {ms_plain['ms_total']:.1f}: "
           f"wave iterations {it:.4g}, reading the stack from HBM {deep:.4g} ({100.0 * deep / max(it, 1):.1f}%), with bookkeeping {slow:.4g} ({100.0 * slow / max(it, 1):.1f}%), "
           f"lanes extending per iteration {ext / max(it, 1):.1f} of 64; lane steps {s['n_occ_blocks']} blocks + {s['n_tab_lookups']} table look-ups; regs {s['n_regs']}; "
-          f"extension calls {s['n_ext_calls']} (diagonal rule {s['n_ext_fast']}), DP calls {out[6]} with {out[7] / max(out[6], 1):.1f} query columns on average, rows: {out[8]} one-column, {out[9]} two-column, {out[10]} general passes; cells {s['n_ext_cells']}", flush=True)
+          f"extension calls {s['n_ext_calls']} (diagonal rule {s['n_ext_fast']}); cells {s['n_ext_cells']}", flush=True)
     gpu.close()
     for k in sets:
         del os.environ[k]
