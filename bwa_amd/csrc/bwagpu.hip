@@ -588,6 +588,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log((double)l);
 		if (!(min_l > 0.05f * l)) { minhsp[l] = (int)(opt->a * min_l + .499); any_seedsw = true; }
 	}
+	const bool dbg_sync = getenv("BWAGPU_DEBUG_SYNC") && atoi(getenv("BWAGPU_DEBUG_SYNC")) != 0;   // diagnostics: wait and report after every stage
 	for (int attempt = 0; attempt < 12; ++attempt) {
 		h->phase = 20 + attempt * 100;
 		int rc = alloc_batch(h, n_threads);
@@ -619,6 +620,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.chain_lds_off = getenv("BWAGPU_CHAIN_LDS") && atoi(getenv("BWAGPU_CHAIN_LDS")) == 0;
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
 		HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "start", hipGetErrorString(e_)); }
 		if (!B.seed_pass3_inline) {   // pass 3 first (cheap), then passes 1-2 on the reads ordered by the repetitiveness it measured
 			hipLaunchKernelGGL(k_seed3, grid, block, 0, h->stream, h->ix, *opt, B);
 			if (!getenv("BWAGPU_SEED_INPUT_ORDER")) {
@@ -634,13 +636,16 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		if (B.rd_words) { if (B.stats) hipLaunchKernelGGL((k_seed<true, true>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B); else hipLaunchKernelGGL((k_seed<true, false>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B); }
 		else { if (B.stats) hipLaunchKernelGGL((k_seed<false, true>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B); else hipLaunchKernelGGL((k_seed<false, false>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B); }
 		HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
+		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_seed3+k_seed", hipGetErrorString(e_)); }
 		hipLaunchKernelGGL(k_publish, grid, block, 0, h->stream, *opt, B);
 		hipLaunchKernelGGL(k_expand, grid, block, 0, h->stream, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "publish+expand", hipGetErrorString(e_)); }
 		i64 sa_blocks = (h->slot_cap + BLOCK - 1) / BLOCK;
 		if (sa_blocks > MAX_RESIDENT_THREADS / BLOCK) sa_blocks = MAX_RESIDENT_THREADS / BLOCK;
 		hipLaunchKernelGGL(k_sa, dim3((unsigned)sa_blocks), block, 0, h->stream, h->ix, B);
 		HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_sa", hipGetErrorString(e_)); }
 		if (getenv("BWAGPU_CHAIN_LANE")) hipLaunchKernelGGL(k_chain, grid, block, 0, h->stream, h->ix, *opt, B);   // round-1 lane-per-read kernel (A/B measurements)
 		else {	// wave per read, heaviest reads (most seeds) first; reads that outgrow the LDS tier are redone by the HBM tier
 			if (int rc2 = order_reads(h, B, B.seed_n)) return rc2;
@@ -651,11 +656,13 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			hipLaunchKernelGGL((k_chain_wave<2, 0, 0, 0>), dim3((unsigned)(nblk < 256 * 7 ? nblk : 256 * 7)), block, (size_t)CW_LDS_BYTES(0, 0, 0) * 4, h->stream, h->ix, *opt, B);
 		}
 		HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_chain", hipGetErrorString(e_)); }
 		if (any_seedsw && h->max_len > WAVE_EXT_MAX_LEN) {   // long reads: one wavefront per read, one lane per seed
 			i64 nblk = ((i64)n + 3) / 4, cap = n_threads / BLOCK;
 			hipLaunchKernelGGL(k_seedsw_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), block, 0, h->stream, h->ix, *opt, B);
 		} else if (any_seedsw) hipLaunchKernelGGL(k_seedsw, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
+		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_seedsw", hipGetErrorString(e_)); }
 		if (int rc2 = order_reads(h, B, B.reg_cap_r)) return rc2;   // heaviest reads (most seeds in kept chains) first
 		// wave-per-read extension with the DP columns in LDS; its row-max scan packs (score << 6 | lane) into 31 bits
 		i64 max_score = (i64)h->max_len * (opt->a > 0 ? opt->a : 1) * 2 + 1024;
@@ -676,6 +683,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		} else                                  // very wide bands: lane-per-read scalar DP with the columns in HBM scratch
 			hipLaunchKernelGGL(k_extend, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
+		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_extend", hipGetErrorString(e_)); }
 		if (h->max_len > WAVE_EXT_MAX_LEN || getenv("BWAGPU_DEDUP_WAVE")) {     // long reads: few reads, long patch alignments -> one wavefront per read
 			int rc_ = 256; while (rc_ < 8 * opt->w + 4 + 128 && rc_ < 2048) rc_ <<= 1;
 			i64 nblk = ((i64)n + 3) / 4, cap = n_threads / BLOCK;   // dp_h/dp_e hold one scratch region per wave of the standard grid
@@ -683,6 +691,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		} else
 			hipLaunchKernelGGL(k_dedup, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
+		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_dedup", hipGetErrorString(e_)); }
 		HIPCHK(h, hipGetLastError());
 		h->phase = 22 + attempt * 100;
 		Counters c;

@@ -586,6 +586,10 @@ __global__ void __launch_bounds__(256) k_sa(DevIndex ix, Batch B)
 		if (!have) {
 			if (s >= n) break;
 			k = B.slot_pos[s]; sa = 0; have = true;
+			// When the slot arena overflows, k_publish drops the reads whose range does not fit and the batch is re-run with a larger
+			// arena -- but this kernel still walks every slot below the capacity, including the never-written head of a dropped read's
+			// range.  Whatever those bytes held before must not become an index address.
+			if (k > ix.seq_len) k = 0;
 		}
 		if (k & ix.sa_mask) {           // one bwt_invPsi step (bwt.c:53-59)
 			++sa;

@@ -93,6 +93,38 @@ def test_edge_cases(small):
     assert_regs_equal(*orc.align(o2, seqs, off), *gpu.align(o2, seqs, off), "arena growth")
 
 
+def _n_rich_reads(g, n, max_len, seed):
+    """Ragged reads of max_len/3..max_len bases with Ns sprinkled in: single Ns, runs, Ns at either end and on the 16-base word
+    boundaries of the seeding kernel's LDS copy, plus an all-N, an empty and a too-short read."""
+    rng = np.random.default_rng(seed)
+    base = simdata.make_reads_se(g, n, length=max_len, seed=seed, sub=0.01)
+    out = []
+    for i, r_ in enumerate(base):
+        r_ = r_[: int(rng.integers(max_len // 3, max_len + 1))].copy()
+        kind = i % 5
+        if kind == 1: r_[int(rng.integers(0, len(r_)))] = 4
+        elif kind == 2: a = int(rng.integers(0, len(r_) - 6)); r_[a:a + 5] = 4
+        elif kind == 3: r_[0] = 4; r_[-1] = 4
+        elif kind == 4 and len(r_) > 40: r_[16] = 4; r_[31] = 4; r_[32] = 4
+        out.append(r_)
+    return out + [np.zeros(0, dtype=np.uint8), np.full(40, 4, dtype=np.uint8), base[0][:max_len], base[1][:17]]
+
+
+@pytest.mark.gpu
+def test_short_read_batches_with_ns_and_seed_length_options(small):
+    """Batches whose longest read is at most 256 bases take the seeding kernel with the reads in LDS (8, 12 or 16 words per lane); reads
+    holding an N fetch their bases from global memory.  Same regions as the oracle for ragged, N-rich reads at three batch shapes, and
+    for -k at, below and above the prefix tables' depth (which switches the bit-mask representation of short stack entries)."""
+    gpu, orc, g = small
+    for max_len in (120, 150, 250):
+        seqs, off = testdata.ragged(_n_rich_reads(g, 2000, max_len, seed=300 + max_len))
+        assert_regs_equal(*orc.align(default_opt(), seqs, off), *gpu.align(default_opt(), seqs, off), f"N-rich ragged reads up to {max_len} bp")
+    seqs, off = testdata.flat(simdata.make_reads_se(g, 3000, seed=77, sub=0.04))
+    for k in (9, 10, 11, 14):
+        opt = default_opt(); opt.min_seed_len = k
+        assert_regs_equal(*orc.align(opt, seqs, off), *gpu.align(opt, seqs, off), f"min_seed_len {k}")
+
+
 @pytest.mark.parametrize("name,n,kw,oname", [
     ("se150", 30000, dict(seed=31, n_frac=0.002), "default"),
     ("se100_noisy", 8000, dict(length=100, seed=32, sub=0.04, dele=0.006, ins=0.006), "default"),

@@ -86,6 +86,51 @@ def test_hostsim_edge_cases_and_arena_growth(sim):
     orc.close()
 
 
+def _n_rich_reads(g, n, max_len, seed):
+    """Ragged reads of 1..max_len bases with Ns sprinkled in: single Ns, runs, Ns at either end, an all-N and an empty read."""
+    rng = np.random.default_rng(seed)
+    base = simdata.make_reads_se(g, n, length=max_len, seed=seed, sub=0.01)
+    out = []
+    for i, r_ in enumerate(base):
+        r_ = r_[: int(rng.integers(max_len // 3, max_len + 1))].copy()
+        kind = i % 5
+        if kind == 1: r_[int(rng.integers(0, len(r_)))] = 4
+        elif kind == 2: a = int(rng.integers(0, len(r_) - 6)); r_[a:a + 5] = 4
+        elif kind == 3: r_[0] = 4; r_[-1] = 4
+        elif kind == 4 and len(r_) > 40: r_[16] = 4; r_[31] = 4; r_[32] = 4       # on and around the 16-base words of the LDS copy
+        out.append(r_)
+    out += [np.zeros(0, dtype=np.uint8), np.full(40, 4, dtype=np.uint8), base[0][:max_len], base[1][:17]]
+    return out
+
+
+@pytest.mark.parametrize("max_len,env", [(150, {}), (250, {}), (120, {"BWAGPU_SEED_NO_VIRT": "1"}), (150, {"BWAGPU_SEED_RD_LDS": "0"}),
+                                         (150, {"BWAGPU_PTAB_M": "5", "BWAGPU_SEED_LDS_ENT": "2"})])
+def test_hostsim_seeding_paths_with_n_reads(monkeypatch, max_len, env):
+    """The seeding kernel's read copy in LDS (2 bits per base; 8, 12 or 16 words per lane by the batch's longest read; reads with an N
+    take their bases from global memory), the short stack entries kept as a bit mask (off with BWAGPU_SEED_NO_VIRT, and narrower with
+    shallow prefix tables), and a two-entry LDS stack that spills almost everything: same regions as the oracle for ragged reads with Ns."""
+    prefix, g = testdata.small_index()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+    orc = orcapi.OrcIndex(prefix)
+    seqs, off = testdata.ragged(_n_rich_reads(g, 14, max_len, seed=300 + max_len))
+    assert_regs_equal(*orc.align(default_opt(), seqs, off), *s2.align(default_opt(), seqs, off), f"N-rich ragged reads up to {max_len} bp, {env}")
+    s2.close(); orc.close()
+
+
+def test_hostsim_min_seed_len_around_the_table_depth(sim):
+    """-k at, below and just above the prefix tables' depth (10): at or below it short matches can be reported, so every stack
+    entry is stored; just above it the shortest stored entry is the one a backward row has just grown to the tables' depth."""
+    prefix, g = testdata.small_index()
+    orc = orcapi.OrcIndex(prefix)
+    seqs, off = testdata.flat(simdata.make_reads_se(g, 10, seed=77, sub=0.04))
+    for k in (9, 10, 11, 14):
+        opt = default_opt(); opt.min_seed_len = k
+        assert_regs_equal(*orc.align(opt, seqs, off), *sim.align(opt, seqs, off), f"min_seed_len {k}")
+    orc.close()
+
+
 def test_hostsim_cloned_handle_shares_index(sim):
     """bwagpu_clone: a second handle on the same resident index gives the same results; both stay usable and are destroyed
     independently (the mock runtime is single-threaded, so the two are driven one after the other here)."""
