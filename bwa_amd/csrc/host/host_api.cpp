@@ -1,5 +1,6 @@
 // host_api.cpp -- batch-level finalize (the reference's worker2 loop, bwamem.c:1217-1233, 1256-1260) over a thread pool,
 // and a flat C entry point used by the tests to compare this host code with the reference on the CPU.
+#include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -80,7 +81,10 @@ char *bwamem_host_regs2sam(void *h, const bwagpu_opt_t *opt, int64_t n_processed
 	std::vector<bwagpu_matesw_t> msw_sorted;
 	if (msw) attach_matesw(n, reads.data(), msw, n_msw, msw_sorted);
 	std::vector<std::string> sam;
+	const bool trace = getenv("BWAMEM_HOST_TRACE") != nullptr;      // diagnostics: time of the finalize stage proper
+	const auto t0 = std::chrono::steady_clock::now();
 	finalize_batch(*opt, ref, n_processed, n, reads.data(), rv, pes0, n_threads, 0, sam, false);
+	if (trace) fprintf(stderr, "[host] finalize_batch: %d reads, %d threads, %.3f s\n", n, n_threads, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 	size_t tot = 0;
 	for (auto &s : sam) tot += s.size();
 	char *out = (char*)malloc(tot + 1); size_t p = 0;
