@@ -59,7 +59,7 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std:
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
 // device memory comes back filled with a poison pattern: code that consumes bytes nobody wrote (a stale arena slot, a flag never
 // cleared) then fails here -- as a wild index or a wrong result -- the way it may on a GPU whose allocator recycles pages
-static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); if (*p) memset(*p, 0xCB, n ? n : 1); return *p ? hipSuccess : hipErrorMock; }
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); if (*p) memset(*p, 0xCB, n < ((size_t)32 << 20) ? (n ? n : 1) : ((size_t)32 << 20));   /* (the first 32 MiB: scratch areas sized for a whole chip are never touched otherwise) */ return *p ? hipSuccess : hipErrorMock; }
 template <class T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
