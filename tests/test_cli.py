@@ -158,5 +158,10 @@ def test_cli_hostsim_two_devices(tmp_path):
     x = ["-p", "-C"]
     assert _run(refapi.REF_BWA, K + x + [prefix, inter]) == _run(cli, K + x + [prefix, inter], env), "smart pairing, 2 devices"
     assert _run(refapi.REF_BWA, ["-K", "9000", "-t", "2", prefix, f1, f2]) == _run(cli, ["-K", "9000", "-t", "2", prefix, f1, f2], env), "small batches, 2 devices"
+    # gap-rich reads: many alignments of 7..64 CIGAR operations, whose records point into each device's operation array -- the
+    # offsets of the second device's records must move with its part of the merged array
+    noisy = str(tmp_path / "noisy.fq")
+    simdata.write_fastq(noisy, simdata.make_reads_se(g, 16, seed=404, sub=0.02, dele=0.03, ins=0.03))
+    assert _run(refapi.REF_BWA, K + [prefix, noisy]) == _run(cli, K + [prefix, noisy], env), "gap-rich reads, 2 devices"
     env3 = dict(env, MOCK_HIP_DEVICES="3", BWAGPU_DEVICES="0,1,2")
     assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], env3), "paired-end, 3 devices"
