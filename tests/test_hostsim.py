@@ -124,8 +124,8 @@ def test_hostsim_min_seed_len_around_the_table_depth(sim):
     entry is stored; just above it the shortest stored entry is the one a backward row has just grown to the tables' depth."""
     prefix, g = testdata.small_index()
     orc = orcapi.OrcIndex(prefix)
-    seqs, off = testdata.flat(simdata.make_reads_se(g, 10, seed=77, sub=0.04))
-    for k in (9, 10, 11, 14):
+    seqs, off = testdata.flat(simdata.make_reads_se(g, 8, seed=77, sub=0.04))
+    for k in (9, 10, 11):
         opt = default_opt(); opt.min_seed_len = k
         assert_regs_equal(*orc.align(opt, seqs, off), *sim.align(opt, seqs, off), f"min_seed_len {k}")
     orc.close()
@@ -286,7 +286,7 @@ def heavy_case():
     assert n_chains[pick[0]] > 200 and n_kept.max() > 100, (n_chains[top], n_kept)
     mid = [int(i) for i in np.nonzero((n_chains >= 36) & (n_chains <= 60))[0][:2]]    # more than tier 0 holds, fewer than tier 1's limit
     assert len(mid) == 2
-    reads = np.concatenate([cand[pick], cand[mid], cand[:3]])
+    reads = np.concatenate([cand[pick[:1]], cand[pick[2:3]], cand[mid], cand[:1]])      # most chains, most kept chains, two for tier 1, an ordinary read
     yield fa, orc, reads
     orc.close()
 
