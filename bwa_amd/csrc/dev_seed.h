@@ -3,7 +3,10 @@
 // One lane per read.  The search is a chain of dependent 64-byte index reads (~1000 per 150 bp read), so
 // throughput comes from having several hundred thousand independent chains in flight, not from
 // parallelising one chain; each lane keeps its bi-interval in registers and fetches a whole Occ block
-// (4 x dwordx4) per rank query.
+// (4 x dwordx4) per rank query.  Measured: the kernel runs at the chip's ceiling for random memory
+// requests, so everything else a lane touches is kept out of HBM -- its read (2 bits per base) and the top of its interval
+// stack live in LDS, matches shorter than the prefix tables' depth are a bit mask in a register (SeedLane::smask), and
+// whatever is left of the stack spills to a per-lane scratch area.
 #pragma once
 #include "dev_fm.h"
 #include "dev_sort.h"
