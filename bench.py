@@ -303,7 +303,11 @@ def main():
                          "alg_bytes_per_launch": alg[roof_k], "kernel_ms": round(dur[roof_k], 3),
                          "per_kernel": {k: {"ms": round(dur[k], 3), "alg_GB": round(alg[k] / 1e9, 3), "GB/s": round(alg[k] / (dur[k] * 1e-3) / 1e9, 1) if dur[k] > 0 else None} for k in dur},
                          "random_64B_ceiling": {"GB/s": 1670.0, "blocks_per_s": 26.0e9,
-                                                "source": "tools/randbw.hip on MI355X, profiles/r01_randbw_microbench.md: random 64-byte reads from HBM saturate at 26e9/s"},
+                                                "source": "tools/randbw.hip on MI355X, profiles/r01_randbw_microbench.md: random 64-byte reads from HBM saturate at 26e9/s",
+                                                # the seeding stage's algorithmic requests alone (index blocks + prefix-table entries; the interval stacks'
+                                                # spill traffic and the interval lists come on top) against that ceiling
+                                                "seeding_alg_requests_per_s": round((work["n_occ_blocks"] + work["n_tab_lookups"]) / (stage_ms["ms_seed"] * 1e-3), 0) if stage_ms["ms_seed"] > 0 else None,
+                                                "seeding_frac": round((work["n_occ_blocks"] + work["n_tab_lookups"]) / (stage_ms["ms_seed"] * 1e-3) / 26.0e9, 4) if stage_ms["ms_seed"] > 0 else None},
                          "ext_gcups": round(work["n_ext_cells"] / (stage_ms["ms_extend"] * 1e-3) / 1e9, 1) if stage_ms["ms_extend"] > 0 else None},
             "stage_ms_solo": {k: round(v, 3) for k, v in stage_ms.items()},
             "work_per_read": {"N_blk": round(work["n_occ_blocks"] / nr, 1), "N_tab": round(work["n_tab_lookups"] / nr, 1), "N_lf": round(work["n_lf_steps"] / nr, 1),
