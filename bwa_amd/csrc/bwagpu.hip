@@ -58,7 +58,7 @@ struct bwagpu_s {
 	// index
 	DevIndex ix = {};
 	struct IndexBufs {
-		DevBuf d_bwt, d_sa, d_pac, d_ctg_off, d_ctg_len, d_ctg_alt, d_ptab; int refs = 1;
+		DevBuf d_bwt, d_sa, d_pac, d_ctg_off, d_ctg_len, d_ctg_alt, d_ptab, d_occ32, d_occ_sb; int refs = 1;
 		// per-base arena needs learnt by any handle on this index (a re-run for arena growth doubles a batch's device time, so a
 		// cloned handle should not have to learn them again); written and read under `m`
 		std::mutex m; double need_slot = 0, need_node = 0, need_reg = 0; int need_mem = 0;
@@ -153,6 +153,57 @@ __global__ void __launch_bounds__(256) k_ptab_records(const u64 *tab, uint4 *rec
 	}
 }
 
+// ---- the 32-byte block layout of the BWT (DevIndex::occ32) --------------------------------------------------------------------
+// counts of the four symbols at the start of 64-base block j, from the reference-format block it is half of
+DEVFN void occ32_start_counts(const DevIndex &ix, u64 j, u64 cnt[4])
+{
+	const uint4 *src = ix.bwt + (j >> 1) * 4;
+	const uint4 c01 = src[0], c23 = src[1];
+	cnt[0] = (u64)c01.y << 32 | c01.x; cnt[1] = (u64)c01.w << 32 | c01.z; cnt[2] = (u64)c23.y << 32 | c23.x; cnt[3] = (u64)c23.w << 32 | c23.z;
+	if (j & 1) {                           // second half: add the first 64 bases of the block
+		const uint4 w0 = src[2];
+		u32 c1 = 0, c2 = 0, c3 = 0;
+		count_pair(w0.x, w0.y, 32, c1, c2, c3); count_pair(w0.z, w0.w, 32, c1, c2, c3);
+		cnt[0] += 64 - c1 - c2 - c3; cnt[1] += c1; cnt[2] += c2; cnt[3] += c3;
+	}
+}
+__global__ void __launch_bounds__(256) k_occ32_sb(DevIndex ix, u64 *sb, u64 n_sb, u64 n_new, int sh /* log2 of 64-base blocks per superblock */)
+{
+	for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < n_sb; s += (u64)gridDim.x * blockDim.x) {
+		u64 cnt[4] = { 0, 0, 0, 0 };
+		if ((s << sh) < n_new) occ32_start_counts(ix, s << sh, cnt);   // (the table has one spare entry past the end)
+		for (int k = 0; k < 4; ++k) sb[s * 4 + k] = cnt[k];
+	}
+}
+__global__ void __launch_bounds__(256) k_occ32_blocks(DevIndex ix, const u64 *sb, uint4 *out, u64 n_new, int sh)
+{
+	for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n_new; j += (u64)gridDim.x * blockDim.x) {
+		u64 cnt[4];
+		occ32_start_counts(ix, j, cnt);
+		const u64 *base = sb + (j >> sh) * 4;
+		uint4 rel; rel.x = (u32)(cnt[0] - base[0]); rel.y = (u32)(cnt[1] - base[1]); rel.z = (u32)(cnt[2] - base[2]); rel.w = (u32)(cnt[3] - base[3]);
+		out[j * 2] = rel;
+		out[j * 2 + 1] = ix.bwt[(j >> 1) * 4 + 2 + (j & 1)];
+	}
+}
+// BWAGPU_OCC32=1: build the second layout from the resident reference-format blocks (the files and everything else keep using those)
+static int build_occ32(bwagpu_t *h)
+{
+	h->ix.occ32 = nullptr; h->ix.occ_sb = nullptr; h->ix.occ_sb_shift = 32;
+	if (!(getenv("BWAGPU_OCC32") && atoi(getenv("BWAGPU_OCC32")) != 0) || h->bwt_blocks == 0) return 0;
+	int shift = getenv("BWAGPU_OCC32_SB_SHIFT") ? atoi(getenv("BWAGPU_OCC32_SB_SHIFT")) : 32;      // (tests: small superblocks on small genomes)
+	if (shift < 8) shift = 8; if (shift > 32) shift = 32;
+	const int sh = shift - 6;
+	const u64 n_new = (u64)h->bwt_blocks * 2, n_sb = (n_new >> sh) + 1;
+	if (h->ibuf->d_occ32.ensure((size_t)n_new * 32) || h->ibuf->d_occ_sb.ensure((size_t)n_sb * 32)) { h->err = "hipMalloc failed (32-byte blocks)"; return BWAGPU_ENOMEM; }
+	hipLaunchKernelGGL(k_occ32_sb, dim3((unsigned)((n_sb + 255) / 256 < 1024 ? (n_sb + 255) / 256 : 1024)), dim3(256), 0, h->stream, h->ix, h->ibuf->d_occ_sb.as<u64>(), n_sb, n_new, sh);
+	hipLaunchKernelGGL(k_occ32_blocks, dim3((unsigned)((n_new + 255) / 256 < 65536 ? (n_new + 255) / 256 : 65536)), dim3(256), 0, h->stream, h->ix, h->ibuf->d_occ_sb.as<u64>(), h->ibuf->d_occ32.as<uint4>(), n_new, sh);
+	hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(h->stream);
+	HIPCHK(h, e1); HIPCHK(h, e2);
+	h->ix.occ32 = h->ibuf->d_occ32.as<uint4>(); h->ix.occ_sb = h->ibuf->d_occ_sb.as<u64>(); h->ix.occ_sb_shift = shift;
+	return 0;
+}
+
 static int build_prefix_tables(bwagpu_t *h, int m)
 {
 	// the packed entries hold 37-bit interval bounds (as do the LDS interval stacks)
@@ -221,9 +272,10 @@ extern "C" int bwagpu_create(bwagpu_t **out, const bwagpu_index_desc_t *d, int d
 	h->h_ctg_off.assign(d->ctg_offset, d->ctg_offset + d->n_seqs);
 	h->h_ctg_len.assign(d->ctg_len, d->ctg_len + d->n_seqs);
 	h->h_ctg_alt.assign(d->ctg_is_alt, d->ctg_is_alt + d->n_seqs);
-	h->ix.ptab = nullptr; h->ix.ptab_m = 0;
+	h->ix.ptab = nullptr; h->ix.ptab_m = 0; h->ix.occ32 = nullptr; h->ix.occ_sb = nullptr;
 	if (!alloc_only) {   // (a handle that receives its index by broadcast builds them in bwagpu_index_ready)
 		int m = getenv("BWAGPU_PTAB_M") ? atoi(getenv("BWAGPU_PTAB_M")) : 10;
+		if ((rc = build_occ32(h))) goto fail;
 		if ((rc = build_prefix_tables(h, m))) goto fail;
 	}
 	*out = h;
@@ -237,7 +289,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 {
 	if (!h) return;
 	if (h->ibuf && --h->ibuf->refs == 0) {
-		DevBuf *ib[] = { &h->ibuf->d_bwt, &h->ibuf->d_sa, &h->ibuf->d_pac, &h->ibuf->d_ctg_off, &h->ibuf->d_ctg_len, &h->ibuf->d_ctg_alt, &h->ibuf->d_ptab };
+		DevBuf *ib[] = { &h->ibuf->d_bwt, &h->ibuf->d_sa, &h->ibuf->d_pac, &h->ibuf->d_ctg_off, &h->ibuf->d_ctg_len, &h->ibuf->d_ctg_alt, &h->ibuf->d_ptab, &h->ibuf->d_occ32, &h->ibuf->d_occ_sb };
 		for (DevBuf *b : ib) b->release();
 		delete h->ibuf;
 	}
@@ -370,6 +422,8 @@ extern "C" int bwagpu_clone_to_device(bwagpu_t *src, int device, bwagpu_t **out)
 	h->ix.bwt = h->ibuf->d_bwt.as<uint4>(); h->ix.sa = h->ibuf->d_sa.as<u64>(); h->ix.pac = h->ibuf->d_pac.as<u8>();
 	h->ix.ctg_off = h->ibuf->d_ctg_off.as<i64>(); h->ix.ctg_len = h->ibuf->d_ctg_len.as<i32>(); h->ix.ctg_alt = h->ibuf->d_ctg_alt.as<i32>();
 	h->ix.ptab = src->ix.ptab ? h->ibuf->d_ptab.as<uint4>() : nullptr;
+	h->bwt_blocks = src->bwt_blocks;
+	if (src->ix.occ32) { if (int rc = build_occ32(h)) { bwagpu_destroy(h); return rc; } } else { h->ix.occ32 = nullptr; h->ix.occ_sb = nullptr; }   // (rebuilt here rather than copied)
 	h->l_pac = src->l_pac; h->n_seqs = src->n_seqs; h->seq_len = src->seq_len; h->sa_intv = src->sa_intv;
 	h->bwt_blocks = src->bwt_blocks; h->bwt_bytes = src->bwt_bytes; h->sa_bytes = src->sa_bytes; h->pac_bytes = src->pac_bytes;
 	h->bwt_size = src->bwt_size; h->n_sa = src->n_sa;
@@ -392,6 +446,7 @@ extern "C" int bwagpu_index_ready(bwagpu_t *h)
 	if (!h) return BWAGPU_EINVAL;
 	HIPCHK(h, hipSetDevice(h->device));
 	int m = getenv("BWAGPU_PTAB_M") ? atoi(getenv("BWAGPU_PTAB_M")) : 10;
+	if (int rc = build_occ32(h)) return rc;
 	return build_prefix_tables(h, m);
 }
 

@@ -38,6 +38,14 @@ struct DevIndex {
 	// the same 16*m-byte record
 	const uint4 *ptab;
 	int ptab_m;
+	// optional second layout of the BWT for the seeding kernels (BWAGPU_OCC32=1): 32-byte blocks of 64 bases -- four 32-bit counts relative to
+	// the block's superblock (2^occ_sb_shift bases, 2^32 unless a test asks for less; occ_sb holds four 64-bit counts per superblock: two or
+	// three entries for a human genome, which never leave the L1 cache) and the 64 bases.
+	// One rank query then costs one 32-byte memory request instead of a 64-byte one; the chip serves those 1.6 times as fast
+	// (profiles/r02_experiments.md).  Null: not built.
+	const uint4 *occ32;
+	const u64 *occ_sb;
+	int occ_sb_shift;
 };
 
 // SA interval kept by the seeding stage: {x0, x2, info}; the reverse-strand start x[1] of bwtintv_t (bwt.h:62)

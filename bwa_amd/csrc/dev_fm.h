@@ -72,15 +72,40 @@ DEVFN void block_occ4_bf(const OccBlock &b, int o, u64 cnt[4])
 // instruction stream (both Occ blocks are always fetched -- the same block twice when k and l share it, an L1 hit --
 // and every data-dependent choice is a select), so that all lanes of a wave run it together whatever their state.
 // Returns the number of distinct 64-byte blocks touched (N_blk of SURVEY.md 8d).
+// Occ counts up to position kk (primary-adjusted, inclusive) from the 32-byte layout: == block_occ4_bf on the 64-byte one.
+DEVFN void occ32_counts(const uint4 &rel, const uint4 &w, const uint4 &sb01, const uint4 &sb23, int o, u64 cnt[4])
+{
+	const int n = o + 1;
+	u32 c1 = 0, c2 = 0, c3 = 0;
+	count_pair_bf(w.x, w.y, n, c1, c2, c3);
+	count_pair_bf(w.z, w.w, n - 32, c1, c2, c3);
+	cnt[0] = ((u64)sb01.y << 32 | sb01.x) + rel.x + (u32)(n - c1 - c2 - c3);
+	cnt[1] = ((u64)sb01.w << 32 | sb01.z) + rel.y + c1;
+	cnt[2] = ((u64)sb23.y << 32 | sb23.x) + rel.z + c2;
+	cnt[3] = ((u64)sb23.w << 32 | sb23.z) + rel.w + c3;
+}
+
 DEVFN int fm_extend1(const DevIndex &ix, const BiIntv &ik, int c, int is_back, BiIntv &out)
 {
 	const u64 a = is_back ? ik.x0 : ik.x1, other = is_back ? ik.x1 : ik.x0;
 	const u64 k = a - 1, l = a - 1 + ik.x2;                    // a >= 1 always (intervals start at L2[c]+1)
 	const u64 kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
-	const OccBlock bk = load_block(ix, kk >> 7), bl = load_block(ix, ll >> 7);
 	u64 tk[4], tl[4];
-	block_occ4_bf(bk, (int)(kk & 127), tk);
-	block_occ4_bf(bl, (int)(ll & 127), tl);
+	int nblk;
+	if (ix.occ32) {                                            // (wave-uniform)
+		const uint4 *bk = ix.occ32 + (kk >> 6) * 2, *bl = ix.occ32 + (ll >> 6) * 2;
+		const uint4 *sk = (const uint4*)(ix.occ_sb + (kk >> ix.occ_sb_shift) * 4), *sl = (const uint4*)(ix.occ_sb + (ll >> ix.occ_sb_shift) * 4);
+		const uint4 rk = bk[0], wk = bk[1], rl = bl[0], wl = bl[1];
+		const uint4 sk0 = sk[0], sk1 = sk[1], sl0 = sl[0], sl1 = sl[1];
+		occ32_counts(rk, wk, sk0, sk1, (int)(kk & 63), tk);
+		occ32_counts(rl, wl, sl0, sl1, (int)(ll & 63), tl);
+		nblk = (kk >> 6) == (ll >> 6) ? 1 : 2;
+	} else {
+		const OccBlock bk = load_block(ix, kk >> 7), bl = load_block(ix, ll >> 7);
+		block_occ4_bf(bk, (int)(kk & 127), tk);
+		block_occ4_bf(bl, (int)(ll & 127), tl);
+		nblk = (kk >> 7) == (ll >> 7) ? 1 : 2;
+	}
 	const u64 d1 = tl[1] - tk[1], d2 = tl[2] - tk[2], d3 = tl[3] - tk[3];
 	u64 o = other + (a <= ix.primary && a + ik.x2 - 1 >= ix.primary);
 	o += c < 3 ? d3 : 0; o += c < 2 ? d2 : 0; o += c < 1 ? d1 : 0;
@@ -91,7 +116,7 @@ DEVFN int fm_extend1(const DevIndex &ix, const BiIntv &ik, int c, int is_back, B
 	out.x2 = tlc - tkc;
 	out.x0 = is_back ? na : o;
 	out.x1 = is_back ? o : na;
-	return (kk >> 7) == (ll >> 7) ? 1 : 2;
+	return nblk;
 }
 
 DEVFN void fm_init(const DevIndex &ix, int c, BiIntv &ik)

@@ -104,11 +104,12 @@ def _n_rich_reads(g, n, max_len, seed):
 
 
 @pytest.mark.parametrize("max_len,env", [(150, {}), (250, {}), (120, {"BWAGPU_SEED_NO_VIRT": "1"}), (150, {"BWAGPU_SEED_RD_LDS": "0"}),
-                                         (150, {"BWAGPU_PTAB_M": "5", "BWAGPU_SEED_LDS_ENT": "2"})])
+                                         (150, {"BWAGPU_PTAB_M": "5", "BWAGPU_SEED_LDS_ENT": "2"}), (150, {"BWAGPU_OCC32": "1"}), (150, {"BWAGPU_OCC32": "1", "BWAGPU_PTAB_M": "0"})])
 def test_hostsim_seeding_paths_with_n_reads(monkeypatch, max_len, env):
     """The seeding kernel's read copy in LDS (2 bits per base; 8, 12 or 16 words per lane by the batch's longest read; reads with an N
     take their bases from global memory), the short stack entries kept as a bit mask (off with BWAGPU_SEED_NO_VIRT, and narrower with
-    shallow prefix tables), and a two-entry LDS stack that spills almost everything: same regions as the oracle for ragged reads with Ns."""
+    shallow prefix tables), a two-entry LDS stack that spills almost everything, and the 32-byte block layout of the BWT (with and without
+    prefix tables, which are then filled through it): same regions as the oracle for ragged reads with Ns."""
     prefix, g = testdata.small_index()
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -117,6 +118,26 @@ def test_hostsim_seeding_paths_with_n_reads(monkeypatch, max_len, env):
     seqs, off = testdata.ragged(_n_rich_reads(g, 14, max_len, seed=300 + max_len))
     assert_regs_equal(*orc.align(default_opt(), seqs, off), *s2.align(default_opt(), seqs, off), f"N-rich ragged reads up to {max_len} bp, {env}")
     s2.close(); orc.close()
+
+
+def test_hostsim_occ32_layout_across_superblocks(monkeypatch):
+    """BWAGPU_OCC32=1 on the 2 Mb genome with superblocks of 2^12 bases (a thousand of them, so the relative counts and the superblock
+    table are both in play; the default of 2^32 bases gives a genome this size one): same regions as the oracle, with the prefix tables
+    (filled through the new layout) and without."""
+    import refapi
+    if not refapi.have_ref():
+        pytest.skip("oracle/_ref not built (needed to index the 2 Mb genome)")
+    prefix, g = testdata.medium_index()
+    orc = orcapi.OrcIndex(prefix)
+    seqs, off = testdata.flat(simdata.make_reads_se(g, 16, seed=88, sub=0.02))
+    want = orc.align(default_opt(), seqs, off)
+    monkeypatch.setenv("BWAGPU_OCC32", "1")
+    for m, shift in (("6", "12"), ("0", "12"), ("6", "32")):
+        monkeypatch.setenv("BWAGPU_PTAB_M", m); monkeypatch.setenv("BWAGPU_OCC32_SB_SHIFT", shift)
+        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+        assert_regs_equal(*want, *s2.align(default_opt(), seqs, off), f"32-byte blocks, prefix tables {m}, superblock shift {shift}")
+        s2.close()
+    orc.close()
 
 
 def test_hostsim_min_seed_len_around_the_table_depth(sim):
