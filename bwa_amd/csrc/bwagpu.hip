@@ -685,11 +685,16 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			}
 		}
 		const size_t seed_lds = ((size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * sizeof(uint4) + (size_t)B.rd_words * 4) * BLOCK;
-		// (four instances: with/without the LDS copy of the reads, with/without the work counters, which cost registers)
 		dim3 sgrid = grid;                    // (BWAGPU_SEED_GRID, measurements: fewer resident workgroups of the seeding kernel; it stays within 5 % down to two per CU -- it is bound by memory requests, not by waves -- but step time with three batches in flight did not move either, nor did making the batches' seeding kernels take turns)
 		if (getenv("BWAGPU_SEED_GRID") && atoi(getenv("BWAGPU_SEED_GRID")) > 0 && (unsigned)atoi(getenv("BWAGPU_SEED_GRID")) < grid.x) sgrid = dim3((unsigned)atoi(getenv("BWAGPU_SEED_GRID")));
-		if (B.rd_words) { if (B.stats) hipLaunchKernelGGL((k_seed<true, true>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B); else hipLaunchKernelGGL((k_seed<true, false>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B); }
-		else { if (B.stats) hipLaunchKernelGGL((k_seed<false, true>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B); else hipLaunchKernelGGL((k_seed<false, false>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B); }
+		// (eight instances: with/without the LDS copy of the reads, the work counters -- which cost registers -- and the 32-byte block layout)
+#define SEED_LAUNCH(RD_, ST_, O_) hipLaunchKernelGGL((k_seed<RD_, ST_, O_>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B)
+		{
+			const bool rd = B.rd_words != 0, st = B.stats != 0, o32 = h->ix.occ32 != nullptr;
+			if (rd) { if (st) { if (o32) SEED_LAUNCH(true, true, true); else SEED_LAUNCH(true, true, false); } else { if (o32) SEED_LAUNCH(true, false, true); else SEED_LAUNCH(true, false, false); } }
+			else { if (st) { if (o32) SEED_LAUNCH(false, true, true); else SEED_LAUNCH(false, true, false); } else { if (o32) SEED_LAUNCH(false, false, true); else SEED_LAUNCH(false, false, false); } }
+		}
+#undef SEED_LAUNCH
 		HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_seed3+k_seed", hipGetErrorString(e_)); }
 		hipLaunchKernelGGL(k_publish, grid, block, 0, h->stream, *opt, B);

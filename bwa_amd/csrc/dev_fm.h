@@ -85,14 +85,15 @@ DEVFN void occ32_counts(const uint4 &rel, const uint4 &w, const uint4 &sb01, con
 	cnt[3] = ((u64)sb23.w << 32 | sb23.z) + rel.w + c3;
 }
 
-DEVFN int fm_extend1(const DevIndex &ix, const BiIntv &ik, int c, int is_back, BiIntv &out)
+// O32: 1 = the 32-byte layout, 0 = the reference-format blocks, -1 = whichever the handle has (decided at run time)
+template <int O32 = -1> DEVFN int fm_extend1(const DevIndex &ix, const BiIntv &ik, int c, int is_back, BiIntv &out)
 {
 	const u64 a = is_back ? ik.x0 : ik.x1, other = is_back ? ik.x1 : ik.x0;
 	const u64 k = a - 1, l = a - 1 + ik.x2;                    // a >= 1 always (intervals start at L2[c]+1)
 	const u64 kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
 	u64 tk[4], tl[4];
 	int nblk;
-	if (ix.occ32) {                                            // (wave-uniform)
+	if (O32 < 0 ? ix.occ32 != nullptr : O32 > 0) {             // (wave-uniform)
 		const uint4 *bk = ix.occ32 + (kk >> 6) * 2, *bl = ix.occ32 + (ll >> 6) * 2;
 		const uint4 *sk = (const uint4*)(ix.occ_sb + (kk >> ix.occ_sb_shift) * 4), *sl = (const uint4*)(ix.occ_sb + (ll >> ix.occ_sb_shift) * 4);
 		const uint4 rk = bk[0], wk = bk[1], rl = bl[0], wl = bl[1];

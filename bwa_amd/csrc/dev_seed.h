@@ -274,7 +274,8 @@ __global__ void __launch_bounds__(256) k_publish(bwagpu_opt_t opt, Batch B)
 }
 
 // RD: the batch's reads are short enough for an LDS copy (Batch::rd_words > 0)
-template<bool RD, bool STATS>
+// O32: the handle has the 32-byte block layout of the BWT (DevIndex::occ32) -- a compile-time choice here, so that neither path pays for the other's registers
+template<bool RD, bool STATS, bool O32>
 __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
 	HIP_DYNAMIC_SHARED(uint4, seed_lds)
@@ -431,7 +432,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			if (tl <= ix.ptab_m) {
 				ptab_load(ix, tl, L.code, ok);
 				if (STATS) ++ntab;
-			} else { const u32 nb = fm_extend1(ix, src, cb, back, ok); if (STATS) nblk += nb; }   // the only extension site of the kernel
+			} else { const u32 nb = fm_extend1<O32 ? 1 : 0>(ix, src, cb, back, ok); if (STATS) nblk += nb; }   // the only extension site of the kernel
 			if (st == SS_FWD) {           // forward sweep of bwt_smem1a (bwt.c:304-320)
 				bool stop = false;
 				if (ok.x2 != L.ik.x2) {

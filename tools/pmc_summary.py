@@ -43,7 +43,7 @@ def main():
     # the seeding kernel has an instance with work counters (one launch per bench run) and one without (the timed launches)
     seeds = sorted(k for k in res if k.startswith("k_seed<"))
     if seeds:
-        plain = [k for k in seeds if k.endswith("false>")]
+        plain = [k for k in seeds if [a.strip() for a in k[k.index("<") + 1:-1].split(",")][1:2] == ["false"]]   # second template argument: work counters
         res["k_seed"] = res[(plain or seeds)[0]]
     json.dump(res, open(dst, "w"), indent=1)
     for k, v in res.items():
