@@ -2,7 +2,7 @@
 // (bwamem.h:161, bwamem.c:1235-1264) re-written from scratch around libbwagpu.so.
 //
 //   worker1 loop  -> bwagpu_align_bseq()            (device, include/bwagpu.h)
-//   mem_pestat    -> hostmem::pestat()              (bwamem_pair.c:72-135)
+//   mem_pestat    -> hostmem::pestat_flat()              (bwamem_pair.c:72-135)
 //   worker2 loop  -> hostmem::finalize_se / finalize_pe
 //                    mark-primary (bwamem.c:519-584), mapQ (:982-1006), CIGAR/NM/MD (bwa.c:148-234 + ksw.c:540-642),
 //                    XA (bwamem_extra.c:124-172), SAM record (bwamem.c:851-976), mate rescue / pairing
@@ -75,7 +75,6 @@ void host_region_cigar(const bwagpu_opt_t &opt, const RefSeqs &ref, const uint8_
 Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint8_t *query, const bwagpu_alnreg_t *ar, const CigHints *hints = nullptr);   // bwamem.c:1119-1189
 void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, const Read &s, const std::vector<Aln> &list, int which, const Aln *mate, const char *rg_id);   // bwamem.c:851-976
 void reg2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, const Read &s, Regs &a, int extra_flag, const Aln *mate, const char *rg_id);   // bwamem.c:1033-1079
-void pestat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const std::vector<Regs> &regs, Pestat pes[4], bool verbose);
 void pestat_flat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const bwagpu_alnreg_t *all, const int64_t *roff, Pestat pes[4], bool verbose);
 void attach_matesw(int n, Read *reads, const bwagpu_matesw_t *recs, int64_t n_recs, std::vector<bwagpu_matesw_t> &sorted);
 int64_t host_matesw_records(const bwagpu_opt_t &opt, const RefSeqs &ref, int n, const uint8_t *seqs, const int64_t *off, const bwagpu_alnreg_t *all, const int64_t *roff,

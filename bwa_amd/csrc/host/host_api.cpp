@@ -10,26 +10,31 @@
 
 namespace hostmem {
 
-// regs[i] for all reads of a batch -> SAM text per read (sam[i]); PE when opt.flag & F_PE (mates interleaved)
-void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_processed, int n, const Read *reads, std::vector<Regs> &regs,
+// the regions of all reads of a batch (flat, read i's at all[roff[i] .. roff[i+1])) -> SAM text per read (sam[i]); PE when opt.flag & F_PE (mates
+// interleaved).  A worker copies a read's regions into a list of its own that it keeps from read to read (the stage's functions reorder, flag
+// and extend that list): per-read lists built by one thread and released by another cost two allocator round trips per read, and
+// the cross-thread releases contend -- a quarter of the stage's time on 8 threads.
+void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_processed, int n, const Read *reads, const bwagpu_alnreg_t *all, const int64_t *roff,
 					const Pestat *pes0, int n_threads, const char *rg_id, std::vector<std::string> &sam, bool verbose)
 {
 	sam.assign(n, std::string());
 	if (opt.flag & F_PE) {
 		Pestat pes[4];
-		if (pes0) memcpy(pes, pes0, sizeof pes); else pestat(opt, ref.l_pac, n, regs, pes, verbose);
+		if (pes0) memcpy(pes, pes0, sizeof pes); else pestat_flat(opt, ref.l_pac, n, all, roff, pes, verbose);
 		parallel_for(n_threads, n >> 1, [&](long i) {
+			thread_local Regs a[2];
+			a[0].assign(all + roff[i << 1], all + roff[(i << 1) + 1]); a[1].assign(all + roff[(i << 1) + 1], all + roff[(i << 1) + 2]);
 			std::string out[2];
-			sam_pe(opt, ref, pes, (uint64_t)((n_processed >> 1) + i), &reads[i << 1], &regs[i << 1], out, rg_id);
+			sam_pe(opt, ref, pes, (uint64_t)((n_processed >> 1) + i), &reads[i << 1], a, out, rg_id);
 			sam[i << 1].swap(out[0]); sam[i << 1 | 1].swap(out[1]);
-			Regs().swap(regs[i << 1]); Regs().swap(regs[i << 1 | 1]);
 		});
 	} else {
 		parallel_for(n_threads, n, [&](long i) {
-			mark_primary_se(opt, regs[i], n_processed + i);
-			if (opt.flag & F_PRIMARY5) reorder_primary5(opt.T, regs[i]);
-			reg2sam(opt, ref, sam[i], reads[i], regs[i], 0, 0, rg_id);
-			Regs().swap(regs[i]);      // release in the worker: the caller would otherwise free a million small blocks serially
+			thread_local Regs a;
+			a.assign(all + roff[i], all + roff[i + 1]);
+			mark_primary_se(opt, a, n_processed + i);
+			if (opt.flag & F_PRIMARY5) reorder_primary5(opt.T, a);
+			reg2sam(opt, ref, sam[i], reads[i], a, 0, 0, rg_id);
 		});
 	}
 }
@@ -70,20 +75,20 @@ char *bwamem_host_regs2sam(void *h, const bwagpu_opt_t *opt, int64_t n_processed
 						   const uint32_t *cig_ops /* optional: bwagpu_batch_cigar_ops output (records with more than 6 operations) */)
 {
 	const RefSeqs &ref = *(RefSeqs*)h;
-	std::vector<Read> reads(n); std::vector<Regs> rv(n); std::vector<CigHints> hints(n);
+	std::vector<Read> reads(n); std::vector<CigHints> hints(n); std::vector<int64_t> roffs((size_t)n + 1, 0);
 	const char *nm = names; int64_t roff = 0;
 	for (int i = 0; i < n; ++i) {
 		reads[i].name = nm; nm += strlen(nm) + 1;
 		reads[i].comment = 0; reads[i].seq = seqs + off[i]; reads[i].qual = quals ? quals + off[i] : 0; reads[i].l_seq = (int)(off[i + 1] - off[i]);
 		if (cigs) { hints[i].regs = regs + roff; hints[i].cigs = cigs + roff; hints[i].n = counts[i]; hints[i].ops = cig_ops; reads[i].hints = &hints[i]; }
-		rv[i].assign(regs + roff, regs + roff + counts[i]); roff += counts[i];
+		roff += counts[i]; roffs[i + 1] = roff;
 	}
 	std::vector<bwagpu_matesw_t> msw_sorted;
 	if (msw) attach_matesw(n, reads.data(), msw, n_msw, msw_sorted);
 	std::vector<std::string> sam;
 	const bool trace = getenv("BWAMEM_HOST_TRACE") != nullptr;      // diagnostics: time of the finalize stage proper
 	const auto t0 = std::chrono::steady_clock::now();
-	finalize_batch(*opt, ref, n_processed, n, reads.data(), rv, pes0, n_threads, 0, sam, false);
+	finalize_batch(*opt, ref, n_processed, n, reads.data(), regs, roffs.data(), pes0, n_threads, 0, sam, false);
 	if (trace) fprintf(stderr, "[host] finalize_batch: %d reads, %d threads, %.3f s\n", n, n_threads, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 	size_t tot = 0;
 	for (auto &s : sam) tot += s.size();

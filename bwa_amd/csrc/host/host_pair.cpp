@@ -98,12 +98,7 @@ template <class Get> static void pestat_impl(const bwagpu_opt_t &opt, int64_t l_
 		}
 }
 
-void pestat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const std::vector<Regs> &regs, Pestat pes[4], bool verbose)
-{
-	pestat_impl(opt, l_pac, n, [&](int i) { return RegSpan{regs[i].data(), regs[i].size()}; }, pes, verbose);
-}
-
-// the same on a batch's flat region array (regions of read i at all[roff[i] .. roff[i+1]))
+// mem_pestat on a batch's flat region array (regions of read i at all[roff[i] .. roff[i+1]))
 void pestat_flat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const bwagpu_alnreg_t *all, const int64_t *roff, Pestat pes[4], bool verbose)
 {
 	pestat_impl(opt, l_pac, n, [&](int i) { return RegSpan{all + roff[i], (size_t)(roff[i + 1] - roff[i])}; }, pes, verbose);

@@ -24,7 +24,7 @@
 #include "bwamem_host.h"
 
 namespace hostmem {
-void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_processed, int n, const Read *reads, std::vector<Regs> &regs,
+void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_processed, int n, const Read *reads, const bwagpu_alnreg_t *all, const int64_t *roff,
 					const Pestat *pes0, int n_threads, const char *rg_id, std::vector<std::string> &sam, bool verbose);
 }
 using namespace hostmem;
@@ -346,13 +346,12 @@ static void finalize_sub(const RefSeqs &ref, Work &w, Sub &u, const Pestat *pes0
 {
 	const double t0 = now_s();
 	const int n = (int)u.idx.size();
-	std::vector<Regs> regs((size_t)n); std::vector<Read> reads((size_t)n); std::vector<CigHints> hints(u.cigs ? (size_t)n : 0);
+	std::vector<Read> reads((size_t)n); std::vector<CigHints> hints(u.cigs ? (size_t)n : 0);
 	std::vector<int64_t> roff((size_t)n + 1, 0);
 	for (int i = 0; i < n; ++i) roff[i + 1] = roff[i] + u.counts[i];
 	parallel_for(u.opt.n_threads, n, [&](long i) {
 		const Seq &q = w.in.seqs[u.idx[i]];
 		const char *T = w.in.text.data();
-		regs[i].assign(u.all + roff[i], u.all + roff[i + 1]);
 		if (u.cigs) { hints[i].regs = u.all + roff[i]; hints[i].cigs = u.cigs + roff[i]; hints[i].n = u.counts[i]; hints[i].ops = u.cig_ops; reads[i].hints = &hints[i]; }
 		reads[i].name = T + q.name;
 		reads[i].comment = copy_comment && q.has_comment ? T + q.comment : nullptr;
@@ -362,7 +361,7 @@ static void finalize_sub(const RefSeqs &ref, Work &w, Sub &u, const Pestat *pes0
 	std::vector<bwagpu_matesw_t> msw_sorted;
 	if (u.msw) attach_matesw(n, reads.data(), u.msw, u.n_msw, msw_sorted);
 	std::vector<std::string> sam;
-	finalize_batch(u.opt, ref, u.n_processed, n, reads.data(), regs, (u.opt.flag & F_PE) ? (u.have_pes ? u.pes : pes0) : nullptr, u.opt.n_threads, rg_id, sam, g_verbose >= 3);
+	finalize_batch(u.opt, ref, u.n_processed, n, reads.data(), u.all, roff.data(), (u.opt.flag & F_PE) ? (u.have_pes ? u.pes : pes0) : nullptr, u.opt.n_threads, rg_id, sam, g_verbose >= 3);
 	bwagpu_free(u.all); u.all = nullptr; bwagpu_free(u.cigs); u.cigs = nullptr; bwagpu_free(u.cig_ops); u.cig_ops = nullptr; bwagpu_free(u.msw); u.msw = nullptr;
 	for (int i = 0; i < n; ++i) w.out[u.idx[i]].swap(sam[i]);
 	if (g_verbose >= 3) fprintf(stderr, "[M::%s] Processed %d reads in %.3f real sec\n", "mem_process_seqs", n, u.t_dev + (now_s() - t0));
