@@ -70,7 +70,7 @@ int mark_primary_se(const bwagpu_opt_t &opt, Regs &av, int64_t id)
 	int n = (int)av.size(), n_pri = 0;
 	if (n == 0) return 0;
 	bwagpu_alnreg_t *a = av.data();
-	std::vector<int> z;
+	thread_local std::vector<int> z, map;      // (scratch kept from read to read: the stage is allocation-bound otherwise)
 	for (int i = 0; i < n; ++i) {
 		a[i].sub = a[i].alt_sc = 0; a[i].secondary = a[i].secondary_all = -1; a[i].hash = hash_64((uint64_t)(id + i));
 		if (!a[i].is_alt) ++n_pri;
@@ -82,7 +82,7 @@ int mark_primary_se(const bwagpu_opt_t &opt, Regs &av, int64_t id)
 		if (!a[i].is_alt && a[i].secondary >= 0 && a[a[i].secondary].is_alt) a[i].alt_sc = a[a[i].secondary].score;
 	}
 	if (n_pri >= 0 && n_pri < n) {
-		std::vector<int> map(n);
+		map.resize(n);
 		if (n_pri > 0) introsort(a, n, HashLess2());
 		for (int i = 0; i < n; ++i) map[a[i].secondary_all] = i;
 		for (int i = 0; i < n; ++i) {
@@ -267,7 +267,8 @@ Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint
 	if (const bwagpu_cigar_t *pc = find_hint(hints, *ar)) {   // the loop below already ran on the device: only NM/MD are left
 		if (pc->n_cigar <= 6) a.cigar.assign(pc->cigar, pc->cigar + pc->n_cigar);
 		else { const uint32_t *o = hints->ops + ((uint64_t)pc->cigar[1] << 32 | pc->cigar[0]); a.cigar.assign(o, o + pc->n_cigar); }
-		std::vector<uint8_t> rseq, qs(query + qb, query + qe);
+		thread_local std::vector<uint8_t> rseq, qs;
+		qs.assign(query + qb, query + qe);
 		ref.get_seq(rb, re, rseq);
 		if (rb >= ref.l_pac) { std::reverse(qs.begin(), qs.end()); std::reverse(rseq.begin(), rseq.end()); }
 		nm_md(rb < ref.l_pac, qs.data(), rseq.data(), a.cigar, &NM, a.md);
@@ -312,7 +313,8 @@ static bool gen_alt(const bwagpu_opt_t &opt, const RefSeqs &ref, const Regs &av,
 {
 	int n = (int)av.size(), tot = 0;
 	const bwagpu_alnreg_t *a = av.data();
-	std::vector<int> cnt(n, 0); std::vector<char> has_alt(n, 0);
+	thread_local std::vector<int> cnt; thread_local std::vector<char> has_alt;
+	cnt.assign(n, 0); has_alt.assign(n, 0);
 	for (int i = 0; i < n; ++i) {
 		int r = pri_idx(opt.XA_drop_ratio, a, i);
 		if (r >= 0) { ++cnt[r]; ++tot; if (a[i].is_alt) has_alt[r] = 1; }

@@ -263,7 +263,8 @@ struct Pair64Less { bool operator()(const Pair64 &a, const Pair64 &b) const { re
 
 static int pair_ends(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], const Regs a[2], int id, int *sub, int *n_sub, int z[2], const int n_pri[2])
 {
-	std::vector<Pair64> v, u;
+	thread_local std::vector<Pair64> v, u;      // (scratch kept from pair to pair)
+	v.clear(); u.clear();
 	const int64_t l_pac = ref.l_pac;
 	int y[4], ret;
 	for (int r = 0; r < 2; ++r)
@@ -326,8 +327,10 @@ int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uin
 {
 	int n = 0, z[2] = {0, 0}, o, subo, n_sub, extra_flag = 1, n_pri[2];
 	Aln h[2];
+	for (int i = 0; i < 2; ++i) out[i].reserve(out[i].size() + 2 * (size_t)s[i].l_seq + 320);      // one allocation instead of the five a growing string makes
 	if (!(opt.flag & F_NO_RESCUE)) {   // mate rescue from the best hits of each end
-		Regs b[2];
+		thread_local Regs b[2];
+		b[0].clear(); b[1].clear();
 		for (int i = 0; i < 2; ++i)
 			for (size_t j = 0; j < a[i].size(); ++j)
 				if (a[i][j].score >= a[i][0].score - opt.pen_unpaired) b[i].push_back(a[i][j]);
