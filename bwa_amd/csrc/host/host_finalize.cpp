@@ -410,7 +410,7 @@ void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &str, cons
 				if (((*p.cigar)[0] & 0xf) == 4 || ((*p.cigar)[0] & 0xf) == 3) qb += (*p.cigar)[0] >> 4;
 				if ((p.cigar->back() & 0xf) == 4 || (p.cigar->back() & 0xf) == 3) qe -= p.cigar->back() >> 4;
 			}
-			for (int i = qb; i < qe; ++i) str += "ACGTN"[s.seq[i]];
+			{ const size_t at = str.size(); str.resize(at + (size_t)(qe > qb ? qe - qb : 0)); char *d = &str[0] + at; for (int i = qb; i < qe; ++i) *d++ = "ACGTN"[s.seq[i]]; }   // (written in place: a checked append per base was a fifth of the stage)
 			str += '\t';
 			if (s.qual) str.append(s.qual + qb, s.qual + qe); else str += '*';
 		} else {
@@ -418,9 +418,9 @@ void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &str, cons
 				if (((*p.cigar)[0] & 0xf) == 4 || ((*p.cigar)[0] & 0xf) == 3) qe -= (*p.cigar)[0] >> 4;
 				if ((p.cigar->back() & 0xf) == 4 || (p.cigar->back() & 0xf) == 3) qb += p.cigar->back() >> 4;
 			}
-			for (int i = qe - 1; i >= qb; --i) str += "TGCAN"[s.seq[i]];
+			{ const size_t at = str.size(); str.resize(at + (size_t)(qe > qb ? qe - qb : 0)); char *d = &str[0] + at; for (int i = qe - 1; i >= qb; --i) *d++ = "TGCAN"[s.seq[i]]; }
 			str += '\t';
-			if (s.qual) for (int i = qe - 1; i >= qb; --i) str += s.qual[i]; else str += '*';
+			if (s.qual) { const size_t at = str.size(); str.resize(at + (size_t)(qe > qb ? qe - qb : 0)); char *d = &str[0] + at; for (int i = qe - 1; i >= qb; --i) *d++ = s.qual[i]; } else str += '*';
 		}
 	}
 	if (!p.cigar->empty()) { str += "\tNM:i:"; put_int(str, p.NM); str += "\tMD:Z:"; str += *p.md; }
