@@ -222,11 +222,12 @@ static void encode_sub(const Batch &in, Sub &u)
 	u.off.assign((size_t)n + 1, 0);
 	for (int i = 0; i < n; ++i) u.off[i + 1] = u.off[i] + (int64_t)in.seqs[u.idx[i]].l_seq;
 	u.flat.resize((size_t)u.off[n] + 1);
-	for (int i = 0; i < n; ++i) {
+	// (100 MB of table look-ups per batch: a tenth of a second on one thread, inside the stage that feeds the device)
+	parallel_for(u.opt.n_threads < 4 ? u.opt.n_threads : 4, n, [&](long i) {
 		const Seq &q = in.seqs[u.idx[i]];
 		const unsigned char *src = (const unsigned char*)in.text.data() + q.seq; uint8_t *d = u.flat.data() + u.off[i];
 		for (int j = 0; j < q.l_seq; ++j) d[j] = g_nt4.t[src[j]];
-	}
+	});
 	u.counts.assign((size_t)n, 0);
 }
 
