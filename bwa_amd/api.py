@@ -34,6 +34,8 @@ assert MATESW_DTYPE.itemsize == 56
 PES_DTYPE = np.dtype([("low", "<i4"), ("high", "<i4"), ("failed", "<i4"), ("pad_", "<i4")])               # bwagpu_pes_t
 CIGAR_DTYPE = np.dtype([("score", "<i4"), ("n_cigar", "<i4"), ("cigar", "<u4", (6,))])   # bwagpu_cigar_t
 assert CIGAR_DTYPE.itemsize == 32
+DP_CASE_DTYPE = np.dtype([("q_off", "<i4"), ("q_len", "<i4"), ("t_off", "<i4"), ("t_len", "<i4"), ("w", "<i4"), ("h0", "<i4"), ("end_bonus", "<i4"), ("flags", "<i4")])   # bwagpu_dp_case_t
+assert DP_CASE_DTYPE.itemsize == 32
 
 
 class Stats(C.Structure):
@@ -53,7 +55,7 @@ EXPORTS = [
     "bwagpu_index_info", "bwagpu_densify_sa", "bwagpu_set_stats", "bwagpu_get_stats", "bwagpu_align_bseq", "bwagpu_align_flat",
     "bwagpu_free", "bwagpu_batch_upload", "bwagpu_batch_run", "bwagpu_batch_download", "bwagpu_set_taps", "bwagpu_tap_intervals",
     "bwagpu_tap_chains", "bwagpu_tap_regs_raw", "bwagpu_index_buffers", "bwagpu_index_export", "bwagpu_clone", "bwagpu_index_ready",
-    "bwagpu_batch_cigars", "bwagpu_batch_cigar_ops", "bwagpu_debug_phase", "bwagpu_batch_matesw", "bwagpu_clone_to_device", "bwagpu_index_build", "bwagpu_built_free", "bwagpu_abi_sizes", "bwagpu_debug_prof",
+    "bwagpu_batch_cigars", "bwagpu_batch_cigar_ops", "bwagpu_debug_phase", "bwagpu_batch_matesw", "bwagpu_clone_to_device", "bwagpu_index_build", "bwagpu_built_free", "bwagpu_abi_sizes", "bwagpu_debug_prof", "bwagpu_debug_dp",
 ]
 
 
@@ -99,6 +101,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.bwagpu_index_ready.argtypes = [C.c_void_p]
     L.bwagpu_index_buffers.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     L.bwagpu_index_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bwagpu_debug_dp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     return L
 
 
@@ -223,6 +226,14 @@ class BwaGpu:
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.L.bwagpu_batch_matesw(self.h, C.byref(opt), pes.ctypes.data, C.byref(p), C.byref(n)))
         return self._take(p, n.value, MATESW_DTYPE)
+
+    def debug_dp(self, opt: MemOpt, kind: int, cases: np.ndarray, seqs: np.ndarray) -> np.ndarray:
+        """bwagpu_debug_dp: one wavefront of a device DP routine per case (DP_CASE_DTYPE) -> int32[n_cases, 72]."""
+        cases = np.ascontiguousarray(cases, dtype=DP_CASE_DTYPE)
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        out = np.zeros((cases.shape[0], 72), dtype=np.int32)
+        self._chk(self.L.bwagpu_debug_dp(self.h, C.byref(opt), kind, cases.shape[0], cases.ctypes.data, seqs.ctypes.data, seqs.shape[0], out.ctypes.data))
+        return out
 
     def align(self, opt: MemOpt, seqs: np.ndarray, off: np.ndarray):
         self.upload(seqs, off)

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -32,6 +33,7 @@
 #include "dev_cigar.h"
 #include "dev_dedupw.h"
 #include "dev_matesw.h"
+#include "dev_debug.h"
 
 #define BWAGPU_VERSION "bwagpu 0.1 (gfx950)"
 
@@ -58,7 +60,7 @@ struct bwagpu_s {
 	// index
 	DevIndex ix = {};
 	struct IndexBufs {
-		DevBuf d_bwt, d_sa, d_pac, d_ctg_off, d_ctg_len, d_ctg_alt, d_ptab, d_occ32, d_occ_sb; int refs = 1;
+		DevBuf d_bwt, d_sa, d_pac, d_ctg_off, d_ctg_len, d_ctg_alt, d_ptab, d_occ32, d_occ_sb; std::atomic<int> refs{1};
 		// per-base arena needs learnt by any handle on this index (a re-run for arena growth doubles a batch's device time, so a
 		// cloned handle should not have to learn them again); written and read under `m`
 		std::mutex m; double need_slot = 0, need_node = 0, need_reg = 0; int need_mem = 0;
@@ -395,9 +397,8 @@ extern "C" int bwagpu_clone(bwagpu_t *src, bwagpu_t **out)
 // (possibly densified) SA, the contig table and the prefix tables travel device to device with hipMemcpyPeer -- point to point
 // over xGMI, the single-process counterpart of the RCCL broadcast that bwa_amd/dist.py does between processes.  The new handle
 // owns its copy; bwagpu_clone() on it gives further streams on that device.
-extern "C" int bwagpu_clone_to_device(bwagpu_t *src, int device, bwagpu_t **out)
+static int clone_to_device_impl(bwagpu_t *src, int device, bwagpu_t **out)
 {
-	if (!src || !out) return BWAGPU_EINVAL;
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return BWAGPU_ENODEV;
 	if (device == src->device) return bwagpu_clone(src, out);
@@ -431,6 +432,16 @@ extern "C" int bwagpu_clone_to_device(bwagpu_t *src, int device, bwagpu_t **out)
 	h->stats_on = src->stats_on; h->taps_on = src->taps_on;
 	*out = h;
 	return BWAGPU_OK;
+}
+
+extern "C" int bwagpu_clone_to_device(bwagpu_t *src, int device, bwagpu_t **out)
+{
+	if (!src || !out) return BWAGPU_EINVAL;
+	int prev = -1;
+	if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+	const int rc = clone_to_device_impl(src, device, out);
+	if (prev >= 0) (void)hipSetDevice(prev);      // the calling thread's current device is left as it was
+	return rc;
 }
 
 extern "C" int bwagpu_index_buffers(bwagpu_t *h, void **bwt, uint64_t *bwt_bytes, void **sa, uint64_t *sa_bytes, void **pac, uint64_t *pac_bytes)
@@ -625,7 +636,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 	HIPCHK(h, hipSetDevice(h->device));
 	memset(&h->stats, 0, sizeof h->stats);
 	h->stats.n_reads = h->n_reads; h->stats.n_bases = h->n_bases;
-	h->ran = false; h->packed_tot = -1;      // regions packed by an earlier download belong to the previous run
+	h->ran = false; h->packed_tot = -1; h->cig_ext_n = -1;      // regions packed by an earlier download (and their CIGAR operations) belong to the previous run
 	if (h->n_reads == 0) { h->ran = true; return BWAGPU_OK; }
 	int n = h->n_reads;
 	// resident lanes: enough to fill the chip, bounded by the seeding scratch budget (2 interval stacks per lane)
@@ -848,6 +859,7 @@ extern "C" int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg
 	if (!h || !h->ran || !regs_out || !n_regs_out) return BWAGPU_EINVAL;
 	HIPCHK(h, hipSetDevice(h->device));
 	const int n = h->n_reads;
+	h->cig_ext_n = -1;
 	if (n == 0) { *regs_out = (bwagpu_alnreg_t*)malloc(sizeof(bwagpu_alnreg_t)); *n_regs_out = 0; return BWAGPU_OK; }
 	h->phase = 30;
 	std::vector<i32> cnt((size_t)n); std::vector<i64> dst((size_t)n);
@@ -883,7 +895,7 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 	if (opt->e_del <= 0 || opt->e_ins <= 0) return BWAGPU_EINVAL;
 	HIPCHK(h, hipSetDevice(h->device));
 	const i64 tot = h->packed_tot;
-	h->phase = 40;
+	h->phase = 40; h->cig_ext_n = -1;
 	static_assert(sizeof(bwagpu_cigar_t) == 32, "layout");
 	bwagpu_cigar_t *res = (bwagpu_cigar_t*)malloc((size_t)(tot ? tot : 1) * sizeof(bwagpu_cigar_t));
 	if (!res) return BWAGPU_ENOMEM;
@@ -922,8 +934,8 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		h->phase = 45;
 		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_cigs.p, (size_t)tot * sizeof(bwagpu_cigar_t), hipMemcpyDeviceToHost, h->stream);
 		if (e == hipSuccess) e = wait_stream(h);
+		if (e != hipSuccess) { free(res); h->cig_ext_n = -1; HIPCHK(h, e); }
 		h->cig_ext_n = (i64)used < ext_cap ? (i64)used : ext_cap;
-		if (e != hipSuccess) { free(res); HIPCHK(h, e); }
 	}
 	if (tot == 0) h->cig_ext_n = 0;
 	*out = res; *n_out = tot;
@@ -1033,6 +1045,63 @@ extern "C" int bwagpu_align_bseq(bwagpu_t *h, const bwagpu_opt_t *opt, int n, bw
 	}
 	free(all);
 	return BWAGPU_OK;
+}
+
+// ---- differential tests of the DP routines (dev_debug.h) ---------------------------------------------------------------------
+extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, int n_cases, const bwagpu_dp_case_t *cases, const uint8_t *seqs, int64_t n_seq_bytes, int32_t *out)
+{
+	if (!h || !opt || n_cases < 0 || kind < 0 || kind > 4 || (n_cases > 0 && (!cases || !seqs || !out)) || n_seq_bytes < 0) return BWAGPU_EINVAL;
+	if (opt->e_del <= 0 || opt->e_ins <= 0) return BWAGPU_EINVAL;
+	if (n_cases == 0) return BWAGPU_OK;
+	static_assert(sizeof(bwagpu_dp_case_t) == 32, "layout");
+	int max_q = 1, max_w = 1;
+	for (int i = 0; i < n_cases; ++i) {
+		const bwagpu_dp_case_t &c = cases[i];
+		if (c.q_len < 0 || c.t_len < 0 || c.q_off < 0 || c.t_off < 0 || (i64)c.q_off + c.q_len > n_seq_bytes || (i64)c.t_off + c.t_len > n_seq_bytes || c.w < 0) return BWAGPU_EINVAL;
+		if ((kind == 0 || kind == 1) && c.h0 <= 0) return BWAGPU_EINVAL;      // ksw_extend2 asserts h0 > 0 (ksw.c:420)
+		if (c.q_len > max_q) max_q = c.q_len;
+		if (c.w > max_w) max_w = c.w;
+	}
+	HIPCHK(h, hipSetDevice(h->device));
+	DevBuf d_seq, d_pac, d_cases, d_out, d_scr;
+	int rc = BWAGPU_OK;
+	const int grid = n_cases < 2048 ? n_cases : 2048;
+	hipError_t e = hipSuccess;
+	if (d_seq.ensure((size_t)n_seq_bytes + 16) || d_pac.ensure((size_t)n_seq_bytes / 4 + 16) || d_cases.ensure((size_t)n_cases * sizeof(bwagpu_dp_case_t)) || d_out.ensure((size_t)n_cases * DBG_OUT_INTS * 4)) { h->err = "hipMalloc failed (debug)"; rc = BWAGPU_ENOMEM; goto done; }
+	e = hipMemcpyAsync(d_seq.p, seqs, (size_t)n_seq_bytes, hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_cases.p, cases, (size_t)n_cases * sizeof(bwagpu_dp_case_t), hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) e = hipMemsetAsync(d_out.p, 0, (size_t)n_cases * DBG_OUT_INTS * 4, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_debug_pack, dim3(256), dim3(256), 0, h->stream, d_seq.as<u8>(), (i64)n_seq_bytes, d_pac.as<u8>());
+		DevIndex ix = h->ix; ix.pac = d_pac.as<u8>(); ix.l_pac = n_seq_bytes;
+		if (kind == 0) {
+			if (max_q > WAVE_EXT_MAX_LEN) { rc = BWAGPU_EINVAL; goto done; }
+			const size_t lds = (8 * (size_t)(max_q + 2 + 64) + 5 * (size_t)((max_q + 64 + 3) & ~3) + 32 + 15) & ~(size_t)15;
+			hipLaunchKernelGGL((k_debug_extend<false>), dim3(grid), dim3(64), lds, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, 0, d_out.as<i32>());
+		} else if (kind == 1) {
+			int ring_cols = 256; while (ring_cols < 2 * max_w + 4 + 128) ring_cols <<= 1;
+			if (ring_cols > 4096) { rc = BWAGPU_EINVAL; goto done; }
+			hipLaunchKernelGGL((k_debug_extend<true>), dim3(grid), dim3(64), (size_t)8 * ring_cols + 32, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, ring_cols, d_out.as<i32>());
+		} else if (kind == 2) {
+			hipLaunchKernelGGL(k_debug_global, dim3(grid), dim3(64), (size_t)CIG_LDS_BYTES(CIG_Z_BIG), h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), d_out.as<i32>());
+		} else if (kind == 3) {
+			int ring_cols = 256; while (ring_cols < 2 * max_w + 4 + 128) ring_cols <<= 1;
+			if (ring_cols > 4096) { rc = BWAGPU_EINVAL; goto done; }
+			hipLaunchKernelGGL(k_debug_global_ring, dim3(grid), dim3(64), (size_t)8 * ring_cols + 32, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), ring_cols, d_out.as<i32>());
+		} else {
+			const int blocks = (n_cases + 63) / 64 < 256 ? (n_cases + 63) / 64 : 256;
+			if (d_scr.ensure((size_t)blocks * MSW_LANE_INTS * 64 * 4)) { h->err = "hipMalloc failed (debug)"; rc = BWAGPU_ENOMEM; goto done; }
+			hipLaunchKernelGGL(k_debug_align2, dim3(blocks), dim3(64), 0, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), d_scr.as<i32>(), d_out.as<i32>());
+		}
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(out, d_out.p, (size_t)n_cases * DBG_OUT_INTS * 4, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = wait_stream(h);
+	if (e != hipSuccess) { h->err = std::string("bwagpu_debug_dp: ") + hipGetErrorString(e); rc = BWAGPU_EHIP; }
+done:
+	(void)hipStreamSynchronize(h->stream);
+	d_seq.release(); d_pac.release(); d_cases.release(); d_out.release(); d_scr.release();
+	return rc;
 }
 
 // ---- stage taps ----------------------------------------------------------------------------------------------

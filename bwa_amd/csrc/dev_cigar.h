@@ -75,7 +75,9 @@ __device__ int wave_ksw_global2(const DevIndex &ix, const bwagpu_opt_t &opt, con
 				// are written by the same lane
 				const u32 nib = (u32)(d & 7) | (u32)(d >> 5 & 1) << 3;
 				u8 *zb = z + (i >> 1) * n_col + (j - beg);
-				*zb = (i & 1) ? (u8)(*zb | nib << 4) : (u8)nib;
+				// (an odd row replaces the high nibble rather than OR-ing into it: while the band still widens, its last column has no even-row
+				// partner that would have cleared the byte, and the LDS holds whatever the previous region left there)
+				*zb = (i & 1) ? (u8)((*zb & 15u) | nib << 4) : (u8)nib;
 			}
 			if (b == beg && lane == 0) hd[beg] = h1_init;
 			carry = imax(carry, __builtin_amdgcn_readlane(inc, 63));

@@ -120,6 +120,22 @@ __device__ MswRes dev_sw_core(int size, int qlen, QF Q, int tlen, TF T, const bw
 	return r;
 }
 
+// ksw_align2 (ksw.c:379-400): the forward pass and, with KSW_XSTART, the pass over the reversed prefixes that finds the start
+// positions.  res = {score, te, qe, score2, te2, tb, qb}.
+template <class QF, class TF>
+__device__ void msw_align2(const bwagpu_opt_t &opt, int qlen, QF Qf, int tlen, TF Tf, int xtra, i32 *S, int res[7])
+{
+	const int size = (xtra & MSW_XBYTE) ? 1 : 2;
+	const MswRes a = dev_sw_core(size, qlen, Qf, tlen, Tf, opt, xtra, S);
+	res[0] = a.score; res[1] = a.te; res[2] = a.qe; res[3] = a.score2; res[4] = a.te2; res[5] = -1; res[6] = -1;
+	if (((xtra & MSW_XSTART) == 0) || ((xtra & MSW_XSUBO) && a.score < (xtra & 0xffff))) return;
+	const int qe = a.qe, te = a.te;
+	auto Q2 = [&](int j) -> int { return Qf(qe - j); };
+	auto T2 = [&](int i) -> int { return i <= te ? Tf(te - i) : Tf(i); };
+	const MswRes b = dev_sw_core(size, qe + 1, Q2, tlen, T2, opt, MSW_XSTOP | a.score, S);
+	if (a.score == b.score) { res[5] = a.te - b.te; res[6] = a.qe - b.qe; }
+}
+
 // One lane per task (tasks drawn from a counter); out[t] is written for every task, r = -1 marking "no alignment was due".
 __global__ void __launch_bounds__(256) k_matesw_sw(DevIndex ix, bwagpu_opt_t opt, Batch Bt, const bwagpu_pes_t *pes, const MateTask *tasks, i64 n_tasks,
 													bwagpu_matesw_t *out, unsigned long long *next, i32 *scratch)
@@ -161,18 +177,11 @@ __global__ void __launch_bounds__(256) k_matesw_sw(DevIndex ix, bwagpu_opt_t opt
 		if (due) {
 			const int tlen = (int)(re - rb);
 			const int xtra = MSW_XSUBO | MSW_XSTART | (l_ms * opt.a < 250 ? MSW_XBYTE : 0) | (opt.min_seed_len * opt.a);
-			const int size = (xtra & MSW_XBYTE) ? 1 : 2;
 			auto Qf = [&](int j) -> int { return is_rev ? (ms[l_ms - 1 - j] < 4 ? 3 - ms[l_ms - 1 - j] : 4) : (int)ms[j]; };
 			auto Tf = [&](int i) -> int { return ref_base(ix, rb + i); };
-			MswRes a = dev_sw_core(size, l_ms, Qf, tlen, Tf, opt, xtra, S);
-			o.r = r; o.score = a.score; o.te = a.te; o.qe = a.qe; o.score2 = a.score2; o.te2 = a.te2;
-			if (!((xtra & MSW_XSUBO) && a.score < (xtra & 0xffff))) {   // start positions: reversed prefixes (ksw.c:392-399)
-				const int qe = a.qe, te = a.te;
-				auto Q2 = [&](int j) -> int { return Qf(qe - j); };
-				auto T2 = [&](int i) -> int { return i <= te ? Tf(te - i) : Tf(i); };
-				MswRes b = dev_sw_core(size, qe + 1, Q2, tlen, T2, opt, MSW_XSTOP | a.score, S);
-				if (a.score == b.score) { o.tb = a.te - b.te; o.qb = a.qe - b.qe; }
-			}
+			int res[7];
+			msw_align2(opt, l_ms, Qf, tlen, Tf, xtra, S, res);
+			o.r = r; o.score = res[0]; o.te = res[1]; o.qe = res[2]; o.score2 = res[3]; o.te2 = res[4]; o.tb = res[5]; o.qb = res[6];
 		}
 		out[t] = o;
 	}

@@ -186,7 +186,7 @@ static bool read_batch(Reader &r1, Reader *r2, int chunk, Batch &out)
 
 struct Nt4 {   // nst_nt4_table (bntseq.c:46-63)
 	uint8_t t[256];
-	Nt4() { memset(t, 4, sizeof t); t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3; }
+	Nt4() { memset(t, 4, sizeof t); t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3; t['-'] = 5; }
 };
 static const Nt4 g_nt4;
 
@@ -235,7 +235,8 @@ static void encode_sub(const Batch &in, Sub &u)
 static std::mutex g_dev_mutex;
 static bool g_dev_serialize = false;   // BWAGPU_CLI_SERIALIZE=1: one device call at a time (the mock HIP runtime of the CPU tests is not thread-safe)
 
-static void device_fail(bwagpu_t *gpu, int rc) { fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu)); exit(EXIT_FAILURE); }
+// (_exit: this runs on a device thread while sibling threads may be inside HIP calls -- no atexit handlers / static destructors under them)
+static void device_fail(bwagpu_t *gpu, int rc) { fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu)); fflush(stderr); fflush(stdout); _exit(EXIT_FAILURE); }
 
 // One mem_process_seqs call's device work on the GPUs of `gpus` (one handle per device).  With several devices
 // the reads are split into contiguous ranges of whole pairs, every device runs the hot path -- and the device-side CIGARs and
@@ -294,6 +295,7 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 		if (!u.all || (have_cigs && !u.cigs)) { fprintf(stderr, "[E::%s] out of memory\n", "mem_process_seqs"); exit(EXIT_FAILURE); }
 		int64_t n_ops = 0; for (auto &s : sh) n_ops += s.n_ops;
 		u.cig_ops = have_cigs ? (uint32_t*)malloc((size_t)(n_ops ? n_ops : 1) * 4) : nullptr;
+		if (have_cigs && !u.cig_ops) { fprintf(stderr, "[E::%s] out of memory\n", "mem_process_seqs"); exit(EXIT_FAILURE); }
 		int64_t k = 0, ko = 0;
 		for (auto &s : sh) {
 			if (s.tot) memcpy(u.all + k, s.all, (size_t)s.tot * sizeof(bwagpu_alnreg_t));

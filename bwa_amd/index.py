@@ -33,6 +33,10 @@ class Built(C.Structure):
 def pack_pac(codes: np.ndarray) -> np.ndarray:
     """2-bit packing of the forward strand, base l in byte l >> 2 at bits (3 - l % 4) * 2 (bntseq.c:229); l_pac/4 + 1 bytes."""
     l_pac = int(codes.shape[0])
+    # an ambiguity code left in the array would be OR-ed into its neighbours' bits: the caller replaces Ns first (bns_fasta2bntseq
+    # does, bntseq.c:266,295-296) and lists them as holes
+    if l_pac and int(codes.max()) > 3:
+        raise ValueError("pack_pac: base codes must be 0..3 (replace ambiguity codes first and pass them to write_pac_ann_amb as holes)")
     out = np.zeros(l_pac // 4 + 1, dtype=np.uint8)
     full = l_pac // 4 * 4
     if full:

@@ -194,6 +194,26 @@ int bwagpu_debug_phase(const bwagpu_t *h);
  * ran its bookkeeping code, and the lanes extending summed over iterations (tools/seed_iter_probe.py). */
 int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16]);
 
+/* ---- differential tests of the device DP routines ----------------------------------------------------------------------- */
+/* One case of bwagpu_debug_dp.  Sequences are nt4 codes in the call's `seqs` array: the query may hold 0..4, the target 0..3 (the
+ * device reads targets from 2-bit packed reference text).  flags: bit 0 = present the query back to front, bit 1 = present the
+ * target back to front, bit 2 = present the target's complement (read through the reverse-strand half of the text). */
+typedef struct {
+	int32_t q_off, q_len, t_off, t_len;
+	int32_t w;               /* band width */
+	int32_t h0;              /* kinds 0,1: ksw_extend2's h0; kind 4: ksw_align2's xtra word */
+	int32_t end_bonus;       /* kinds 0,1 */
+	int32_t flags;
+} bwagpu_dp_case_t;
+/* Runs one wavefront of a device DP routine per case, set up exactly as the product kernel sets it up, and returns 72 ints per
+ * case.  kind 0: ksw_extend2 as k_extend_wave runs it for short reads (ksw.c:416; columns and read profile in LDS), kind 1: the
+ * same in ring mode (long reads) -> {score, qle, tle, gtle, gscore, max_off, answered-without-DP, cells}; kind 2: ksw_global2 with
+ * traceback as k_cigar runs it (ksw.c:540) -> {score, n_ops, ops...} (n_ops -1: more than 64 operations, -2: outside the kernel's
+ * limits); kind 3: the score-only ksw_global2 of k_dedup_wave -> {score}; kind 4: ksw_align2 as k_matesw_sw runs it (ksw.c:379)
+ * -> {score, te, qe, score2, te2, tb, qb}; kind 5: ksw_global2 with traceback as the long-segment kernel runs it (direction
+ * nibbles in HBM) -> like kind 2.  opt supplies the scoring (mat, gap costs, zdrop). */
+int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, int n_cases, const bwagpu_dp_case_t *cases, const uint8_t *seqs, int64_t n_seq_bytes, int32_t *out);
+
 /* ---- optional widening past mem_process_seqs' first loop ---- */
 /* After bwagpu_batch_download: one bwagpu_cigar_t per downloaded region, in the same order, computed on the device.  They
  * are what worker2's mem_reg2aln (bwamem.c:1119-1152) would compute on the host for that region; a finalize stage can use

@@ -44,7 +44,9 @@ static inline const char *hipGetErrorString(hipError_t) { return "mock hip error
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { const char *e = getenv("MOCK_HIP_DEVICES"); *n = e ? atoi(e) : 1; return hipSuccess; }   // all mock devices share the host's memory
 static inline hipError_t hipMemcpyPeer(void *d, int, const void *s, int, size_t n) { memcpy(d, s, n); return hipSuccess; }
-static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+extern int mock_cur_device;
+static inline hipError_t hipSetDevice(int d) { mock_cur_device = d; return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = mock_cur_device; return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

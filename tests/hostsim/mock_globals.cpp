@@ -8,6 +8,7 @@
 #include <unistd.h>
 
 dim3 threadIdx, blockIdx, blockDim, gridDim;
+int mock_cur_device = 0;
 static unsigned char g_lds[160 * 1024] __attribute__((aligned(64)));
 unsigned char *mock_dyn_lds = g_lds;
 

@@ -72,8 +72,8 @@ def _write_inputs(tmp_path, g, n_pairs, seed):
                 f.write(f"@w{i}\n".encode() + s[:60] + b"\n" + s[60:] + b"\n+w\n" + q[:100] + b"\n" + q[100:] + b"\n\n")
             elif i % 4 == 2:
                 f.write(f">w{i}\n".encode() + s.lower()[:75] + b"\n" + s[75:].replace(b"A", b"R", 1) + b"\n")
-            else:
-                f.write(f"@w{i}\n".encode() + s + b"\n+\n" + q + b"\n")
+            else:   # (a '-' among the bases: nst_nt4_table gives it code 5, not 4, bntseq.c:46-63)
+                f.write(f"@w{i}\n".encode() + s[:40] + b"-" + s[41:] + b"\n+\n" + q + b"\n")
     return f1, f2, inter, fasta
 
 

@@ -1,0 +1,316 @@
+"""Differential fuzz of the device DP routines through bwagpu_debug_dp (one wavefront per case, set up as the product kernels set
+them up) against the compiled reference's exported ksw_extend2 (ksw.c:416), ksw_global2 (ksw.c:540) and ksw_align2 (ksw.c:379):
+k_extend_wave's wave_ksw_extend2 in both modes (incl. the diagonal shortcut, the one- and two-column row forms, multi-pass rows and
+the stale-cell rule of SURVEY App. A.10), k_cigar's wave_ksw_global2, k_dedup_wave's score-only ring form, k_matesw_sw's
+ksw_align2 restatement, and the long-segment traceback kernel.
+
+CPU: a few hundred cases per routine on the mock runtime (tests/hostsim).  -m gpu: 5000 per routine on the device."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import refapi
+import testdata
+from bwa_amd.api import BwaGpu, DP_CASE_DTYPE
+from bwa_amd.structs import default_opt, pacbio_opt
+
+pytestmark = pytest.mark.skipif(not refapi.have_ref(), reason="oracle/_ref not built")
+
+KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000
+
+
+class Kswr(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("score", "te", "qe", "score2", "te2", "tb", "qb")]
+
+
+def _opts():
+    a = default_opt()
+    b = pacbio_opt()
+    c = default_opt()     # asymmetric gap costs, other clipping penalties
+    c.o_del, c.e_del, c.o_ins, c.e_ins, c.zdrop = 8, 2, 5, 1, 40
+    d = default_opt()     # scaled scores (-A 2), no z-drop
+    d.a, d.b, d.o_del, d.o_ins, d.e_del, d.e_ins, d.zdrop = 2, 8, 12, 12, 2, 2, 0
+    for i in range(4):
+        for j in range(4):
+            d.mat[i * 5 + j] = 2 if i == j else -8
+    return [a, b, c, d]
+
+
+def _mutate(rng, t, sub, indel):
+    q = t.copy()
+    m = rng.random(len(q)) < sub
+    q[m] = rng.integers(0, 5, size=int(m.sum())).astype(np.uint8)       # incl. N
+    out, i = [], 0
+    while i < len(q):
+        r = rng.random()
+        if r < indel:
+            i += int(rng.integers(1, 6))                                # deletion from the query
+            continue
+        if r < 2 * indel:
+            out.extend(rng.integers(0, 4, size=int(rng.integers(1, 6))).tolist())
+        out.append(int(q[i])); i += 1
+    return np.asarray(out if out else [0], dtype=np.uint8)
+
+
+def _seen(t, flags):
+    s = t
+    if flags & 4:
+        s = (3 - s[::-1]).astype(np.uint8)
+    if flags & 2:
+        s = s[::-1]
+    return np.ascontiguousarray(s)
+
+
+class CaseSet:
+    def __init__(self):
+        self.seqs, self.cases, self.pos, self.py = [], [], 0, []
+
+    def add(self, q, t, w, h0, eb, flags):
+        q = np.ascontiguousarray(q, dtype=np.uint8); t = np.ascontiguousarray(t, dtype=np.uint8)
+        self.cases.append((self.pos, len(q), self.pos + len(q), len(t), w, h0, eb, flags))
+        self.seqs += [q, t]; self.pos += len(q) + len(t)
+        self.py.append((q[::-1].copy() if flags & 1 else q, _seen(t, flags), w, h0, eb))
+
+    def arrays(self):
+        return np.array(self.cases, dtype=DP_CASE_DTYPE), np.concatenate(self.seqs)
+
+
+def extend_cases(rng, n, max_len):
+    cs = CaseSet()
+    ws = [1, 5, 100, 400]
+    for it in range(n):
+        kind = it % 5
+        tlen = int(rng.integers(1, max_len))
+        t = rng.integers(0, 4, size=tlen).astype(np.uint8)
+        if kind == 4:      # the stale-cell family: large h0, small band, a run of mismatches first, then a good diagonal
+            h0 = int(rng.integers(40, 250)); w = int(rng.integers(3, 30))
+            tlen = max(tlen, 60); t = rng.integers(0, 4, size=tlen).astype(np.uint8)
+            q = _mutate(rng, t, 0.02, 0.0)[: max_len - 1]
+            k = min(len(q) - 1, max(1, (h0 - int(rng.integers(1, 9))) // 4))
+            q[:k] = (t[:k] + 1 + rng.integers(0, 3, size=k)) % 4
+            cs.add(q, t, w, h0, int(rng.choice([0, 5])), 0)
+            continue
+        q = _mutate(rng, t, float(rng.choice([0.0, 0.02, 0.1, 0.3])), float(rng.choice([0.0, 0.005, 0.03])))[: max_len - 1]
+        if kind == 3:      # unrelated sequences: the band collapses early
+            q = rng.integers(0, 5, size=int(rng.integers(1, max_len))).astype(np.uint8)
+        w = int(rng.choice(ws)) if kind != 2 else int(rng.integers(1, 201))
+        cs.add(q, t, w, int(rng.integers(1, 300)), int(rng.choice([0, 5, 9])), int(rng.integers(0, 8)))
+    return cs
+
+
+def ref_extend(o, q, t, w, h0, eb):
+    R = refapi.lib()
+    outs = [C.c_int() for _ in range(5)]
+    sc = R.ksw_extend2(len(q), q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p), 5, C.cast(o.mat, C.c_void_p), o.o_del, o.e_del, o.o_ins, o.e_ins,
+                       w, eb, o.zdrop, h0, *[C.byref(x) for x in outs])
+    qle, tle, gtle, gscore, max_off = [x.value for x in outs]
+    return [sc, qle, tle, gtle, gscore, max_off]
+
+
+def py_extend_stale_differs(o, q, t, w, h0, eb):
+    """Does this case read a never-written column beyond every `end` reached so far with a non-zero first-row value?  (A restatement of
+    ksw.c:430-505's band bookkeeping only: enough to know that the stale-cell rule is exercised, not a checker of results.)"""
+    qlen, tlen = len(q), len(t)
+    oe_ins = o.o_ins + o.e_ins
+    ramp = [h0, max(h0 - oe_ins, 0)]
+    for j in range(2, qlen + 1):
+        ramp.append(ramp[-1] - o.e_ins if ramp[-1] > o.e_ins else 0)
+    mat = [o.mat[i] for i in range(25)]
+    mx = max(mat)
+    lim = int((qlen * mx + eb - o.o_ins) / o.e_ins + 1.); w = min(w, max(lim, 1))
+    lim = int((qlen * mx + eb - o.o_del) / o.e_del + 1.); w = min(w, max(lim, 1))
+    H = ramp[:] + [0]; E = [0] * (qlen + 2); written = [False] * (qlen + 2)
+    beg, end, mxs, max_i, max_j = 0, qlen, h0, -1, -1
+    hit = False
+    for i in range(tlen):
+        f, m, mj = 0, 0, -1
+        beg = max(beg, i - w); end = min(end, i + w + 1, qlen)
+        h1 = max(h0 - (o.o_del + o.e_del * (i + 1)), 0) if beg == 0 else 0
+        for j in range(beg, end):
+            if i > 0 and not written[j] and H[j] != 0:
+                hit = True
+            M, e = H[j], E[j]
+            H[j] = h1; written[j] = True
+            M = M + mat[t[i] * 5 + q[j]] if M else 0
+            h = max(M, e, f); h1 = h
+            if h >= m:
+                m, mj = h, j
+            E[j] = max(e - o.e_del, M - (o.o_del + o.e_del), 0)
+            f = max(f - o.e_ins, M - oe_ins, 0)
+        H[end] = h1; E[end] = 0; written[end] = True
+        if m == 0:
+            break
+        if m > mxs:
+            mxs, max_i, max_j = m, i, mj
+        elif o.zdrop > 0:
+            di, dj = i - max_i, mj - max_j
+            if (di > dj and mxs - m - (di - dj) * o.e_del > o.zdrop) or (di <= dj and mxs - m - (dj - di) * o.e_ins > o.zdrop):
+                break
+        j = beg
+        while j < end and H[j] == 0 and E[j] == 0:
+            j += 1
+        beg = j
+        j = end
+        while j >= beg and H[j] == 0 and E[j] == 0:
+            j -= 1
+        end = min(j + 2, qlen)
+    return hit
+
+
+def run_extend(dev, kind, n, max_len, seed, need_stale):
+    rng = np.random.default_rng(seed)
+    fast = stale = 0
+    for oi, o in enumerate(_opts()):
+        cs = extend_cases(rng, n // 4, max_len)
+        cases, seqs = cs.arrays()
+        out = dev.debug_dp(o, kind, cases, seqs)
+        for k, (q, t, w, h0, eb) in enumerate(cs.py):
+            exp = ref_extend(o, q, t, w, h0, eb)
+            assert out[k, :6].tolist() == exp, f"kind {kind} opt {oi} case {k}: device {out[k, :8].tolist()} reference {exp} (qlen {len(q)} tlen {len(t)} w {w} h0 {h0} eb {eb} flags {cases['flags'][k]})"
+            if need_stale and k % 5 == 4 and k < 400:
+                stale += py_extend_stale_differs(o, q, t, w, h0, eb)
+        fast += int(out[:, 6].sum())
+    assert fast > 0, "no case took the diagonal shortcut"
+    if need_stale:
+        assert stale > 0, "no case exercised the stale-cell rule"
+
+
+def global_cases(rng, n, max_len, max_cols):
+    cs = CaseSet()
+    for it in range(n):
+        tlen = int(rng.integers(1, max_len))
+        t = rng.integers(0, 4, size=tlen).astype(np.uint8)
+        q = _mutate(rng, t, float(rng.choice([0.0, 0.03, 0.12])), float(rng.choice([0.0, 0.01, 0.04])))[:max_len]
+        dl = abs(len(q) - tlen)
+        w = dl + 3 + int(rng.integers(0, 40)) if it % 3 else dl + 3
+        if min(len(q), 2 * w + 1) > max_cols:
+            w = max(dl + 3, (max_cols - 1) // 2)
+        if min(len(q), 2 * w + 1) > max_cols:
+            q = q[:max_cols]; w = abs(len(q) - tlen) + 3
+        cs.add(q, t, w, 0, 0, int(rng.integers(0, 8)))
+    return cs
+
+
+def ref_global(o, q, t, w):
+    R = refapi.lib()
+    n = C.c_int(); cg = C.POINTER(C.c_uint32)()
+    sc = R.ksw_global2(len(q), q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p), 5, C.cast(o.mat, C.c_void_p), o.o_del, o.e_del, o.o_ins, o.e_ins, w, C.byref(n), C.byref(cg))
+    ops = [cg[i] for i in range(n.value)]
+    refapi.lib().refshim_free(cg)
+    return sc, ops
+
+
+def run_global(dev, kind, n, max_len, max_cols, seed):
+    rng = np.random.default_rng(seed)
+    served = 0
+    for oi, o in enumerate(_opts()):
+        cs = global_cases(rng, n // 4, max_len, max_cols)
+        cases, seqs = cs.arrays()
+        out = dev.debug_dp(o, kind, cases, seqs)
+        for k, (q, t, w, _, _) in enumerate(cs.py):
+            sc, ops = ref_global(o, q, t, w)
+            if kind == 3:
+                if out[k, 1] == -2:
+                    continue
+                assert out[k, 0] == sc, f"kind 3 opt {oi} case {k}: {out[k, 0]} vs {sc}"
+                served += 1
+                continue
+            if out[k, 1] == -2 or (out[k, 1] == -1 and len(ops) > 64):
+                continue
+            assert out[k, 0] == sc and out[k, 1] == len(ops) and out[k, 2:2 + len(ops)].astype(np.uint32).tolist() == ops, \
+                f"kind {kind} opt {oi} case {k}: device {out[k, :2 + max(0, out[k, 1])].tolist()} reference {sc} {ops} (qlen {len(q)} tlen {len(t)} w {w})"
+            served += 1
+    assert served > n * 0.6, f"only {served} of {n} cases served by the kernel"
+
+
+def run_align2(dev, n, seed):
+    R = refapi.lib()
+    R.ksw_align2.restype = Kswr
+    rng = np.random.default_rng(seed)
+    n_sub = n_start = 0
+    for oi, o in enumerate(_opts()):
+        cs = CaseSet(); xs = []
+        for it in range(n // 4):
+            qlen = int(rng.integers(20, 260 if it % 7 else 500))
+            tlen = int(rng.integers(qlen // 2 + 1, 900))
+            t = rng.integers(0, 4, size=tlen).astype(np.uint8)
+            p = int(rng.integers(0, max(1, tlen - qlen)))
+            q = _mutate(rng, t[p:p + qlen], float(rng.choice([0.03, 0.1, 0.21])), float(rng.choice([0.0, 0.01, 0.03])))[:500]
+            if it % 6 == 0 and tlen > 2 * qlen + 40:      # a second, weaker copy: score2 / te2
+                t[-qlen:] = np.minimum(_mutate(rng, t[p:p + qlen], 0.08, 0.0), 3)
+            if it % 9 == 0:
+                q = rng.integers(0, 5, size=len(q)).astype(np.uint8)
+            minsc = int(rng.choice([19, 25, 40])) * o.a
+            xtra = KSW_XSUBO | KSW_XSTART | (KSW_XBYTE if len(q) * o.a < 250 else 0) | minsc
+            if it % 11 == 0:
+                xtra &= ~KSW_XSTART
+            cs.add(q, t, 0, xtra, 0, int(rng.integers(0, 8)))
+            xs.append(xtra)
+        cases, seqs = cs.arrays()
+        out = dev.debug_dp(o, 4, cases, seqs)
+        for k, (q, t, _, xtra, _) in enumerate(cs.py):
+            r = R.ksw_align2(len(q), q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p), 5, C.cast(o.mat, C.c_void_p), o.o_del, o.e_del, o.o_ins, o.e_ins, xtra, None)
+            exp = [r.score, r.te, r.qe, r.score2, r.te2, r.tb, r.qb]
+            assert out[k, :7].tolist() == exp, f"align2 opt {oi} case {k}: device {out[k, :7].tolist()} reference {exp} (qlen {len(q)} tlen {len(t)} xtra {xtra:#x})"
+            n_sub += r.score2 > 0; n_start += r.tb >= 0
+    assert n_sub > 0 and n_start > 0
+
+
+# ---- CPU: the product source under the mock runtime --------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def sim():
+    import hostsim_build
+    prefix, _ = testdata.small_index()
+    s = BwaGpu(prefix, lib_path=hostsim_build.build())
+    yield s
+    s.close()
+
+
+def test_sim_extend_fuzz(sim):
+    run_extend(sim, 0, 240, 160, 11, need_stale=True)
+
+
+def test_sim_extend_ring_fuzz(sim):
+    run_extend(sim, 1, 120, 160, 12, need_stale=False)
+
+
+def test_sim_global_fuzz(sim):
+    run_global(sim, 2, 160, 150, 192, 13)
+    run_global(sim, 3, 80, 150, 1 << 30, 14)
+
+
+def test_sim_align2_fuzz(sim):
+    run_align2(sim, 60, 15)
+
+
+# ---- GPU ----------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gpu():
+    prefix, _ = testdata.small_index()
+    g = BwaGpu(prefix)
+    yield g
+    g.close()
+
+
+@pytest.mark.gpu
+def test_gpu_extend_fuzz(gpu):
+    run_extend(gpu, 0, 5000, 400, 21, need_stale=True)
+    run_extend(gpu, 0, 1000, 1000, 22, need_stale=False)
+
+
+@pytest.mark.gpu
+def test_gpu_extend_ring_fuzz(gpu):
+    run_extend(gpu, 1, 5000, 400, 23, need_stale=True)
+
+
+@pytest.mark.gpu
+def test_gpu_global_fuzz(gpu):
+    run_global(gpu, 2, 5000, 320, 192, 24)
+    run_global(gpu, 3, 5000, 600, 1 << 30, 25)
+
+
+@pytest.mark.gpu
+def test_gpu_align2_fuzz(gpu):
+    run_align2(gpu, 5000, 26)
