@@ -15,13 +15,17 @@ host finalize; the end-to-end `bwa-amd mem` rates (FASTQ in -> SAM out) are repo
 no data-path collective ("weak" scaling: every rank aligns its own `--reads`); the index reaches ranks > 0 by RCCL broadcast.
 
 Parity gate: the unmodified reference (`oracle/_ref/bwa mem`, also the CPU baseline) and the product command line
-(`bwa-amd mem`) align the same single-end and paired-end samples with the same -K; their SAM must be byte-identical apart from
-@PG, otherwise the run exits non-zero.
+(`bwa-amd mem`) align the same samples with the same -K -- a single-end sample in one batch and a paired-end sample in EIGHT
+batches (at least four per device handle: arenas, learnt sizes and packed buffers are re-used from batch to batch) -- and their
+SAM must be byte-identical apart from @PG, otherwise the run exits non-zero.  With --gpus N > 1 rank 0 still runs the gate, and
+the product then splits every batch over the N devices (BWAGPU_DEVICES), as does the end-to-end run.
 
 Extra objects on the JSON line:
-  roofline     the longest kernel's algorithmic bytes / its measured duration (HIP events on the library's stream)
-  cpu_baseline the reference on the paired-end sample (and the single-end one under "se"), on this box's host cores
-  parity       result of the gate
+  roofline       the longest kernel's algorithmic bytes / its measured duration (HIP events on the library's stream)
+  cpu_baseline   the reference on the paired-end sample (and the single-end one under "se"), on this box's host cores
+  parity         result of the gate (se, pe, multibatch)
+  end_to_end_pe  FASTQ -> SAM rate of `bwa-amd mem` on a few million pairs, with per-stage microseconds per read
+  longread       BASELINE configs[4]: 10 kb reads with -x pacbio (hot-path rate, GCUPS, reference on a prefix, SAM parity on it)
 """
 import argparse
 import hashlib
@@ -82,13 +86,13 @@ def sam_body_digest(path: str):
     return h.hexdigest(), n
 
 
-def run_reference(prefix: str, files, threads: int, out_sam: str):
-    """Unmodified reference `bwa mem -t threads -K 100000000`; reads/s from its own per-batch timing lines
+def run_reference(prefix: str, files, threads: int, out_sam: str, K: int = 100000000, extra=()):
+    """Unmodified reference `bwa mem -t threads -K <K>`; reads/s from its own per-batch timing lines
     (bwamem.c:1263: '[M::mem_process_seqs] Processed N reads in X CPU sec, Y real sec') and the whole-run real time (main.c:126)."""
     bwa = os.path.join(ROOT, "oracle", "_ref", "bwa")
     t = time.time()
     with open(out_sam, "wb") as fo:
-        p = subprocess.run([bwa, "mem", "-t", str(threads), "-K", "100000000", "-v", "3", prefix] + list(files), stdout=fo, stderr=subprocess.PIPE, text=True)
+        p = subprocess.run([bwa, "mem", "-t", str(threads), "-K", str(K), "-v", "3"] + list(extra) + [prefix] + list(files), stdout=fo, stderr=subprocess.PIPE, text=True)
     wall = time.time() - t
     n = tot = 0.0
     for m in re.finditer(r"Processed (\d+) reads in ([\d.]+) CPU sec, ([\d.]+) real sec", p.stderr):
@@ -114,19 +118,32 @@ def run_instrumented(prefix: str, files, threads: int):
     return {"n_reads": n, "n_2occ4": k[0] / n, "N_blk": k[1] / n, "N_sa": k[2] / n, "N_lf": k[3] / n, "W_ref": k[4] / n, "ext_calls": k[5] / n, "ext_cells": k[6] / n, "glb_cells": k[7] / n}
 
 
-def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: int = 2):
-    """The stand-alone `bwa-amd mem` (FASTQ in -> device hot path + device CIGARs / mate rescue -> host finalize -> SAM text)."""
+def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: int | None = None, K: int = 100000000, extra=(), devices=None):
+    """The stand-alone `bwa-amd mem` (FASTQ in -> device hot path + device CIGARs / mate rescue -> host finalize -> SAM text).
+    devices: device ids for BWAGPU_DEVICES (every batch is split over them), None = device 0."""
     cli = os.path.join(ROOT, "bwa_amd", "bwa-amd")
-    cmd = [cli, "mem", "-t", str(threads), "-K", "100000000", "-v", "3"] + (["-o", out_sam] if out_sam else []) + [prefix] + list(files)
+    cmd = [cli, "mem", "-t", str(threads), "-K", str(K), "-v", "3"] + list(extra) + (["-o", out_sam] if out_sam else []) + [prefix] + list(files)
+    env = dict(os.environ)
+    if streams:
+        env["BWAGPU_CLI_STREAMS"] = str(streams)
+    if devices and len(devices) > 1:
+        env["BWAGPU_DEVICES"] = ",".join(str(d) for d in devices)
     t = time.time()
-    p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=dict(os.environ, BWAGPU_CLI_STREAMS=str(streams)))
+    p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=env)
     wall = time.time() - t
     m = re.search(r"\[M::main_mem\] (\d+) reads in ([\d.]+) sec .*: (\d+) reads/s", p.stderr)
     if p.returncode != 0 or not m:
         log("[bench] bwa-amd mem failed:", p.stderr[-800:])
         return None
     busy = re.search(r"stage busy time: (.*)", p.stderr)
-    return {"reads_per_s": float(m.group(3)), "n": int(m.group(1)), "wall_s": wall, "stages": busy.group(1) if busy else ""}
+    n_reads = int(m.group(1))
+    stage_us = {}
+    if busy and n_reads:     # busy seconds of each pipeline stage -> microseconds per read (a stage's share of one host core, or of the device)
+        for name, sec in re.findall(r"([a-z+]+) ([\d.]+) s", busy.group(1)):
+            stage_us[name] = round(float(sec) / n_reads * 1e6, 3)
+    hm = re.search(r"over (\d+) handles", p.stderr)
+    return {"reads_per_s": float(m.group(3)), "n": n_reads, "wall_s": wall, "stages": busy.group(1) if busy else "", "stage_us_per_read": stage_us, "handles": int(hm.group(1)) if hm else None,
+            "n_batches": len(re.findall(r"\[M::process\] read \d+ sequences", p.stderr))}
 
 
 def effective_cpus() -> int:
@@ -164,6 +181,12 @@ def main():
     ap.add_argument("--e2e-reads", type=int, default=6_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference runs (and with them the parity gate)")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--parity-pairs", type=int, default=800_000, help="pairs of the multi-batch paired-end parity / CPU-baseline sample (eight batches)")
+    ap.add_argument("--no-longread", action="store_true", help="skip the BASELINE configs[4] leg (10 kb reads, -x pacbio)")
+    ap.add_argument("--long-reads", type=int, default=8000)
+    ap.add_argument("--long-len", type=int, default=10000)
+    ap.add_argument("--long-steps", type=int, default=2)
+    ap.add_argument("--long-sample", type=int, default=2000, help="reads of the long-read CPU-baseline / parity prefix")
     args = ap.parse_args()
 
     import torch
@@ -259,144 +282,228 @@ def main():
     digest = hashlib.sha256(counts.tobytes() + regs.tobytes()).hexdigest()[:16]
     for hdl in handles[1:]:
         hdl.close()
+    if dist is not None:
+        # everything below is host-side work of rank 0 (reference runs, the command-line product over all N devices): the other ranks
+        # release their GPUs and leave now, so that no collective is left waiting for minutes
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            gpu.close()
+            sys.exit(0)
 
     rc_exit = 0
-    if rank == 0:
-        total_reads = n_batch * world * args.steps
-        value = total_reads / dt / 1e6
-        nr = float(work["n_reads"])
-        # algorithmic bytes per launch: one 64-byte block per Occ lookup / LF step, 16 bytes per prefix-table entry,
-        # 8 bytes per SA sample, the read bases; chaining: the slot records it reads (20 B) and the 160-byte B-tree nodes and
-        # 64-byte chain records it touches (counted by the instrumented pass); extension: packed reference window + read + regions
-        alg = {
-            "k_seed": 64.0 * work["n_occ_blocks"] + 16.0 * work["n_tab_lookups"] + work["n_bases"] / 2,
-            "k_sa": 64.0 * work["n_lf_steps"] + 8.0 * work["n_seeds"],
-            "k_chain": 20.0 * work["n_seeds"] + 160.0 * work.get("n_bt_nodes", 0) + 64.0 * work.get("n_chain_recs", 0),
-            "k_extend_wave": work["ref_bases"] / 4 + work["n_bases"] + 88.0 * work["n_regs_raw"],
-            "k_dedup": 2 * 88.0 * work["n_regs_raw"],
-        }
-        dur = {"k_seed": stage_ms["ms_seed"], "k_sa": stage_ms["ms_sa"], "k_chain": stage_ms["ms_chain"], "k_extend_wave": stage_ms["ms_extend"], "k_dedup": stage_ms["ms_dedup"]}
-        roof_k = max(dur, key=lambda k: dur[k])           # the longest kernel, whatever it is
-        achieved = alg[roof_k] / (dur[roof_k] * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                traffic = pj.get(roof_k, {}).get("hbm_bytes_per_launch")
-                if roof_k == "k_seed" and traffic and "k_seed3" in pj:     # the seeding stage is two kernels since round 2 (pass 3 runs first)
-                    traffic += pj["k_seed3"].get("hbm_bytes_per_launch", 0.0)
-            except Exception:
-                traffic = None
-        layout = f"{n_batch // 2} pairs of 2x{args.read_len} bp (mates interleaved)" if pe else f"{n_batch} single-end {args.read_len} bp reads"
-        out = {
-            "metric": "Mreads/s (whole job), 2x150 bp vs GRCh38-scale index, resident hot path (mem_align1_core of every read); SAM parity gate vs bwa mem",
-            "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32/u64 (integer DP + FM-index ranks)", "data": "synthetic",
-            "config": {"workload": f"{layout} per GPU per step vs seeded synthetic {args.genome_mbp:g} Mbp genome (GRCh38 stand-in, seq_len {2 * int(args.genome_mbp * 1e6):.3g}; BASELINE configs[{2 if pe else 1}] layout)",
-                       "reads_per_gpu": n_batch, "read_len": args.read_len, "layout": args.layout, "genome_mbp": args.genome_mbp, "sa_intv": args.dense_sa or 32,
-                       "sharding": f"reads x{world}, no collective", "batches_in_flight": S, "result_sha256_16": digest,
-                       "timed": "kernels of the hot path on batches resident in HBM (no PCIe, no host finalize); see end_to_end_* for FASTQ->SAM"},
-            "roofline": {"bound": "hbm", "kernel": roof_k + (" (+ k_seed3: the seeding stage)" if roof_k == "k_seed" else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "alg_bytes_per_launch": alg[roof_k], "kernel_ms": round(dur[roof_k], 3),
-                         "per_kernel": {k: {"ms": round(dur[k], 3), "alg_GB": round(alg[k] / 1e9, 3), "GB/s": round(alg[k] / (dur[k] * 1e-3) / 1e9, 1) if dur[k] > 0 else None} for k in dur},
-                         "random_64B_ceiling": {"GB/s": 1670.0, "blocks_per_s": 26.0e9,
-                                                "source": "tools/randbw.hip on MI355X, profiles/r01_randbw_microbench.md: random 64-byte reads from HBM saturate at 26e9/s",
-                                                # the seeding stage's algorithmic requests alone (index blocks + prefix-table entries; the interval stacks'
-                                                # spill traffic and the interval lists come on top) against that ceiling
-                                                "seeding_alg_requests_per_s": round((work["n_occ_blocks"] + work["n_tab_lookups"]) / (stage_ms["ms_seed"] * 1e-3), 0) if stage_ms["ms_seed"] > 0 else None,
-                                                "seeding_frac": round((work["n_occ_blocks"] + work["n_tab_lookups"]) / (stage_ms["ms_seed"] * 1e-3) / 26.0e9, 4) if stage_ms["ms_seed"] > 0 else None},
-                         "ext_gcups": round(work["n_ext_cells"] / (stage_ms["ms_extend"] * 1e-3) / 1e9, 1) if stage_ms["ms_extend"] > 0 else None},
-            "stage_ms_solo": {k: round(v, 3) for k, v in stage_ms.items()},
-            "work_per_read": {"N_blk": round(work["n_occ_blocks"] / nr, 1), "N_tab": round(work["n_tab_lookups"] / nr, 1), "N_lf": round(work["n_lf_steps"] / nr, 1),
-                              "N_sa": round(work["n_seeds"] / nr, 2), "ext_cells": round(work["n_ext_cells"] / nr, 0),
-                              "regs": round(work["n_regs"] / nr, 3)},
-            "index_build": {"device_s": round(idx_info.get("build_ms", 0) / 1e3, 3) if idx_info else None,
-                            "what": "bwagpu_index_build: suffix sort of forward+reverse text in HBM, BWT/Occ/SA in the reference's layout (byte-identical to bwa index)"},
-        }
-        if bcast_s is not None:
-            out["index_broadcast"] = {"ranks": world, "seconds": round(bcast_s, 3), "what": "rank 0 loads the index files and uploads; RCCL broadcast of .bwt/.sa/.pac buffers over xGMI; every rank then builds its prefix tables"}
-        gpu.close()
-        if world == 1 and not args.no_cpu_baseline:
-            threads = effective_cpus()
-            cache = os.path.dirname(prefix)
-            n_s = min(args.cpu_sample, n_batch) // 2 * 2
-            # ---- single-end sample: reference vs product, same reads, same -K ----
-            se_reads = batches[0][:n_s] if not pe else simdata.make_reads_se(g, n_s, length=args.read_len, seed=4001)
-            fq = os.path.join(cache, "sample_se.fq")
-            simdata.write_fastq(fq, se_reads)
-            ref_se = run_reference(prefix, [fq], threads, os.path.join(cache, "ref_se.sam"))
-            our_se = run_product(prefix, [fq], threads, os.path.join(cache, "our_se.sam"))
-            # ---- paired-end sample ----
-            if pe:
-                p1, p2 = batches[0][0:n_s:2], batches[0][1:n_s:2]
-            else:
-                p1, p2 = simdata.make_reads_pe(g, n_s // 2, length=args.read_len, seed=4002)
-            f1, f2 = os.path.join(cache, "sample_1.fq"), os.path.join(cache, "sample_2.fq")
-            simdata.write_fastq(f1, p1, suffix="/1"); simdata.write_fastq(f2, p2, suffix="/2")
-            ref_pe = run_reference(prefix, [f1, f2], threads, os.path.join(cache, "ref_pe.sam"))
-            our_pe = run_product(prefix, [f1, f2], threads, os.path.join(cache, "our_pe.sam"))
-            par = {"se": False, "pe": False, "n_se": n_s, "n_pairs": n_s // 2,
-                   "how": "sha256 of the SAM text minus @PG lines: oracle/_ref/bwa mem vs bwa-amd mem, same FASTQ, -K 100000000"}
-            if ref_se and our_se:
-                a, b = sam_body_digest(os.path.join(cache, "ref_se.sam")), sam_body_digest(os.path.join(cache, "our_se.sam"))
-                par["se"] = a == b and a[1] >= n_s
-                par["se_records"] = a[1]
-            if ref_pe and our_pe:
-                a, b = sam_body_digest(os.path.join(cache, "ref_pe.sam")), sam_body_digest(os.path.join(cache, "our_pe.sam"))
-                par["pe"] = a == b and a[1] >= n_s
-                par["pe_records"] = a[1]
-            out["parity"] = par
-            # B_alg per read: the reference's own counts on the paired-end sample next to what the device path does for
-            # the same result (prefix tables replace short-match steps: N_blk falls, 16-byte look-ups appear; the SA is denser: N_lf falls)
-            ins = run_instrumented(prefix, [f1, f2], threads)
-            l_seq = args.read_len
-            regs_pr = work["n_regs"] / nr
-            dev_b = (alg["k_seed"] + alg["k_sa"]) / nr + (work["ref_bases"] / 4 + work["n_bases"] + 88.0 * work["n_regs"]) / nr
-            out["b_alg_per_read"] = {"device": {"bytes": round(dev_b, 0), "N_blk": round(work["n_occ_blocks"] / nr, 1), "N_tab_16B": round(work["n_tab_lookups"] / nr, 1),
-                                                "N_lf": round(work["n_lf_steps"] / nr, 1), "N_sa": round(work["n_seeds"] / nr, 2), "W_ref": round(work["ref_bases"] / nr, 0),
-                                                "ext_cells": round(work["n_ext_cells"] / nr, 0), "sa_intv": args.dense_sa or 32}}
-            if ins:
-                ref_b = 64.0 * ins["N_blk"] + 64.0 * ins["N_lf"] + 8.0 * ins["N_sa"] + ins["W_ref"] / 4 + l_seq + 88.0 * regs_pr
-                out["b_alg_per_read"]["reference"] = {"bytes": round(ref_b, 0), **{k_: round(v_, 2) for k_, v_ in ins.items() if k_ != "n_reads"}, "sa_intv": 32,
-                                                      "how": f"oracle/_ref/bwa_instr (counters patched into a scratch copy of bwt.c/ksw.c/bwamem.c at build time) on the {ins['n_reads']}-read paired-end sample; "
-                                                             "B_alg = 64 N_blk + 64 N_lf + 8 N_sa + W_ref/4 + l_seq + 88 n_regs"}
-            if not (par["se"] and par["pe"]):
-                rc_exit = 3
-                log("[bench] PARITY GATE FAILED:", par)
-            note = f"`bwa mem -t {threads} -K 100000000`, whole mem_process_seqs incl. SAM text, rate from its own per-batch real-time lines; the box exposes {os.cpu_count()} hardware threads but its cgroup quota is {threads} CPUs"
-            if ref_pe:
-                out["cpu_baseline"] = {"value": round(ref_pe["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "cores": threads, "kind": "reference",
-                                       "sample": f"{n_s // 2} pairs of 2x{args.read_len} bp of the benchmark's read model ({'first pairs of batch 0' if pe else 'seed 4002'}); {note}; {ref_pe['wall_s']:.1f}s wall incl. index load"}
-                if ref_se:
-                    out["cpu_baseline"]["se"] = {"value": round(ref_se["reads_per_s"] / 1e6, 4), "sample": f"{n_s} single-end reads, same command"}
-            if not args.no_e2e:
-                # a few million reads, so that the figure reflects the pipeline's steady state rather than its fill and drain
-                n_e = max(args.e2e_reads, n_batch) // 2 * 2
-                r1, r2 = simdata.make_reads_pe(g, n_e // 2, length=args.read_len, seed=77)
-                simdata.write_fastq(f1, r1, suffix="/1"); simdata.write_fastq(f2, r2, suffix="/2")
-                e2e = run_product(prefix, [f1, f2], threads, None)
-                if e2e:
-                    out["end_to_end_pe"] = {"value": round(e2e["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "stages": e2e["stages"],
-                                            "what": f"`bwa-amd mem -t {threads}` on {n_e // 2} pairs as two FASTQ files (the BASELINE metric's layout): parsing + H2D + device hot path + device CIGARs and "
-                                                    f"mate-rescue alignments + D2H + mem_pestat/pairing/SAM text on the host, batches of 100 Mbp, 2 in flight; wall time after the index is loaded"}
-                    if ref_pe:
-                        out["end_to_end_pe"]["vs_cpu_baseline"] = round(e2e["reads_per_s"] / ref_pe["reads_per_s"], 1)
+    total_reads = n_batch * world * args.steps
+    value = total_reads / dt / 1e6
+    nr = float(work["n_reads"])
+    occ32 = os.environ.get("BWAGPU_OCC32", "1") != "0"
+    blk_bytes = 32.0 if occ32 else 64.0
+    # algorithmic bytes per launch: one index block per Occ lookup / LF step (64 bytes in the reference's layout; the
+    # device's default layout answers the same query from a 32-byte block), 16 bytes per prefix-table entry, 8 bytes per SA sample, the
+    # read bases; chaining: the slot records it reads (20 B) and the 160-byte B-tree nodes and 64-byte chain records it touches (counted
+    # by the instrumented pass); extension: packed reference window + read + regions
+    alg = {
+        "k_seed": 64.0 * work["n_occ_blocks"] + 16.0 * work["n_tab_lookups"] + work["n_bases"] / 2,
+        "k_sa": 64.0 * work["n_lf_steps"] + 8.0 * work["n_seeds"],
+        "k_chain": 20.0 * work["n_seeds"] + 160.0 * work.get("n_bt_nodes", 0) + 64.0 * work.get("n_chain_recs", 0),
+        "k_extend_wave": work["ref_bases"] / 4 + work["n_bases"] + 88.0 * work["n_regs_raw"],
+        "k_dedup": 2 * 88.0 * work["n_regs_raw"],
+    }
+    dur = {"k_seed": stage_ms["ms_seed"], "k_sa": stage_ms["ms_sa"], "k_chain": stage_ms["ms_chain"], "k_extend_wave": stage_ms["ms_extend"], "k_dedup": stage_ms["ms_dedup"]}
+    roof_k = max(dur, key=lambda k: dur[k])           # the longest kernel, whatever it is
+    achieved = alg[roof_k] / (dur[roof_k] * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc):
+        try:
+            pj = json.load(open(pmc))
+            traffic = pj.get(roof_k, {}).get("hbm_bytes_per_launch")
+            if roof_k == "k_seed" and traffic and "k_seed3" in pj:     # the seeding stage is two kernels since round 2 (pass 3 runs first)
+                traffic += pj["k_seed3"].get("hbm_bytes_per_launch", 0.0)
+            traffic_src = ("NOT measured in this run: read from profiles/pmc_latest.json (" + str(pj.get("_meta", {}).get("what", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes")) +
+                           ", taken " + str(pj.get("_meta", {}).get("date", "in an earlier run of the same workload")) + ")")
+        except Exception:
+            traffic = None
+    layout = f"{n_batch // 2} pairs of 2x{args.read_len} bp (mates interleaved)" if pe else f"{n_batch} single-end {args.read_len} bp reads"
+    # the chip's measured ceilings for dependent random reads by request size (tools/randbw2.hip, profiles/r02_experiments.md; the
+    # cooperative-fetch variants are in tools/randbw3.hip / profiles/r03_randbw3.md)
+    ceil = {16: 48.3e9, 32: 37.8e9, 64: 23.0e9}
+    n_blk, n_tab = work["n_occ_blocks"], work["n_tab_lookups"]
+    seed_s = stage_ms["ms_seed"] * 1e-3
+    out = {
+        "metric": "Mreads/s (whole job), 2x150 bp vs GRCh38-scale index, resident hot path (mem_align1_core of every read); SAM parity gate vs bwa mem; FASTQ->SAM rate under end_to_end_pe",
+        "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32/u64 (integer DP + FM-index ranks)", "data": "synthetic",
+        "config": {"workload": f"{layout} per GPU per step vs seeded synthetic {args.genome_mbp:g} Mbp genome (GRCh38 stand-in, seq_len {2 * int(args.genome_mbp * 1e6):.3g}; BASELINE configs[{2 if pe else 1}] layout)",
+                   "reads_per_gpu": n_batch, "read_len": args.read_len, "layout": args.layout, "genome_mbp": args.genome_mbp, "sa_intv": args.dense_sa or 32,
+                   "occ_block_bytes": int(blk_bytes),
+                   "sharding": f"reads x{world}, no collective", "batches_in_flight": S, "result_sha256_16": digest,
+                   "timed": "kernels of the hot path on batches resident in HBM (no PCIe, no host finalize); see end_to_end_* for FASTQ->SAM"},
+        "roofline": {"bound": "hbm", "kernel": roof_k + (" (+ k_seed3: the seeding stage)" if roof_k == "k_seed" else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                     "alg_bytes_per_launch": alg[roof_k], "kernel_ms": round(dur[roof_k], 3),
+                     "alg_bytes_note": "SURVEY 8(d)'s unit: 64 bytes per Occ block the REFERENCE layout would touch (N_blk counted per rank query pair exactly as bwt_2occ4 does), "
+                                       f"whatever the device layout; the device's own blocks are {int(blk_bytes)} bytes",
+                     "per_kernel": {k: {"ms": round(dur[k], 3), "alg_GB": round(alg[k] / 1e9, 3), "GB/s": round(alg[k] / (dur[k] * 1e-3) / 1e9, 1) if dur[k] > 0 else None} for k in dur},
+                     "random_request_ceiling": {"requests_per_s_by_bytes": {str(k): v for k, v in ceil.items()},
+                                                "source": "tools/randbw2.hip on MI355X (profiles/r02_experiments.md): dependent random reads from a 4 GiB table saturate at 48.3 / 37.8 / 23.0 G/s for 16 / 32 / 64-byte requests",
+                                                # time the seeding stage's algorithmic requests alone would need at those ceilings (index blocks of the layout in use + 16-byte
+                                                # prefix-table entries; the interval stacks' spill traffic and the interval lists come on top)
+                                                "seeding_alg_requests_per_s": round((n_blk + n_tab) / seed_s, 0) if seed_s > 0 else None,
+                                                "seeding_frac": round((n_blk / ceil[int(blk_bytes)] + n_tab / ceil[16]) / seed_s, 4) if seed_s > 0 else None},
+                     "ext_gcups": round(work["n_ext_cells"] / (stage_ms["ms_extend"] * 1e-3) / 1e9, 1) if stage_ms["ms_extend"] > 0 else None},
+        "stage_ms_solo": {k: round(v, 3) for k, v in stage_ms.items()},
+        "work_per_read": {"N_blk": round(work["n_occ_blocks"] / nr, 1), "N_tab": round(work["n_tab_lookups"] / nr, 1), "N_lf": round(work["n_lf_steps"] / nr, 1),
+                          "N_sa": round(work["n_seeds"] / nr, 2), "ext_cells": round(work["n_ext_cells"] / nr, 0), "ext_calls": round(work["n_ext_calls"] / nr, 2),
+                          "ext_fast": round(work["n_ext_fast"] / nr, 2), "regs": round(work["n_regs"] / nr, 3)},
+        "index_build": {"device_s": round(idx_info.get("build_ms", 0) / 1e3, 3) if idx_info else None,
+                        "what": "bwagpu_index_build: suffix sort of forward+reverse text in HBM, BWT/Occ/SA in the reference's layout (byte-identical to bwa index)"},
+    }
+    if bcast_s is not None:
+        out["index_broadcast"] = {"ranks": world, "seconds": round(bcast_s, 3), "what": "rank 0 loads the index files and uploads; RCCL broadcast of .bwt/.sa/.pac buffers over xGMI; every rank then builds its 32-byte blocks and prefix tables"}
+    gpu.close()
+    devices = list(range(world))              # the command-line product splits every batch over these (BWAGPU_DEVICES)
+    if not args.no_cpu_baseline:
+        threads = effective_cpus()
+        cache = os.path.dirname(prefix)
+        n_s = min(args.cpu_sample, n_batch) // 2 * 2
+        # ---- single-end sample: reference vs product, same reads, same -K ----
+        se_reads = batches[0][:n_s] if not pe else simdata.make_reads_se(g, n_s, length=args.read_len, seed=4001)
+        fq = os.path.join(cache, "sample_se.fq")
+        simdata.write_fastq(fq, se_reads)
+        ref_se = run_reference(prefix, [fq], threads, os.path.join(cache, "ref_se.sam"))
+        our_se = run_product(prefix, [fq], threads, os.path.join(cache, "our_se.sam"), devices=devices)
+        # ---- paired-end sample, MANY BATCHES: -K small enough that every device handle of the product sees at least four batches (a
+        # handle re-uses arenas, learnt sizes and packed buffers from batch to batch; mem_pestat depends on the batching, so -K is the
+        # same on both sides, fastmap.c:394, bwamem.c:1258) ----
+        n_mb = max(args.parity_pairs, 8) // 2 * 2
+        K_mb = max(1, (n_mb * 2 * args.read_len) // 8 // 1_000_000) * 1_000_000            # eight batches
+        p1, p2 = simdata.make_reads_pe(g, n_mb, length=args.read_len, seed=4002)
+        f1, f2 = os.path.join(cache, "sample_1.fq"), os.path.join(cache, "sample_2.fq")
+        simdata.write_fastq(f1, p1, suffix="/1"); simdata.write_fastq(f2, p2, suffix="/2")
+        ref_pe = run_reference(prefix, [f1, f2], threads, os.path.join(cache, "ref_pe.sam"), K=K_mb)
+        our_pe = run_product(prefix, [f1, f2], threads, os.path.join(cache, "our_pe.sam"), K=K_mb, devices=devices)
+        par = {"se": False, "pe": False, "multibatch": False, "n_se": n_s, "n_pairs": n_mb,
+               "how": f"sha256 of the SAM text minus @PG lines: oracle/_ref/bwa mem vs bwa-amd mem on the same FASTQ; single-end sample with -K 100000000 (one batch), paired-end sample with -K {K_mb} on both sides"}
+        if ref_se and our_se:
+            a, b = sam_body_digest(os.path.join(cache, "ref_se.sam")), sam_body_digest(os.path.join(cache, "our_se.sam"))
+            par["se"] = a == b and a[1] >= n_s
+            par["se_records"] = a[1]
+        if ref_pe and our_pe:
+            a, b = sam_body_digest(os.path.join(cache, "ref_pe.sam")), sam_body_digest(os.path.join(cache, "our_pe.sam"))
+            par["pe"] = a == b and a[1] >= 2 * n_mb
+            par["pe_records"] = a[1]
+            par["pe_batches"] = our_pe["n_batches"]; par["pe_handles"] = our_pe["handles"]
+            par["multibatch"] = bool(par["pe"] and our_pe["n_batches"] >= 4 * (our_pe["handles"] or 2))
+            par["pe_product_Mreads_s"] = round(our_pe["reads_per_s"] / 1e6, 4)
+            if world > 1:
+                par["devices"] = devices
+        out["parity"] = par
+        # B_alg per read: the reference's own counts on a prefix of the paired-end sample next to what the device path does for
+        # the same result (prefix tables replace short-match steps: N_blk falls, 16-byte look-ups appear; the SA is denser: N_lf falls)
+        n_i = min(n_mb, 100_000)
+        fi1, fi2 = os.path.join(cache, "instr_1.fq"), os.path.join(cache, "instr_2.fq")
+        simdata.write_fastq(fi1, p1[:n_i], suffix="/1"); simdata.write_fastq(fi2, p2[:n_i], suffix="/2")
+        ins = run_instrumented(prefix, [fi1, fi2], threads)
+        l_seq = args.read_len
+        regs_pr = work["n_regs"] / nr
+        dev_b = (alg["k_seed"] + alg["k_sa"]) / nr + (work["ref_bases"] / 4 + work["n_bases"] + 88.0 * work["n_regs"]) / nr
+        out["b_alg_per_read"] = {"device": {"bytes": round(dev_b, 0), "N_blk": round(work["n_occ_blocks"] / nr, 1), "N_tab_16B": round(work["n_tab_lookups"] / nr, 1),
+                                            "N_lf": round(work["n_lf_steps"] / nr, 1), "N_sa": round(work["n_seeds"] / nr, 2), "W_ref": round(work["ref_bases"] / nr, 0),
+                                            "ext_cells": round(work["n_ext_cells"] / nr, 0), "sa_intv": args.dense_sa or 32}}
+        if ins:
+            ref_b = 64.0 * ins["N_blk"] + 64.0 * ins["N_lf"] + 8.0 * ins["N_sa"] + ins["W_ref"] / 4 + l_seq + 88.0 * regs_pr
+            out["b_alg_per_read"]["reference"] = {"bytes": round(ref_b, 0), **{k_: round(v_, 2) for k_, v_ in ins.items() if k_ != "n_reads"}, "sa_intv": 32,
+                                                  "how": f"oracle/_ref/bwa_instr (counters patched into a scratch copy of bwt.c/ksw.c/bwamem.c at build time) on {ins['n_reads']} reads of the paired-end sample; "
+                                                         "B_alg = 64 N_blk + 64 N_lf + 8 N_sa + W_ref/4 + l_seq + 88 n_regs"}
+        if not (par["se"] and par["pe"] and par["multibatch"]):
+            rc_exit = 3
+            log("[bench] PARITY GATE FAILED:", par)
+        note = f"`bwa mem -t {threads}`, whole mem_process_seqs incl. SAM text, rate from its own per-batch real-time lines; the box exposes {os.cpu_count()} hardware threads but its cgroup quota is {threads} CPUs"
+        if ref_pe:
+            out["cpu_baseline"] = {"value": round(ref_pe["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "cores": threads, "kind": "reference",
+                                   "sample": f"{n_mb} pairs of 2x{args.read_len} bp of the benchmark's read model (seed 4002), -K {K_mb}; {note}; {ref_pe['wall_s']:.1f}s wall incl. index load"}
+            if ref_se:
+                out["cpu_baseline"]["se"] = {"value": round(ref_se["reads_per_s"] / 1e6, 4), "sample": f"{n_s} single-end reads, -K 100000000"}
+        if not args.no_e2e:
+            # a few million reads, so that the figure reflects the pipeline's steady state rather than its fill and drain
+            n_e = max(args.e2e_reads, n_batch) // 2 * 2
+            r1, r2 = simdata.make_reads_pe(g, n_e // 2, length=args.read_len, seed=77)
+            simdata.write_fastq(f1, r1, suffix="/1"); simdata.write_fastq(f2, r2, suffix="/2")
+            e2e = run_product(prefix, [f1, f2], threads, None, devices=devices)
+            if e2e:
+                out["end_to_end_pe"] = {"value": round(e2e["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "n_gpus": world, "stages": e2e["stages"], "stage_us_per_read": e2e["stage_us_per_read"],
+                                        "what": f"`bwa-amd mem -t {threads}` on {n_e // 2} pairs as two FASTQ files (the BASELINE metric's layout, SAM discarded; the same command's SAM is what parity.pe compares): parsing + H2D + "
+                                                f"device hot path + device CIGARs and mate-rescue alignments + D2H + mem_pestat/pairing/SAM text on the host, batches of 100 Mbp"
+                                                + (f", every batch split over devices {devices} (BWAGPU_DEVICES)" if world > 1 else "") + "; wall time after the index is loaded"}
+                if ref_pe:
+                    out["end_to_end_pe"]["vs_cpu_baseline"] = round(e2e["reads_per_s"] / ref_pe["reads_per_s"], 1)
+            if world == 1:
                 simdata.write_fastq(fq, np.concatenate([r1, r2]))
                 e2e = run_product(prefix, [fq], threads, None)
                 if e2e:
-                    out["end_to_end_se"] = {"value": round(e2e["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "stages": e2e["stages"], "what": f"same reads as {n_e} single-end reads"}
-        out["bench_wall_s"] = round(time.time() - t_all, 1)
-    else:
-        gpu.close()
-    if dist is not None:
-        dist.destroy_process_group()
-    if rank == 0:
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)      # the one JSON line, last thing on stdout (RCCL prints a version banner of its own at start-up)
+                    out["end_to_end_se"] = {"value": round(e2e["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "stages": e2e["stages"], "stage_us_per_read": e2e["stage_us_per_read"], "what": f"same reads as {n_e} single-end reads"}
+            del r1, r2
+        if world == 1 and not args.no_longread:
+            try:
+                out["longread"] = longread_bench(args, prefix, g, threads, cache)
+                if out["longread"].get("parity") is False:
+                    rc_exit = 3
+                    log("[bench] LONG-READ PARITY GATE FAILED")
+            except Exception as e:   # (the long-read leg must not take the headline line with it)
+                out["longread"] = {"error": repr(e)}
+    out["bench_wall_s"] = round(time.time() - t_all, 1)
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)      # the one JSON line, last thing on stdout (RCCL prints a version banner of its own at start-up)
     sys.exit(rc_exit)
+
+
+def longread_bench(args, prefix, g, threads, cache):
+    """BASELINE configs[4]: 10 kb PacBio-like reads (SURVEY 8d error model: 1.5 % substitutions, 4 % deletions, 9 % insertions) with
+    `-x pacbio` against the same index.  Resident hot path rate of one batch, DP-cell throughput (extension + patch alignments +
+    seed re-scoring), the reference on a prefix of the reads, and a SAM parity gate on that prefix through `bwa-amd mem -x pacbio`."""
+    from bwa_amd import simdata
+    from bwa_amd.api import BwaGpu
+    from bwa_amd.structs import pacbio_opt
+    L, n = args.long_len, args.long_reads
+    reads = simdata.make_reads_long(g, n, length=L, seed=7)
+    gpu = BwaGpu(prefix)
+    if args.dense_sa:
+        gpu.densify_sa(args.dense_sa)
+    gpu.set_taps(False)
+    opt = pacbio_opt()
+    gpu.upload(np.ascontiguousarray(reads.reshape(-1)), np.arange(0, n + 1, dtype=np.int64) * L)
+    gpu.set_stats(True); gpu.run(opt); work = gpu.stats()          # (also the warm-up: arenas learn their sizes)
+    gpu.set_stats(False)
+    ms, st = [], None
+    for _ in range(args.long_steps):
+        t = time.perf_counter(); gpu.run(opt); ms.append((time.perf_counter() - t) * 1e3); st = gpu.stats()
+    gpu.close()
+    best = min(ms)
+    cells = work["n_ext_cells"] + work["n_glb_cells"] + work["n_sw_cells"]
+    dp_ms = st["ms_extend"] + st["ms_dedup"] + st["ms_seedsw"]
+    res = {"what": f"BASELINE configs[4] layout: {n} reads of {L} bp (1.5 % sub, 4 % del, 9 % ins), -x pacbio, same index; one batch resident in HBM, best of {args.long_steps} passes of the hot path",
+           "reads_per_s": round(n / best * 1e3, 1), "Mbp_per_s": round(n * L / best / 1e3, 2), "ms_per_pass": round(best, 2),
+           "stage_ms": {k: round(st[k], 2) for k in ("ms_seed", "ms_sa", "ms_chain", "ms_seedsw", "ms_extend", "ms_dedup", "ms_total")},
+           "dp_cells_per_read": {"extend": round(work["n_ext_cells"] / n), "global_score": round(work["n_glb_cells"] / n), "seed_sw": round(work["n_sw_cells"] / n)},
+           "gcups": round(cells / (dp_ms * 1e-3) / 1e9, 1) if dp_ms > 0 else None,
+           "gcups_note": "extension + patch (score-only global) + seed re-scoring cells / the three kernels' time; the final CIGARs' cells are counted under end_to_end"}
+    # ---- reference and product command lines on a prefix ----
+    n_p = min(args.long_sample, n)
+    fq = os.path.join(cache, "long_sample.fq")
+    simdata.write_fastq(fq, reads[:n_p])
+    ref = run_reference(prefix, [fq], threads, os.path.join(cache, "ref_long.sam"), extra=["-x", "pacbio"])
+    our = run_product(prefix, [fq], threads, os.path.join(cache, "our_long.sam"), extra=["-x", "pacbio"])
+    if ref:
+        res["cpu_baseline"] = {"value": round(ref["reads_per_s"], 1), "unit": "reads/s", "cores": threads, "kind": "reference",
+                               "sample": f"first {n_p} reads, `bwa mem -x pacbio -t {threads} -K 100000000`, rate from its own per-batch real-time lines; {ref['wall_s']:.1f}s wall"}
+    if our:
+        res["end_to_end"] = {"reads_per_s": round(our["reads_per_s"], 1), "stages": our["stages"], "what": f"`bwa-amd mem -x pacbio -t {threads}` on the same {n_p} reads, FASTQ -> SAM"}
+    if ref and our:
+        a, b = sam_body_digest(os.path.join(cache, "ref_long.sam")), sam_body_digest(os.path.join(cache, "our_long.sam"))
+        res["parity"] = bool(a == b and a[1] >= n_p)
+        res["parity_records"] = a[1]
+    return res
 
 
 if __name__ == "__main__":

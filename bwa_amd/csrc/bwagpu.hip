@@ -188,11 +188,12 @@ __global__ void __launch_bounds__(256) k_occ32_blocks(DevIndex ix, const u64 *sb
 		out[j * 2 + 1] = ix.bwt[(j >> 1) * 4 + 2 + (j & 1)];
 	}
 }
-// BWAGPU_OCC32=1: build the second layout from the resident reference-format blocks (the files and everything else keep using those)
+// The seeding and SA kernels read this layout (default; BWAGPU_OCC32=0 keeps them on the reference-format blocks): built from the resident
+// reference-format blocks, which stay the interchange format (files, index broadcast, bwagpu_index_buffers)
 static int build_occ32(bwagpu_t *h)
 {
 	h->ix.occ32 = nullptr; h->ix.occ_sb = nullptr; h->ix.occ_sb_shift = 32;
-	if (!(getenv("BWAGPU_OCC32") && atoi(getenv("BWAGPU_OCC32")) != 0) || h->bwt_blocks == 0) return 0;
+	if ((getenv("BWAGPU_OCC32") && atoi(getenv("BWAGPU_OCC32")) == 0) || h->bwt_blocks == 0) return 0;   // (BWAGPU_OCC32=0: keep to the reference-format blocks)
 	int shift = getenv("BWAGPU_OCC32_SB_SHIFT") ? atoi(getenv("BWAGPU_OCC32_SB_SHIFT")) : 32;      // (tests: small superblocks on small genomes)
 	if (shift < 8) shift = 8; if (shift > 32) shift = 32;
 	const int sh = shift - 6;

@@ -125,22 +125,38 @@ DEVFN void fm_init(const DevIndex &ix, int c, BiIntv &ik)
 	ik.x0 = ix.L2[c] + 1; ik.x2 = ix.L2[c + 1] - ix.L2[c]; ik.x1 = ix.L2[3 - c] + 1; ik.info = 0;
 }
 
+// One bwt_invPsi step (bwt.c:53-59) for k != primary: the row of the suffix one base to the left.  Reads one index block of whichever
+// layout the handle has (wave-uniform choice).
+DEVFN u64 fm_lf(const DevIndex &ix, u64 k)
+{
+	const u64 x = k - (k > ix.primary);        // position in the $-less BWT string (note: '>' here); k and x never straddle a block edge
+	u64 cnt[4]; int c;                           // because occ(k) adjusts k the same way when k > primary
+	if (ix.occ32 != nullptr) {
+		const uint4 *b = ix.occ32 + (x >> 6) * 2;
+		const uint4 *sb = (const uint4*)(ix.occ_sb + (x >> ix.occ_sb_shift) * 4);
+		const uint4 rel = b[0], w = b[1], s0 = sb[0], s1 = sb[1];
+		const int o = (int)(x & 63);
+		const u32 word = o < 32 ? (o < 16 ? w.x : w.y) : (o < 48 ? w.z : w.w);
+		c = (word >> ((~o & 15) << 1)) & 3;
+		occ32_counts(rel, w, s0, s1, o, cnt);
+	} else {
+		const OccBlock b = load_block(ix, x >> 7);
+		const int o = (int)(x & 127);
+		const u32 word = o < 64 ? (o < 32 ? (o < 16 ? b.w0.x : b.w0.y) : (o < 48 ? b.w0.z : b.w0.w))
+								: (o < 96 ? (o < 80 ? b.w1.x : b.w1.y) : (o < 112 ? b.w1.z : b.w1.w));
+		c = (word >> ((~o & 15) << 1)) & 3;
+		block_occ4_bf(b, o, cnt);              // == bwt_occ(k, c): count of c in BWT[0..x]
+	}
+	return c == 0 ? ix.L2[0] + cnt[0] : c == 1 ? ix.L2[1] + cnt[1] : c == 2 ? ix.L2[2] + cnt[2] : ix.L2[3] + cnt[3];
+}
+
 // bwt_sa (bwt.c:86-96) with bwt_invPsi (bwt.c:53-59): walk LF until a sampled row.  *steps += walk length.
 DEVFN u64 fm_sa(const DevIndex &ix, u64 k, u32 *steps)
 {
 	u64 sa = 0;
 	while (k & ix.sa_mask) {
 		++sa;
-		if (k == ix.primary) { k = 0; continue; }
-		u64 x = k - (k > ix.primary);          // position in the $-less BWT string (note: '>' here)
-		OccBlock b = load_block(ix, x >> 7);   // k and x differ by at most one and never straddle a block edge
-		int o = (int)(x & 127);                // because occ(k) adjusts k the same way when k > primary
-		u32 w = o < 64 ? (o < 32 ? (o < 16 ? b.w0.x : b.w0.y) : (o < 48 ? b.w0.z : b.w0.w))
-					   : (o < 96 ? (o < 80 ? b.w1.x : b.w1.y) : (o < 112 ? b.w1.z : b.w1.w));
-		int c = (w >> ((~o & 15) << 1)) & 3;
-		u64 cnt[4];
-		block_occ4(b, o, cnt);                 // == bwt_occ(k, c): count of c in BWT[0..x]
-		k = ix.L2[c] + cnt[c];
+		k = k == ix.primary ? 0 : fm_lf(ix, k);
 	}
 	*steps += (u32)sa;
 	return sa + ix.sa[k >> ix.sa_shift];

@@ -597,18 +597,7 @@ __global__ void __launch_bounds__(256) k_sa(DevIndex ix, Batch B)
 		}
 		if (k & ix.sa_mask) {           // one bwt_invPsi step (bwt.c:53-59)
 			++sa;
-			if (k == ix.primary) k = 0;
-			else {
-				u64 x = k - (k > ix.primary);
-				OccBlock b = load_block(ix, x >> 7);
-				int o = (int)(x & 127);
-				u32 w = o < 64 ? (o < 32 ? (o < 16 ? b.w0.x : b.w0.y) : (o < 48 ? b.w0.z : b.w0.w))
-							   : (o < 96 ? (o < 80 ? b.w1.x : b.w1.y) : (o < 112 ? b.w1.z : b.w1.w));
-				int c = (w >> ((~o & 15) << 1)) & 3;
-				u64 cnt[4];
-				block_occ4_bf(b, o, cnt);
-				k = (c == 0 ? ix.L2[0] + cnt[0] : c == 1 ? ix.L2[1] + cnt[1] : c == 2 ? ix.L2[2] + cnt[2] : ix.L2[3] + cnt[3]);
-			}
+			k = k == ix.primary ? 0 : fm_lf(ix, k);
 		} else {                        // sampled row reached: finish this lookup, move to the lane's next slot
 			u64 rbeg = sa + ix.sa[k >> ix.sa_shift];
 			steps += (u32)sa;

@@ -655,7 +655,7 @@ int main(int argc, char *argv[])
 
 	std::thread writer([&] {      // stage 4: output in input order
 		WorkP w;
-		while (to_out.pop(w)) { const double tw = now_s(); for (auto &t : w->out) fwrite(t.data(), 1, t.size(), stdout); busy_write += now_s() - tw; }
+		while (to_out.pop(w)) { const double tw = now_s(); for (auto &t : w->out) fwrite(t.data(), 1, strnlen(t.data(), t.size()), stdout); /* (the reference fputs() a read's records, fastmap.c:116: a NUL -- the letter of base code 5, a '-' in the input -- ends them) */ busy_write += now_s() - tw; }
 	});
 
 	for (;;) {                    // stage 3 (this thread drives the worker pool of finalize_batch)

@@ -140,6 +140,32 @@ def test_cli_gpu(tmp_path):
     _compare_all(cli, fa, f1, f2, inter, fasta)
 
 
+@pytest.mark.gpu
+def test_cli_gpu_two_devices(tmp_path):
+    """BWAGPU_DEVICES on hardware: when the box has at least two GPUs, `bwa-amd mem` with every batch split over devices
+    0 and 1 (index copied device to device with hipMemcpyPeer, bwagpu_clone_to_device) must reproduce `bwa mem` -- paired-end (one
+    mem_pestat over the gathered shards), single-end, and many small batches."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f"this box has {n} GPU(s): the multi-device path of bwa-amd mem (BWAGPU_DEVICES, hipMemcpyPeer) needs two and was NOT exercised on hardware by this run")
+    assert refapi.have_ref(), "oracle/_ref (the compiled reference) is missing on the GPU box"
+    from bwa_amd import build as b
+    _, cli = b.build_host(verbose=False)
+    fa, g = testdata.medium_index()
+    f1, f2, inter, fasta = _write_inputs(tmp_path, g, 20000, seed=405)
+    env = dict(os.environ, BWAGPU_DEVICES="0,1")
+    K = ["-K", "100000000", "-t", "4"]
+    p = subprocess.run([cli, "mem"] + K + ["-v", "3", fa, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0 and b"index copied to 2 devices" in p.stderr, p.stderr.decode()[-800:]
+    assert _run(refapi.REF_BWA, K + [fa, f1, f2]) == _body(p.stdout), "paired-end, 2 GPUs"
+    assert _run(refapi.REF_BWA, K + [fa, f1]) == _run(cli, K + [fa, f1], env), "single-end, 2 GPUs"
+    assert _run(refapi.REF_BWA, ["-K", "300000", "-t", "4", fa, f1, f2]) == _run(cli, ["-K", "300000", "-t", "4", fa, f1, f2], env), "20 batches, 2 GPUs"
+    if n >= 3:
+        env3 = dict(os.environ, BWAGPU_DEVICES=",".join(str(i) for i in range(min(n, 8))))
+        assert _run(refapi.REF_BWA, K + [fa, f1, f2]) == _run(cli, K + [fa, f1, f2], env3), f"paired-end, {min(n, 8)} GPUs"
+
+
 @pytest.mark.skipif(not refapi.have_ref(), reason="oracle/_ref not built")
 def test_cli_hostsim_two_devices(tmp_path):
     """Multi-GPU in the product: with BWAGPU_DEVICES=0,1 every batch is split into two contiguous ranges of whole
@@ -163,8 +189,10 @@ def test_cli_hostsim_two_devices(tmp_path):
     noisy = str(tmp_path / "noisy.fq")
     simdata.write_fastq(noisy, simdata.make_reads_se(g, 16, seed=404, sub=0.02, dele=0.03, ins=0.03))
     assert _run(refapi.REF_BWA, K + [prefix, noisy]) == _run(cli, K + [prefix, noisy], env), "gap-rich reads, 2 devices"
-    # the optional 32-byte block layout of the BWT is rebuilt on every device the index is copied to
+    # the 32-byte block layout of the BWT is rebuilt on every device the index is copied to (here with small superblocks, so that the
+    # superblock table is in play); and the same run on the reference-format blocks
     env_occ = dict(env, BWAGPU_OCC32="1", BWAGPU_OCC32_SB_SHIFT="10")
-    assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], env_occ), "paired-end, 2 devices, 32-byte blocks"
+    assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], env_occ), "paired-end, 2 devices, 32-byte blocks with 2^10-base superblocks"
+    assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], dict(env, BWAGPU_OCC32="0")), "paired-end, 2 devices, 64-byte blocks"
     env3 = dict(env, MOCK_HIP_DEVICES="3", BWAGPU_DEVICES="0,1,2")
     assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], env3), "paired-end, 3 devices"
