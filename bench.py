@@ -45,8 +45,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the best measured streaming copy
 
 
+_T0 = time.time()
+
+
 def log(*a):
-    print(*a, file=sys.stderr, flush=True)
+    print(f"[{time.time() - _T0:7.1f}s]", *a, file=sys.stderr, flush=True)
 
 
 def build_or_load_index(genome_mbp: float, cache: str, rank: int, barrier):
@@ -86,13 +89,18 @@ def sam_body_digest(path: str):
     return h.hexdigest(), n
 
 
-def run_reference(prefix: str, files, threads: int, out_sam: str, K: int = 100000000, extra=()):
+def run_reference(prefix: str, files, threads: int, out_sam: str, K: int = 100000000, extra=(), timeout: float = 240.0):
     """Unmodified reference `bwa mem -t threads -K <K>`; reads/s from its own per-batch timing lines
     (bwamem.c:1263: '[M::mem_process_seqs] Processed N reads in X CPU sec, Y real sec') and the whole-run real time (main.c:126)."""
     bwa = os.path.join(ROOT, "oracle", "_ref", "bwa")
     t = time.time()
-    with open(out_sam, "wb") as fo:
-        p = subprocess.run([bwa, "mem", "-t", str(threads), "-K", str(K), "-v", "3"] + list(extra) + [prefix] + list(files), stdout=fo, stderr=subprocess.PIPE, text=True)
+    log(f"[bench] reference: bwa mem -t {threads} -K {K} {' '.join(extra)} on {[os.path.basename(f) for f in files]}")
+    try:
+        with open(out_sam, "wb") as fo:
+            p = subprocess.run([bwa, "mem", "-t", str(threads), "-K", str(K), "-v", "3"] + list(extra) + [prefix] + list(files), stdout=fo, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        log(f"[bench] reference bwa mem did not finish within {timeout:.0f} s")
+        return None
     wall = time.time() - t
     n = tot = 0.0
     for m in re.finditer(r"Processed (\d+) reads in ([\d.]+) CPU sec, ([\d.]+) real sec", p.stderr):
@@ -109,7 +117,11 @@ def run_instrumented(prefix: str, files, threads: int):
     exe = os.path.join(ROOT, "oracle", "_ref", "bwa_instr")
     if not os.path.exists(exe):
         return None
-    p = subprocess.run([exe, "mem", "-t", str(threads), "-K", "100000000", "-v", "3", prefix] + list(files), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    log("[bench] instrumented reference (work counters)")
+    try:
+        p = subprocess.run([exe, "mem", "-t", str(threads), "-K", "100000000", "-v", "3", prefix] + list(files), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=120)
+    except subprocess.TimeoutExpired:
+        return None
     m = re.search(r"\[orc_instr\] n_2occ4 (\d+) N_blk (\d+) N_sa (\d+) N_lf (\d+) W_ref (\d+) ext_calls (\d+) ext_cells (\d+) glb_cells (\d+)", p.stderr)
     n = sum(int(x) for x in re.findall(r"Processed (\d+) reads", p.stderr))
     if p.returncode != 0 or not m or n == 0:
@@ -118,7 +130,7 @@ def run_instrumented(prefix: str, files, threads: int):
     return {"n_reads": n, "n_2occ4": k[0] / n, "N_blk": k[1] / n, "N_sa": k[2] / n, "N_lf": k[3] / n, "W_ref": k[4] / n, "ext_calls": k[5] / n, "ext_cells": k[6] / n, "glb_cells": k[7] / n}
 
 
-def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: int | None = None, K: int = 100000000, extra=(), devices=None):
+def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: int | None = None, K: int = 100000000, extra=(), devices=None, timeout: float = 240.0):
     """The stand-alone `bwa-amd mem` (FASTQ in -> device hot path + device CIGARs / mate rescue -> host finalize -> SAM text).
     devices: device ids for BWAGPU_DEVICES (every batch is split over them), None = device 0."""
     cli = os.path.join(ROOT, "bwa_amd", "bwa-amd")
@@ -129,7 +141,12 @@ def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: 
     if devices and len(devices) > 1:
         env["BWAGPU_DEVICES"] = ",".join(str(d) for d in devices)
     t = time.time()
-    p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=env)
+    log(f"[bench] product: bwa-amd mem -t {threads} -K {K} {' '.join(extra)} on {[os.path.basename(f) for f in files]}" + (f" devices {devices}" if devices and len(devices) > 1 else ""))
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=env, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        log(f"[bench] bwa-amd mem did not finish within {timeout:.0f} s")
+        return None
     wall = time.time() - t
     m = re.search(r"\[M::main_mem\] (\d+) reads in ([\d.]+) sec .*: (\d+) reads/s", p.stderr)
     if p.returncode != 0 or not m:
@@ -183,10 +200,10 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--parity-pairs", type=int, default=800_000, help="pairs of the multi-batch paired-end parity / CPU-baseline sample (eight batches)")
     ap.add_argument("--no-longread", action="store_true", help="skip the BASELINE configs[4] leg (10 kb reads, -x pacbio)")
-    ap.add_argument("--long-reads", type=int, default=8000)
+    ap.add_argument("--long-reads", type=int, default=4000)
     ap.add_argument("--long-len", type=int, default=10000)
     ap.add_argument("--long-steps", type=int, default=2)
-    ap.add_argument("--long-sample", type=int, default=2000, help="reads of the long-read CPU-baseline / parity prefix")
+    ap.add_argument("--long-sample", type=int, default=400, help="reads of the long-read CPU-baseline / parity prefix")
     args = ap.parse_args()
 
     import torch
@@ -250,6 +267,7 @@ def main():
         batches.append(rd)
     n_batch = batches[0].shape[0]
 
+    log(f"[bench] index resident, {S} batches of {n_batch} reads uploaded")
     # one untimed instrumented solo pass: algorithmic work counters of batch 0 (roofline numerator) and solo kernel times
     gpu.set_stats(True)
     gpu.run(opt)
@@ -292,6 +310,7 @@ def main():
             sys.exit(0)
 
     rc_exit = 0
+    log(f"[bench] hot path timed: {dt / args.steps * 1e3:.1f} ms/step; solo stages {stage_ms}")
     total_reads = n_batch * world * args.steps
     value = total_reads / dt / 1e6
     nr = float(work["n_reads"])
@@ -466,6 +485,7 @@ def longread_bench(args, prefix, g, threads, cache):
     from bwa_amd.api import BwaGpu
     from bwa_amd.structs import pacbio_opt
     L, n = args.long_len, args.long_reads
+    log(f"[bench] long-read leg: {n} reads of {L} bp")
     reads = simdata.make_reads_long(g, n, length=L, seed=7)
     gpu = BwaGpu(prefix)
     if args.dense_sa:
@@ -480,6 +500,7 @@ def longread_bench(args, prefix, g, threads, cache):
         t = time.perf_counter(); gpu.run(opt); ms.append((time.perf_counter() - t) * 1e3); st = gpu.stats()
     gpu.close()
     best = min(ms)
+    log(f"[bench] long-read hot path: {best:.1f} ms per pass; stages {st}")
     cells = work["n_ext_cells"] + work["n_glb_cells"] + work["n_sw_cells"]
     dp_ms = st["ms_extend"] + st["ms_dedup"] + st["ms_seedsw"]
     res = {"what": f"BASELINE configs[4] layout: {n} reads of {L} bp (1.5 % sub, 4 % del, 9 % ins), -x pacbio, same index; one batch resident in HBM, best of {args.long_steps} passes of the hot path",
@@ -492,8 +513,8 @@ def longread_bench(args, prefix, g, threads, cache):
     n_p = min(args.long_sample, n)
     fq = os.path.join(cache, "long_sample.fq")
     simdata.write_fastq(fq, reads[:n_p])
-    ref = run_reference(prefix, [fq], threads, os.path.join(cache, "ref_long.sam"), extra=["-x", "pacbio"])
-    our = run_product(prefix, [fq], threads, os.path.join(cache, "our_long.sam"), extra=["-x", "pacbio"])
+    ref = run_reference(prefix, [fq], threads, os.path.join(cache, "ref_long.sam"), extra=["-x", "pacbio"], timeout=150)
+    our = run_product(prefix, [fq], threads, os.path.join(cache, "our_long.sam"), extra=["-x", "pacbio"], timeout=150)
     if ref:
         res["cpu_baseline"] = {"value": round(ref["reads_per_s"], 1), "unit": "reads/s", "cores": threads, "kind": "reference",
                                "sample": f"first {n_p} reads, `bwa mem -x pacbio -t {threads} -K 100000000`, rate from its own per-batch real-time lines; {ref['wall_s']:.1f}s wall"}

@@ -188,12 +188,13 @@ __global__ void __launch_bounds__(256) k_occ32_blocks(DevIndex ix, const u64 *sb
 		out[j * 2 + 1] = ix.bwt[(j >> 1) * 4 + 2 + (j & 1)];
 	}
 }
-// The seeding and SA kernels read this layout (default; BWAGPU_OCC32=0 keeps them on the reference-format blocks): built from the resident
-// reference-format blocks, which stay the interchange format (files, index broadcast, bwagpu_index_buffers)
+// BWAGPU_OCC32=1 (A/B measurements): the seeding and SA kernels read this second layout, built from the resident reference-format blocks.
+// It was the answer to "32-byte requests come 1.6 times as fast as 64-byte ones" (profiles/r02_experiments.md) until tools/randbw3.hip showed
+// that the 64-byte blocks themselves come 2.2 times as fast when a quad fetches them together -- which is what the seeding kernels now do.
 static int build_occ32(bwagpu_t *h)
 {
 	h->ix.occ32 = nullptr; h->ix.occ_sb = nullptr; h->ix.occ_sb_shift = 32;
-	if ((getenv("BWAGPU_OCC32") && atoi(getenv("BWAGPU_OCC32")) == 0) || h->bwt_blocks == 0) return 0;   // (BWAGPU_OCC32=0: keep to the reference-format blocks)
+	if (!(getenv("BWAGPU_OCC32") && atoi(getenv("BWAGPU_OCC32")) != 0) || h->bwt_blocks == 0) return 0;
 	int shift = getenv("BWAGPU_OCC32_SB_SHIFT") ? atoi(getenv("BWAGPU_OCC32_SB_SHIFT")) : 32;      // (tests: small superblocks on small genomes)
 	if (shift < 8) shift = 8; if (shift > 32) shift = 32;
 	const int sh = shift - 6;
@@ -668,7 +669,10 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.tmp_intv = h->d_tmp_intv.as<BiIntv>(); B.mem_cap = h->mem_cap;
 		B.rd_words = h->rd_words; B.seq_2b = h->d_seq_2b.as<u32>(); B.seq_flags = h->d_seq_flags.as<u8>();
 		// LDS per lane: 160 bytes at four blocks per CU -- the read's 2-bit copy first, interval-stack entries with the rest
-		const int lds_ent_dflt = h->rd_words ? ((160 - 4 * h->rd_words) / 16 < SEED_LDS_ENT ? (160 - 4 * h->rd_words) / 16 : SEED_LDS_ENT) : SEED_LDS_ENT;
+		// (three blocks per CU -- the register allocation of the cooperative seeding kernel for 3 waves per SIMD, BWAGPU_SEED_OCC=3 -- leave each lane 208 bytes)
+		const int seed_occ = getenv("BWAGPU_SEED_OCC") ? atoi(getenv("BWAGPU_SEED_OCC")) : 4;
+		const int lane_lds = seed_occ == 3 && h->ix.occ32 == nullptr && !(getenv("BWAGPU_SEED_COOP") && atoi(getenv("BWAGPU_SEED_COOP")) == 0) ? 208 : 160, ent_max = lane_lds == 208 ? 13 : SEED_LDS_ENT;
+		const int lds_ent_dflt = h->rd_words ? ((lane_lds - 4 * h->rd_words) / 16 < ent_max ? (lane_lds - 4 * h->rd_words) / 16 : ent_max) : ent_max;
 		B.seed_lds_ent = (h->seq_len < ((u64)1 << 37) && h->max_len < 65536) ? (getenv("BWAGPU_SEED_LDS_ENT") ? atoi(getenv("BWAGPU_SEED_LDS_ENT")) : lds_ent_dflt) : 0;
 		if (((size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * 16 + (size_t)B.rd_words * 4) * BLOCK > 65536) B.rd_words = 0;   // (an LDS_ENT override too large for both)
 		B.intv_n = h->d_intv_n.as<i32>(); B.intv_off = h->d_intv_off.as<i64>(); B.intv = h->d_intv.as<Intv3>();
@@ -683,13 +687,16 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>(); B.chain_todo = h->d_chain_todo.as<i32>(); B.chain_todo2 = B.chain_todo + n + 4; B.seed_w = h->d_seed_w.as<i32>(); B.seed_order = nullptr;
 		B.seed_prio = !(getenv("BWAGPU_SEED_PRIO") && atoi(getenv("BWAGPU_SEED_PRIO")) == 0);
 		B.seed_no_virt = getenv("BWAGPU_SEED_NO_VIRT") && atoi(getenv("BWAGPU_SEED_NO_VIRT")) != 0;
+		B.seed_coop = h->ix.occ32 == nullptr && !(getenv("BWAGPU_SEED_COOP") && atoi(getenv("BWAGPU_SEED_COOP")) == 0);
 		B.seed_pass3_inline = getenv("BWAGPU_SEED_PASS3_INLINE") && atoi(getenv("BWAGPU_SEED_PASS3_INLINE")) != 0;
 		B.chain_lds_off = getenv("BWAGPU_CHAIN_LDS") && atoi(getenv("BWAGPU_CHAIN_LDS")) == 0;
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
 		HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "start", hipGetErrorString(e_)); }
 		if (!B.seed_pass3_inline) {   // pass 3 first (cheap), then passes 1-2 on the reads ordered by the repetitiveness it measured
-			hipLaunchKernelGGL(k_seed3, grid, block, 0, h->stream, h->ix, *opt, B);
+			if (h->ix.occ32 != nullptr) hipLaunchKernelGGL(k_seed3<1>, grid, block, 0, h->stream, h->ix, *opt, B);
+			else if (B.seed_coop) hipLaunchKernelGGL(k_seed3<2>, grid, block, 0, h->stream, h->ix, *opt, B);
+			else hipLaunchKernelGGL(k_seed3<0>, grid, block, 0, h->stream, h->ix, *opt, B);
 			if (!getenv("BWAGPU_SEED_INPUT_ORDER")) {
 				i32 *keep = B.order; B.order = h->d_seed_order.as<i32>();
 				if (int rc2 = order_reads(h, B, B.seed_w)) return rc2;
@@ -699,13 +706,17 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		const size_t seed_lds = ((size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * sizeof(uint4) + (size_t)B.rd_words * 4) * BLOCK;
 		dim3 sgrid = grid;                    // (BWAGPU_SEED_GRID, measurements: fewer resident workgroups of the seeding kernel; it stays within 5 % down to two per CU -- it is bound by memory requests, not by waves -- but step time with three batches in flight did not move either, nor did making the batches' seeding kernels take turns)
 		if (getenv("BWAGPU_SEED_GRID") && atoi(getenv("BWAGPU_SEED_GRID")) > 0 && (unsigned)atoi(getenv("BWAGPU_SEED_GRID")) < grid.x) sgrid = dim3((unsigned)atoi(getenv("BWAGPU_SEED_GRID")));
-		// (eight instances: with/without the LDS copy of the reads, the work counters -- which cost registers -- and the 32-byte block layout)
-#define SEED_LAUNCH(RD_, ST_, O_) hipLaunchKernelGGL((k_seed<RD_, ST_, O_>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B)
+		// (twelve instances: with/without the LDS copy of the reads, the work counters -- which cost registers -- and the three ways of reading the index)
+#define SEED_LAUNCH(RD_, ST_, B_, O_) hipLaunchKernelGGL((k_seed<RD_, ST_, B_, O_>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B)
+#define SEED_LAUNCH_B(RD_, ST_) do { if (blk == 2 && socc == 3) SEED_LAUNCH(RD_, ST_, 2, 3); else if (blk == 2) SEED_LAUNCH(RD_, ST_, 2, 4); else if (blk == 1) SEED_LAUNCH(RD_, ST_, 1, 4); else SEED_LAUNCH(RD_, ST_, 0, 4); } while (0)
 		{
-			const bool rd = B.rd_words != 0, st = B.stats != 0, o32 = h->ix.occ32 != nullptr;
-			if (rd) { if (st) { if (o32) SEED_LAUNCH(true, true, true); else SEED_LAUNCH(true, true, false); } else { if (o32) SEED_LAUNCH(true, false, true); else SEED_LAUNCH(true, false, false); } }
-			else { if (st) { if (o32) SEED_LAUNCH(false, true, true); else SEED_LAUNCH(false, true, false); } else { if (o32) SEED_LAUNCH(false, false, true); else SEED_LAUNCH(false, false, false); } }
+			const bool rd = B.rd_words != 0, st = B.stats != 0;
+			const int blk = h->ix.occ32 != nullptr ? 1 : (B.seed_coop ? 2 : 0);
+			const int socc = seed_occ;   // (measurements: register allocation of the cooperative form for 3 or 4 waves per SIMD)
+			if (rd) { if (st) SEED_LAUNCH_B(true, true); else SEED_LAUNCH_B(true, false); }
+			else { if (st) SEED_LAUNCH_B(false, true); else SEED_LAUNCH_B(false, false); }
 		}
+#undef SEED_LAUNCH_B
 #undef SEED_LAUNCH
 		HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_seed3+k_seed", hipGetErrorString(e_)); }

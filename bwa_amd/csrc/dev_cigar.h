@@ -118,7 +118,7 @@ __device__ int wave_ksw_global2(const DevIndex &ix, const bwagpu_opt_t &opt, con
 DEVFN int dev_infer_bw(int l1, int l2, int score, int a, int q, int r)
 {	// infer_bw (bwamem.c:818-825)
 	if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
-	int w = (int)((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.);
+	int w = trunc_div_add((l1 < l2 ? l1 : l2) * a - score - q, r, 2);   // (int)((double)x / r + 2.), bwamem.c:822
 	const int d = l1 > l2 ? l1 - l2 : l2 - l1;
 	if (w < d) w = d;
 	return w;
@@ -155,8 +155,8 @@ __device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const 
 				if (lane == 0) L.ops[0] = (u32)l_query << 4;
 				wave_sync();
 			} else {
-				int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
-				int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+				int max_ins = trunc_div_add(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins, opt.e_ins, 1);
+				int max_del = trunc_div_add(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del, opt.e_del, 1);
 				int max_gap = max_ins > max_del ? max_ins : max_del;
 				const int dl = rlen > l_query ? rlen - l_query : l_query - rlen;
 				max_gap = max_gap > 1 ? max_gap : 1;

@@ -166,6 +166,7 @@ struct Batch {
 	i32 *chain_n;              // per read: chains after filtering
 	i32 *chain_todo, *chain_todo2; // reads deferred by tier 0 / tier 1 of k_chain_wave to the next tier
 	int seed_prio;             // waves holding the heaviest 3 % of k_seed's reads run at raised issue priority (BWAGPU_SEED_PRIO=0 turns it off)
+	int seed_coop;             // the seeding kernels fetch index blocks quad-cooperatively (fm_occ_coop; off with BWAGPU_SEED_COOP=0 or when the 32-byte layout is in use)
 	int seed_pass3_inline;     // A/B switch (BWAGPU_SEED_PASS3_INLINE=1): pass 3 inside k_seed's state machine as in round 1, instead of k_seed3
 	int chain_lds_off;         // test hook (BWAGPU_CHAIN_LDS=0): the LDS tiers defer every read
 	// --- B-tree nodes

@@ -47,8 +47,8 @@ __device__ int dev_global_score(const DevIndex &ix, const bwagpu_opt_t &opt, int
 		for (int i = 0; i < l_query; ++i) score += opt.mat[ref_base(ix, t0 + (i64)i * tdir) * 5 + query[q0 + i * qdir]];
 		return score;
 	}
-	int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
-	int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+	int max_ins = trunc_div_add(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins, opt.e_ins, 1);
+	int max_del = trunc_div_add(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del, opt.e_del, 1);
 	int mg = max_ins > max_del ? max_ins : max_del, dl = rlen - l_query;
 	if (dl < 0) dl = -dl;
 	if (mg < 1) mg = 1;

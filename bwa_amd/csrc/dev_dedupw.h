@@ -84,8 +84,8 @@ __device__ int wave_global_score(const DevIndex &ix, const bwagpu_opt_t &opt, in
 		for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
 		return s;
 	}
-	int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
-	int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+	int max_ins = trunc_div_add(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins, opt.e_ins, 1);
+	int max_del = trunc_div_add(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del, opt.e_del, 1);
 	int mg = max_ins > max_del ? max_ins : max_del, dl = rlen - l_query;
 	if (dl < 0) dl = -dl;
 	if (mg < 1) mg = 1;

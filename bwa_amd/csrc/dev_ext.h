@@ -14,11 +14,18 @@ DEVFN int ref_base(const DevIndex &ix, i64 p)
 	return p < ix.l_pac ? pac_base(ix.pac, p) : 3 - pac_base(ix.pac, (ix.l_pac << 1) - 1 - p);
 }
 
+// (int)((double)x / e + k.) for integers x, k and e > 0, in integer arithmetic.  The reference computes several band limits this way
+// (bwamem.c:649-650, ksw.c:436-443, bwa.c:180-181, bwamem.c:822).  The double quotient is the correctly rounded x/e, whose distance to the
+// next integer is at least 1/e unless it is one, far more than the rounding errors of the division and of the addition for 32-bit
+// operands, and the conversion truncates toward zero: exactly C's (x + k*e) / e.  A double division costs the device ~40 instructions, and
+// with the usual gap extension penalty of 1 there is nothing to divide.
+DEVFN int trunc_div_add(int x, int e, int k) { const int z = x + k * e; return e == 1 ? z : z / e; }
+
 // cal_max_gap (bwamem.c:647-654)
 DEVFN int dev_max_gap(const bwagpu_opt_t &opt, int qlen)
 {
-	int l_del = (int)((double)(qlen * opt.a - opt.o_del) / opt.e_del + 1.);
-	int l_ins = (int)((double)(qlen * opt.a - opt.o_ins) / opt.e_ins + 1.);
+	int l_del = trunc_div_add(qlen * opt.a - opt.o_del, opt.e_del, 1);
+	int l_ins = trunc_div_add(qlen * opt.a - opt.o_ins, opt.e_ins, 1);
 	int l = l_del > l_ins ? l_del : l_ins;
 	if (l < 1) l = 1;
 	return l < opt.w << 1 ? l : opt.w << 1;
@@ -40,8 +47,8 @@ __device__ ExtRes dev_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, i
 	H[0] = h0;
 	if (qlen >= 1) H[DPS] = h0 > oe_ins ? h0 - oe_ins : 0;
 	for (j = 2; j <= qlen && H[(j - 1) * DPS] > e_ins; ++j) H[j * DPS] = H[(j - 1) * DPS] - e_ins;
-	int lim = (int)((double)(qlen * mat_max + end_bonus - o_ins) / e_ins + 1.); if (lim < 1) lim = 1; if (w > lim) w = lim;
-	lim = (int)((double)(qlen * mat_max + end_bonus - o_del) / e_del + 1.); if (lim < 1) lim = 1; if (w > lim) w = lim;
+	int lim = trunc_div_add(qlen * mat_max + end_bonus - o_ins, e_ins, 1); if (lim < 1) lim = 1; if (w > lim) w = lim;
+	lim = trunc_div_add(qlen * mat_max + end_bonus - o_del, e_del, 1); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	for (int i = 0; i < tlen; ++i) {
 		const int8_t *srow = opt.mat + ref_base(ix, t0 + (i64)i * tdir) * 5;
 		int f = 0, h1, m = 0, mj = -1;

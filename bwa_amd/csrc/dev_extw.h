@@ -160,11 +160,13 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		wave_sync();
 	}
 	int init_hi = -1;                                  // RING: columns 0..init_hi hold valid (initial or computed) values
-	int lim = (int)((double)(qlen * mat_max + end_bonus - o_ins) / e_ins + 1.); if (lim < 1) lim = 1; if (w > lim) w = lim;
-	lim = (int)((double)(qlen * mat_max + end_bonus - o_del) / e_del + 1.); if (lim < 1) lim = 1; if (w > lim) w = lim;
+	int lim = trunc_div_add(qlen * mat_max + end_bonus - o_ins, e_ins, 1); if (lim < 1) lim = 1; if (w > lim) w = lim;
+	lim = trunc_div_add(qlen * mat_max + end_bonus - o_del, e_del, 1); if (lim < 1) lim = 1; if (w > lim) w = lim;
+	w = uni(w);
 	int beg = 0, end = qlen, max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, treg = 0;
 	u32 cells32 = 0;
 	const bool two_col_ok = h0 + qlen * mat_max < (1 << 23);      // (score << 7 | column) must fit the scan's 31 bits
+	const int lane_e = lane * e_ins;
 	for (int i = 0; i < tlen; ++i) {
 		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
 		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
@@ -186,34 +188,63 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		}
 		int h1_init = 0;
 		if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
-		int m = 0, mj = -1, carry = W_NEG, hprev = h1_init, first_nz = -1, last_nz = -1, bnd = 0;
 		cells32 += (u32)(end > beg ? end - beg : 0);
-		if (!RING && end - beg <= 64) {
-			// The band fits one pass of the wave (always, for 150 bp reads): the same arithmetic without the pass loop and its carries
-			// -- the kernel is bound by scalar instructions (one scalar unit per CU), and the loop's control was half of them.
-			const int nact = end - beg;
-			const int j = beg + lane; const bool act = lane < nact;
+		bool stop;
+		if (!RING && end - beg <= 63) {
+			// The band fits one pass of the wave with a lane to spare (always, for 150 bp reads).  The kernel is bound by instruction issue --
+			// scalar instructions first (one issue slot per SIMD and four cycles, like the vector ones) -- so this form is written for few of both:
+			//  * a lane reads and writes only its own column: H(i,j) reaches column j+1 by a lane shift, lane 0 takes H(i,beg-1) = h1 as the
+			//    shift's fill value, and the spare lane nact stores column `end` = {H(i,end-1), 0} (ksw.c:485);
+			//  * F's offsets j * e_ins shrink to lane * e_ins: the row's common term beg * e_ins cancels between the scan's input and output;
+			//  * the row maximum is taken over max(M, E) instead of H = max(M, E, F).  F(i,j) <= max(0, max_k M(i,k) - oe_ins) lies strictly
+			//    below a positive row maximum, so neither the maximum nor the "last column wins" choice (ksw.c:473-474) changes -- but the
+			//    maximum's scan no longer waits for F's, and the two six-step DPP chains interleave instead of idling between dependent steps;
+			//  * the band's trimming (ksw.c:502-505) reads one ballot: bit L = column beg+L holds a non-zero {h, e}, column `end` included.
+			const int nact = end - beg;                       // (can be negative: the band has moved past the last live column)
+			const int j = beg + lane; const bool act = lane < nact, wr = lane <= nact;
 			const int2 old = eh[j];                           // (the LDS region is padded by 64 columns)
-			const int sc = qrow[(act ? j : beg) * qdir];
-			wave_sync();
+			const int sc = qrow[j * qdir];                    // (inactive lanes read the profile's padding or its neighbourhood, never past the wave's LDS)
 			const int M = old.x ? old.x + sc : 0;          // ksw.c:469: a dead diagonal cell stays dead
-			const int a = act ? imax(M - oe_ins, 0) + j * e_ins : W_NEG;
-			const int inc = wave_incl_scan_max(a);
+			const int hme = imax(M, old.y);
+			const int kmax = wave_incl_scan_max(act ? (hme << 6 | lane) : -1);
+			const int inc = wave_incl_scan_max(act ? imax(M - oe_ins, 0) + lane_e : W_NEG);
 			const int exc = wave_shift_up1(inc, W_NEG);
-			const int f = lane == 0 ? 0 : exc - (j - 1) * e_ins;       // F(i,j): best insertion ending left of column j
-			const int h = imax(imax(M, old.y), f);                    // H(i,j) = max(M, E, F), ksw.c:470-471
-			const int e_new = imax(imax(old.y - e_del, M - oe_del), 0); // E(i+1,j), ksw.c:475-479
-			if (act) { eh[j].y = e_new; eh[j + 1].x = h; }            // H(i,j) becomes the diagonal of column j+1 in row i+1; the last lane's is eh[end].h = h1 (ksw.c:485)
-			if (lane == 0) eh[beg].x = h1_init;
-			if (lane == (nact ? nact - 1 : 0)) eh[end].y = 0;
+			const int f = lane == 0 ? 0 : exc - lane_e + e_ins;         // F(i,j): best insertion ending left of column j
+			const int h = imax(hme, f);                               // H(i,j) = max(M, E, F), ksw.c:470-471
+			const int e_new = act ? imax(imax(old.y - e_del, M - oe_del), 0) : 0;   // E(i+1,j), ksw.c:475-479
 			const int hleft = wave_shift_up1(h, h1_init);             // eh[j].h after this row = H(i,j-1)
-			const u64 nzm = __ballot(act && (hleft | e_new) != 0);
-			if (nzm) { first_nz = beg + __builtin_ctzll(nzm); last_nz = beg + 63 - __builtin_clzll(nzm); }
-			const int key = __builtin_amdgcn_readlane(wave_incl_scan_max(act ? (h << 6 | lane) : -1), 63);   // last column wins ties (ksw.c:473-474)
-			if (key >= 0) { m = key >> 6; mj = beg + (key & 63); }
-			if (nact) hprev = __builtin_amdgcn_readlane(h, nact - 1);
+			if (wr) eh[j] = make_int2(hleft, e_new);
+			const u64 nzm = __ballot(wr && (hleft | e_new) != 0);
+			const int key = __builtin_amdgcn_readlane(kmax, 63);
+			const int h1l = __builtin_amdgcn_readlane(h, nact > 0 ? nact - 1 : 0);
 			wave_sync();
-		} else if (!RING && end - beg <= 128 && two_col_ok) {
+			// The row's bookkeeping as straight-line scalar selects with ONE exit test at the end of the loop body: written with breaks and
+			// a continue, the structurizer turned it into a state machine of ~75 scalar instructions per row.
+			{
+				const bool fin = (nact > 0 ? end : beg) == qlen;       // ksw.c:486-489
+				const int h1 = nact > 0 ? h1l : h1_init;              // H(i, end-1) as left in h1 by the reference's column loop
+				max_ie = (fin && h1 >= gscore) ? i : max_ie;
+				gscore = (fin && h1 > gscore) ? h1 : gscore;
+			}
+			const int m = key >> 6, mj = beg + (key & 63);
+			stop = key < 64;                                  // m == 0 (ksw.c:490); then m <= 0 < max and nothing below changes the results
+			const bool better = m > max;                      // ksw.c:491-493
+			int off = mj - i; off = off < 0 ? -off : off;
+			max_off = (better && off > max_off) ? off : max_off;
+			if (!better && zdrop > 0 && max - m > zdrop) {    // ksw.c:494-500 (the drop alone must exceed zdrop before the gap term can matter)
+				const int di = i - max_i, dj = mj - max_j;
+				stop = stop || (di > dj ? max - m - (di - dj) * e_del > zdrop : max - m - (dj - di) * e_ins > zdrop);
+			}
+			max_i = better ? i : max_i; max_j = better ? mj : max_j; max = better ? m : max;
+			// band for the next row (ksw.c:502-505): skip leading / trailing columns whose {h,e} are both zero
+			const u64 nz_lo = nzm & ((1ull << (nact & 63)) - 1);
+			const int nbeg = nz_lo ? beg + __builtin_ctzll(nz_lo) : end;
+			const int jl = nzm ? beg + 63 - __builtin_clzll(nzm) : nbeg - 1;
+			beg = nbeg;
+			end = jl + 2 < qlen ? jl + 2 : qlen;
+		} else {
+		int m = 0, mj = -1, carry = W_NEG, hprev = h1_init, first_nz = -1, last_nz = -1, bnd = 0;
+		if (!RING && end - beg <= 128 && two_col_ok) {
 			// 65..128 columns (the longer half of a 150 bp read's extensions): each lane owns two adjacent columns, so the row still takes ONE
 			// prefix scan for F and one for the row maximum instead of two passes of the loop below with their carries.  A lane's two
 			// {H,E} slots are read and written by that lane only -- H(i,j) reaches the owner of column j+1 through a lane shift, not LDS.
@@ -223,12 +254,15 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			const int2 oA = eh[jA], oB = eh[jB];               // (the LDS region is padded by 64 columns past the longest read)
 			const int scA = qrow[(actA ? jA : beg) * qdir], scB = qrow[(actB ? jB : beg) * qdir];
 			const int MA = oA.x ? oA.x + scA : 0, MB = oB.x ? oB.x + scB : 0;      // ksw.c:469
-			const int aA = actA ? imax(MA - oe_ins, 0) + jA * e_ins : W_NEG;
-			const int aB = actB ? imax(MB - oe_ins, 0) + jB * e_ins : W_NEG;
+			const int aA = actA ? imax(MA - oe_ins, 0) + 2 * lane_e : W_NEG;           // (F's offsets without the row's common term beg * e_ins, as above)
+			const int aB = actB ? imax(MB - oe_ins, 0) + 2 * lane_e + e_ins : W_NEG;
+			const int hmA = imax(MA, oA.y), hmB = imax(MB, oB.y);
+			const int kA = actA ? (hmA << 7 | 2 * lane) : -1, kB = actB ? (hmB << 7 | (2 * lane + 1)) : -1;   // last column wins ties (ksw.c:473-474); F never holds the row maximum
+			const int kmax = wave_incl_scan_max(imax(kA, kB));
 			const int exc = wave_shift_up1(wave_incl_scan_max(imax(aA, aB)), W_NEG);   // best insertion start among the columns of the lanes below
-			const int fA = lane == 0 ? 0 : exc - (jA - 1) * e_ins;
-			const int fB = imax(exc, aA) - (jB - 1) * e_ins;
-			const int hA = imax(imax(MA, oA.y), fA), hB = imax(imax(MB, oB.y), fB);   // ksw.c:470-471
+			const int fA = lane == 0 ? 0 : exc - 2 * lane_e + e_ins;
+			const int fB = imax(exc, aA) - 2 * lane_e;
+			const int hA = imax(hmA, fA), hB = imax(hmB, fB);                          // ksw.c:470-471
 			const int eA = imax(imax(oA.y - e_del, MA - oe_del), 0), eB = imax(imax(oB.y - e_del, MB - oe_del), 0);   // ksw.c:475-479
 			const int hleftA = wave_shift_up1(hB, h1_init);                       // H(i, jA-1): the lane below's second column
 			if (jA <= end) eh[jA] = make_int2(hleftA, actA ? eA : 0);                 // (column `end` gets {h1, 0}, ksw.c:485)
@@ -239,8 +273,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 				const int la = nzA ? 2 * (63 - __builtin_clzll(nzA)) : -1, lb = nzB ? 2 * (63 - __builtin_clzll(nzB)) + 1 : -1;
 				first_nz = beg + (fa < fb ? fa : fb); last_nz = beg + (la > lb ? la : lb);
 			}
-			const int kA = actA ? (hA << 7 | 2 * lane) : -1, kB = actB ? (hB << 7 | (2 * lane + 1)) : -1;   // last column wins ties (ksw.c:473-474)
-			const int key = __builtin_amdgcn_readlane(wave_incl_scan_max(imax(kA, kB)), 63);
+			const int key = __builtin_amdgcn_readlane(kmax, 63);
 			if (key >= 0) { m = key >> 7; mj = beg + (key & 127); }
 			const int lastc = nact - 1;
 			hprev = (lastc & 1) ? __builtin_amdgcn_readlane(hB, lastc >> 1) : __builtin_amdgcn_readlane(hA, lastc >> 1);
@@ -286,21 +319,23 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		const int h1 = beg < end ? hprev : h1_init;      // H(i, end-1) as left in h1 by the reference's column loop
 		const int jfin = beg < end ? end : beg;
 		if (jfin == qlen) { if (h1 >= gscore) max_ie = i; if (h1 > gscore) gscore = h1; }
-		if (m == 0) break;
+		stop = m == 0;
 		if (m > max) {
 			int off = mj - i; if (off < 0) off = -off;
 			max = m; max_i = i; max_j = mj;
 			if (off > max_off) max_off = off;
-		} else if (zdrop > 0) {
+		} else if (zdrop > 0 && !stop) {
 			const int di = i - max_i, dj = mj - max_j;
-			if (di > dj) { if (max - m - (di - dj) * e_del > zdrop) break; }
-			else if (max - m - (dj - di) * e_ins > zdrop) break;
+			if (di > dj) stop = max - m - (di - dj) * e_del > zdrop;
+			else stop = max - m - (dj - di) * e_ins > zdrop;
 		}
 		// band for the next row (ksw.c:502-505): skip leading / trailing columns whose {h,e} are both zero
 		const int nbeg = first_nz >= 0 ? first_nz : end;
 		const int jl = h1 != 0 ? end : (last_nz >= 0 ? last_nz : nbeg - 1);
 		beg = nbeg;
 		end = jl + 2 < qlen ? jl + 2 : qlen;
+		}
+		if (stop) break;
 	}
 	#undef EHI
 	#undef SCORE_AT

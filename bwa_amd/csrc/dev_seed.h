@@ -54,7 +54,7 @@ struct SeedLane {
 	u64 min_intv, last_x2;
 	int sx, i, n0, nprev, nc, j, c, ret, last_start;
 	bool any;
-	BiIntv ik, p;
+	BiIntv ik;
 	u32 code;                 // prefix-table window: forward sweep, q[sx..sx+ptab_m); backward sweep, q[i..i+ptab_m) (window_code)
 	// Matches shorter than the prefix tables' depth are not kept in the stack at all: whatever is done with such an entry -- extend it
 	// by a base, compare interval sizes -- is answered by the table for the string it stands for, so its end position is all there is to
@@ -274,9 +274,12 @@ __global__ void __launch_bounds__(256) k_publish(bwagpu_opt_t opt, Batch B)
 }
 
 // RD: the batch's reads are short enough for an LDS copy (Batch::rd_words > 0)
-// O32: the handle has the 32-byte block layout of the BWT (DevIndex::occ32) -- a compile-time choice here, so that neither path pays for the other's registers
-template<bool RD, bool STATS, bool O32>
-__global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, Batch B)
+// BLK: how the extension reads the index -- 2 (default): the reference-format 64-byte blocks, fetched quad-cooperatively (fm_occ_coop);
+//      0: the same blocks, each lane fetching its own (A/B measurements); 1: the 32-byte layout (DevIndex::occ32, BWAGPU_OCC32=1), per lane.
+//      A compile-time choice, so that no path pays for another's registers.
+// OCC: waves per SIMD the register allocation aims at (the cooperative form holds more live values: 4 spills a little, 3 does not)
+template<bool RD, bool STATS, int BLK, int OCC>
+__global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
 	HIP_DYNAMIC_SHARED(uint4, seed_lds)
 	const int cap = B.max_len + 1 + PTAB_MAX;
@@ -304,7 +307,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 	// wave then runs that code once for all of them.
 	int deferred = 0;
 	u32 n_iter = 0, n_slow = 0, n_ext_lanes = 0, n_deep = 0;
-	while (L.st != SS_DONE) {
+	while (__ballot(L.st != SS_DONE)) {       // (a lane that has run out of reads stays in the loop: its quad still needs it to fetch and count, fm_occ_coop)
 		if (STATS) ++n_iter;
 		const bool slow = L.st < SS_FWD || L.st == SS_FINAL;
 		const u64 sm = __ballot(slow);
@@ -409,30 +412,38 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 		const int st = L.st;
 		if (STATS) n_ext_lanes += (u32)__popcll(__ballot(st == SS_FWD || st == SS_BWD || st == SS_STRAT));
 		if (STATS && __ballot(st == SS_BWD && L.j >= S.n_lds && L.j < L.nprev)) ++n_deep;
-		if (st == SS_FWD || st == SS_BWD || st == SS_STRAT) {
-			BiIntv ok, src;
-			const int back = st == SS_BWD;
-			bool short_ent = false;
+		const bool ext = st == SS_FWD || st == SS_BWD || st == SS_STRAT;
+		BiIntv ok, src, p;        // p: the stack entry a backward step extends (it lives for this iteration only)
+		p.x0 = p.x1 = p.x2 = p.info = 0;
+		const int back = st == SS_BWD;
+		bool short_ent = false;
+		int cb = 0, tl = 0;
+		ok.x0 = ok.x1 = ok.x2 = ok.info = 0; src = ok;
+		if (ext) {
 			if (back) {
-				if (L.j < L.nprev) L.p = S.load(L, L.j);
+				if (L.j < L.nprev) p = S.load(L, L.j);
 				else {                                   // the stack's entries are done: the short ones, longest first
 					const int len = 32 - __clz((int)L.srem);
 					L.srem &= ~(1u << (len - 1));
-					L.p.x0 = L.p.x1 = L.p.x2 = 0; L.p.info = (u64)(L.i + 1 + len); short_ent = true;
+					p.x0 = p.x1 = p.x2 = 0; p.info = (u64)(L.i + 1 + len); short_ent = true;
 				}
 			}
-			src.x0 = back ? L.p.x0 : L.ik.x0; src.x1 = back ? L.p.x1 : L.ik.x1; src.x2 = back ? L.p.x2 : L.ik.x2; src.info = 0;
+			src.x0 = back ? p.x0 : L.ik.x0; src.x1 = back ? p.x1 : L.ik.x1; src.x2 = back ? p.x2 : L.ik.x2; src.info = 0;
 			const int qi = back ? 0 : seed_q(L, nib, L.i);
-			const int cb = back ? L.c : 3 - qi;
-			// A match no longer than ptab_m bases has its bi-interval in the prefix tables (filled by the same fm_extend1 at
-			// start-up, k_ptab_level; a bi-interval is a function of the string, whichever way it was extended): one 16-byte
-			// entry instead of two index blocks.  That covers the first steps of every forward search and, in the first
-			// backward rows, the short change-point intervals, whose match q[i..end) is still short.
-			const int tl = back ? (int)L.p.info - L.i : L.i - L.sx + 1;    // length of the extended match
-			if (tl <= ix.ptab_m) {
-				ptab_load(ix, tl, L.code, ok);
-				if (STATS) ++ntab;
-			} else { const u32 nb = fm_extend1<O32 ? 1 : 0>(ix, src, cb, back, ok); if (STATS) nblk += nb; }   // the only extension site of the kernel
+			cb = back ? L.c : 3 - qi;
+			tl = back ? (int)p.info - L.i : L.i - L.sx + 1;    // length of the extended match
+		}
+		// A match no longer than ptab_m bases has its bi-interval in the prefix tables (filled by the same extension routine at
+		// start-up, k_ptab_level; a bi-interval is a function of the string, whichever way it was extended): one 16-byte
+		// entry instead of two index blocks.  That covers the first steps of every forward search and, in the first
+		// backward rows, the short change-point intervals, whose match q[i..end) is still short.
+		const bool blocks = ext && tl > ix.ptab_m;
+		if (BLK == 2) {           // all lanes together: the quad of a lane that needs blocks fetches them with it (the only extension site of the kernel)
+			const u32 nb = fm_extend1_coop(ix, blocks, src, cb, back, ok); if (STATS && blocks) nblk += nb;
+		}
+		if (ext) {
+			if (!blocks) { ptab_load(ix, tl, L.code, ok); if (STATS) ++ntab; }
+			else if (BLK != 2) { const u32 nb = fm_extend1<BLK>(ix, src, cb, back, ok); if (STATS) nblk += nb; }
 			if (st == SS_FWD) {           // forward sweep of bwt_smem1a (bwt.c:304-320)
 				bool stop = false;
 				if (ok.x2 != L.ik.x2) {
@@ -447,11 +458,11 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 			} else if (st == SS_BWD) {    // one interval of one backward row (bwt.c:328-342)
 				if (ok.x2 < L.min_intv) {
 					if (L.nc == 0 && (!L.any || L.i + 1 < L.last_start)) {
-						L.em.add(L.p.x0, L.p.x2, L.i + 1, (int)L.p.info); L.any = true; L.last_start = L.i + 1;
+						L.em.add(p.x0, p.x2, L.i + 1, (int)p.info); L.any = true; L.last_start = L.i + 1;
 					}
 				} else if (L.nc == 0 || ok.x2 != L.last_x2) {
-					ok.info = L.p.info;
-					const int nl = (int)L.p.info - L.i;      // bases of the extended match
+					ok.info = p.info;
+					const int nl = (int)p.info - L.i;      // bases of the extended match
 					if (nl < S.virt_m) L.snew |= 1u << (nl - 1);
 					else { S.store(L, L.ncl, ok); ++L.ncl; }   // in place: ncl <= j, or one past the deep end for a short entry that has grown up
 					++L.nc; L.last_x2 = ok.x2;
@@ -485,7 +496,7 @@ __global__ void __launch_bounds__(256, 4) k_seed(DevIndex ix, bwagpu_opt_t opt, 
 // is a plain forward extension loop: run inside k_seed's state machine each of its steps paid for that machine's whole divergent
 // iteration (~1060 VALU instructions); here an iteration is the extension plus a dozen instructions of control.  One lane per
 // read, reads drawn from a per-wave pool.
-__global__ void __launch_bounds__(256) k_seed3(DevIndex ix, bwagpu_opt_t opt, Batch B)
+template <int BLK> __global__ void __launch_bounds__(256, 3) k_seed3(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
 	SeedLane L;                   // only the read window (qoff, win, win_w, len), x, sx, i, ik, code and the emitter are used
 	L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len; L.em.intv = B.intv; L.em.r = -1; L.em.n = 0; L.em.overflow = false;
@@ -497,7 +508,7 @@ __global__ void __launch_bounds__(256) k_seed3(DevIndex ix, bwagpu_opt_t opt, Ba
 	enum { T_FETCH = 0, T_START, T_EXT, T_DONE };
 	int st = T_FETCH, pool_base = 0, pool_cnt = 0;
 	u32 nblk = 0, ntab = 0, weight = 0;
-	while (st != T_DONE) {
+	while (__ballot(st != T_DONE)) {          // (a lane without reads stays: its quad needs it, fm_occ_coop)
 		const u64 wm = __ballot(st == T_FETCH);
 		if (wm) {
 			if (pool_cnt == 0) {
@@ -533,11 +544,15 @@ __global__ void __launch_bounds__(256) k_seed3(DevIndex ix, bwagpu_opt_t opt, Ba
 				else st = T_EXT;
 			}
 		}
-		if (st == T_EXT) {        // one forward extension (bwt.c:364-377)
-			BiIntv ok;
-			const int tl = L.i - L.sx + 1;
-			if (tl <= ix.ptab_m) { ptab_load(ix, tl, L.code, ok); ++ntab; }
-			else nblk += fm_extend1(ix, L.ik, 3 - seed_q(L, nib, L.i), 0, ok);
+		const bool ext = st == T_EXT;        // one forward extension (bwt.c:364-377)
+		const int tl = L.i - L.sx + 1;
+		const bool blocks = ext && tl > ix.ptab_m;
+		const int cb = blocks ? 3 - seed_q(L, nib, L.i) : 0;
+		BiIntv ok; ok.x0 = ok.x1 = ok.x2 = ok.info = 0;
+		if (BLK == 2) { const int nb = fm_extend1_coop(ix, blocks, L.ik, cb, 0, ok); if (blocks) nblk += nb; }   // (all lanes together)
+		if (ext) {
+			if (!blocks) { ptab_load(ix, tl, L.code, ok); ++ntab; }
+			else if (BLK != 2) nblk += fm_extend1<BLK>(ix, L.ik, cb, 0, ok);
 			if (tl == opt.min_seed_len) weight += (u32)(ok.x2 > 65535 ? 65535 : ok.x2);   // occurrences of the seed-length match: the read's repetitiveness
 			if (ok.x2 < opt.max_mem_intv && L.i - L.sx >= opt.min_seed_len) {
 				if (ok.x2 > 0) L.em.add(ok.x0, ok.x2, L.sx, L.i + 1);

@@ -29,6 +29,7 @@ struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned 
 struct uint4 { uint32_t x, y, z, w; };
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 static inline int4 make_int4(int x, int y, int z, int w) { int4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 static inline int2 make_int2(int x, int y) { int2 r; r.x = x; r.y = y; return r; }
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
@@ -98,7 +99,8 @@ static inline int mock_update_dpp(int old, int src, int ctrl, int row_mask, int 
 	uint64_t o[64], m; mock_exchange((uint32_t)src, o, &m);
 	int l = mock_lane(), row = l >> 4, s = -1;
 	if (!((row_mask >> row) & 1) || !((bank_mask >> ((l & 15) >> 2)) & 1)) return old;
-	if (ctrl >= 0x111 && ctrl <= 0x11f) { int n = ctrl - 0x110; s = (l & 15) >= n ? l - n : -1; }
+	if (ctrl >= 0 && ctrl <= 0xff) s = (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3);      // quad_perm
+	else if (ctrl >= 0x111 && ctrl <= 0x11f) { int n = ctrl - 0x110; s = (l & 15) >= n ? l - n : -1; }
 	else if (ctrl == 0x138) s = l >= 1 ? l - 1 : -1;
 	else if (ctrl == 0x142) s = row >= 1 ? row * 16 - 1 : -1;
 	else if (ctrl == 0x143) s = row >= 2 ? 31 : -1;

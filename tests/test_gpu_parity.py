@@ -163,29 +163,29 @@ def test_dense_sa_gives_identical_results(medium):
     g2.close()
 
 
-def test_reference_format_blocks_give_identical_results(medium, monkeypatch):
-    """BWAGPU_OCC32=0: seeding, SA look-ups, SA densification and the prefix tables read the reference-format 64-byte blocks instead of
-    the 32-byte layout (the default): same regions, same interval taps, with the SA at the reference's interval and densified."""
+def test_index_access_variants_give_identical_results(medium, monkeypatch):
+    """The seeding kernels read the reference-format 64-byte blocks quad-cooperatively by default; BWAGPU_SEED_COOP=0 lets every lane fetch
+    its own blocks, BWAGPU_OCC32=1 switches seeding, SA look-ups, SA densification and the prefix tables to the 32-byte layout: same
+    regions and interval taps in every variant, with the SA at the reference's interval and densified."""
     from bwa_amd.api import BwaGpu
     gpu, orc, ref, g = medium
     fa, _ = testdata.medium_index()
     seqs, off = testdata.flat(simdata.make_reads_se(g, 8000, seed=39, sub=0.02))
     base = gpu.align(default_opt(), seqs, off)
     n0, iv0 = gpu.tap_intervals()
-    assert_regs_equal(*ref.align(default_opt(), seqs, off), *base, "32-byte blocks vs compiled reference")
-    monkeypatch.setenv("BWAGPU_OCC32", "0")
-    g2 = BwaGpu(fa)
-    assert_regs_equal(*base, *g2.align(default_opt(), seqs, off), "64-byte blocks, sa_intv 32")
-    n1, iv1 = g2.tap_intervals()
-    assert np.array_equal(n0, n1) and iv0.tobytes() == iv1.tobytes()
-    g2.densify_sa(2)
-    assert_regs_equal(*base, *g2.align(default_opt(), seqs, off), "64-byte blocks, sa_intv 2")
-    g2.close()
-    monkeypatch.delenv("BWAGPU_OCC32")
-    g3 = BwaGpu(fa)
-    g3.densify_sa(2)
-    assert_regs_equal(*base, *g3.align(default_opt(), seqs, off), "32-byte blocks, sa_intv 2")
-    g3.close()
+    assert_regs_equal(*ref.align(default_opt(), seqs, off), *base, "quad-cooperative fetch vs compiled reference")
+    for env in ({"BWAGPU_SEED_COOP": "0"}, {"BWAGPU_OCC32": "1"}, {"BWAGPU_PTAB_M": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g2 = BwaGpu(fa)
+        assert_regs_equal(*base, *g2.align(default_opt(), seqs, off), f"{env}, sa_intv 32")
+        n1, iv1 = g2.tap_intervals()
+        assert np.array_equal(n0, n1) and iv0.tobytes() == iv1.tobytes(), env
+        g2.densify_sa(2)
+        assert_regs_equal(*base, *g2.align(default_opt(), seqs, off), f"{env}, sa_intv 2")
+        g2.close()
+        for k in env:
+            monkeypatch.delenv(k)
 
 
 def test_properties_at_scale(medium):
