@@ -32,8 +32,8 @@ MATESW_DTYPE = np.dtype([("read", "<i4"), ("r", "<i4"), ("anchor_rb", "<i8"), ("
                          ("score2", "<i4"), ("te2", "<i4"), ("tb", "<i4"), ("qb", "<i4"), ("pad_", "<i4"), ("pad2_", "<i4")])   # bwagpu_matesw_t (56 bytes with its tail padding)
 assert MATESW_DTYPE.itemsize == 56
 PES_DTYPE = np.dtype([("low", "<i4"), ("high", "<i4"), ("failed", "<i4"), ("pad_", "<i4")])               # bwagpu_pes_t
-CIGAR_DTYPE = np.dtype([("score", "<i4"), ("n_cigar", "<i4"), ("cigar", "<u4", (6,))])   # bwagpu_cigar_t
-assert CIGAR_DTYPE.itemsize == 32
+CIGAR_DTYPE = np.dtype([("score", "<i4"), ("n_cigar", "<i4"), ("cigar", "<u4", (6,)), ("nm", "<i4"), ("md_len", "<i4"), ("md", "<u8")])   # bwagpu_cigar_t
+assert CIGAR_DTYPE.itemsize == 48
 DP_CASE_DTYPE = np.dtype([("q_off", "<i4"), ("q_len", "<i4"), ("t_off", "<i4"), ("t_len", "<i4"), ("w", "<i4"), ("h0", "<i4"), ("end_bonus", "<i4"), ("flags", "<i4")])   # bwagpu_dp_case_t
 assert DP_CASE_DTYPE.itemsize == 32
 

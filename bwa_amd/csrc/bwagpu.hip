@@ -908,7 +908,7 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 	HIPCHK(h, hipSetDevice(h->device));
 	const i64 tot = h->packed_tot;
 	h->phase = 40; h->cig_ext_n = -1;
-	static_assert(sizeof(bwagpu_cigar_t) == 32, "layout");
+	static_assert(sizeof(bwagpu_cigar_t) == 48, "layout");
 	bwagpu_cigar_t *res = (bwagpu_cigar_t*)malloc((size_t)(tot ? tot : 1) * sizeof(bwagpu_cigar_t));
 	if (!res) return BWAGPU_ENOMEM;
 	if (tot) {

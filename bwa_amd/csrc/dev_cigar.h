@@ -20,9 +20,10 @@
 #define CIG_MAX_COLS 192       // widest band (columns per row)
 #define CIG_MAX_OPS 6          // operations kept per record (bwagpu_cigar_t)
 #define CIG_TMP_OPS 64
+#define CIG_MD_CAP 1024        // longest MD string kept (bytes of LDS per wave)
 
-struct CigLds { i32 *hd, *e; int8_t *qp; u8 *z; u32 *ops; int qstride, z_cells; };
-#define CIG_LDS_BYTES(zc) ((2 * (CIG_MAX_LEN + 2 + 64) * 4 + 5 * (CIG_MAX_LEN + 64) + (zc) / 2 + CIG_MAX_COLS + CIG_TMP_OPS * 4 + 15) & ~15)   // per wave
+struct CigLds { i32 *hd, *e; int8_t *qp; u8 *z; u32 *ops; u8 *md; int qstride, z_cells; };
+#define CIG_LDS_BYTES(zc) ((2 * (CIG_MAX_LEN + 2 + 64) * 4 + 5 * (CIG_MAX_LEN + 64) + (zc) / 2 + CIG_MAX_COLS + CIG_TMP_OPS * 4 + CIG_MD_CAP + 15) & ~15)   // per wave
 
 // ksw_global2 (ksw.c:540-642).  Returns the score; *n_ops < 0 when the traceback does not fit CIG_TMP_OPS.  Operations are
 // left in L.ops in traceback (reversed) order, run-length merged.
@@ -115,6 +116,49 @@ __device__ int wave_ksw_global2(const DevIndex &ix, const bwagpu_opt_t &opt, con
 	return score;
 }
 
+// NM and MD (bwa.c:196-226) of an alignment whose operations lie in ops[0 .. n_ops) in traceback (reversed) order, over the sequences as
+// the DP saw them (both reversed for a reverse-strand hit, in which case MD's letters are complemented: fwd == false).  The bases of an
+// operation are compared 64 at a time; the characters are written by lane 0 (the deleted bases of a D by their lanes).  Returns NM;
+// *md_len may exceed md_cap, in which case the string is incomplete and the caller gives the region up.
+__device__ int wave_nm_md(const DevIndex &ix, const u8 *q, int q0, int qdir, i64 t0, int tdir, bool fwd, const u32 *ops, int n_ops, u8 *md, int md_cap, int *md_len)
+{
+	const int lane = threadIdx.x & 63;
+	int x = 0, y = 0, u = 0, nm = 0, n = 0;
+	auto put = [&](int c) { if (lane == 0 && n < md_cap) md[n] = (u8)c; ++n; };
+	auto put_int = [&](int v) { int d = 1; while (d * 10 <= v) d *= 10; for (; d > 0; d /= 10) put('0' + v / d % 10); };
+	auto letter = [&](int b) -> int { return (int)(0x54474341u >> (8 * (fwd ? b : 3 - b)) & 255u); };   // "ACGT"[b], or its complement
+	for (int k = 0; k < n_ops; ++k) {
+		const u32 o = ops[n_ops - 1 - k];
+		const int op = uni((int)(o & 15u)), len = uni((int)(o >> 4));
+		if (op == 0) {
+			for (int b = 0; b < len; b += 64) {
+				const int i = b + lane; const bool in = i < len;
+				const int rb = in ? ref_base(ix, t0 + (i64)(y + i) * tdir) : 0;
+				const int qb = in ? (int)q[q0 + (x + i) * qdir] : 0;
+				u64 mm = __ballot(in && qb != rb);
+				int cur = 0;
+				while (mm) {                                  // (uniform: one turn per mismatch)
+					const int p = __builtin_ctzll(mm); mm &= mm - 1;
+					u += p - cur; put_int(u); put(letter(__builtin_amdgcn_readlane(rb, p))); u = 0; cur = p + 1; ++nm;
+				}
+				u += (len - b < 64 ? len - b : 64) - cur;
+			}
+			x += len; y += len;
+		} else if (op == 2) {
+			if (k > 0 && k < n_ops - 1) {                     // (a deletion at either end is squeezed out later and does not count, bwa.c:214)
+				put_int(u); put('^');
+				for (int i = lane; i < len; i += 64) if (n + i < md_cap) md[n + i] = (u8)letter(ref_base(ix, t0 + (i64)(y + i) * tdir));
+				n += len; u = 0; nm += len;
+			}
+			y += len;
+		} else { x += len; nm += len; }
+	}
+	put_int(u);
+	wave_sync();
+	*md_len = n;
+	return nm;
+}
+
 DEVFN int dev_infer_bw(int l1, int l2, int score, int a, int q, int r)
 {	// infer_bw (bwamem.c:818-825)
 	if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
@@ -173,14 +217,29 @@ __device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const 
 			w2 <<= 1;
 		} while (++i < 3 && score < truesc - opt.a);
 		if (defer) res_n = -2;
-		else if (!give_up && n_ops <= CIG_MAX_OPS) { res_score = score; res_n = n_ops; }
-		else if (!give_up) {   // 7 .. CIG_TMP_OPS operations: they go to the batch's operation array, the record holds their offset
+		else if (!give_up) {
+			int md_len = 0;
+			const int nm = wave_nm_md(ix, query, q0, qdir, t0, tdir, !rev, L.ops, n_ops, L.md, CIG_MD_CAP, &md_len);
+			// 7 .. CIG_TMP_OPS operations and MD strings of more than 8 characters go to the batch's operation array; the record holds their offsets
+			const int n_ext_ops = n_ops > CIG_MAX_OPS ? n_ops : 0, n_ext_md = md_len > 8 ? (md_len + 3) >> 2 : 0;
 			unsigned long long at = 0;
-			if (lane == 0) at = atomicAdd(ext_used, (unsigned long long)n_ops);
-			at = (unsigned long long)lane0_i64((i64)at);
-			if (ext && (i64)(at + n_ops) <= ext_cap) {
-				for (int k = lane; k < n_ops; k += 64) ext[at + k] = L.ops[n_ops - 1 - k];   // traceback order reversed
-				if (lane == 0) { out->score = score; out->n_cigar = n_ops; out->cigar[0] = (u32)at; out->cigar[1] = (u32)(at >> 32); for (int k = 2; k < CIG_MAX_OPS; ++k) out->cigar[k] = 0; }
+			bool fits = md_len <= CIG_MD_CAP;
+			if (fits && n_ext_ops + n_ext_md > 0) {
+				if (lane == 0) at = atomicAdd(ext_used, (unsigned long long)(n_ext_ops + n_ext_md));
+				at = (unsigned long long)lane0_i64((i64)at);
+				fits = ext && (i64)(at + n_ext_ops + n_ext_md) <= ext_cap;
+			}
+			if (fits) {
+				for (int k = lane; k < n_ext_ops; k += 64) ext[at + k] = L.ops[n_ops - 1 - k];   // traceback order reversed
+				auto md4 = [&](int w) -> u32 { u32 v = 0; for (int b = 0; b < 4; ++b) if (4 * w + b < md_len) v |= (u32)L.md[4 * w + b] << (8 * b); return v; };
+				for (int w = lane; w < n_ext_md; w += 64) ext[at + n_ext_ops + w] = md4(w);
+				if (lane == 0) {
+					out->score = score; out->n_cigar = n_ops;
+					if (n_ext_ops) { out->cigar[0] = (u32)at; out->cigar[1] = (u32)(at >> 32); for (int k = 2; k < CIG_MAX_OPS; ++k) out->cigar[k] = 0; }
+					else for (int k = 0; k < CIG_MAX_OPS; ++k) out->cigar[k] = k < n_ops ? L.ops[n_ops - 1 - k] : 0;
+					out->nm = nm; out->md_len = md_len;
+					out->md = n_ext_md ? (u64)(at + n_ext_ops) : ((u64)md4(1) << 32 | md4(0));
+				}
 				wave_sync();
 				return;
 			}
@@ -188,8 +247,8 @@ __device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const 
 		}
 	}
 	if (lane == 0) {
-		out->score = res_score; out->n_cigar = res_n;
-		for (int k = 0; k < CIG_MAX_OPS; ++k) out->cigar[k] = k < res_n ? L.ops[res_n - 1 - k] : 0;   // traceback order reversed
+		out->score = res_score; out->n_cigar = res_n; out->nm = -1; out->md_len = 0; out->md = 0;
+		for (int k = 0; k < CIG_MAX_OPS; ++k) out->cigar[k] = 0;
 	}
 	wave_sync();
 }
@@ -208,13 +267,14 @@ __global__ void __launch_bounds__(256) k_cigar(DevIndex ix, bwagpu_opt_t opt, Ba
 	L.qp = (int8_t*)(L.e + (CIG_MAX_LEN + 2 + 64));
 	L.z = (u8*)(L.qp + 5 * L.qstride);
 	L.ops = (u32*)(L.z + z_cells / 2 + CIG_MAX_COLS);
+	L.md = (u8*)(L.ops + CIG_TMP_OPS);
 	WaveQueue wq; wq_init(wq);
 	for (;;) {
 		long long g;
 		if (!wq_next(wq, next, n_regs, g)) break;
 		if (tier > 0 && uni(out[g].n_cigar) != -2) continue;
 		const bwagpu_alnreg_t p = regs[g];
-		if (p.score < opt.T) { if (lane == 0) { out[g].score = 1; out[g].n_cigar = -1; for (int k = 0; k < CIG_MAX_OPS; ++k) out[g].cigar[k] = 0; } continue; }
+		if (p.score < opt.T) { if (lane == 0) { out[g].score = 1; out[g].n_cigar = -1; out[g].nm = -1; out[g].md_len = 0; out[g].md = 0; for (int k = 0; k < CIG_MAX_OPS; ++k) out[g].cigar[k] = 0; } continue; }
 		const int r = reg_read[g];
 		cigar_region(ix, opt, B.seq + B.off[r], p, L, out + g, ext, ext_used, ext_cap);
 		if (tier > 0 && lane == 0 && out[g].n_cigar == -2) out[g].n_cigar = -1;

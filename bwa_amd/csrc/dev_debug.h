@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(64) k_debug_global(DevIndex ix, bwagpu_opt_t o
 	L.qp = (int8_t*)(L.e + (CIG_MAX_LEN + 2 + 64));
 	L.z = (u8*)(L.qp + 5 * L.qstride);
 	L.ops = (u32*)(L.z + CIG_Z_BIG / 2 + CIG_MAX_COLS);
+	L.md = (u8*)(L.ops + CIG_TMP_OPS);
 	for (int k = blockIdx.x; k < n_cases; k += gridDim.x) {
 		const bwagpu_dp_case_t c = cases[k];
 		const u8 *q = seqs + c.q_off;

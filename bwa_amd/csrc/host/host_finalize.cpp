@@ -215,7 +215,7 @@ static const bwagpu_cigar_t *find_hint(const CigHints *h, const bwagpu_alnreg_t 
 	for (int k = 0; k < h->n; ++k) {
 		const bwagpu_alnreg_t &r = h->regs[k];
 		if (r.rb == a.rb && r.re == a.re && r.qb == a.qb && r.qe == a.qe && r.truesc == a.truesc && r.w == a.w)
-			return h->cigs[k].n_cigar >= 0 && (h->cigs[k].n_cigar <= 6 || h->ops) ? &h->cigs[k] : nullptr;
+			return h->cigs[k].n_cigar >= 0 && ((h->cigs[k].n_cigar <= 6 && h->cigs[k].md_len <= 8) || h->ops) ? &h->cigs[k] : nullptr;
 	}
 	return nullptr;
 }
@@ -224,7 +224,7 @@ static const bwagpu_cigar_t *find_hint(const CigHints *h, const bwagpu_alnreg_t 
 // they also let the CPU suite exercise the hint path on thousands of reads).
 void host_region_cigar(const bwagpu_opt_t &opt, const RefSeqs &ref, const uint8_t *query, const bwagpu_alnreg_t &ar, bwagpu_cigar_t *out, std::vector<uint32_t> *ext)
 {
-	out->score = 2; out->n_cigar = -1; for (int k = 0; k < 6; ++k) out->cigar[k] = 0;
+	out->score = 2; out->n_cigar = -1; out->nm = -1; out->md_len = 0; out->md = 0; for (int k = 0; k < 6; ++k) out->cigar[k] = 0;
 	if (ar.score < opt.T) { out->score = 1; return; }
 	const int qb = ar.qb, qe = ar.qe; const int64_t rb = ar.rb, re = ar.re;
 	if (qe - qb <= 0 || rb >= re || (rb < ref.l_pac && re > ref.l_pac)) return;
@@ -241,15 +241,21 @@ void host_region_cigar(const bwagpu_opt_t &opt, const RefSeqs &ref, const uint8_
 		last_sc = score;
 		w2 <<= 1;
 	} while (++i < 3 && score < ar.truesc - opt.a);
-	if (cigar.size() > 6) {   // 7..64 operations go to the operation array, like the device's records
-		if (!ext || cigar.size() > 64) { out->score = 3; return; }
+	// MD strings of more than 8 characters and 7..64 operations go to the operation array, like the device's records (operations first)
+	const bool ext_ops = cigar.size() > 6, ext_md = md.size() > 8;
+	if ((ext_ops || ext_md) && !ext) { out->score = 3; return; }
+	if (cigar.size() > 64 || md.size() > 1024) { out->score = 3; return; }
+	auto md4 = [&](size_t w) { uint32_t v = 0; for (size_t b = 0; b < 4; ++b) if (4 * w + b < md.size()) v |= (uint32_t)(unsigned char)md[4 * w + b] << (8 * b); return v; };
+	out->score = score; out->n_cigar = (int)cigar.size(); out->nm = NM; out->md_len = (int)md.size();
+	if (ext_ops) {
 		const uint64_t at = ext->size();
 		ext->insert(ext->end(), cigar.begin(), cigar.end());
-		out->score = score; out->n_cigar = (int)cigar.size(); out->cigar[0] = (uint32_t)at; out->cigar[1] = (uint32_t)(at >> 32);
-		return;
-	}
-	out->score = score; out->n_cigar = (int)cigar.size();
-	for (size_t k = 0; k < cigar.size(); ++k) out->cigar[k] = cigar[k];
+		out->cigar[0] = (uint32_t)at; out->cigar[1] = (uint32_t)(at >> 32);
+	} else for (size_t k = 0; k < cigar.size(); ++k) out->cigar[k] = cigar[k];
+	if (ext_md) {
+		out->md = ext->size();
+		for (size_t w = 0; w < (md.size() + 3) / 4; ++w) ext->push_back(md4(w));
+	} else out->md = (uint64_t)md4(1) << 32 | md4(0);
 }
 
 Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint8_t *query, const bwagpu_alnreg_t *ar, const CigHints *hints)
@@ -264,14 +270,12 @@ Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint
 	int w2 = infer_bw(qe - qb, (int)(re - rb), ar->truesc, opt.a, opt.o_ins, opt.e_ins);
 	w2 = w2 > tmp ? w2 : tmp;
 	if (w2 > opt.w) w2 = w2 < ar->w ? w2 : ar->w;
-	if (const bwagpu_cigar_t *pc = find_hint(hints, *ar)) {   // the loop below already ran on the device: only NM/MD are left
+	if (const bwagpu_cigar_t *pc = find_hint(hints, *ar)) {   // the loop below already ran on the device, NM and MD (bwa.c:196-226) included
 		if (pc->n_cigar <= 6) a.cigar.assign(pc->cigar, pc->cigar + pc->n_cigar);
 		else { const uint32_t *o = hints->ops + ((uint64_t)pc->cigar[1] << 32 | pc->cigar[0]); a.cigar.assign(o, o + pc->n_cigar); }
-		thread_local std::vector<uint8_t> rseq, qs;
-		qs.assign(query + qb, query + qe);
-		ref.get_seq(rb, re, rseq);
-		if (rb >= ref.l_pac) { std::reverse(qs.begin(), qs.end()); std::reverse(rseq.begin(), rseq.end()); }
-		nm_md(rb < ref.l_pac, qs.data(), rseq.data(), a.cigar, &NM, a.md);
+		NM = pc->nm;
+		if (pc->md_len <= 8) { char b[8]; memcpy(b, &pc->md, 8); a.md.assign(b, (size_t)pc->md_len); }
+		else a.md.assign((const char*)(hints->ops + pc->md), (size_t)pc->md_len);      // (four characters per entry, first in the low byte: the bytes in order on this little-endian host)
 	} else do {
 		w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
 		gen_cigar2(opt, ref, w2, qe - qb, query + qb, rb, re, &score, a.cigar, &NM, a.md);

@@ -302,9 +302,10 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 			if (have_cigs && s.tot) {   // (a shard without regions has no records); offsets into the operation array move with the shard's part of it
 				memcpy(u.cigs + k, s.cigs, (size_t)s.tot * sizeof(bwagpu_cigar_t));
 				if (s.n_ops) memcpy(u.cig_ops + ko, s.ops, (size_t)s.n_ops * 4);
-				if (ko) for (int64_t i = 0; i < s.tot; ++i) if (u.cigs[k + i].n_cigar > 6) {
-					const uint64_t at = ((uint64_t)u.cigs[k + i].cigar[1] << 32 | u.cigs[k + i].cigar[0]) + (uint64_t)ko;
-					u.cigs[k + i].cigar[0] = (uint32_t)at; u.cigs[k + i].cigar[1] = (uint32_t)(at >> 32);
+				if (ko) for (int64_t i = 0; i < s.tot; ++i) {
+					bwagpu_cigar_t &c = u.cigs[k + i];
+					if (c.n_cigar > 6) { const uint64_t at = ((uint64_t)c.cigar[1] << 32 | c.cigar[0]) + (uint64_t)ko; c.cigar[0] = (uint32_t)at; c.cigar[1] = (uint32_t)(at >> 32); }
+					if (c.n_cigar >= 0 && c.md_len > 8) c.md += (uint64_t)ko;
 				}
 			}
 			k += s.tot; ko += s.n_ops;

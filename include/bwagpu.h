@@ -98,15 +98,20 @@ typedef struct {
 } bwagpu_alnreg_t;
 
 /* Banded global alignment of one region as mem_reg2aln's band-doubling loop around bwa_gen_cigar2 leaves it
- * (bwamem.c:1143-1152, bwa.c:148-195): score and BAM-style CIGAR (len << 4 | op, op M=0 I=1 D=2) before clipping and before
- * the leading/trailing-deletion squeeze.  n_cigar 1..6: the operations are in cigar[]; n_cigar 7..64: they are entries
- * [at, at + n_cigar) of the batch's operation array (bwagpu_batch_cigar_ops), at = cigar[1] << 32 | cigar[0].
- * n_cigar == -1: not computed on the device (region below opt->T, outside the kernel's limits, or more than 64
- * operations; `score` then holds the reason 1/2/3) -- the caller runs bwa_gen_cigar2 itself. */
+ * (bwamem.c:1143-1152, bwa.c:148-234): score, BAM-style CIGAR (len << 4 | op, op M=0 I=1 D=2) before clipping and before
+ * the leading/trailing-deletion squeeze, and the NM / MD values computed from it (bwa.c:196-226).  n_cigar 1..6: the operations are
+ * in cigar[]; n_cigar 7..64: they are entries [at, at + n_cigar) of the batch's operation array (bwagpu_batch_cigar_ops),
+ * at = cigar[1] << 32 | cigar[0].  MD: md_len characters; up to 8 of them are the bytes of `md` (first character in the low byte),
+ * longer strings are packed four to an entry (first character in the low byte) at entries [md, md + (md_len + 3) / 4) of the
+ * operation array.  n_cigar == -1: not computed on the device (region below opt->T, outside the kernel's limits, or more than
+ * 64 operations; `score` then holds the reason 1/2/3, nm is -1) -- the caller runs bwa_gen_cigar2 itself. */
 typedef struct {
 	int32_t score;
 	int32_t n_cigar;
 	uint32_t cigar[6];
+	int32_t nm;
+	int32_t md_len;
+	uint64_t md;
 } bwagpu_cigar_t;
 
 /* Insert-size window of one orientation as mem_matesw uses it: mem_pestat_t::low/high/failed (bwamem.h:108-112). */

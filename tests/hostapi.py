@@ -68,7 +68,7 @@ class HostFinalize:
         from bwa_amd.api import CIGAR_DTYPE
         regs = np.ascontiguousarray(regs); counts = np.ascontiguousarray(counts, dtype=np.int32); seqs_nt4 = np.ascontiguousarray(seqs_nt4, dtype=np.uint8)
         out = np.zeros(regs.shape[0], dtype=CIGAR_DTYPE)
-        cap = 64 * regs.shape[0] + 64
+        cap = 330 * regs.shape[0] + 64
         ops = np.zeros(cap, dtype=np.uint32) if with_ops else None
         n = lib().bwamem_host_region_cigars(self.h, C.byref(opt), off.shape[0] - 1, seqs_nt4.ctypes.data, off.ctypes.data, counts.ctypes.data, regs.ctypes.data, out.ctypes.data,
                                             ops.ctypes.data if with_ops else None, cap)
@@ -100,9 +100,10 @@ class HostFinalize:
 
 
 def decode_cigars(cigs, ops):
-    """bwagpu_cigar_t records as [(score, n_cigar, (op, ...))]: records with more than 6 operations are looked up in the operation
-    array, whose order differs between producers (the device appends in the order its waves finish)."""
+    """bwagpu_cigar_t records as [(score, n_cigar, (op, ...), nm, md)]: records with more than 6 operations or an MD string of more than 8
+    characters are looked up in the operation array, whose order differs between producers (the device appends in the order its waves finish)."""
     out = []
+    raw = ops.tobytes() if ops is not None else b""
     for c in cigs:
         n = int(c["n_cigar"])
         if n > 6:
@@ -111,5 +112,14 @@ def decode_cigars(cigs, ops):
             body = tuple(int(x) for x in ops[at:at + n])
         else:
             body = tuple(int(x) for x in c["cigar"][:max(n, 0)])
-        out.append((int(c["score"]), n, body))
+        ml = int(c["md_len"])
+        if n < 0:
+            md = b""
+        elif ml <= 8:
+            md = int(c["md"]).to_bytes(8, "little")[:ml]
+        else:
+            at = int(c["md"])
+            assert at * 4 + ml <= len(raw), (at, ml, len(raw))
+            md = raw[at * 4: at * 4 + ml]
+        out.append((int(c["score"]), n, body, int(c["nm"]), md))
     return out

@@ -241,9 +241,10 @@ def test_device_cigars_match_the_reference_sam(medium):
         assert cigs.shape[0] == regs.shape[0]
         hc, hops = host.region_cigars(opt, seqs, off, counts, regs, with_ops=True)
         assert (cigs["score"] == hc["score"]).all() and (cigs["n_cigar"] == hc["n_cigar"]).all() and ops.shape[0] == hops.shape[0]
-        few = cigs["n_cigar"] <= 6
+        assert (cigs["nm"] == hc["nm"]).all() and (cigs["md_len"] == hc["md_len"]).all()
+        few = (cigs["n_cigar"] <= 6) & (cigs["md_len"] <= 8)
         assert cigs[few].tobytes() == hc[few].tobytes(), "device records differ from the host's"
-        assert hostapi.decode_cigars(cigs[~few], ops) == hostapi.decode_cigars(hc[~few], hops), "device operation arrays differ from the host's"
+        assert hostapi.decode_cigars(cigs[~few], ops) == hostapi.decode_cigars(hc[~few], hops), "device operation arrays (CIGARs, MD strings) differ from the host's"
         want = ref.process_seqs(opt, names, ascii_[seqs].tobytes(), quals, off)
         got = host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs, cig_ops=ops)
         if got != want:

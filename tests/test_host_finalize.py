@@ -136,9 +136,13 @@ def test_cigar_hints_do_not_change_the_sam(pair):
         quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
         want = ref.process_seqs(opt, names, ASCII[seqs].tobytes(), quals, off)
         counts, regs = ref.align(opt, seqs, off)
-        cigs = host.region_cigars(opt, seqs, off, counts, regs)
+        cigs, ops = host.region_cigars(opt, seqs, off, counts, regs, with_ops=True)
         assert (cigs["n_cigar"][regs["score"] >= opt.T] >= 0).mean() > 0.8
-        assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs) == want
+        assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs, cig_ops=ops) == want
+        # without the operation array only records that are complete in themselves (at most 6 operations, MD of at most 8 characters) are usable
+        few = host.region_cigars(opt, seqs, off, counts, regs)
+        assert 0.05 < (few["n_cigar"][regs["score"] >= opt.T] >= 0).mean() < 0.8
+        assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=few) == want
 
 
 def _noisy_mate_pairs(g, n_pairs, seed):
@@ -167,8 +171,8 @@ def test_matesw_hints_do_not_change_the_sam(pair):
     recs = host.matesw_records(opt, seqs, off, counts, regs, pes)
     assert (recs["r"] >= 0).sum() > 300, "too few rescue alignments to mean anything"
     assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, msw=recs) == want
-    cigs = host.region_cigars(opt, seqs, off, counts, regs)
-    assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs, msw=recs) == want
+    cigs, ops = host.region_cigars(opt, seqs, off, counts, regs, with_ops=True)
+    assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs, msw=recs, cig_ops=ops) == want
 
 
 def test_ksw_align2_fuzz():
