@@ -188,13 +188,16 @@ __global__ void __launch_bounds__(256) k_occ32_blocks(DevIndex ix, const u64 *sb
 		out[j * 2 + 1] = ix.bwt[(j >> 1) * 4 + 2 + (j & 1)];
 	}
 }
-// BWAGPU_OCC32=1 (A/B measurements): the seeding and SA kernels read this second layout, built from the resident reference-format blocks.
-// It was the answer to "32-byte requests come 1.6 times as fast as 64-byte ones" (profiles/r02_experiments.md) until tools/randbw3.hip showed
-// that the 64-byte blocks themselves come 2.2 times as fast when a quad fetches them together -- which is what the seeding kernels now do.
+// The seeding and SA kernels read this layout (default; BWAGPU_OCC32=0 keeps them on the reference-format blocks): built from the resident
+// reference-format blocks, which stay the interchange format (files, index broadcast, bwagpu_index_buffers).  Measured at 3.1 Gbp
+// (profiles/r03_seed_variants.md): k_seed 94.6 ms on the 64-byte blocks, 84.6 ms on these -- and 134.5 ms with the 64-byte blocks fetched
+// quad-cooperatively (BWAGPU_SEED_COOP=1), although that fetch pattern moves the chip's random-block ceiling from 22.9e9 to 51.3e9 per second
+// (tools/randbw3.hip): the kernel asks for 14.6e9 blocks per second, it is bound by its ~1000 vector instructions per wave iteration and by the
+// latency of the dependent chain at 4 waves per SIMD, and the cooperative form adds instructions and registers (3 waves per SIMD) to both.
 static int build_occ32(bwagpu_t *h)
 {
 	h->ix.occ32 = nullptr; h->ix.occ_sb = nullptr; h->ix.occ_sb_shift = 32;
-	if (!(getenv("BWAGPU_OCC32") && atoi(getenv("BWAGPU_OCC32")) != 0) || h->bwt_blocks == 0) return 0;
+	if ((getenv("BWAGPU_OCC32") && atoi(getenv("BWAGPU_OCC32")) == 0) || h->bwt_blocks == 0) return 0;   // (BWAGPU_OCC32=0: keep to the reference-format blocks)
 	int shift = getenv("BWAGPU_OCC32_SB_SHIFT") ? atoi(getenv("BWAGPU_OCC32_SB_SHIFT")) : 32;      // (tests: small superblocks on small genomes)
 	if (shift < 8) shift = 8; if (shift > 32) shift = 32;
 	const int sh = shift - 6;
@@ -670,8 +673,8 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.rd_words = h->rd_words; B.seq_2b = h->d_seq_2b.as<u32>(); B.seq_flags = h->d_seq_flags.as<u8>();
 		// LDS per lane: 160 bytes at four blocks per CU -- the read's 2-bit copy first, interval-stack entries with the rest
 		// (three blocks per CU -- the register allocation of the cooperative seeding kernel for 3 waves per SIMD, BWAGPU_SEED_OCC=3 -- leave each lane 208 bytes)
-		const int seed_occ = getenv("BWAGPU_SEED_OCC") ? atoi(getenv("BWAGPU_SEED_OCC")) : 4;
-		const int lane_lds = seed_occ == 3 && h->ix.occ32 == nullptr && !(getenv("BWAGPU_SEED_COOP") && atoi(getenv("BWAGPU_SEED_COOP")) == 0) ? 208 : 160, ent_max = lane_lds == 208 ? 13 : SEED_LDS_ENT;
+		const int seed_occ = getenv("BWAGPU_SEED_OCC") ? atoi(getenv("BWAGPU_SEED_OCC")) : 3;
+		const int lane_lds = seed_occ == 3 && h->ix.occ32 == nullptr && getenv("BWAGPU_SEED_COOP") && atoi(getenv("BWAGPU_SEED_COOP")) != 0 ? 208 : 160, ent_max = lane_lds == 208 ? 13 : SEED_LDS_ENT;
 		const int lds_ent_dflt = h->rd_words ? ((lane_lds - 4 * h->rd_words) / 16 < ent_max ? (lane_lds - 4 * h->rd_words) / 16 : ent_max) : ent_max;
 		B.seed_lds_ent = (h->seq_len < ((u64)1 << 37) && h->max_len < 65536) ? (getenv("BWAGPU_SEED_LDS_ENT") ? atoi(getenv("BWAGPU_SEED_LDS_ENT")) : lds_ent_dflt) : 0;
 		if (((size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * 16 + (size_t)B.rd_words * 4) * BLOCK > 65536) B.rd_words = 0;   // (an LDS_ENT override too large for both)
@@ -687,7 +690,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>(); B.chain_todo = h->d_chain_todo.as<i32>(); B.chain_todo2 = B.chain_todo + n + 4; B.seed_w = h->d_seed_w.as<i32>(); B.seed_order = nullptr;
 		B.seed_prio = !(getenv("BWAGPU_SEED_PRIO") && atoi(getenv("BWAGPU_SEED_PRIO")) == 0);
 		B.seed_no_virt = getenv("BWAGPU_SEED_NO_VIRT") && atoi(getenv("BWAGPU_SEED_NO_VIRT")) != 0;
-		B.seed_coop = h->ix.occ32 == nullptr && !(getenv("BWAGPU_SEED_COOP") && atoi(getenv("BWAGPU_SEED_COOP")) == 0);
+		B.seed_coop = h->ix.occ32 == nullptr && getenv("BWAGPU_SEED_COOP") && atoi(getenv("BWAGPU_SEED_COOP")) != 0;   // (opt-in: a measured loss, see build_occ32)
 		B.seed_pass3_inline = getenv("BWAGPU_SEED_PASS3_INLINE") && atoi(getenv("BWAGPU_SEED_PASS3_INLINE")) != 0;
 		B.chain_lds_off = getenv("BWAGPU_CHAIN_LDS") && atoi(getenv("BWAGPU_CHAIN_LDS")) == 0;
 		dim3 grid(n_threads / BLOCK), block(BLOCK);

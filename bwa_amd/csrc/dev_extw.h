@@ -163,10 +163,49 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 	int lim = trunc_div_add(qlen * mat_max + end_bonus - o_ins, e_ins, 1); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	lim = trunc_div_add(qlen * mat_max + end_bonus - o_del, e_del, 1); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	w = uni(w);
-	int beg = 0, end = qlen, max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, treg = 0;
 	u32 cells32 = 0;
+	int beg = 0, end = qlen, max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, treg = 0;
 	const bool two_col_ok = h0 + qlen * mat_max < (1 << 23);      // (score << 7 | column) must fit the scan's 31 bits
 	const int lane_e = lane * e_ins;
+	// Deferred bookkeeping of the single-pass rows.  What a row contributes to the running maximum (ksw.c:491-493), to the z-drop test
+	// (:494-500) and to the to-end score (:486-489) are three numbers -- its maximum m, that maximum's column mj, and H(i, end-1) when the
+	// band touches the query's end -- and none of them steers the next row (the band's trimming does, and stays in the row).  Kept per row in
+	// scalar registers this bookkeeping was ~45 of a row's ~90 scalar instructions, and the kernel is bound by exactly those (one scalar
+	// issue slot per SIMD every four cycles).  So a row only parks its three numbers in lane `hist_n` of three vector registers, and every
+	// 32 rows -- or when the extension ends, or before a row of another form -- the parked rows are evaluated together, one lane per row:
+	// prefix maxima give every row the (max, max_i, max_j) it would have seen, the first z-drop hit ends the extension there (the rows computed
+	// past it are simply not counted; the next call re-initialises the columns they wrote), and the survivors update the state.
+	int hist_m = 0, hist_j = 0, hist_h1 = 0, hist_n = 0, hist_row0 = 0;
+	auto hist_flush = [&]() -> bool {       // returns true when a parked row ended the extension by z-drop
+		const int cnt = hist_n;
+		if (cnt == 0) return false;
+		const bool val = lane < cnt;
+		const int r = hist_row0 + lane;
+		const int pm = imax(wave_shift_up1(wave_incl_scan_max(val ? hist_m : I32_MIN), I32_MIN), max);     // the maximum before row r
+		const bool imp = val && hist_m > pm;                                                           // row r raises it
+		const int lk = wave_shift_up1(wave_incl_scan_max(imp ? ((lane + 1) << 16 | hist_j) : 0), 0);  // the latest raising row before r (0: none among the parked ones)
+		bool zb = false;
+		if (zdrop > 0 && val && !imp) {
+			const int pmi = lk ? hist_row0 + (lk >> 16) - 1 : max_i, pmj = lk ? (lk & 0xffff) : max_j;
+			const int di = r - pmi, dj = hist_j - pmj;
+			zb = di > dj ? pm - hist_m - (di - dj) * e_del > zdrop : pm - hist_m - (dj - di) * e_ins > zdrop;
+		}
+		const u64 zm = __ballot(zb);
+		const int last = zm ? __builtin_ctzll(zm) : cnt - 1;                 // the last row that counts
+		const bool use = lane <= last;
+		const u64 im = __ballot(imp && use);
+		if (im) {
+			const int l = 63 - __builtin_clzll(im);                          // the raises are strictly increasing: the last one holds the maximum
+			max = __builtin_amdgcn_readlane(hist_m, l); max_i = hist_row0 + l; max_j = __builtin_amdgcn_readlane(hist_j, l);
+			int off = hist_j - r; off = off < 0 ? -off : off;
+			const int mo = __builtin_amdgcn_readlane(wave_incl_scan_max(imp && use ? off : 0), 63);
+			max_off = mo > max_off ? mo : max_off;
+		}
+		const int g = __builtin_amdgcn_readlane(wave_incl_scan_max(use && hist_h1 >= 0 ? (hist_h1 << 6 | lane) : -1), 63);   // the best to-end score, latest row on ties
+		if (g >= 0 && (g >> 6) >= gscore) { max_ie = hist_row0 + (g & 63); gscore = g >> 6; }
+		hist_row0 += cnt; hist_n = 0;
+		return zm != 0;
+	};
 	for (int i = 0; i < tlen; ++i) {
 		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
 		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
@@ -216,33 +255,22 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			if (wr) eh[j] = make_int2(hleft, e_new);
 			const u64 nzm = __ballot(wr && (hleft | e_new) != 0);
 			const int key = __builtin_amdgcn_readlane(kmax, 63);
-			const int h1l = __builtin_amdgcn_readlane(h, nact > 0 ? nact - 1 : 0);
 			wave_sync();
-			// The row's bookkeeping as straight-line scalar selects with ONE exit test at the end of the loop body: written with breaks and
-			// a continue, the structurizer turned it into a state machine of ~75 scalar instructions per row.
-			{
-				const bool fin = (nact > 0 ? end : beg) == qlen;       // ksw.c:486-489
-				const int h1 = nact > 0 ? h1l : h1_init;              // H(i, end-1) as left in h1 by the reference's column loop
-				max_ie = (fin && h1 >= gscore) ? i : max_ie;
-				gscore = (fin && h1 > gscore) ? h1 : gscore;
-			}
-			const int m = key >> 6, mj = beg + (key & 63);
-			stop = key < 64;                                  // m == 0 (ksw.c:490); then m <= 0 < max and nothing below changes the results
-			const bool better = m > max;                      // ksw.c:491-493
-			int off = mj - i; off = off < 0 ? -off : off;
-			max_off = (better && off > max_off) ? off : max_off;
-			if (!better && zdrop > 0 && max - m > zdrop) {    // ksw.c:494-500 (the drop alone must exceed zdrop before the gap term can matter)
-				const int di = i - max_i, dj = mj - max_j;
-				stop = stop || (di > dj ? max - m - (di - dj) * e_del > zdrop : max - m - (dj - di) * e_ins > zdrop);
-			}
-			max_i = better ? i : max_i; max_j = better ? mj : max_j; max = better ? m : max;
+			int h1 = -1;                                      // H(i, end-1) as left in h1 by the reference's column loop, when it feeds the to-end score (ksw.c:486-489)
+			if ((nact > 0 ? end : beg) == qlen) h1 = nact > 0 ? __builtin_amdgcn_readlane(h, nact - 1) : h1_init;
+			stop = key < 64;                                  // m == 0 (ksw.c:490)
+			{ const bool mine = lane == hist_n; hist_m = mine ? key >> 6 : hist_m; hist_j = mine ? beg + (key & 63) : hist_j; hist_h1 = mine ? h1 : hist_h1; }
+			++hist_n;
 			// band for the next row (ksw.c:502-505): skip leading / trailing columns whose {h,e} are both zero
 			const u64 nz_lo = nzm & ((1ull << (nact & 63)) - 1);
 			const int nbeg = nz_lo ? beg + __builtin_ctzll(nz_lo) : end;
 			const int jl = nzm ? beg + 63 - __builtin_clzll(nzm) : nbeg - 1;
 			beg = nbeg;
 			end = jl + 2 < qlen ? jl + 2 : qlen;
+			if (hist_n == 32 || stop) stop = hist_flush() || stop;
 		} else {
+		if (hist_flush()) break;                         // (rows of the other forms keep their bookkeeping per row: bring the state up to date first)
+		hist_row0 = i + 1;
 		int m = 0, mj = -1, carry = W_NEG, hprev = h1_init, first_nz = -1, last_nz = -1, bnd = 0;
 		if (!RING && end - beg <= 128 && two_col_ok) {
 			// 65..128 columns (the longer half of a 150 bp read's extensions): each lane owns two adjacent columns, so the row still takes ONE
@@ -337,6 +365,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		}
 		if (stop) break;
 	}
+	hist_flush();
 	#undef EHI
 	#undef SCORE_AT
 	cells += cells32;

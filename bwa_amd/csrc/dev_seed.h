@@ -274,8 +274,9 @@ __global__ void __launch_bounds__(256) k_publish(bwagpu_opt_t opt, Batch B)
 }
 
 // RD: the batch's reads are short enough for an LDS copy (Batch::rd_words > 0)
-// BLK: how the extension reads the index -- 2 (default): the reference-format 64-byte blocks, fetched quad-cooperatively (fm_occ_coop);
-//      0: the same blocks, each lane fetching its own (A/B measurements); 1: the 32-byte layout (DevIndex::occ32, BWAGPU_OCC32=1), per lane.
+// BLK: how the extension reads the index -- 1 (default): the 32-byte layout (DevIndex::occ32), each lane fetching its own blocks; 0: the
+//      reference-format 64-byte blocks, per lane (BWAGPU_OCC32=0); 2: those blocks fetched quad-cooperatively (fm_occ_coop; BWAGPU_OCC32=0
+//      BWAGPU_SEED_COOP=1 -- a measured loss at this kernel's instruction count, kept for the day that count has come down).
 //      A compile-time choice, so that no path pays for another's registers.
 // OCC: waves per SIMD the register allocation aims at (the cooperative form holds more live values: 4 spills a little, 3 does not)
 template<bool RD, bool STATS, int BLK, int OCC>

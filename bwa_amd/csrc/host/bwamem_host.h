@@ -75,7 +75,7 @@ void host_region_cigar(const bwagpu_opt_t &opt, const RefSeqs &ref, const uint8_
 Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint8_t *query, const bwagpu_alnreg_t *ar, const CigHints *hints = nullptr);   // bwamem.c:1119-1189
 void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, const Read &s, const std::vector<Aln> &list, int which, const Aln *mate, const char *rg_id);   // bwamem.c:851-976
 void reg2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, const Read &s, Regs &a, int extra_flag, const Aln *mate, const char *rg_id);   // bwamem.c:1033-1079
-void pestat_flat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const bwagpu_alnreg_t *all, const int64_t *roff, Pestat pes[4], bool verbose);
+void pestat_flat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const bwagpu_alnreg_t *all, const int64_t *roff, Pestat pes[4], bool verbose, int n_threads = 1);
 void attach_matesw(int n, Read *reads, const bwagpu_matesw_t *recs, int64_t n_recs, std::vector<bwagpu_matesw_t> &sorted);
 int64_t host_matesw_records(const bwagpu_opt_t &opt, const RefSeqs &ref, int n, const uint8_t *seqs, const int64_t *off, const bwagpu_alnreg_t *all, const int64_t *roff,
 							const Pestat pes[4], bwagpu_matesw_t *out, int64_t cap);   // == bwagpu_batch_matesw, on the host   // bwamem_pair.c:72-135

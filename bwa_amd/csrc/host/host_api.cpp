@@ -20,7 +20,7 @@ void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_proce
 	sam.assign(n, std::string());
 	if (opt.flag & F_PE) {
 		Pestat pes[4];
-		if (pes0) memcpy(pes, pes0, sizeof pes); else pestat_flat(opt, ref.l_pac, n, all, roff, pes, verbose);
+		if (pes0) memcpy(pes, pes0, sizeof pes); else pestat_flat(opt, ref.l_pac, n, all, roff, pes, verbose, n_threads < 4 ? n_threads : 4);
 		parallel_for(n_threads, n >> 1, [&](long i) {
 			thread_local Regs a[2];
 			a[0].assign(all + roff[i << 1], all + roff[(i << 1) + 1]); a[1].assign(all + roff[(i << 1) + 1], all + roff[(i << 1) + 2]);

@@ -43,20 +43,32 @@ template <class R> static int cal_sub(const bwagpu_opt_t &opt, const R &r)
 
 struct U64Less { bool operator()(uint64_t a, uint64_t b) const { return a < b; } };
 
-template <class Get> static void pestat_impl(const bwagpu_opt_t &opt, int64_t l_pac, int n, Get get, Pestat pes[4], bool verbose)
+// The insert sizes of a batch's uniquely placed pairs, per orientation (the filter of bwamem_pair.c:79-91).  The pairs are independent,
+// so the batch is cut into one contiguous range per thread and the ranges' lists are concatenated; everything downstream sorts the
+// lists first, so their order is immaterial.
+template <class Get> static void collect_isizes(const bwagpu_opt_t &opt, int64_t l_pac, int n_pairs, Get get, int n_threads, std::vector<uint64_t> isize[4])
+{
+	const int T = n_threads < 1 ? 1 : (n_pairs < 20000 ? 1 : (n_threads > 16 ? 16 : n_threads));
+	std::vector<std::vector<uint64_t>> part((size_t)T * 4);
+	parallel_for(T, T, [&](long t) {
+		const int lo = (int)((int64_t)n_pairs * t / T), hi = (int)((int64_t)n_pairs * (t + 1) / T);
+		for (int i = lo; i < hi; ++i) {
+			const auto r0 = get(i << 1), r1 = get(i << 1 | 1);
+			int64_t is;
+			if (r0.empty() || r1.empty() || r0[0].rid != r1[0].rid) continue;
+			if (cal_sub(opt, r0) > 0.8 * r0[0].score || cal_sub(opt, r1) > 0.8 * r1[0].score) continue;
+			const int dir = infer_dir(l_pac, r0[0].rb, r1[0].rb, &is);
+			if (is && is <= opt.max_ins) part[(size_t)t * 4 + dir].push_back((uint64_t)is);
+		}
+	});
+	for (int d = 0; d < 4; ++d) { isize[d].clear(); for (int t = 0; t < T; ++t) isize[d].insert(isize[d].end(), part[(size_t)t * 4 + d].begin(), part[(size_t)t * 4 + d].end()); }
+}
+
+template <class Get> static void pestat_impl(const bwagpu_opt_t &opt, int64_t l_pac, int n, Get get, Pestat pes[4], bool verbose, int n_threads)
 {
 	std::vector<uint64_t> isize[4];
 	memset(pes, 0, 4 * sizeof(Pestat));
-	for (int i = 0; i < n >> 1; ++i) {
-		const auto r0 = get(i << 1), r1 = get(i << 1 | 1);
-		int64_t is;
-		if (r0.empty() || r1.empty()) continue;
-		if (cal_sub(opt, r0) > 0.8 * r0[0].score) continue;
-		if (cal_sub(opt, r1) > 0.8 * r1[0].score) continue;
-		if (r0[0].rid != r1[0].rid) continue;
-		int dir = infer_dir(l_pac, r0[0].rb, r1[0].rb, &is);
-		if (is && is <= opt.max_ins) isize[dir].push_back((uint64_t)is);
-	}
+	collect_isizes(opt, l_pac, n >> 1, get, n_threads, isize);
 	if (verbose) fprintf(stderr, "[M::%s] # candidate unique pairs for (FF, FR, RF, RR): (%ld, %ld, %ld, %ld)\n", "mem_pestat", (long)isize[0].size(), (long)isize[1].size(), (long)isize[2].size(), (long)isize[3].size());
 	for (int d = 0; d < 4; ++d) {
 		Pestat *r = &pes[d];
@@ -99,9 +111,9 @@ template <class Get> static void pestat_impl(const bwagpu_opt_t &opt, int64_t l_
 }
 
 // mem_pestat on a batch's flat region array (regions of read i at all[roff[i] .. roff[i+1]))
-void pestat_flat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const bwagpu_alnreg_t *all, const int64_t *roff, Pestat pes[4], bool verbose)
+void pestat_flat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const bwagpu_alnreg_t *all, const int64_t *roff, Pestat pes[4], bool verbose, int n_threads)
 {
-	pestat_impl(opt, l_pac, n, [&](int i) { return RegSpan{all + roff[i], (size_t)(roff[i + 1] - roff[i])}; }, pes, verbose);
+	pestat_impl(opt, l_pac, n, [&](int i) { return RegSpan{all + roff[i], (size_t)(roff[i + 1] - roff[i])}; }, pes, verbose, n_threads);
 }
 
 // ---- mem_sort_dedup_patch with bns == 0: no patching, only redundancy removal and the final sort (bwamem.c:463-515) ----

@@ -317,7 +317,7 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 		else {   // mem_pestat needs the whole batch's regions (bwamem.c:1258): they have just arrived
 			std::vector<int64_t> roff((size_t)n + 1, 0);
 			for (int i = 0; i < n; ++i) roff[i + 1] = roff[i] + u.counts[i];
-			pestat_flat(u.opt, ref.l_pac, n, u.all, roff.data(), u.pes, g_verbose >= 3);
+			pestat_flat(u.opt, ref.l_pac, n, u.all, roff.data(), u.pes, g_verbose >= 3, u.opt.n_threads < 4 ? u.opt.n_threads : 4);
 		}
 		u.have_pes = true;
 		bwagpu_pes_t dp[4];

@@ -164,17 +164,17 @@ def test_dense_sa_gives_identical_results(medium):
 
 
 def test_index_access_variants_give_identical_results(medium, monkeypatch):
-    """The seeding kernels read the reference-format 64-byte blocks quad-cooperatively by default; BWAGPU_SEED_COOP=0 lets every lane fetch
-    its own blocks, BWAGPU_OCC32=1 switches seeding, SA look-ups, SA densification and the prefix tables to the 32-byte layout: same
-    regions and interval taps in every variant, with the SA at the reference's interval and densified."""
+    """Seeding, SA look-ups, SA densification and the prefix tables read the 32-byte layout of the BWT by default; BWAGPU_OCC32=0 keeps them
+    on the reference-format 64-byte blocks, BWAGPU_SEED_COOP=1 lets the seeding kernels fetch those quad-cooperatively: same regions and
+    interval taps in every variant, with the SA at the reference's interval and densified."""
     from bwa_amd.api import BwaGpu
     gpu, orc, ref, g = medium
     fa, _ = testdata.medium_index()
     seqs, off = testdata.flat(simdata.make_reads_se(g, 8000, seed=39, sub=0.02))
     base = gpu.align(default_opt(), seqs, off)
     n0, iv0 = gpu.tap_intervals()
-    assert_regs_equal(*ref.align(default_opt(), seqs, off), *base, "quad-cooperative fetch vs compiled reference")
-    for env in ({"BWAGPU_SEED_COOP": "0"}, {"BWAGPU_OCC32": "1"}, {"BWAGPU_PTAB_M": "0"}):
+    assert_regs_equal(*ref.align(default_opt(), seqs, off), *base, "32-byte blocks vs compiled reference")
+    for env in ({"BWAGPU_OCC32": "0"}, {"BWAGPU_OCC32": "0", "BWAGPU_SEED_COOP": "1"}, {"BWAGPU_OCC32": "0", "BWAGPU_SEED_COOP": "1", "BWAGPU_SEED_OCC": "4"}, {"BWAGPU_PTAB_M": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         g2 = BwaGpu(fa)

@@ -104,14 +104,14 @@ def _n_rich_reads(g, n, max_len, seed):
 
 
 @pytest.mark.parametrize("max_len,env", [(150, {}), (250, {}), (120, {"BWAGPU_SEED_NO_VIRT": "1"}), (150, {"BWAGPU_SEED_RD_LDS": "0"}),
-                                         (150, {"BWAGPU_PTAB_M": "5", "BWAGPU_SEED_LDS_ENT": "2"}), (150, {"BWAGPU_OCC32": "1"}), (150, {"BWAGPU_OCC32": "1", "BWAGPU_PTAB_M": "0"}), (150, {"BWAGPU_PTAB_M": "0"}),
-                                         (150, {"BWAGPU_SEED_COOP": "0"}), (150, {"BWAGPU_SEED_COOP": "0", "BWAGPU_PTAB_M": "0"})])
+                                         (150, {"BWAGPU_PTAB_M": "5", "BWAGPU_SEED_LDS_ENT": "2"}), (150, {"BWAGPU_OCC32": "0"}), (150, {"BWAGPU_OCC32": "0", "BWAGPU_PTAB_M": "0"}), (150, {"BWAGPU_PTAB_M": "0"}),
+                                         (150, {"BWAGPU_OCC32": "0", "BWAGPU_SEED_COOP": "1"}), (150, {"BWAGPU_OCC32": "0", "BWAGPU_SEED_COOP": "1", "BWAGPU_PTAB_M": "0"})])
 def test_hostsim_seeding_paths_with_n_reads(monkeypatch, max_len, env):
     """The seeding kernel's read copy in LDS (2 bits per base; 8, 12 or 16 words per lane by the batch's longest read; reads with an N
     take their bases from global memory), the short stack entries kept as a bit mask (off with BWAGPU_SEED_NO_VIRT, and narrower with
-    shallow prefix tables), a two-entry LDS stack that spills almost everything, and the three ways of reading the index -- the reference-format
-    64-byte blocks fetched quad-cooperatively (the default) or by each lane for itself (BWAGPU_SEED_COOP=0), and the 32-byte layout
-    (BWAGPU_OCC32=1) -- with and without prefix tables: same regions as the oracle for ragged reads with Ns."""
+    shallow prefix tables), a two-entry LDS stack that spills almost everything, and the three ways of reading the index -- the 32-byte
+    layout (the default), the reference-format 64-byte blocks fetched by each lane for itself (BWAGPU_OCC32=0) or quad-cooperatively
+    (BWAGPU_SEED_COOP=1 on top) -- with and without prefix tables: same regions as the oracle for ragged reads with Ns."""
     prefix, g = testdata.small_index()
     for k, v in env.items():
         monkeypatch.setenv(k, v)

@@ -13,19 +13,26 @@ from bwa_amd.structs import pacbio_opt
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--genome-mbp", type=float, default=512.0)
+    ap.add_argument("--genome-mbp", type=float, default=3100.0)
     ap.add_argument("--reads", type=int, default=20000)
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--cache", default=os.environ.get("BWA_AMD_CACHE", "/tmp/bwa_amd_bench"))
     a = ap.parse_args()
     import torch
-    fa, g = bench.build_or_load_index(a.genome_mbp, a.cache, 0, lambda: torch.cuda.synchronize())
+    fa, g, _ = bench.build_or_load_index(a.genome_mbp, a.cache, 0, lambda: torch.cuda.synchronize())
     gpu = BwaGpu(fa); gpu.densify_sa(4); gpu.set_taps(False)
-    rd = simdata.make_reads_se(g, a.reads, length=a.read_len, seed=5, sub=0.04, dele=0.04, ins=0.04)
+    rd = simdata.make_reads_long(g, a.reads, length=a.read_len, seed=7)      # SURVEY 8d's PacBio-like model: 1.5 % sub, 4 % del, 9 % ins
     off = np.arange(0, a.reads + 1, dtype=np.int64) * a.read_len
     opt = pacbio_opt()
     gpu.upload(np.ascontiguousarray(rd.reshape(-1)), off)
+    gpu.set_stats(True)
     t = time.time(); gpu.run(opt); dt0 = time.time() - t
+    w = gpu.stats()
+    print(f"[longread] first pass {dt0:.2f}s (retries {w['n_retries']}); per read: intervals {w['n_intv'] / a.reads:.0f}, seeds {w['n_seeds'] / a.reads:.0f}, chains kept {w['n_chains'] / a.reads:.1f}, "
+          f"seed-SW calls {w['n_sw_calls'] / a.reads:.0f} ({w['n_sw_cells'] / a.reads / 1e6:.2f} M cells), extension calls {w['n_ext_calls'] / a.reads:.1f} ({w['n_ext_cells'] / a.reads / 1e6:.2f} M cells), "
+          f"patch alignments {w['n_glb_calls'] / a.reads:.1f} ({w['n_glb_cells'] / a.reads / 1e6:.2f} M cells), regions {w['n_regs_raw'] / a.reads:.1f} -> {w['n_regs'] / a.reads:.1f}; "
+          "stage ms: " + ", ".join(f"{k[3:]} {w[k]:.0f}" for k in ("ms_seed", "ms_sa", "ms_chain", "ms_seedsw", "ms_extend", "ms_dedup")), flush=True)
+    gpu.set_stats(False)
     t = time.time(); gpu.run(opt); dt = time.time() - t
     st = gpu.stats()
     counts, regs = gpu.download()
