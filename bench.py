@@ -135,7 +135,7 @@ def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: 
     devices: device ids for BWAGPU_DEVICES (every batch is split over them), None = device 0."""
     cli = os.path.join(ROOT, "bwa_amd", "bwa-amd")
     cmd = [cli, "mem", "-t", str(threads), "-K", str(K), "-v", "3"] + list(extra) + (["-o", out_sam] if out_sam else []) + [prefix] + list(files)
-    env = dict(os.environ)
+    env = dict(os.environ, BWAGPU_CLI_TRACE="1")      # (per-batch timings of the device stage on stderr, averaged below)
     if streams:
         env["BWAGPU_CLI_STREAMS"] = str(streams)
     if devices and len(devices) > 1:
@@ -159,7 +159,16 @@ def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: 
         for name, sec in re.findall(r"([a-z+]+) ([\d.]+) s", busy.group(1)):
             stage_us[name] = round(float(sec) / n_reads * 1e6, 3)
     hm = re.search(r"over (\d+) handles", p.stderr)
-    return {"reads_per_s": float(m.group(3)), "n": n_reads, "wall_s": wall, "stages": busy.group(1) if busy else "", "stage_us_per_read": stage_us, "handles": int(hm.group(1)) if hm else None,
+    dev = re.findall(r"\[D::device_sub\] (\d+) reads .*: upload ([\d.]+) run ([\d.]+) download\+cigars ([\d.]+) pestat\+matesw ([\d.]+) s \(pestat ([\d.]+), (\d+) mate", p.stderr)
+    dev_ms = {}
+    if dev:
+        full = max(int(d[0]) for d in dev)
+        rows = [d for d in dev if int(d[0]) >= 0.9 * full] or dev       # (full-size batches: the last one is short)
+        for k_, name in enumerate(("upload", "hot_path", "download_cigars", "pestat_matesw", "pestat")):
+            dev_ms[name] = round(sum(float(d[k_ + 1]) for d in rows) / len(rows) * 1e3, 1)
+        dev_ms["matesw_alignments"] = int(sum(int(d[6]) for d in rows) / len(rows))
+        dev_ms["reads_per_batch"] = full
+    return {"reads_per_s": float(m.group(3)), "n": n_reads, "wall_s": wall, "stages": busy.group(1) if busy else "", "stage_us_per_read": stage_us, "handles": int(hm.group(1)) if hm else None, "device_stage_ms_per_batch": dev_ms,
             "n_batches": len(re.findall(r"\[M::process\] read \d+ sequences", p.stderr))}
 
 
@@ -200,10 +209,10 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--parity-pairs", type=int, default=800_000, help="pairs of the multi-batch paired-end parity / CPU-baseline sample (eight batches)")
     ap.add_argument("--no-longread", action="store_true", help="skip the BASELINE configs[4] leg (10 kb reads, -x pacbio)")
-    ap.add_argument("--long-reads", type=int, default=4000)
+    ap.add_argument("--long-reads", type=int, default=2000)
     ap.add_argument("--long-len", type=int, default=10000)
     ap.add_argument("--long-steps", type=int, default=2)
-    ap.add_argument("--long-sample", type=int, default=400, help="reads of the long-read CPU-baseline / parity prefix")
+    ap.add_argument("--long-sample", type=int, default=128, help="reads of the long-read CPU-baseline / parity prefix")
     args = ap.parse_args()
 
     import torch
@@ -452,6 +461,7 @@ def main():
             e2e = run_product(prefix, [f1, f2], threads, None, devices=devices)
             if e2e:
                 out["end_to_end_pe"] = {"value": round(e2e["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "n_gpus": world, "stages": e2e["stages"], "stage_us_per_read": e2e["stage_us_per_read"],
+                                        "device_stage_ms_per_batch": e2e["device_stage_ms_per_batch"], "handles": e2e["handles"],
                                         "what": f"`bwa-amd mem -t {threads}` on {n_e // 2} pairs as two FASTQ files (the BASELINE metric's layout, SAM discarded; the same command's SAM is what parity.pe compares): parsing + H2D + "
                                                 f"device hot path + device CIGARs and mate-rescue alignments + D2H + mem_pestat/pairing/SAM text on the host, batches of 100 Mbp"
                                                 + (f", every batch split over devices {devices} (BWAGPU_DEVICES)" if world > 1 else "") + "; wall time after the index is loaded"}

@@ -771,9 +771,18 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_extend", hipGetErrorString(e_)); }
 		if (h->max_len > WAVE_EXT_MAX_LEN || getenv("BWAGPU_DEDUP_WAVE")) {     // long reads: few reads, long patch alignments -> one wavefront per read
-			int rc_ = 256; while (rc_ < 8 * opt->w + 4 + 128 && rc_ < 2048) rc_ <<= 1;
-			i64 nblk = ((i64)n + 3) / 4, cap = n_threads / BLOCK;   // dp_h/dp_e hold one scratch region per wave of the standard grid
-			hipLaunchKernelGGL(k_dedup_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)(8 * rc_ + 32) * 4, h->stream, h->ix, *opt, B, rc_);
+			// Ring of {H,E} columns for the patch alignments' band: 2 w + 132 columns, where w = max(min(.., 4 opt.w), |rlen - l_query| + 3) (bwa.c:180-187)
+			// and the length difference of two merged regions of a 10 kb read with 13 % indels runs to several hundred bases.  A band the ring
+			// cannot hold falls back to one lane with its columns in HBM -- 10^7 cells at one lane's pace: measured 0.6 s per call, 58 s of a
+			// 100-read batch's 59 (profiles/r03_longread_probe.md) -- so the ring is sized for 1/8 of the longest read and capped by what one
+			// wave's LDS share allows; wider rings mean fewer waves per workgroup (the dynamic LDS of a workgroup is 64 KiB).
+			int need = 8 * opt->w + 4 + 128; if (need < h->max_len / 4 + 132) need = h->max_len / 4 + 132;
+			int rc_ = 256; while (rc_ < need && rc_ < 4096) rc_ <<= 1;
+			if (getenv("BWAGPU_DEDUP_RING")) rc_ = atoi(getenv("BWAGPU_DEDUP_RING"));      // test hook: a power of two, 256..4096
+			if (rc_ < 256 || rc_ > 4096 || (rc_ & (rc_ - 1))) rc_ = 1024;
+			const int wpb = rc_ <= 1024 ? 4 : (rc_ <= 2048 ? 2 : 1);
+			i64 nblk = ((i64)n + wpb - 1) / wpb, cap = (n_threads / 64) / wpb;   // dp_h/dp_e hold one scratch region per wave of the standard grid
+			hipLaunchKernelGGL(k_dedup_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)(8 * rc_ + 32) * wpb, h->stream, h->ix, *opt, B, rc_);
 		} else
 			hipLaunchKernelGGL(k_dedup, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[6], h->stream));

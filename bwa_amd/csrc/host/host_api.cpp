@@ -39,6 +39,53 @@ void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_proce
 	}
 }
 
+// The same, delivering the batch's SAM text in input order as one string per chunk of `chunk` reads (an even number) instead of one per
+// read: the per-read strings were two allocator round trips per read, the second of them a release on the writer's thread.  A read's text
+// ends at its first NUL, as it does when the reference fputs() it (fastmap.c:116; the letter of base code 5 is a NUL).
+void finalize_batch_chunks(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_processed, int n, const Read *reads, const bwagpu_alnreg_t *all, const int64_t *roff,
+						   const Pestat *pes0, int n_threads, const char *rg_id, int chunk, std::vector<std::string> &text, bool verbose)
+{
+	if (chunk < 2) chunk = 2;
+	chunk &= ~1;
+	const long n_chunks = ((long)n + chunk - 1) / chunk;
+	text.resize((size_t)n_chunks);                    // (strings a caller hands back in keep their capacity: no fresh pages to fault in)
+	const bool pe = (opt.flag & F_PE) != 0;
+	Pestat pes[4];
+	if (pe) { if (pes0) memcpy(pes, pes0, sizeof pes); else pestat_flat(opt, ref.l_pac, n, all, roff, pes, verbose, n_threads < 4 ? n_threads : 4); }
+	auto put = [](std::string &dst, const std::string &s) { dst.append(s.data(), strnlen(s.data(), s.size())); };
+	std::atomic<long> next(0);
+	auto work = [&]() {
+		Regs a[2]; std::string out[2];
+		for (;;) {
+			const long c = next.fetch_add(1);
+			if (c >= n_chunks) break;
+			const int lo = (int)(c * chunk), hi = lo + chunk < n ? lo + chunk : n;
+			std::string &dst = text[(size_t)c];
+			dst.clear();
+			if (dst.capacity() < (size_t)(hi - lo) * 720) dst.reserve((size_t)(hi - lo) * 720);
+			if (pe) {
+				for (int i = lo; i + 1 < hi; i += 2) {
+					a[0].assign(all + roff[i], all + roff[i + 1]); a[1].assign(all + roff[i + 1], all + roff[i + 2]);
+					out[0].clear(); out[1].clear();
+					sam_pe(opt, ref, pes, (uint64_t)((n_processed + i) >> 1), &reads[i], a, out, rg_id);
+					put(dst, out[0]); put(dst, out[1]);
+				}
+			} else {
+				for (int i = lo; i < hi; ++i) {
+					a[0].assign(all + roff[i], all + roff[i + 1]);
+					mark_primary_se(opt, a[0], n_processed + i);
+					if (opt.flag & F_PRIMARY5) reorder_primary5(opt.T, a[0]);
+					out[0].clear();
+					reg2sam(opt, ref, out[0], reads[i], a[0], 0, 0, rg_id);
+					put(dst, out[0]);
+				}
+			}
+		}
+	};
+	if (n_threads <= 1 || n_chunks <= 1) work();
+	else { std::vector<std::thread> th; for (int t = 0; t < n_threads; ++t) th.emplace_back(work); for (auto &t : th) t.join(); }
+}
+
 // group bwagpu_batch_matesw records by the read they align and attach the slices to the reads
 void attach_matesw(int n, Read *reads, const bwagpu_matesw_t *recs, int64_t n_recs, std::vector<bwagpu_matesw_t> &sorted)
 {
@@ -88,7 +135,8 @@ char *bwamem_host_regs2sam(void *h, const bwagpu_opt_t *opt, int64_t n_processed
 	std::vector<std::string> sam;
 	const bool trace = getenv("BWAMEM_HOST_TRACE") != nullptr;      // diagnostics: time of the finalize stage proper
 	const auto t0 = std::chrono::steady_clock::now();
-	finalize_batch(*opt, ref, n_processed, n, reads.data(), regs, roffs.data(), pes0, n_threads, 0, sam, false);
+	if (getenv("BWAMEM_HOST_BY_READ")) finalize_batch(*opt, ref, n_processed, n, reads.data(), regs, roffs.data(), pes0, n_threads, 0, sam, false);   // (the per-read form, which the command line uses for -p batches)
+	else finalize_batch_chunks(*opt, ref, n_processed, n, reads.data(), regs, roffs.data(), pes0, n_threads, 0, 64, sam, false);
 	if (trace) fprintf(stderr, "[host] finalize_batch: %d reads, %d threads, %.3f s\n", n, n_threads, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 	size_t tot = 0;
 	for (auto &s : sam) tot += s.size();

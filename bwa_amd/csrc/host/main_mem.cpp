@@ -26,6 +26,8 @@
 namespace hostmem {
 void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_processed, int n, const Read *reads, const bwagpu_alnreg_t *all, const int64_t *roff,
 					const Pestat *pes0, int n_threads, const char *rg_id, std::vector<std::string> &sam, bool verbose);
+void finalize_batch_chunks(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_processed, int n, const Read *reads, const bwagpu_alnreg_t *all, const int64_t *roff,
+						   const Pestat *pes0, int n_threads, const char *rg_id, int chunk, std::vector<std::string> &text, bool verbose);
 }
 using namespace hostmem;
 
@@ -203,7 +205,7 @@ struct Sub {      // one mem_process_seqs call (bwamem.c:1235-1264) on the reads
 	Pestat pes[4]; bool have_pes = false;     // insert-size windows, when they had to be computed before the finalize stage
 	double t_dev = 0;
 };
-struct Work { long no = 0; Batch in; std::vector<Sub> subs; std::vector<std::string> out; };
+struct Work { long no = 0; Batch in; std::vector<Sub> subs; std::vector<std::string> out; bool by_read = false; /* SAM text in output order: one string per chunk of reads, or (by_read, smart pairing) per read */ };
 typedef std::unique_ptr<Work> WorkP;
 
 struct Chan {     // bounded FIFO between two stages
@@ -312,6 +314,7 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 			bwagpu_free(s.all); s.all = nullptr; bwagpu_free(s.cigs); s.cigs = nullptr; bwagpu_free(s.ops); s.ops = nullptr;
 		}
 	}
+	double t_pes = 0;
 	if (g_device_matesw && pe && !(u.opt.flag & F_NO_RESCUE) && u.tot > 0) {
 		if (pes0) memcpy(u.pes, pes0, sizeof u.pes);
 		else {   // mem_pestat needs the whole batch's regions (bwamem.c:1258): they have just arrived
@@ -320,6 +323,7 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 			pestat_flat(u.opt, ref.l_pac, n, u.all, roff.data(), u.pes, g_verbose >= 3, u.opt.n_threads < 4 ? u.opt.n_threads : 4);
 		}
 		u.have_pes = true;
+		t_pes = now_s() - t4;
 		bwagpu_pes_t dp[4];
 		for (int d = 0; d < 4; ++d) { dp[d].low = u.pes[d].low; dp[d].high = u.pes[d].high; dp[d].failed = u.pes[d].failed; dp[d].pad_ = 0; }
 		on_devices([&](int d) {
@@ -341,8 +345,8 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 	}
 	t5 = now_s();
 	u.t_dev = t5 - t0;
-	if (trace) fprintf(stderr, "[D::device_sub] %d reads on %d device(s) -> %ld regions (flag 0x%x): upload %.3f run %.3f download+cigars %.3f pestat+matesw %.3f s\n", n, D, (long)u.tot, u.opt.flag,
-					   t1 - t0, t2 - t1, t3 - t2, t5 - t4);
+	if (trace) fprintf(stderr, "[D::device_sub] %d reads on %d device(s) -> %ld regions (flag 0x%x): upload %.3f run %.3f download+cigars %.3f pestat+matesw %.3f s (pestat %.3f, %ld mate-rescue alignments)\n", n, D, (long)u.tot, u.opt.flag,
+					   t1 - t0, t2 - t1, t3 - t2, t5 - t4, t_pes, (long)u.n_msw);
 }
 
 // stage 3: mem_pestat + kt_for(worker2) (bwamem.c:1254-1260) on the host cores
@@ -364,10 +368,15 @@ static void finalize_sub(const RefSeqs &ref, Work &w, Sub &u, const Pestat *pes0
 	if (u.opt.flag & F_PE) for (int i = 0; i + 1 < n; i += 2) if (strcmp(reads[i].name, reads[i + 1].name) != 0) { fprintf(stderr, "[mem_sam_pe] paired reads have different names: \"%s\", \"%s\"\n", reads[i].name, reads[i + 1].name); exit(EXIT_FAILURE); }
 	std::vector<bwagpu_matesw_t> msw_sorted;
 	if (u.msw) attach_matesw(n, reads.data(), u.msw, u.n_msw, msw_sorted);
-	std::vector<std::string> sam;
-	finalize_batch(u.opt, ref, u.n_processed, n, reads.data(), u.all, roff.data(), (u.opt.flag & F_PE) ? (u.have_pes ? u.pes : pes0) : nullptr, u.opt.n_threads, rg_id, sam, g_verbose >= 3);
+	const Pestat *pes = (u.opt.flag & F_PE) ? (u.have_pes ? u.pes : pes0) : nullptr;
+	if (!w.by_read)      // the batch is one mem_process_seqs call (always, without -p): reads are in output order, text comes by the chunk
+		finalize_batch_chunks(u.opt, ref, u.n_processed, n, reads.data(), u.all, roff.data(), pes, u.opt.n_threads, rg_id, 64, w.out, g_verbose >= 3);
+	else {
+		std::vector<std::string> sam;
+		finalize_batch(u.opt, ref, u.n_processed, n, reads.data(), u.all, roff.data(), pes, u.opt.n_threads, rg_id, sam, g_verbose >= 3);
+		for (int i = 0; i < n; ++i) w.out[u.idx[i]].swap(sam[i]);
+	}
 	bwagpu_free(u.all); u.all = nullptr; bwagpu_free(u.cigs); u.cigs = nullptr; bwagpu_free(u.cig_ops); u.cig_ops = nullptr; bwagpu_free(u.msw); u.msw = nullptr;
-	for (int i = 0; i < n; ++i) w.out[u.idx[i]].swap(sam[i]);
 	if (g_verbose >= 3) fprintf(stderr, "[M::%s] Processed %d reads in %.3f real sec\n", "mem_process_seqs", n, u.t_dev + (now_s() - t0));
 }
 
@@ -552,7 +561,7 @@ int main(int argc, char *argv[])
 	if (getenv("BWAGPU_CLI_SERIALIZE")) g_dev_serialize = atoi(getenv("BWAGPU_CLI_SERIALIZE")) != 0;
 	if (getenv("BWAGPU_CLI_MATESW")) g_device_matesw = atoi(getenv("BWAGPU_CLI_MATESW"));
 	if (getenv("BWAGPU_CLI_CIGARS")) g_device_cigars = atoi(getenv("BWAGPU_CLI_CIGARS"));
-	int n_dev = getenv("BWAGPU_CLI_STREAMS") ? atoi(getenv("BWAGPU_CLI_STREAMS")) : 2;      // batches in flight on the device
+	int n_dev = getenv("BWAGPU_CLI_STREAMS") ? atoi(getenv("BWAGPU_CLI_STREAMS")) : 3;      // batches in flight on the device
 	if (n_dev < 1) n_dev = 1;
 	// devices: BWAGPU_DEVICES=0,1,... (default: the one of BWAGPU_DEVICE); every batch is split over all of them.  The index reaches
 	// the other devices by device-to-device copies (bwagpu_clone_to_device); handles[slot][device], one slot per batch in flight.
@@ -573,7 +582,7 @@ int main(int argc, char *argv[])
 	Chan to_dev(2), to_out(2);
 	// text arenas and base arrays of finished batches are handed back to the reader: re-using them saves a few hundred MB of
 	// first-touch page faults per batch on the one thread that paces the pipeline
-	std::mutex pool_m; std::vector<Batch> batch_pool; std::vector<std::vector<uint8_t>> flat_pool;
+	std::mutex pool_m; std::vector<Batch> batch_pool; std::vector<std::vector<uint8_t>> flat_pool; std::vector<std::vector<std::string>> out_pool;   // (and the chunk strings of written batches)
 	std::mutex dm; std::condition_variable dcv; std::map<long, WorkP> done; long next_fin = 0;   // device -> finalize, re-ordered
 	std::atomic<long> n_works(-1), n_reads_total(0);
 	double busy_read = 0, busy_fin = 0, busy_write = 0; std::atomic<long> busy_dev_us(0);   // per-stage busy time (-v 3 summary)
@@ -605,7 +614,6 @@ int main(int argc, char *argv[])
 			const int n = (int)w->in.seqs.size();
 			long bp = 0; for (auto &q : w->in.seqs) bp += (long)q.l_seq;
 			if (g_verbose >= 3) fprintf(stderr, "[M::%s] read %d sequences (%ld bp)...\n", "process", n, bp);
-			w->out.assign((size_t)n, std::string());
 			if (opt.flag & F_SMARTPE) {   // -p: adjacent records with equal names are pairs (bseq_classify, bwa.c:114-130)
 				Sub se, pe; bool has_last = true; int i;
 				for (i = 1; i < n; ++i) {
@@ -619,6 +627,7 @@ int main(int argc, char *argv[])
 				pe.opt = opt; pe.opt.flag |= F_PE; pe.n_processed = n_processed + (int64_t)se.idx.size();
 				if (!se.idx.empty()) w->subs.push_back(std::move(se));
 				if (!pe.idx.empty()) w->subs.push_back(std::move(pe));
+				if (w->subs.size() > 1) { w->out.assign((size_t)n, std::string()); w->by_read = true; }   // (two calls whose reads interleave in the output: text by the read)
 			} else {
 				Sub u; u.idx.resize((size_t)n); for (int i = 0; i < n; ++i) u.idx[i] = i;
 				u.opt = opt; u.n_processed = n_processed;
@@ -656,7 +665,8 @@ int main(int argc, char *argv[])
 
 	std::thread writer([&] {      // stage 4: output in input order
 		WorkP w;
-		while (to_out.pop(w)) { const double tw = now_s(); for (auto &t : w->out) fwrite(t.data(), 1, strnlen(t.data(), t.size()), stdout); /* (the reference fputs() a read's records, fastmap.c:116: a NUL -- the letter of base code 5, a '-' in the input -- ends them) */ busy_write += now_s() - tw; }
+		while (to_out.pop(w)) { const double tw = now_s(); for (auto &t : w->out) fwrite(t.data(), 1, w->by_read ? strnlen(t.data(), t.size()) : t.size(), stdout);
+			if (!w->by_read) { std::lock_guard<std::mutex> l(pool_m); if (out_pool.size() < 4) out_pool.push_back(std::move(w->out)); } /* (the reference fputs() a read's records, fastmap.c:116: a NUL -- the letter of base code 5, a '-' in the input -- ends them) */ busy_write += now_s() - tw; }
 	});
 
 	for (;;) {                    // stage 3 (this thread drives the worker pool of finalize_batch)
@@ -668,6 +678,7 @@ int main(int argc, char *argv[])
 			w = std::move(done[next_fin]); done.erase(next_fin);
 		}
 		const double tf = now_s();
+		if (!w->by_read) { std::lock_guard<std::mutex> l(pool_m); if (!out_pool.empty()) { w->out = std::move(out_pool.back()); out_pool.pop_back(); } }
 		for (Sub &u : w->subs) finalize_sub(ref, *w, u, pes0, rg_id.c_str(), copy_comment != 0);
 		busy_fin += now_s() - tf;
 		{

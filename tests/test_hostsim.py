@@ -37,6 +37,23 @@ def test_hostsim_regs_match_golden(sim):
         assert_regs_equal(counts[:k], regs.astype(ALNREG_DTYPE)[: int(counts[:k].sum())], c, r, f"golden {name}")
 
 
+def test_hostsim_long_read_dedup_ring_sizes(monkeypatch):
+    """k_dedup_wave's ring of {H,E} columns is sized by the batch's longest read, and its workgroups shrink to two waves (2048 columns) or one
+    (4096) to stay within a workgroup's LDS; a ring too small for a patch alignment's band sends that alignment to the one-lane fall-back
+    (256 columns): same regions in every case."""
+    prefix, g = testdata.small_index()
+    orc = orcapi.OrcIndex(prefix)
+    reads = simdata.make_reads_long(g, 2, length=2500, seed=23)
+    seqs, off = testdata.flat(reads)
+    want = orc.align(pacbio_opt(), seqs, off)
+    for ring in ("256", "2048", "4096"):
+        monkeypatch.setenv("BWAGPU_DEDUP_RING", ring)
+        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+        assert_regs_equal(*want, *s2.align(pacbio_opt(), seqs, off), f"2.5 kb -x pacbio reads, dedup ring {ring}")
+        s2.close()
+    orc.close()
+
+
 def test_hostsim_stage_taps_match_golden(sim):
     z = np.load(os.path.join(testdata.GOLDEN, "golden_stages.npz"))
     k = 40
