@@ -15,8 +15,8 @@ host finalize; the end-to-end `bwa-amd mem` rates (FASTQ in -> SAM out) are repo
 no data-path collective ("weak" scaling: every rank aligns its own `--reads`); the index reaches ranks > 0 by RCCL broadcast.
 
 Parity gate: the unmodified reference (`oracle/_ref/bwa mem`, also the CPU baseline) and the product command line
-(`bwa-amd mem`) align the same samples with the same -K -- a single-end sample in one batch and a paired-end sample in EIGHT
-batches (at least four per device handle: arenas, learnt sizes and packed buffers are re-used from batch to batch) -- and their
+(`bwa-amd mem`) align the same samples with the same -K -- a single-end sample in one batch and a paired-end sample in TWELVE
+batches (four per device handle: arenas, learnt sizes and packed buffers are re-used from batch to batch) -- and their
 SAM must be byte-identical apart from @PG, otherwise the run exits non-zero.  With --gpus N > 1 rank 0 still runs the gate, and
 the product then splits every batch over the N devices (BWAGPU_DEVICES), as does the end-to-end run.
 
@@ -207,7 +207,7 @@ def main():
     ap.add_argument("--e2e-reads", type=int, default=6_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference runs (and with them the parity gate)")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--parity-pairs", type=int, default=800_000, help="pairs of the multi-batch paired-end parity / CPU-baseline sample (eight batches)")
+    ap.add_argument("--parity-pairs", type=int, default=800_000, help="pairs of the multi-batch paired-end parity / CPU-baseline sample (twelve batches)")
     ap.add_argument("--no-longread", action="store_true", help="skip the BASELINE configs[4] leg (10 kb reads, -x pacbio)")
     ap.add_argument("--long-reads", type=int, default=2000)
     ap.add_argument("--long-len", type=int, default=10000)
@@ -401,11 +401,11 @@ def main():
         simdata.write_fastq(fq, se_reads)
         ref_se = run_reference(prefix, [fq], threads, os.path.join(cache, "ref_se.sam"))
         our_se = run_product(prefix, [fq], threads, os.path.join(cache, "our_se.sam"), devices=devices)
-        # ---- paired-end sample, MANY BATCHES: -K small enough that every device handle of the product sees at least four batches (a
+        # ---- paired-end sample, MANY BATCHES: -K small enough that every one of the product's three device handles sees four batches (a
         # handle re-uses arenas, learnt sizes and packed buffers from batch to batch; mem_pestat depends on the batching, so -K is the
         # same on both sides, fastmap.c:394, bwamem.c:1258) ----
         n_mb = max(args.parity_pairs, 8) // 2 * 2
-        K_mb = max(1, (n_mb * 2 * args.read_len) // 8 // 1_000_000) * 1_000_000            # eight batches
+        K_mb = max(1, (n_mb * 2 * args.read_len) // 12 // 1_000_000) * 1_000_000           # twelve batches: four for each of the command line's three device handles
         p1, p2 = simdata.make_reads_pe(g, n_mb, length=args.read_len, seed=4002)
         f1, f2 = os.path.join(cache, "sample_1.fq"), os.path.join(cache, "sample_2.fq")
         simdata.write_fastq(f1, p1, suffix="/1"); simdata.write_fastq(f2, p2, suffix="/2")

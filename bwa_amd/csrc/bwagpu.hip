@@ -77,6 +77,7 @@ struct bwagpu_s {
 	volatile int phase = 0;       // progress marker for bwagpu_debug_phase (diagnostics of a stuck call)
 	i64 packed_tot = -1;          // regions packed by the last bwagpu_batch_download (-1: none)
 	DevBuf d_msw_tasks, d_msw_out, d_msw_pes, d_msw_scratch;
+	DevBuf d_cigl_z, d_cigl_ops, d_cigl_md;      // scratch of the long-segment CIGAR tier (k_cigar_long): direction matrices, operations, MD strings per workgroup
 	DevBuf d_cig_ext; i64 cig_ext_n = -1;   // operation array of the last bwagpu_batch_cigars (records with 7..64 operations point into it)
 	DevBuf d_seq_2b, d_seq_flags; int rd_words = 0;   // per-read 2-bit copies for k_seed's LDS (k_pack_reads2b)
 	DevBuf d_pack_off, d_regs_packed, d_pack_read, d_cigs, d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
@@ -300,7 +301,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 		for (DevBuf *b : ib) b->release();
 		delete h->ibuf;
 	}
-	DevBuf *all[] = { &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
+	DevBuf *all[] = { &h->d_cigl_z, &h->d_cigl_ops, &h->d_cigl_md, &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_chain_todo, &h->d_seed_w, &h->d_seed_order, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
@@ -597,6 +598,16 @@ extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, cons
 	return BWAGPU_OK;
 }
 
+// Waves that own a DP scratch region (dp_h / dp_e).  The lane-per-read kernels need one per wave of the seeding grid; the wave-per-read
+// kernels of long-read batches (k_seedsw_wave, k_dedup_wave) should fill the chip whatever that grid is -- for 10 kb reads the seeding
+// scratch limits it to a few dozen waves, which left 2000 reads to 32 waves (measured: 3.1 of a batch's 4.8 s) -- so they get up to 1024.
+static int dp_wave_count(const bwagpu_t *h, int n_threads)
+{
+	int w = (n_threads + 63) / 64;
+	if (h->max_len > WAVE_EXT_MAX_LEN) { int want = h->n_reads < 1024 ? h->n_reads : 1024; if (want > w) w = want; }
+	return w;
+}
+
 static int alloc_batch(bwagpu_t *h, int n_threads)
 {
 	int n = h->n_reads; size_t sc = (size_t)h->slot_cap + 8;   // +8: chunked readers may touch a few slots past the last read's range
@@ -613,7 +624,7 @@ static int alloc_batch(bwagpu_t *h, int n_threads)
 	bad |= h->d_reg_n_raw.ensure((size_t)n * 4 + 16); bad |= h->d_reg_n.ensure((size_t)n * 4 + 16);
 	bad |= h->d_regs.ensure((size_t)h->reg_cap * sizeof(bwagpu_alnreg_t));
 	if (h->taps_on) bad |= h->d_regs_raw.ensure((size_t)h->reg_cap * sizeof(bwagpu_alnreg_t));
-	int n_waves = (n_threads + 63) / 64;
+	int n_waves = dp_wave_count(h, n_threads);
 	bad |= h->d_dp_h.ensure((size_t)n_waves * (h->max_len + 2) * DPS * 4);
 	bad |= h->d_dp_e.ensure((size_t)n_waves * (h->max_len + 2) * DPS * 4);
 	bad |= h->d_minhsp.ensure((size_t)(h->max_len + 2) * 4);
@@ -685,7 +696,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.reg_off = h->d_reg_off.as<i64>(); B.reg_cap_r = h->d_reg_cap_r.as<i32>(); B.reg_n_raw = h->d_reg_n_raw.as<i32>(); B.reg_n = h->d_reg_n.as<i32>();
 		B.regs = h->d_regs.as<bwagpu_alnreg_t>(); B.reg_cap = h->reg_cap;
 		B.regs_raw = h->taps_on ? h->d_regs_raw.as<bwagpu_alnreg_t>() : nullptr;
-		B.dp_h = h->d_dp_h.as<i32>(); B.dp_e = h->d_dp_e.as<i32>(); B.dp_waves = (n_threads + 63) / 64;
+		B.dp_h = h->d_dp_h.as<i32>(); B.dp_e = h->d_dp_e.as<i32>(); B.dp_waves = dp_wave_count(h, n_threads);
 		B.seedsw_minhsp = h->d_minhsp.as<i32>();
 		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>(); B.chain_todo = h->d_chain_todo.as<i32>(); B.chain_todo2 = B.chain_todo + n + 4; B.seed_w = h->d_seed_w.as<i32>(); B.seed_order = nullptr;
 		B.seed_prio = !(getenv("BWAGPU_SEED_PRIO") && atoi(getenv("BWAGPU_SEED_PRIO")) == 0);
@@ -744,7 +755,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_chain", hipGetErrorString(e_)); }
 		if (any_seedsw && h->max_len > WAVE_EXT_MAX_LEN) {   // long reads: one wavefront per read, one lane per seed
-			i64 nblk = ((i64)n + 3) / 4, cap = n_threads / BLOCK;
+			i64 nblk = ((i64)n + 3) / 4, cap = B.dp_waves / 4 > 0 ? B.dp_waves / 4 : 1;      // (one DP scratch region per wave)
 			hipLaunchKernelGGL(k_seedsw_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), block, 0, h->stream, h->ix, *opt, B);
 		} else if (any_seedsw) hipLaunchKernelGGL(k_seedsw, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
@@ -781,7 +792,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			if (getenv("BWAGPU_DEDUP_RING")) rc_ = atoi(getenv("BWAGPU_DEDUP_RING"));      // test hook: a power of two, 256..4096
 			if (rc_ < 256 || rc_ > 4096 || (rc_ & (rc_ - 1))) rc_ = 1024;
 			const int wpb = rc_ <= 1024 ? 4 : (rc_ <= 2048 ? 2 : 1);
-			i64 nblk = ((i64)n + wpb - 1) / wpb, cap = (n_threads / 64) / wpb;   // dp_h/dp_e hold one scratch region per wave of the standard grid
+			i64 nblk = ((i64)n + wpb - 1) / wpb, cap = B.dp_waves / wpb > 0 ? B.dp_waves / wpb : 1;   // dp_h/dp_e hold one scratch region per wave
 			hipLaunchKernelGGL(k_dedup_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)(8 * rc_ + 32) * wpb, h->stream, h->ix, *opt, B, rc_);
 		} else
 			hipLaunchKernelGGL(k_dedup, grid, block, 0, h->stream, h->ix, *opt, B);
@@ -931,8 +942,19 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		const int n_tier = getenv("BWAGPU_CIG_TIERS") ? atoi(getenv("BWAGPU_CIG_TIERS")) : 2;   // diagnostics
 		// operation array: sized for a typical batch; one that needs more (gap-rich reads) reports the total it reserved and is
 		// redone once with exactly that much
-		i64 ext_cap = getenv("BWAGPU_CIG_OPS_CAP") ? atoll(getenv("BWAGPU_CIG_OPS_CAP")) : tot * 4 + 65536;   // (the variable: tests of the second attempt)
+		i64 ext_cap = tot * 4 + 65536;
+		if (h->max_len > CIG_MAX_LEN && h->n_bases / 2 + 65536 > ext_cap) ext_cap = h->n_bases / 2 + 65536;   // (long reads: ~0.37 entries per base at 13 % indels -- operations and MD characters)
+		if (getenv("BWAGPU_CIG_OPS_CAP")) ext_cap = atoll(getenv("BWAGPU_CIG_OPS_CAP"));   // (tests of the second attempt)
 		if (ext_cap < 1) ext_cap = 1;
+		// third tier (k_cigar_long): segments, bands and operation counts beyond the LDS tiers' limits; one 64-thread workgroup per region at a time,
+		// each with a direction matrix of its own in HBM -- sized for the batch's longest read with half again as many reference bases and the
+		// widest band the kernel takes, as many workgroups as 24 GiB hold (at most 1024)
+		const bool long_tier = !(getenv("BWAGPU_CIG_LONG") && atoi(getenv("BWAGPU_CIG_LONG")) == 0);
+		i64 z_cap = ((i64)h->max_len + h->max_len / 2 + 64) * CIGL_MAX_COLS; z_cap = (z_cap + 15) & ~(i64)15;
+		int n_long = (int)(((i64)24 << 30) / z_cap); if (n_long > 1024) n_long = 1024; if (n_long < 8) n_long = 8;
+		if (h->max_len <= CIG_MAX_LEN && n_long > 256) n_long = 256;
+		if (long_tier && (h->d_cigl_z.ensure((size_t)z_cap * n_long) || h->d_cigl_ops.ensure((size_t)n_long * CIGL_MAX_OPS * 4) || h->d_cigl_md.ensure((size_t)n_long * CIGL_MD_CAP))) {
+			free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
 		unsigned long long used = 0;
 		hipError_t e = hipSuccess;
 		for (int attempt = 0; attempt < 2; ++attempt) {
@@ -949,6 +971,16 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 								   h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_pack_read.as<i32>(), h->d_cigs.as<bwagpu_cigar_t>(), next, zc[tier], tier,
 								   h->d_cig_ext.as<u32>(), ext_used, ext_cap);
 				e = hipGetLastError();
+			}
+			if (e == hipSuccess && long_tier) {
+				e = hipMemsetAsync(next, 0, sizeof(unsigned long long), h->stream);
+				if (e == hipSuccess) {
+					h->phase = 44;
+					hipLaunchKernelGGL(k_cigar_long, dim3((unsigned)n_long), dim3(64), (size_t)CIGL_LDS_BYTES, h->stream, h->ix, *opt, B, tot,
+									   h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_pack_read.as<i32>(), h->d_cigs.as<bwagpu_cigar_t>(), next,
+									   h->d_cigl_z.as<u8>(), z_cap, h->d_cigl_ops.as<u32>(), h->d_cigl_md.as<u8>(), h->d_cig_ext.as<u32>(), ext_used, ext_cap);
+					e = hipGetLastError();
+				}
 			}
 			if (e == hipSuccess) e = hipMemcpyAsync(&used, ext_used, sizeof used, hipMemcpyDeviceToHost, h->stream);
 			if (e == hipSuccess) e = wait_stream(h);
@@ -990,7 +1022,7 @@ extern "C" int bwagpu_batch_matesw(bwagpu_t *h, const bwagpu_opt_t *opt, const b
 	const i64 task_cap = (i64)n * 2 + 1024;          // more candidates than this are simply left to the host
 	const int waves = 1024;
 	if (h->d_msw_tasks.ensure((size_t)task_cap * sizeof(MateTask)) || h->d_msw_out.ensure((size_t)task_cap * sizeof(bwagpu_matesw_t)) ||
-		h->d_msw_pes.ensure(4 * sizeof(bwagpu_pes_t)) || h->d_msw_scratch.ensure((size_t)waves * MSW_LANE_INTS * 64 * 4) || h->d_ctr.ensure(sizeof(Counters))) {
+		h->d_msw_pes.ensure(4 * sizeof(bwagpu_pes_t)) || h->d_ctr.ensure(sizeof(Counters))) {
 		h->err = "hipMalloc failed (mate rescue)"; return BWAGPU_ENOMEM;
 	}
 	unsigned long long *n_tasks = &h->d_ctr.as<Counters>()->next_chain, *next = &h->d_ctr.as<Counters>()->next_dedup;   // idle counters at this point
@@ -1009,8 +1041,9 @@ extern "C" int bwagpu_batch_matesw(bwagpu_t *h, const bwagpu_opt_t *opt, const b
 	if (!res) return BWAGPU_ENOMEM;
 	if (nt) {
 		Batch B = {}; B.seq = h->d_seq.as<u8>(); B.off = h->d_off.as<i64>(); B.n_reads = n; B.max_len = h->max_len;
-		hipLaunchKernelGGL(k_matesw_sw, dim3(waves / 4), dim3(BLOCK), 0, h->stream, h->ix, *opt, B, h->d_msw_pes.as<bwagpu_pes_t>(), h->d_msw_tasks.as<MateTask>(), (i64)nt,
-						   h->d_msw_out.as<bwagpu_matesw_t>(), next, h->d_msw_scratch.as<i32>());
+		const i64 want = ((i64)nt + 3) / 4;           // one wavefront per alignment, four per workgroup
+		hipLaunchKernelGGL(k_matesw_sw, dim3((unsigned)(want < waves / 4 * 8 ? want : waves / 4 * 8)), dim3(BLOCK), 0, h->stream, h->ix, *opt, B, h->d_msw_pes.as<bwagpu_pes_t>(), h->d_msw_tasks.as<MateTask>(), (i64)nt,
+						   h->d_msw_out.as<bwagpu_matesw_t>(), next);
 		hipError_t e = hipGetLastError();
 		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_msw_out.p, (size_t)nt * sizeof(bwagpu_matesw_t), hipMemcpyDeviceToHost, h->stream);
 		if (e == hipSuccess) e = wait_stream(h);
@@ -1074,7 +1107,7 @@ extern "C" int bwagpu_align_bseq(bwagpu_t *h, const bwagpu_opt_t *opt, int n, bw
 // ---- differential tests of the DP routines (dev_debug.h) ---------------------------------------------------------------------
 extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, int n_cases, const bwagpu_dp_case_t *cases, const uint8_t *seqs, int64_t n_seq_bytes, int32_t *out)
 {
-	if (!h || !opt || n_cases < 0 || kind < 0 || kind > 4 || (n_cases > 0 && (!cases || !seqs || !out)) || n_seq_bytes < 0) return BWAGPU_EINVAL;
+	if (!h || !opt || n_cases < 0 || kind < 0 || kind > 5 || (n_cases > 0 && (!cases || !seqs || !out)) || n_seq_bytes < 0) return BWAGPU_EINVAL;
 	if (opt->e_del <= 0 || opt->e_ins <= 0) return BWAGPU_EINVAL;
 	if (n_cases == 0) return BWAGPU_OK;
 	static_assert(sizeof(bwagpu_dp_case_t) == 32, "layout");
@@ -1087,7 +1120,7 @@ extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, i
 		if (c.w > max_w) max_w = c.w;
 	}
 	HIPCHK(h, hipSetDevice(h->device));
-	DevBuf d_seq, d_pac, d_cases, d_out, d_scr;
+	DevBuf d_seq, d_pac, d_cases, d_out, d_scr, d_pac2;
 	int rc = BWAGPU_OK;
 	const int grid = n_cases < 2048 ? n_cases : 2048;
 	hipError_t e = hipSuccess;
@@ -1112,10 +1145,14 @@ extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, i
 			int ring_cols = 256; while (ring_cols < 2 * max_w + 4 + 128) ring_cols <<= 1;
 			if (ring_cols > 4096) { rc = BWAGPU_EINVAL; goto done; }
 			hipLaunchKernelGGL(k_debug_global_ring, dim3(grid), dim3(64), (size_t)8 * ring_cols + 32, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), ring_cols, d_out.as<i32>());
+		} else if (kind == 5) {
+			int max_t = 1; for (int i = 0; i < n_cases; ++i) if (cases[i].t_len > max_t) max_t = cases[i].t_len;
+			i64 z_cap = ((i64)max_t + 16) * CIGL_MAX_COLS; z_cap = (z_cap + 15) & ~(i64)15;
+			const int blocks = grid < 64 ? grid : 64;
+			if (d_scr.ensure((size_t)blocks * z_cap) || d_pac2.ensure((size_t)blocks * CIGL_MAX_OPS * 4)) { h->err = "hipMalloc failed (debug)"; rc = BWAGPU_ENOMEM; goto done; }
+			hipLaunchKernelGGL(k_debug_global_long, dim3(blocks), dim3(64), (size_t)CIGL_LDS_BYTES, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), d_scr.as<u8>(), z_cap, d_pac2.as<u32>(), d_out.as<i32>());
 		} else {
-			const int blocks = (n_cases + 63) / 64 < 256 ? (n_cases + 63) / 64 : 256;
-			if (d_scr.ensure((size_t)blocks * MSW_LANE_INTS * 64 * 4)) { h->err = "hipMalloc failed (debug)"; rc = BWAGPU_ENOMEM; goto done; }
-			hipLaunchKernelGGL(k_debug_align2, dim3(blocks), dim3(64), 0, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), d_scr.as<i32>(), d_out.as<i32>());
+			hipLaunchKernelGGL(k_debug_align2, dim3(grid), dim3(64), 0, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), d_out.as<i32>());
 		}
 		e = hipGetLastError();
 	}
@@ -1124,7 +1161,7 @@ extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, i
 	if (e != hipSuccess) { h->err = std::string("bwagpu_debug_dp: ") + hipGetErrorString(e); rc = BWAGPU_EHIP; }
 done:
 	(void)hipStreamSynchronize(h->stream);
-	d_seq.release(); d_pac.release(); d_cases.release(); d_out.release(); d_scr.release();
+	d_seq.release(); d_pac.release(); d_cases.release(); d_out.release(); d_scr.release(); d_pac2.release();
 	return rc;
 }
 

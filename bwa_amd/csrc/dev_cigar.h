@@ -127,9 +127,11 @@ __device__ int wave_nm_md(const DevIndex &ix, const u8 *q, int q0, int qdir, i64
 	auto put = [&](int c) { if (lane == 0 && n < md_cap) md[n] = (u8)c; ++n; };
 	auto put_int = [&](int v) { int d = 1; while (d * 10 <= v) d *= 10; for (; d > 0; d /= 10) put('0' + v / d % 10); };
 	auto letter = [&](int b) -> int { return (int)(0x54474341u >> (8 * (fwd ? b : 3 - b)) & 255u); };   // "ACGT"[b], or its complement
+	int ocache = 0, obase = -64;                      // the operations, fetched 64 at a time (the long-segment kernel keeps them in HBM)
 	for (int k = 0; k < n_ops; ++k) {
-		const u32 o = ops[n_ops - 1 - k];
-		const int op = uni((int)(o & 15u)), len = uni((int)(o >> 4));
+		if (k - obase >= 64) { obase = k; const int idx = n_ops - 1 - (k + lane); ocache = idx >= 0 ? (int)ops[idx] : 0; }
+		const u32 o = (u32)__builtin_amdgcn_readlane(ocache, k - obase);
+		const int op = (int)(o & 15u), len = (int)(o >> 4);
 		if (op == 0) {
 			for (int b = 0; b < len; b += 64) {
 				const int i = b + lane; const bool in = i < len;
@@ -251,6 +253,236 @@ __device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const 
 		for (int k = 0; k < CIG_MAX_OPS; ++k) out->cigar[k] = 0;
 	}
 	wave_sync();
+}
+
+// ---- long segments (BASELINE configs[4]: 10 kb reads) --------------------------------------------------------------------------------
+// The same recurrence for segments of any length: the band's {H, E} columns live in an LDS ring (as in k_dedup_wave's score-only form), scores
+// come from the 25-entry matrix and the query bases, and the direction codes -- one byte per cell, rows padded to 16 bytes -- go to a
+// scratch area of the wave in HBM (ksw.c:548-549 keeps the same matrix in host memory).  The traceback (ksw.c:624-639) is a chain of
+// ~2 (qlen + tlen) dependent one-byte look-ups; left to one lane reading HBM it would cost a memory round trip per step, so the wave
+// fetches the path's neighbourhood a tile at a time -- the 48 bytes around the diagonal's column in each of 64 rows -- into LDS and lane 0
+// walks the tile; a path that drifts out of a row's window (more than 16 gap columns within 64 rows) just ends the tile early.  Operations
+// are pushed to the wave's HBM scratch as they complete, in traceback order.
+#define CIGL_MAX_COLS 2048      // widest band (columns per row)
+#define CIGL_RING 4096          // ring of {H,E} columns: >= 2 w + 132 for every band the kernel takes
+#define CIGL_MAX_OPS 32768
+#define CIGL_MD_CAP 98304
+#define CIGL_TILE_W 48
+#define CIGL_LDS_BYTES (2 * CIGL_RING * 4 + 32 + 64 * CIGL_TILE_W + 16)
+struct CigLongLds { i32 *hd, *e; int8_t *mat; u8 *tile; };
+struct CigLongScratch { u8 *z; i64 z_cap; u32 *ops; u8 *md; };
+
+__device__ int wave_ksw_global2_long(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen, i64 t0, int tdir, int tlen,
+									 int w, const CigLongLds &L, const CigLongScratch &S, int *n_ops)
+{
+	const int lane = threadIdx.x & 63;
+	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+	const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1, zs = (n_col + 15) & ~15;       // row stride of the direction matrix
+	i32 *hd = L.hd, *e_ = L.e; const int rm = CIGL_RING - 1;
+	int init_hi = -1, treg = 0;
+	for (int i = 0; i < tlen; ++i) {
+		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
+		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
+		const int beg = i > w ? i - w : 0, end = i + w + 1 < qlen ? i + w + 1 : qlen;
+		{	// first-row values (ksw.c:566-570) of the columns this row can reach for the first time
+			const int hi = i + w + 2 < qlen ? i + w + 2 : qlen;
+			if (hi > init_hi) {
+				for (int j = init_hi + 1 + lane; j <= hi; j += 64) {
+					hd[j & rm] = j == 0 ? 0 : (j <= w ? -(o_ins + e_ins * j) : CIG_NEG_INF);
+					e_[j & rm] = CIG_NEG_INF;
+				}
+				init_hi = hi;
+				wave_sync();
+			}
+		}
+		const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : CIG_NEG_INF;
+		int carry = I32_MIN, bnd = 0;
+		u8 *zrow = S.z + (i64)i * zs;
+		for (int b = beg; b < end; b += 64) {
+			const int j = b + lane; const bool act = j < end;
+			int dg = hd[j & rm]; const int ec = e_[j & rm];
+			const int qc = j < qlen ? (int)q[q0 + j * qdir] : 4;
+			const int sc = L.mat[tb * 5 + qc];
+			const int bnd_next = hd[(b + 64) & rm];
+			if (b != beg && lane == 0) dg = bnd;
+			wave_sync();
+			const int m = dg + sc;
+			const int a = act ? m - oe_ins + j * e_ins : I32_MIN;
+			const int inc = wave_incl_scan_max(a);
+			const int exc = imax(wave_shift_up1(inc, I32_MIN), carry);
+			int f = CIG_NEG_INF - (j - beg) * e_ins;
+			if (j > beg && act) f = imax(f, exc - (j - 1) * e_ins);
+			int d = m >= ec ? 0 : 1, h = m >= ec ? m : ec;             // ksw.c:587-590
+			if (h < f) { d = 2; h = f; }
+			int t = m - oe_del, en = ec - e_del;
+			if (en > t) d |= 4; else en = t;                          // E continues (ksw.c:592-595)
+			t = m - oe_ins;
+			if (f - e_ins > t) d |= 8;                                // F continues (ksw.c:596-599)
+			if (act) { e_[j & rm] = en; hd[(j + 1) & rm] = h; zrow[j - beg] = (u8)d; }
+			if (b == beg && lane == 0) hd[beg & rm] = h1_init;
+			carry = imax(carry, __builtin_amdgcn_readlane(inc, 63));
+			bnd = bnd_next;
+			wave_sync();
+		}
+		if (lane == 0) e_[end & rm] = CIG_NEG_INF;
+		wave_sync();
+	}
+	const int score = hd[qlen & rm];
+	__threadfence();                                              // the direction bytes are read back below through other lanes
+	wave_sync();
+	// ---- traceback (ksw.c:624-639) ----
+	int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, which = 0, n = 0;
+	int cur_op = -1, cur_len = 0;                                 // the run being built (lane 0)
+	while (i >= 0 && k >= 0 && n <= CIGL_MAX_OPS) {
+		// tile: row i - r for lane r, the CIGL_TILE_W bytes from the 16-byte boundary at or below (column the diagonal through (i,k) has in that row) - 16
+		{
+			const int ii = i - lane;
+			if (ii >= 0) {
+				const int bi = ii > w ? ii - w : 0;
+				int ws = ((k - lane) - bi - 16) & ~15; if (ws < 0) ws = 0;
+				const uint4 *src = (const uint4*)(S.z + (i64)ii * zs + ws);
+				uint4 *dst = (uint4*)(L.tile + lane * CIGL_TILE_W);
+#pragma unroll
+				for (int p = 0; p < CIGL_TILE_W / 16; ++p) if (ws + 16 * p < zs) dst[p] = src[p];
+			}
+		}
+		wave_sync();
+		if (lane == 0) {
+			const int i0 = i, k0 = k;
+			while (i >= 0 && k >= 0 && i0 - i < 64 && n <= CIGL_MAX_OPS) {
+				const int r = i0 - i, bi = i > w ? i - w : 0;
+				int ws = ((k0 - r) - bi - 16) & ~15; if (ws < 0) ws = 0;
+				const int c = (k - bi) - ws;
+				if (c < 0 || c >= CIGL_TILE_W) break;                  // drifted out of this row's window: start a new tile here
+				const u32 dd = L.tile[r * CIGL_TILE_W + c];
+				which = which == 0 ? (int)(dd & 3) : which == 1 ? (int)(dd >> 2 & 1) : (int)(dd >> 3 & 1) << 1;
+				const int op = which == 0 ? 0 : (which == 1 ? 2 : 1);
+				if (op == cur_op) ++cur_len;
+				else { if (cur_op >= 0) { if (n < CIGL_MAX_OPS) S.ops[n] = (u32)cur_len << 4 | (u32)cur_op; ++n; } cur_op = op; cur_len = 1; }
+				if (which == 0) { --i; --k; } else if (which == 1) --i; else --k;
+			}
+		}
+		i = __builtin_amdgcn_readlane(i, 0); k = __builtin_amdgcn_readlane(k, 0); n = __builtin_amdgcn_readlane(n, 0);
+		wave_sync();
+	}
+	if (lane == 0) {
+		auto push = [&](int op, int len) {
+			if (op == cur_op) cur_len += len;
+			else { if (cur_op >= 0) { if (n < CIGL_MAX_OPS) S.ops[n] = (u32)cur_len << 4 | (u32)cur_op; ++n; } cur_op = op; cur_len = len; }
+		};
+		if (i >= 0) push(2, i + 1);
+		if (k >= 0) push(1, k + 1);
+		if (cur_op >= 0) { if (n < CIGL_MAX_OPS) S.ops[n] = (u32)cur_len << 4 | (u32)cur_op; ++n; }
+	}
+	n = __builtin_amdgcn_readlane(n, 0);
+	__threadfence();
+	wave_sync();
+	*n_ops = n > CIGL_MAX_OPS ? -1 : n;
+	return score;
+}
+
+// One region of the long tier: mem_reg2aln's band-doubling loop (bwamem.c:1143-1152) around the routine above, then NM / MD and the record.
+__device__ void cigar_region_long(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *query, const bwagpu_alnreg_t &p, const CigLongLds &L, const CigLongScratch &S,
+								  bwagpu_cigar_t *out, u32 *ext, unsigned long long *ext_used, i64 ext_cap)
+{
+	const int lane = threadIdx.x & 63;
+	const i64 rb = uni64(p.rb), re = uni64(p.re), l_pac = ix.l_pac;
+	const int qb = uni(p.qb), qe = uni(p.qe), truesc = uni(p.truesc), pw = uni(p.w);
+	const int l_query = qe - qb;
+	if (!(l_query > 0 && rb < re && !(rb < l_pac && re > l_pac) && re - rb < (1 << 24) && l_query < (1 << 24))) return;     // (the record keeps its "not computed" state)
+	const int rlen = (int)(re - rb);
+	const bool rev = rb >= l_pac;
+	const int q0 = rev ? qe - 1 : qb, qdir = rev ? -1 : 1;
+	const i64 t0 = rev ? re - 1 : rb; const int tdir = rev ? -1 : 1;
+	int tmp = dev_infer_bw(l_query, rlen, truesc, opt.a, opt.o_del, opt.e_del);
+	int w2 = dev_infer_bw(l_query, rlen, truesc, opt.a, opt.o_ins, opt.e_ins);
+	w2 = w2 > tmp ? w2 : tmp;
+	if (w2 > opt.w) w2 = w2 < pw ? w2 : pw;
+	int i = 0, score = 0, last_sc = -(1 << 30), n_ops = -1;
+	do {
+		w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+		if (l_query == rlen && w2 == 0) {
+			int s = 0;
+			for (int j = lane; j < l_query; j += 64) s += opt.mat[ref_base(ix, t0 + (i64)j * tdir) * 5 + query[q0 + j * qdir]];
+			for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+			score = s; n_ops = 1;
+			if (lane == 0) S.ops[0] = (u32)l_query << 4;
+			__threadfence();
+			wave_sync();
+		} else {
+			int max_ins = trunc_div_add(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins, opt.e_ins, 1);
+			int max_del = trunc_div_add(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del, opt.e_del, 1);
+			int max_gap = max_ins > max_del ? max_ins : max_del;
+			const int dl = rlen > l_query ? rlen - l_query : l_query - rlen;
+			max_gap = max_gap > 1 ? max_gap : 1;
+			int w = (max_gap + dl + 1) >> 1; w = w < w2 ? w : w2;
+			const int min_w = dl + 3; w = w > min_w ? w : min_w;
+			const int n_col = l_query < 2 * w + 1 ? l_query : 2 * w + 1;
+			if (n_col > CIGL_MAX_COLS || (i64)rlen * ((n_col + 15) & ~15) > S.z_cap) return;
+			score = wave_ksw_global2_long(ix, opt, query, q0, qdir, l_query, t0, tdir, rlen, w, L, S, &n_ops);
+			if (n_ops < 0) return;
+		}
+		if (score == last_sc || w2 == opt.w << 2) break;
+		last_sc = score;
+		w2 <<= 1;
+	} while (++i < 3 && score < truesc - opt.a);
+	int md_len = 0;
+	const int nm = wave_nm_md(ix, query, q0, qdir, t0, tdir, !rev, S.ops, n_ops, S.md, CIGL_MD_CAP, &md_len);
+	if (md_len > CIGL_MD_CAP) return;
+	__threadfence();
+	wave_sync();
+	const int n_ext_ops = n_ops > CIG_MAX_OPS ? n_ops : 0, n_ext_md = md_len > 8 ? (md_len + 3) >> 2 : 0;
+	unsigned long long at = 0;
+	bool fits = true;
+	if (n_ext_ops + n_ext_md > 0) {
+		if (lane == 0) at = atomicAdd(ext_used, (unsigned long long)(n_ext_ops + n_ext_md));
+		at = (unsigned long long)lane0_i64((i64)at);
+		fits = ext && (i64)(at + n_ext_ops + n_ext_md) <= ext_cap;
+	}
+	if (!fits) { if (lane == 0) out->score = 3; wave_sync(); return; }
+	for (int k = lane; k < n_ext_ops; k += 64) ext[at + k] = S.ops[n_ops - 1 - k];
+	auto md4 = [&](int w_) -> u32 { u32 v = 0; for (int b = 0; b < 4; ++b) if (4 * w_ + b < md_len) v |= (u32)S.md[4 * w_ + b] << (8 * b); return v; };
+	for (int w_ = lane; w_ < n_ext_md; w_ += 64) ext[at + n_ext_ops + w_] = md4(w_);
+	if (lane == 0) {
+		out->score = score; out->n_cigar = n_ops;
+		if (n_ext_ops) { out->cigar[0] = (u32)at; out->cigar[1] = (u32)(at >> 32); for (int k = 2; k < CIG_MAX_OPS; ++k) out->cigar[k] = 0; }
+		else for (int k = 0; k < CIG_MAX_OPS; ++k) out->cigar[k] = k < n_ops ? S.ops[n_ops - 1 - k] : 0;
+		out->nm = nm; out->md_len = md_len;
+		out->md = n_ext_md ? (u64)(at + n_ext_ops) : ((u64)md4(1) << 32 | md4(0));
+	}
+	wave_sync();
+}
+
+// Third tier of bwagpu_batch_cigars: one wavefront per region the LDS tiers left uncomputed for their limits (segments over CIG_MAX_LEN bases,
+// bands over CIG_MAX_COLS columns, more than CIG_TMP_OPS operations).  64 threads per workgroup; scratch: one CigLongScratch per workgroup.
+__global__ void __launch_bounds__(64) k_cigar_long(DevIndex ix, bwagpu_opt_t opt, Batch B, i64 n_regs, const bwagpu_alnreg_t *regs, const i32 *reg_read, bwagpu_cigar_t *out,
+													unsigned long long *next, u8 *z_all, i64 z_cap, u32 *ops_all, u8 *md_all, u32 *ext, unsigned long long *ext_used, i64 ext_cap)
+{
+	HIP_DYNAMIC_SHARED(unsigned char, cigl_lds)
+	const int lane = threadIdx.x & 63;
+	CigLongLds L;
+	L.hd = (i32*)cigl_lds; L.e = L.hd + CIGL_RING;
+	L.mat = (int8_t*)(L.e + CIGL_RING);
+	L.tile = (u8*)(cigl_lds + 2 * CIGL_RING * 4 + 32);
+	if (lane < 25) L.mat[lane] = opt.mat[lane];
+	CigLongScratch S;
+	S.z = z_all + (i64)blockIdx.x * z_cap; S.z_cap = z_cap; S.ops = ops_all + (size_t)blockIdx.x * CIGL_MAX_OPS; S.md = md_all + (size_t)blockIdx.x * CIGL_MD_CAP;
+	wave_sync();
+	for (;;) {       // records are drawn 256 at a time and screened 64 at a time: nearly all of a short-read batch's are already computed
+		const long long base = wave_fetch_n(next, 256);
+		if (base >= n_regs) break;
+		for (int c = 0; c < 256; c += 64) {
+			const long long g = base + c + lane;
+			u64 todo = __ballot(g < n_regs && out[g].n_cigar < 0 && out[g].score != 1);   // not computed by an LDS tier, and not below the output threshold
+			while (todo) {
+				const int l = __builtin_ctzll(todo); todo &= todo - 1;
+				const long long gg = base + c + l;
+				const bwagpu_alnreg_t p = regs[gg];
+				cigar_region_long(ix, opt, B.seq + B.off[reg_read[gg]], p, L, S, out + gg, ext, ext_used, ext_cap);
+			}
+		}
+	}
 }
 
 // One wavefront per packed region (bwagpu_batch_download's order); regions below the output threshold T are skipped.

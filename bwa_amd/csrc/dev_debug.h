@@ -116,23 +116,51 @@ __global__ void __launch_bounds__(64) k_debug_global_ring(DevIndex ix, bwagpu_op
 	}
 }
 
-// kind 4: ksw_align2 as k_matesw_sw runs it (one lane per case; h0 carries the xtra word); out: score, te, qe, score2, te2, tb, qb
-__global__ void __launch_bounds__(64) k_debug_align2(DevIndex ix, bwagpu_opt_t opt, int n_cases, const bwagpu_dp_case_t *cases, const u8 *seqs, i32 *scratch, i32 *out)
+// kind 4: ksw_align2 as k_matesw_sw runs it (one wavefront per case; h0 carries the xtra word); out: score, te, qe, score2, te2, tb, qb
+__global__ void __launch_bounds__(64) k_debug_align2(DevIndex ix, bwagpu_opt_t opt, int n_cases, const bwagpu_dp_case_t *cases, const u8 *seqs, i32 *out)
 {
-	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; const int lane = threadIdx.x & 63;
-	i32 *S = scratch + wave * ((size_t)MSW_LANE_INTS * 64) + lane;
-	for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_cases; k += gridDim.x * blockDim.x) {
+	__shared__ i32 dbg_runs[MSW_RUN_INTS];
+	const int lane = threadIdx.x & 63;
+	for (int k = blockIdx.x; k < n_cases; k += gridDim.x) {
 		const bwagpu_dp_case_t c = cases[k];
 		i32 *o = out + (size_t)k * DBG_OUT_INTS;
-		if (c.q_len > MSW_MAX_Q || c.t_len > MSW_MAX_T) { o[0] = 0; o[1] = -2; continue; }
+		if (c.q_len > MSW_MAX_Q || c.t_len > MSW_MAX_T) { if (lane == 0) { o[0] = 0; o[1] = -2; } continue; }
 		const u8 *q = seqs + c.q_off;
 		int q0, qdir, tdir; i64 t0;
 		dbg_case_geometry(c, ix.l_pac, q0, qdir, t0, tdir);
 		auto Qf = [&](int j) -> int { return (int)q[q0 + j * qdir]; };
 		auto Tf = [&](int i) -> int { return ref_base(ix, t0 + (i64)i * tdir); };
 		int res[7];
-		msw_align2(opt, c.q_len, Qf, c.t_len, Tf, c.h0, S, res);
-		for (int j = 0; j < 7; ++j) o[j] = res[j];
+		msw_align2(opt, c.q_len, Qf, c.t_len, Tf, c.h0, dbg_runs, res);
+		if (lane == 0) for (int j = 0; j < 7; ++j) o[j] = res[j];
+		wave_sync();
+	}
+}
+
+// kind 5: wave_ksw_global2_long as k_cigar_long sets it up; out: score, n_ops (-1: too many, -2: outside the limits), the first 70 operations
+__global__ void __launch_bounds__(64) k_debug_global_long(DevIndex ix, bwagpu_opt_t opt, int n_cases, const bwagpu_dp_case_t *cases, const u8 *seqs, u8 *z_all, i64 z_cap, u32 *ops_all, i32 *out)
+{
+	HIP_DYNAMIC_SHARED(unsigned char, dbg_lds)
+	const int lane = threadIdx.x & 63;
+	CigLongLds L;
+	L.hd = (i32*)dbg_lds; L.e = L.hd + CIGL_RING;
+	L.mat = (int8_t*)(L.e + CIGL_RING);
+	L.tile = (u8*)(dbg_lds + 2 * CIGL_RING * 4 + 32);
+	if (lane < 25) L.mat[lane] = opt.mat[lane];
+	CigLongScratch S;
+	S.z = z_all + (i64)blockIdx.x * z_cap; S.z_cap = z_cap; S.ops = ops_all + (size_t)blockIdx.x * CIGL_MAX_OPS; S.md = nullptr;
+	wave_sync();
+	for (int k = blockIdx.x; k < n_cases; k += gridDim.x) {
+		const bwagpu_dp_case_t c = cases[k];
+		int q0, qdir, tdir; i64 t0;
+		dbg_case_geometry(c, ix.l_pac, q0, qdir, t0, tdir);
+		i32 *o = out + (size_t)k * DBG_OUT_INTS;
+		const int n_col = c.q_len < 2 * c.w + 1 ? c.q_len : 2 * c.w + 1;
+		if (n_col > CIGL_MAX_COLS || (i64)c.t_len * ((n_col + 15) & ~15) > z_cap) { if (lane == 0) { o[0] = 0; o[1] = -2; } continue; }
+		int n_ops = 0;
+		const int score = wave_ksw_global2_long(ix, opt, seqs + c.q_off, q0, qdir, c.q_len, t0, tdir, c.t_len, c.w, L, S, &n_ops);
+		if (lane == 0) { o[0] = score; o[1] = n_ops; for (int j = 0; j < n_ops && j < DBG_OUT_INTS - 2; ++j) o[2 + j] = (i32)S.ops[n_ops - 1 - j]; }
+		wave_sync();
 	}
 }
 

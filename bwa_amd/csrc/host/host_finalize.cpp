@@ -244,7 +244,7 @@ void host_region_cigar(const bwagpu_opt_t &opt, const RefSeqs &ref, const uint8_
 	// MD strings of more than 8 characters and 7..64 operations go to the operation array, like the device's records (operations first)
 	const bool ext_ops = cigar.size() > 6, ext_md = md.size() > 8;
 	if ((ext_ops || ext_md) && !ext) { out->score = 3; return; }
-	if (cigar.size() > 64 || md.size() > 1024) { out->score = 3; return; }
+	if (cigar.size() > 32768 || md.size() > 98304) { out->score = 3; return; }      // (the device's limits, k_cigar_long)
 	auto md4 = [&](size_t w) { uint32_t v = 0; for (size_t b = 0; b < 4; ++b) if (4 * w + b < md.size()) v |= (uint32_t)(unsigned char)md[4 * w + b] << (8 * b); return v; };
 	out->score = score; out->n_cigar = (int)cigar.size(); out->nm = NM; out->md_len = (int)md.size();
 	if (ext_ops) {

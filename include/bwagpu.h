@@ -100,11 +100,11 @@ typedef struct {
 /* Banded global alignment of one region as mem_reg2aln's band-doubling loop around bwa_gen_cigar2 leaves it
  * (bwamem.c:1143-1152, bwa.c:148-234): score, BAM-style CIGAR (len << 4 | op, op M=0 I=1 D=2) before clipping and before
  * the leading/trailing-deletion squeeze, and the NM / MD values computed from it (bwa.c:196-226).  n_cigar 1..6: the operations are
- * in cigar[]; n_cigar 7..64: they are entries [at, at + n_cigar) of the batch's operation array (bwagpu_batch_cigar_ops),
- * at = cigar[1] << 32 | cigar[0].  MD: md_len characters; up to 8 of them are the bytes of `md` (first character in the low byte),
+ * in cigar[]; n_cigar > 6 (up to 32768: a 10 kb read with 13 % indels has ~2500): they are entries [at, at + n_cigar) of the batch's
+ * operation array (bwagpu_batch_cigar_ops), at = cigar[1] << 32 | cigar[0].  MD: md_len characters; up to 8 of them are the bytes of `md` (first character in the low byte),
  * longer strings are packed four to an entry (first character in the low byte) at entries [md, md + (md_len + 3) / 4) of the
- * operation array.  n_cigar == -1: not computed on the device (region below opt->T, outside the kernel's limits, or more than
- * 64 operations; `score` then holds the reason 1/2/3, nm is -1) -- the caller runs bwa_gen_cigar2 itself. */
+ * operation array.  n_cigar == -1: not computed on the device (region below opt->T; a band of more than 2048 columns, more than 32768
+ * operations or an MD string of more than 96 KiB; `score` then holds the reason 1/2/3, nm is -1) -- the caller runs bwa_gen_cigar2 itself. */
 typedef struct {
 	int32_t score;
 	int32_t n_cigar;
@@ -215,8 +215,8 @@ typedef struct {
  * same in ring mode (long reads) -> {score, qle, tle, gtle, gscore, max_off, answered-without-DP, cells}; kind 2: ksw_global2 with
  * traceback as k_cigar runs it (ksw.c:540) -> {score, n_ops, ops...} (n_ops -1: more than 64 operations, -2: outside the kernel's
  * limits); kind 3: the score-only ksw_global2 of k_dedup_wave -> {score}; kind 4: ksw_align2 as k_matesw_sw runs it (ksw.c:379)
- * -> {score, te, qe, score2, te2, tb, qb}; kind 5: ksw_global2 with traceback as the long-segment kernel runs it (direction
- * nibbles in HBM) -> like kind 2.  opt supplies the scoring (mat, gap costs, zdrop). */
+ * -> {score, te, qe, score2, te2, tb, qb}; kind 5: ksw_global2 with traceback as the long-segment kernel k_cigar_long runs it (columns
+ * in an LDS ring, direction bytes in HBM, tiled traceback) -> {score, n_ops, up to 70 ops...} (n_ops may exceed 70: the first 70 are returned).  opt supplies the scoring (mat, gap costs, zdrop). */
 int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, int n_cases, const bwagpu_dp_case_t *cases, const uint8_t *seqs, int64_t n_seq_bytes, int32_t *out);
 
 /* ---- optional widening past mem_process_seqs' first loop ---- */

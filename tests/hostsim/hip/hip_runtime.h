@@ -113,6 +113,7 @@ static inline int mock_readlane(int v, int src) { uint64_t o[64], m; mock_exchan
 #define __builtin_amdgcn_readlane(v, l) mock_readlane((v), (l))
 #define __builtin_amdgcn_readfirstlane(v) (v)   /* used only on wave-uniform values */
 #define __builtin_amdgcn_fence(...) ((void)0)
+#define __threadfence() ((void)0)
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define __builtin_amdgcn_wave_barrier() mock_wave_barrier()
 #define HIP_DYNAMIC_SHARED(type, var) type *var = (type*)mock_dyn_lds;

@@ -177,12 +177,15 @@ def run_extend(dev, kind, n, max_len, seed, need_stale):
         assert stale > 0, "no case exercised the stale-cell rule"
 
 
-def global_cases(rng, n, max_len, max_cols):
+def global_cases(rng, n, max_len, max_cols, big_gaps=False):
     cs = CaseSet()
     for it in range(n):
         tlen = int(rng.integers(1, max_len))
         t = rng.integers(0, 4, size=tlen).astype(np.uint8)
         q = _mutate(rng, t, float(rng.choice([0.0, 0.03, 0.12])), float(rng.choice([0.0, 0.01, 0.04])))[:max_len]
+        if big_gaps and it % 3 == 0 and len(q) > 150:      # a gap of 20-70 columns: the traceback leaves a tile row's window
+            p, g = int(rng.integers(40, len(q) - 80)), int(rng.integers(20, 70))
+            q = np.concatenate([q[:p], q[p + g:]]) if it % 2 else np.concatenate([q[:p], rng.integers(0, 4, size=g).astype(np.uint8), q[p:]])
         dl = abs(len(q) - tlen)
         w = dl + 3 + int(rng.integers(0, 40)) if it % 3 else dl + 3
         if min(len(q), 2 * w + 1) > max_cols:
@@ -206,7 +209,7 @@ def run_global(dev, kind, n, max_len, max_cols, seed):
     rng = np.random.default_rng(seed)
     served = 0
     for oi, o in enumerate(_opts()):
-        cs = global_cases(rng, n // 4, max_len, max_cols)
+        cs = global_cases(rng, n // 4, max_len, max_cols, big_gaps=kind == 5)
         cases, seqs = cs.arrays()
         out = dev.debug_dp(o, kind, cases, seqs)
         for k, (q, t, w, _, _) in enumerate(cs.py):
@@ -215,6 +218,14 @@ def run_global(dev, kind, n, max_len, max_cols, seed):
                 if out[k, 1] == -2:
                     continue
                 assert out[k, 0] == sc, f"kind 3 opt {oi} case {k}: {out[k, 0]} vs {sc}"
+                served += 1
+                continue
+            if kind == 5:      # the long-segment kernel: any number of operations (the entry returns the first 70)
+                if out[k, 1] == -2:
+                    continue
+                m = min(70, len(ops))
+                assert out[k, 0] == sc and out[k, 1] == len(ops) and out[k, 2:2 + m].astype(np.uint32).tolist() == ops[:m], \
+                    f"kind 5 opt {oi} case {k}: device {out[k, :2 + m].tolist()} reference {sc} {len(ops)} {ops[:m]} (qlen {len(q)} tlen {len(t)} w {w})"
                 served += 1
                 continue
             if out[k, 1] == -2 or (out[k, 1] == -1 and len(ops) > 64):
@@ -279,6 +290,7 @@ def test_sim_extend_ring_fuzz(sim):
 def test_sim_global_fuzz(sim):
     run_global(sim, 2, 160, 150, 192, 13)
     run_global(sim, 3, 80, 150, 1 << 30, 14)
+    run_global(sim, 5, 48, 420, 2048, 16)
 
 
 def test_sim_align2_fuzz(sim):
@@ -309,6 +321,7 @@ def test_gpu_extend_ring_fuzz(gpu):
 def test_gpu_global_fuzz(gpu):
     run_global(gpu, 2, 5000, 320, 192, 24)
     run_global(gpu, 3, 5000, 600, 1 << 30, 25)
+    run_global(gpu, 5, 2000, 2500, 2048, 27)
 
 
 @pytest.mark.gpu

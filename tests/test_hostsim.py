@@ -257,6 +257,28 @@ def test_hostsim_device_cigars_give_the_same_sam(sim, monkeypatch):
     host.close()
 
 
+def test_hostsim_long_segment_cigars(sim):
+    """The third tier of bwagpu_batch_cigars (k_cigar_long: columns in an LDS ring, direction bytes in HBM, tiled traceback, operations
+    and MD strings of any length): for noisy 1.3 kb -x pacbio reads -- hundreds of operations per alignment -- the records equal the host
+    code's and the hinted SAM equals the plain one; every region is served by the device."""
+    import hostapi
+    prefix, g = testdata.small_index()
+    host = hostapi.HostFinalize(prefix)
+    reads = simdata.make_reads_long(g, 3, length=1300, seed=97)
+    seqs, off = testdata.flat(reads)
+    opt = pacbio_opt()
+    counts, regs = sim.align(opt, seqs, off)
+    cigs, ops = sim.cigars(opt), sim.cigar_ops()
+    want, want_ops = host.region_cigars(opt, seqs, off, counts, regs, with_ops=True)
+    assert hostapi.decode_cigars(cigs, ops) == hostapi.decode_cigars(want, want_ops), "device records differ from the host's"
+    ok = regs["score"] >= opt.T
+    assert (cigs["n_cigar"][ok] > 64).sum() >= 2 and (cigs["n_cigar"][ok] >= 0).all(), cigs["n_cigar"]
+    names = [f"q{i}" for i in range(off.shape[0] - 1)]
+    quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
+    assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs, cig_ops=ops) == host.regs2sam(opt, names, seqs, quals, off, counts, regs)
+    host.close()
+
+
 def test_hostsim_long_reads_ring_extension(sim):
     """Reads beyond the short-read limit take the wave extension kernel in ring mode ({H,E} columns of the band only, lazily
     initialised) -- same regions as the oracle for noisy 1.8 kb reads with the pacbio preset and a 1.5 kb read with defaults (the GPU suite runs 4-5 kb)."""
