@@ -204,12 +204,12 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU (handles sharing the index)")
     ap.add_argument("--dense-sa", type=int, default=4, help="densify the SA on the device to this interval (0 = keep the reference's 32)")
     ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads of the single-end parity / CPU-baseline sample; the paired-end one has this many reads too")
-    ap.add_argument("--e2e-reads", type=int, default=6_000_000)
+    ap.add_argument("--e2e-reads", type=int, default=12_000_000, help="reads of the end-to-end runs (pipeline fill and drain cost ~0.8 s whatever the length)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference runs (and with them the parity gate)")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--parity-pairs", type=int, default=800_000, help="pairs of the multi-batch paired-end parity / CPU-baseline sample (twelve batches)")
     ap.add_argument("--no-longread", action="store_true", help="skip the BASELINE configs[4] leg (10 kb reads, -x pacbio)")
-    ap.add_argument("--long-reads", type=int, default=2000)
+    ap.add_argument("--long-reads", type=int, default=6000)
     ap.add_argument("--long-len", type=int, default=10000)
     ap.add_argument("--long-steps", type=int, default=2)
     ap.add_argument("--long-sample", type=int, default=128, help="reads of the long-read CPU-baseline / parity prefix")
@@ -370,8 +370,9 @@ def main():
         "roofline": {"bound": "hbm", "kernel": roof_k + (" (+ k_seed3: the seeding stage)" if roof_k == "k_seed" else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                      "alg_bytes_per_launch": alg[roof_k], "kernel_ms": round(dur[roof_k], 3),
-                     "alg_bytes_note": "SURVEY 8(d)'s unit: 64 bytes per Occ block the REFERENCE layout would touch (N_blk counted per rank query pair exactly as bwt_2occ4 does), "
-                                       f"whatever the device layout; the device's own blocks are {int(blk_bytes)} bytes",
+                     "alg_bytes_note": "SURVEY 8(d)'s unit: 64 bytes per Occ block of the REFERENCE layout (N_blk counted per rank-query pair exactly as bwt_2occ4 does, 1 if k and l share a 128-base block else 2), "
+                                       f"16 bytes per prefix-table entry, l_seq/2 for the read; the device's own index blocks are {int(blk_bytes)} bytes, see achieved_device_layout",
+                     "achieved_device_layout": round((alg["k_seed"] - (64.0 - blk_bytes) * work["n_occ_blocks"]) / (dur["k_seed"] * 1e-3) / 1e9, 2) if roof_k == "k_seed" and dur["k_seed"] > 0 else None,
                      "per_kernel": {k: {"ms": round(dur[k], 3), "alg_GB": round(alg[k] / 1e9, 3), "GB/s": round(alg[k] / (dur[k] * 1e-3) / 1e9, 1) if dur[k] > 0 else None} for k in dur},
                      "random_request_ceiling": {"requests_per_s_by_bytes": {str(k): v for k, v in ceil.items()},
                                                 "source": "tools/randbw2.hip on MI355X (profiles/r02_experiments.md): dependent random reads from a 4 GiB table saturate at 48.3 / 37.8 / 23.0 G/s for 16 / 32 / 64-byte requests",
@@ -528,8 +529,13 @@ def longread_bench(args, prefix, g, threads, cache):
     if ref:
         res["cpu_baseline"] = {"value": round(ref["reads_per_s"], 1), "unit": "reads/s", "cores": threads, "kind": "reference",
                                "sample": f"first {n_p} reads, `bwa mem -x pacbio -t {threads} -K 100000000`, rate from its own per-batch real-time lines; {ref['wall_s']:.1f}s wall"}
-    if our:
-        res["end_to_end"] = {"reads_per_s": round(our["reads_per_s"], 1), "stages": our["stages"], "what": f"`bwa-amd mem -x pacbio -t {threads}` on the same {n_p} reads, FASTQ -> SAM"}
+    # ---- the product on the whole batch: FASTQ -> SAM rate with the CIGARs, NM and MD of the long alignments computed on the device ----
+    fq_all = os.path.join(cache, "long_all.fq")
+    simdata.write_fastq(fq_all, reads)
+    e2e = run_product(prefix, [fq_all], threads, None, extra=["-x", "pacbio"], timeout=200, K=max(100000000, n * L // 3))
+    if e2e:
+        res["end_to_end"] = {"reads_per_s": round(e2e["reads_per_s"], 1), "Mbp_per_s": round(e2e["reads_per_s"] * L / 1e6, 2), "stages": e2e["stages"],
+                             "what": f"`bwa-amd mem -x pacbio -t {threads}` on all {n} reads, FASTQ -> SAM (SAM discarded; the prefix's SAM is what `parity` compares)"}
     if ref and our:
         a, b = sam_body_digest(os.path.join(cache, "ref_long.sam")), sam_body_digest(os.path.join(cache, "our_long.sam"))
         res["parity"] = bool(a == b and a[1] >= n_p)

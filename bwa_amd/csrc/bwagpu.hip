@@ -72,6 +72,7 @@ struct bwagpu_s {
 	// batch
 	int n_reads = 0, max_len = 0; i64 n_bases = 0;
 	bool have_batch = false, ran = false;
+	int cigar_filter = 0;           // bwagpu_set_cigar_filter
 	int stats_on = 0, taps_on = 0;       // stage taps cost a second region arena and a copy per batch: off unless a test asks (bwagpu_set_taps)
 	bwagpu_stats_t stats = {};
 	volatile int phase = 0;       // progress marker for bwagpu_debug_phase (diagnostics of a stuck call)
@@ -394,7 +395,7 @@ extern "C" int bwagpu_clone(bwagpu_t *src, bwagpu_t **out)
 	h->bwt_blocks = src->bwt_blocks; h->bwt_bytes = src->bwt_bytes; h->sa_bytes = src->sa_bytes; h->pac_bytes = src->pac_bytes;
 	h->bwt_size = src->bwt_size; h->n_sa = src->n_sa;
 	h->h_ctg_off = src->h_ctg_off; h->h_ctg_len = src->h_ctg_len; h->h_ctg_alt = src->h_ctg_alt;
-	h->stats_on = src->stats_on; h->taps_on = src->taps_on;
+	h->stats_on = src->stats_on; h->taps_on = src->taps_on; h->cigar_filter = src->cigar_filter;
 	*out = h;
 	return BWAGPU_OK;
 }
@@ -435,7 +436,7 @@ static int clone_to_device_impl(bwagpu_t *src, int device, bwagpu_t **out)
 	h->bwt_blocks = src->bwt_blocks; h->bwt_bytes = src->bwt_bytes; h->sa_bytes = src->sa_bytes; h->pac_bytes = src->pac_bytes;
 	h->bwt_size = src->bwt_size; h->n_sa = src->n_sa;
 	h->h_ctg_off = src->h_ctg_off; h->h_ctg_len = src->h_ctg_len; h->h_ctg_alt = src->h_ctg_alt;
-	h->stats_on = src->stats_on; h->taps_on = src->taps_on;
+	h->stats_on = src->stats_on; h->taps_on = src->taps_on; h->cigar_filter = src->cigar_filter;
 	*out = h;
 	return BWAGPU_OK;
 }
@@ -501,6 +502,7 @@ extern "C" int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16])
 }
 
 extern "C" int bwagpu_set_stats(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->stats_on = enable ? 1 : 0; return BWAGPU_OK; }
+extern "C" int bwagpu_set_cigar_filter(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->cigar_filter = enable ? 1 : 0; return BWAGPU_OK; }
 extern "C" int bwagpu_set_taps(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->taps_on = enable ? 1 : 0; return BWAGPU_OK; }
 extern "C" int bwagpu_get_stats(const bwagpu_t *h, bwagpu_stats_t *out) { if (!h || !out) return BWAGPU_EINVAL; *out = h->stats; return BWAGPU_OK; }
 
@@ -951,7 +953,7 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		// widest band the kernel takes, as many workgroups as 24 GiB hold (at most 1024)
 		const bool long_tier = !(getenv("BWAGPU_CIG_LONG") && atoi(getenv("BWAGPU_CIG_LONG")) == 0);
 		i64 z_cap = ((i64)h->max_len + h->max_len / 2 + 64) * CIGL_MAX_COLS; z_cap = (z_cap + 15) & ~(i64)15;
-		int n_long = (int)(((i64)24 << 30) / z_cap); if (n_long > 1024) n_long = 1024; if (n_long < 8) n_long = 8;
+		int n_long = (int)(((i64)24 << 30) / z_cap); if (n_long > 1024) n_long = 1024; if (n_long > tot) n_long = (int)tot; if (n_long < 8) n_long = 8;
 		if (h->max_len <= CIG_MAX_LEN && n_long > 256) n_long = 256;
 		if (long_tier && (h->d_cigl_z.ensure((size_t)z_cap * n_long) || h->d_cigl_ops.ensure((size_t)n_long * CIGL_MAX_OPS * 4) || h->d_cigl_md.ensure((size_t)n_long * CIGL_MD_CAP))) {
 			free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
@@ -969,7 +971,7 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 				i64 nblk = (tot + wpb - 1) / wpb, cap = 256 * 6;
 				hipLaunchKernelGGL(k_cigar, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, tot,
 								   h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_pack_read.as<i32>(), h->d_cigs.as<bwagpu_cigar_t>(), next, zc[tier], tier,
-								   h->d_cig_ext.as<u32>(), ext_used, ext_cap);
+								   h->d_cig_ext.as<u32>(), ext_used, ext_cap, h->cigar_filter ? h->d_pack_off.as<i64>() : (const i64*)nullptr);
 				e = hipGetLastError();
 			}
 			if (e == hipSuccess && long_tier) {

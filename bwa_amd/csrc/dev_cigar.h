@@ -487,8 +487,12 @@ __global__ void __launch_bounds__(64) k_cigar_long(DevIndex ix, bwagpu_opt_t opt
 
 // One wavefront per packed region (bwagpu_batch_download's order); regions below the output threshold T are skipped.
 // tier 0 visits every region and defers (n_cigar = -2) those whose band needs more LDS than z_cells; tier 1 redoes exactly those.
+// best_of: null, or for every read the index of its first (best-scoring) packed region: with it, regions that overlap the read's best region
+// and score below XA_drop_ratio times its score are left uncomputed (reason 1) -- the finalize stage hardly ever asks for them (they are
+// neither a line of their own nor within reach of an XA list, bwamem_extra.c:118-134), and should it ask, it computes them itself.  They are the
+// expensive ones: diverged repeat copies whose low score means a wide band (bwamem.c:818-825).
 __global__ void __launch_bounds__(256) k_cigar(DevIndex ix, bwagpu_opt_t opt, Batch B, i64 n_regs, const bwagpu_alnreg_t *regs, const i32 *reg_read, bwagpu_cigar_t *out,
-											   unsigned long long *next, int z_cells, int tier, u32 *ext, unsigned long long *ext_used, i64 ext_cap)
+											   unsigned long long *next, int z_cells, int tier, u32 *ext, unsigned long long *ext_used, i64 ext_cap, const i64 *best_of)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, cig_lds)
 	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -508,6 +512,14 @@ __global__ void __launch_bounds__(256) k_cigar(DevIndex ix, bwagpu_opt_t opt, Ba
 		const bwagpu_alnreg_t p = regs[g];
 		if (p.score < opt.T) { if (lane == 0) { out[g].score = 1; out[g].n_cigar = -1; out[g].nm = -1; out[g].md_len = 0; out[g].md = 0; for (int k = 0; k < CIG_MAX_OPS; ++k) out[g].cigar[k] = 0; } continue; }
 		const int r = reg_read[g];
+		if (best_of) {
+			const bwagpu_alnreg_t &b = regs[best_of[r]];
+			const int lo = p.qb > b.qb ? p.qb : b.qb, hi = p.qe < b.qe ? p.qe : b.qe, ml = p.qe - p.qb < b.qe - b.qb ? p.qe - p.qb : b.qe - b.qb;
+			if (hi > lo && hi - lo >= ml * opt.mask_level && p.score < b.score * opt.XA_drop_ratio) {
+				if (lane == 0) { out[g].score = 1; out[g].n_cigar = -1; out[g].nm = -1; out[g].md_len = 0; out[g].md = 0; for (int k = 0; k < CIG_MAX_OPS; ++k) out[g].cigar[k] = 0; }
+				continue;
+			}
+		}
 		cigar_region(ix, opt, B.seq + B.off[r], p, L, out + g, ext, ext_used, ext_cap);
 		if (tier > 0 && lane == 0 && out[g].n_cigar == -2) out[g].n_cigar = -1;
 	}

@@ -1,7 +1,7 @@
 // dev_dedup.h -- mem_sort_dedup_patch (bwamem.c:463-515) with mem_patch_reg (bwamem.c:432-461), whose global
 // alignment is bwa_gen_cigar2 in score-only mode (bwa.c:148-194) -> ksw_global2 without traceback (ksw.c:604-619).
 #pragma once
-#include "dev_ext.h"
+#include "dev_extw.h"
 
 #define DEV_NEG_INF (-0x40000000)
 
@@ -143,10 +143,11 @@ __global__ void __launch_bounds__(256) k_dedup(DevIndex ix, bwagpu_opt_t opt, Ba
 	i32 *H = B.dp_h + (size_t)wave * (B.max_len + 2) * DPS + lane;
 	i32 *E = B.dp_e + (size_t)wave * (B.max_len + 2) * DPS + lane;
 	u64 calls = 0, cells = 0, nreg = 0;
-	for (;;) {
-		const int r = (int)atomicAdd(&B.ctr->next_dedup, 1ull);
-		if (r >= B.n_reads) break;
-		dedup_read(ix, opt, B, r, H, E, calls, cells); nreg += B.reg_n[r];
+	for (;;) {       // reads are drawn 64 at a time, one atomic per wave: a million same-address atomics are ~13 ms on this chip, the whole of this kernel's time
+		const long long base = wave_fetch_n(&B.ctr->next_dedup, 64);
+		if (base >= B.n_reads) break;
+		const int r = (int)base + lane;
+		if (r < B.n_reads) { dedup_read(ix, opt, B, r, H, E, calls, cells); nreg += B.reg_n[r]; }
 	}
 	if (B.stats) {
 		atomicAdd(&B.ctr->glb_calls, (unsigned long long)calls);

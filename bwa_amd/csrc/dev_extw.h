@@ -551,9 +551,10 @@ template <bool RING, int OCC> __global__ void __launch_bounds__(256, OCC) k_exte
 	u64 calls = 0, cells = 0, refb = 0, nraw = 0, fast = 0;
 	// Reads are handed out heaviest first from a global counter: a wave that drew light reads simply draws more of them, and
 	// the launch needs no particular relation between its grid and the number of resident workgroups.
+	WaveQueue wq; wq_init(wq);                       // (the heaviest reads one at a time, the bulk in chunks: an eighth of the atomics on the counter)
 	for (;;) {
-		const long long k = wave_fetch(&B.ctr->next_ext);
-		if (k >= B.n_reads) break;
+		long long k;
+		if (!wq_next(wq, &B.ctr->next_ext, B.n_reads, k)) break;
 		const int r = B.order[k];
 		ext_read_wave<RING>(ix, opt, B, r, L, calls, cells, refb, fast);
 		wave_sync();

@@ -100,7 +100,7 @@ template <int O32 = -1> DEVFN int fm_extend1(const DevIndex &ix, const BiIntv &i
 		const uint4 sk0 = sk[0], sk1 = sk[1], sl0 = sl[0], sl1 = sl[1];
 		occ32_counts(rk, wk, sk0, sk1, (int)(kk & 63), tk);
 		occ32_counts(rl, wl, sl0, sl1, (int)(ll & 63), tl);
-		nblk = (kk >> 6) == (ll >> 6) ? 1 : 2;
+		nblk = (kk >> 7) == (ll >> 7) ? 1 : 2;                     // (counted in the reference's 128-base blocks, SURVEY 8d's N_blk, whatever the layout read)
 	} else {
 		const OccBlock bk = load_block(ix, kk >> 7), bl = load_block(ix, ll >> 7);
 		block_occ4_bf(bk, (int)(kk & 127), tk);

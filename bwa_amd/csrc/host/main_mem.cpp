@@ -530,6 +530,7 @@ int main(int argc, char *argv[])
 		if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s\n", "main_mem", bwagpu_strerror(rc)); return 1; }
 	}
 	bwagpu_set_taps(gpu, 0);
+	bwagpu_set_cigar_filter(gpu, getenv("BWAGPU_CLI_CIGAR_FILTER") ? atoi(getenv("BWAGPU_CLI_CIGAR_FILTER")) : 1);   // (clones inherit it)
 	{	// SA look-ups walk ~31 LF steps with the reference's interval of 32; HBM has room for a denser array (same values)
 		const int dense = getenv("BWAGPU_CLI_DENSE_SA") ? atoi(getenv("BWAGPU_CLI_DENSE_SA")) : 4;
 		if (dense > 0) { int rc = bwagpu_densify_sa(gpu, dense); if (rc != BWAGPU_OK && g_verbose >= 2) fprintf(stderr, "[W::%s] SA not densified: %s\n", "main_mem", bwagpu_strerror(rc)); }

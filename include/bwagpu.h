@@ -224,6 +224,11 @@ int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, int n_cases,
  * are what worker2's mem_reg2aln (bwamem.c:1119-1152) would compute on the host for that region; a finalize stage can use
  * them instead of calling bwa_gen_cigar2 (NM/MD are still derived on the host from the CIGAR).  Free with bwagpu_free. */
 int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_cigar_t **out, int64_t *n_out);
+/* Enable (1) / disable (0, default) a filter in bwagpu_batch_cigars: regions that overlap their read's best region (by mask_level, as
+ * mem_mark_primary_se judges overlap, bwamem.c:519-545) and score below XA_drop_ratio times its score are not computed (reason 1).  Such a
+ * region is neither printed nor listed in an XA tag (bwamem_extra.c:118-134) unless a third region stands between the two, so a finalize stage
+ * that treats the records as hints loses nothing but the rare recomputation -- and the device skips its most expensive alignments. */
+int bwagpu_set_cigar_filter(bwagpu_t *h, int enable);
 /* The operation array of the last bwagpu_batch_cigars call (records with more than 6 operations point into it).  Free with bwagpu_free. */
 int bwagpu_batch_cigar_ops(bwagpu_t *h, uint32_t **ops, int64_t *n_ops);
 

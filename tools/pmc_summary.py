@@ -25,7 +25,8 @@ def main():
     note, fd, wd = sys.argv[1:4]
     dst = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(__file__), "..", "profiles", "pmc_latest.json")
     F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
-    res = {"_note": note}
+    import datetime
+    res = {"_note": note, "_meta": {"what": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, round-3 kernels", "date": datetime.date.today().isoformat()}}
     for k in sorted(F, key=lambda k: -max(F[k])):
         if not k.startswith("k_"):
             continue
@@ -47,7 +48,7 @@ def main():
         res["k_seed"] = res[(plain or seeds)[0]]
     json.dump(res, open(dst, "w"), indent=1)
     for k, v in res.items():
-        if k != "_note":
+        if not k.startswith("_"):
             print(f"{k:20s} fetch {v['FETCH_SIZE_KB']*1024/1e9:8.2f} GB  write {v['WRITE_SIZE_KB']*1024/1e9:8.2f} GB  x{v['launches_seen']}")
 
 
