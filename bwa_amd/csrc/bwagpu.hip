@@ -540,6 +540,45 @@ static const int MAX_RESIDENT_THREADS = 256 * 2048;   // 256 CUs x 32 waves x 64
 static const int WAVE_EXT_MAX_LEN = 1100;
 static const int SEED_LDS_ENT = 10;                     // 10 x 16 B x 256 lanes = 40 KiB of LDS per block -> 4 blocks (16 waves) per CU; measured best of {4,7,10,15}               // 4 waves x (8+5) B/column must fit the 64 KiB dynamic-LDS limit
 
+// first guess of a batch's arena sizes from its shape (n_reads, n_bases, max_len); grown on overflow
+static void size_arenas(bwagpu_t *h)
+{
+	const int n = h->n_reads;
+	i64 nb = h->n_bases > 1024 ? h->n_bases : 1024;
+	h->slot_cap = nb / 3 + 4096;     // (a 3.1 Gbp repeat-rich genome needs ~0.26 slots and ~0.15 region records per base)
+	h->node_cap = h->slot_cap / 4 + 2 * (i64)n + 64;
+	h->reg_cap = nb / 5 + 4096;
+	// capacity of one read's interval list: reads keep ~10-30 intervals whatever their length class; grown x4 on overflow
+	h->mem_cap = h->max_len / 3 < 64 ? 64 : h->max_len / 3;
+	// what earlier batches -- of this handle or of another handle on the same index -- turned out to need carries over
+	{
+		std::lock_guard<std::mutex> l(h->ibuf->m);
+		if (h->ibuf->need_slot > h->need_slot) h->need_slot = h->ibuf->need_slot;
+		if (h->ibuf->need_node > h->need_node) h->need_node = h->ibuf->need_node;
+		if (h->ibuf->need_reg > h->need_reg) h->need_reg = h->ibuf->need_reg;
+		if (h->ibuf->need_mem > h->need_mem) h->need_mem = h->ibuf->need_mem;
+	}
+	if ((i64)(h->need_slot * nb) > h->slot_cap) h->slot_cap = (i64)(h->need_slot * nb);
+	if ((i64)(h->need_node * nb) > h->node_cap) h->node_cap = (i64)(h->need_node * nb);
+	if ((i64)(h->need_reg * nb) > h->reg_cap) h->reg_cap = (i64)(h->need_reg * nb);
+	if (h->need_mem > h->mem_cap) h->mem_cap = h->need_mem;
+	if (getenv("BWAGPU_MEM_CAP")) h->mem_cap = atoi(getenv("BWAGPU_MEM_CAP"));   // test hook: force the overflow/retry path
+}
+
+// resident lanes of the lane-per-read kernels: enough to fill the chip, bounded by the seeding scratch budget (2 interval stacks per lane)
+static int resident_threads(const bwagpu_t *h)
+{
+	const int BLOCK_ = 256;
+	size_t per_lane = (size_t)(h->max_len + 1 + PTAB_MAX) * sizeof(BiIntv) + (size_t)2 * (h->max_len + 2) * 4;
+	size_t budget = (size_t)12 << 30;
+	i64 max_thr = (i64)(budget / per_lane);
+	if (max_thr > 256 * 2048) max_thr = 256 * 2048;
+	if (max_thr < BLOCK_) max_thr = BLOCK_;
+	int n_threads = (int)(((i64)h->n_reads + BLOCK_ - 1) / BLOCK_ * BLOCK_);
+	if (n_threads > max_thr) n_threads = (int)(max_thr / BLOCK_ * BLOCK_);
+	return n_threads;
+}
+
 extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, const int64_t *off)
 {
 	if (!h || n < 0 || (n > 0 && (!seqs || !off))) return BWAGPU_EINVAL;
@@ -576,26 +615,7 @@ extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, cons
 		}
 		HIPCHK(h, wait_stream(h));
 	}
-	// first guess of the arena sizes (grown on overflow)
-	i64 nb = h->n_bases > 1024 ? h->n_bases : 1024;
-	h->slot_cap = nb / 3 + 4096;     // (a 3.1 Gbp repeat-rich genome needs ~0.26 slots and ~0.15 region records per base)
-	h->node_cap = h->slot_cap / 4 + 2 * (i64)n + 64;
-	h->reg_cap = nb / 5 + 4096;
-	// capacity of one read's interval list: reads keep ~10-30 intervals whatever their length class; grown x4 on overflow
-	h->mem_cap = h->max_len / 3 < 64 ? 64 : h->max_len / 3;
-	// what earlier batches -- of this handle or of another handle on the same index -- turned out to need carries over
-	{
-		std::lock_guard<std::mutex> l(h->ibuf->m);
-		if (h->ibuf->need_slot > h->need_slot) h->need_slot = h->ibuf->need_slot;
-		if (h->ibuf->need_node > h->need_node) h->need_node = h->ibuf->need_node;
-		if (h->ibuf->need_reg > h->need_reg) h->need_reg = h->ibuf->need_reg;
-		if (h->ibuf->need_mem > h->need_mem) h->need_mem = h->ibuf->need_mem;
-	}
-	if ((i64)(h->need_slot * nb) > h->slot_cap) h->slot_cap = (i64)(h->need_slot * nb);
-	if ((i64)(h->need_node * nb) > h->node_cap) h->node_cap = (i64)(h->need_node * nb);
-	if ((i64)(h->need_reg * nb) > h->reg_cap) h->reg_cap = (i64)(h->need_reg * nb);
-	if (h->need_mem > h->mem_cap) h->mem_cap = h->need_mem;
-	if (getenv("BWAGPU_MEM_CAP")) h->mem_cap = atoi(getenv("BWAGPU_MEM_CAP"));   // test hook: force the overflow/retry path
+	size_arenas(h);
 	h->have_batch = true;
 	return BWAGPU_OK;
 }
@@ -647,6 +667,30 @@ static int order_reads(bwagpu_t *h, const Batch &B, const i32 *weight)
 	return 0;
 }
 
+// Allocate now what a batch of this shape will need -- read arrays, arenas, scratch, packed results: device buffers are only ever grown, so
+// the first real batch of the handle finds them in place instead of spending ~0.4 s in hipMalloc inside the pipeline.
+extern "C" int bwagpu_batch_reserve(bwagpu_t *h, int n_reads, int64_t n_bases, int max_len)
+{
+	if (!h || n_reads <= 0 || n_bases <= 0 || max_len <= 0 || max_len > 0x3fffffff) return BWAGPU_EINVAL;
+	HIPCHK(h, hipSetDevice(h->device));
+	const int n0 = h->n_reads, m0 = h->max_len; const i64 b0 = h->n_bases; const bool have0 = h->have_batch, ran0 = h->ran;
+	const i64 sc0 = h->slot_cap, nc0 = h->node_cap, rc0 = h->reg_cap; const int mc0 = h->mem_cap;
+	h->n_reads = n_reads; h->n_bases = n_bases; h->max_len = max_len;
+	size_arenas(h);
+	int bad = alloc_batch(h, resident_threads(h)) != 0;
+	const u64 n_words = ((u64)n_bases + 15) / 16;
+	const int rdw = max_len <= 256 ? (((max_len + 15) / 16 + 3) & ~3) : 0;
+	bad |= h->d_seq.ensure((size_t)n_bases + 16); bad |= h->d_seq_nib.ensure((size_t)(n_words + 1) * 8); bad |= h->d_off.ensure((size_t)(n_reads + 1) * 8);
+	if (rdw) { bad |= h->d_seq_2b.ensure((size_t)n_reads * rdw * 4 + 64); bad |= h->d_seq_flags.ensure((size_t)n_reads + 16); }
+	const i64 tot = (i64)n_reads * 4;        // (packed results: ~3.2 regions per read on a repeat-rich genome)
+	bad |= h->d_pack_off.ensure((size_t)n_reads * 8); bad |= h->d_regs_packed.ensure((size_t)tot * sizeof(bwagpu_alnreg_t)); bad |= h->d_pack_read.ensure((size_t)tot * 4);
+	bad |= h->d_cigs.ensure((size_t)tot * sizeof(bwagpu_cigar_t)); bad |= h->d_cig_ext.ensure((size_t)(tot * 4 + 65536) * 4);
+	h->n_reads = n0; h->n_bases = b0; h->max_len = m0; h->have_batch = have0; h->ran = ran0;
+	h->slot_cap = sc0; h->node_cap = nc0; h->reg_cap = rc0; h->mem_cap = mc0;
+	if (bad) { h->err = "hipMalloc failed (reserve)"; return BWAGPU_ENOMEM; }
+	return BWAGPU_OK;
+}
+
 extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 {
 	if (!h || !opt || !h->have_batch) return BWAGPU_EINVAL;
@@ -658,13 +702,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 	if (h->n_reads == 0) { h->ran = true; return BWAGPU_OK; }
 	int n = h->n_reads;
 	// resident lanes: enough to fill the chip, bounded by the seeding scratch budget (2 interval stacks per lane)
-	size_t per_lane = (size_t)(h->max_len + 1 + PTAB_MAX) * sizeof(BiIntv) + (size_t)2 * (h->max_len + 2) * 4;
-	size_t budget = (size_t)12 << 30;
-	i64 max_thr = (i64)(budget / per_lane);
-	if (max_thr > MAX_RESIDENT_THREADS) max_thr = MAX_RESIDENT_THREADS;
-	if (max_thr < BLOCK) max_thr = BLOCK;
-	int n_threads = (int)(((i64)n + BLOCK - 1) / BLOCK * BLOCK);
-	if (n_threads > max_thr) n_threads = (int)(max_thr / BLOCK * BLOCK);
+	const int n_threads = resident_threads(h);
 	// mem_flt_chained_seeds thresholds per read length (bwamem.c:626-628); log() stays on the host
 	std::vector<i32> minhsp(h->max_len + 2, -1);
 	bool any_seedsw = false;
@@ -745,8 +783,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		hipLaunchKernelGGL(k_sa, dim3((unsigned)sa_blocks), block, 0, h->stream, h->ix, B);
 		HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_sa", hipGetErrorString(e_)); }
-		if (getenv("BWAGPU_CHAIN_LANE")) hipLaunchKernelGGL(k_chain, grid, block, 0, h->stream, h->ix, *opt, B);   // round-1 lane-per-read kernel (A/B measurements)
-		else {	// wave per read, heaviest reads (most seeds) first; reads that outgrow the LDS tier are redone by the HBM tier
+		{	// wave per read, heaviest reads (most seeds) first; reads that outgrow the LDS tier are redone by the HBM tier
 			if (int rc2 = order_reads(h, B, B.seed_n)) return rc2;
 			i64 nblk = ((i64)n + 3) / 4, cap = 256 * 8;
 			hipLaunchKernelGGL((k_chain_wave<0, 10, 32, 128>), dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)CW_LDS_BYTES(10, 32, 128) * 4, h->stream, h->ix, *opt, B);

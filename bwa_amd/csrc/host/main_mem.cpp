@@ -645,6 +645,9 @@ int main(int argc, char *argv[])
 
 	std::vector<std::thread> devs;
 	for (int d = 0; d < n_dev; ++d) devs.emplace_back([&, d] {      // stage 2: one host thread per device handle
+		// while the reader parses the first batch: the arenas of a batch of -K bases (150 bp reads assumed; anything else grows them later)
+		if (!g_dev_serialize && !(getenv("BWAGPU_CLI_RESERVE") && atoi(getenv("BWAGPU_CLI_RESERVE")) == 0))      // (not under the mock runtime of the CPU tests)
+			for (bwagpu_t *hh : handles[d]) (void)bwagpu_batch_reserve(hh, (int)((int64_t)chunk / 150 / (int64_t)handles[d].size()) + 1024, (int64_t)chunk / (int64_t)handles[d].size() + (1 << 20), 256);
 		WorkP w;
 		while (to_dev.pop(w)) {
 			{ std::unique_lock<std::mutex> l(dm); dcv.wait(l, [&] { return w->no - next_fin <= (long)n_dev; }); }   // do not run ahead of the host

@@ -324,6 +324,9 @@ void bwagpu_free(void *p);
 /* Split form for callers that overlap transfers with compute, and for measuring the device path with the batch
  * already resident in HBM: upload -> run (device only, asynchronous kernels + one final sync) -> download. */
 int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, const int64_t *off);
+/* Optional, any time: allocate the device buffers a batch of about this shape will need (they are only ever grown), so that the handle's
+ * first batch does not pay for them inside a pipeline. */
+int bwagpu_batch_reserve(bwagpu_t *h, int n_reads, int64_t n_bases, int max_len);
 int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt);
 int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg_t **regs_out, int64_t *n_regs_out);
 
