@@ -122,7 +122,7 @@ def _n_rich_reads(g, n, max_len, seed):
 
 @pytest.mark.parametrize("max_len,env", [(150, {}), (250, {}), (120, {"BWAGPU_SEED_NO_VIRT": "1"}), (150, {"BWAGPU_SEED_RD_LDS": "0"}),
                                          (150, {"BWAGPU_PTAB_M": "5", "BWAGPU_SEED_LDS_ENT": "2"}), (150, {"BWAGPU_OCC32": "0"}), (150, {"BWAGPU_OCC32": "0", "BWAGPU_PTAB_M": "0"}), (150, {"BWAGPU_PTAB_M": "0"}),
-                                         (150, {"BWAGPU_OCC32": "0", "BWAGPU_SEED_COOP": "1"}), (150, {"BWAGPU_OCC32": "0", "BWAGPU_SEED_COOP": "1", "BWAGPU_PTAB_M": "0"})])
+                                         (150, {"BWAGPU_OCC32": "0", "BWAGPU_SEED_COOP": "1"})])
 def test_hostsim_seeding_paths_with_n_reads(monkeypatch, max_len, env):
     """The seeding kernel's read copy in LDS (2 bits per base; 8, 12 or 16 words per lane by the batch's longest read; reads with an N
     take their bases from global memory), the short stack entries kept as a bit mask (off with BWAGPU_SEED_NO_VIRT, and narrower with
