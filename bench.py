@@ -532,7 +532,7 @@ def longread_bench(args, prefix, g, threads, cache):
     # ---- the product on the whole batch: FASTQ -> SAM rate with the CIGARs, NM and MD of the long alignments computed on the device ----
     fq_all = os.path.join(cache, "long_all.fq")
     simdata.write_fastq(fq_all, reads)
-    e2e = run_product(prefix, [fq_all], threads, None, extra=["-x", "pacbio"], timeout=200, K=max(1000000, n * L // 6))      # six batches over three device handles
+    e2e = run_product(prefix, [fq_all], threads, None, extra=["-x", "pacbio"], timeout=200, K=max(1000000, n * L // 3 + L))      # one batch per device handle: the long-read kernels are latency-bound (a 1000-read batch takes what a 6000-read one does)
     if e2e:
         res["end_to_end"] = {"reads_per_s": round(e2e["reads_per_s"], 1), "Mbp_per_s": round(e2e["reads_per_s"] * L / 1e6, 2), "stages": e2e["stages"],
                              "device_stage_ms_per_batch": e2e["device_stage_ms_per_batch"],

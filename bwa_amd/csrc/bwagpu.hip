@@ -19,6 +19,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <chrono>
 
 #include "dev_common.h"
 #include "dev_fm.h"
@@ -78,7 +79,8 @@ struct bwagpu_s {
 	volatile int phase = 0;       // progress marker for bwagpu_debug_phase (diagnostics of a stuck call)
 	i64 packed_tot = -1;          // regions packed by the last bwagpu_batch_download (-1: none)
 	DevBuf d_msw_tasks, d_msw_out, d_msw_pes, d_msw_scratch;
-	DevBuf d_cigl_z, d_cigl_ops, d_cigl_md;      // scratch of the long-segment CIGAR tier (k_cigar_long): direction matrices, operations, MD strings per workgroup
+	i64 cigl_z_cap = 0;                          // bytes per direction matrix of the long CIGAR tier's scratch (grows with the batches)
+	DevBuf d_cigl_z, d_cigl_ops, d_cigl_md, d_cigl_list;      // scratch of the long-segment CIGAR tier (k_cigar_long): direction matrices, operations, MD strings per workgroup
 	DevBuf d_cig_ext; i64 cig_ext_n = -1;   // operation array of the last bwagpu_batch_cigars (records with 7..64 operations point into it)
 	DevBuf d_seq_2b, d_seq_flags; int rd_words = 0;   // per-read 2-bit copies for k_seed's LDS (k_pack_reads2b)
 	DevBuf d_pack_off, d_regs_packed, d_pack_read, d_cigs, d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
@@ -302,7 +304,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 		for (DevBuf *b : ib) b->release();
 		delete h->ibuf;
 	}
-	DevBuf *all[] = { &h->d_cigl_z, &h->d_cigl_ops, &h->d_cigl_md, &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
+	DevBuf *all[] = { &h->d_cigl_list, &h->d_cigl_z, &h->d_cigl_ops, &h->d_cigl_md, &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_chain_todo, &h->d_seed_w, &h->d_seed_order, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
@@ -986,14 +988,19 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		if (getenv("BWAGPU_CIG_OPS_CAP")) ext_cap = atoll(getenv("BWAGPU_CIG_OPS_CAP"));   // (tests of the second attempt)
 		if (ext_cap < 1) ext_cap = 1;
 		// third tier (k_cigar_long): segments, bands and operation counts beyond the LDS tiers' limits; one 64-thread workgroup per region at a time,
-		// each with a direction matrix of its own in HBM -- sized for the batch's longest read with half again as many reference bases and the
-		// widest band the kernel takes, as many workgroups as 24 GiB hold (at most 1024)
+		// each with a direction matrix of its own in HBM.  A sizing pass (k_cigar_long_plan) counts the regions the LDS tiers left and the largest
+		// matrix any of them can ask for; the scratch is as many such matrices as there are regions, at most 1024 and at most BWAGPU_CIGL_GIB (16).
 		const bool long_tier = !(getenv("BWAGPU_CIG_LONG") && atoi(getenv("BWAGPU_CIG_LONG")) == 0);
-		i64 z_cap = ((i64)h->max_len + h->max_len / 2 + 64) * CIGL_MAX_COLS; z_cap = (z_cap + 15) & ~(i64)15;
-		int n_long = (int)(((i64)24 << 30) / z_cap); if (n_long > 1024) n_long = 1024; if (n_long > tot) n_long = (int)tot; if (n_long < 8) n_long = 8;
-		if (h->max_len <= CIG_MAX_LEN && n_long > 256) n_long = 256;
-		if (long_tier && (h->d_cigl_z.ensure((size_t)z_cap * n_long) || h->d_cigl_ops.ensure((size_t)n_long * CIGL_MAX_OPS * 4) || h->d_cigl_md.ensure((size_t)n_long * CIGL_MD_CAP))) {
-			free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
+		const i64 cigl_budget = (i64)((getenv("BWAGPU_CIGL_GIB") ? atof(getenv("BWAGPU_CIGL_GIB")) : 16.) * (double)((i64)1 << 30));
+		const bool cig_trace = getenv("BWAGPU_CIG_TRACE") != nullptr;
+		auto t_last = std::chrono::steady_clock::now();
+		auto lap = [&](const char *what) {
+			if (!cig_trace) return;
+			(void)wait_stream(h);
+			auto t = std::chrono::steady_clock::now();
+			fprintf(stderr, "[bwagpu] cigars: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+			t_last = t;
+		};
 		unsigned long long used = 0;
 		hipError_t e = hipSuccess;
 		for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1011,14 +1018,38 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 								   h->d_cig_ext.as<u32>(), ext_used, ext_cap, h->cigar_filter ? h->d_pack_off.as<i64>() : (const i64*)nullptr);
 				e = hipGetLastError();
 			}
+			lap("LDS tiers");
 			if (e == hipSuccess && long_tier) {
-				e = hipMemsetAsync(next, 0, sizeof(unsigned long long), h->stream);
+				unsigned long long *plan_d = h->d_ctr.as<Counters>()->cigl_plan, plan[2] = { 0, 0 };
+				if (h->d_cigl_list.ensure((size_t)tot * 4)) { free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
+				e = hipMemsetAsync(plan_d, 0, sizeof plan, h->stream);
 				if (e == hipSuccess) {
-					h->phase = 44;
-					hipLaunchKernelGGL(k_cigar_long, dim3((unsigned)n_long), dim3(64), (size_t)CIGL_LDS_BYTES, h->stream, h->ix, *opt, B, tot,
-									   h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_pack_read.as<i32>(), h->d_cigs.as<bwagpu_cigar_t>(), next,
-									   h->d_cigl_z.as<u8>(), z_cap, h->d_cigl_ops.as<u32>(), h->d_cigl_md.as<u8>(), h->d_cig_ext.as<u32>(), ext_used, ext_cap);
+					h->phase = 43;
+					i64 nb = (tot + 255) / 256; if (nb > 2048) nb = 2048;
+					hipLaunchKernelGGL(k_cigar_long_plan, dim3((unsigned)nb), dim3(256), 0, h->stream, h->ix, *opt, tot, h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_cigs.as<bwagpu_cigar_t>(), plan_d, h->d_cigl_list.as<i32>());
 					e = hipGetLastError();
+				}
+				if (e == hipSuccess) e = hipMemcpyAsync(plan, plan_d, sizeof plan, hipMemcpyDeviceToHost, h->stream);
+				if (e == hipSuccess) e = wait_stream(h);
+				if (e == hipSuccess && plan[0] > 0 && plan[1] > 0) {
+					// matrices a quarter larger than this batch's largest and a multiple of 1 MiB, so that the next batches rarely re-allocate
+					i64 z_cap = (i64)plan[1] + (i64)plan[1] / 4; z_cap = (z_cap + ((i64)1 << 20) - 1) & ~(((i64)1 << 20) - 1);
+					if (h->cigl_z_cap > z_cap) z_cap = h->cigl_z_cap;
+					i64 n_long = cigl_budget / z_cap; if (n_long > 1024) n_long = 1024; if (n_long > (i64)plan[0]) n_long = (i64)plan[0]; if (n_long < 1) n_long = 1;
+					if (h->d_cigl_z.ensure((size_t)z_cap * n_long) || h->d_cigl_ops.ensure((size_t)n_long * CIGL_MAX_OPS * 4) || h->d_cigl_md.ensure((size_t)n_long * CIGL_MD_CAP)) {
+						free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
+					h->cigl_z_cap = z_cap;
+					if (cig_trace) fprintf(stderr, "[bwagpu] cigars: long tier: %llu regions, largest matrix %.1f MB, %lld workgroups x %.1f MB\n", plan[0], plan[1] / 1e6, (long long)n_long, z_cap / 1e6);
+					lap("long tier plan + scratch");
+					e = hipMemsetAsync(next, 0, sizeof(unsigned long long), h->stream);
+					if (e == hipSuccess) {
+						h->phase = 44;
+						hipLaunchKernelGGL(k_cigar_long, dim3((unsigned)n_long), dim3(64), (size_t)CIGL_LDS_BYTES, h->stream, h->ix, *opt, B, (i64)plan[0], h->d_cigl_list.as<i32>(),
+										   h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_pack_read.as<i32>(), h->d_cigs.as<bwagpu_cigar_t>(), next,
+										   h->d_cigl_z.as<u8>(), z_cap, h->d_cigl_ops.as<u32>(), h->d_cigl_md.as<u8>(), h->d_cig_ext.as<u32>(), ext_used, ext_cap);
+						e = hipGetLastError();
+					}
+					lap("k_cigar_long");
 				}
 			}
 			if (e == hipSuccess) e = hipMemcpyAsync(&used, ext_used, sizeof used, hipMemcpyDeviceToHost, h->stream);
@@ -1186,7 +1217,7 @@ extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, i
 			hipLaunchKernelGGL(k_debug_global_ring, dim3(grid), dim3(64), (size_t)8 * ring_cols + 32, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), ring_cols, d_out.as<i32>());
 		} else if (kind == 5) {
 			int max_t = 1; for (int i = 0; i < n_cases; ++i) if (cases[i].t_len > max_t) max_t = cases[i].t_len;
-			i64 z_cap = ((i64)max_t + 16) * CIGL_MAX_COLS; z_cap = (z_cap + 15) & ~(i64)15;
+			i64 z_cap = ((i64)max_t + 16) * ((CIGL_MAX_COLS + 15) & ~15); z_cap = (z_cap + 15) & ~(i64)15;
 			const int blocks = grid < 64 ? grid : 64;
 			if (d_scr.ensure((size_t)blocks * z_cap) || d_pac2.ensure((size_t)blocks * CIGL_MAX_OPS * 4)) { h->err = "hipMalloc failed (debug)"; rc = BWAGPU_ENOMEM; goto done; }
 			hipLaunchKernelGGL(k_debug_global_long, dim3(blocks), dim3(64), (size_t)CIGL_LDS_BYTES, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), d_scr.as<u8>(), z_cap, d_pac2.as<u32>(), d_out.as<i32>());

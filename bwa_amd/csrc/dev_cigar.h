@@ -263,17 +263,37 @@ __device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const 
 // fetches the path's neighbourhood a tile at a time -- the 48 bytes around the diagonal's column in each of 64 rows -- into LDS and lane 0
 // walks the tile; a path that drifts out of a row's window (more than 16 gap columns within 64 rows) just ends the tile early.  Operations
 // are pushed to the wave's HBM scratch as they complete, in traceback order.
-#define CIGL_MAX_COLS 2048      // widest band (columns per row)
-#define CIGL_RING 4096          // ring of {H,E} columns: >= 2 w + 132 for every band the kernel takes
+#define CIGL_MAX_COLS 1900      // widest band (columns per row)
+#define CIGL_RING 2048          // ring of {H,E} columns: >= 2 w + 132 for every band the kernel takes (2 w + 1 <= CIGL_MAX_COLS)
 #define CIGL_MAX_OPS 32768
 #define CIGL_MD_CAP 98304
 #define CIGL_TILE_W 48
-#define CIGL_LDS_BYTES (2 * CIGL_RING * 4 + 32 + 64 * CIGL_TILE_W + 16)
-struct CigLongLds { i32 *hd, *e; int8_t *mat; u8 *tile; };
+#define CIGL_QCAP 16384         // query bases kept in LDS, in alignment order (longer segments read theirs from the batch)
+#define CIGL_LDS_BYTES (2 * CIGL_RING * 4 + 32 + 64 * CIGL_TILE_W + CIGL_QCAP + 16)
+struct CigLongLds { i32 *hd, *e; int8_t *mat; u8 *tile; u8 *qs; };
 struct CigLongScratch { u8 *z; i64 z_cap; u32 *ops; u8 *md; };
 
-__device__ int wave_ksw_global2_long(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen, i64 t0, int tdir, int tlen,
-									 int w, const CigLongLds &L, const CigLongScratch &S, int *n_ops)
+DEVFN void cigl_lds_setup(unsigned char *lds, CigLongLds &L)
+{
+	L.hd = (i32*)lds; L.e = L.hd + CIGL_RING;
+	L.mat = (int8_t*)(L.e + CIGL_RING);
+	L.tile = (u8*)(lds + 2 * CIGL_RING * 4 + 32);
+	L.qs = L.tile + 64 * CIGL_TILE_W;
+}
+
+// The segment's query bases into LDS, in alignment order (column j's base at qs[j]); false: too long, the DP reads the batch's array.
+DEVFN bool cigl_stage_query(const CigLongLds &L, const u8 *q, int q0, int qdir, int qlen)
+{
+	if (qlen > CIGL_QCAP) return false;
+	const int lane = threadIdx.x & 63;
+	for (int j = lane; j < qlen; j += 64) L.qs[j] = q[q0 + j * qdir];
+	wave_sync();
+	return true;
+}
+
+// The matrix fill (ksw.c:566-619): direction bytes of every band cell to S.z, the score returned.  q_lds: the query is staged (cigl_stage_query).
+__device__ int wave_ksw_global2_long_fill(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen, i64 t0, int tdir, int tlen,
+										  int w, const CigLongLds &L, const CigLongScratch &S, bool q_lds)
 {
 	const int lane = threadIdx.x & 63;
 	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
@@ -302,7 +322,7 @@ __device__ int wave_ksw_global2_long(const DevIndex &ix, const bwagpu_opt_t &opt
 		for (int b = beg; b < end; b += 64) {
 			const int j = b + lane; const bool act = j < end;
 			int dg = hd[j & rm]; const int ec = e_[j & rm];
-			const int qc = j < qlen ? (int)q[q0 + j * qdir] : 4;
+			const int qc = j < qlen ? (q_lds ? (int)L.qs[j] : (int)q[q0 + j * qdir]) : 4;
 			const int sc = L.mat[tb * 5 + qc];
 			const int bnd_next = hd[(b + 64) & rm];
 			if (b != beg && lane == 0) dg = bnd;
@@ -329,9 +349,16 @@ __device__ int wave_ksw_global2_long(const DevIndex &ix, const bwagpu_opt_t &opt
 		wave_sync();
 	}
 	const int score = hd[qlen & rm];
-	__threadfence();                                              // the direction bytes are read back below through other lanes
+	__threadfence();                                              // the direction bytes are read back by the traceback through other lanes
 	wave_sync();
-	// ---- traceback (ksw.c:624-639) ----
+	return score;
+}
+
+// The traceback (ksw.c:624-639) over the direction bytes the fill left in S.z for the same (qlen, tlen, w); operations to S.ops in traceback order.
+__device__ void wave_ksw_global2_long_trace(int qlen, int tlen, int w, const CigLongLds &L, const CigLongScratch &S, int *n_ops)
+{
+	const int lane = threadIdx.x & 63;
+	const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1, zs = (n_col + 15) & ~15;
 	int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, which = 0, n = 0;
 	int cur_op = -1, cur_len = 0;                                 // the run being built (lane 0)
 	while (i >= 0 && k >= 0 && n <= CIGL_MAX_OPS) {
@@ -379,6 +406,14 @@ __device__ int wave_ksw_global2_long(const DevIndex &ix, const bwagpu_opt_t &opt
 	__threadfence();
 	wave_sync();
 	*n_ops = n > CIGL_MAX_OPS ? -1 : n;
+}
+
+__device__ int wave_ksw_global2_long(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen, i64 t0, int tdir, int tlen,
+									 int w, const CigLongLds &L, const CigLongScratch &S, int *n_ops)
+{
+	const bool q_lds = cigl_stage_query(L, q, q0, qdir, qlen);
+	const int score = wave_ksw_global2_long_fill(ix, opt, q, q0, qdir, qlen, t0, tdir, tlen, w, L, S, q_lds);
+	wave_ksw_global2_long_trace(qlen, tlen, w, L, S, n_ops);
 	return score;
 }
 
@@ -400,8 +435,11 @@ __device__ void cigar_region_long(const DevIndex &ix, const bwagpu_opt_t &opt, c
 	w2 = w2 > tmp ? w2 : tmp;
 	if (w2 > opt.w) w2 = w2 < pw ? w2 : pw;
 	int i = 0, score = 0, last_sc = -(1 << 30), n_ops = -1;
+	int w_fill = -1;                                              // band of the last matrix fill whose traceback is still owed
+	const bool q_lds = cigl_stage_query(L, query, q0, qdir, l_query);
 	do {
 		w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+		w_fill = -1;
 		if (l_query == rlen && w2 == 0) {
 			int s = 0;
 			for (int j = lane; j < l_query; j += 64) s += opt.mat[ref_base(ix, t0 + (i64)j * tdir) * 5 + query[q0 + j * qdir]];
@@ -420,13 +458,17 @@ __device__ void cigar_region_long(const DevIndex &ix, const bwagpu_opt_t &opt, c
 			const int min_w = dl + 3; w = w > min_w ? w : min_w;
 			const int n_col = l_query < 2 * w + 1 ? l_query : 2 * w + 1;
 			if (n_col > CIGL_MAX_COLS || (i64)rlen * ((n_col + 15) & ~15) > S.z_cap) return;
-			score = wave_ksw_global2_long(ix, opt, query, q0, qdir, l_query, t0, tdir, rlen, w, L, S, &n_ops);
-			if (n_ops < 0) return;
+			score = wave_ksw_global2_long_fill(ix, opt, query, q0, qdir, l_query, t0, tdir, rlen, w, L, S, q_lds);
+			w_fill = w;                                           // (the reference traces every attempt back; only the last one's CIGAR is used)
 		}
 		if (score == last_sc || w2 == opt.w << 2) break;
 		last_sc = score;
 		w2 <<= 1;
 	} while (++i < 3 && score < truesc - opt.a);
+	if (w_fill >= 0) {
+		wave_ksw_global2_long_trace(l_query, rlen, w_fill, L, S, &n_ops);
+		if (n_ops < 0) return;
+	}
 	int md_len = 0;
 	const int nm = wave_nm_md(ix, query, q0, qdir, t0, tdir, !rev, S.ops, n_ops, S.md, CIGL_MD_CAP, &md_len);
 	if (md_len > CIGL_MD_CAP) return;
@@ -454,34 +496,52 @@ __device__ void cigar_region_long(const DevIndex &ix, const bwagpu_opt_t &opt, c
 	wave_sync();
 }
 
+// Sizing pass of the third tier: list[0 .. plan[0]) = the regions the LDS tiers left uncomputed, plan[1] = the largest direction matrix (bytes)
+// any of them can ask for -- the widest band cigar_region_long's loop can reach is max(min((max_gap + dl + 1) / 2, 4 opt.w), dl + 3).
+__global__ void __launch_bounds__(256) k_cigar_long_plan(DevIndex ix, bwagpu_opt_t opt, i64 n_regs, const bwagpu_alnreg_t *regs, const bwagpu_cigar_t *out, unsigned long long *plan, i32 *list)
+{
+	unsigned long long need = 0;
+	for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < n_regs; g += (i64)gridDim.x * blockDim.x) {
+		if (!(out[g].n_cigar < 0 && out[g].score != 1)) continue;
+		const bwagpu_alnreg_t &p = regs[g];
+		const int l_query = p.qe - p.qb;
+		if (!(l_query > 0 && p.rb < p.re && !(p.rb < ix.l_pac && p.re > ix.l_pac) && p.re - p.rb < (1 << 24) && l_query < (1 << 24))) continue;
+		const int rlen = (int)(p.re - p.rb);
+		int max_ins = trunc_div_add(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins, opt.e_ins, 1);
+		int max_del = trunc_div_add(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del, opt.e_del, 1);
+		int max_gap = max_ins > max_del ? max_ins : max_del; max_gap = max_gap > 1 ? max_gap : 1;
+		const int dl = rlen > l_query ? rlen - l_query : l_query - rlen;
+		int w = (max_gap + dl + 1) >> 1; w = w < opt.w << 2 ? w : opt.w << 2;
+		w = w > dl + 3 ? w : dl + 3;
+		int n_col = l_query < 2 * w + 1 ? l_query : 2 * w + 1;
+		list[atomicAdd(plan, 1ull)] = (i32)g;                     // the tier's work list (a handful per short-read batch, every region of a long-read one)
+		if (n_col > CIGL_MAX_COLS) n_col = (dl + 3) * 2 + 1 <= CIGL_MAX_COLS ? CIGL_MAX_COLS : 0;      // (attempts over the limit leave the region to the host)
+		const unsigned long long b = (unsigned long long)rlen * (unsigned long long)((n_col + 15) & ~15);
+		need = b > need ? b : need;
+	}
+	if (need) atomicMax(plan + 1, need);
+}
+
 // Third tier of bwagpu_batch_cigars: one wavefront per region the LDS tiers left uncomputed for their limits (segments over CIG_MAX_LEN bases,
-// bands over CIG_MAX_COLS columns, more than CIG_TMP_OPS operations).  64 threads per workgroup; scratch: one CigLongScratch per workgroup.
-__global__ void __launch_bounds__(64) k_cigar_long(DevIndex ix, bwagpu_opt_t opt, Batch B, i64 n_regs, const bwagpu_alnreg_t *regs, const i32 *reg_read, bwagpu_cigar_t *out,
+// bands over CIG_MAX_COLS columns, more than CIG_TMP_OPS operations), drawn one at a time from k_cigar_long_plan's list.  64 threads per
+// workgroup; scratch: one CigLongScratch per workgroup.
+__global__ void __launch_bounds__(64) k_cigar_long(DevIndex ix, bwagpu_opt_t opt, Batch B, i64 n_list, const i32 *list, const bwagpu_alnreg_t *regs, const i32 *reg_read, bwagpu_cigar_t *out,
 													unsigned long long *next, u8 *z_all, i64 z_cap, u32 *ops_all, u8 *md_all, u32 *ext, unsigned long long *ext_used, i64 ext_cap)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, cigl_lds)
 	const int lane = threadIdx.x & 63;
 	CigLongLds L;
-	L.hd = (i32*)cigl_lds; L.e = L.hd + CIGL_RING;
-	L.mat = (int8_t*)(L.e + CIGL_RING);
-	L.tile = (u8*)(cigl_lds + 2 * CIGL_RING * 4 + 32);
+	cigl_lds_setup(cigl_lds, L);
 	if (lane < 25) L.mat[lane] = opt.mat[lane];
 	CigLongScratch S;
 	S.z = z_all + (i64)blockIdx.x * z_cap; S.z_cap = z_cap; S.ops = ops_all + (size_t)blockIdx.x * CIGL_MAX_OPS; S.md = md_all + (size_t)blockIdx.x * CIGL_MD_CAP;
 	wave_sync();
-	for (;;) {       // records are drawn 256 at a time and screened 64 at a time: nearly all of a short-read batch's are already computed
-		const long long base = wave_fetch_n(next, 256);
-		if (base >= n_regs) break;
-		for (int c = 0; c < 256; c += 64) {
-			const long long g = base + c + lane;
-			u64 todo = __ballot(g < n_regs && out[g].n_cigar < 0 && out[g].score != 1);   // not computed by an LDS tier, and not below the output threshold
-			while (todo) {
-				const int l = __builtin_ctzll(todo); todo &= todo - 1;
-				const long long gg = base + c + l;
-				const bwagpu_alnreg_t p = regs[gg];
-				cigar_region_long(ix, opt, B.seq + B.off[reg_read[gg]], p, L, S, out + gg, ext, ext_used, ext_cap);
-			}
-		}
+	for (;;) {
+		const long long k = wave_fetch(next);
+		if (k >= n_list) break;
+		const long long gg = uni(list[k]);
+		const bwagpu_alnreg_t p = regs[gg];
+		cigar_region_long(ix, opt, B.seq + B.off[reg_read[gg]], p, L, S, out + gg, ext, ext_used, ext_cap);
 	}
 }
 

@@ -93,6 +93,7 @@ struct Counters {          // device-side bump allocators + flags
 	unsigned long long prof[16];                   // diagnostics (bwagpu_debug_prof): [12] k_seed iterations that read the interval stack from HBM, [13..15] its wave iterations, bookkeeping iterations, extending lanes (stats runs)
 	unsigned long long ext_fast;                   // ksw_extend2 calls answered by the diagonal rule (no DP)
 	unsigned long long bt_nodes, chain_recs;       // B-tree nodes visited by look-ups / chain records touched (k_chain's algorithmic bytes)
+	unsigned long long cigl_plan[2];               // k_cigar_long_plan: regions left to the long CIGAR tier, bytes of the largest direction matrix among them
 };
 #define seed_used seed_used_.v
 #define node_used node_used_.v

@@ -143,9 +143,7 @@ __global__ void __launch_bounds__(64) k_debug_global_long(DevIndex ix, bwagpu_op
 	HIP_DYNAMIC_SHARED(unsigned char, dbg_lds)
 	const int lane = threadIdx.x & 63;
 	CigLongLds L;
-	L.hd = (i32*)dbg_lds; L.e = L.hd + CIGL_RING;
-	L.mat = (int8_t*)(L.e + CIGL_RING);
-	L.tile = (u8*)(dbg_lds + 2 * CIGL_RING * 4 + 32);
+	cigl_lds_setup(dbg_lds, L);
 	if (lane < 25) L.mat[lane] = opt.mat[lane];
 	CigLongScratch S;
 	S.z = z_all + (i64)blockIdx.x * z_cap; S.z_cap = z_cap; S.ops = ops_all + (size_t)blockIdx.x * CIGL_MAX_OPS; S.md = nullptr;

@@ -76,6 +76,7 @@ static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long l
 static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
 static inline unsigned long long atomicOr(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p |= v; return o; }
+static inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 static inline unsigned int atomicAdd(unsigned int *p, unsigned int v) { unsigned int o = *p; *p += v; return o; }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
 

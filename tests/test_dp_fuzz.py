@@ -290,7 +290,7 @@ def test_sim_extend_ring_fuzz(sim):
 def test_sim_global_fuzz(sim):
     run_global(sim, 2, 160, 150, 192, 13)
     run_global(sim, 3, 80, 150, 1 << 30, 14)
-    run_global(sim, 5, 48, 420, 2048, 16)
+    run_global(sim, 5, 48, 420, 1900, 16)
 
 
 def test_sim_align2_fuzz(sim):
@@ -321,7 +321,7 @@ def test_gpu_extend_ring_fuzz(gpu):
 def test_gpu_global_fuzz(gpu):
     run_global(gpu, 2, 5000, 320, 192, 24)
     run_global(gpu, 3, 5000, 600, 1 << 30, 25)
-    run_global(gpu, 5, 2000, 2500, 2048, 27)
+    run_global(gpu, 5, 2000, 2500, 1900, 27)
 
 
 @pytest.mark.gpu

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=3100.0)
     ap.add_argument("--reads", type=int, default=20000)
     ap.add_argument("--read-len", type=int, default=10000)
+    ap.add_argument("--cigars", action="store_true")
     ap.add_argument("--cache", default=os.environ.get("BWA_AMD_CACHE", "/tmp/bwa_amd_bench"))
     a = ap.parse_args()
     import torch
@@ -36,6 +37,11 @@ def main():
     t = time.time(); gpu.run(opt); dt = time.time() - t
     st = gpu.stats()
     counts, regs = gpu.download()
+    if a.cigars:       # the CIGAR stage as `bwa-amd mem` drives it; BWAGPU_CIG_TRACE=1 splits it into its launches on stderr
+        for k in range(2):
+            t = time.time(); cg = gpu.cigars(opt); ops = gpu.cigar_ops(); dtc = time.time() - t
+            served = int((cg["n_cigar"] >= 0).sum())
+            print(f"[longread] cigars pass {k}: {dtc:.2f}s for {cg.shape[0]} regions ({served} with a device CIGAR, {ops.shape[0] / 1e6:.1f} M extension entries)", flush=True)
     print(f"[longread] {a.reads} x {a.read_len} bp -x pacbio: first pass {dt0:.2f}s, second {dt:.2f}s -> {a.reads / dt:.0f} reads/s ({a.reads * a.read_len / dt / 1e6:.1f} Mbp/s); "
           f"regions {regs.shape[0]}, retries {st['n_retries']}, stage ms: " + ", ".join(f"{k[3:]} {st[k]:.0f}" for k in ("ms_seed", "ms_sa", "ms_chain", "ms_seedsw", "ms_extend", "ms_dedup")), flush=True)
 
