@@ -159,6 +159,33 @@ def test_hostsim_occ32_layout_across_superblocks(monkeypatch):
     orc.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"BWAGPU_OCC32": "0"}])
+def test_hostsim_densified_sa_equals_the_walk(monkeypatch, env):
+    """bwagpu_densify_sa fills the new samples from one LF walk per OLD sample (k_densify); every kept row must hold what the oracle's
+    bwt_sa returns for it (bwt.c:91-103), including row 0 (-1), the primary row and the last row, at intervals 8, 2 and 1."""
+    import ctypes as C
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    prefix, _ = testdata.small_index()
+    orc = orcapi.OrcIndex(prefix)
+    for intv in (8, 2, 1):
+        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+        meta0 = s2.index_meta()
+        s2.densify_sa(intv)
+        meta = s2.index_meta()
+        assert meta["sa_intv"] == intv and meta["n_sa"] == (meta["seq_len"] + intv) // intv and meta0["sa_intv"] == 32
+        ptr, nbytes = s2.index_buffers()[1]
+        assert nbytes == meta["n_sa"] * 8
+        sa = np.frombuffer((C.c_uint64 * meta["n_sa"]).from_address(ptr), dtype=np.uint64)     # (mock runtime: device memory is host memory)
+        assert sa[0] == np.uint64(2 ** 64 - 1)
+        rows = np.arange(1, meta["n_sa"], max(1, meta["n_sa"] // 4000)).tolist() + [meta["n_sa"] - 1, meta["primary"] // intv, meta["primary"] // intv + 1]
+        for r in rows:
+            if 0 < r < meta["n_sa"]:
+                assert int(sa[r]) == orc.sa(r * intv), f"interval {intv}, row {r * intv}"
+        s2.close()
+    orc.close()
+
+
 def test_hostsim_min_seed_len_around_the_table_depth(sim):
     """-k at, below and just above the prefix tables' depth (10): at or below it short matches can be reported, so every stack
     entry is stored; just above it the shortest stored entry is the one a backward row has just grown to the tables' depth."""
