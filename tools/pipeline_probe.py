@@ -17,7 +17,9 @@ while argv and argv[0].startswith("--"):
     argv = argv[2:]
 prefix, g, _ = bench.build_or_load_index(float(os.environ.get("MBP", "3100")), "/tmp/bwa_amd_bench", 0, lambda: None)
 opt = default_opt(); opt.flag |= 2
-gpu = BwaGpu(prefix); gpu.densify_sa(4); gpu.set_taps(False)
+gpu = BwaGpu(prefix)
+_t = time.perf_counter(); gpu.densify_sa(4); print(f"[densify 32 -> 4] {time.perf_counter() - _t:.3f} s", flush=True)
+gpu.set_taps(False)
 handles = [gpu] + [gpu.clone() for _ in range(S - 1)]
 for si, h in enumerate(handles):
     r1, r2 = simdata.make_reads_pe(g, 500_000, seed=1000 + si)
