@@ -284,7 +284,7 @@ def test_hostsim_device_cigars_give_the_same_sam(sim, monkeypatch):
     host.close()
 
 
-def test_hostsim_long_segment_cigars(sim):
+def test_hostsim_long_segment_cigars(sim, monkeypatch):
     """The third tier of bwagpu_batch_cigars (k_cigar_long: columns in an LDS ring, direction bytes in HBM, tiled traceback, operations
     and MD strings of any length): for noisy 1.3 kb -x pacbio reads -- hundreds of operations per alignment -- the records equal the host
     code's and the hinted SAM equals the plain one; every region is served by the device."""
@@ -300,6 +300,10 @@ def test_hostsim_long_segment_cigars(sim):
     assert hostapi.decode_cigars(cigs, ops) == hostapi.decode_cigars(want, want_ops), "device records differ from the host's"
     ok = regs["score"] >= opt.T
     assert (cigs["n_cigar"][ok] > 64).sum() >= 2 and (cigs["n_cigar"][ok] >= 0).all(), cigs["n_cigar"]
+    monkeypatch.setenv("BWAGPU_CIGL_GIB", "0.000001")       # a scratch budget below one direction matrix: one workgroup takes the tier's whole work list
+    cigs1, ops1 = sim.cigars(opt), sim.cigar_ops()
+    assert hostapi.decode_cigars(cigs1, ops1) == hostapi.decode_cigars(cigs, ops)
+    monkeypatch.delenv("BWAGPU_CIGL_GIB")
     names = [f"q{i}" for i in range(off.shape[0] - 1)]
     quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
     assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs, cig_ops=ops) == host.regs2sam(opt, names, seqs, quals, off, counts, regs)
