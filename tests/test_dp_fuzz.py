@@ -294,7 +294,7 @@ def test_sim_global_fuzz(sim):
 
 
 def test_sim_align2_fuzz(sim):
-    run_align2(sim, 60, 15)
+    run_align2(sim, 40, 15)
 
 
 # ---- GPU ----------------------------------------------------------------------------------------------------------------------

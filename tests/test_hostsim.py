@@ -291,7 +291,7 @@ def test_hostsim_long_segment_cigars(sim, monkeypatch):
     import hostapi
     prefix, g = testdata.small_index()
     host = hostapi.HostFinalize(prefix)
-    reads = simdata.make_reads_long(g, 3, length=1300, seed=97)
+    reads = simdata.make_reads_long(g, 2, length=1300, seed=97)
     seqs, off = testdata.flat(reads)
     opt = pacbio_opt()
     counts, regs = sim.align(opt, seqs, off)
@@ -329,7 +329,7 @@ def test_hostsim_device_matesw_records_match_the_host(sim):
     from bwa_amd.api import MATESW_DTYPE, PES_DTYPE
     prefix, g = testdata.small_index()
     host = hostapi.HostFinalize(prefix)
-    r1, r2 = simdata.make_reads_pe(g, 60, seed=98)
+    r1, r2 = simdata.make_reads_pe(g, 40, seed=98)
     rng = np.random.default_rng(99)
     r2 = np.where(rng.random(r2.shape) < 0.14, (r2 + rng.integers(1, 4, r2.shape)) % 4, r2).astype(np.uint8)
     reads = np.empty((2 * r1.shape[0], r1.shape[1]), dtype=np.uint8); reads[0::2], reads[1::2] = r1, r2
