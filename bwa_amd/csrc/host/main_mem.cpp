@@ -3,6 +3,9 @@
 // (chunk_size * n_threads bases per batch unless -K, fastmap.c:394), same SAM header (bwa.c:407-439), so that for the same
 // input and the same -K the output equals `bwa mem`'s except for the @PG line.
 #include <ctype.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <getopt.h>
 #include <math.h>
 #include <stdio.h>
@@ -72,9 +75,40 @@ struct Seq { size_t name = 0, comment = 0, seq = 0, qual = 0; int l_name = 0, l_
 typedef std::vector<char> Arena;
 
 struct Reader {
-	gzFile fp = nullptr; std::vector<char> buf; int pos = 0, len = 0; int last = 0; bool eof = false;
-	bool open(const char *fn) { fp = strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(fileno(stdin), "r"); if (fp) gzbuffer(fp, 1 << 20); buf.resize(1 << 20); return fp != nullptr; }
-	bool fill() { if (eof) return false; len = gzread(fp, buf.data(), (unsigned)buf.size()); pos = 0; if (len <= 0) { len = 0; eof = true; return false; } return true; }
+	gzFile fp = nullptr; int raw_fd = -1; std::vector<char> buf; int pos = 0, len = 0; int last = 0; bool eof = false;
+	// A regular file that does not start with the gzip magic is read with read(2) straight into the parse buffer: zlib's transparent mode
+	// would copy every byte twice more on the thread that paces the pipeline.  Everything else (gzip files, stdin) goes through zlib as in
+	// the reference (kseq.h over gzread, fastmap.c:357-372).
+	bool open(const char *fn) {
+		buf.resize(1 << 20);
+		if (strcmp(fn, "-")) {
+			const int fd = ::open(fn, O_RDONLY);
+			if (fd < 0) return false;
+			unsigned char magic[2] = { 0, 0 };
+			struct stat st;
+			if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && pread(fd, magic, 2, 0) >= 0 && !(magic[0] == 0x1f && magic[1] == 0x8b)) { raw_fd = fd; return true; }
+			fp = gzdopen(fd, "r");
+			if (!fp) ::close(fd);
+		} else fp = gzdopen(fileno(stdin), "r");
+		if (fp) gzbuffer(fp, 1 << 20);
+		return fp != nullptr;
+	}
+	bool fill() {
+		if (eof) return false;
+		if (raw_fd >= 0) { do len = (int)::read(raw_fd, buf.data(), buf.size()); while (len < 0 && errno == EINTR); }
+		else len = gzread(fp, buf.data(), (unsigned)buf.size());
+		pos = 0;
+		if (len <= 0) { len = 0; eof = true; return false; }
+		return true;
+	}
+	// does any of the n bytes at p hold a blank or control character (<= ' ')?  Eight bytes per step.
+	static bool has_blank(const char *p, size_t n) {
+		const uint64_t ones = ~0ull / 255;
+		size_t i = 0;
+		for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); if ((w - ones * 0x21) & ~w & (ones * 0x80)) return true; }
+		for (; i < n; ++i) if ((unsigned char)p[i] <= ' ') return true;
+		return false;
+	}
 	int getc_() { if (pos >= len && !fill()) return -1; return (unsigned char)buf[pos++]; }
 	// append the bytes up to the next delimiter (newline, or any white space when `space`) to `out` and consume the delimiter;
 	// returns the delimiter, or -1 at end of input.  Whole buffer spans are copied at once.
@@ -105,7 +139,7 @@ struct Reader {
 		const size_t ls = (size_t)(n2 - sq), lq = (size_t)(n4 - ql);
 		if (ls == 0 || ls != lq || n1[-1] == '\r' || n2[-1] == '\r' || n4[-1] == '\r') return false;
 		if (sq[0] == '>' || sq[0] == '+' || sq[0] == '@') return false;              // the general reader treats these as record structure
-		for (size_t i = 0; i < ls; ++i) if ((unsigned char)sq[i] <= ' ') return false;   // blanks / control characters: general path
+		if (has_blank(sq, ls)) return false;                                           // blanks / control characters: general path
 		const char *h = b + 1, *he = n1, *ne = h;
 		while (ne < he && !isspace((unsigned char)*ne)) ++ne;
 		s = Seq();
