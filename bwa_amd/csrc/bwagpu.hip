@@ -16,6 +16,7 @@
 #include <string.h>
 #include <math.h>
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -119,7 +120,60 @@ extern "C" const char *bwagpu_strerror(int code)
 	}
 }
 extern "C" const char *bwagpu_last_error(const bwagpu_t *h) { return h ? h->err.c_str() : ""; }
-extern "C" void bwagpu_free(void *p) { free(p); }
+// ---- result buffers ------------------------------------------------------------------------------------------------
+// The large per-batch results (regions, CIGAR records, operation array, mate-rescue records: ~300 MB per 667 k reads) are copied out of the
+// device with hipMemcpyAsync.  Into malloc'ed memory the runtime stages such a copy through bounce buffers; into page-locked memory it is one
+// DMA at the link's rate.  Page-locking itself costs more than the copy, so the blocks are kept: bwagpu_free puts a pooled block back,
+// result_alloc hands out the smallest free block that fits (sizes are rounded up so that consecutive batches find each other's blocks).
+// Results under 1 MiB (BWAGPU_PINNED_MIN_KB), and everything when BWAGPU_PINNED_RESULTS=0, come from malloc as before.  The pool is bounded (4 GiB page-locked).
+namespace {
+struct ResultPool {
+	std::mutex m;
+	std::map<void*, size_t> live;                   // blocks handed out -> capacity
+	std::multimap<size_t, void*> idle;              // capacity -> block
+	size_t pinned = 0;
+	const size_t cap_total = (size_t)4 << 30;
+	void *get(size_t bytes)
+	{
+		const bool enabled = !(getenv("BWAGPU_PINNED_RESULTS") && atoi(getenv("BWAGPU_PINNED_RESULTS")) == 0);
+		const size_t min_bytes = getenv("BWAGPU_PINNED_MIN_KB") ? (size_t)atoll(getenv("BWAGPU_PINNED_MIN_KB")) << 10 : (size_t)1 << 20;   // (tests: 0 pools everything)
+		if (!enabled || bytes < min_bytes) return malloc(bytes ? bytes : 1);
+		size_t want = (size_t)1 << 20; while (want < bytes) want += want >> 2 > ((size_t)1 << 20) ? (want >> 2) & ~(((size_t)1 << 20) - 1) : (size_t)1 << 20;   // 1 MiB steps, then ~25 % steps
+		{
+			std::lock_guard<std::mutex> l(m);
+			auto it = idle.lower_bound(bytes);
+			if (it != idle.end() && it->first <= want * 2) { void *p = it->second; live[p] = it->first; idle.erase(it); return p; }
+			if (pinned + want > cap_total) {           // make room: drop idle blocks, smallest first
+				while (!idle.empty() && pinned + want > cap_total) { auto b = idle.begin(); (void)hipHostFree(b->second); pinned -= b->first; idle.erase(b); }
+				if (pinned + want > cap_total) return malloc(bytes);
+			}
+			pinned += want;
+		}
+		void *p = nullptr;
+		if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess || !p) {
+			(void)hipGetLastError();
+			std::lock_guard<std::mutex> l(m); pinned -= want;
+			return malloc(bytes);
+		}
+		std::lock_guard<std::mutex> l(m);
+		live[p] = want;
+		return p;
+	}
+	void put(void *p)
+	{
+		if (!p) return;
+		{
+			std::lock_guard<std::mutex> l(m);
+			auto it = live.find(p);
+			if (it != live.end()) { idle.emplace(it->second, p); live.erase(it); return; }
+		}
+		free(p);
+	}
+};
+ResultPool g_results;
+}
+static void *result_alloc(size_t bytes) { return g_results.get(bytes); }
+extern "C" void bwagpu_free(void *p) { g_results.put(p); }
 
 static int upload(bwagpu_t *h, DevBuf &b, const void *src, size_t bytes)
 {
@@ -960,11 +1014,11 @@ extern "C" int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg
 	HIPCHK(h, wait_stream(h));
 	i64 tot = 0;
 	for (int i = 0; i < n; ++i) { dst[i] = tot; tot += cnt[i]; if (counts) counts[i] = cnt[i]; }
-	bwagpu_alnreg_t *res = (bwagpu_alnreg_t*)malloc((size_t)(tot ? tot : 1) * sizeof(bwagpu_alnreg_t));
+	bwagpu_alnreg_t *res = (bwagpu_alnreg_t*)result_alloc((size_t)(tot ? tot : 1) * sizeof(bwagpu_alnreg_t));
 	if (!res) return BWAGPU_ENOMEM;
 	h->phase = 31;
 	if (tot) {
-		if (h->d_pack_off.ensure((size_t)n * 8) || h->d_regs_packed.ensure((size_t)tot * sizeof(bwagpu_alnreg_t)) || h->d_pack_read.ensure((size_t)tot * 4)) { free(res); h->err = "hipMalloc failed (packed regions)"; return BWAGPU_ENOMEM; }
+		if (h->d_pack_off.ensure((size_t)n * 8) || h->d_regs_packed.ensure((size_t)tot * sizeof(bwagpu_alnreg_t)) || h->d_pack_read.ensure((size_t)tot * 4)) { bwagpu_free(res); h->err = "hipMalloc failed (packed regions)"; return BWAGPU_ENOMEM; }
 		h->phase = 32;
 		hipError_t e = hipMemcpyAsync(h->d_pack_off.p, dst.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream);
 		if (e == hipSuccess) {
@@ -975,7 +1029,7 @@ extern "C" int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg
 		}
 		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_regs_packed.p, (size_t)tot * sizeof(bwagpu_alnreg_t), hipMemcpyDeviceToHost, h->stream);
 		if (e == hipSuccess) e = wait_stream(h);
-		if (e != hipSuccess) { free(res); HIPCHK(h, e); }
+		if (e != hipSuccess) { bwagpu_free(res); HIPCHK(h, e); }
 	}
 	h->packed_tot = tot; h->phase = 39;
 	*regs_out = res; *n_regs_out = tot;
@@ -990,10 +1044,10 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 	const i64 tot = h->packed_tot;
 	h->phase = 40; h->cig_ext_n = -1;
 	static_assert(sizeof(bwagpu_cigar_t) == 48, "layout");
-	bwagpu_cigar_t *res = (bwagpu_cigar_t*)malloc((size_t)(tot ? tot : 1) * sizeof(bwagpu_cigar_t));
+	bwagpu_cigar_t *res = (bwagpu_cigar_t*)result_alloc((size_t)(tot ? tot : 1) * sizeof(bwagpu_cigar_t));
 	if (!res) return BWAGPU_ENOMEM;
 	if (tot) {
-		if (h->d_cigs.ensure((size_t)tot * sizeof(bwagpu_cigar_t)) || h->d_ctr.ensure(sizeof(Counters))) { free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
+		if (h->d_cigs.ensure((size_t)tot * sizeof(bwagpu_cigar_t)) || h->d_ctr.ensure(sizeof(Counters))) { bwagpu_free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
 		Batch B = {}; B.seq = h->d_seq.as<u8>(); B.off = h->d_off.as<i64>(); B.n_reads = h->n_reads; B.max_len = h->max_len;
 		unsigned long long *next = &h->d_ctr.as<Counters>()->next_ext, *ext_used = &h->d_ctr.as<Counters>()->cig_ext_used;
 		const int zc[2] = { CIG_Z_SMALL, CIG_Z_BIG };
@@ -1021,7 +1075,7 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		unsigned long long used = 0;
 		hipError_t e = hipSuccess;
 		for (int attempt = 0; attempt < 2; ++attempt) {
-			if (h->d_cig_ext.ensure((size_t)ext_cap * 4)) { free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
+			if (h->d_cig_ext.ensure((size_t)ext_cap * 4)) { bwagpu_free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
 			e = hipMemsetAsync(ext_used, 0, sizeof(unsigned long long), h->stream);
 			for (int tier = 0; tier < n_tier && e == hipSuccess; ++tier) {   // narrow bands at high occupancy, then the deferred wide ones
 				e = hipMemsetAsync(next, 0, sizeof(unsigned long long), h->stream);
@@ -1038,7 +1092,7 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 			lap("LDS tiers");
 			if (e == hipSuccess && long_tier) {
 				unsigned long long *plan_d = h->d_ctr.as<Counters>()->cigl_plan, plan[2] = { 0, 0 };
-				if (h->d_cigl_list.ensure((size_t)tot * 4)) { free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
+				if (h->d_cigl_list.ensure((size_t)tot * 4)) { bwagpu_free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
 				e = hipMemsetAsync(plan_d, 0, sizeof plan, h->stream);
 				if (e == hipSuccess) {
 					h->phase = 43;
@@ -1054,7 +1108,7 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 					if (h->cigl_z_cap > z_cap) z_cap = h->cigl_z_cap;
 					i64 n_long = cigl_budget / z_cap; if (n_long > 1024) n_long = 1024; if (n_long > (i64)plan[0]) n_long = (i64)plan[0]; if (n_long < 1) n_long = 1;
 					if (h->d_cigl_z.ensure((size_t)z_cap * n_long) || h->d_cigl_ops.ensure((size_t)n_long * CIGL_MAX_OPS * 4) || h->d_cigl_md.ensure((size_t)n_long * CIGL_MD_CAP)) {
-						free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
+						bwagpu_free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
 					h->cigl_z_cap = z_cap;
 					if (cig_trace) fprintf(stderr, "[bwagpu] cigars: long tier: %llu regions, largest matrix %.1f MB, %lld workgroups x %.1f MB\n", plan[0], plan[1] / 1e6, (long long)n_long, z_cap / 1e6);
 					lap("long tier plan + scratch");
@@ -1077,7 +1131,7 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		h->phase = 45;
 		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_cigs.p, (size_t)tot * sizeof(bwagpu_cigar_t), hipMemcpyDeviceToHost, h->stream);
 		if (e == hipSuccess) e = wait_stream(h);
-		if (e != hipSuccess) { free(res); h->cig_ext_n = -1; HIPCHK(h, e); }
+		if (e != hipSuccess) { bwagpu_free(res); h->cig_ext_n = -1; HIPCHK(h, e); }
 		h->cig_ext_n = (i64)used < ext_cap ? (i64)used : ext_cap;
 	}
 	if (tot == 0) h->cig_ext_n = 0;
@@ -1090,9 +1144,9 @@ extern "C" int bwagpu_batch_cigar_ops(bwagpu_t *h, uint32_t **ops, int64_t *n_op
 	if (!h || !ops || !n_ops || h->cig_ext_n < 0) return BWAGPU_EINVAL;
 	HIPCHK(h, hipSetDevice(h->device));
 	const i64 n = h->cig_ext_n;
-	uint32_t *res = (uint32_t*)malloc((size_t)(n ? n : 1) * 4);
+	uint32_t *res = (uint32_t*)result_alloc((size_t)(n ? n : 1) * 4);
 	if (!res) return BWAGPU_ENOMEM;
-	if (n) { hipError_t e = hipMemcpyAsync(res, h->d_cig_ext.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream); if (e == hipSuccess) e = wait_stream(h); if (e != hipSuccess) { free(res); HIPCHK(h, e); } }
+	if (n) { hipError_t e = hipMemcpyAsync(res, h->d_cig_ext.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream); if (e == hipSuccess) e = wait_stream(h); if (e != hipSuccess) { bwagpu_free(res); HIPCHK(h, e); } }
 	*ops = res; *n_ops = n;
 	return BWAGPU_OK;
 }
@@ -1124,7 +1178,7 @@ extern "C" int bwagpu_batch_matesw(bwagpu_t *h, const bwagpu_opt_t *opt, const b
 	HIPCHK(h, hipMemcpyAsync(&nt, n_tasks, 8, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(h, wait_stream(h));
 	if ((i64)nt > task_cap) nt = (unsigned long long)task_cap;
-	bwagpu_matesw_t *res = (bwagpu_matesw_t*)malloc((size_t)(nt ? nt : 1) * sizeof(bwagpu_matesw_t));
+	bwagpu_matesw_t *res = (bwagpu_matesw_t*)result_alloc((size_t)(nt ? nt : 1) * sizeof(bwagpu_matesw_t));
 	if (!res) return BWAGPU_ENOMEM;
 	if (nt) {
 		Batch B = {}; B.seq = h->d_seq.as<u8>(); B.off = h->d_off.as<i64>(); B.n_reads = n; B.max_len = h->max_len;
@@ -1134,7 +1188,7 @@ extern "C" int bwagpu_batch_matesw(bwagpu_t *h, const bwagpu_opt_t *opt, const b
 		hipError_t e = hipGetLastError();
 		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_msw_out.p, (size_t)nt * sizeof(bwagpu_matesw_t), hipMemcpyDeviceToHost, h->stream);
 		if (e == hipSuccess) e = wait_stream(h);
-		if (e != hipSuccess) { free(res); HIPCHK(h, e); }
+		if (e != hipSuccess) { bwagpu_free(res); HIPCHK(h, e); }
 	}
 	*out = res; *n_out = (int64_t)nt;
 	return BWAGPU_OK;

@@ -65,6 +65,9 @@ static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); if (*p) memset(*p, 0xCB, n < ((size_t)32 << 20) ? (n ? n : 1) : ((size_t)32 << 20));   /* (the first 32 MiB: scratch areas sized for a whole chip are never touched otherwise) */ return *p ? hipSuccess : hipErrorMock; }
 template <class T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+#define hipHostMallocDefault 0
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); if (*p) memset(*p, 0xCD, n < ((size_t)1 << 20) ? n : ((size_t)1 << 20)); return *p ? hipSuccess : hipErrorMock; }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }

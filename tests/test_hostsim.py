@@ -284,6 +284,24 @@ def test_hostsim_device_cigars_give_the_same_sam(sim, monkeypatch):
     host.close()
 
 
+def test_hostsim_pooled_result_buffers(sim, monkeypatch):
+    """The large per-batch results come from a pool of page-locked blocks that bwagpu_free refills (a threshold of 0 KiB sends the small
+    results of this test through it): the same records as with plain malloc, over several batches of different sizes, blocks re-used."""
+    prefix, g = testdata.small_index()
+    opt = default_opt()
+    sets = [testdata.flat(simdata.make_reads_se(g, n, seed=170 + n, sub=0.03, dele=0.004, ins=0.004)) for n in (10, 4, 10)]
+    want = []
+    monkeypatch.setenv("BWAGPU_PINNED_RESULTS", "0")
+    for seqs, off in sets:
+        c, r = sim.align(opt, seqs, off)
+        want.append((c.copy(), r.copy(), sim.cigars(opt).copy(), sim.cigar_ops().copy()))
+    monkeypatch.delenv("BWAGPU_PINNED_RESULTS"); monkeypatch.setenv("BWAGPU_PINNED_MIN_KB", "0")
+    for (seqs, off), (c0, r0, g0, o0) in zip(sets, want):
+        c, r = sim.align(opt, seqs, off)
+        cg, ops = sim.cigars(opt), sim.cigar_ops()
+        assert np.array_equal(c, c0) and r.tobytes() == r0.tobytes() and cg.tobytes() == g0.tobytes() and ops.tobytes() == o0.tobytes()
+
+
 def test_hostsim_long_segment_cigars(sim, monkeypatch):
     """The third tier of bwagpu_batch_cigars (k_cigar_long: columns in an LDS ring, direction bytes in HBM, tiled traceback, operations
     and MD strings of any length): for noisy 1.3 kb -x pacbio reads -- hundreds of operations per alignment -- the records equal the host

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """End-to-end throughput of the stand-alone `bwa-amd mem` (FASTQ in -> SAM out) on the bench genome; GPU box only.
 
-usage: e2e_bench.py [--genome-mbp 512] [--reads 1000000] [--threads 64,128] [--streams 1,2,3] [--pe]
-Prints one line per configuration: wall reads/s as reported by the program after the index was loaded."""
+usage: e2e_bench.py [--genome-mbp 3100] [--reads 1000000] [--threads 16] [--streams 3] [--pe] [--env "NAME=VALUE ...;NAME=VALUE ..."]
+Prints one line per configuration (threads x streams x environment set): wall reads/s as reported by the program after the index was
+loaded, its stage busy times, and the device stage's mean step times per batch."""
 import argparse, os, re, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,16 +13,17 @@ from bwa_amd import simdata
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--genome-mbp", type=float, default=512.0)
+    ap.add_argument("--genome-mbp", type=float, default=3100.0)
     ap.add_argument("--reads", type=int, default=1_000_000)
-    ap.add_argument("--threads", default="64,128")
-    ap.add_argument("--streams", default="1,2,3")
+    ap.add_argument("--threads", default="16")
+    ap.add_argument("--streams", default="3")
+    ap.add_argument("--env", default="", help="environment sets to compare, separated by ';' (an empty set = defaults)")
     ap.add_argument("--chunk", default="100000000")
     ap.add_argument("--pe", action="store_true")
     ap.add_argument("--cache", default=os.environ.get("BWA_AMD_CACHE", "/tmp/bwa_amd_bench"))
     a = ap.parse_args()
     import torch
-    fa, g = bench.build_or_load_index(a.genome_mbp, a.cache, 0, lambda: torch.cuda.synchronize())
+    fa, g, _ = bench.build_or_load_index(a.genome_mbp, a.cache, 0, lambda: torch.cuda.synchronize())
     t = time.time()
     if a.pe:
         r1, r2 = simdata.make_reads_pe(g, a.reads // 2, seed=77)
@@ -36,14 +38,21 @@ def main():
     cli = os.path.join(ROOT, "bwa_amd", "bwa-amd")
     for th in a.threads.split(","):
         for st in a.streams.split(","):
-            env = dict(os.environ, BWAGPU_CLI_STREAMS=st)
-            t = time.time()
-            p = subprocess.run([cli, "mem", "-t", th, "-K", a.chunk, "-v", "3", fa] + files, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=env)
-            m = re.search(r"\[M::main_mem\] (\d+) reads in ([\d.]+) sec .*: (\d+) reads/s", p.stderr)
-            print(f"[e2e] {'PE' if a.pe else 'SE'} -t {th} streams {st} -K {a.chunk}: rc={p.returncode} {m.group(0) if m else p.stderr[-300:]}  (process wall {time.time() - t:.1f}s)", flush=True)
-            m2 = re.search(r"stage busy time: .*", p.stderr)
-            if m2:
-                print("[e2e]    " + m2.group(0), flush=True)
+            for es in a.env.split(";"):
+                env = dict(os.environ, BWAGPU_CLI_STREAMS=st, BWAGPU_CLI_TRACE="1")
+                env.update(dict(kv.split("=", 1) for kv in es.split()))
+                t = time.time()
+                p = subprocess.run([cli, "mem", "-t", th, "-K", a.chunk, "-v", "3", fa] + files, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=env)
+                m = re.search(r"\[M::main_mem\] (\d+) reads in ([\d.]+) sec .*: (\d+) reads/s", p.stderr)
+                print(f"[e2e] {'PE' if a.pe else 'SE'} -t {th} streams {st} [{es.strip() or 'defaults'}]: rc={p.returncode} {m.group(0) if m else p.stderr[-300:]}  (process wall {time.time() - t:.1f}s)", flush=True)
+                m2 = re.search(r"stage busy time: .*", p.stderr)
+                if m2:
+                    print("[e2e]    " + m2.group(0), flush=True)
+                steps = re.findall(r"upload ([\d.]+) run ([\d.]+) download\+cigars ([\d.]+) pestat\+matesw ([\d.]+) s", p.stderr)
+                if steps:
+                    k = len(steps)
+                    print("[e2e]    device stage per batch (ms, mean of %d): upload %.1f, hot path %.1f, download + CIGARs %.1f, pestat + mate rescue %.1f" %
+                          ((k,) + tuple(1e3 * sum(float(x[i]) for x in steps) / k for i in range(4))), flush=True)
 
 
 if __name__ == "__main__":
