@@ -1235,13 +1235,13 @@ extern "C" int bwagpu_align_bseq(bwagpu_t *h, const bwagpu_opt_t *opt, int n, bw
 		if (!regs[i].a) {   // leave no half-filled output behind
 			for (int j = 0; j < i; ++j) { free(regs[j].a); regs[j].a = nullptr; regs[j].n = regs[j].m = 0; }
 			regs[i].n = regs[i].m = 0;
-			free(all);
+			bwagpu_free(all);
 			return BWAGPU_ENOMEM;
 		}
 		memcpy(regs[i].a, all + k, (size_t)counts[i] * sizeof(bwagpu_alnreg_t));
 		k += counts[i];
 	}
-	free(all);
+	bwagpu_free(all);
 	return BWAGPU_OK;
 }
 

@@ -222,7 +222,7 @@ int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, int n_cases,
 /* ---- optional widening past mem_process_seqs' first loop ---- */
 /* After bwagpu_batch_download: one bwagpu_cigar_t per downloaded region, in the same order, computed on the device.  They
  * are what worker2's mem_reg2aln (bwamem.c:1119-1152) would compute on the host for that region; a finalize stage can use
- * them instead of calling bwa_gen_cigar2 (NM/MD are still derived on the host from the CIGAR).  Free with bwagpu_free. */
+ * them instead of calling bwa_gen_cigar2 (the records carry NM and the MD string as well, bwa.c:196-238).  Free with bwagpu_free. */
 int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_cigar_t **out, int64_t *n_out);
 /* Enable (1) / disable (0, default) a filter in bwagpu_batch_cigars: regions that overlap their read's best region (by mask_level, as
  * mem_mark_primary_se judges overlap, bwamem.c:519-545) and score below XA_drop_ratio times its score are not computed (reason 1).  Such a
@@ -315,11 +315,12 @@ int bwagpu_get_stats(const bwagpu_t *h, bwagpu_stats_t *out);
 int bwagpu_align_bseq(bwagpu_t *h, const bwagpu_opt_t *opt, int n, bwagpu_bseq1_t *seqs, bwagpu_alnreg_v *regs);
 
 /* Flat form of the same call: reads are nt4 codes (0..4) concatenated in `seqs`, read i = seqs[off[i]..off[i+1]).
- *   counts[i] = number of regions of read i; *regs_out = malloc()ed array of all regions in read order
- *   (caller frees with bwagpu_free); *n_regs_out = total. */
+ *   counts[i] = number of regions of read i; *regs_out = array of all regions in read order
+ *   (caller frees with bwagpu_free -- NOT free(): large results are page-locked blocks of a pool that bwagpu_free refills,
+ *   BWAGPU_PINNED_RESULTS=0 turns that off); *n_regs_out = total. */
 int bwagpu_align_flat(bwagpu_t *h, const bwagpu_opt_t *opt, int n, const uint8_t *seqs, const int64_t *off,
 					  int32_t *counts, bwagpu_alnreg_t **regs_out, int64_t *n_regs_out);
-void bwagpu_free(void *p);
+void bwagpu_free(void *p);   /* releases any array an entry point of this library returned through an out-pointer (thread-safe) */
 
 /* Split form for callers that overlap transfers with compute, and for measuring the device path with the batch
  * already resident in HBM: upload -> run (device only, asynchronous kernels + one final sync) -> download. */
