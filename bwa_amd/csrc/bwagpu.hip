@@ -138,7 +138,9 @@ struct ResultPool {
 		const bool enabled = !(getenv("BWAGPU_PINNED_RESULTS") && atoi(getenv("BWAGPU_PINNED_RESULTS")) == 0);
 		const size_t min_bytes = getenv("BWAGPU_PINNED_MIN_KB") ? (size_t)atoll(getenv("BWAGPU_PINNED_MIN_KB")) << 10 : (size_t)1 << 20;   // (tests: 0 pools everything)
 		if (!enabled || bytes < min_bytes) return malloc(bytes ? bytes : 1);
-		size_t want = (size_t)1 << 20; while (want < bytes) want += want >> 2 > ((size_t)1 << 20) ? (want >> 2) & ~(((size_t)1 << 20) - 1) : (size_t)1 << 20;   // 1 MiB steps, then ~25 % steps
+		size_t step = (size_t)1 << 20;                 // block sizes: multiples of 1 MiB up to 8 MiB, then of a quarter of the power of two below
+		while (step * 8 <= bytes) step <<= 1;
+		const size_t want = (bytes + step - 1) / step * step;
 		{
 			std::lock_guard<std::mutex> l(m);
 			auto it = idle.lower_bound(bytes);
