@@ -152,7 +152,7 @@ struct ResultPool {
 			pinned += want;
 		}
 		void *p = nullptr;
-		if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess || !p) {
+		if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess || !p) {     // (portable: a block may serve another device's handle next time)
 			(void)hipGetLastError();
 			std::lock_guard<std::mutex> l(m); pinned -= want;
 			return malloc(bytes);

@@ -66,6 +66,7 @@ static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1);
 template <class T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 #define hipHostMallocDefault 0
+#define hipHostMallocPortable 1
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); if (*p) memset(*p, 0xCD, n < ((size_t)1 << 20) ? n : ((size_t)1 << 20)); return *p ? hipSuccess : hipErrorMock; }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
