@@ -272,8 +272,8 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		if (hist_flush()) break;                         // (rows of the other forms keep their bookkeeping per row: bring the state up to date first)
 		hist_row0 = i + 1;
 		int m = 0, mj = -1, carry = W_NEG, hprev = h1_init, first_nz = -1, last_nz = -1, bnd = 0;
-		if (!RING && end - beg <= 128 && two_col_ok) {
-			// 65..128 columns (the longer half of a 150 bp read's extensions): each lane owns two adjacent columns, so the row still takes ONE
+		if (!RING && end - beg <= 127 && two_col_ok) {     // (127: column `end` needs a slot of its own, like the spare lane of the single-pass form)
+			// 65..127 columns (the longer half of a 150 bp read's extensions): each lane owns two adjacent columns, so the row still takes ONE
 			// prefix scan for F and one for the row maximum instead of two passes of the loop below with their carries.  A lane's two
 			// {H,E} slots are read and written by that lane only -- H(i,j) reaches the owner of column j+1 through a lane shift, not LDS.
 			const int nact = end - beg;

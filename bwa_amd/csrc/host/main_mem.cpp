@@ -76,11 +76,19 @@ typedef std::vector<char> Arena;
 
 struct Reader {
 	gzFile fp = nullptr; int raw_fd = -1; std::vector<char> buf; int pos = 0, len = 0; int last = 0; bool eof = false;
-	// A regular file that does not start with the gzip magic is read with read(2) straight into the parse buffer: zlib's transparent mode
-	// would copy every byte twice more on the thread that paces the pipeline.  Everything else (gzip files, stdin) goes through zlib as in
-	// the reference (kseq.h over gzread, fastmap.c:357-372).
+	// The file is read (and, for gzip input, inflated) by a thread of its own, one buffer ahead of the parser: inflating a FASTQ stream
+	// costs several times what parsing it does, and for paired input the two files' streams then inflate side by side.
+	std::thread ahead; std::mutex m; std::condition_variable cv;
+	std::vector<char> nbuf; int nlen = 0; bool nfull = false, stop = false;
+	~Reader() {
+		if (ahead.joinable()) { { std::lock_guard<std::mutex> l(m); stop = true; } cv.notify_all(); ahead.join(); }
+		if (fp) gzclose(fp); else if (raw_fd >= 0) ::close(raw_fd);
+	}
+	// A regular file that does not start with the gzip magic is read with read(2) straight into the buffer: zlib's transparent mode
+	// would copy every byte twice more.  Everything else (gzip files, stdin) goes through zlib as in the reference (kseq.h over gzread,
+	// fastmap.c:357-372).
 	bool open(const char *fn) {
-		buf.resize(1 << 20);
+		buf.resize(1 << 20); nbuf.resize(1 << 20);
 		if (strcmp(fn, "-")) {
 			const int fd = ::open(fn, O_RDONLY);
 			if (fd < 0) return false;
@@ -93,10 +101,30 @@ struct Reader {
 		if (fp) gzbuffer(fp, 1 << 20);
 		return fp != nullptr;
 	}
+	int read_some(char *dst, size_t cap) {
+		int n;
+		if (raw_fd >= 0) { do n = (int)::read(raw_fd, dst, cap); while (n < 0 && errno == EINTR); }
+		else n = gzread(fp, dst, (unsigned)cap);
+		return n;
+	}
+	void read_ahead() {
+		for (;;) {
+			{ std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !nfull || stop; }); if (stop) return; }
+			const int n = read_some(nbuf.data(), nbuf.size());       // (nbuf belongs to this thread while !nfull)
+			{ std::lock_guard<std::mutex> l(m); nlen = n; nfull = true; }
+			cv.notify_all();
+			if (n <= 0) return;
+		}
+	}
 	bool fill() {
 		if (eof) return false;
-		if (raw_fd >= 0) { do len = (int)::read(raw_fd, buf.data(), buf.size()); while (len < 0 && errno == EINTR); }
-		else len = gzread(fp, buf.data(), (unsigned)buf.size());
+		if (!ahead.joinable()) ahead = std::thread([this] { read_ahead(); });
+		{
+			std::unique_lock<std::mutex> l(m);
+			cv.wait(l, [&] { return nfull; });
+			buf.swap(nbuf); len = nlen; nfull = false;
+		}
+		cv.notify_all();
 		pos = 0;
 		if (len <= 0) { len = 0; eof = true; return false; }
 		return true;

@@ -100,6 +100,24 @@ def extend_cases(rng, n, max_len):
     return cs
 
 
+def wide_band_cases(rng, n):
+    """Rows of exactly 64 and exactly 128 live columns (and their neighbours): a large h0 keeps every column of the first-row ramp alive, so
+    with beg = 0 the band grows by one column per row from w + 1 to qlen and passes through every width on the way -- the widths at which
+    the kernel changes its row form (one column per lane, two columns per lane, several passes)."""
+    cs = CaseSet()
+    for it in range(n):
+        wide = it % 4 != 0
+        qlen = int(rng.integers(128, 135)) if wide else int(rng.integers(64, 70))
+        w = int(rng.choice([100, 127, 110])) if wide else int(rng.choice([40, 63, 50]))
+        if it % 4 == 1:
+            qlen, w = 129, int(rng.choice([100, 90, 64]))     # the row after the 128-column one reads column 128 as the query's last
+        tlen = int(rng.integers(qlen - 10, qlen + 20))
+        t = rng.integers(0, 4, size=tlen).astype(np.uint8)
+        q = (rng.integers(0, 4, size=qlen).astype(np.uint8) if it % 3 else _mutate(rng, np.resize(t, qlen), 0.25, 0.02)[:qlen])
+        cs.add(q, t, w, int(rng.integers(qlen + 80, qlen + 200)), int(rng.choice([0, 5])), int(rng.integers(0, 8)))
+    return cs
+
+
 def ref_extend(o, q, t, w, h0, eb):
     R = refapi.lib()
     outs = [C.c_int() for _ in range(5)]
@@ -172,6 +190,12 @@ def run_extend(dev, kind, n, max_len, seed, need_stale):
             if need_stale and k % 5 == 4 and k < 400:
                 stale += py_extend_stale_differs(o, q, t, w, h0, eb)
         fast += int(out[:, 6].sum())
+        cs = wide_band_cases(rng, max(16, n // 12))
+        cases, seqs = cs.arrays()
+        out = dev.debug_dp(o, kind, cases, seqs)
+        for k, (q, t, w, h0, eb) in enumerate(cs.py):
+            exp = ref_extend(o, q, t, w, h0, eb)
+            assert out[k, :6].tolist() == exp, f"kind {kind} opt {oi} wide-band case {k}: device {out[k, :8].tolist()} reference {exp} (qlen {len(q)} tlen {len(t)} w {w} h0 {h0} eb {eb} flags {cases['flags'][k]})"
     assert fast > 0, "no case took the diagonal shortcut"
     if need_stale:
         assert stale > 0, "no case exercised the stale-cell rule"
