@@ -212,6 +212,8 @@ def global_cases(rng, n, max_len, max_cols, big_gaps=False):
             q = np.concatenate([q[:p], q[p + g:]]) if it % 2 else np.concatenate([q[:p], rng.integers(0, 4, size=g).astype(np.uint8), q[p:]])
         dl = abs(len(q) - tlen)
         w = dl + 3 + int(rng.integers(0, 40)) if it % 3 else dl + 3
+        if it % 5 == 0 and not big_gaps:     # bands of exactly 63 .. 65, 127 .. 129, 191 .. 193 columns: the widths at which a row takes another pass of the wave
+            w = max(w, int(rng.choice([31, 32, 63, 64, 95, 96])))
         if min(len(q), 2 * w + 1) > max_cols:
             w = max(dl + 3, (max_cols - 1) // 2)
         if min(len(q), 2 * w + 1) > max_cols:
@@ -269,10 +271,14 @@ def run_align2(dev, n, seed):
         cs = CaseSet(); xs = []
         for it in range(n // 4):
             qlen = int(rng.integers(20, 260 if it % 7 else 500))
+            if it % 5 == 0:      # padded query lengths around the two instances' column counts and around multiples of the wave
+                qlen = int(rng.choice([63, 64, 65, 127, 128, 129, 175, 176, 177, 191, 192, 193, 255, 256, 257, 496, 500]))
             tlen = int(rng.integers(qlen // 2 + 1, 900))
             t = rng.integers(0, 4, size=tlen).astype(np.uint8)
             p = int(rng.integers(0, max(1, tlen - qlen)))
             q = _mutate(rng, t[p:p + qlen], float(rng.choice([0.03, 0.1, 0.21])), float(rng.choice([0.0, 0.01, 0.03])))[:500]
+            if it % 5 == 0 and len(q) != qlen:
+                q = np.concatenate([q, rng.integers(0, 4, size=qlen).astype(np.uint8)])[:qlen]
             if it % 6 == 0 and tlen > 2 * qlen + 40:      # a second, weaker copy: score2 / te2
                 t[-qlen:] = np.minimum(_mutate(rng, t[p:p + qlen], 0.08, 0.0), 3)
             if it % 9 == 0:
