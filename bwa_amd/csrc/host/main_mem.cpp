@@ -88,7 +88,9 @@ struct Reader {
 	// would copy every byte twice more.  Everything else (gzip files, stdin) goes through zlib as in the reference (kseq.h over gzread,
 	// fastmap.c:357-372).
 	bool open(const char *fn) {
-		buf.resize(1 << 20); nbuf.resize(1 << 20);
+		size_t cap = 1 << 20;
+		if (getenv("BWAGPU_CLI_BUF")) { cap = (size_t)atoll(getenv("BWAGPU_CLI_BUF")); if (cap < 8) cap = 8; }   // (tests: records that straddle buffer ends)
+		buf.resize(cap); nbuf.resize(cap);
 		if (strcmp(fn, "-")) {
 			const int fd = ::open(fn, O_RDONLY);
 			if (fd < 0) return false;

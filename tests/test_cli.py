@@ -130,6 +130,24 @@ def test_cli_hostsim(tmp_path):
     _compare_all(_sim_cli(), prefix, f1, f2, inter, fasta, env=dict(os.environ, BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1", BWAGPU_PTAB_M="6"), full=False)   # (small prefix tables: a million emulated lanes per handle otherwise)
 
 
+@pytest.mark.skipif(not refapi.have_ref(), reason="oracle/_ref not built")
+def test_cli_hostsim_reader_buffer_ends(tmp_path):
+    """The input stage parses out of a 1 MiB buffer that a read-ahead thread refills; the test files fit one buffer, so the paths that
+    handle a record (a name, a CRLF, a multi-line sequence, a '+' line, a gzip member) straddling buffer ends only run on big inputs.
+    With buffers of 13 and 100 bytes every record of the awkward inputs straddles several: same SAM as `bwa mem`."""
+    prefix, g = testdata.small_index()
+    f1, f2, inter, fasta = _write_inputs(tmp_path, g, 8, seed=405)
+    weird = os.path.join(os.path.dirname(f1), "weird.fq")
+    cli = _sim_cli()
+    K = ["-K", "100000000", "-t", "2"]
+    runs = [(["-C", prefix, weird], "awkward FASTQ/FASTA mix"), (["-p", "-C", prefix, inter], "interleaved gzip"), ([prefix, fasta], "multi-line FASTA"), ([prefix, f1, f2], "two files")]
+    for args, what in runs:
+        want = _run(refapi.REF_BWA, K + args)
+        for cap in ("13", "100"):
+            env = dict(os.environ, BWAGPU_CLI_STREAMS="1", BWAGPU_CLI_SERIALIZE="1", BWAGPU_PTAB_M="6", BWAGPU_CLI_BUF=cap)
+            assert want == _run(cli, K + args, env), f"{what}, {cap}-byte buffers"
+
+
 @pytest.mark.gpu
 def test_cli_gpu(tmp_path):
     assert refapi.have_ref(), "oracle/_ref (the compiled reference) is missing on the GPU box"
