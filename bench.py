@@ -213,6 +213,8 @@ def main():
     ap.add_argument("--long-len", type=int, default=10000)
     ap.add_argument("--long-steps", type=int, default=2)
     ap.add_argument("--long-sample", type=int, default=128, help="reads of the long-read CPU-baseline / parity prefix")
+    ap.add_argument("--variants", default="BWAGPU_SEED_MRG=1;BWAGPU_SEED_MRG=2", help="';'-separated environment settings to A/B against the defaults in a child process (tools/variant_probe.py); '' = none")
+    ap.add_argument("--variants-timeout", type=float, default=150.0)
     args = ap.parse_args()
 
     import torch
@@ -482,10 +484,40 @@ def main():
                     log("[bench] LONG-READ PARITY GATE FAILED")
             except Exception as e:   # (the long-read leg must not take the headline line with it)
                 out["longread"] = {"error": repr(e)}
+    if world == 1 and args.variants.strip():
+        out["variants"] = run_variants(args, prefix)
     out["bench_wall_s"] = round(time.time() - t_all, 1)
     sys.stdout.flush()
     print(json.dumps(out), flush=True)      # the one JSON line, last thing on stdout (RCCL prints a version banner of its own at start-up)
     sys.exit(rc_exit)
+
+
+def run_variants(args, prefix):
+    """Kernel variants that sit behind environment switches, A/B'd against the defaults on the headline's workload by tools/variant_probe.py
+    in a CHILD process with a time limit: solo stage times, step time with the same batches in flight, and a digest of the regions that
+    must equal the defaults'.  Informational -- `value` above is always the default configuration's; a variant that faults or hangs costs
+    this object its entries and nothing else."""
+    cfgs = [c.strip() for c in args.variants.split(";") if c.strip()]
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "variant_probe.py"), "--prefix", prefix, "--codes", prefix + ".codes.npy", "--reads", str(args.reads), "--read-len", str(args.read_len),
+           "--streams", str(args.streams), "--dense-sa", str(args.dense_sa), "--steps", "6"] + cfgs
+    log(f"[bench] variants (child process, <= {args.variants_timeout:.0f} s): {cfgs}")
+    t = time.time()
+    res = {"what": "tools/variant_probe.py in a child process: each configuration's solo stage times (ms per batch of --reads), step time with --streams batches in flight and "
+                   "whether its regions equal the default configuration's; `value` is never taken from here", "runs": []}
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=args.variants_timeout)
+        text, res["rc"] = p.stdout, p.returncode
+        if p.returncode != 0:
+            res["stderr_tail"] = p.stderr[-400:]
+    except subprocess.TimeoutExpired as e:
+        text, res["rc"] = (e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")), "timeout"
+    for line in text.splitlines():
+        try:
+            res["runs"].append(json.loads(line))
+        except ValueError:
+            pass
+    res["wall_s"] = round(time.time() - t, 1)
+    return res
 
 
 def longread_bench(args, prefix, g, threads, cache):

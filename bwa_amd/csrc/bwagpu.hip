@@ -237,6 +237,17 @@ __global__ void __launch_bounds__(256) k_occ32_sb(DevIndex ix, u64 *sb, u64 n_sb
 		for (int k = 0; k < 4; ++k) sb[s * 4 + k] = cnt[k];
 	}
 }
+// Second form of the superblock table for the one-trip rank routine (dev_fm.h, occ32x_*): entry [s][c] = { count of c, sum of the counts of
+// the symbols above c } -- what an extension by c needs from a position's superblock in ONE 16-byte load instead of the whole 32-byte row
+__global__ void __launch_bounds__(256) k_occ32_sbx(const u64 *sb, uint4 *out, u64 n_sb)
+{
+	for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n_sb * 4; t += (u64)gridDim.x * blockDim.x) {
+		const u64 *row = sb + (t >> 2) * 4; const int c = (int)(t & 3);
+		u64 above = 0;
+		for (int i = c + 1; i < 4; ++i) above += row[i];
+		out[t] = make_uint4((u32)row[c], (u32)(row[c] >> 32), (u32)above, (u32)(above >> 32));
+	}
+}
 __global__ void __launch_bounds__(256) k_occ32_blocks(DevIndex ix, const u64 *sb, uint4 *out, u64 n_new, int sh)
 {
 	for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n_new; j += (u64)gridDim.x * blockDim.x) {
@@ -256,24 +267,28 @@ __global__ void __launch_bounds__(256) k_occ32_blocks(DevIndex ix, const u64 *sb
 // latency of the dependent chain at 4 waves per SIMD, and the cooperative form adds instructions and registers (3 waves per SIMD) to both.
 static int build_occ32(bwagpu_t *h)
 {
-	h->ix.occ32 = nullptr; h->ix.occ_sb = nullptr; h->ix.occ_sb_shift = 32;
+	h->ix.occ32 = nullptr; h->ix.occ_sb = nullptr; h->ix.occ_sbx = nullptr; h->ix.occ_sb_shift = 32; h->ix.occ32_bytes = h->ix.occ_sbx_bytes = 0;
 	if ((getenv("BWAGPU_OCC32") && atoi(getenv("BWAGPU_OCC32")) == 0) || h->bwt_blocks == 0) return 0;   // (BWAGPU_OCC32=0: keep to the reference-format blocks)
 	int shift = getenv("BWAGPU_OCC32_SB_SHIFT") ? atoi(getenv("BWAGPU_OCC32_SB_SHIFT")) : 32;      // (tests: small superblocks on small genomes)
 	if (shift < 8) shift = 8; if (shift > 32) shift = 32;
 	const int sh = shift - 6;
 	const u64 n_new = (u64)h->bwt_blocks * 2, n_sb = (n_new >> sh) + 1;
-	if (h->ibuf->d_occ32.ensure((size_t)n_new * 32) || h->ibuf->d_occ_sb.ensure((size_t)n_sb * 32)) { h->err = "hipMalloc failed (32-byte blocks)"; return BWAGPU_ENOMEM; }
+	if (h->ibuf->d_occ32.ensure((size_t)n_new * 32) || h->ibuf->d_occ_sb.ensure((size_t)n_sb * (32 + 64))) { h->err = "hipMalloc failed (32-byte blocks)"; return BWAGPU_ENOMEM; }   // (both forms of the superblock table, one after the other)
 	hipLaunchKernelGGL(k_occ32_sb, dim3((unsigned)((n_sb + 255) / 256 < 1024 ? (n_sb + 255) / 256 : 1024)), dim3(256), 0, h->stream, h->ix, h->ibuf->d_occ_sb.as<u64>(), n_sb, n_new, sh);
 	hipLaunchKernelGGL(k_occ32_blocks, dim3((unsigned)((n_new + 255) / 256 < 65536 ? (n_new + 255) / 256 : 65536)), dim3(256), 0, h->stream, h->ix, h->ibuf->d_occ_sb.as<u64>(), h->ibuf->d_occ32.as<uint4>(), n_new, sh);
+	hipLaunchKernelGGL(k_occ32_sbx, dim3((unsigned)((n_sb * 4 + 255) / 256 < 1024 ? (n_sb * 4 + 255) / 256 : 1024)), dim3(256), 0, h->stream, h->ibuf->d_occ_sb.as<u64>(), (uint4*)(h->ibuf->d_occ_sb.as<u64>() + n_sb * 4), n_sb);
 	hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(h->stream);
 	HIPCHK(h, e1); HIPCHK(h, e2);
 	h->ix.occ32 = h->ibuf->d_occ32.as<uint4>(); h->ix.occ_sb = h->ibuf->d_occ_sb.as<u64>(); h->ix.occ_sb_shift = shift;
+	h->ix.occ_sbx = (const uint4*)(h->ibuf->d_occ_sb.as<u64>() + n_sb * 4);
+	h->ix.occ32_bytes = n_new * 32; h->ix.occ_sbx_bytes = n_sb * 64;
 	return 0;
 }
 
 static int build_prefix_tables(bwagpu_t *h, int m)
 {
 	// the packed entries hold 37-bit interval bounds (as do the LDS interval stacks)
+	h->ix.ptab_bytes = 0;
 	if (m < 2 || h->ix.seq_len >= ((u64)1 << 36)) { h->ix.ptab = nullptr; h->ix.ptab_m = 0; return 0; }
 	if (m > PTAB_MAX) m = PTAB_MAX;
 	size_t entries = ((((size_t)1 << (2 * (m + 1))) - 4) / 3);
@@ -290,7 +305,7 @@ static int build_prefix_tables(bwagpu_t *h, int m)
 	hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(h->stream);
 	levels.release();
 	HIPCHK(h, e1); HIPCHK(h, e2);
-	h->ix.ptab = h->ibuf->d_ptab.as<uint4>(); h->ix.ptab_m = m;
+	h->ix.ptab = h->ibuf->d_ptab.as<uint4>(); h->ix.ptab_m = m; h->ix.ptab_bytes = n_rec * sizeof(uint4);
 	return 0;
 }
 
@@ -339,7 +354,7 @@ extern "C" int bwagpu_create(bwagpu_t **out, const bwagpu_index_desc_t *d, int d
 	h->h_ctg_off.assign(d->ctg_offset, d->ctg_offset + d->n_seqs);
 	h->h_ctg_len.assign(d->ctg_len, d->ctg_len + d->n_seqs);
 	h->h_ctg_alt.assign(d->ctg_is_alt, d->ctg_is_alt + d->n_seqs);
-	h->ix.ptab = nullptr; h->ix.ptab_m = 0; h->ix.occ32 = nullptr; h->ix.occ_sb = nullptr;
+	h->ix.ptab = nullptr; h->ix.ptab_m = 0; h->ix.ptab_bytes = 0; h->ix.occ32 = nullptr; h->ix.occ_sb = nullptr; h->ix.occ_sbx = nullptr; h->ix.occ32_bytes = h->ix.occ_sbx_bytes = 0;
 	if (!alloc_only) {   // (a handle that receives its index by broadcast builds them in bwagpu_index_ready)
 		int m = getenv("BWAGPU_PTAB_M") ? atoi(getenv("BWAGPU_PTAB_M")) : 10;
 		if ((rc = build_occ32(h))) goto fail;
@@ -489,7 +504,7 @@ static int clone_to_device_impl(bwagpu_t *src, int device, bwagpu_t **out)
 	h->ix.ctg_off = h->ibuf->d_ctg_off.as<i64>(); h->ix.ctg_len = h->ibuf->d_ctg_len.as<i32>(); h->ix.ctg_alt = h->ibuf->d_ctg_alt.as<i32>();
 	h->ix.ptab = src->ix.ptab ? h->ibuf->d_ptab.as<uint4>() : nullptr;
 	h->bwt_blocks = src->bwt_blocks;
-	if (src->ix.occ32) { if (int rc = build_occ32(h)) { bwagpu_destroy(h); return rc; } } else { h->ix.occ32 = nullptr; h->ix.occ_sb = nullptr; }   // (rebuilt here rather than copied)
+	if (src->ix.occ32) { if (int rc = build_occ32(h)) { bwagpu_destroy(h); return rc; } } else { h->ix.occ32 = nullptr; h->ix.occ_sb = nullptr; h->ix.occ_sbx = nullptr; h->ix.occ32_bytes = h->ix.occ_sbx_bytes = 0; }   // (rebuilt here rather than copied)
 	h->l_pac = src->l_pac; h->n_seqs = src->n_seqs; h->seq_len = src->seq_len; h->sa_intv = src->sa_intv;
 	h->bwt_blocks = src->bwt_blocks; h->bwt_bytes = src->bwt_bytes; h->sa_bytes = src->sa_bytes; h->pac_bytes = src->pac_bytes;
 	h->bwt_size = src->bwt_size; h->n_sa = src->n_sa;
@@ -613,6 +628,7 @@ extern "C" int bwagpu_densify_sa(bwagpu_t *h, int new_intv)
 static const int BLOCK = 256;
 static const int MAX_RESIDENT_THREADS = 256 * 2048;   // 256 CUs x 32 waves x 64 lanes
 static const int WAVE_EXT_MAX_LEN = 1100;
+static const int SEED_MRG_DEFAULT = 0;                  // k_seed / k_seed3 variant when BWAGPU_SEED_MRG is not set (dev_seed.h)
 static const int SEED_LDS_ENT = 10;                     // 10 x 16 B x 256 lanes = 40 KiB of LDS per block -> 4 blocks (16 waves) per CU; measured best of {4,7,10,15}               // 4 waves x (8+5) B/column must fit the 64 KiB dynamic-LDS limit
 
 // first guess of a batch's arena sizes from its shape (n_reads, n_bases, max_len); grown on overflow
@@ -819,11 +835,17 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.seed_coop = h->ix.occ32 == nullptr && getenv("BWAGPU_SEED_COOP") && atoi(getenv("BWAGPU_SEED_COOP")) != 0;   // (opt-in: a measured loss, see build_occ32)
 		B.seed_pass3_inline = getenv("BWAGPU_SEED_PASS3_INLINE") && atoi(getenv("BWAGPU_SEED_PASS3_INLINE")) != 0;
 		B.chain_lds_off = getenv("BWAGPU_CHAIN_LDS") && atoi(getenv("BWAGPU_CHAIN_LDS")) == 0;
+		// memory round trips per iteration of the seeding kernels (dev_seed.h, k_seed's MRG): 0 = as compiled, 1 = table entries and whole index
+		// blocks in one trip, 2 = plus the next interval-stack entry a step ahead
+		int seed_mrg = getenv("BWAGPU_SEED_MRG") ? atoi(getenv("BWAGPU_SEED_MRG")) : SEED_MRG_DEFAULT;
+		if (h->ix.occ32 == nullptr || h->ix.ptab == nullptr || h->ix.occ32_bytes > BUF_MAX_BYTES || h->ix.ptab_bytes > BUF_MAX_BYTES) seed_mrg = 0;   // (its loads address 32-bit offsets into buffers of < 4 GiB: a genome beyond ~8.5 Gbp of index keeps the plain kernels)
+		B.tmp_intv_bytes = (u64)n_threads * (u64)(h->max_len + 1 + PTAB_MAX) * sizeof(BiIntv);
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
 		HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "start", hipGetErrorString(e_)); }
 		if (!B.seed_pass3_inline) {   // pass 3 first (cheap), then passes 1-2 on the reads ordered by the repetitiveness it measured
-			if (h->ix.occ32 != nullptr) hipLaunchKernelGGL(k_seed3<1>, grid, block, 0, h->stream, h->ix, *opt, B);
+			if (h->ix.occ32 != nullptr && seed_mrg) hipLaunchKernelGGL((k_seed3<1, true>), grid, block, 0, h->stream, h->ix, *opt, B);
+			else if (h->ix.occ32 != nullptr) hipLaunchKernelGGL(k_seed3<1>, grid, block, 0, h->stream, h->ix, *opt, B);
 			else if (B.seed_coop) hipLaunchKernelGGL(k_seed3<2>, grid, block, 0, h->stream, h->ix, *opt, B);
 			else hipLaunchKernelGGL(k_seed3<0>, grid, block, 0, h->stream, h->ix, *opt, B);
 			if (!getenv("BWAGPU_SEED_INPUT_ORDER")) {
@@ -836,12 +858,14 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		dim3 sgrid = grid;                    // (BWAGPU_SEED_GRID, measurements: fewer resident workgroups of the seeding kernel; it stays within 5 % down to two per CU -- it is bound by memory requests, not by waves -- but step time with three batches in flight did not move either, nor did making the batches' seeding kernels take turns)
 		if (getenv("BWAGPU_SEED_GRID") && atoi(getenv("BWAGPU_SEED_GRID")) > 0 && (unsigned)atoi(getenv("BWAGPU_SEED_GRID")) < grid.x) sgrid = dim3((unsigned)atoi(getenv("BWAGPU_SEED_GRID")));
 		// (twelve instances: with/without the LDS copy of the reads, the work counters -- which cost registers -- and the three ways of reading the index)
-#define SEED_LAUNCH(RD_, ST_, B_, O_) hipLaunchKernelGGL((k_seed<RD_, ST_, B_, O_>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B)
-#define SEED_LAUNCH_B(RD_, ST_) do { if (blk == 2 && socc == 3) SEED_LAUNCH(RD_, ST_, 2, 3); else if (blk == 2) SEED_LAUNCH(RD_, ST_, 2, 4); else if (blk == 1) SEED_LAUNCH(RD_, ST_, 1, 4); else SEED_LAUNCH(RD_, ST_, 0, 4); } while (0)
+#define SEED_LAUNCH(RD_, ST_, B_, O_, M_) hipLaunchKernelGGL((k_seed<RD_, ST_, B_, O_, M_>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B)
+#define SEED_LAUNCH_B(RD_, ST_) do { if (blk == 2 && socc == 3) SEED_LAUNCH(RD_, ST_, 2, 3, 0); else if (blk == 2) SEED_LAUNCH(RD_, ST_, 2, 4, 0); else if (blk == 1 && mrg == 2) SEED_LAUNCH(RD_, ST_, 1, 4, 2); \
+		else if (blk == 1 && mrg == 1) SEED_LAUNCH(RD_, ST_, 1, 4, 1); else if (blk == 1) SEED_LAUNCH(RD_, ST_, 1, 4, 0); else SEED_LAUNCH(RD_, ST_, 0, 4, 0); } while (0)
 		{
 			const bool rd = B.rd_words != 0, st = B.stats != 0;
 			const int blk = h->ix.occ32 != nullptr ? 1 : (B.seed_coop ? 2 : 0);
 			const int socc = seed_occ;   // (measurements: register allocation of the cooperative form for 3 or 4 waves per SIMD)
+			const int mrg = seed_mrg;
 			if (rd) { if (st) SEED_LAUNCH_B(true, true); else SEED_LAUNCH_B(true, false); }
 			else { if (st) SEED_LAUNCH_B(false, true); else SEED_LAUNCH_B(false, false); }
 		}

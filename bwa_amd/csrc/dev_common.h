@@ -19,6 +19,12 @@ typedef int32_t i32;
 typedef uint8_t u8;
 
 #define DEVFN __device__ __forceinline__
+// Scheduling fence for a 32-bit register value (no instruction is emitted): the value has to be in its register here -- loads issued
+// before have landed; none of them is narrowed, split or sunk past this point.  (The CPU test harness supplies its own no-op.)
+#ifndef DEV_KEEP
+#define DEV_KEEP(v) asm volatile("" : "+v"(v))
+#endif
+typedef __amdgpu_buffer_rsrc_t BufRsrc;   // a buffer descriptor (V#) for range-checked loads (dev_fm.h: buf_rsrc, buf_load16)
 
 // The index as the kernels see it.
 struct DevIndex {
@@ -45,6 +51,8 @@ struct DevIndex {
 	// (profiles/r02_experiments.md).  Null: not built.
 	const uint4 *occ32;
 	const u64 *occ_sb;
+	const uint4 *occ_sbx;  // the same table per symbol: [superblock][c] = { count of c, summed counts of the symbols above c } (one-trip rank routine, dev_fm.h)
+	u64 occ32_bytes, occ_sbx_bytes, ptab_bytes;   // sizes of occ32 / occ_sbx / ptab (buffer descriptors of the one-trip routine)
 	int occ_sb_shift;
 };
 
@@ -90,7 +98,7 @@ struct Counters {          // device-side bump allocators + flags
 	// algorithmic work counters (bwagpu_stats_t)
 	unsigned long long n_intv, n_chains, n_regs_raw, n_regs;
 	unsigned long long occ_blocks, lf_steps, ext_calls, ext_cells, glb_calls, glb_cells, ref_bases, sw_calls, sw_cells, tab_lookups;
-	unsigned long long prof[16];                   // diagnostics (bwagpu_debug_prof): [12] k_seed iterations that read the interval stack from HBM, [13..15] its wave iterations, bookkeeping iterations, extending lanes (stats runs)
+	unsigned long long prof[16];                   // diagnostics (bwagpu_debug_prof): [10] k_seed lane steps that take an interval-stack entry from HBM scratch, [11] those served by an entry fetched a step ahead (MRG 2), [12] k_seed iterations that read the interval stack from HBM, [13..15] its wave iterations, bookkeeping iterations, extending lanes (stats runs)
 	unsigned long long ext_fast;                   // ksw_extend2 calls answered by the diagonal rule (no DP)
 	unsigned long long bt_nodes, chain_recs;       // B-tree nodes visited by look-ups / chain records touched (k_chain's algorithmic bytes)
 	unsigned long long cigl_plan[2];               // k_cigar_long_plan: regions left to the long CIGAR tier, bytes of the largest direction matrix among them
@@ -143,6 +151,7 @@ struct Batch {
 	Counters *ctr;
 	// --- seeding scratch: per resident lane one interval stack (first entries in LDS, see SeedStack)
 	BiIntv *tmp_intv;          // [n_seed_threads][max_len+1]: spill area of the lanes' interval stacks
+	u64 tmp_intv_bytes;        // ... its size (k_seed<MRG = 2> reads it through a buffer descriptor when it is below 4 GiB)
 	int seed_lds_ent;          // stack entries per lane kept in LDS (0 when seq_len >= 2^37 or max_len >= 2^16: the packing would not fit)
 	int seed_no_virt;          // diagnostics: keep short matches in the stack as well (see SeedLane::smask)
 	int mem_cap;               // capacity of one read's interval list

@@ -85,6 +85,79 @@ DEVFN void occ32_counts(const uint4 &rel, const uint4 &w, const uint4 &sb01, con
 	cnt[3] = ((u64)sb23.w << 32 | sb23.z) + rel.w + c3;
 }
 
+// The two rank queries of one extension on the 32-byte layout, in three pieces -- positions, loads, arithmetic -- so that a caller
+// can put other loads of its own between "issue" and "finish" and pay ONE memory round trip for all of them (ext_one_trip,
+// dev_seed.h).  Left to itself the compiler (a) loads a block's first count word only in the lanes whose symbol is A, in a block of
+// its own AFTER the other 28 bytes have arrived -- a second dependent round trip per extension -- and (b) waits for whatever a
+// conditional block loaded before leaving that block.  Here the loads are BUFFER loads (V#: base, size; 32-bit byte offset per
+// lane): a lane that does not need one passes an offset beyond the buffer's size -- the hardware's range check then returns zeros
+// without a memory request -- so there is no branch around any load and the whole set issues back to back.  dev_keep() is an
+// empty asm statement that reads and writes the registers: every load issued before it has to have landed there, none can be
+// narrowed or sunk past it, and it costs no instruction.
+// The routine also asks less of the superblock table: an extension by symbol c needs, per position, the superblock's count of c and
+// the summed counts of the symbols above c (they only ever enter a difference) -- DevIndex::occ_sbx holds exactly that pair per
+// (superblock, symbol), so a position costs one 16-byte load where the row form costs two, and eight registers fewer stay live.
+#define BUF_OOB 0xFFFFFF00u        // an offset no buffer reaches (sizes are capped at BUF_MAX_BYTES; +32 of instruction offset cannot wrap)
+#define BUF_MAX_BYTES 0xFFFFFE00ull
+DEVFN BufRsrc buf_rsrc(const void *p, u64 bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(u32)(bytes > BUF_MAX_BYTES ? 0 : bytes), 0x00020000); }   // (raw buffer, 32-bit elements; a table too large for a V# reads as empty)
+DEVFN uint4 buf_load16(BufRsrc r, u32 off) { const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0); return make_uint4(v[0], v[1], v[2], v[3]); }
+struct Occ32Pos { u64 kk, ll; };
+struct Occ32Data { uint4 rk, wk, rl, wl, sk, sl; };
+DEVFN void dev_keep(uint4 &v) { DEV_KEEP(v.x); DEV_KEEP(v.y); DEV_KEEP(v.z); DEV_KEEP(v.w); }
+DEVFN void occ32_keep(Occ32Data &d) { dev_keep(d.rk); dev_keep(d.wk); dev_keep(d.rl); dev_keep(d.wl); dev_keep(d.sk); dev_keep(d.sl); }
+DEVFN Occ32Pos occ32_pos(const DevIndex &ix, const BiIntv &ik, int is_back)
+{
+	const u64 a = is_back ? ik.x0 : ik.x1;
+	const u64 k = a - 1, l = a - 1 + ik.x2;                    // a >= 1 always (intervals start at L2[c]+1)
+	Occ32Pos p; p.kk = k - (k >= ix.primary); p.ll = l - (l >= ix.primary);
+	return p;
+}
+struct Occ32Bufs { BufRsrc occ, sbx; };
+DEVFN Occ32Bufs occ32_bufs(const DevIndex &ix)
+{
+	Occ32Bufs b; b.occ = buf_rsrc(ix.occ32, ix.occ32_bytes); b.sbx = buf_rsrc(ix.occ_sbx, ix.occ_sbx_bytes);
+	return b;
+}
+// `need` false: the lane issues the same six instructions and moves no data
+DEVFN void occ32_issue(const DevIndex &ix, const Occ32Bufs &bf, bool need, const Occ32Pos &p, int c, Occ32Data &d)
+{
+	const u32 ok = need ? (u32)(p.kk >> 6) << 5 : BUF_OOB, ol = need ? (u32)(p.ll >> 6) << 5 : BUF_OOB;
+	const u32 sk = need ? ((u32)(p.kk >> ix.occ_sb_shift) * 4 + (u32)c) << 4 : BUF_OOB, sl = need ? ((u32)(p.ll >> ix.occ_sb_shift) * 4 + (u32)c) << 4 : BUF_OOB;
+	d.rk = buf_load16(bf.occ, ok); d.wk = buf_load16(bf.occ, ok + 16); d.rl = buf_load16(bf.occ, ol); d.wl = buf_load16(bf.occ, ol + 16);
+	d.sk = buf_load16(bf.sbx, sk); d.sl = buf_load16(bf.sbx, sl);
+}
+// per-symbol counts of one position relative to its superblock: block-relative counts + the symbols of the block up to offset o
+DEVFN void occ32_rel(const uint4 &rel, const uint4 &w, int o, u64 v[4])
+{
+	const int n = o + 1;
+	u32 c1 = 0, c2 = 0, c3 = 0;
+	count_pair_bf(w.x, w.y, n, c1, c2, c3);
+	count_pair_bf(w.z, w.w, n - 32, c1, c2, c3);
+	v[0] = (u64)rel.x + (u32)(n - c1 - c2 - c3); v[1] = (u64)rel.y + c1; v[2] = (u64)rel.z + c2; v[3] = (u64)rel.w + c3;
+}
+// bwt_extend for one child (bwt.c:262-275) from the loaded data -- the arithmetic of fm_extend1 below with every count split into
+// its superblock part and its part relative to the superblock (sums and differences modulo 2^64, so the results are the same
+// numbers); returns N_blk in the reference's 128-base units
+DEVFN int occ32_finish(const DevIndex &ix, const BiIntv &ik, int c, int is_back, const Occ32Pos &p, const Occ32Data &d, BiIntv &out)
+{
+	const u64 a = is_back ? ik.x0 : ik.x1, other = is_back ? ik.x1 : ik.x0;
+	u64 vk[4], vl[4];
+	occ32_rel(d.rk, d.wk, (int)(p.kk & 63), vk);
+	occ32_rel(d.rl, d.wl, (int)(p.ll & 63), vl);
+	const u64 sbk = (u64)d.sk.y << 32 | d.sk.x, abk = (u64)d.sk.w << 32 | d.sk.z, sbl = (u64)d.sl.y << 32 | d.sl.x, abl = (u64)d.sl.w << 32 | d.sl.z;
+	const u64 d1 = vl[1] - vk[1], d2 = vl[2] - vk[2], d3 = vl[3] - vk[3];
+	u64 o = other + (a <= ix.primary && a + ik.x2 - 1 >= ix.primary) + (abl - abk);
+	o += c < 3 ? d3 : 0; o += c < 2 ? d2 : 0; o += c < 1 ? d1 : 0;
+	const u64 tkc = sbk + (c == 0 ? vk[0] : c == 1 ? vk[1] : c == 2 ? vk[2] : vk[3]);
+	const u64 tlc = sbl + (c == 0 ? vl[0] : c == 1 ? vl[1] : c == 2 ? vl[2] : vl[3]);
+	const u64 L2c = c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
+	const u64 na = L2c + 1 + tkc;
+	out.x2 = tlc - tkc;
+	out.x0 = is_back ? na : o;
+	out.x1 = is_back ? o : na;
+	return (p.kk >> 7) == (p.ll >> 7) ? 1 : 2;
+}
+
 // O32: 1 = the 32-byte layout, 0 = the reference-format blocks, -1 = whichever the handle has (decided at run time)
 template <int O32 = -1> DEVFN int fm_extend1(const DevIndex &ix, const BiIntv &ik, int c, int is_back, BiIntv &out)
 {

@@ -218,6 +218,29 @@ DEVFN void ptab_load(const DevIndex &ix, int j, u32 w, BiIntv &out)
 	out = SeedStack::unpack(ix.ptab[(u64)w * (u32)ix.ptab_m + (u32)(j - 1)]);
 }
 
+// One memory round trip per extension step (k_seed<.., MRG>, k_seed3<.., true>; 32-byte index layout).  A wave's lanes are a mix
+// of table look-ups (short matches) and block look-ups (long ones); written as `if (short) table else blocks` each side waits for
+// its own loads before the other side issues, and the block side itself comes in two dependent parts (dev_fm.h, Occ32Data).  Here
+// every lane issues the same eight range-checked loads -- one table entry, two blocks and their superblock entries, and (pf_off)
+// the interval-stack entry of its NEXT step -- with out-of-range offsets for the ones it does not need, and the wave waits once.
+// Returns N_blk (0 for a table look-up).
+struct SeedBufs { Occ32Bufs occ; BufRsrc ptab, stk; };
+DEVFN int ext_one_trip(const DevIndex &ix, const SeedBufs &bf, bool ext, bool blocks, const BiIntv &src, int c, int back, int tl, u32 code, BiIntv &ok, u32 pf_off, uint4 &pf)
+{
+	const Occ32Pos pp = occ32_pos(ix, src, back);      // (lanes that do not extend hold src = 0: the arithmetic is harmless, nothing is loaded)
+	Occ32Data od;
+	uint4 te = buf_load16(bf.ptab, ext && !blocks ? (code * (u32)ix.ptab_m + (u32)(tl - 1)) << 4 : BUF_OOB);
+	occ32_issue(ix, bf.occ, blocks, pp, c, od);
+	pf = buf_load16(bf.stk, pf_off);                   // (BUF_OOB: zeros, i.e. "no entry", SeedStack::pack never yields w == 0)
+	occ32_keep(od); dev_keep(te); dev_keep(pf);
+	int nb = 0;
+	if (ext) {
+		if (!blocks) ok = SeedStack::unpack(te);
+		else nb = occ32_finish(ix, src, c, back, pp, od, ok);
+	}
+	return nb;
+}
+
 // 2-bit code of q[x..x+m), first base most significant; N and positions past the read's end read as 0 (no match that the
 // tables are asked about extends over them)
 DEVFN u32 window_code(SeedLane &L, const u64 *nib, int x, int m)
@@ -279,7 +302,11 @@ __global__ void __launch_bounds__(256) k_publish(bwagpu_opt_t opt, Batch B)
 //      BWAGPU_SEED_COOP=1 -- a measured loss at this kernel's instruction count, kept for the day that count has come down).
 //      A compile-time choice, so that no path pays for another's registers.
 // OCC: waves per SIMD the register allocation aims at (the cooperative form holds more live values: 4 spills a little, 3 does not)
-template<bool RD, bool STATS, int BLK, int OCC>
+// MRG (BLK == 1 only): memory round trips per wave iteration.  0: as the compiler schedules them -- interval-stack entry from HBM scratch,
+//      then the table look-ups, then the index blocks, then the blocks' first words for the lanes extending by A: up to four dependent
+//      trips.  1: table entries and whole blocks are issued together and waited for once (ext_one_trip).  2: additionally, a backward
+//      row's next interval-stack entry, when it lives in HBM scratch, is fetched in the same trip, one step ahead: one trip per iteration.
+template<bool RD, bool STATS, int BLK, int OCC, int MRG = 0>
 __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
 	HIP_DYNAMIC_SHARED(uint4, seed_lds)
@@ -307,7 +334,16 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	// their bookkeeping state until eight of them have gathered (or three iterations have passed, or nobody can extend), and the
 	// wave then runs that code once for all of them.
 	int deferred = 0;
-	u32 n_iter = 0, n_slow = 0, n_ext_lanes = 0, n_deep = 0;
+	u32 n_iter = 0, n_slow = 0, n_ext_lanes = 0, n_deep = 0, n_deep_l = 0, n_pf_l = 0;
+	// MRG == 2: the stack entry this lane's next backward step will read, fetched a step ahead (pf.w != 0: valid -- an entry's `info`, its
+	// match's end position >= 1, sits in the top half of w).  A backward step that is not the last of its row is always followed by the
+	// step for entry j + 1 of the same row, and the steps in between write survivors at depths <= j only (SeedStack::store).
+	uint4 pf = make_uint4(0, 0, 0, 0);
+	SeedBufs bf;
+	if (MRG && BLK == 1) {
+		bf.occ = occ32_bufs(ix); bf.ptab = buf_rsrc(ix.ptab, ix.ptab_bytes);
+		bf.stk = buf_rsrc(B.tmp_intv, MRG == 2 ? B.tmp_intv_bytes : 0);      // (an area beyond a descriptor's reach -- long reads -- reads as empty: no entry is ever prefetched)
+	}
 	while (__ballot(L.st != SS_DONE)) {       // (a lane that has run out of reads stays in the loop: its quad still needs it to fetch and count, fm_occ_coop)
 		if (STATS) ++n_iter;
 		const bool slow = L.st < SS_FWD || L.st == SS_FINAL;
@@ -422,8 +458,10 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 		ok.x0 = ok.x1 = ok.x2 = ok.info = 0; src = ok;
 		if (ext) {
 			if (back) {
-				if (L.j < L.nprev) p = S.load(L, L.j);
-				else {                                   // the stack's entries are done: the short ones, longest first
+				if (L.j < L.nprev) {
+					if (STATS && L.j >= S.n_lds) { ++n_deep_l; if (MRG == 2 && pf.w != 0) ++n_pf_l; }
+					if (MRG == 2 && pf.w != 0) p = SeedStack::unpack(pf); else p = S.load(L, L.j);
+				} else {                                 // the stack's entries are done: the short ones, longest first
 					const int len = 32 - __clz((int)L.srem);
 					L.srem &= ~(1u << (len - 1));
 					p.x0 = p.x1 = p.x2 = 0; p.info = (u64)(L.i + 1 + len); short_ent = true;
@@ -442,8 +480,16 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 		if (BLK == 2) {           // all lanes together: the quad of a lane that needs blocks fetches them with it (the only extension site of the kernel)
 			const u32 nb = fm_extend1_coop(ix, blocks, src, cb, back, ok); if (STATS && blocks) nblk += nb;
 		}
+		if (MRG && BLK == 1) {
+			u32 pf_off = BUF_OOB;       // byte offset of the lane's next stack entry in the spill area (SeedStack::glob_col, packed entries)
+			if (MRG == 2 && back && !short_ent && S.n_lds && L.j + 1 < L.nprev && L.j + 1 >= S.n_lds)
+				pf_off = ((u32)(blockIdx.x * blockDim.x + threadIdx.x) * (u32)S.glob_cap + PTAB_MAX) * (u32)sizeof(BiIntv) + (u32)(L.top - (L.j + 1)) * (u32)sizeof(uint4);
+			const u32 nb = (u32)ext_one_trip(ix, bf, ext, blocks, src, cb, back, tl, L.code, ok, pf_off, pf);
+			if (STATS && ext) { if (blocks) nblk += nb; else ++ntab; }
+		}
 		if (ext) {
-			if (!blocks) { ptab_load(ix, tl, L.code, ok); if (STATS) ++ntab; }
+			if (MRG && BLK == 1) ;
+			else if (!blocks) { ptab_load(ix, tl, L.code, ok); if (STATS) ++ntab; }
 			else if (BLK != 2) { const u32 nb = fm_extend1<BLK>(ix, src, cb, back, ok); if (STATS) nblk += nb; }
 			if (st == SS_FWD) {           // forward sweep of bwt_smem1a (bwt.c:304-320)
 				bool stop = false;
@@ -487,6 +533,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	}
 	if (STATS) {
 		atomicAdd(&B.ctr->occ_blocks, (unsigned long long)nblk); atomicAdd(&B.ctr->tab_lookups, (unsigned long long)ntab);
+		atomicAdd(&B.ctr->prof[10], (unsigned long long)n_deep_l); atomicAdd(&B.ctr->prof[11], (unsigned long long)n_pf_l);
 		if ((threadIdx.x & 63) == 0) { atomicAdd(&B.ctr->prof[12], (unsigned long long)n_deep); atomicAdd(&B.ctr->prof[13], (unsigned long long)n_iter); atomicAdd(&B.ctr->prof[14], (unsigned long long)n_slow); atomicAdd(&B.ctr->prof[15], (unsigned long long)n_ext_lanes); }
 	}
 }
@@ -497,7 +544,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 // is a plain forward extension loop: run inside k_seed's state machine each of its steps paid for that machine's whole divergent
 // iteration (~1060 VALU instructions); here an iteration is the extension plus a dozen instructions of control.  One lane per
 // read, reads drawn from a per-wave pool.
-template <int BLK> __global__ void __launch_bounds__(256, 3) k_seed3(DevIndex ix, bwagpu_opt_t opt, Batch B)
+template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k_seed3(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
 	SeedLane L;                   // only the read window (qoff, win, win_w, len), x, sx, i, ik, code and the emitter are used
 	L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len; L.em.intv = B.intv; L.em.r = -1; L.em.n = 0; L.em.overflow = false;
@@ -509,6 +556,8 @@ template <int BLK> __global__ void __launch_bounds__(256, 3) k_seed3(DevIndex ix
 	enum { T_FETCH = 0, T_START, T_EXT, T_DONE };
 	int st = T_FETCH, pool_base = 0, pool_cnt = 0;
 	u32 nblk = 0, ntab = 0, weight = 0;
+	SeedBufs bf;
+	if (MRG && BLK == 1) { bf.occ = occ32_bufs(ix); bf.ptab = buf_rsrc(ix.ptab, ix.ptab_bytes); bf.stk = buf_rsrc(nullptr, 0); }
 	while (__ballot(st != T_DONE)) {          // (a lane without reads stays: its quad needs it, fm_occ_coop)
 		const u64 wm = __ballot(st == T_FETCH);
 		if (wm) {
@@ -551,8 +600,15 @@ template <int BLK> __global__ void __launch_bounds__(256, 3) k_seed3(DevIndex ix
 		const int cb = blocks ? 3 - seed_q(L, nib, L.i) : 0;
 		BiIntv ok; ok.x0 = ok.x1 = ok.x2 = ok.info = 0;
 		if (BLK == 2) { const int nb = fm_extend1_coop(ix, blocks, L.ik, cb, 0, ok); if (blocks) nblk += nb; }   // (all lanes together)
+		if (MRG && BLK == 1) {
+			uint4 none;
+			BiIntv srcv = L.ik; if (!ext) srcv.x0 = srcv.x1 = srcv.x2 = 0;
+			const int nb = ext_one_trip(ix, bf, ext, blocks, srcv, cb, 0, tl, L.code, ok, BUF_OOB, none);
+			if (ext) { if (blocks) nblk += nb; else ++ntab; }
+		}
 		if (ext) {
-			if (!blocks) { ptab_load(ix, tl, L.code, ok); ++ntab; }
+			if (MRG && BLK == 1) ;
+			else if (!blocks) { ptab_load(ix, tl, L.code, ok); ++ntab; }
 			else if (BLK != 2) nblk += fm_extend1<BLK>(ix, L.ik, cb, 0, ok);
 			if (tl == opt.min_seed_len) weight += (u32)(ok.x2 > 65535 ? 65535 : ok.x2);   // occurrences of the seed-length match: the read's repetitiveness
 			if (ok.x2 < opt.max_mem_intv && L.i - L.sx >= opt.min_seed_len) {

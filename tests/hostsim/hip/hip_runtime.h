@@ -121,6 +121,19 @@ static inline int mock_readlane(int v, int src) { uint64_t o[64], m; mock_exchan
 #define __threadfence() ((void)0)
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define __builtin_amdgcn_wave_barrier() mock_wave_barrier()
+#define DEV_KEEP(v) ((void)0)            /* scheduling fence of the device code (dev_common.h): nothing to do here */
+// buffer descriptors and range-checked 16-byte loads (gfx9 raw buffers: a lane whose offset + 16 exceeds the size reads zeros)
+struct mock_rsrc_t { const unsigned char *p; uint32_t n; };
+typedef mock_rsrc_t __amdgpu_buffer_rsrc_t;
+struct mock_v4u32 { uint32_t v[4]; uint32_t operator[](int i) const { return v[i]; } };
+static inline mock_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void *p, short stride, int n, int flags) { (void)stride; (void)flags; mock_rsrc_t r; r.p = (const unsigned char*)p; r.n = (uint32_t)n; return r; }
+static inline mock_v4u32 __builtin_amdgcn_raw_buffer_load_b128(mock_rsrc_t r, int voff, int soff, int aux)
+{
+	(void)aux; mock_v4u32 o; memset(&o, 0, sizeof o);
+	const uint64_t off = (uint64_t)(uint32_t)voff + (uint32_t)soff;
+	if (off + 16 <= r.n) memcpy(&o, r.p + off, 16);
+	return o;
+}
 #define HIP_DYNAMIC_SHARED(type, var) type *var = (type*)mock_dyn_lds;
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) mock_launch((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); })

@@ -122,13 +122,17 @@ def _n_rich_reads(g, n, max_len, seed):
 
 @pytest.mark.parametrize("max_len,env", [(150, {}), (250, {}), (120, {"BWAGPU_SEED_NO_VIRT": "1"}), (150, {"BWAGPU_SEED_RD_LDS": "0"}),
                                          (150, {"BWAGPU_PTAB_M": "5", "BWAGPU_SEED_LDS_ENT": "2"}), (150, {"BWAGPU_OCC32": "0"}), (150, {"BWAGPU_OCC32": "0", "BWAGPU_PTAB_M": "0"}), (150, {"BWAGPU_PTAB_M": "0"}),
-                                         (150, {"BWAGPU_OCC32": "0", "BWAGPU_SEED_COOP": "1"})])
+                                         (150, {"BWAGPU_OCC32": "0", "BWAGPU_SEED_COOP": "1"}),
+                                         (150, {"BWAGPU_SEED_MRG": "1"}), (150, {"BWAGPU_SEED_MRG": "2"}), (250, {"BWAGPU_SEED_MRG": "2", "BWAGPU_SEED_LDS_ENT": "2"}),
+                                         (150, {"BWAGPU_SEED_MRG": "2", "BWAGPU_SEED_RD_LDS": "0", "BWAGPU_PTAB_M": "5"}), (150, {"BWAGPU_SEED_MRG": "2", "BWAGPU_SEED_NO_VIRT": "1", "BWAGPU_SEED_LDS_ENT": "1"})])
 def test_hostsim_seeding_paths_with_n_reads(monkeypatch, max_len, env):
     """The seeding kernel's read copy in LDS (2 bits per base; 8, 12 or 16 words per lane by the batch's longest read; reads with an N
     take their bases from global memory), the short stack entries kept as a bit mask (off with BWAGPU_SEED_NO_VIRT, and narrower with
     shallow prefix tables), a two-entry LDS stack that spills almost everything, and the three ways of reading the index -- the 32-byte
     layout (the default), the reference-format 64-byte blocks fetched by each lane for itself (BWAGPU_OCC32=0) or quad-cooperatively
-    (BWAGPU_SEED_COOP=1 on top) -- with and without prefix tables: same regions as the oracle for ragged reads with Ns."""
+    (BWAGPU_SEED_COOP=1 on top) -- with and without prefix tables; and the one-round-trip forms of the 32-byte layout (BWAGPU_SEED_MRG=1:
+    table entries and whole blocks through range-checked buffer loads; 2: the next interval-stack entry fetched a step ahead, with LDS
+    stacks so small that nearly every backward step takes a prefetched entry): same regions as the oracle for ragged reads with Ns."""
     prefix, g = testdata.small_index()
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -151,8 +155,8 @@ def test_hostsim_occ32_layout_across_superblocks(monkeypatch):
     seqs, off = testdata.flat(simdata.make_reads_se(g, 16, seed=88, sub=0.02))
     want = orc.align(default_opt(), seqs, off)
     monkeypatch.setenv("BWAGPU_OCC32", "1")
-    for m, shift in (("6", "12"), ("0", "12"), ("6", "32")):
-        monkeypatch.setenv("BWAGPU_PTAB_M", m); monkeypatch.setenv("BWAGPU_OCC32_SB_SHIFT", shift)
+    for m, shift, mrg in (("6", "12", "0"), ("0", "12", "0"), ("6", "32", "0"), ("6", "12", "2"), ("6", "32", "1")):      # (BWAGPU_SEED_MRG: the per-symbol form of the superblock table)
+        monkeypatch.setenv("BWAGPU_PTAB_M", m); monkeypatch.setenv("BWAGPU_OCC32_SB_SHIFT", shift); monkeypatch.setenv("BWAGPU_SEED_MRG", mrg)
         s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
         assert_regs_equal(*want, *s2.align(default_opt(), seqs, off), f"32-byte blocks, prefix tables {m}, superblock shift {shift}")
         s2.close()
@@ -226,16 +230,23 @@ def test_hostsim_interval_list_overflow_retries(monkeypatch):
     s2.close(); orc.close()
 
 
-@pytest.mark.parametrize("ent", ["1", "3"])
-def test_hostsim_lds_stack_ring_eviction(monkeypatch, ent):
+@pytest.mark.parametrize("ent,mrg", [("1", "0"), ("3", "0"), ("1", "2"), ("3", "2")])
+def test_hostsim_lds_stack_ring_eviction(monkeypatch, ent, mrg):
     """A tiny LDS interval stack: the forward sweep's ring wraps and evicts to the HBM spill area, and the backward sweep
     reads deep entries back from it; the seeds (and everything downstream) are unchanged."""
     prefix, g = testdata.small_index()
-    monkeypatch.setenv("BWAGPU_SEED_LDS_ENT", ent)
+    monkeypatch.setenv("BWAGPU_SEED_LDS_ENT", ent); monkeypatch.setenv("BWAGPU_SEED_MRG", mrg)   # (2: deep entries arrive one step ahead of their use)
     s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
     seqs, off = testdata.flat(simdata.make_reads_se(g, 14, seed=93))
     orc = orcapi.OrcIndex(prefix)
+    s2.set_stats(True)
     assert_regs_equal(*orc.align(default_opt(), seqs, off), *s2.align(default_opt(), seqs, off), f"LDS stack of {ent}")
+    import ctypes as C
+    prof = (C.c_ulonglong * 16)()
+    s2.L.bwagpu_debug_prof.argtypes = [C.c_void_p, C.c_void_p]
+    s2.L.bwagpu_debug_prof(s2.h, prof)
+    assert prof[10] > 20, "the test's reads no longer spill their interval stacks"
+    assert prof[11] == (prof[10] if mrg == "2" else 0), "every deep entry of a backward row is fetched one step ahead (and only with BWAGPU_SEED_MRG=2)"
     s2.close(); orc.close()
 
 

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""A/B runs of kernel variants that sit behind environment switches (GPU).  bench.py starts this as a child process with a time limit
+and copies what it prints into the `variants` object of its JSON line -- a variant that faults or hangs takes this process with it,
+never the headline measurement.
+
+Every argument is one configuration: space-separated NAME=VALUE settings ("" = the library's defaults, always run first).  For each
+one: the resident hot path of one batch alone on the chip (stage times from the library's HIP events, best of `--passes`), the
+step time with `--streams` batches in flight (the headline's timing loop), and a digest of the batch's regions, which must equal the
+default configuration's -- a variant may only change when things are computed, never what.
+
+Prints one JSON object per configuration, one per line, as it goes (so that a time-out keeps the lines already out).
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("configs", nargs="*")
+    ap.add_argument("--prefix", required=True, help="index files (bench.py's cache)")
+    ap.add_argument("--codes", required=True, help="the genome's base codes (.npy), to draw the reads from")
+    ap.add_argument("--reads", type=int, default=1_000_000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--streams", type=int, default=3)
+    ap.add_argument("--passes", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--dense-sa", type=int, default=4)
+    ap.add_argument("--lib", default=None, help="(tests) the mock-runtime build of the library")
+    args = ap.parse_args()
+
+    from bwa_amd import simdata
+    from bwa_amd.api import BwaGpu
+    from bwa_amd.structs import default_opt
+
+    g = np.load(args.codes, mmap_mode="r")
+    opt = default_opt()
+    opt.flag |= 0x2
+    S = max(1, args.streams)
+    batches = []
+    for si in range(S):
+        r1, r2 = simdata.make_reads_pe(g, args.reads // 2, length=args.read_len, seed=1000 + si)      # (bench.py's rank-0 batches)
+        rd = np.empty((2 * r1.shape[0], r1.shape[1]), dtype=np.uint8)
+        rd[0::2] = r1; rd[1::2] = r2
+        batches.append((np.ascontiguousarray(rd.reshape(-1)), np.arange(0, rd.shape[0] + 1, dtype=np.int64) * args.read_len))
+    n_batch = batches[0][1].shape[0] - 1
+
+    base_digest = None
+    for cfg in [""] + [c for c in args.configs if c.strip()]:
+        sets = dict(kv.split("=", 1) for kv in cfg.split())
+        for k, v in sets.items():
+            os.environ[k] = v
+        t0 = time.time()
+        res = {"config": cfg or "defaults"}
+        try:
+            gpu = BwaGpu(args.prefix, lib_path=args.lib)          # (a fresh handle per configuration: some switches are read when the index is laid out)
+            if args.dense_sa:
+                gpu.densify_sa(args.dense_sa)
+            gpu.set_taps(False)
+            handles = [gpu] + [gpu.clone() for _ in range(S - 1)]
+            for hdl, (flat, off) in zip(handles, batches):
+                hdl.set_taps(False)
+                hdl.upload(flat, off)
+            gpu.run(opt)                                          # warm-up: arenas learn their sizes
+            solo = []
+            for _ in range(args.passes):
+                gpu.run(opt)
+                solo.append(gpu.stats())
+            keys = ("ms_seed", "ms_publish", "ms_sa", "ms_chain", "ms_extend", "ms_dedup", "ms_total")
+            res["stage_ms_solo"] = {k: round(min(s[k] for s in solo), 3) for k in keys}
+            counts, regs = gpu.download()
+            res["result_sha256_16"] = hashlib.sha256(counts.tobytes() + regs.tobytes()).hexdigest()[:16]
+            if base_digest is None:
+                base_digest = res["result_sha256_16"]
+            res["same_result_as_defaults"] = res["result_sha256_16"] == base_digest
+
+            def worker(hdl, n):
+                for _ in range(n):
+                    hdl.run(opt)
+            th = [threading.Thread(target=worker, args=(h_, 1)) for h_ in handles]      # warm-up of the other handles
+            [t.start() for t in th]; [t.join() for t in th]
+            share = [args.steps // S + (1 if i < args.steps % S else 0) for i in range(S)]
+            t1 = time.perf_counter()
+            th = [threading.Thread(target=worker, args=(handles[i], share[i])) for i in range(S) if share[i]]
+            [t.start() for t in th]; [t.join() for t in th]
+            dt = time.perf_counter() - t1
+            res["ms_per_step"] = round(dt / args.steps * 1e3, 3)
+            res["Mreads_s"] = round(n_batch * args.steps / dt / 1e6, 4)
+            res["steps"] = args.steps; res["streams"] = S
+            for hdl in handles[1:]:
+                hdl.close()
+            gpu.close()
+        except Exception as e:       # (a configuration the library refuses must not take the others with it)
+            res["error"] = repr(e)
+        res["wall_s"] = round(time.time() - t0, 1)
+        print(json.dumps(res), flush=True)
+        for k in sets:
+            del os.environ[k]
+
+
+if __name__ == "__main__":
+    main()
