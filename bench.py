@@ -498,25 +498,30 @@ def run_variants(args, prefix):
     must equal the defaults'.  Informational -- `value` above is always the default configuration's; a variant that faults or hangs costs
     this object its entries and nothing else."""
     cfgs = [c.strip() for c in args.variants.split(";") if c.strip()]
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "variant_probe.py"), "--prefix", prefix, "--codes", prefix + ".codes.npy", "--reads", str(args.reads), "--read-len", str(args.read_len),
-           "--streams", str(args.streams), "--dense-sa", str(args.dense_sa), "--steps", "6"] + cfgs
-    log(f"[bench] variants (child process, <= {args.variants_timeout:.0f} s): {cfgs}")
-    t = time.time()
-    res = {"what": "tools/variant_probe.py in a child process: each configuration's solo stage times (ms per batch of --reads), step time with --streams batches in flight and "
-                   "whether its regions equal the default configuration's; `value` is never taken from here", "runs": []}
-    try:
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=args.variants_timeout)
-        text, res["rc"] = p.stdout, p.returncode
-        if p.returncode != 0:
-            res["stderr_tail"] = p.stderr[-400:]
-    except subprocess.TimeoutExpired as e:
-        text, res["rc"] = (e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")), "timeout"
-    for line in text.splitlines():
+    probe = [sys.executable, os.path.join(ROOT, "tools", "variant_probe.py"), "--prefix", prefix, "--codes", prefix + ".codes.npy", "--dense-sa", str(args.dense_sa)]
+    res = {"what": "tools/variant_probe.py in child processes: each configuration's solo stage times (ms per batch), step time with --streams batches in flight (short reads) or "
+                   "time per pass (long reads), and whether its regions equal the default configuration's; `value` is never taken from here"}
+    legs = [("short_reads", ["--reads", str(args.reads), "--read-len", str(args.read_len), "--streams", str(args.streams), "--steps", "6"], args.variants_timeout)]
+    if not args.no_longread:
+        legs.append(("long_reads", ["--long-reads", str(args.long_reads), "--long-len", str(args.long_len)], args.variants_timeout * 0.6))
+    for name, extra, limit in legs:
+        log(f"[bench] variants, {name} (child process, <= {limit:.0f} s): {cfgs}")
+        t = time.time()
+        leg = {"runs": []}
         try:
-            res["runs"].append(json.loads(line))
-        except ValueError:
-            pass
-    res["wall_s"] = round(time.time() - t, 1)
+            p = subprocess.run(probe + extra + cfgs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit)
+            text, leg["rc"] = p.stdout, p.returncode
+            if p.returncode != 0:
+                leg["stderr_tail"] = p.stderr[-400:]
+        except subprocess.TimeoutExpired as e:
+            text, leg["rc"] = (e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")), "timeout"
+        for line in text.splitlines():
+            try:
+                leg["runs"].append(json.loads(line))
+            except ValueError:
+                pass
+        leg["wall_s"] = round(time.time() - t, 1)
+        res[name] = leg
     return res
 
 

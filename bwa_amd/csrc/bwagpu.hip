@@ -840,6 +840,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		int seed_mrg = getenv("BWAGPU_SEED_MRG") ? atoi(getenv("BWAGPU_SEED_MRG")) : SEED_MRG_DEFAULT;
 		if (h->ix.occ32 == nullptr || h->ix.ptab == nullptr || h->ix.occ32_bytes > BUF_MAX_BYTES || h->ix.ptab_bytes > BUF_MAX_BYTES) seed_mrg = 0;   // (its loads address 32-bit offsets into buffers of < 4 GiB: a genome beyond ~8.5 Gbp of index keeps the plain kernels)
 		B.tmp_intv_bytes = (u64)n_threads * (u64)(h->max_len + 1 + PTAB_MAX) * sizeof(BiIntv);
+		B.seq_nib_bytes = (((u64)h->n_bases + 15) / 16) * 8;
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
 		HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "start", hipGetErrorString(e_)); }
@@ -859,7 +860,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		if (getenv("BWAGPU_SEED_GRID") && atoi(getenv("BWAGPU_SEED_GRID")) > 0 && (unsigned)atoi(getenv("BWAGPU_SEED_GRID")) < grid.x) sgrid = dim3((unsigned)atoi(getenv("BWAGPU_SEED_GRID")));
 		// (twelve instances: with/without the LDS copy of the reads, the work counters -- which cost registers -- and the three ways of reading the index)
 #define SEED_LAUNCH(RD_, ST_, B_, O_, M_) hipLaunchKernelGGL((k_seed<RD_, ST_, B_, O_, M_>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B)
-#define SEED_LAUNCH_B(RD_, ST_) do { if (blk == 2 && socc == 3) SEED_LAUNCH(RD_, ST_, 2, 3, 0); else if (blk == 2) SEED_LAUNCH(RD_, ST_, 2, 4, 0); else if (blk == 1 && mrg == 2) SEED_LAUNCH(RD_, ST_, 1, 4, 2); \
+#define SEED_LAUNCH_B(RD_, ST_) do { if (blk == 2 && socc == 3) SEED_LAUNCH(RD_, ST_, 2, 3, 0); else if (blk == 2) SEED_LAUNCH(RD_, ST_, 2, 4, 0); else if (blk == 1 && mrg == 2) SEED_LAUNCH(RD_, ST_, 1, (RD_ ? 4 : 3), 2);   /* (no LDS copy of the reads: long reads, few lanes -- registers instead of spills) */ \
 		else if (blk == 1 && mrg == 1) SEED_LAUNCH(RD_, ST_, 1, 4, 1); else if (blk == 1) SEED_LAUNCH(RD_, ST_, 1, 4, 0); else SEED_LAUNCH(RD_, ST_, 0, 4, 0); } while (0)
 		{
 			const bool rd = B.rd_words != 0, st = B.stats != 0;

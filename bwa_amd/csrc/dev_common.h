@@ -98,7 +98,7 @@ struct Counters {          // device-side bump allocators + flags
 	// algorithmic work counters (bwagpu_stats_t)
 	unsigned long long n_intv, n_chains, n_regs_raw, n_regs;
 	unsigned long long occ_blocks, lf_steps, ext_calls, ext_cells, glb_calls, glb_cells, ref_bases, sw_calls, sw_cells, tab_lookups;
-	unsigned long long prof[16];                   // diagnostics (bwagpu_debug_prof): [10] k_seed lane steps that take an interval-stack entry from HBM scratch, [11] those served by an entry fetched a step ahead (MRG 2), [12] k_seed iterations that read the interval stack from HBM, [13..15] its wave iterations, bookkeeping iterations, extending lanes (stats runs)
+	unsigned long long prof[16];                   // diagnostics (bwagpu_debug_prof): [9] read windows k_seed fetched a step ahead (MRG 2, reads without an LDS copy), [10] k_seed lane steps that take an interval-stack entry from HBM scratch, [11] those served by an entry fetched a step ahead (MRG 2), [12] k_seed iterations that read the interval stack from HBM, [13..15] its wave iterations, bookkeeping iterations, extending lanes (stats runs)
 	unsigned long long ext_fast;                   // ksw_extend2 calls answered by the diagonal rule (no DP)
 	unsigned long long bt_nodes, chain_recs;       // B-tree nodes visited by look-ups / chain records touched (k_chain's algorithmic bytes)
 	unsigned long long cigl_plan[2];               // k_cigar_long_plan: regions left to the long CIGAR tier, bytes of the largest direction matrix among them
@@ -144,6 +144,7 @@ struct Batch {
 	int stats;                 // collect work counters
 	const u8 *seq;             // concatenated nt4 codes
 	u64 *seq_nib;              // the same bases at 4 bits each, 16 per word (k_pack_reads; read by the seeding kernel)
+	u64 seq_nib_bytes;         // ... its size (buffer descriptor of k_seed<RD = false, MRG = 2>)
 	const i64 *off;            // n_reads + 1
 	u32 *seq_2b;               // [n_reads][rd_words]: every read's bases at 2 bits each from a word boundary of its own (k_pack_reads2b) ...
 	u8 *seq_flags;             // ... and per read: 1 = the read holds an N (its lane then reads bases from seq_nib)

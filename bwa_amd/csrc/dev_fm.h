@@ -100,6 +100,7 @@ DEVFN void occ32_counts(const uint4 &rel, const uint4 &w, const uint4 &sb01, con
 #define BUF_OOB 0xFFFFFF00u        // an offset no buffer reaches (sizes are capped at BUF_MAX_BYTES; +32 of instruction offset cannot wrap)
 #define BUF_MAX_BYTES 0xFFFFFE00ull
 DEVFN BufRsrc buf_rsrc(const void *p, u64 bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(u32)(bytes > BUF_MAX_BYTES ? 0 : bytes), 0x00020000); }   // (raw buffer, 32-bit elements; a table too large for a V# reads as empty)
+DEVFN uint2 buf_load8(BufRsrc r, u32 off) { const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0); return make_uint2(v[0], v[1]); }
 DEVFN uint4 buf_load16(BufRsrc r, u32 off) { const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0); return make_uint4(v[0], v[1], v[2], v[3]); }
 struct Occ32Pos { u64 kk, ll; };
 struct Occ32Data { uint4 rk, wk, rl, wl, sk, sl; };

@@ -47,6 +47,7 @@ struct SeedLane {
 	int st, len, x, k2, old_n, pass;      // (the read's number is em.r)
 	u64 qoff, win;            // the read's offset in the packed base array; the 16-base window last fetched from it
 	u32 win_w;                // index of that window (~0u: none)
+	u64 win2; u32 win2_w;     // k_seed<RD = false, MRG = 2>: a second window -- the one the sweep is about to walk into, fetched a step ahead with the index blocks
 	const u32 *rd;            // k_seed<true>: the block's LDS copy of its lanes' reads (2 bits per base), [word][lane]
 	int rd_on;                // ... in use for the current read (it holds no N)
 	const u8 *raw; const i64 *off;   // ... and where a read with an N finds its bases (Batch::seq, Batch::off)
@@ -141,7 +142,11 @@ DEVFN int seed_q(SeedLane &L, const u64 *nib, int i)
 	if (nib == nullptr) { const u8 c = L.raw[L.off[L.em.r] + i]; return c > 3 ? 4 : (int)c; }   // k_seed<true>, a read with an N (rare): byte by byte
 	const u64 g = L.qoff + (u64)i;
 	const u32 w = (u32)(g >> 4);
-	if (w != L.win_w) { L.win = nib[w]; L.win_w = w; }
+	if (w != L.win_w) {
+		if (w == L.win2_w) { const u64 t = L.win; L.win = L.win2; L.win2 = t; L.win2_w = L.win_w; }   // (win2_w stays ~0u where nothing prefetches)
+		else L.win = nib[w];
+		L.win_w = w;
+	}
 	return (int)(L.win >> (((u32)g & 15) << 2)) & 15;
 }
 
@@ -224,14 +229,16 @@ DEVFN void ptab_load(const DevIndex &ix, int j, u32 w, BiIntv &out)
 // every lane issues the same eight range-checked loads -- one table entry, two blocks and their superblock entries, and (pf_off)
 // the interval-stack entry of its NEXT step -- with out-of-range offsets for the ones it does not need, and the wave waits once.
 // Returns N_blk (0 for a table look-up).
-struct SeedBufs { Occ32Bufs occ; BufRsrc ptab, stk; };
-DEVFN int ext_one_trip(const DevIndex &ix, const SeedBufs &bf, bool ext, bool blocks, const BiIntv &src, int c, int back, int tl, u32 code, BiIntv &ok, u32 pf_off, uint4 &pf)
+struct SeedBufs { Occ32Bufs occ; BufRsrc ptab, stk, nib; };
+template <bool WIN = false> DEVFN int ext_one_trip(const DevIndex &ix, const SeedBufs &bf, bool ext, bool blocks, const BiIntv &src, int c, int back, int tl, u32 code, BiIntv &ok, u32 pf_off, uint4 &pf, u32 win_off = BUF_OOB, u64 *win = nullptr)
 {
 	const Occ32Pos pp = occ32_pos(ix, src, back);      // (lanes that do not extend hold src = 0: the arithmetic is harmless, nothing is loaded)
 	Occ32Data od;
 	uint4 te = buf_load16(bf.ptab, ext && !blocks ? (code * (u32)ix.ptab_m + (u32)(tl - 1)) << 4 : BUF_OOB);
 	occ32_issue(ix, bf.occ, blocks, pp, c, od);
 	pf = buf_load16(bf.stk, pf_off);                   // (BUF_OOB: zeros, i.e. "no entry", SeedStack::pack never yields w == 0)
+	uint2 wv = make_uint2(0, 0);
+	if (WIN) { wv = buf_load8(bf.nib, win_off); DEV_KEEP(wv.x); DEV_KEEP(wv.y); *win = (u64)wv.y << 32 | wv.x; }      // (the 16 bases the sweep walks into next)
 	occ32_keep(od); dev_keep(te); dev_keep(pf);
 	int nb = 0;
 	if (ext) {
@@ -320,7 +327,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	L.smask = L.srem = L.snew = 0; L.ncl = 0;
 	L.em.intv = B.intv; L.em.r = -1; L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len;
 	L.em.split_len = split_len; L.em.split_width = (u64)opt.split_width; L.em.cand = 0; L.em.base = 0;
-	L.st = SS_FETCH; L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u;
+	L.st = SS_FETCH; L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u; L.win2 = 0; L.win2_w = ~0u;
 	u32 *rd_lds = (u32*)(seed_lds + (size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * blockDim.x);   // (after the stacks)
 	L.rd = rd_lds; L.rd_on = 0; L.raw = B.seq; L.off = B.off;
 	const u64 *nib = RD ? nullptr : B.seq_nib;
@@ -334,7 +341,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	// their bookkeeping state until eight of them have gathered (or three iterations have passed, or nobody can extend), and the
 	// wave then runs that code once for all of them.
 	int deferred = 0;
-	u32 n_iter = 0, n_slow = 0, n_ext_lanes = 0, n_deep = 0, n_deep_l = 0, n_pf_l = 0;
+	u32 n_iter = 0, n_slow = 0, n_ext_lanes = 0, n_deep = 0, n_deep_l = 0, n_pf_l = 0, n_win_l = 0;
 	// MRG == 2: the stack entry this lane's next backward step will read, fetched a step ahead (pf.w != 0: valid -- an entry's `info`, its
 	// match's end position >= 1, sits in the top half of w).  A backward step that is not the last of its row is always followed by the
 	// step for entry j + 1 of the same row, and the steps in between write survivors at depths <= j only (SeedStack::store).
@@ -343,6 +350,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	if (MRG && BLK == 1) {
 		bf.occ = occ32_bufs(ix); bf.ptab = buf_rsrc(ix.ptab, ix.ptab_bytes);
 		bf.stk = buf_rsrc(B.tmp_intv, MRG == 2 ? B.tmp_intv_bytes : 0);      // (an area beyond a descriptor's reach -- long reads -- reads as empty: no entry is ever prefetched)
+		bf.nib = buf_rsrc(B.seq_nib, MRG == 2 && !RD ? B.seq_nib_bytes : 0);
 	}
 	while (__ballot(L.st != SS_DONE)) {       // (a lane that has run out of reads stays in the loop: its quad still needs it to fetch and count, fm_occ_coop)
 		if (STATS) ++n_iter;
@@ -484,7 +492,21 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 			u32 pf_off = BUF_OOB;       // byte offset of the lane's next stack entry in the spill area (SeedStack::glob_col, packed entries)
 			if (MRG == 2 && back && !short_ent && S.n_lds && L.j + 1 < L.nprev && L.j + 1 >= S.n_lds)
 				pf_off = ((u32)(blockIdx.x * blockDim.x + threadIdx.x) * (u32)S.glob_cap + PTAB_MAX) * (u32)sizeof(BiIntv) + (u32)(L.top - (L.j + 1)) * (u32)sizeof(uint4);
-			const u32 nb = (u32)ext_one_trip(ix, bf, ext, blocks, src, cb, back, tl, L.code, ok, pf_off, pf);
+			u32 nb;
+			if (MRG == 2 && !RD) {
+				// Reads too long for an LDS copy take their bases from the packed array in HBM, 16 per fetch -- a dependent round trip of its
+				// own whenever some lane of the wave walks into a new word, i.e. in most iterations.  The word a lane will need next
+				// (forward sweep: base i + 1, looked at when this step's result is in; backward row: base i - 1, at the row's end) comes
+				// with this step's loads instead.
+				u32 win_off = BUF_OOB, ww = 0; u64 wnew = 0;
+				const int want = back ? L.i - 1 : L.i + 1;
+				if (ext && want >= 0 && want < L.len) {
+					ww = (u32)((L.qoff + (u64)want) >> 4);
+					if (ww != L.win_w && ww != L.win2_w) win_off = ww << 3;
+				}
+				nb = (u32)ext_one_trip<true>(ix, bf, ext, blocks, src, cb, back, tl, L.code, ok, pf_off, pf, win_off, &wnew);
+				if (win_off != BUF_OOB && B.seq_nib_bytes <= BUF_MAX_BYTES) { L.win2 = wnew; L.win2_w = ww; if (STATS) ++n_win_l; }
+			} else nb = (u32)ext_one_trip(ix, bf, ext, blocks, src, cb, back, tl, L.code, ok, pf_off, pf);
 			if (STATS && ext) { if (blocks) nblk += nb; else ++ntab; }
 		}
 		if (ext) {
@@ -533,7 +555,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	}
 	if (STATS) {
 		atomicAdd(&B.ctr->occ_blocks, (unsigned long long)nblk); atomicAdd(&B.ctr->tab_lookups, (unsigned long long)ntab);
-		atomicAdd(&B.ctr->prof[10], (unsigned long long)n_deep_l); atomicAdd(&B.ctr->prof[11], (unsigned long long)n_pf_l);
+		atomicAdd(&B.ctr->prof[9], (unsigned long long)n_win_l); atomicAdd(&B.ctr->prof[10], (unsigned long long)n_deep_l); atomicAdd(&B.ctr->prof[11], (unsigned long long)n_pf_l);
 		if ((threadIdx.x & 63) == 0) { atomicAdd(&B.ctr->prof[12], (unsigned long long)n_deep); atomicAdd(&B.ctr->prof[13], (unsigned long long)n_iter); atomicAdd(&B.ctr->prof[14], (unsigned long long)n_slow); atomicAdd(&B.ctr->prof[15], (unsigned long long)n_ext_lanes); }
 	}
 }
@@ -549,7 +571,7 @@ template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k
 	SeedLane L;                   // only the read window (qoff, win, win_w, len), x, sx, i, ik, code and the emitter are used
 	L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len; L.em.intv = B.intv; L.em.r = -1; L.em.n = 0; L.em.overflow = false;
 	L.em.split_len = 0x7fffffff; L.em.split_width = 0; L.em.cand = 0; L.em.base = 0;
-	L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u; L.x = 0; L.sx = 0; L.i = 0; L.code = 0; L.rd = nullptr; L.rd_on = 0; L.raw = nullptr; L.off = nullptr;
+	L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u; L.win2 = 0; L.win2_w = ~0u; L.x = 0; L.sx = 0; L.i = 0; L.code = 0; L.rd = nullptr; L.rd_on = 0; L.raw = nullptr; L.off = nullptr;
 	L.ik.x0 = L.ik.x1 = L.ik.x2 = L.ik.info = 0;
 	const u64 *nib = B.seq_nib;
 	const int lane = threadIdx.x & 63;
@@ -557,7 +579,7 @@ template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k
 	int st = T_FETCH, pool_base = 0, pool_cnt = 0;
 	u32 nblk = 0, ntab = 0, weight = 0;
 	SeedBufs bf;
-	if (MRG && BLK == 1) { bf.occ = occ32_bufs(ix); bf.ptab = buf_rsrc(ix.ptab, ix.ptab_bytes); bf.stk = buf_rsrc(nullptr, 0); }
+	if (MRG && BLK == 1) { bf.occ = occ32_bufs(ix); bf.ptab = buf_rsrc(ix.ptab, ix.ptab_bytes); bf.stk = buf_rsrc(nullptr, 0); bf.nib = bf.stk; }
 	while (__ballot(st != T_DONE)) {          // (a lane without reads stays: its quad needs it, fm_occ_coop)
 		const u64 wm = __ballot(st == T_FETCH);
 		if (wm) {

@@ -28,6 +28,8 @@
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct uint4 { uint32_t x, y, z, w; };
 struct int2 { int x, y; };
+struct uint2 { uint32_t x, y; };
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { uint2 r; r.x = x; r.y = y; return r; }
 struct int4 { int x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 static inline int4 make_int4(int x, int y, int z, int w) { int4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
@@ -123,9 +125,17 @@ static inline int mock_readlane(int v, int src) { uint64_t o[64], m; mock_exchan
 #define __builtin_amdgcn_wave_barrier() mock_wave_barrier()
 #define DEV_KEEP(v) ((void)0)            /* scheduling fence of the device code (dev_common.h): nothing to do here */
 // buffer descriptors and range-checked 16-byte loads (gfx9 raw buffers: a lane whose offset + 16 exceeds the size reads zeros)
+struct mock_v4u32 { uint32_t v[4]; uint32_t operator[](int i) const { return v[i]; } };
 struct mock_rsrc_t { const unsigned char *p; uint32_t n; };
 typedef mock_rsrc_t __amdgpu_buffer_rsrc_t;
-struct mock_v4u32 { uint32_t v[4]; uint32_t operator[](int i) const { return v[i]; } };
+struct mock_v2u32 { uint32_t v[2]; uint32_t operator[](int i) const { return v[i]; } };
+static inline mock_v2u32 __builtin_amdgcn_raw_buffer_load_b64(mock_rsrc_t r, int voff, int soff, int aux)
+{
+	(void)aux; mock_v2u32 o; memset(&o, 0, sizeof o);
+	const uint64_t off = (uint64_t)(uint32_t)voff + (uint32_t)soff;
+	if (off + 8 <= r.n) memcpy(&o, r.p + off, 8);
+	return o;
+}
 static inline mock_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void *p, short stride, int n, int flags) { (void)stride; (void)flags; mock_rsrc_t r; r.p = (const unsigned char*)p; r.n = (uint32_t)n; return r; }
 static inline mock_v4u32 __builtin_amdgcn_raw_buffer_load_b128(mock_rsrc_t r, int voff, int soff, int aux)
 {

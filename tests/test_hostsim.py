@@ -40,16 +40,24 @@ def test_hostsim_regs_match_golden(sim):
 def test_hostsim_long_read_dedup_ring_sizes(monkeypatch):
     """k_dedup_wave's ring of {H,E} columns is sized by the batch's longest read, and its workgroups shrink to two waves (2048 columns) or one
     (4096) to stay within a workgroup's LDS; a ring too small for a patch alignment's band sends that alignment to the one-lane fall-back
-    (256 columns): same regions in every case (2048 columns / two waves: the GPU suite's long-read tests)."""
+    (256 columns): same regions in every case (2048 columns / two waves: the GPU suite's long-read tests).  The second run also takes the
+    one-round-trip seeding kernel in its long-read form (BWAGPU_SEED_MRG=2: stack entries and read windows fetched a step ahead)."""
     prefix, g = testdata.small_index()
     orc = orcapi.OrcIndex(prefix)
     reads = simdata.make_reads_long(g, 1, length=1800, seed=23)
     seqs, off = testdata.flat(reads)
     want = orc.align(pacbio_opt(), seqs, off)
-    for ring in ("256", "4096"):
-        monkeypatch.setenv("BWAGPU_DEDUP_RING", ring)
+    for ring, mrg in (("256", "0"), ("4096", "2")):
+        monkeypatch.setenv("BWAGPU_DEDUP_RING", ring); monkeypatch.setenv("BWAGPU_SEED_MRG", mrg)
         s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
-        assert_regs_equal(*want, *s2.align(pacbio_opt(), seqs, off), f"1.8 kb -x pacbio read, dedup ring {ring}")
+        s2.set_stats(True)
+        assert_regs_equal(*want, *s2.align(pacbio_opt(), seqs, off), f"1.8 kb -x pacbio read, dedup ring {ring}, seeding variant {mrg}")
+        if mrg == "2":       # a read too long for an LDS copy: its 16-base windows arrive one step ahead, with the index blocks
+            import ctypes as C
+            prof = (C.c_ulonglong * 16)()
+            s2.L.bwagpu_debug_prof.argtypes = [C.c_void_p, C.c_void_p]
+            s2.L.bwagpu_debug_prof(s2.h, prof)
+            assert prof[9] >= 1800 // 16, f"only {prof[9]} read windows were fetched ahead"
         s2.close()
     orc.close()
 

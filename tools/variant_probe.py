@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--dense-sa", type=int, default=4)
     ap.add_argument("--lib", default=None, help="(tests) the mock-runtime build of the library")
+    ap.add_argument("--long-reads", type=int, default=0, help="long-read mode (BASELINE configs[4]): this many reads of --long-len bases, -x pacbio, one batch, one handle")
+    ap.add_argument("--long-len", type=int, default=10000)
     args = ap.parse_args()
 
     from bwa_amd import simdata
@@ -44,6 +46,8 @@ def main():
     from bwa_amd.structs import default_opt
 
     g = np.load(args.codes, mmap_mode="r")
+    if args.long_reads:
+        return long_mode(args, g)
     opt = default_opt()
     opt.flag |= 0x2
     S = max(1, args.streams)
@@ -56,6 +60,7 @@ def main():
     n_batch = batches[0][1].shape[0] - 1
 
     base_digest = None
+    shared = None
     for cfg in [""] + [c for c in args.configs if c.strip()]:
         sets = dict(kv.split("=", 1) for kv in cfg.split())
         for k, v in sets.items():
@@ -63,10 +68,7 @@ def main():
         t0 = time.time()
         res = {"config": cfg or "defaults"}
         try:
-            gpu = BwaGpu(args.prefix, lib_path=args.lib)          # (a fresh handle per configuration: some switches are read when the index is laid out)
-            if args.dense_sa:
-                gpu.densify_sa(args.dense_sa)
-            gpu.set_taps(False)
+            gpu, shared = open_index(args, sets, shared)
             handles = [gpu] + [gpu.clone() for _ in range(S - 1)]
             for hdl, (flat, off) in zip(handles, batches):
                 hdl.set_taps(False)
@@ -99,8 +101,66 @@ def main():
             res["steps"] = args.steps; res["streams"] = S
             for hdl in handles[1:]:
                 hdl.close()
-            gpu.close()
+            if gpu is not shared:
+                gpu.close()
         except Exception as e:       # (a configuration the library refuses must not take the others with it)
+            res["error"] = repr(e)
+        res["wall_s"] = round(time.time() - t0, 1)
+        print(json.dumps(res), flush=True)
+        for k in sets:
+            del os.environ[k]
+
+
+LAYOUT_KEYS = ("BWAGPU_OCC32", "BWAGPU_OCC32_SB_SHIFT", "BWAGPU_PTAB_M")      # switches read when the index is laid out in HBM: such a configuration gets a handle of its own
+
+
+def open_index(args, sets, shared):
+    """The handle a configuration runs on: one shared by all configurations whose switches are read per batch, a fresh one otherwise."""
+    from bwa_amd.api import BwaGpu
+    own = any(k in LAYOUT_KEYS for k in sets)
+    if not own and shared is not None:
+        return shared, shared
+    gpu = BwaGpu(args.prefix, lib_path=args.lib)
+    if args.dense_sa:
+        gpu.densify_sa(args.dense_sa)
+    gpu.set_taps(False)
+    return gpu, (shared if own else gpu)
+
+
+def long_mode(args, g):
+    """BASELINE configs[4]'s layout (bench.py's long-read leg): one resident batch of long reads, -x pacbio, stage times of the hot path."""
+    from bwa_amd import simdata
+    from bwa_amd.structs import pacbio_opt
+    n, L = args.long_reads, args.long_len
+    reads = simdata.make_reads_long(g, n, length=L, seed=7)
+    flat, off = np.ascontiguousarray(reads.reshape(-1)), np.arange(0, n + 1, dtype=np.int64) * L
+    opt = pacbio_opt()
+    base_digest, shared = None, None
+    for cfg in [""] + [c for c in args.configs if c.strip()]:
+        sets = dict(kv.split("=", 1) for kv in cfg.split())
+        for k, v in sets.items():
+            os.environ[k] = v
+        t0 = time.time()
+        res = {"config": cfg or "defaults", "mode": f"{n} reads of {L} bp, -x pacbio"}
+        try:
+            gpu, shared = open_index(args, sets, shared)
+            gpu.upload(flat, off)
+            gpu.run(opt)                                          # warm-up: arenas learn their sizes
+            runs = []
+            for _ in range(args.passes):
+                t1 = time.perf_counter(); gpu.run(opt); ms = (time.perf_counter() - t1) * 1e3
+                st = gpu.stats(); st["ms_pass"] = ms; runs.append(st)
+            best = min(runs, key=lambda s_: s_["ms_pass"])
+            res["stage_ms"] = {k: round(best[k], 2) for k in ("ms_seed", "ms_publish", "ms_sa", "ms_chain", "ms_seedsw", "ms_extend", "ms_dedup", "ms_total")}
+            res["ms_per_pass"] = round(best["ms_pass"], 2); res["reads_per_s"] = round(n / best["ms_pass"] * 1e3, 1)
+            counts, regs = gpu.download()
+            res["result_sha256_16"] = hashlib.sha256(counts.tobytes() + regs.tobytes()).hexdigest()[:16]
+            if base_digest is None:
+                base_digest = res["result_sha256_16"]
+            res["same_result_as_defaults"] = res["result_sha256_16"] == base_digest
+            if gpu is not shared:
+                gpu.close()
+        except Exception as e:
             res["error"] = repr(e)
         res["wall_s"] = round(time.time() - t0, 1)
         print(json.dumps(res), flush=True)
