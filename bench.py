@@ -505,6 +505,8 @@ def run_variants(args, prefix):
     if not args.no_longread:
         legs.append(("long_reads", ["--long-reads", str(args.long_reads), "--long-len", str(args.long_len)], args.variants_timeout * 0.6))
     for name, extra, limit in legs:
+        if name == "long_reads":
+            cfgs = cfgs + ["BWAGPU_PUBLISH_BLK=1"] + [c + " BWAGPU_PUBLISH_BLK=1" for c in cfgs[-1:]]      # (the workgroup-per-read interval sort exists for long-read batches only)
         log(f"[bench] variants, {name} (child process, <= {limit:.0f} s): {cfgs}")
         t = time.time()
         leg = {"runs": []}

@@ -874,8 +874,12 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 #undef SEED_LAUNCH
 		HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_seed3+k_seed", hipGetErrorString(e_)); }
-		hipLaunchKernelGGL(k_publish, grid, block, 0, h->stream, *opt, B);
-		hipLaunchKernelGGL(k_expand, grid, block, 0, h->stream, *opt, B);
+		if (h->max_len > WAVE_EXT_MAX_LEN && getenv("BWAGPU_PUBLISH_BLK") && atoi(getenv("BWAGPU_PUBLISH_BLK")) != 0)    // long reads: one workgroup per read sorts, counts and expands (opt-in until measured)
+			hipLaunchKernelGGL(k_publish_blk, dim3((unsigned)(n < (int)grid.x ? (n > 0 ? n : 1) : (int)grid.x)), block, 0, h->stream, *opt, B);
+		else {
+			hipLaunchKernelGGL(k_publish, grid, block, 0, h->stream, *opt, B);
+			hipLaunchKernelGGL(k_expand, grid, block, 0, h->stream, *opt, B);
+		}
 		HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "publish+expand", hipGetErrorString(e_)); }
 		i64 sa_blocks = (h->slot_cap + BLOCK - 1) / BLOCK;

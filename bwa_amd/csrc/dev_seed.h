@@ -303,6 +303,108 @@ __global__ void __launch_bounds__(256) k_publish(bwagpu_opt_t opt, Batch B)
 	if (B.stats) atomicAdd(&B.ctr->n_intv, (unsigned long long)nintv);
 }
 
+// k_publish + k_expand for long reads: one workgroup per read.  A 10 kb read leaves a few thousand intervals and as many SA rows; sorted
+// and expanded by one lane (24-byte records in HBM, a dependent access per comparison) that was 0.17 s per batch whatever its size --
+// a floor, not a rate.  Here the keys are sorted in LDS (bitonic network over {info, index}; equal keys are identical intervals, so any
+// sorting order gives the reference's result), the records are permuted through the block's share of the seeding scratch area, the slot
+// counts are a block reduction and every interval writes its SA rows from its own prefix sum.  A read with more than PUB_MAX intervals
+// takes the serial path inside this kernel.
+#define PUB_MAX 4096
+__global__ void __launch_bounds__(256) k_publish_blk(bwagpu_opt_t opt, Batch B)
+{
+	__shared__ u64 s_key[PUB_MAX];
+	__shared__ unsigned short s_idx[PUB_MAX];
+	__shared__ u32 s_part[256];
+	__shared__ u64 s_bcast[2];
+	const int tid = threadIdx.x;
+	const int cap = B.max_len + 1 + PTAB_MAX;
+	Intv3 *tmp = (Intv3*)(B.tmp_intv + (size_t)blockIdx.x * blockDim.x * (size_t)cap);       // this block's lanes' interval stacks: free since k_seed ended
+	const size_t tmp_recs = (size_t)blockDim.x * (size_t)cap * sizeof(BiIntv) / sizeof(Intv3);
+	u64 nintv = 0;
+	for (int r = blockIdx.x; r < B.n_reads; r += gridDim.x) {
+		const int n = B.intv_n[r];
+		if (tid == 0) { B.intv_off[r] = (i64)r * B.mem_cap; B.seed_n[r] = 0; B.seed_off[r] = 0; B.node_off[r] = 0; }
+		if (n == 0) continue;                      // (uniform over the block)
+		Intv3 *iv = B.intv + (size_t)r * B.mem_cap;
+		if (n > PUB_MAX || (size_t)n > tmp_recs) { if (tid == 0) dev_introsort(iv, n, IntvInfoLess()); }
+		else if (n > 1) {
+			int N = 2; while (N < n) N <<= 1;
+			for (int i = tid; i < N; i += blockDim.x) { s_key[i] = i < n ? iv[i].info : ~0ull; s_idx[i] = (unsigned short)i; }
+			__syncthreads();
+			for (int k = 2; k <= N; k <<= 1)
+				for (int j = k >> 1; j > 0; j >>= 1) {
+					for (int i = tid; i < N; i += blockDim.x) {
+						const int p = i ^ j;
+						if (p > i) {
+							const u64 a = s_key[i], b = s_key[p];
+							const bool up = (i & k) == 0;
+							if (up ? a > b : a < b) { s_key[i] = b; s_key[p] = a; const unsigned short t = s_idx[i]; s_idx[i] = s_idx[p]; s_idx[p] = t; }
+						}
+					}
+					__syncthreads();
+				}
+			for (int i = tid; i < n; i += blockDim.x) tmp[i] = iv[s_idx[i]];
+			__syncthreads();
+			for (int i = tid; i < n; i += blockDim.x) iv[i] = tmp[i];
+		}
+		__syncthreads();
+		// SA rows per interval (mem_chain's k-loop bounds, bwamem.c:304-305): block-wide sum, then one reservation
+		u32 mine = 0;
+		for (int i = tid; i < n; i += blockDim.x) {
+			const u64 x2 = iv[i].x2;
+			const u64 step = x2 > (u64)opt.max_occ ? x2 / opt.max_occ : 1;
+			const u64 cnt = (x2 + step - 1) / step;
+			mine += (u32)(cnt < (u64)opt.max_occ ? cnt : (u64)opt.max_occ);
+		}
+		s_part[tid] = mine;
+		__syncthreads();
+		if (tid == 0) {
+			u64 ns = 0;
+			for (int t = 0; t < (int)blockDim.x; ++t) ns += s_part[t];
+			const u64 soff = atomicAdd(&B.ctr->seed_used, (unsigned long long)ns);
+			const u64 nnode = ns / 4 + 2;
+			const u64 noff = atomicAdd(&B.ctr->node_used, (unsigned long long)nnode);
+			u64 okv = 1;
+			if (soff + ns > (u64)B.slot_cap) { atomicOr(&B.ctr->overflow, 2ull); B.intv_n[r] = 0; okv = 0; }
+			else if (noff + nnode > (u64)B.node_cap) { atomicOr(&B.ctr->overflow, 4ull); B.intv_n[r] = 0; okv = 0; }
+			else { B.seed_n[r] = (i32)ns; B.seed_off[r] = (i64)soff; B.node_off[r] = (i64)noff; nintv += (u64)n; }
+			s_bcast[0] = okv; s_bcast[1] = soff;
+		}
+		__syncthreads();
+		if (s_bcast[0]) {
+			// k_expand's loop (bwamem.c:304-305): an interval's first slot is the sum of the counts of all intervals before it in sorted
+			// order -- a running prefix over chunks of 256 intervals
+			const u64 soff = s_bcast[1];
+			__syncthreads();
+			u32 base = 0;
+			for (int i0 = 0; i0 < n; i0 += blockDim.x) {
+				const int i = i0 + tid;
+				Intv3 p; p.x0 = p.x2 = p.info = 0; u32 cnt = 0; int step = 1;
+				if (i < n) {
+					p = iv[i];
+					step = p.x2 > (u64)opt.max_occ ? (int)(p.x2 / opt.max_occ) : 1;
+					const u64 c64 = (p.x2 + (u64)step - 1) / (u64)step;
+					cnt = (u32)(c64 < (u64)opt.max_occ ? c64 : (u64)opt.max_occ);
+				}
+				s_part[tid] = cnt;
+				__syncthreads();
+				if (tid == 0) { u32 run = 0; for (int t = 0; t < (int)blockDim.x; ++t) { const u32 v = s_part[t]; s_part[t] = run; run += v; } s_bcast[0] = run; }
+				__syncthreads();
+				if (i < n) {
+					const i32 qb = (i32)(p.info >> 32), sl = (i32)((u32)p.info - (u32)(p.info >> 32));
+					u64 s = soff + base + s_part[tid];
+					i64 k = 0;
+					for (u32 c = 0; c < cnt; ++c, k += step, ++s) { B.slot_pos[s] = p.x0 + (u64)k; B.slot_qbeg[s] = qb; B.slot_len[s] = sl; }
+				}
+				base += (u32)s_bcast[0];
+				__syncthreads();
+			}
+		}
+		__syncthreads();
+	}
+	if (B.stats && tid == 0) atomicAdd(&B.ctr->n_intv, (unsigned long long)nintv);
+}
+
 // RD: the batch's reads are short enough for an LDS copy (Batch::rd_words > 0)
 // BLK: how the extension reads the index -- 1 (default): the 32-byte layout (DevIndex::occ32), each lane fetching its own blocks; 0: the
 //      reference-format 64-byte blocks, per lane (BWAGPU_OCC32=0); 2: those blocks fetched quad-cooperatively (fm_occ_coop; BWAGPU_OCC32=0

@@ -41,14 +41,15 @@ def test_hostsim_long_read_dedup_ring_sizes(monkeypatch):
     """k_dedup_wave's ring of {H,E} columns is sized by the batch's longest read, and its workgroups shrink to two waves (2048 columns) or one
     (4096) to stay within a workgroup's LDS; a ring too small for a patch alignment's band sends that alignment to the one-lane fall-back
     (256 columns): same regions in every case (2048 columns / two waves: the GPU suite's long-read tests).  The second run also takes the
-    one-round-trip seeding kernel in its long-read form (BWAGPU_SEED_MRG=2: stack entries and read windows fetched a step ahead)."""
+    one-round-trip seeding kernel in its long-read form (BWAGPU_SEED_MRG=2: stack entries and read windows fetched a step ahead) and the
+    workgroup-per-read form of the interval sort and SA-row expansion (BWAGPU_PUBLISH_BLK=1)."""
     prefix, g = testdata.small_index()
     orc = orcapi.OrcIndex(prefix)
     reads = simdata.make_reads_long(g, 1, length=1800, seed=23)
     seqs, off = testdata.flat(reads)
     want = orc.align(pacbio_opt(), seqs, off)
     for ring, mrg in (("256", "0"), ("4096", "2")):
-        monkeypatch.setenv("BWAGPU_DEDUP_RING", ring); monkeypatch.setenv("BWAGPU_SEED_MRG", mrg)
+        monkeypatch.setenv("BWAGPU_DEDUP_RING", ring); monkeypatch.setenv("BWAGPU_SEED_MRG", mrg); monkeypatch.setenv("BWAGPU_PUBLISH_BLK", "1" if mrg == "2" else "0")
         s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
         s2.set_stats(True)
         assert_regs_equal(*want, *s2.align(pacbio_opt(), seqs, off), f"1.8 kb -x pacbio read, dedup ring {ring}, seeding variant {mrg}")
@@ -60,6 +61,32 @@ def test_hostsim_long_read_dedup_ring_sizes(monkeypatch):
             assert prof[9] >= 1800 // 16, f"only {prof[9]} read windows were fetched ahead"
         s2.close()
     orc.close()
+
+
+def test_hostsim_publish_per_workgroup(monkeypatch):
+    """BWAGPU_PUBLISH_BLK=1 (long-read batches): one workgroup per read sorts the interval list (bitonic network in LDS; equal keys are
+    identical intervals), counts the SA rows and expands them from a block-wide prefix sum.  With -k 9 on the repeat-rich 2 Mb genome a
+    1.3 kb read leaves ~800 intervals -- several 256-interval chunks -- next to a read with a handful and one with none: interval lists
+    (order included), slot counts and regions equal the one-lane-per-read kernels'."""
+    import refapi
+    if not refapi.have_ref():
+        pytest.skip("oracle/_ref not built (needed to index the 2 Mb genome)")
+    prefix, g = testdata.medium_index()
+    reads = simdata.make_reads_long(g, 2, length=1300, seed=5)
+    seqs, off = testdata.ragged([reads[1], reads[0][:40], np.full(300, 4, dtype=np.uint8), reads[0][:1150]])
+    opt = pacbio_opt(); opt.min_seed_len = 9; opt.max_occ = 7
+    got = {}
+    for blk in ("0", "1"):
+        monkeypatch.setenv("BWAGPU_PUBLISH_BLK", blk)
+        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+        s2.set_stats(True)
+        c, r = s2.align(opt, seqs, off)
+        ic, iv = s2.tap_intervals()
+        st = s2.stats()
+        got[blk] = (c.tobytes(), r.tobytes(), ic.tobytes(), iv.tobytes(), st["n_seeds"], st["n_intv"])
+        assert ic.max() > 512 and ic.min() == 0
+        s2.close()
+    assert got["0"] == got["1"]
 
 
 def test_hostsim_stage_taps_match_golden(sim):
