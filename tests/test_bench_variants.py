@@ -1,0 +1,33 @@
+"""CPU: bench.py's `variants` object end to end -- bench.run_variants starts tools/variant_probe.py as a child process per leg and collects its
+JSON lines -- against the mock runtime (one stream: the mock is single-threaded), so that the code the driver's GPU run depends on has run
+somewhere before it runs there.  The numbers mean nothing here; the structure and the result digests do."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+import hostsim_build
+import testdata
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_bench_variants_object(monkeypatch, tmp_path):
+    import bench
+    prefix, g = testdata.small_index()
+    for ext in (".bwt", ".sa", ".pac", ".ann", ".amb"):          # (the probe reads <prefix>.codes.npy next to the index files)
+        os.symlink(prefix + ext, str(tmp_path / ("idx" + ext)))
+    np.save(str(tmp_path / "idx.codes.npy"), g)
+    monkeypatch.setenv("BWA_AMD_PROBE_LIB", hostsim_build.build())
+    args = argparse.Namespace(variants="BWAGPU_SEED_MRG=1;BWAGPU_SEED_MRG=2", variants_timeout=600.0, reads=8, read_len=150, streams=1, dense_sa=0,
+                              no_longread=False, long_reads=1, long_len=1150)
+    res = bench.run_variants(args, str(tmp_path / "idx"))
+    short, long_ = res["short_reads"], res["long_reads"]
+    assert short["rc"] == 0 and long_["rc"] == 0, (short, long_)
+    assert [r["config"] for r in short["runs"]] == ["defaults", "BWAGPU_SEED_MRG=1", "BWAGPU_SEED_MRG=2"]
+    assert [r["config"] for r in long_["runs"]] == ["defaults", "BWAGPU_SEED_MRG=2", "BWAGPU_SEED_MRG=2 BWAGPU_PUBLISH_BLK=1"]
+    for r in short["runs"] + long_["runs"]:
+        assert "error" not in r and r["same_result_as_defaults"] is True, r
+    assert all("ms_per_step" in r and "stage_ms_solo" in r for r in short["runs"]) and all("ms_per_pass" in r for r in long_["runs"])
