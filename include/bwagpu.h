@@ -311,7 +311,9 @@ int bwagpu_get_stats(const bwagpu_t *h, bwagpu_stats_t *out);
  *   seqs[i].seq holds ASCII bases or 0..4 codes; on return it holds 0..4 codes (the in-place mutation
  *   contract of mem_align1_core, bwamem.c:1087-1088).  regs[i] receives {n, m, a} with a malloc()ed array
  *   the caller free()s, exactly as worker2 does (bwamem.c:1227,1231).  With MEM_F_PE set in opt->flag nothing
- *   changes on this path: both mates are aligned independently (bwamem.c:1209-1213). */
+ *   changes on this path: both mates are aligned independently (bwamem.c:1209-1213).
+ *   With n = 1 it is also the device half of mem_align1 (bwamem_extra.c:102-112; example.c:40): the binding copies the sequence,
+ *   calls this and then the reference's own mem_mark_primary_se (integration/mem_process_seqs_gpu.c, __wrap_mem_align1). */
 int bwagpu_align_bseq(bwagpu_t *h, const bwagpu_opt_t *opt, int n, bwagpu_bseq1_t *seqs, bwagpu_alnreg_v *regs);
 
 /* Flat form of the same call: reads are nt4 codes (0..4) concatenated in `seqs`, read i = seqs[off[i]..off[i+1]).

@@ -79,3 +79,23 @@ void __wrap_mem_process_seqs(const mem_opt_t *opt, const bwt_t *bwt, const bntse
 	if (bwa_verbose >= 3)
 		fprintf(stderr, "[M::%s] Processed %d reads in %.3f CPU sec, %.3f real sec\n", "mem_process_seqs", n, cputime() - ctime, realtime() - rtime);
 }
+
+/* mem_align1 (bwamem_extra.c:102-112; the library entry point bwamem.h documents, caller example.c:40): one read through the same
+ * device path.  Like the reference's it works on a copy of the sequence, marks primaries with a random id and returns a malloc'd array
+ * (-Wl,--wrap=mem_align1: oracle/_ref/example_gpu is the reference's example.c linked this way). */
+mem_alnreg_v __wrap_mem_align1(const mem_opt_t *opt, const bwt_t *bwt, const bntseq_t *bns, const uint8_t *pac, int l_seq, const char *seq_)
+{
+	bseq1_t s; mem_alnreg_v ar; int rc;
+	bwagpu_t *h = gpu_handle(bwt, bns, pac);
+	memset(&s, 0, sizeof s);
+	s.l_seq = l_seq; s.seq = (char*)malloc(l_seq > 0 ? l_seq : 1);
+	memcpy(s.seq, seq_, l_seq);
+	ar.n = ar.m = 0; ar.a = 0;
+	/* was: mem_align1_core(opt, bwt, bns, pac, l_seq, seq, 0)  (bwamem_extra.c:108) */
+	rc = bwagpu_align_bseq(h, (const bwagpu_opt_t*)opt, 1, (bwagpu_bseq1_t*)&s, (bwagpu_alnreg_v*)&ar);
+	if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s: %s\n", __func__, bwagpu_strerror(rc), bwagpu_last_error(h)); exit(EXIT_FAILURE); }
+	mem_mark_primary_se(opt, ar.n, ar.a, lrand48());
+	free(s.seq);
+	return ar;
+}
+

@@ -82,3 +82,50 @@ def test_dropin_binary_sam_identical(tmp_path):
 
     assert run(refapi.REF_BWA, [fa, f1]) == run(bwa_gpu, [fa, f1])               # single-end
     assert run(refapi.REF_BWA, [fa, f1, f2]) == run(bwa_gpu, [fa, f1, f2])       # paired-end (mem_pestat + mem_sam_pe on the host)
+
+
+def _example_lines(binary, fa, fq, env=None):
+    import subprocess
+    p = subprocess.run([binary, fa, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=1200)
+    assert p.returncode == 0, p.stderr[-500:]
+    return p.stdout
+
+
+def _example_inputs(tmp_path, g, n, seed):
+    reads = simdata.make_reads_se(g, n, seed=seed, sub=0.02, n_frac=0.002)
+    fq = str(tmp_path / "lite.fq")
+    simdata.write_fastq(fq, reads)
+    return fq
+
+
+@needs_ref
+def test_mem_align1_binding_hostsim(tmp_path):
+    """mem_align1 (bwamem_extra.c:102-112) through the drop-in boundary: oracle/_ref/example_gpu is the reference's example.c
+    (bwamem-lite: mem_align1 + mem_reg2aln per read, position / mapQ / CIGAR / NM printed) with mem_align1 redirected (ld --wrap) to
+    integration/mem_process_seqs_gpu.c -> bwagpu_align_bseq of one read + the reference's own mem_mark_primary_se.  Here the device
+    library is the mock-runtime build (found first through LD_LIBRARY_PATH); same lines as the stock example."""
+    import os
+    import hostsim_build
+    ex, ex_gpu = os.path.join(refapi.REF_DIR, "example"), os.path.join(refapi.REF_DIR, "example_gpu")
+    if not (os.path.exists(ex) and os.path.exists(ex_gpu)):
+        pytest.skip("oracle/_ref/example[_gpu] not built (make -C oracle example)")
+    fa, g = testdata.small_index()
+    fq = _example_inputs(tmp_path, g, 12, seed=71)
+    os.symlink(hostsim_build.build(), str(tmp_path / "libbwagpu.so"))
+    env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    want, got = _example_lines(ex, fa, fq), _example_lines(ex_gpu, fa, fq, env=env)
+    assert got == want and want.count(b"\n") >= 10
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_mem_align1_binding_gpu(tmp_path):
+    """The same on the device: every read is a batch of one through bwagpu_align_bseq."""
+    import os
+    ex, ex_gpu = os.path.join(refapi.REF_DIR, "example"), os.path.join(refapi.REF_DIR, "example_gpu")
+    if not (os.path.exists(ex) and os.path.exists(ex_gpu)):
+        pytest.skip("oracle/_ref/example[_gpu] not built (make -C oracle example)")
+    fa, g = testdata.medium_index()
+    fq = _example_inputs(tmp_path, g, 300, seed=72)
+    want, got = _example_lines(ex, fa, fq), _example_lines(ex_gpu, fa, fq)
+    assert got == want and want.count(b"\n") >= 280
