@@ -505,7 +505,9 @@ def run_variants(args, prefix):
         legs.append(("long_reads", ["--long-reads", str(args.long_reads), "--long-len", str(args.long_len), "--passes", "1"], args.variants_timeout * 0.6))
     for name, extra, limit in legs:
         if name == "long_reads":
-            cfgs = cfgs[-1:] + [c + " BWAGPU_PUBLISH_BLK=1" for c in cfgs[-1:]]      # (the last configuration alone and with the workgroup-per-read interval sort, which exists for long-read batches only)
+            # the last configuration alone, with the workgroup-per-read interval sort, and with the DP kernels' query bases in LDS on top (the
+            # latter two exist for long-read batches only)
+            cfgs = cfgs[-1:] + [cfgs[-1] + " BWAGPU_PUBLISH_BLK=1", cfgs[-1] + " BWAGPU_PUBLISH_BLK=1 BWAGPU_LONG_QLDS=1", "BWAGPU_LONG_QLDS=1"]
         log(f"[bench] variants, {name} (child process, <= {limit:.0f} s): {cfgs}")
         t = time.time()
         leg = {"runs": []}

@@ -838,6 +838,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		// memory round trips per iteration of the seeding kernels (dev_seed.h, k_seed's MRG): 0 = as compiled, 1 = table entries and whole index
 		// blocks in one trip, 2 = plus the next interval-stack entry a step ahead
 		int seed_mrg = getenv("BWAGPU_SEED_MRG") ? atoi(getenv("BWAGPU_SEED_MRG")) : SEED_MRG_DEFAULT;
+		const bool long_qlds = getenv("BWAGPU_LONG_QLDS") && atoi(getenv("BWAGPU_LONG_QLDS")) != 0;   // long-read DP kernels: query bases from an LDS copy
 		if (h->ix.occ32 == nullptr || h->ix.ptab == nullptr || h->ix.occ32_bytes > BUF_MAX_BYTES || h->ix.ptab_bytes > BUF_MAX_BYTES) seed_mrg = 0;   // (its loads address 32-bit offsets into buffers of < 4 GiB: a genome beyond ~8.5 Gbp of index keeps the plain kernels)
 		B.tmp_intv_bytes = (u64)n_threads * (u64)(h->max_len + 1 + PTAB_MAX) * sizeof(BiIntv);
 		B.seq_nib_bytes = (((u64)h->n_bases + 15) / 16) * 8;
@@ -913,13 +914,18 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			i64 nblk = ((i64)n + 3) / 4, cap = 256 * 8;
 			const int occ = getenv("BWAGPU_EXT_OCC") ? atoi(getenv("BWAGPU_EXT_OCC")) : 6;   // waves per SIMD the register allocation aims at (measured at 3.1 Gbp: 4 -> 63 ms, 5 -> 58 ms, 6 -> 56 ms)
 			const dim3 g((unsigned)(nblk < cap ? nblk : cap));
-			if (occ == 6) hipLaunchKernelGGL((k_extend_wave<false, 6>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
-			else if (occ == 5) hipLaunchKernelGGL((k_extend_wave<false, 5>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
-			else hipLaunchKernelGGL((k_extend_wave<false, 4>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
+			if (occ == 6) hipLaunchKernelGGL((k_extend_wave<false, 6>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0, 0);
+			else if (occ == 5) hipLaunchKernelGGL((k_extend_wave<false, 5>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0, 0);
+			else hipLaunchKernelGGL((k_extend_wave<false, 4>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0, 0);
 		} else if (max_score < (1 << 24) && ring_cols <= 2048) {
-			int lds_wave = 8 * ring_cols + 32;   // the band's columns only: independent of the read length
-			i64 nblk = ((i64)n + 3) / 4, cap = 256 * 8;
-			hipLaunchKernelGGL((k_extend_wave<true, 4>), dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, ring_cols);
+			// the band's columns only: independent of the read length -- plus, optionally, a copy of the read (BWAGPU_LONG_QLDS=1, opt-in until
+			// measured: the rows' query-base look-ups then stay in LDS), with fewer waves per workgroup where four copies exceed its 64 KiB
+			int q_cap = long_qlds ? (h->max_len + 15) & ~15 : 0;
+			if (8 * ring_cols + 32 + q_cap > 65536) q_cap = 0;
+			const int lds_wave = 8 * ring_cols + 32 + q_cap;
+			int wpb = 4; while (wpb > 1 && lds_wave * wpb > 65536) wpb >>= 1;
+			i64 nblk = ((i64)n + wpb - 1) / wpb, cap = 256 * 8 * (4 / wpb);
+			hipLaunchKernelGGL((k_extend_wave<true, 4>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, lds_wave, ring_cols, q_cap);
 		} else                                  // very wide bands: lane-per-read scalar DP with the columns in HBM scratch
 			hipLaunchKernelGGL(k_extend, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
@@ -934,9 +940,12 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			int rc_ = 256; while (rc_ < need && rc_ < 4096) rc_ <<= 1;
 			if (getenv("BWAGPU_DEDUP_RING")) rc_ = atoi(getenv("BWAGPU_DEDUP_RING"));      // test hook: a power of two, 256..4096
 			if (rc_ < 256 || rc_ > 4096 || (rc_ & (rc_ - 1))) rc_ = 1024;
-			const int wpb = rc_ <= 1024 ? 4 : (rc_ <= 2048 ? 2 : 1);
+			int q_cap = long_qlds ? (h->max_len + 15) & ~15 : 0;      // room for a patch alignment's query segment next to the ring (see k_extend_wave above)
+			if (8 * rc_ + 32 + q_cap > 65536) q_cap = 0;
+			int wpb = rc_ <= 1024 ? 4 : (rc_ <= 2048 ? 2 : 1);
+			while (wpb > 1 && (8 * rc_ + 32 + q_cap) * wpb > 65536) wpb >>= 1;
 			i64 nblk = ((i64)n + wpb - 1) / wpb, cap = B.dp_waves / wpb > 0 ? B.dp_waves / wpb : 1;   // dp_h/dp_e hold one scratch region per wave
-			hipLaunchKernelGGL(k_dedup_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)(8 * rc_ + 32) * wpb, h->stream, h->ix, *opt, B, rc_);
+			hipLaunchKernelGGL(k_dedup_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)(8 * rc_ + 32 + q_cap) * wpb, h->stream, h->ix, *opt, B, rc_, q_cap);
 		} else
 			hipLaunchKernelGGL(k_dedup, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
@@ -1295,6 +1304,7 @@ extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, i
 	DevBuf d_seq, d_pac, d_cases, d_out, d_scr, d_pac2;
 	int rc = BWAGPU_OK;
 	const int grid = n_cases < 2048 ? n_cases : 2048;
+	const bool dbg_qlds = getenv("BWAGPU_LONG_QLDS") && atoi(getenv("BWAGPU_LONG_QLDS")) != 0;   // kinds 1 and 3 with the LDS copy of the query (as the long-read kernels make it under the same switch)
 	hipError_t e = hipSuccess;
 	if (d_seq.ensure((size_t)n_seq_bytes + 16) || d_pac.ensure((size_t)n_seq_bytes / 4 + 16) || d_cases.ensure((size_t)n_cases * sizeof(bwagpu_dp_case_t)) || d_out.ensure((size_t)n_cases * DBG_OUT_INTS * 4)) { h->err = "hipMalloc failed (debug)"; rc = BWAGPU_ENOMEM; goto done; }
 	e = hipMemcpyAsync(d_seq.p, seqs, (size_t)n_seq_bytes, hipMemcpyHostToDevice, h->stream);
@@ -1306,17 +1316,19 @@ extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, i
 		if (kind == 0) {
 			if (max_q > WAVE_EXT_MAX_LEN) { rc = BWAGPU_EINVAL; goto done; }
 			const size_t lds = (8 * (size_t)(max_q + 2 + 64) + 5 * (size_t)((max_q + 64 + 3) & ~3) + 32 + 15) & ~(size_t)15;
-			hipLaunchKernelGGL((k_debug_extend<false>), dim3(grid), dim3(64), lds, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, 0, d_out.as<i32>());
+			hipLaunchKernelGGL((k_debug_extend<false>), dim3(grid), dim3(64), lds, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, 0, d_out.as<i32>(), 0);
 		} else if (kind == 1) {
 			int ring_cols = 256; while (ring_cols < 2 * max_w + 4 + 128) ring_cols <<= 1;
 			if (ring_cols > 4096) { rc = BWAGPU_EINVAL; goto done; }
-			hipLaunchKernelGGL((k_debug_extend<true>), dim3(grid), dim3(64), (size_t)8 * ring_cols + 32, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, ring_cols, d_out.as<i32>());
+			const int q_cap = dbg_qlds && 8 * ring_cols + 32 + ((max_q + 15) & ~15) <= 65536 ? (max_q + 15) & ~15 : 0;
+			hipLaunchKernelGGL((k_debug_extend<true>), dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, ring_cols, d_out.as<i32>(), q_cap);
 		} else if (kind == 2) {
 			hipLaunchKernelGGL(k_debug_global, dim3(grid), dim3(64), (size_t)CIG_LDS_BYTES(CIG_Z_BIG), h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), d_out.as<i32>());
 		} else if (kind == 3) {
 			int ring_cols = 256; while (ring_cols < 2 * max_w + 4 + 128) ring_cols <<= 1;
 			if (ring_cols > 4096) { rc = BWAGPU_EINVAL; goto done; }
-			hipLaunchKernelGGL(k_debug_global_ring, dim3(grid), dim3(64), (size_t)8 * ring_cols + 32, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), ring_cols, d_out.as<i32>());
+			const int q_cap = dbg_qlds && 8 * ring_cols + 32 + ((max_q + 15) & ~15) <= 65536 ? (max_q + 15) & ~15 : 0;
+			hipLaunchKernelGGL(k_debug_global_ring, dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), ring_cols, d_out.as<i32>(), q_cap);
 		} else if (kind == 5) {
 			int max_t = 1; for (int i = 0; i < n_cases; ++i) if (cases[i].t_len > max_t) max_t = cases[i].t_len;
 			i64 z_cap = ((i64)max_t + 16) * ((CIGL_MAX_COLS + 15) & ~15); z_cap = (z_cap + 15) & ~(i64)15;

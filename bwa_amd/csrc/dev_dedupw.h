@@ -8,7 +8,8 @@
 #include "dev_dedup.h"
 #include "dev_extw.h"
 
-struct DedupLds { i32 *hd, *e; const int8_t *mat; int ring_mask; i32 *H, *E; /* lane 0's HBM scratch columns (dev_ksw_global2_score) for bands wider than the ring */ };
+struct DedupLds { i32 *hd, *e; const int8_t *mat; int ring_mask; i32 *H, *E; /* lane 0's HBM scratch columns (dev_ksw_global2_score) for bands wider than the ring */
+	u8 *qbuf; int qcap; /* optional (BWAGPU_LONG_QLDS=1): room for a patch alignment's query segment in alignment order */ };
 
 // ksw_global2 without traceback (ksw.c:540-619), columns in a ring of ring_mask+1 entries, lazily initialised
 __device__ int wave_global2_score_ring(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen, i64 t0, int tdir, int tlen,
@@ -19,6 +20,14 @@ __device__ int wave_global2_score_ring(const DevIndex &ix, const bwagpu_opt_t &o
 	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
 	i32 *hd = L.hd, *e_ = L.e; const int rm = L.ring_mask;
 	int init_hi = -1, treg = 0;
+	// the segment's bases in alignment order, in LDS when there is room: every pass of every row looks its lanes' bases up, and from the
+	// batch's array that is a dependent memory round trip in a loop that runs one wave per SIMD (see ext_read_wave)
+	const u8 *qs = nullptr;
+	if (L.qcap >= qlen && qlen > 0) {
+		for (int j = lane; j < qlen; j += 64) L.qbuf[j] = q[q0 + j * qdir];
+		wave_sync();
+		qs = L.qbuf;
+	}
 	for (int i = 0; i < tlen; ++i) {
 		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
 		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
@@ -40,7 +49,7 @@ __device__ int wave_global2_score_ring(const DevIndex &ix, const bwagpu_opt_t &o
 		for (int b = beg; b < end; b += 64) {
 			const int j = b + lane; const bool act = j < end;
 			int dg = hd[j & rm]; const int ec = e_[j & rm];
-			const int qc = j < qlen ? (int)q[q0 + j * qdir] : 4;
+			const int qc = j < qlen ? (qs ? (int)qs[j] : (int)q[q0 + j * qdir]) : 4;
 			const int sc = L.mat[tb * 5 + qc];
 			const int bnd_next = hd[(b + 64) & rm];
 			if (b != beg && lane == 0) dg = bnd;
@@ -208,16 +217,17 @@ __device__ void dedup_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 }
 
 // One wavefront per read.
-__global__ void __launch_bounds__(256) k_dedup_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int ring_cols)
+__global__ void __launch_bounds__(256) k_dedup_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int ring_cols, int q_cap)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, ddw_lds)
 	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	unsigned char *base = ddw_lds + (size_t)wave_in_blk * (8 * ring_cols + 32);
+	unsigned char *base = ddw_lds + (size_t)wave_in_blk * (8 * ring_cols + 32 + q_cap);
 	DedupLds L;
 	L.hd = (i32*)base; L.e = L.hd + ring_cols; L.ring_mask = ring_cols - 1;
 	int8_t *m = (int8_t*)(base + (size_t)8 * ring_cols);
 	if (lane < 25) m[lane] = opt.mat[lane];
 	L.mat = m;
+	L.qbuf = base + (size_t)8 * ring_cols + 32; L.qcap = q_cap;
 	{
 		const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_blk;
 		L.H = B.dp_h + wave * (B.max_len + 2) * DPS; L.E = B.dp_e + wave * (B.max_len + 2) * DPS;

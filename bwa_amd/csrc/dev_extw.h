@@ -93,7 +93,8 @@ DEVFN bwagpu_seed_t uni_seed(bwagpu_seed_t s) { s.rbeg = uni64(s.rbeg); s.qbeg =
 // ksw_extend2 only touches columns i-w .. i+w+1, columns left of the band are dead and columns right of it still hold their
 // first-row values, so eh[] is a ring of ring_mask+1 columns that is initialised lazily as the band advances, and scores come
 // from a 25-entry copy of the matrix (mat) and the query bases in global memory.
-struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t *mat; };
+// qbuf/qcap (RING, optional): room for a copy of the read; qlds: that copy once ext_read_wave has made it (null: bases come from the batch in HBM)
+struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t *mat; u8 *qbuf; int qcap; const u8 *qlds; };
 
 template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, int mat_max, const u8 *q, int q0, const int qdir, int qlen,
 								   i64 t0, const int tdir, int tlen, int w, int end_bonus, int h0, const WaveLds &L, u64 &cells, u64 &fast)
@@ -117,7 +118,8 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 	// most extensions of a read's true locus: a couple of wave steps instead of ~60 rows.
 	// score of reference base b against column j's query base: the read's profile (built once per read, indexed in the read's own
 	// coordinates whichever way the extension runs), or for long reads the matrix copy and the base itself
-	#define SCORE_AT(b, j) (RING ? (int)L.mat[(b) * 5 + q[q0 + (j) * qdir]] : (int)qp[(b) * qs + q0 + (j) * qdir])
+	#define QBASE(idx) (L.qlds ? (int)L.qlds[idx] : (int)q[idx])       // (wave-uniform choice)
+	#define SCORE_AT(b, j) (RING ? (int)L.mat[(b) * 5 + QBASE(q0 + (j) * qdir)] : (int)qp[(b) * qs + q0 + (j) * qdir])
 	if (tlen >= qlen && qlen > 0) {
 		const int oe_min = oe_del < oe_ins ? oe_del : oe_ins;
 		int P = 0;
@@ -312,7 +314,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 				// the LDS region is padded by 64 columns, so inactive lanes may read (never write) past `end`
 				int2 old = eh[EHI(j)];
 				int sc;
-				if (RING) { const int qc = j < qlen ? (int)q[q0 + j * qdir] : 4; sc = L.mat[tb * 5 + qc]; }
+				if (RING) { const int qc = j < qlen ? QBASE(q0 + j * qdir) : 4; sc = L.mat[tb * 5 + qc]; }
 				else sc = qrow[(act ? j : beg) * qdir];
 				const int bnd_next = eh[EHI(b + 64)].x;             // next pass's diagonal for its lane 0, before lane 63 overwrites it
 				if (b != beg && lane == 0) old.x = bnd;
@@ -368,16 +370,18 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 	hist_flush();
 	#undef EHI
 	#undef SCORE_AT
+	#undef QBASE
 	cells += cells32;
 	ExtRes r; r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
 	return r;
 }
 
 // mem_chain2aln for all chains of one read, executed by one wavefront.
-template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const WaveLds &L,
+template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const WaveLds &L0,
 							  u64 &n_calls, u64 &n_cells, u64 &n_refb, u64 &n_fast)
 {
 	const int lane = threadIdx.x & 63;
+	WaveLds L = L0;
 	r = uni(r);
 	int n_ch = uni(B.chain_n[r]);
 	if (n_ch == 0) { if (lane == 0) B.reg_n_raw[r] = 0; return; }
@@ -397,6 +401,16 @@ template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwa
 			for (int k = 0; k < 5; ++k) L.qp[k * L.qstride + j] = L.mat[k * 5 + qc];
 		}
 		wave_sync();
+	} else {
+		// Long reads (BWAGPU_LONG_QLDS=1): every pass of every DP row looks up its lanes' query bases, and from the batch's array in HBM that
+		// is a dependent memory round trip in a loop that runs one or two waves per SIMD -- nothing hides it.  One copy of the read per
+		// wave (1 byte per base, the read's own coordinates) turns it into an LDS look-up next to the matrix's.
+		L.qlds = nullptr;
+		if (L.qcap >= l_query && l_query > 0) {
+			for (int j = lane; j < l_query; j += 64) L.qbuf[j] = query[j];
+			wave_sync();
+			L.qlds = L.qbuf;
+		}
 	}
 	for (int ci = 0; ci < n_ch; ++ci) {
 		const bwagpu_chain_t c = chains[ci];
@@ -529,18 +543,22 @@ template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwa
 
 // One wavefront per read, 4 waves per workgroup; dynamic LDS = 4 private regions of
 // 8*(max_len+2+64) bytes of {H,E} columns + 5*qstride bytes of query profile, or (RING, long reads) of ring_cols*8 + 32 bytes.
-template <bool RING, int OCC> __global__ void __launch_bounds__(256, OCC) k_extend_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int lds_per_wave, int ring_cols)
+// q_cap (RING): bytes per wave behind the ring and the matrix for a copy of the read (0: none)
+template <bool RING, int OCC> __global__ void __launch_bounds__(256, OCC) k_extend_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int lds_per_wave, int ring_cols, int q_cap)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, dyn_lds)
 	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	WaveLds L;
+	L.qlds = nullptr;
 	unsigned char *base = dyn_lds + (size_t)wave_in_blk * lds_per_wave;
 	L.eh = (int2*)base;                                      // max_len + 2 columns + 64 of read-only padding
 	if (RING) {
 		int8_t *m = (int8_t*)(base + (size_t)8 * ring_cols);
 		if (lane < 25) m[lane] = opt.mat[lane];
 		L.mat = m; L.ring_mask = ring_cols - 1; L.qp = nullptr; L.qstride = 0;
+		L.qbuf = base + (size_t)8 * ring_cols + 32; L.qcap = q_cap;
 	} else {
+		L.qbuf = nullptr; L.qcap = 0;
 		L.qstride = (B.max_len + 64 + 3) & ~3;
 		L.qp = (int8_t*)(base + (size_t)8 * (B.max_len + 2 + 64));
 		int8_t *m = L.qp + 5 * L.qstride;                  // (the scoring matrix: dynamic indexing of the kernel argument would go through scratch memory)

@@ -317,6 +317,14 @@ def test_sim_extend_ring_fuzz(sim):
     run_extend(sim, 1, 120, 160, 12, need_stale=False)
 
 
+def test_sim_ring_forms_with_the_query_in_lds(sim, monkeypatch):
+    """BWAGPU_LONG_QLDS=1: the ring-mode extension and the score-only ring aligner read their query bases from an LDS copy (the switchable
+    form of the long-read kernels); same outputs as the reference's ksw_extend2 / ksw_global2."""
+    monkeypatch.setenv("BWAGPU_LONG_QLDS", "1")
+    run_extend(sim, 1, 48, 400, seed=17, need_stale=False)
+    run_global(sim, 3, 32, 150, 90, seed=18)
+
+
 def test_sim_global_fuzz(sim):
     run_global(sim, 2, 160, 150, 192, 13)
     run_global(sim, 3, 80, 150, 1 << 30, 14)

@@ -42,14 +42,15 @@ def test_hostsim_long_read_dedup_ring_sizes(monkeypatch):
     (4096) to stay within a workgroup's LDS; a ring too small for a patch alignment's band sends that alignment to the one-lane fall-back
     (256 columns): same regions in every case (2048 columns / two waves: the GPU suite's long-read tests).  The second run also takes the
     one-round-trip seeding kernel in its long-read form (BWAGPU_SEED_MRG=2: stack entries and read windows fetched a step ahead) and the
-    workgroup-per-read form of the interval sort and SA-row expansion (BWAGPU_PUBLISH_BLK=1)."""
+    workgroup-per-read form of the interval sort and SA-row expansion (BWAGPU_PUBLISH_BLK=1), and keeps the query bases of the extension and
+    patch-alignment rows in LDS (BWAGPU_LONG_QLDS=1)."""
     prefix, g = testdata.small_index()
     orc = orcapi.OrcIndex(prefix)
     reads = simdata.make_reads_long(g, 1, length=1800, seed=23)
     seqs, off = testdata.flat(reads)
     want = orc.align(pacbio_opt(), seqs, off)
     for ring, mrg in (("256", "0"), ("4096", "2")):
-        monkeypatch.setenv("BWAGPU_DEDUP_RING", ring); monkeypatch.setenv("BWAGPU_SEED_MRG", mrg); monkeypatch.setenv("BWAGPU_PUBLISH_BLK", "1" if mrg == "2" else "0")
+        monkeypatch.setenv("BWAGPU_DEDUP_RING", ring); monkeypatch.setenv("BWAGPU_SEED_MRG", mrg); monkeypatch.setenv("BWAGPU_PUBLISH_BLK", "1" if mrg == "2" else "0"); monkeypatch.setenv("BWAGPU_LONG_QLDS", "1" if mrg == "2" else "0")
         s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
         s2.set_stats(True)
         assert_regs_equal(*want, *s2.align(pacbio_opt(), seqs, off), f"1.8 kb -x pacbio read, dedup ring {ring}, seeding variant {mrg}")
