@@ -277,6 +277,11 @@ def main():
         hdl.upload(np.ascontiguousarray(rd.reshape(-1)), np.arange(0, rd.shape[0] + 1, dtype=np.int64) * args.read_len)   # resident in HBM
         batches.append(rd)
     n_batch = batches[0].shape[0]
+    variant_files = []
+    if world == 1 and args.variants.strip():       # the variants leg (a child process at the end) runs on these very batches
+        for si, rd in enumerate(batches):
+            variant_files.append(os.path.join(os.path.dirname(prefix), f"variant_batch{si}.npy"))
+            np.save(variant_files[-1], rd)
 
     log(f"[bench] index resident, {S} batches of {n_batch} reads uploaded")
     # one untimed instrumented solo pass: algorithmic work counters of batch 0 (roofline numerator) and solo kernel times
@@ -484,14 +489,14 @@ def main():
             except Exception as e:   # (the long-read leg must not take the headline line with it)
                 out["longread"] = {"error": repr(e)}
     if world == 1 and args.variants.strip():
-        out["variants"] = run_variants(args, prefix)
+        out["variants"] = run_variants(args, prefix, variant_files)
     out["bench_wall_s"] = round(time.time() - t_all, 1)
     sys.stdout.flush()
     print(json.dumps(out), flush=True)      # the one JSON line, last thing on stdout (RCCL prints a version banner of its own at start-up)
     sys.exit(rc_exit)
 
 
-def run_variants(args, prefix):
+def run_variants(args, prefix, batch_files=()):
     """Kernel variants that sit behind environment switches, A/B'd against the defaults on the headline's workload by tools/variant_probe.py
     in a CHILD process with a time limit: solo stage times, step time with the same batches in flight, and a digest of the regions that
     must equal the defaults'.  Informational -- `value` above is always the default configuration's; a variant that faults or hangs costs
@@ -500,9 +505,12 @@ def run_variants(args, prefix):
     probe = [sys.executable, os.path.join(ROOT, "tools", "variant_probe.py"), "--prefix", prefix, "--codes", prefix + ".codes.npy", "--dense-sa", str(args.dense_sa)]
     res = {"what": "tools/variant_probe.py in child processes: each configuration's solo stage times (ms per batch), step time with --streams batches in flight (short reads) or "
                    "time per pass (long reads), and whether its regions equal the default configuration's; `value` is never taken from here"}
-    legs = [("short_reads", ["--reads", str(args.reads), "--read-len", str(args.read_len), "--streams", str(args.streams), "--steps", "6"], args.variants_timeout)]
+    legs = [("short_reads", ["--reads", str(args.reads), "--read-len", str(args.read_len), "--streams", str(args.streams), "--steps", "6"] +
+             (["--batch-files", ",".join(batch_files)] if batch_files else []), args.variants_timeout)]
     if not args.no_longread:
-        legs.append(("long_reads", ["--long-reads", str(args.long_reads), "--long-len", str(args.long_len), "--passes", "1"], args.variants_timeout * 0.6))
+        long_file = os.path.join(os.path.dirname(prefix), "long_reads.npy")       # (left there by the long-read leg)
+        legs.append(("long_reads", ["--long-reads", str(args.long_reads), "--long-len", str(args.long_len), "--passes", "1"] +
+                     (["--long-file", long_file] if os.path.exists(long_file) else []), args.variants_timeout * 0.6))
     for name, extra, limit in legs:
         if name == "long_reads":
             # the last configuration alone, with the workgroup-per-read interval sort, and with the DP kernels' query bases in LDS on top (the
@@ -538,6 +546,7 @@ def longread_bench(args, prefix, g, threads, cache):
     L, n = args.long_len, args.long_reads
     log(f"[bench] long-read leg: {n} reads of {L} bp")
     reads = simdata.make_reads_long(g, n, length=L, seed=7)
+    np.save(os.path.join(cache, "long_reads.npy"), reads)         # (the variants leg aligns the same batch)
     gpu = BwaGpu(prefix)
     if args.dense_sa:
         gpu.densify_sa(args.dense_sa)

@@ -23,7 +23,11 @@ def test_bench_variants_object(monkeypatch, tmp_path):
     monkeypatch.setenv("BWA_AMD_PROBE_LIB", hostsim_build.build())
     args = argparse.Namespace(variants="BWAGPU_SEED_MRG=1;BWAGPU_SEED_MRG=2", variants_timeout=600.0, reads=8, read_len=150, streams=1, dense_sa=0,
                               no_longread=False, long_reads=1, long_len=1150)
-    res = bench.run_variants(args, str(tmp_path / "idx"))
+    from bwa_amd import simdata
+    short = simdata.make_reads_se(g, 8, seed=3)                   # bench.py hands its own batches over as files
+    np.save(str(tmp_path / "variant_batch0.npy"), short)
+    np.save(str(tmp_path / "long_reads.npy"), simdata.make_reads_long(g, 1, length=1150, seed=4))
+    res = bench.run_variants(args, str(tmp_path / "idx"), [str(tmp_path / "variant_batch0.npy")])
     short, long_ = res["short_reads"], res["long_reads"]
     assert short["rc"] == 0 and long_["rc"] == 0, (short, long_)
     assert [r["config"] for r in short["runs"]] == ["defaults", "BWAGPU_SEED_MRG=1", "BWAGPU_SEED_MRG=2"]

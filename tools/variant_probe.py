@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--lib", default=os.environ.get("BWA_AMD_PROBE_LIB"), help="(tests) the mock-runtime build of the library")
     ap.add_argument("--long-reads", type=int, default=0, help="long-read mode (BASELINE configs[4]): this many reads of --long-len bases, -x pacbio, one batch, one handle")
     ap.add_argument("--long-len", type=int, default=10000)
+    ap.add_argument("--batch-files", default="", help="comma-separated .npy files (reads x bases, nt4 codes) to use as the batches instead of drawing them (bench.py hands over its own)")
+    ap.add_argument("--long-file", default="", help="the same for the long-read batch")
     args = ap.parse_args()
 
     from bwa_amd import simdata
@@ -52,11 +54,15 @@ def main():
     opt.flag |= 0x2
     S = max(1, args.streams)
     batches = []
+    files = [f for f in args.batch_files.split(",") if f]
     for si in range(S):
-        r1, r2 = simdata.make_reads_pe(g, args.reads // 2, length=args.read_len, seed=1000 + si)      # (bench.py's rank-0 batches)
-        rd = np.empty((2 * r1.shape[0], r1.shape[1]), dtype=np.uint8)
-        rd[0::2] = r1; rd[1::2] = r2
-        batches.append((np.ascontiguousarray(rd.reshape(-1)), np.arange(0, rd.shape[0] + 1, dtype=np.int64) * args.read_len))
+        if files:
+            rd = np.load(files[si % len(files)])
+        else:
+            r1, r2 = simdata.make_reads_pe(g, args.reads // 2, length=args.read_len, seed=1000 + si)      # (bench.py's rank-0 batches)
+            rd = np.empty((2 * r1.shape[0], r1.shape[1]), dtype=np.uint8)
+            rd[0::2] = r1; rd[1::2] = r2
+        batches.append((np.ascontiguousarray(rd.reshape(-1)), np.arange(0, rd.shape[0] + 1, dtype=np.int64) * rd.shape[1]))
     n_batch = batches[0][1].shape[0] - 1
 
     base_digest = None
@@ -132,7 +138,10 @@ def long_mode(args, g):
     from bwa_amd import simdata
     from bwa_amd.structs import pacbio_opt
     n, L = args.long_reads, args.long_len
-    reads = simdata.make_reads_long(g, n, length=L, seed=7)
+    if args.long_file:
+        reads = np.load(args.long_file); n, L = reads.shape
+    else:
+        reads = simdata.make_reads_long(g, n, length=L, seed=7)
     flat, off = np.ascontiguousarray(reads.reshape(-1)), np.arange(0, n + 1, dtype=np.int64) * L
     opt = pacbio_opt()
     base_digest, shared = None, None
