@@ -278,7 +278,7 @@ def main():
         batches.append(rd)
     n_batch = batches[0].shape[0]
     variant_files = []
-    if world == 1 and args.variants.strip():       # the variants leg (a child process at the end) runs on these very batches
+    if world == 1 and args.variants.strip() and not args.no_cpu_baseline:       # the variants leg (a child process at the end) runs on these very batches
         for si, rd in enumerate(batches):
             variant_files.append(os.path.join(os.path.dirname(prefix), f"variant_batch{si}.npy"))
             np.save(variant_files[-1], rd)
@@ -488,7 +488,7 @@ def main():
                     log("[bench] LONG-READ PARITY GATE FAILED")
             except Exception as e:   # (the long-read leg must not take the headline line with it)
                 out["longread"] = {"error": repr(e)}
-    if world == 1 and args.variants.strip():
+    if world == 1 and args.variants.strip() and not args.no_cpu_baseline:      # (a full run only: the profiling runs pass --no-cpu-baseline)
         out["variants"] = run_variants(args, prefix, variant_files)
     out["bench_wall_s"] = round(time.time() - t_all, 1)
     sys.stdout.flush()

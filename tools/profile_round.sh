@@ -2,7 +2,8 @@
 # Profiles of one round on the GPU box (run through gpurun): kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in passes of
 # their own (the TCC block cannot count both at once, MI355X_MICROARCH.md), all on `bench.py --steps 1 --warmup 0 --streams 1`
 # (default workload: 500 k pairs of 2x150 bp vs the 3.1 Gbp stand-in).  Results land under gpurun_out/<tag>/; copy what is to be
-# kept into profiles/.
+# kept into profiles/.  Kernel variants are chosen through the environment as everywhere else, e.g.
+#   BWAGPU_SEED_MRG=2 tools/profile_round.sh r04_mrg2
 tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
