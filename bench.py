@@ -513,9 +513,9 @@ def run_variants(args, prefix, batch_files=()):
                      (["--long-file", long_file] if os.path.exists(long_file) else []), args.variants_timeout * 0.6))
     for name, extra, limit in legs:
         if name == "long_reads":
-            # the last configuration alone, with the workgroup-per-read interval sort, and with the DP kernels' query bases in LDS on top (the
-            # latter two exist for long-read batches only)
-            cfgs = cfgs[-1:] + [cfgs[-1] + " BWAGPU_PUBLISH_BLK=1", cfgs[-1] + " BWAGPU_PUBLISH_BLK=1 BWAGPU_LONG_QLDS=1", "BWAGPU_LONG_QLDS=1"]
+            # the last configuration alone, with the workgroup-per-read interval sort, with the DP kernels' query bases and the seed re-scoring's
+            # state in LDS on top; then the latter two alone (all three exist for long-read batches only)
+            cfgs = cfgs[-1:] + [cfgs[-1] + " BWAGPU_PUBLISH_BLK=1", cfgs[-1] + " BWAGPU_PUBLISH_BLK=1 BWAGPU_LONG_QLDS=1 BWAGPU_SEEDSW_LDS=1", "BWAGPU_LONG_QLDS=1", "BWAGPU_SEEDSW_LDS=1"]
         log(f"[bench] variants, {name} (child process, <= {limit:.0f} s): {cfgs}")
         t = time.time()
         leg = {"runs": []}

@@ -899,8 +899,16 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_chain", hipGetErrorString(e_)); }
 		if (any_seedsw && h->max_len > WAVE_EXT_MAX_LEN) {   // long reads: one wavefront per read, one lane per seed
-			i64 nblk = ((i64)n + 3) / 4, cap = B.dp_waves / 4 > 0 ? B.dp_waves / 4 : 1;      // (one DP scratch region per wave)
-			hipLaunchKernelGGL(k_seedsw_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), block, 0, h->stream, h->ix, *opt, B);
+			int sc_max = 0; for (int k = 0; k < 25; ++k) if (opt->mat[k] > sc_max) sc_max = opt->mat[k];
+			const i64 wcap = B.dp_waves > 0 ? B.dp_waves : 1;
+			if (getenv("BWAGPU_SEEDSW_LDS") && atoi(getenv("BWAGPU_SEEDSW_LDS")) != 0 && SEEDSW_LDS_COLS * sc_max < 65536) {
+				// the cell loop's state in LDS (dev_local_score_lds), one wave per workgroup; opt-in until measured
+				if (SEEDSW_LDS_COLS * sc_max < 256) hipLaunchKernelGGL((k_seedsw_wave<8>), dim3((unsigned)(n < wcap ? n : wcap)), dim3(64), (size_t)SEEDSW_LDS_COLS * 64 * 3, h->stream, h->ix, *opt, B);
+				else hipLaunchKernelGGL((k_seedsw_wave<16>), dim3((unsigned)(n < wcap ? n : wcap)), dim3(64), (size_t)SEEDSW_LDS_COLS * 64 * 5, h->stream, h->ix, *opt, B);
+			} else {
+				i64 nblk = ((i64)n + 3) / 4, cap = wcap / 4 > 0 ? wcap / 4 : 1;      // (one DP scratch region per wave)
+				hipLaunchKernelGGL((k_seedsw_wave<0>), dim3((unsigned)(nblk < cap ? nblk : cap)), block, 0, h->stream, h->ix, *opt, B);
+			}
 		} else if (any_seedsw) hipLaunchKernelGGL(k_seedsw, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_seedsw", hipGetErrorString(e_)); }

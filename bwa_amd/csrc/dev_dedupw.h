@@ -251,7 +251,8 @@ __global__ void __launch_bounds__(256) k_dedup_wave(DevIndex ix, bwagpu_opt_t op
 // ---- mem_flt_chained_seeds (bwamem.c:624-645) for long reads: one wavefront per read, one lane per seed --------------------
 // The local re-alignments of a read's seeds are independent of each other; only the compaction that follows is ordered.
 // (seedsw_read, dev_seedsw.h, is the lane-per-read form of the same logic.)
-__device__ void seedsw_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, i32 *H, i32 *E, u64 &calls, u64 &cells)
+// CB: 0 = DP rows in HBM scratch (H, E); 8 / 16 = everything in LDS (dev_local_score_lds: HE, Q, rows)
+template <int CB> __device__ void seedsw_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, i32 *H, i32 *E, void *HE, u8 *Q, const u64 *rows, u64 &calls, u64 &cells)
 {
 	const int lane = threadIdx.x & 63;
 	const int n_ch = uni(B.chain_n[r]);
@@ -283,7 +284,8 @@ __device__ void seedsw_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, co
 				if (is_rev) { i64 t2 = fb; fb = (l_pac << 1) - fe; fe = (l_pac << 1) - t2; }
 				if (rb < fb) rb = fb;
 				if (re > fe) re = fe;
-				sc = dev_local_score(ix, opt, query + qb, qe - qb, rb, (int)(re - rb), H, E, cells);
+				if (CB) sc = dev_local_score_lds<CB ? CB : 8>(ix, opt, rows, query + qb, qe - qb, rb, (int)(re - rb), (typename SwCell<CB ? CB : 8>::T*)HE, Q, cells);
+				else sc = dev_local_score(ix, opt, query + qb, qe - qb, rb, (int)(re - rb), H, E, cells);
 				++calls;
 			}
 		}
@@ -308,17 +310,25 @@ __device__ void seedsw_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, co
 	wave_sync();
 }
 
-__global__ void __launch_bounds__(256) k_seedsw_wave(DevIndex ix, bwagpu_opt_t opt, Batch B)
+// CB != 0: per wave, dynamic LDS of SEEDSW_LDS_COLS x 64 cells of 2 CB bits + as many query bytes (launched with one wave per workgroup)
+template <int CB> __global__ void __launch_bounds__(256) k_seedsw_wave(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
+	HIP_DYNAMIC_SHARED(unsigned char, ssw_lds)
 	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_blk;
 	i32 *H = B.dp_h + wave * (B.max_len + 2) * DPS + lane;
 	i32 *E = B.dp_e + wave * (B.max_len + 2) * DPS + lane;
+	const size_t cell_bytes = CB ? (size_t)CB / 4 : 0, per_wave = (size_t)SEEDSW_LDS_COLS * 64 * (cell_bytes + 1);
+	unsigned char *base = ssw_lds + (size_t)wave_in_blk * per_wave;
+	void *HE = CB ? (void*)(base + (size_t)lane * cell_bytes) : nullptr;
+	u8 *Q = CB ? base + (size_t)SEEDSW_LDS_COLS * 64 * cell_bytes + lane : nullptr;
+	u64 rows[5] = { 0, 0, 0, 0, 0 };
+	if (CB) mat_rows(opt, rows);
 	u64 calls = 0, cells = 0;
 	for (;;) {
 		const long long k = wave_fetch(&B.ctr->next_seedsw);
 		if (k >= B.n_reads) break;
-		seedsw_read_wave(ix, opt, B, (int)k, H, E, calls, cells);
+		seedsw_read_wave<CB>(ix, opt, B, (int)k, H, E, HE, Q, rows, calls, cells);
 	}
 	if (B.stats) { atomicAdd(&B.ctr->sw_calls, (unsigned long long)calls); atomicAdd(&B.ctr->sw_cells, (unsigned long long)cells); }
 }

@@ -30,6 +30,50 @@ __device__ int dev_local_score(const DevIndex &ix, const bwagpu_opt_t &opt, cons
 	return best;
 }
 
+// The same score with everything the cell loop touches in LDS (k_seedsw_wave<CB>, BWAGPU_SEEDSW_LDS=1).  The window is under 200 x 200
+// (bwamem.c:611): per lane, 200 columns of {H, E} packed into one cell of 2 x CB bits (CB = 8 when every score stays below 256 -- a = 1, the
+// presets' value -- else 16), [column][lane], and the window's query bases as bytes next to them; the five rows of the scoring matrix are
+// five 64-bit words in scalar registers (mat_rows), a cell's score a shift of the row its target base selects.  In the form above every
+// cell waits for four dependent memory round trips (its query base, the matrix entry, E and H from HBM scratch) in a kernel that runs
+// one wave per SIMD; here it waits for two independent LDS reads.  H, E and F are clamped at 0 by the recurrence, so unsigned cells hold them.
+#define SEEDSW_LDS_COLS 200
+template <int CB> struct SwCell;
+template <> struct SwCell<8> { typedef unsigned short T; };
+template <> struct SwCell<16> { typedef u32 T; };
+DEVFN void mat_rows(const bwagpu_opt_t &opt, u64 rows[5])
+{
+	for (int b = 0; b < 5; ++b) { u64 r = 0; for (int k = 0; k < 5; ++k) r |= (u64)(u8)opt.mat[b * 5 + k] << (8 * k); rows[b] = r; }
+}
+template <int CB> __device__ int dev_local_score_lds(const DevIndex &ix, const bwagpu_opt_t &opt, const u64 rows[5], const u8 *q, int qlen, i64 t0, int tlen,
+													   typename SwCell<CB>::T *HE, u8 *Q, u64 &cells)
+{
+	typedef typename SwCell<CB>::T cell_t;
+	const int e_del = opt.e_del, e_ins = opt.e_ins, oe_del = opt.o_del + e_del, oe_ins = opt.o_ins + e_ins;
+	const u32 mask = (1u << CB) - 1;
+	int best = 0;
+	for (int j = 0; j < qlen; ++j) { HE[j * 64] = 0; Q[j * 64] = q[j]; }
+	for (int i = 0; i < tlen; ++i) {
+		const int tb = ref_base(ix, t0 + i);
+		const u64 row = tb == 0 ? rows[0] : tb == 1 ? rows[1] : tb == 2 ? rows[2] : tb == 3 ? rows[3] : rows[4];
+		int f = 0, hdiag = 0;
+		for (int j = 0; j < qlen; ++j) {
+			const u32 he = HE[j * 64];
+			const int qc = Q[j * 64];
+			int h = hdiag + (int)(int8_t)(u8)(row >> (8 * qc)), e = (int)(he >> CB), t;
+			hdiag = (int)(he & mask);
+			if (h < e) h = e;
+			if (h < f) h = f;
+			if (h < 0) h = 0;
+			if (h > best) best = h;
+			t = h - oe_del; if (t < 0) t = 0; e -= e_del; if (e < 0) e = 0; if (e < t) e = t;
+			HE[j * 64] = (cell_t)((u32)e << CB | (u32)h);
+			t = h - oe_ins; if (t < 0) t = 0; f -= e_ins; if (f < 0) f = 0; if (t > f) f = t;
+		}
+	}
+	cells += (u64)qlen * tlen;
+	return best;
+}
+
 __device__ void seedsw_read(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, i32 *H, i32 *E, u64 &calls, u64 &cells)
 {
 	int n_ch = B.chain_n[r];

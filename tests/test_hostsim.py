@@ -90,6 +90,35 @@ def test_hostsim_publish_per_workgroup(monkeypatch):
     assert got["0"] == got["1"]
 
 
+@pytest.mark.parametrize("scale", [1, 2])
+def test_hostsim_seed_rescoring_in_lds(monkeypatch, scale):
+    """BWAGPU_SEEDSW_LDS=1 (long-read batches): mem_seed_sw's local alignments (bwamem.c:597-621) with their DP rows, the window's query bases
+    and the scoring matrix in LDS / registers -- 8-bit cells for a = 1, 16-bit cells for scaled scores: the seeds' scores after
+    mem_flt_chained_seeds, the surviving seeds and the regions equal the HBM-scratch form's."""
+    from bwa_amd.structs import fill_scmat
+    prefix, g = testdata.small_index()
+    reads = simdata.make_reads_long(g, 2, length=1400, seed=5)
+    seqs, off = testdata.ragged([reads[0], reads[1][:1250], reads[0][:60]])
+    opt = pacbio_opt()
+    if scale == 2:
+        opt.a = 2; opt.b = 2
+        for x in ("o_del", "o_ins", "e_del", "e_ins", "zdrop", "pen_clip5", "pen_clip3"):
+            setattr(opt, x, getattr(opt, x) * 2)
+        fill_scmat(opt)
+    got = {}
+    for lds in ("0", "1"):
+        monkeypatch.setenv("BWAGPU_SEEDSW_LDS", lds)
+        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+        s2.set_stats(True)
+        c, r = s2.align(opt, seqs, off)
+        cc, ch, sd = s2.tap_chains()
+        st = s2.stats()
+        assert st["n_sw_cells"] > 100000 and (sd["score"] > 0).any()
+        got[lds] = (c.tobytes(), r.tobytes(), cc.tobytes(), ch.tobytes(), sd.tobytes(), st["n_sw_cells"])
+        s2.close()
+    assert got["0"] == got["1"]
+
+
 def test_hostsim_stage_taps_match_golden(sim):
     z = np.load(os.path.join(testdata.GOLDEN, "golden_stages.npz"))
     k = 40
