@@ -119,6 +119,37 @@ def test_hostsim_seed_rescoring_in_lds(monkeypatch, scale):
     assert got["0"] == got["1"]
 
 
+def test_hostsim_seeding_variants_same_intervals(monkeypatch):
+    """Seeding alone, in bulk: with a chain-weight threshold nothing passes, the stages after seeding have no work, so a few thousand reads
+    of the repeat-rich 2 Mb genome (substitutions, indels, Ns) cost seconds on the mock runtime.  The interval lists (order included) of the
+    one-round-trip kernels -- BWAGPU_SEED_MRG=1, =2, =2 on a two-entry LDS stack, =2 without the LDS copy of the reads -- equal the default
+    kernel's, whose intervals the golden-fixture tests pin to the reference."""
+    import refapi
+    if not refapi.have_ref():
+        pytest.skip("oracle/_ref not built (needed to index the 2 Mb genome)")
+    prefix, g = testdata.medium_index()
+    reads = list(simdata.make_reads_se(g, 700, seed=301, sub=0.02, dele=0.003, ins=0.003, n_frac=0.002))
+    reads += [r_[: 40 + (i * 7) % 110] for i, r_ in enumerate(simdata.make_reads_se(g, 300, seed=302, sub=0.05))]
+    reads += list(simdata.make_reads_se(g, 150, length=250, seed=303, sub=0.01))
+    seqs, off = testdata.ragged(reads)
+    opt = default_opt(); opt.min_chain_weight = 1 << 20
+    got = {}
+    for name, env in (("default", {}), ("mrg1", {"BWAGPU_SEED_MRG": "1"}), ("mrg2", {"BWAGPU_SEED_MRG": "2"}),
+                      ("mrg2 small stack", {"BWAGPU_SEED_MRG": "2", "BWAGPU_SEED_LDS_ENT": "2"}), ("mrg2 no read copy", {"BWAGPU_SEED_MRG": "2", "BWAGPU_SEED_RD_LDS": "0"})):
+        for k in ("BWAGPU_SEED_MRG", "BWAGPU_SEED_LDS_ENT", "BWAGPU_SEED_RD_LDS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+        c, r = s2.align(opt, seqs, off)
+        ic, iv = s2.tap_intervals()
+        assert int(c.sum()) == 0 and int(ic.sum()) > 5 * len(reads)
+        got[name] = (ic.tobytes(), iv.tobytes())
+        s2.close()
+    for name in got:
+        assert got[name] == got["default"], name
+
+
 def test_hostsim_stage_taps_match_golden(sim):
     z = np.load(os.path.join(testdata.GOLDEN, "golden_stages.npz"))
     k = 40
