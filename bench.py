@@ -214,7 +214,7 @@ def main():
     ap.add_argument("--long-steps", type=int, default=2)
     ap.add_argument("--long-sample", type=int, default=128, help="reads of the long-read CPU-baseline / parity prefix")
     ap.add_argument("--variants", default="BWAGPU_SEED_MRG=1;BWAGPU_SEED_MRG=2", help="';'-separated environment settings to A/B against the defaults in a child process (tools/variant_probe.py); '' = none")
-    ap.add_argument("--variants-timeout", type=float, default=100.0, help="seconds for the short-read child process (the long-read one gets 0.6 of it)")
+    ap.add_argument("--variants-timeout", type=float, default=100.0, help="seconds for the short-read child process (the long-read one gets 0.8 of it)")
     args = ap.parse_args()
 
     import torch
@@ -510,12 +510,12 @@ def run_variants(args, prefix, batch_files=()):
     if not args.no_longread:
         long_file = os.path.join(os.path.dirname(prefix), "long_reads.npy")       # (left there by the long-read leg)
         legs.append(("long_reads", ["--long-reads", str(args.long_reads), "--long-len", str(args.long_len), "--passes", "1"] +
-                     (["--long-file", long_file] if os.path.exists(long_file) else []), args.variants_timeout * 0.6))
+                     (["--long-file", long_file] if os.path.exists(long_file) else []), args.variants_timeout * 0.8))
     for name, extra, limit in legs:
         if name == "long_reads":
-            # the last configuration alone, with the workgroup-per-read interval sort, with the DP kernels' query bases and the seed re-scoring's
-            # state in LDS on top; then the latter two alone (all three exist for long-read batches only)
-            cfgs = cfgs[-1:] + [cfgs[-1] + " BWAGPU_PUBLISH_BLK=1", cfgs[-1] + " BWAGPU_PUBLISH_BLK=1 BWAGPU_LONG_QLDS=1 BWAGPU_SEEDSW_LDS=1", "BWAGPU_LONG_QLDS=1", "BWAGPU_SEEDSW_LDS=1"]
+            # the long-read switches, each alone and all together (they exist for long-read batches only; BWAGPU_SEED_MRG=2 is the last short-read entry)
+            alone = [cfgs[-1], "BWAGPU_SEED_CHUNK=256", "BWAGPU_PUBLISH_BLK=1", "BWAGPU_LONG_QLDS=1", "BWAGPU_SEEDSW_LDS=1"]
+            cfgs = alone + [" ".join(alone)]
         log(f"[bench] variants, {name} (child process, <= {limit:.0f} s): {cfgs}")
         t = time.time()
         leg = {"runs": []}

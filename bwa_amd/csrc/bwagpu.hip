@@ -83,6 +83,7 @@ struct bwagpu_s {
 	i64 cigl_z_cap = 0;                          // bytes per direction matrix of the long CIGAR tier's scratch (grows with the batches)
 	DevBuf d_cigl_z, d_cigl_ops, d_cigl_md, d_cigl_list;      // scratch of the long-segment CIGAR tier (k_cigar_long): direction matrices, operations, MD strings per workgroup
 	DevBuf d_cig_ext; i64 cig_ext_n = -1;   // operation array of the last bwagpu_batch_cigars (records with 7..64 operations point into it)
+	DevBuf d_vr_tab, d_vr_chain, d_vr_meta, d_vr_intv;   // chunk-parallel pass 1 of long-read batches (k_seed<LR>): task tables, chains, per-task counters, SMEM lists
 	DevBuf d_seq_2b, d_seq_flags; int rd_words = 0;   // per-read 2-bit copies for k_seed's LDS (k_pack_reads2b)
 	DevBuf d_pack_off, d_regs_packed, d_pack_read, d_cigs, d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
 	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_blob;
@@ -375,7 +376,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 		for (DevBuf *b : ib) b->release();
 		delete h->ibuf;
 	}
-	DevBuf *all[] = { &h->d_cigl_list, &h->d_cigl_z, &h->d_cigl_ops, &h->d_cigl_md, &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
+	DevBuf *all[] = { &h->d_vr_tab, &h->d_vr_chain, &h->d_vr_meta, &h->d_vr_intv, &h->d_cigl_list, &h->d_cigl_z, &h->d_cigl_ops, &h->d_cigl_md, &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_chain_todo, &h->d_seed_w, &h->d_seed_order, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
@@ -721,12 +722,12 @@ static int dp_wave_count(const bwagpu_t *h, int n_threads)
 	return w;
 }
 
-static int alloc_batch(bwagpu_t *h, int n_threads)
+static int alloc_batch(bwagpu_t *h, int n_threads, int seed_lanes)
 {
 	int n = h->n_reads; size_t sc = (size_t)h->slot_cap + 8;   // +8: chunked readers may touch a few slots past the last read's range
 	int bad = 0;
 	bad |= h->d_ctr.ensure(sizeof(Counters));
-	bad |= h->d_tmp_intv.ensure((size_t)n_threads * (h->max_len + 1 + PTAB_MAX) * sizeof(BiIntv));
+	bad |= h->d_tmp_intv.ensure((size_t)(seed_lanes > n_threads ? seed_lanes : n_threads) * (h->max_len + 1 + PTAB_MAX) * sizeof(BiIntv));
 	bad |= h->d_intv_n.ensure((size_t)n * 4 + 16); bad |= h->d_intv_off.ensure((size_t)n * 8 + 16);
 	bad |= h->d_intv.ensure(((size_t)n * h->mem_cap + 16) * sizeof(Intv3));
 	bad |= h->d_seed_n.ensure((size_t)n * 4 + 16); bad |= h->d_seed_off.ensure((size_t)n * 8 + 16);
@@ -768,7 +769,7 @@ extern "C" int bwagpu_batch_reserve(bwagpu_t *h, int n_reads, int64_t n_bases, i
 	const i64 sc0 = h->slot_cap, nc0 = h->node_cap, rc0 = h->reg_cap; const int mc0 = h->mem_cap;
 	h->n_reads = n_reads; h->n_bases = n_bases; h->max_len = max_len;
 	size_arenas(h);
-	int bad = alloc_batch(h, resident_threads(h)) != 0;
+	int bad = alloc_batch(h, resident_threads(h), 0) != 0;
 	const u64 n_words = ((u64)n_bases + 15) / 16;
 	const int rdw = max_len <= 256 ? (((max_len + 15) / 16 + 3) & ~3) : 0;
 	bad |= h->d_seq.ensure((size_t)n_bases + 16); bad |= h->d_seq_nib.ensure((size_t)(n_words + 1) * 8); bad |= h->d_off.ensure((size_t)(n_reads + 1) * 8);
@@ -802,9 +803,39 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		if (!(min_l > 0.05f * l)) { minhsp[l] = (int)(opt->a * min_l + .499); any_seedsw = true; }
 	}
 	const bool dbg_sync = getenv("BWAGPU_DEBUG_SYNC") && atoi(getenv("BWAGPU_DEBUG_SYNC")) != 0;   // diagnostics: wait and report after every stage
+	// Chunk-parallel pass 1 of long-read batches (BWAGPU_SEED_CHUNK=<bases per chunk>, opt-in until measured; dev_seed.h, k_seed's LR): one task per
+	// (read, chunk); the tables go up once per batch, the per-task results live in HBM between the two launches.
+	int chunk_len = getenv("BWAGPU_SEED_CHUNK") ? atoi(getenv("BWAGPU_SEED_CHUNK")) : 0, n_vreads = 0, chunk_lanes = 0, vr_cap = 0;
+	if (chunk_len < 32 || chunk_len > 32768 || h->max_len <= WAVE_EXT_MAX_LEN || h->max_len >= 65536 || h->ix.occ32 == nullptr || h->ix.ptab == nullptr || h->rd_words != 0) chunk_len = 0;
+	if (chunk_len) {
+		std::vector<i32> tab; tab.reserve((size_t)(h->n_bases / chunk_len) * 2 + 3 * (size_t)n + 16);
+		std::vector<i32> first((size_t)n + 1);
+		for (int r = 0; r < n; ++r) {
+			first[r] = n_vreads;
+			const i64 len = h->h_off[r + 1] - h->h_off[r];
+			n_vreads += (int)((len + chunk_len - 1) / chunk_len);
+		}
+		first[n] = n_vreads;
+		// layout of d_vr_tab: vr_read[n_vreads], vr_beg[n_vreads], vr_first[n + 1]
+		tab.resize((size_t)2 * n_vreads + (size_t)n + 1);
+		for (int r = 0, v = 0; r < n; ++r) {
+			const i64 len = h->h_off[r + 1] - h->h_off[r];
+			for (i64 b = 0; b < len; b += chunk_len, ++v) { tab[v] = r; tab[(size_t)n_vreads + v] = (i32)b; }
+		}
+		memcpy(tab.data() + (size_t)2 * n_vreads, first.data(), ((size_t)n + 1) * 4);
+		vr_cap = 2 * chunk_len < 64 ? 64 : 2 * chunk_len;
+		if (getenv("BWAGPU_SEED_CHUNK_CAP") && atoi(getenv("BWAGPU_SEED_CHUNK_CAP")) > 0) vr_cap = atoi(getenv("BWAGPU_SEED_CHUNK_CAP"));   // (tests: tasks whose lists overflow are recomputed by the stitcher)
+		chunk_lanes = (n_vreads + BLOCK - 1) / BLOCK * BLOCK; if (chunk_lanes > 65536) chunk_lanes = 65536;   // persistent lanes, tasks drawn from a counter
+		if (n_vreads == 0) chunk_len = 0;
+		else if (h->d_vr_tab.ensure(tab.size() * 4) || h->d_vr_chain.ensure((size_t)n_vreads * chunk_len * 4) || h->d_vr_meta.ensure((size_t)n_vreads * 4 * 4) ||
+				 h->d_vr_intv.ensure((size_t)n_vreads * vr_cap * sizeof(Intv3))) { h->err = "hipMalloc failed (chunk tasks)"; return BWAGPU_ENOMEM; }
+		else HIPCHK(h, hipMemcpyAsync(h->d_vr_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, h->stream));   // (pageable source: staged before the call returns)
+	}
+	if (!chunk_len) { n_vreads = 0; chunk_lanes = 0; }
+	if (dbg_sync) fprintf(stderr, "[bwagpu] pass 1 by chunks: %d bases per chunk, %d tasks on %d lanes (max_len %d, rd_words %d)\n", chunk_len, n_vreads, chunk_lanes, h->max_len, h->rd_words);
 	for (int attempt = 0; attempt < 12; ++attempt) {
 		h->phase = 20 + attempt * 100;
-		int rc = alloc_batch(h, n_threads);
+		int rc = alloc_batch(h, n_threads, chunk_lanes);
 		if (rc) return rc;
 		HIPCHK(h, hipMemcpyAsync(h->d_minhsp.p, minhsp.data(), minhsp.size() * 4, hipMemcpyHostToDevice, h->stream));
 		HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
@@ -835,12 +866,17 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.seed_coop = h->ix.occ32 == nullptr && getenv("BWAGPU_SEED_COOP") && atoi(getenv("BWAGPU_SEED_COOP")) != 0;   // (opt-in: a measured loss, see build_occ32)
 		B.seed_pass3_inline = getenv("BWAGPU_SEED_PASS3_INLINE") && atoi(getenv("BWAGPU_SEED_PASS3_INLINE")) != 0;
 		B.chain_lds_off = getenv("BWAGPU_CHAIN_LDS") && atoi(getenv("BWAGPU_CHAIN_LDS")) == 0;
+		B.chunk_len = chunk_len; B.n_vreads = n_vreads; B.vr_cap = vr_cap;
+		if (chunk_len) {
+			B.vr_read = h->d_vr_tab.as<i32>(); B.vr_beg = B.vr_read + n_vreads; B.vr_first = B.vr_beg + n_vreads;
+			B.vr_chain = h->d_vr_chain.as<i32>(); B.vr_nchain = h->d_vr_meta.as<i32>(); B.vr_exit = B.vr_nchain + n_vreads; B.vr_nintv = B.vr_exit + n_vreads; B.vr_from = B.vr_nintv + n_vreads;
+			B.vr_intv = h->d_vr_intv.as<Intv3>();
+		}
 		// memory round trips per iteration of the seeding kernels (dev_seed.h, k_seed's MRG): 0 = as compiled, 1 = table entries and whole index
 		// blocks in one trip, 2 = plus the next interval-stack entry a step ahead
 		int seed_mrg = getenv("BWAGPU_SEED_MRG") ? atoi(getenv("BWAGPU_SEED_MRG")) : SEED_MRG_DEFAULT;
 		const bool long_qlds = getenv("BWAGPU_LONG_QLDS") && atoi(getenv("BWAGPU_LONG_QLDS")) != 0;   // long-read DP kernels: query bases from an LDS copy
 		if (h->ix.occ32 == nullptr || h->ix.ptab == nullptr || h->ix.occ32_bytes > BUF_MAX_BYTES || h->ix.ptab_bytes > BUF_MAX_BYTES) seed_mrg = 0;   // (its loads address 32-bit offsets into buffers of < 4 GiB: a genome beyond ~8.5 Gbp of index keeps the plain kernels)
-		B.tmp_intv_bytes = (u64)n_threads * (u64)(h->max_len + 1 + PTAB_MAX) * sizeof(BiIntv);
 		B.seq_nib_bytes = (((u64)h->n_bases + 15) / 16) * 8;
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
 		HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
@@ -868,7 +904,17 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			const int blk = h->ix.occ32 != nullptr ? 1 : (B.seed_coop ? 2 : 0);
 			const int socc = seed_occ;   // (measurements: register allocation of the cooperative form for 3 or 4 waves per SIMD)
 			const int mrg = seed_mrg;
-			if (rd) { if (st) SEED_LAUNCH_B(true, true); else SEED_LAUNCH_B(true, false); }
+			if (chunk_len && blk == 1 && !rd) {
+				// long reads, pass 1 by chunks: the workers (persistent lanes drawing tasks), then the lane-per-read kernel as stitcher (+ pass 2)
+				Batch BA = B; BA.seed_order = nullptr;
+				const dim3 agrid((unsigned)(chunk_lanes / BLOCK));
+#define SEED_LAUNCH_LR(ST_, M_) do { hipLaunchKernelGGL((k_seed<false, ST_, 1, 3, M_, 1>), agrid, block, seed_lds, h->stream, h->ix, *opt, BA); \
+					hipLaunchKernelGGL((k_seed<false, ST_, 1, 3, M_, 2>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B); } while (0)
+				if (mrg == 2) { if (st) SEED_LAUNCH_LR(true, 2); else SEED_LAUNCH_LR(false, 2); }
+				else { if (st) SEED_LAUNCH_LR(true, 0); else SEED_LAUNCH_LR(false, 0); }
+#undef SEED_LAUNCH_LR
+			}
+			else if (rd) { if (st) SEED_LAUNCH_B(true, true); else SEED_LAUNCH_B(true, false); }
 			else { if (st) SEED_LAUNCH_B(false, true); else SEED_LAUNCH_B(false, false); }
 		}
 #undef SEED_LAUNCH_B

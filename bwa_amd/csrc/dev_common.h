@@ -87,6 +87,7 @@ struct alignas(128) HotCounter { unsigned long long v; unsigned long long pad_[1
 struct Counters {          // device-side bump allocators + flags
 	HotCounter seed_used_, node_used_, reg_used_;
 	HotCounter next_read_, next_read3_;   // work counters of the seeding kernels (passes 1-2, pass 3)
+	HotCounter next_vread_;               // ... and of the chunk workers of long-read batches (k_seed<LR = 1>)
 	HotCounter next_ext_;    // work counter of the wave extension kernel (position in Batch::order)
 	HotCounter next_seedsw_; // work counter of the wave-per-read seed re-scoring kernel (long reads)
 	HotCounter next_chain_, next_dedup_;       // work counters of the chaining and de-duplication kernels
@@ -108,6 +109,7 @@ struct Counters {          // device-side bump allocators + flags
 #define reg_used reg_used_.v
 #define next_read next_read_.v
 #define next_read3 next_read3_.v
+#define next_vread next_vread_.v
 #define next_ext next_ext_.v
 #define next_seedsw next_seedsw_.v
 #define next_chain next_chain_.v
@@ -152,7 +154,6 @@ struct Batch {
 	Counters *ctr;
 	// --- seeding scratch: per resident lane one interval stack (first entries in LDS, see SeedStack)
 	BiIntv *tmp_intv;          // [n_seed_threads][max_len+1]: spill area of the lanes' interval stacks
-	u64 tmp_intv_bytes;        // ... its size (k_seed<MRG = 2> reads it through a buffer descriptor when it is below 4 GiB)
 	int seed_lds_ent;          // stack entries per lane kept in LDS (0 when seq_len >= 2^37 or max_len >= 2^16: the packing would not fit)
 	int seed_no_virt;          // diagnostics: keep short matches in the stack as well (see SeedLane::smask)
 	int mem_cap;               // capacity of one read's interval list
@@ -176,6 +177,13 @@ struct Batch {
 	u8 *slot_blob;
 	i32 *chain_n;              // per read: chains after filtering
 	i32 *chain_todo, *chain_todo2; // reads deferred by tier 0 / tier 1 of k_chain_wave to the next tier
+	// --- chunk-parallel pass 1 of long-read batches (k_seed<LR>, BWAGPU_SEED_CHUNK): one task per (read, chunk of chunk_len bases); a read's tasks are consecutive
+	int chunk_len, n_vreads, vr_cap;
+	const i32 *vr_read, *vr_beg;    // per task: its read, the first base of its chunk
+	const i32 *vr_first;            // per read: its first task
+	i32 *vr_chain;                  // [n_vreads][chunk_len]: the positions the task's chain visited inside its chunk, ascending
+	i32 *vr_nchain, *vr_exit, *vr_nintv, *vr_from;   // per task: chain length (0: unusable), where the chain left the chunk, SMEMs found, and (stitcher) the chunk-relative position its results are valid from (-1: not at all)
+	Intv3 *vr_intv;                 // [n_vreads][vr_cap]: the SMEMs, x2's bits 48.. = chunk-relative position of the search that found them
 	int seed_prio;             // waves holding the heaviest 3 % of k_seed's reads run at raised issue priority (BWAGPU_SEED_PRIO=0 turns it off)
 	int seed_coop;             // the seeding kernels fetch index blocks quad-cooperatively (fm_occ_coop; off with BWAGPU_SEED_COOP=0 or when the 32-byte layout is in use)
 	int seed_pass3_inline;     // A/B switch (BWAGPU_SEED_PASS3_INLINE=1): pass 3 inside k_seed's state machine as in round 1, instead of k_seed3

@@ -20,10 +20,11 @@ struct SeedEmit {        // the MEM list of the read being seeded (lane-private 
 	// pass 2 (bwamem.c:160-168) walks pass 1's SMEMs looking for the long and rare ones; re-reading the list costs a memory round
 	// trip per entry with the whole wave waiting, so the test is made here and remembered: bit k = entry base + k qualifies
 	int split_len, base; u64 split_width, cand;
+	u64 tag;        // k_seed<LR = 1>: the position of the search that reports, relative to its chunk, << 48 -- kept in the spare top bits of x2 (0 elsewhere)
 	DEVFN void add(u64 x0, u64 x2, int start, int end) {
 		if (end - start < min_seed_len) return;
 		if (n == cap) { overflow = true; return; }
-		Intv3 v; v.x0 = x0; v.x2 = x2; v.info = (u64)start << 32 | (u32)end;
+		Intv3 v; v.x0 = x0; v.x2 = x2 | tag; v.info = (u64)start << 32 | (u32)end;
 		if (end - start >= split_len && x2 <= split_width && n - base < 64) cand |= 1ull << (n - base);
 		mem()[n++] = v;
 	}
@@ -415,7 +416,17 @@ __global__ void __launch_bounds__(256) k_publish_blk(bwagpu_opt_t opt, Batch B)
 //      then the table look-ups, then the index blocks, then the blocks' first words for the lanes extending by A: up to four dependent
 //      trips.  1: table entries and whole blocks are issued together and waited for once (ext_one_trip).  2: additionally, a backward
 //      row's next interval-stack entry, when it lives in HBM scratch, is fetched in the same trip, one step ahead: one trip per iteration.
-template<bool RD, bool STATS, int BLK, int OCC, int MRG = 0>
+// LR (long-read batches, BWAGPU_SEED_CHUNK): pass 1 of a read is a chain of searches x -> ret(x) (bwamem.c:147-157), ~40 000 dependent index look-ups
+//      for a 10 kb read, and a batch has fewer reads than the chip has SIMDs.  The searches are pure functions of x, and chains started at different
+//      positions merge as soon as they share one (ret is monotone; a match that ends at a read error ends there for every start inside it).  So:
+//      1 = chunk worker: a lane takes a TASK (read, chunk of Batch::chunk_len bases), walks the chain from the chunk's first base until it leaves the
+//          chunk, and records the positions it visited, where it left, and the SMEMs it found, each tagged with its search's position (vr_*).
+//      2 = stitcher: the ordinary lane-per-read kernel, except that in pass 1, standing at x, it first looks x up in the chain recorded for x's
+//          chunk: found -> everything that worker did from x on is what this lane would do, so it notes "chunk valid from x" and jumps to where
+//          the worker left; not found -> it runs the search itself, as ever, and tries again at the next position.  When pass 1 is over it
+//          appends the valid part of every chunk's SMEMs to the read's list (order is immaterial: k_publish sorts) and goes on to pass 2.
+//      Exact whatever happens: a chunk that never merges is simply recomputed by the stitcher.
+template<bool RD, bool STATS, int BLK, int OCC, int MRG = 0, int LR = 0>
 __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
 	HIP_DYNAMIC_SHARED(uint4, seed_lds)
@@ -428,7 +439,9 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	S.virt_m = (ix.ptab_m >= 2 && opt.min_seed_len > ix.ptab_m && !B.seed_no_virt) ? ix.ptab_m : 0;
 	L.smask = L.srem = L.snew = 0; L.ncl = 0;
 	L.em.intv = B.intv; L.em.r = -1; L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len;
-	L.em.split_len = split_len; L.em.split_width = (u64)opt.split_width; L.em.cand = 0; L.em.base = 0;
+	L.em.split_len = split_len; L.em.split_width = (u64)opt.split_width; L.em.cand = 0; L.em.base = 0; L.em.tag = 0;
+	if (LR == 1) { L.em.intv = B.vr_intv; L.em.cap = B.vr_cap; }
+	int vr_beg = 0, vr_end = 0, vr_nch = 0;       // LR == 1: the task's chunk [vr_beg, vr_end) and the number of chain positions recorded (the task itself is L.em.r)
 	L.st = SS_FETCH; L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u; L.win2 = 0; L.win2_w = ~0u;
 	u32 *rd_lds = (u32*)(seed_lds + (size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * blockDim.x);   // (after the stacks)
 	L.rd = rd_lds; L.rd_on = 0; L.raw = B.seq; L.off = B.off;
@@ -451,7 +464,8 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	SeedBufs bf;
 	if (MRG && BLK == 1) {
 		bf.occ = occ32_bufs(ix); bf.ptab = buf_rsrc(ix.ptab, ix.ptab_bytes);
-		bf.stk = buf_rsrc(B.tmp_intv, MRG == 2 ? B.tmp_intv_bytes : 0);      // (an area beyond a descriptor's reach -- long reads -- reads as empty: no entry is ever prefetched)
+		// (the workgroup's share of the spill area: the descriptor's base is a per-workgroup scalar, so the whole area may exceed 4 GiB)
+		bf.stk = buf_rsrc((const u8*)B.tmp_intv + (size_t)blockIdx.x * blockDim.x * (size_t)cap * sizeof(BiIntv), MRG == 2 ? (u64)blockDim.x * (u64)cap * sizeof(BiIntv) : 0);
 		bf.nib = buf_rsrc(B.seq_nib, MRG == 2 && !RD ? B.seq_nib_bytes : 0);
 	}
 	while (__ballot(L.st != SS_DONE)) {       // (a lane that has run out of reads stays in the loop: its quad still needs it to fetch and count, fm_occ_coop)
@@ -466,7 +480,9 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 		if (run_slow) {
 			deferred = 0; if (STATS) ++n_slow;
 			if (L.st == SS_FINAL) {
-				if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull); else B.intv_n[L.em.r] = L.em.n;
+				if (LR == 1) {       // (a task whose list overflowed is marked unusable: the stitcher recomputes its chunk)
+					B.vr_nintv[L.em.r] = L.em.overflow ? 0 : L.em.n; B.vr_nchain[L.em.r] = L.em.overflow ? 0 : vr_nch; B.vr_exit[L.em.r] = L.x; B.vr_from[L.em.r] = -1;
+				} else if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull); else B.intv_n[L.em.r] = L.em.n;
 				L.st = SS_FETCH;
 			}
 			const bool want = L.st == SS_FETCH;
@@ -474,11 +490,11 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 			if (wm) {
 				if (pool_cnt == 0) {
 					const int first = __ffsll((unsigned long long)__ballot(1)) - 1;        // lane 0 may already have left the loop
-					const unsigned long long old = atomicAdd(&B.ctr->next_read, (threadIdx.x & 63) == first ? 64ull : 0ull);
+					const unsigned long long old = atomicAdd(LR == 1 ? &B.ctr->next_vread : &B.ctr->next_read, (threadIdx.x & 63) == first ? 64ull : 0ull);
 					pool_base = __shfl((int)old, first); pool_cnt = 64;
 					// lane l looks up the pool's read number l now: a lane taking a read later gets it from a register of the wave
 					// instead of a memory round trip of its own in front of the reads of the read's data
-					{ const int idx = pool_base + (int)(threadIdx.x & 63); pool_r = idx < B.n_reads ? (B.seed_order ? B.seed_order[idx] : idx) : 0; }
+					{ const int idx = pool_base + (int)(threadIdx.x & 63); pool_r = LR == 1 ? idx : (idx < B.n_reads ? (B.seed_order ? B.seed_order[idx] : idx) : 0); }
 					// the waves holding the (predicted) heaviest reads get issue priority: a lane's long chain of dependent extensions then
 					// advances at the pace of the wave alone on its SIMD instead of a quarter of it
 					if (B.seed_order && B.seed_prio) { if (pool_base < B.n_reads / 32) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
@@ -490,8 +506,15 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 				const int r = __shfl(pool_r, (64 - pool_cnt + rank) & 63);
 				if (want && rank < pool_cnt) {
 					const int idx = pool_base + rank;
-					if (idx >= B.n_reads) L.st = SS_DONE;
-					else {
+					if (idx >= (LR == 1 ? B.n_vreads : B.n_reads)) L.st = SS_DONE;
+					else if (LR == 1) {       // a task: chunk [vr_beg, vr_end) of read rr; its results go to the task's own lists
+						const int rr = B.vr_read[r];
+						L.em.r = r; L.qoff = (u64)B.off[rr]; L.len = (int)(B.off[rr + 1] - B.off[rr]);
+						L.win_w = ~0u;
+						vr_beg = B.vr_beg[r]; vr_end = vr_beg + B.chunk_len < L.len ? vr_beg + B.chunk_len : L.len; vr_nch = 0;
+						L.em.n = 0; L.em.base = 0; L.em.overflow = false; L.em.cand = 0;
+						L.x = vr_beg; L.st = SS_PASS1;
+					} else {
 						L.em.r = r; L.qoff = (u64)B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
 						L.win_w = ~0u;
 						if (RD) {
@@ -520,7 +543,34 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 				switch (L.st) {
 				case SS_PASS1:   // pass 1: all SMEMs, left to right (bwamem.c:147-157)
 					while (L.x < L.len && seed_q(L, nib, L.x) > 3) ++L.x;
-					if (L.x >= L.len) { L.old_n = L.em.n; L.k2 = L.em.base; L.st = SS_PASS2; }   // pass 2 re-seeds pass 1's SMEMs (the entries after pass 3's)
+					if (LR == 1) {       // chunk worker: stop at the first position beyond the chunk (L.x is then where the chain left it)
+						if (L.x >= vr_end) L.st = SS_FINAL;
+						else { B.vr_chain[(size_t)L.em.r * (u32)B.chunk_len + (u32)vr_nch++] = L.x; L.em.tag = (u64)(u32)(L.x - vr_beg) << 48; smem_start(ix, L, S, nib, L.x, 1, 1); }
+						break;
+					}
+					if (LR == 2 && L.x < L.len) {       // stitcher: did the worker of this position's chunk come by here?
+						const int v = B.vr_first[L.em.r] + L.x / B.chunk_len, nch = B.vr_nchain[v];
+						const i32 *ch = B.vr_chain + (size_t)v * (u32)B.chunk_len;
+						int lo = 0, hi = nch;              // (the recorded positions ascend)
+						while (lo < hi) { const int mid = (lo + hi) >> 1; if (ch[mid] < L.x) lo = mid + 1; else hi = mid; }
+						if (lo < nch && ch[lo] == L.x) { B.vr_from[v] = L.x - B.vr_beg[v]; L.x = B.vr_exit[v]; break; }   // (stays in SS_PASS1: the next round looks at the next chunk)
+					}
+					if (L.x >= L.len) {
+						if (LR == 2) {       // the valid part of every chunk's SMEMs joins the read's list
+							const int v0 = B.vr_first[L.em.r], nv = (L.len + B.chunk_len - 1) / B.chunk_len;
+							for (int v = v0; v < v0 + nv; ++v) {
+								const int from = B.vr_from[v];
+								if (from < 0) continue;
+								const Intv3 *src = B.vr_intv + (size_t)v * (u32)B.vr_cap;
+								const int ne = B.vr_nintv[v];
+								for (int e = 0; e < ne; ++e) {
+									const Intv3 t = src[e];
+									if ((int)(t.x2 >> 48) >= from) L.em.add(t.x0, t.x2 & (((u64)1 << 48) - 1), (int)(t.info >> 32), (int)(u32)t.info);
+								}
+							}
+						}
+						L.old_n = L.em.n; L.k2 = L.em.base; L.st = SS_PASS2;   // pass 2 re-seeds pass 1's SMEMs (the entries after pass 3's)
+					}
 					else smem_start(ix, L, S, nib, L.x, 1, 1);
 					break;
 				case SS_PASS2: { // pass 2: re-seed from the middle of long, rare SMEMs (bwamem.c:160-168)
@@ -593,7 +643,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 		if (MRG && BLK == 1) {
 			u32 pf_off = BUF_OOB;       // byte offset of the lane's next stack entry in the spill area (SeedStack::glob_col, packed entries)
 			if (MRG == 2 && back && !short_ent && S.n_lds && L.j + 1 < L.nprev && L.j + 1 >= S.n_lds)
-				pf_off = ((u32)(blockIdx.x * blockDim.x + threadIdx.x) * (u32)S.glob_cap + PTAB_MAX) * (u32)sizeof(BiIntv) + (u32)(L.top - (L.j + 1)) * (u32)sizeof(uint4);
+				pf_off = ((u32)threadIdx.x * (u32)S.glob_cap + PTAB_MAX) * (u32)sizeof(BiIntv) + (u32)(L.top - (L.j + 1)) * (u32)sizeof(uint4);
 			u32 nb;
 			if (MRG == 2 && !RD) {
 				// Reads too long for an LDS copy take their bases from the packed array in HBM, 16 per fetch -- a dependent round trip of its
@@ -672,7 +722,7 @@ template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k
 {
 	SeedLane L;                   // only the read window (qoff, win, win_w, len), x, sx, i, ik, code and the emitter are used
 	L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len; L.em.intv = B.intv; L.em.r = -1; L.em.n = 0; L.em.overflow = false;
-	L.em.split_len = 0x7fffffff; L.em.split_width = 0; L.em.cand = 0; L.em.base = 0;
+	L.em.split_len = 0x7fffffff; L.em.split_width = 0; L.em.cand = 0; L.em.base = 0; L.em.tag = 0;
 	L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u; L.win2 = 0; L.win2_w = ~0u; L.x = 0; L.sx = 0; L.i = 0; L.code = 0; L.rd = nullptr; L.rd_on = 0; L.raw = nullptr; L.off = nullptr;
 	L.ik.x0 = L.ik.x1 = L.ik.x2 = L.ik.info = 0;
 	const u64 *nib = B.seq_nib;

@@ -150,6 +150,44 @@ def test_hostsim_seeding_variants_same_intervals(monkeypatch):
         assert got[name] == got["default"], name
 
 
+def test_hostsim_long_read_pass1_by_chunks(monkeypatch):
+    """BWAGPU_SEED_CHUNK=<n> (long-read batches): pass 1 of mem_collect_intv split into tasks of n bases -- chunk workers record the chain of
+    search positions they walk and the SMEMs they find, the lane-per-read kernel jumps from chunk to chunk wherever its own position lies on a
+    worker's chain and recomputes where it does not (k_seed's LR modes).  Noisy 3 kb reads, reads with N runs, nearly exact reads whose matches
+    span several chunks, a read of one chunk, an all-N and an empty read; chunk sizes that do and do not divide the reads, with the
+    one-round-trip fetch, and with task lists so small that most tasks overflow and are recomputed: the interval lists (order included) equal
+    the serial kernel's."""
+    import refapi
+    if not refapi.have_ref():
+        pytest.skip("oracle/_ref not built (needed to index the 2 Mb genome)")
+    prefix, g = testdata.medium_index()
+    reads = list(simdata.make_reads_long(g, 3, length=3000, seed=5))
+    rng = np.random.default_rng(3)
+    reads[1] = reads[1][:1700].copy(); reads[1][rng.integers(0, 1700, 12)] = 4; reads[1][500:530] = 4
+    reads[2] = reads[2][:1151]
+    reads += [reads[0][:90], np.full(200, 4, dtype=np.uint8), np.zeros(0, dtype=np.uint8)]
+    reads += list(simdata.make_reads_se(g, 2, length=1300, seed=9, sub=0.002))
+    seqs, off = testdata.ragged(reads)
+    opt = pacbio_opt(); opt.min_chain_weight = 1 << 20          # (nothing passes the chain filter: the stages after seeding have no work)
+    got, blocks = {}, {}
+    for name, env in (("serial", {}), ("64", {"BWAGPU_SEED_CHUNK": "64"}), ("256 + one trip", {"BWAGPU_SEED_CHUNK": "256", "BWAGPU_SEED_MRG": "2"}),
+                      ("100", {"BWAGPU_SEED_CHUNK": "100"}), ("128, lists of 6", {"BWAGPU_SEED_CHUNK": "128", "BWAGPU_SEED_CHUNK_CAP": "6"})):
+        for k in ("BWAGPU_SEED_CHUNK", "BWAGPU_SEED_MRG", "BWAGPU_SEED_CHUNK_CAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+        s2.set_stats(True)
+        c, r = s2.align(opt, seqs, off)
+        ic, iv = s2.tap_intervals()
+        got[name] = (ic.tobytes(), iv.tobytes()); blocks[name] = s2.stats()["n_occ_blocks"]
+        assert int(ic.max()) > 40
+        s2.close()
+    for name in got:
+        assert got[name] == got["serial"], name
+    assert blocks["64"] > blocks["256 + one trip"] > blocks["serial"], blocks      # (the workers' overlap is real work: smaller chunks, more of it)
+
+
 def test_hostsim_stage_taps_match_golden(sim):
     z = np.load(os.path.join(testdata.GOLDEN, "golden_stages.npz"))
     k = 40

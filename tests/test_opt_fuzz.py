@@ -157,10 +157,11 @@ def test_sim_option_fuzz():
 def test_sim_option_fuzz_one_trip_seeding(monkeypatch):
     """The same draws' kind through the switchable kernel forms of this round: seeding with one memory round trip per iteration
     (BWAGPU_SEED_MRG=2, on LDS stacks of two entries so that nearly every backward step takes a prefetched entry) and, for the long-read
-    presets, the workgroup-per-read interval sort (BWAGPU_PUBLISH_BLK=1) and the LDS copy of the query in the DP kernels (BWAGPU_LONG_QLDS=1)."""
+    presets, the workgroup-per-read interval sort (BWAGPU_PUBLISH_BLK=1) the LDS copy of the query in the DP kernels (BWAGPU_LONG_QLDS=1), the LDS form of the seed re-scoring (BWAGPU_SEEDSW_LDS=1) and pass 1 by
+    chunks of 128 bases (BWAGPU_SEED_CHUNK)."""
     import hostsim_build
     from bwa_amd.api import BwaGpu
-    for k, v in (("BWAGPU_SEED_MRG", "2"), ("BWAGPU_SEED_LDS_ENT", "2"), ("BWAGPU_PUBLISH_BLK", "1"), ("BWAGPU_LONG_QLDS", "1")):
+    for k, v in (("BWAGPU_SEED_MRG", "2"), ("BWAGPU_SEED_LDS_ENT", "2"), ("BWAGPU_PUBLISH_BLK", "1"), ("BWAGPU_LONG_QLDS", "1"), ("BWAGPU_SEEDSW_LDS", "1"), ("BWAGPU_SEED_CHUNK", "128")):
         monkeypatch.setenv(k, v)
     prefix, g = testdata.small_index()
     sim, ref = BwaGpu(prefix, lib_path=hostsim_build.build()), refapi.RefIndex(prefix)
