@@ -519,13 +519,7 @@ def run_variants(args, prefix, batch_files=()):
         log(f"[bench] variants, {name} (child process, <= {limit:.0f} s): {cfgs}")
         t = time.time()
         leg = {"runs": []}
-        try:
-            p = subprocess.run(probe + extra + cfgs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit)
-            text, leg["rc"] = p.stdout, p.returncode
-            if p.returncode != 0:
-                leg["stderr_tail"] = p.stderr[-400:]
-        except subprocess.TimeoutExpired as e:
-            text, leg["rc"] = (e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")), "timeout"
+        text, leg["rc"] = run_child(probe + extra + cfgs, limit, leg)
         for line in text.splitlines():
             try:
                 leg["runs"].append(json.loads(line))
@@ -534,6 +528,32 @@ def run_variants(args, prefix, batch_files=()):
         leg["wall_s"] = round(time.time() - t, 1)
         res[name] = leg
     return res
+
+
+def run_child(cmd, limit, leg):
+    """Run `cmd` in a session of its own for at most `limit` seconds; returns (stdout so far, return code | "timeout").  The child's
+    output goes to files, not pipes, and a child that does not die within 10 s of SIGKILL (a process stuck on a wedged device) is left
+    behind rather than waited for: the bench line must still come out."""
+    import signal
+    import tempfile
+    with tempfile.TemporaryFile("w+") as fo, tempfile.TemporaryFile("w+") as fe:
+        p = subprocess.Popen(cmd, stdout=fo, stderr=fe, text=True, start_new_session=True)
+        try:
+            rc = p.wait(timeout=limit)
+        except subprocess.TimeoutExpired:
+            rc = "timeout"
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                leg["unreaped"] = True
+        fo.seek(0); fe.seek(0)
+        if rc != 0:
+            leg["stderr_tail"] = fe.read()[-400:]
+        return fo.read(), rc
 
 
 def longread_bench(args, prefix, g, threads, cache):
