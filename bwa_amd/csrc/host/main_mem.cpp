@@ -343,29 +343,55 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 		if (d == 0) t2 = now_s();
 		if (rc == BWAGPU_OK) rc = bwagpu_batch_download(gpus[d], u.counts.data() + s.lo, &s.all, &s.tot);
 		if (rc != BWAGPU_OK) device_fail(gpus[d], rc);
-		if (g_device_cigars && s.tot > 0) {       // the DP of mem_reg2aln on the device as well; the host keeps NM/MD and the text
-			int64_t nc = 0;
-			rc = bwagpu_batch_cigars(gpus[d], &u.opt, &s.cigs, &nc);
-			if (rc != BWAGPU_OK || nc != s.tot) device_fail(gpus[d], rc);
-			rc = bwagpu_batch_cigar_ops(gpus[d], &s.ops, &s.n_ops);
-			if (rc != BWAGPU_OK) device_fail(gpus[d], rc);
-		}
 	});
-	t3 = t4 = now_s();
-	if (D == 1) { u.all = sh[0].all; u.tot = sh[0].tot; u.cigs = sh[0].cigs; u.cig_ops = sh[0].ops; }
-	else {   // gather in read order
+	if (D == 1) { u.all = sh[0].all; u.tot = sh[0].tot; }
+	else {   // gather the regions in read order
 		u.tot = 0; for (auto &s : sh) u.tot += s.tot;
 		u.all = (bwagpu_alnreg_t*)malloc((size_t)(u.tot ? u.tot : 1) * sizeof(bwagpu_alnreg_t));
-		const bool have_cigs = g_device_cigars && u.tot > 0;
-		u.cigs = have_cigs ? (bwagpu_cigar_t*)malloc((size_t)u.tot * sizeof(bwagpu_cigar_t)) : nullptr;
-		if (!u.all || (have_cigs && !u.cigs)) { fprintf(stderr, "[E::%s] out of memory\n", "mem_process_seqs"); exit(EXIT_FAILURE); }
-		int64_t n_ops = 0; for (auto &s : sh) n_ops += s.n_ops;
-		u.cig_ops = have_cigs ? (uint32_t*)malloc((size_t)(n_ops ? n_ops : 1) * 4) : nullptr;
-		if (have_cigs && !u.cig_ops) { fprintf(stderr, "[E::%s] out of memory\n", "mem_process_seqs"); exit(EXIT_FAILURE); }
-		int64_t k = 0, ko = 0;
+		if (!u.all) { fprintf(stderr, "[E::%s] out of memory\n", "mem_process_seqs"); exit(EXIT_FAILURE); }
+		int64_t k = 0;
 		for (auto &s : sh) {
 			if (s.tot) memcpy(u.all + k, s.all, (size_t)s.tot * sizeof(bwagpu_alnreg_t));
-			if (have_cigs && s.tot) {   // (a shard without regions has no records); offsets into the operation array move with the shard's part of it
+			k += s.tot;
+			bwagpu_free(s.all); s.all = nullptr;
+		}
+	}
+	// mem_pestat needs the whole batch's regions (bwamem.c:1258) and nothing else: it runs on host threads while the devices
+	// produce the CIGARs of the same regions (it used to wait for them: 26 of a batch's 377 ms in this stage)
+	const bool want_matesw = g_device_matesw && pe && !(u.opt.flag & F_NO_RESCUE) && u.tot > 0;
+	double t_pes = 0;
+	std::thread pes_thread;
+	if (want_matesw) {
+		if (pes0) memcpy(u.pes, pes0, sizeof u.pes);
+		else pes_thread = std::thread([&] {
+			const double tp = now_s();
+			std::vector<int64_t> roff((size_t)n + 1, 0);
+			for (int i = 0; i < n; ++i) roff[i + 1] = roff[i] + u.counts[i];
+			pestat_flat(u.opt, ref.l_pac, n, u.all, roff.data(), u.pes, g_verbose >= 3, u.opt.n_threads < 4 ? u.opt.n_threads : 4);
+			t_pes = now_s() - tp;
+		});
+		u.have_pes = true;
+	}
+	const bool have_cigs = g_device_cigars && u.tot > 0;
+	if (have_cigs) on_devices([&](int d) {       // the DP of mem_reg2aln, NM and MD on the device as well; the host keeps the text
+		Shard &s = sh[d];
+		if (s.tot == 0) return;
+		int64_t nc = 0;
+		int rc = bwagpu_batch_cigars(gpus[d], &u.opt, &s.cigs, &nc);
+		if (rc != BWAGPU_OK || nc != s.tot) device_fail(gpus[d], rc);
+		rc = bwagpu_batch_cigar_ops(gpus[d], &s.ops, &s.n_ops);
+		if (rc != BWAGPU_OK) device_fail(gpus[d], rc);
+	});
+	t3 = now_s();
+	if (D == 1) { u.cigs = sh[0].cigs; u.cig_ops = sh[0].ops; }
+	else if (have_cigs) {
+		u.cigs = (bwagpu_cigar_t*)malloc((size_t)u.tot * sizeof(bwagpu_cigar_t));
+		int64_t n_ops = 0; for (auto &s : sh) n_ops += s.n_ops;
+		u.cig_ops = (uint32_t*)malloc((size_t)(n_ops ? n_ops : 1) * 4);
+		if (!u.cigs || !u.cig_ops) { fprintf(stderr, "[E::%s] out of memory\n", "mem_process_seqs"); exit(EXIT_FAILURE); }
+		int64_t k = 0, ko = 0;
+		for (auto &s : sh) {
+			if (s.tot) {   // (a shard without regions has no records); offsets into the operation array move with the shard's part of it
 				memcpy(u.cigs + k, s.cigs, (size_t)s.tot * sizeof(bwagpu_cigar_t));
 				if (s.n_ops) memcpy(u.cig_ops + ko, s.ops, (size_t)s.n_ops * 4);
 				if (ko) for (int64_t i = 0; i < s.tot; ++i) {
@@ -375,19 +401,12 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 				}
 			}
 			k += s.tot; ko += s.n_ops;
-			bwagpu_free(s.all); s.all = nullptr; bwagpu_free(s.cigs); s.cigs = nullptr; bwagpu_free(s.ops); s.ops = nullptr;
+			bwagpu_free(s.cigs); s.cigs = nullptr; bwagpu_free(s.ops); s.ops = nullptr;
 		}
 	}
-	double t_pes = 0;
-	if (g_device_matesw && pe && !(u.opt.flag & F_NO_RESCUE) && u.tot > 0) {
-		if (pes0) memcpy(u.pes, pes0, sizeof u.pes);
-		else {   // mem_pestat needs the whole batch's regions (bwamem.c:1258): they have just arrived
-			std::vector<int64_t> roff((size_t)n + 1, 0);
-			for (int i = 0; i < n; ++i) roff[i + 1] = roff[i] + u.counts[i];
-			pestat_flat(u.opt, ref.l_pac, n, u.all, roff.data(), u.pes, g_verbose >= 3, u.opt.n_threads < 4 ? u.opt.n_threads : 4);
-		}
-		u.have_pes = true;
-		t_pes = now_s() - t4;
+	t4 = now_s();
+	if (pes_thread.joinable()) pes_thread.join();
+	if (want_matesw) {
 		bwagpu_pes_t dp[4];
 		for (int d = 0; d < 4; ++d) { dp[d].low = u.pes[d].low; dp[d].high = u.pes[d].high; dp[d].failed = u.pes[d].failed; dp[d].pad_ = 0; }
 		on_devices([&](int d) {
