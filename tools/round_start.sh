@@ -1,0 +1,26 @@
+#!/bin/bash
+# First GPU call of a round (run through gpurun, ~20 box-minutes): what was built behind switches without a GPU at hand gets its
+# numbers in one go.  Results land under gpurun_out/<tag>/; copy what is to be kept into profiles/.
+#   /usr/local/graft/bin/gpurun --timeout 2100 -- 'bash tools/round_start.sh r04'
+# 1. the -m gpu suite (parity first: a failing test ends the script -- fix that before anything is timed)
+# 2. the full default bench line; its `variants` object A/Bs the switchable kernel forms against the defaults on the same batches
+#    (short reads: BWAGPU_SEED_MRG=1 / 2; long reads: BWAGPU_SEED_MRG=2, BWAGPU_SEED_CHUNK=256, BWAGPU_PUBLISH_BLK=1,
+#    BWAGPU_LONG_QLDS=1, BWAGPU_SEEDSW_LDS=1, each alone and all together) with a digest that must equal the defaults'
+# 3. kernel trace + FETCH_SIZE / WRITE_SIZE + SQ counters of the default configuration (tools/profile_round.sh); to profile a
+#    variant that won in step 2, run e.g.  BWAGPU_SEED_MRG=2 bash tools/profile_round.sh r04_mrg2  in a later call
+# Further configurations for step 2's probe can be given as extra arguments, e.g.  "BWAGPU_SEED_MRG=2 BWAGPU_PTAB_M=12".
+tag=${1:-r04}; shift
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+out=gpurun_out/$tag; mkdir -p $out
+timeout 900 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1 || { tail -30 $out/pytest_gpu.log; echo "GPU SUITE FAILED"; exit 1; }
+tail -3 $out/pytest_gpu.log
+timeout 700 python bench.py > $out/bench.json 2> $out/bench.log; echo "bench rc $?"; tail -c 800 $out/bench.json; echo
+C=/tmp/bwa_amd_bench
+P=$(ls $C/*.bwt 2>/dev/null | head -1); P=${P%.bwt}
+if [ -n "$P" ] && [ $# -gt 0 ]; then
+  timeout 420 python tools/variant_probe.py --prefix $P --codes $P.codes.npy --batch-files $C/variant_batch0.npy,$C/variant_batch1.npy,$C/variant_batch2.npy --steps 6 "$@" > $out/variants_extra.jsonl 2> $out/variants_extra.log
+  cat $out/variants_extra.jsonl
+fi
+bash tools/profile_round.sh $tag > $out/profile.log 2>&1
+ls $out
