@@ -11,6 +11,9 @@
 // oracle/_ref/libbwaref.so on the CPU (no GPU needed: regions come from the oracle).
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #include <string>
 #include <atomic>
 #include <thread>
@@ -36,6 +39,28 @@ struct RefSeqs {
 };
 
 struct Pestat { int low, high, failed; double avg, std; };          // == mem_pestat_t (bwamem.h:108-112)
+
+// SAM text under construction (the reference's kstring_t, kstring.h): a plain growing byte buffer.  Not std::string: a record is ~25 short
+// fields, and a checked append with a terminator written per field -- plus resize()'s zero fill ahead of the base and quality loops --
+// was half of what a record costs.  need(k) makes room for k more bytes and returns where they go; the caller adds what it wrote to n.
+struct SamText {
+	char *d = nullptr; size_t n = 0, cap = 0;
+	SamText() = default;
+	SamText(const SamText&) = delete; SamText &operator=(const SamText&) = delete;
+	~SamText() { free(d); }
+	void clear() { n = 0; }
+	size_t size() const { return n; }
+	const char *data() const { return d ? d : ""; }
+	void reserve(size_t c) { if (c > cap) grow(c); }
+	char *need(size_t k) { if (n + k > cap) grow(n + k + (cap > 256 ? cap : 256)); return d + n; }
+	void append(const char *p, size_t k) { memcpy(need(k), p, k); n += k; }
+	void append(const char *b, const char *e) { append(b, (size_t)(e - b)); }
+	SamText &operator+=(char c) { *need(1) = c; ++n; return *this; }
+	SamText &operator+=(const char *z) { append(z, strlen(z)); return *this; }
+	SamText &operator+=(const std::string &z) { append(z.data(), z.size()); return *this; }
+private:
+	void grow(size_t c) { char *p = (char*)realloc(d, c); if (!p) { fprintf(stderr, "[E::SamText] out of memory\n"); abort(); } d = p; cap = c; }
+};
 
 struct Aln {   // == the information of mem_aln_t (bwamem.h:114-126)
 	int64_t pos = -1; int rid = -1, flag = 0; bool is_rev = false, is_alt = false; int mapq = 0, NM = 0;
@@ -73,13 +98,13 @@ void reorder_primary5(int T, Regs &a);                              // bwamem.c:
 int approx_mapq_se(const bwagpu_opt_t &opt, const bwagpu_alnreg_t &a);   // bwamem.c:982-1006
 void host_region_cigar(const bwagpu_opt_t &opt, const RefSeqs &ref, const uint8_t *query, const bwagpu_alnreg_t &ar, bwagpu_cigar_t *out, std::vector<uint32_t> *ext);   // == one bwagpu_batch_cigars record (+ its entries of the operation array)
 Aln reg2aln(const bwagpu_opt_t &opt, const RefSeqs &ref, int l_query, const uint8_t *query, const bwagpu_alnreg_t *ar, const CigHints *hints = nullptr);   // bwamem.c:1119-1189
-void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, const Read &s, const std::vector<Aln> &list, int which, const Aln *mate, const char *rg_id);   // bwamem.c:851-976
-void reg2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, const Read &s, Regs &a, int extra_flag, const Aln *mate, const char *rg_id);   // bwamem.c:1033-1079
+void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, SamText &out, const Read &s, const std::vector<Aln> &list, int which, const Aln *mate, const char *rg_id);   // bwamem.c:851-976
+void reg2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, SamText &out, const Read &s, Regs &a, int extra_flag, const Aln *mate, const char *rg_id);   // bwamem.c:1033-1079
 void pestat_flat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const bwagpu_alnreg_t *all, const int64_t *roff, Pestat pes[4], bool verbose, int n_threads = 1);
 void attach_matesw(int n, Read *reads, const bwagpu_matesw_t *recs, int64_t n_recs, std::vector<bwagpu_matesw_t> &sorted);
 int64_t host_matesw_records(const bwagpu_opt_t &opt, const RefSeqs &ref, int n, const uint8_t *seqs, const int64_t *off, const bwagpu_alnreg_t *all, const int64_t *roff,
 							const Pestat pes[4], bwagpu_matesw_t *out, int64_t cap);   // == bwagpu_batch_matesw, on the host   // bwamem_pair.c:72-135
-int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uint64_t id, const Read s[2], Regs a[2], std::string out[2], const char *rg_id);   // bwamem_pair.c:276-419
+int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uint64_t id, const Read s[2], Regs a[2], SamText out[2], const char *rg_id);   // bwamem_pair.c:276-419
 
 // DP kernels of the finalize stage
 int ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins, int w, std::vector<uint32_t> *cigar);   // ksw.c:540-642

@@ -24,9 +24,10 @@ void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_proce
 		parallel_for(n_threads, n >> 1, [&](long i) {
 			thread_local Regs a[2];
 			a[0].assign(all + roff[i << 1], all + roff[(i << 1) + 1]); a[1].assign(all + roff[(i << 1) + 1], all + roff[(i << 1) + 2]);
-			std::string out[2];
+			thread_local SamText out[2];
+			out[0].clear(); out[1].clear();
 			sam_pe(opt, ref, pes, (uint64_t)((n_processed >> 1) + i), &reads[i << 1], a, out, rg_id);
-			sam[i << 1].swap(out[0]); sam[i << 1 | 1].swap(out[1]);
+			sam[i << 1].assign(out[0].data(), out[0].size()); sam[i << 1 | 1].assign(out[1].data(), out[1].size());
 		});
 	} else {
 		parallel_for(n_threads, n, [&](long i) {
@@ -34,7 +35,10 @@ void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_proce
 			a.assign(all + roff[i], all + roff[i + 1]);
 			mark_primary_se(opt, a, n_processed + i);
 			if (opt.flag & F_PRIMARY5) reorder_primary5(opt.T, a);
-			reg2sam(opt, ref, sam[i], reads[i], a, 0, 0, rg_id);
+			thread_local SamText out;
+			out.clear();
+			reg2sam(opt, ref, out, reads[i], a, 0, 0, rg_id);
+			sam[i].assign(out.data(), out.size());
 		});
 	}
 }
@@ -52,10 +56,10 @@ void finalize_batch_chunks(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t 
 	const bool pe = (opt.flag & F_PE) != 0;
 	Pestat pes[4];
 	if (pe) { if (pes0) memcpy(pes, pes0, sizeof pes); else pestat_flat(opt, ref.l_pac, n, all, roff, pes, verbose, n_threads < 4 ? n_threads : 4); }
-	auto put = [](std::string &dst, const std::string &s) { dst.append(s.data(), strnlen(s.data(), s.size())); };
+	auto put = [](std::string &dst, const SamText &s) { dst.append(s.data(), strnlen(s.data(), s.size())); };
 	std::atomic<long> next(0);
 	auto work = [&]() {
-		Regs a[2]; std::string out[2];
+		Regs a[2]; SamText out[2];
 		for (;;) {
 			const long c = next.fetch_add(1);
 			if (c >= n_chunks) break;

@@ -20,7 +20,7 @@ uint64_t hash_64(uint64_t key)
 	return key;
 }
 
-static inline void put_int(std::string &s, long long v)
+template <class S> static inline void put_int(S &s, long long v)
 {	// decimal text of v (what kputw/kputl/ksprintf("%d") emit), without a trip through snprintf
 	char buf[24]; int k = 24;
 	unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
@@ -28,6 +28,19 @@ static inline void put_int(std::string &s, long long v)
 	if (v < 0) buf[--k] = '-';
 	s.append(buf + k, (size_t)(24 - k));
 }
+
+// SamText forms: digits written in place (no temporary, no variable-size memcpy call), literals copied with their size known at compile time
+static inline void put_int(SamText &s, long long v)
+{
+	char *w = s.need(21);
+	unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+	if (v < 0) { *w++ = '-'; ++s.n; }
+	int nd = 1;
+	for (unsigned long long t = u; t >= 10; t /= 10) ++nd;
+	for (int i = nd - 1; i >= 0; --i) { w[i] = (char)('0' + u % 10); u /= 10; }
+	s.n += (size_t)nd;
+}
+template <size_t N> static inline void lit(SamText &s, const char (&z)[N]) { memcpy(s.need(N - 1), z, N - 1); s.n += N - 1; }
 
 // ---- primary / secondary marking (bwamem.c:519-584) -------------------------------------------------------------------
 static void mark_core(const bwagpu_opt_t &opt, int n, bwagpu_alnreg_t *a, std::vector<int> &z)
@@ -354,7 +367,7 @@ static int get_rlen(const std::vector<uint32_t> &c)
 	return l;
 }
 
-static void add_cigar(const bwagpu_opt_t &opt, const std::vector<uint32_t> &cigar, bool is_alt, std::string &s, int which)
+static void add_cigar(const bwagpu_opt_t &opt, const std::vector<uint32_t> &cigar, bool is_alt, SamText &s, int which)
 {	// bwamem.c:838-849
 	if (!cigar.empty()) {
 		for (uint32_t x : cigar) {
@@ -365,7 +378,7 @@ static void add_cigar(const bwagpu_opt_t &opt, const std::vector<uint32_t> &ciga
 	} else s += '*';
 }
 
-void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &str, const Read &s, const std::vector<Aln> &list, int which, const Aln *m_, const char *rg_id)
+void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, SamText &str, const Read &s, const std::vector<Aln> &list, int which, const Aln *m_, const char *rg_id)
 {
 	// The reference works on copies of the record and of the mate (bwamem.c:859-872) because it borrows coordinates from the
 	// mapped end for an unmapped one; only a few scalars and "has no CIGAR any more" change, so those are copied here.
@@ -391,7 +404,7 @@ void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &str, cons
 		put_int(str, p.pos + 1); str += '\t';
 		put_int(str, p.mapq); str += '\t';
 		add_cigar(opt, *p.cigar, p.is_alt, str, which);
-	} else str += "*\t0\t0\t*";
+	} else lit(str, "*\t0\t0\t*");
 	str += '\t';
 	if (m && m->rid >= 0) {
 		if (p.rid == m->rid) str += '='; else str += ref.ctg[m->rid].name;
@@ -403,9 +416,9 @@ void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &str, cons
 			if (m->cigar->empty() || p.cigar->empty()) str += '0';
 			else put_int(str, -(p0 - p1 + (p0 > p1 ? 1 : p0 < p1 ? -1 : 0)));
 		} else str += '0';
-	} else str += "*\t0\t0";
+	} else lit(str, "*\t0\t0");
 	str += '\t';
-	if (p.flag & 0x100) str += "*\t*";
+	if (p.flag & 0x100) lit(str, "*\t*");
 	else {
 		int qb = 0, qe = s.l_seq;
 		const bool trim = !p.cigar->empty() && which && !(opt.flag & F_SOFTCLIP) && !p.is_alt;
@@ -414,7 +427,7 @@ void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &str, cons
 				if (((*p.cigar)[0] & 0xf) == 4 || ((*p.cigar)[0] & 0xf) == 3) qb += (*p.cigar)[0] >> 4;
 				if ((p.cigar->back() & 0xf) == 4 || (p.cigar->back() & 0xf) == 3) qe -= p.cigar->back() >> 4;
 			}
-			{ const size_t at = str.size(); str.resize(at + (size_t)(qe > qb ? qe - qb : 0)); char *d = &str[0] + at; for (int i = qb; i < qe; ++i) *d++ = "ACGTN"[s.seq[i]]; }   // (written in place: a checked append per base was a fifth of the stage)
+			{ const size_t k = (size_t)(qe > qb ? qe - qb : 0); char *d = str.need(k); for (int i = qb; i < qe; ++i) *d++ = "ACGTN"[s.seq[i]]; str.n += k; }   // (written in place: a checked append per base was a fifth of the stage)
 			str += '\t';
 			if (s.qual) str.append(s.qual + qb, s.qual + qe); else str += '*';
 		} else {
@@ -422,22 +435,22 @@ void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &str, cons
 				if (((*p.cigar)[0] & 0xf) == 4 || ((*p.cigar)[0] & 0xf) == 3) qe -= (*p.cigar)[0] >> 4;
 				if ((p.cigar->back() & 0xf) == 4 || (p.cigar->back() & 0xf) == 3) qb += p.cigar->back() >> 4;
 			}
-			{ const size_t at = str.size(); str.resize(at + (size_t)(qe > qb ? qe - qb : 0)); char *d = &str[0] + at; for (int i = qe - 1; i >= qb; --i) *d++ = "TGCAN"[s.seq[i]]; }
+			{ const size_t k = (size_t)(qe > qb ? qe - qb : 0); char *d = str.need(k); for (int i = qe - 1; i >= qb; --i) *d++ = "TGCAN"[s.seq[i]]; str.n += k; }
 			str += '\t';
-			if (s.qual) { const size_t at = str.size(); str.resize(at + (size_t)(qe > qb ? qe - qb : 0)); char *d = &str[0] + at; for (int i = qe - 1; i >= qb; --i) *d++ = s.qual[i]; } else str += '*';
+			if (s.qual) { const size_t k = (size_t)(qe > qb ? qe - qb : 0); char *d = str.need(k); for (int i = qe - 1; i >= qb; --i) *d++ = s.qual[i]; str.n += k; } else str += '*';
 		}
 	}
-	if (!p.cigar->empty()) { str += "\tNM:i:"; put_int(str, p.NM); str += "\tMD:Z:"; str += *p.md; }
-	if (m && !m->cigar->empty()) { str += "\tMC:Z:"; add_cigar(opt, *m->cigar, m->is_alt, str, which); }
-	if (m) { str += "\tMQ:i:"; put_int(str, m->mapq); }
-	if (p.score >= 0) { str += "\tAS:i:"; put_int(str, p.score); }
-	if (p.sub >= 0) { str += "\tXS:i:"; put_int(str, p.sub); }
-	if (rg_id && rg_id[0]) { str += "\tRG:Z:"; str += rg_id; }
+	if (!p.cigar->empty()) { lit(str, "\tNM:i:"); put_int(str, p.NM); lit(str, "\tMD:Z:"); str += *p.md; }
+	if (m && !m->cigar->empty()) { lit(str, "\tMC:Z:"); add_cigar(opt, *m->cigar, m->is_alt, str, which); }
+	if (m) { lit(str, "\tMQ:i:"); put_int(str, m->mapq); }
+	if (p.score >= 0) { lit(str, "\tAS:i:"); put_int(str, p.score); }
+	if (p.sub >= 0) { lit(str, "\tXS:i:"); put_int(str, p.sub); }
+	if (rg_id && rg_id[0]) { lit(str, "\tRG:Z:"); str += rg_id; }
 	if (!(p.flag & 0x100)) {
 		int i;
 		for (i = 0; i < n; ++i) if (i != which && !(list[i].flag & 0x100)) break;
 		if (i < n) {
-			str += "\tSA:Z:";
+			lit(str, "\tSA:Z:");
 			for (i = 0; i < n; ++i) {
 				const Aln &r = list[i];
 				if (i == which || (r.flag & 0x100)) continue;
@@ -451,14 +464,14 @@ void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &str, cons
 	if (p.has_xa) { str += (opt.flag & F_XB) ? "\tXB:Z:" : "\tXA:Z:"; str += *p.xa; }
 	if (s.comment) { str += '\t'; str += s.comment; }
 	if ((opt.flag & F_REF_HDR) && p.rid >= 0 && !ref.ctg[p.rid].anno.empty()) {
-		str += "\tXR:Z:";
+		lit(str, "\tXR:Z:");
 		for (char c : ref.ctg[p.rid].anno) str += c == '\t' ? ' ' : c;
 	}
 	str += '\n';
 }
 
 // ---- all records of one read (mem_reg2sam, bwamem.c:1033-1079) -----------------------------------------------------------
-void reg2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, std::string &out, const Read &s, Regs &av, int extra_flag, const Aln *m, const char *rg_id)
+void reg2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, SamText &out, const Read &s, Regs &av, int extra_flag, const Aln *m, const char *rg_id)
 {
 	std::vector<std::string> xa; std::vector<char> has;
 	bool have_xa = false;

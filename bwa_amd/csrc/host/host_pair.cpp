@@ -335,7 +335,7 @@ bool gen_alt_for_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Regs &av,
 static inline int raw_mapq(int diff, int a) { return (int)(6.02 * diff / a + .499); }
 
 // ---- mem_sam_pe (bwamem_pair.c:276-419) ------------------------------------------------------------------------------------
-int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uint64_t id, const Read s[2], Regs a[2], std::string out[2], const char *rg_id)
+int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uint64_t id, const Read s[2], Regs a[2], SamText out[2], const char *rg_id)
 {
 	int n = 0, z[2] = {0, 0}, o, subo, n_sub, extra_flag = 1, n_pri[2];
 	Aln h[2];
