@@ -10,6 +10,8 @@ OUT = os.path.join(SIM, "libbwagpu_hostsim.so")
 
 
 def build():
+    if os.environ.get("BWA_AMD_HOSTSIM_LIB"):       # e.g. a build of the same sources with -fsanitize=address,undefined (tools/sanitize_mock.sh)
+        return os.environ["BWA_AMD_HOSTSIM_LIB"]
     csrc = os.path.join(ROOT, "bwa_amd", "csrc")
     srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))] + [
         os.path.join(SIM, "hip", "hip_runtime.h"), os.path.join(SIM, "mock_globals.cpp"), os.path.join(ROOT, "include", "bwagpu.h"),
