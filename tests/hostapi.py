@@ -11,6 +11,8 @@ _lib = None
 
 
 def build():
+    if os.environ.get("BWA_AMD_HOST_LIB"):       # (a sanitizer build of the same sources: tools/sanitize_mock.sh)
+        return os.environ["BWA_AMD_HOST_LIB"]
     srcs = [os.path.join(HOST_DIR, f) for f in sorted(os.listdir(HOST_DIR)) if f.endswith((".cpp", ".h")) and not f.startswith("main_")]
     if os.path.exists(HOST_SO) and all(os.path.getmtime(HOST_SO) >= os.path.getmtime(s) for s in srcs):
         return HOST_SO

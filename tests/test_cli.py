@@ -27,6 +27,8 @@ def _run(binary, args, env=None):
 
 
 def _sim_cli():
+    if os.environ.get("BWA_AMD_SIM_CLI"):        # (a sanitizer build of the same sources: tools/sanitize_mock.sh)
+        return os.environ["BWA_AMD_SIM_CLI"]
     import hostsim_build
     from bwa_amd import build as b
     hostsim_build.build()
