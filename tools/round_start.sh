@@ -8,6 +8,7 @@
 #    BWAGPU_LONG_QLDS=1, BWAGPU_SEEDSW_LDS=1, each alone and all together) with a digest that must equal the defaults'
 # 3. kernel trace + FETCH_SIZE / WRITE_SIZE + SQ counters of the default configuration (tools/profile_round.sh); to profile a
 #    variant that won in step 2, run e.g.  BWAGPU_SEED_MRG=2 bash tools/profile_round.sh r04_mrg2  in a later call
+# 4. kernel stats of `bwa-amd mem` itself on the bench's FASTQ files (hot path + CIGAR + mate-rescue kernels side by side)
 # Further configurations for step 2's probe can be given as extra arguments, e.g.  "BWAGPU_SEED_MRG=2 BWAGPU_PTAB_M=12".
 tag=${1:-r04}; shift
 cd /tmp && export TMPDIR=/tmp
@@ -21,6 +22,12 @@ P=$(ls $C/*.bwt 2>/dev/null | head -1); P=${P%.bwt}
 if [ -n "$P" ] && [ $# -gt 0 ]; then
   timeout 420 python tools/variant_probe.py --prefix $P --codes $P.codes.npy --batch-files $C/variant_batch0.npy,$C/variant_batch1.npy,$C/variant_batch2.npy --steps 6 "$@" > $out/variants_extra.jsonl 2> $out/variants_extra.log
   cat $out/variants_extra.jsonl
+fi
+# 4. the kernels of the FASTQ->SAM run (never profiled so far: what do the CIGAR and mate-rescue kernels cost next to the hot path?)
+if [ -n "$P" ] && [ -e $C/sample_1.fq ]; then
+  BWAGPU_CLI_TRACE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/e2e_trace -o e -- bwa_amd/bwa-amd mem -t 16 -K 100000000 $P $C/sample_1.fq $C/sample_2.fq > /dev/null 2> $out/e2e_trace.log
+  find $out/e2e_trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/e2e_kernel_stats.csv
+  grep "device_sub" $out/e2e_trace.log | tail -5
 fi
 bash tools/profile_round.sh $tag > $out/profile.log 2>&1
 ls $out
