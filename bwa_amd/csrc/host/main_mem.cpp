@@ -6,6 +6,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/mman.h>
 #include <getopt.h>
 #include <math.h>
 #include <stdio.h>
@@ -71,8 +72,46 @@ static std::string unescape(const char *s)
 // ---- FASTA/FASTQ input (what kseq_read + bseq_read deliver, kseq.h:175-220, bwa.c:79-112) ----------------------------
 // One record = four NUL-terminated strings in its batch's text arena (no per-record allocation: the reader is a single
 // thread and sets the pace of the whole pipeline).
-struct Seq { size_t name = 0, comment = 0, seq = 0, qual = 0; int l_name = 0, l_seq = 0, l_qual = 0; bool has_comment = false, has_qual = false; };
+struct Seq { size_t name = 0, comment = 0, seq = 0, qual = 0; int l_name = 0, l_seq = 0, l_qual = 0; bool has_comment = false, has_qual = false;
+	char *base = nullptr;   /* the text the offsets refer to when it is not the batch's own arena (a parsed block, see ParFile) */ };
 typedef std::vector<char> Arena;
+
+// does any of the n bytes at p hold a blank or control character (<= ' ')?  Eight bytes per step.
+static bool has_blank(const char *p, size_t n) {
+	const uint64_t ones = ~0ull / 255;
+	size_t i = 0;
+	for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); if ((w - ones * 0x21) & ~w & (ones * 0x80)) return true; }
+	for (; i < n; ++i) if ((unsigned char)p[i] <= ' ') return true;
+	return false;
+}
+
+// One plain four-line FASTQ record at b (the text ends at e): appended to A as name\0 comment\0 bases\0 qualities\0, its successor's
+// address returned -- or null, nothing appended, when the record is not of that kind or not completely there (the general reader
+// decides then).  Both the streaming reader and the block parsers below go through here, so they accept exactly the same records.
+static const char *parse_fast_record(const char *b, const char *e, Seq &s, Arena &A)
+{
+	if (b >= e || *b != '@') return nullptr;
+	const char *n1 = (const char*)memchr(b, '\n', (size_t)(e - b)); if (!n1 || n1 + 1 >= e) return nullptr;
+	const char *n2 = (const char*)memchr(n1 + 1, '\n', (size_t)(e - n1 - 1)); if (!n2 || n2 + 1 >= e || n2[1] != '+') return nullptr;
+	const char *n3 = (const char*)memchr(n2 + 1, '\n', (size_t)(e - n2 - 1)); if (!n3 || n3 + 1 >= e) return nullptr;
+	const char *n4 = (const char*)memchr(n3 + 1, '\n', (size_t)(e - n3 - 1)); if (!n4) return nullptr;
+	const char *sq = n1 + 1, *ql = n3 + 1;
+	const size_t ls = (size_t)(n2 - sq), lq = (size_t)(n4 - ql);
+	if (ls == 0 || ls != lq || n1[-1] == '\r' || n2[-1] == '\r' || n4[-1] == '\r') return nullptr;
+	if (sq[0] == '>' || sq[0] == '+' || sq[0] == '@') return nullptr;              // the general reader treats these as record structure
+	if (has_blank(sq, ls)) return nullptr;                                         // blanks / control characters: general path
+	const char *h = b + 1, *he = n1, *ne = h;
+	while (ne < he && !isspace((unsigned char)*ne)) ++ne;
+	s = Seq();
+	s.name = A.size(); s.l_name = (int)(ne - h);
+	A.insert(A.end(), h, ne); A.push_back(0);
+	s.comment = A.size();
+	if (ne < he) { s.has_comment = true; A.insert(A.end(), ne + 1, he); }
+	A.push_back(0);
+	s.seq = A.size(); s.l_seq = (int)ls; A.insert(A.end(), sq, sq + ls); A.push_back(0);
+	s.qual = A.size(); s.l_qual = (int)lq; s.has_qual = true; A.insert(A.end(), ql, ql + lq); A.push_back(0);
+	return n4 + 1;
+}
 
 struct Reader {
 	gzFile fp = nullptr; int raw_fd = -1; std::vector<char> buf; int pos = 0, len = 0; int last = 0; bool eof = false;
@@ -131,14 +170,6 @@ struct Reader {
 		if (len <= 0) { len = 0; eof = true; return false; }
 		return true;
 	}
-	// does any of the n bytes at p hold a blank or control character (<= ' ')?  Eight bytes per step.
-	static bool has_blank(const char *p, size_t n) {
-		const uint64_t ones = ~0ull / 255;
-		size_t i = 0;
-		for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); if ((w - ones * 0x21) & ~w & (ones * 0x80)) return true; }
-		for (; i < n; ++i) if ((unsigned char)p[i] <= ' ') return true;
-		return false;
-	}
 	int getc_() { if (pos >= len && !fill()) return -1; return (unsigned char)buf[pos++]; }
 	// append the bytes up to the next delimiter (newline, or any white space when `space`) to `out` and consume the delimiter;
 	// returns the delimiter, or -1 at end of input.  Whole buffer spans are copied at once.
@@ -159,28 +190,9 @@ struct Reader {
 	// located with four memchr calls and appended in bulk; anything else goes through the general reader below.
 	bool read_fast(Seq &s, Arena &A) {
 		if (last != 0 || pos >= len) return false;
-		const char *b = buf.data() + pos, *e = buf.data() + len;
-		if (*b != '@') return false;
-		const char *n1 = (const char*)memchr(b, '\n', (size_t)(e - b)); if (!n1 || n1 + 1 >= e) return false;
-		const char *n2 = (const char*)memchr(n1 + 1, '\n', (size_t)(e - n1 - 1)); if (!n2 || n2 + 1 >= e || n2[1] != '+') return false;
-		const char *n3 = (const char*)memchr(n2 + 1, '\n', (size_t)(e - n2 - 1)); if (!n3 || n3 + 1 >= e) return false;
-		const char *n4 = (const char*)memchr(n3 + 1, '\n', (size_t)(e - n3 - 1)); if (!n4) return false;
-		const char *sq = n1 + 1, *ql = n3 + 1;
-		const size_t ls = (size_t)(n2 - sq), lq = (size_t)(n4 - ql);
-		if (ls == 0 || ls != lq || n1[-1] == '\r' || n2[-1] == '\r' || n4[-1] == '\r') return false;
-		if (sq[0] == '>' || sq[0] == '+' || sq[0] == '@') return false;              // the general reader treats these as record structure
-		if (has_blank(sq, ls)) return false;                                           // blanks / control characters: general path
-		const char *h = b + 1, *he = n1, *ne = h;
-		while (ne < he && !isspace((unsigned char)*ne)) ++ne;
-		s = Seq();
-		s.name = A.size(); s.l_name = (int)(ne - h);
-		A.insert(A.end(), h, ne); A.push_back(0);
-		s.comment = A.size();
-		if (ne < he) { s.has_comment = true; A.insert(A.end(), ne + 1, he); }
-		A.push_back(0);
-		s.seq = A.size(); s.l_seq = (int)ls; A.insert(A.end(), sq, sq + ls); A.push_back(0);
-		s.qual = A.size(); s.l_qual = (int)lq; s.has_qual = true; A.insert(A.end(), ql, ql + lq); A.push_back(0);
-		pos = (int)(n4 + 1 - buf.data());
+		const char *next = parse_fast_record(buf.data() + pos, buf.data() + len, s, A);
+		if (!next) return false;
+		pos = (int)(next - buf.data());
 		return true;
 	}
 	bool read(Seq &s, Arena &A) {
@@ -231,18 +243,190 @@ struct Reader {
 	}
 };
 
-// "/1" and "/2" name suffixes are dropped (trim_readno, bwa.c:66-71)
-static void trim_readno(Seq &s, Arena &A) { if (s.l_name > 2 && A[s.name + s.l_name - 2] == '/' && isdigit((unsigned char)A[s.name + s.l_name - 1])) { s.l_name -= 2; A[s.name + s.l_name] = 0; } }
-
-struct Batch { Arena text; std::vector<Seq> seqs; };
-
-static bool read_batch(Reader &r1, Reader *r2, int chunk, Batch &out)
+// ---- block-parallel input (BWAGPU_CLI_PARSE_THREADS=N; default 4 when the batches are split over several devices) ---------------
+// One thread parses ~8 M records per second; one MI355X takes half of that, a node of eight needs four times it.  A plain FASTQ file is
+// therefore read in blocks that end on a record boundary, the blocks are parsed by a pool of threads (parse_fast_record, the streaming
+// reader's own fast path) into arenas of their own, and the batch builder copies finished records out in file order -- one memcpy per
+// record instead of the parse.  Exactness does not rest on finding the boundaries right: a block must be consumed to its last byte by
+// records of the plain kind; the first byte that is not -- a record the fast path declines, or a cut that was not a record start, which
+// leaves the block before it with an incomplete last record -- is, by induction from the file's first byte, the start of a record, and
+// from there on the file goes through the streaming reader (lseek), whose general path has the reference's kseq semantics.  gzip
+// input and pipes keep the streaming reader throughout.
+struct ParBlock {
+	const char *raw = nullptr; size_t len = 0; int64_t file_off = 0; bool last = false, whole = false;   // whole: the buffer held no cut (or the file ended) -- what follows the consumed part is not known to be a record start
+	Arena text; std::vector<Seq> seqs; size_t end_at = 0;      // bytes of raw that became records
+	bool parsed = false;
+};
+// blocks are shared: a batch keeps the blocks its records lie in (no copy of the text), the last owner hands a block back to this pool
+static std::mutex g_blk_m; static std::vector<ParBlock*> g_blk_pool;
+static std::shared_ptr<ParBlock> new_block()
 {
-	out.seqs.clear(); out.text.clear();
+	ParBlock *b = nullptr;
+	{ std::lock_guard<std::mutex> l(g_blk_m); if (!g_blk_pool.empty()) { b = g_blk_pool.back(); g_blk_pool.pop_back(); } }
+	if (!b) b = new ParBlock();
+	return std::shared_ptr<ParBlock>(b, [](ParBlock *x) { std::lock_guard<std::mutex> l(g_blk_m); if (g_blk_pool.size() < 256) g_blk_pool.push_back(x); else delete x; });
+}
+struct ParFile;
+struct ParPool {
+	std::mutex m; std::condition_variable cv; std::deque<std::pair<ParFile*, ParBlock*>> q; bool stop = false; std::vector<std::thread> th;
+	explicit ParPool(int n) { for (int i = 0; i < n; ++i) th.emplace_back([this] { run(); }); }
+	~ParPool() { { std::lock_guard<std::mutex> l(m); stop = true; } cv.notify_all(); for (auto &t : th) t.join(); }
+	void run();
+};
+struct ParFile {
+	std::string path; int fd = -1; const char *map = nullptr; size_t size = 0; size_t blk = (size_t)4 << 20; ParPool *pool = nullptr;
+	std::mutex m; std::condition_variable cv;
+	std::deque<std::shared_ptr<ParBlock>> inflight;      // in file order; the front one is handed to the consumer once parsed
+	int pending = 0;                                      // blocks queued in or being parsed by the pool
+	bool io_done = false, stop = false;
+	std::thread io;
+	std::shared_ptr<ParBlock> cur; size_t ci = 0; long cur_batch = -1;   // consumer side (cur_batch: the batch that already holds cur)
+	bool fallback = false; Reader ser; long n_par = 0;
+	~ParFile() { shutdown(); if (map) munmap((void*)map, size); if (fd >= 0) ::close(fd); }
+	void shutdown() {
+		if (!pool) return;
+		{ std::lock_guard<std::mutex> l(m); stop = true; }
+		cv.notify_all();
+		if (io.joinable()) io.join();
+		{	// blocks of this file still waiting in the pool's queue are taken back; those being parsed are waited for
+			std::lock_guard<std::mutex> lp(pool->m);
+			for (auto it = pool->q.begin(); it != pool->q.end();) if (it->first == this) { it = pool->q.erase(it); std::lock_guard<std::mutex> l(m); --pending; } else ++it;
+		}
+		std::unique_lock<std::mutex> l(m);
+		cv.wait(l, [&] { return pending == 0; });
+	}
+	// the last position in [1, n) that starts a line with '@' and whose next-but-one line starts with '+' (0: none)
+	static size_t find_cut(const char *b, size_t n) {
+		size_t p = n;
+		while (p > 0) {
+			const char *nl = (const char*)memrchr(b, '\n', p);      // the newest line start before p
+			if (!nl) return 0;
+			const size_t ls = (size_t)(nl - b) + 1;
+			p = (size_t)(nl - b);
+			if (ls >= n || b[ls] != '@') continue;
+			const char *e1 = (const char*)memchr(b + ls, '\n', n - ls); if (!e1) continue;
+			const char *e2 = (const char*)memchr(e1 + 1, '\n', (size_t)(b + n - e1 - 1)); if (!e2 || e2 + 1 >= b + n) continue;
+			if (e2[1] == '+') return ls;
+		}
+		return 0;
+	}
+	void read_blocks() {      // (cuts only: the file is mapped, its pages are first touched by the threads that parse them)
+		size_t off = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> l(m);
+				cv.wait(l, [&] { return stop || inflight.size() < 8; });
+				if (stop) break;
+			}
+			std::shared_ptr<ParBlock> B = new_block();
+			const size_t n = size - off < blk ? size - off : blk;
+			const bool eof = off + n == size;
+			B->raw = map + off; B->file_off = (int64_t)off; B->seqs.clear(); B->text.clear(); B->end_at = 0; B->parsed = false; B->last = eof; B->whole = eof;
+			size_t cut = eof ? n : find_cut(map + off, n);
+			if (!eof && cut == 0) { cut = n; B->whole = true; }       // no boundary in sight (records longer than a block, or not this kind of file)
+			B->len = cut;
+			off += cut;
+			const bool end = eof || B->whole;
+			ParBlock *raw_ptr = B.get();
+			{ std::lock_guard<std::mutex> l(m); inflight.push_back(B); ++pending; }
+			{ std::lock_guard<std::mutex> lp(pool->m); pool->q.emplace_back(this, raw_ptr); }
+			pool->cv.notify_one();
+			if (end) break;                                          // after a block without a cut the consumer goes to the streaming reader
+		}
+		{ std::lock_guard<std::mutex> l(m); io_done = true; }
+		cv.notify_all();
+	}
+	bool open(const char *fn, ParPool *pl) {      // true: this file is read in blocks
+		const int f = ::open(fn, O_RDONLY);
+		if (f < 0) return false;
+		unsigned char magic[2] = { 0, 0 }; struct stat st;
+		if (!(fstat(f, &st) == 0 && S_ISREG(st.st_mode) && pread(f, magic, 2, 0) >= 0 && !(magic[0] == 0x1f && magic[1] == 0x8b))) { ::close(f); return false; }
+		size = (size_t)st.st_size;
+		if (size > 0) {
+			void *mp = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, f, 0);
+			if (mp == MAP_FAILED) { ::close(f); return false; }
+			madvise(mp, size, MADV_SEQUENTIAL);
+			map = (const char*)mp;
+		}
+		fd = f; path = fn; pool = pl;
+		if (getenv("BWAGPU_CLI_PAR_BLOCK")) { blk = (size_t)atoll(getenv("BWAGPU_CLI_PAR_BLOCK")); if (blk < 16) blk = 16; }   // (tests: cuts in every position)
+		io = std::thread([this] { read_blocks(); });
+		return true;
+	}
+	// the next record: in a parsed block (s.base set; the batch `hold` keeps the block) or, after the switch, appended to A
+	bool read(Seq &s, Arena &A, std::vector<std::shared_ptr<ParBlock>> &hold, long batch_id) {
+		for (;;) {
+			if (fallback) return ser.read(s, A);
+			if (!cur) {
+				std::unique_lock<std::mutex> l(m);
+				cv.wait(l, [&] { return (!inflight.empty() && inflight.front()->parsed) || (inflight.empty() && io_done); });
+				if (inflight.empty()) return false;                  // (an empty file)
+				cur = std::move(inflight.front()); inflight.pop_front(); ci = 0; cur_batch = -1;
+				l.unlock(); cv.notify_all();
+			}
+			if (ci < cur->seqs.size()) {
+				s = cur->seqs[ci++]; s.base = cur->text.data(); ++n_par;
+				if (cur_batch != batch_id) { hold.push_back(cur); cur_batch = batch_id; }
+				return true;
+			}
+			const bool clean = cur->end_at == cur->len && !cur->whole, at_eof = cur->last && cur->end_at == cur->len;
+			const int64_t resume = cur->file_off + (int64_t)cur->end_at;
+			cur.reset();
+			if (clean) continue;
+			if (at_eof) return false;
+			// the rest of the file through the streaming reader, from the first byte that did not become a record
+			shutdown();
+			{ std::lock_guard<std::mutex> l(m); inflight.clear(); }
+			if (!ser.open(path.c_str()) || ser.raw_fd < 0 || lseek(ser.raw_fd, (off_t)resume, SEEK_SET) < 0) { fprintf(stderr, "[E::%s] fail to re-open file `%s'.\n", "main_mem", path.c_str()); exit(EXIT_FAILURE); }
+			if (getenv("BWAGPU_CLI_TRACE")) fprintf(stderr, "[D::input] %s: %ld records from parsed blocks, the streaming reader takes over at byte %ld\n", path.c_str(), n_par, (long)resume);
+			fallback = true;
+		}
+	}
+};
+void ParPool::run()
+{
+	for (;;) {
+		std::pair<ParFile*, ParBlock*> t;
+		{
+			std::unique_lock<std::mutex> l(m);
+			cv.wait(l, [&] { return stop || !q.empty(); });
+			if (q.empty()) return;
+			t = q.front(); q.pop_front();
+		}
+		ParBlock &B = *t.second;
+		const char *b = B.raw, *e = b + B.len, *p = b;
+		if (B.text.capacity() < B.len) B.text.reserve(B.len + 1024);
+		Seq s;
+		while (p < e) { const char *nx = parse_fast_record(p, e, s, B.text); if (!nx) break; B.seqs.push_back(s); p = nx; }
+		B.end_at = (size_t)(p - b);
+		{ std::lock_guard<std::mutex> l(t.first->m); B.parsed = true; --t.first->pending; t.first->cv.notify_all(); }   // (notified under the lock: shutdown() may let the file go as soon as pending is 0)
+	}
+}
+// an input file: read in blocks when it is a plain file and a pool is given, through the streaming reader otherwise
+struct Source {
+	Reader ser; std::unique_ptr<ParFile> par;
+	bool open(const char *fn, ParPool *pool) {
+		if (pool && strcmp(fn, "-")) { par.reset(new ParFile()); if (par->open(fn, pool)) return true; par.reset(); }
+		return ser.open(fn);
+	}
+	bool read(Seq &s, Arena &A, std::vector<std::shared_ptr<ParBlock>> &hold, long batch_id) { return par ? par->read(s, A, hold, batch_id) : ser.read(s, A); }
+};
+
+// "/1" and "/2" name suffixes are dropped (trim_readno, bwa.c:66-71)
+static void trim_readno(Seq &s, Arena &A) { char *T = s.base ? s.base : A.data(); if (s.l_name > 2 && T[s.name + s.l_name - 2] == '/' && isdigit((unsigned char)T[s.name + s.l_name - 1])) { s.l_name -= 2; T[s.name + s.l_name] = 0; } }
+
+struct Batch { Arena text; std::vector<Seq> seqs; std::vector<std::shared_ptr<ParBlock>> blocks;   /* parsed blocks the records with a base of their own lie in */
+	const char *T(const Seq &q) const { return q.base ? q.base : text.data(); } };
+
+static bool read_batch(Source &r1, Source *r2, int chunk, Batch &out)
+{
+	static long batch_no = 0;
+	const long id = batch_no++;
+	out.seqs.clear(); out.text.clear(); out.blocks.clear();
 	if (out.text.capacity() == 0) { out.text.reserve((size_t)chunk * 5 / 2 + (1 << 20)); out.seqs.reserve((size_t)chunk / 64 + 1024); }   // ~2.3 text bytes per base
 	long size = 0; Seq s, s2;
-	while (r1.read(s, out.text)) {
-		if (r2 && !r2->read(s2, out.text)) { fprintf(stderr, "[W::%s] the 2nd file has fewer sequences.\n", "bseq_read"); break; }
+	while (r1.read(s, out.text, out.blocks, id)) {
+		if (r2 && !r2->read(s2, out.text, out.blocks, id)) { fprintf(stderr, "[W::%s] the 2nd file has fewer sequences.\n", "bseq_read"); break; }
 		trim_readno(s, out.text); size += s.l_seq; out.seqs.push_back(s);
 		if (r2) { trim_readno(s2, out.text); size += s2.l_seq; out.seqs.push_back(s2); }
 		if (size >= chunk && (out.seqs.size() & 1) == 0) break;
@@ -291,7 +475,7 @@ static void encode_sub(const Batch &in, Sub &u)
 	// (100 MB of table look-ups per batch: a tenth of a second on one thread, inside the stage that feeds the device)
 	parallel_for(u.opt.n_threads < 4 ? u.opt.n_threads : 4, n, [&](long i) {
 		const Seq &q = in.seqs[u.idx[i]];
-		const unsigned char *src = (const unsigned char*)in.text.data() + q.seq; uint8_t *d = u.flat.data() + u.off[i];
+		const unsigned char *src = (const unsigned char*)in.T(q) + q.seq; uint8_t *d = u.flat.data() + u.off[i];
 		for (int j = 0; j < q.l_seq; ++j) d[j] = g_nt4.t[src[j]];
 	});
 	u.counts.assign((size_t)n, 0);
@@ -442,7 +626,7 @@ static void finalize_sub(const RefSeqs &ref, Work &w, Sub &u, const Pestat *pes0
 	for (int i = 0; i < n; ++i) roff[i + 1] = roff[i] + u.counts[i];
 	parallel_for(u.opt.n_threads, n, [&](long i) {
 		const Seq &q = w.in.seqs[u.idx[i]];
-		const char *T = w.in.text.data();
+		const char *T = w.in.T(q);
 		if (u.cigs) { hints[i].regs = u.all + roff[i]; hints[i].cigs = u.cigs + roff[i]; hints[i].n = u.counts[i]; hints[i].ops = u.cig_ops; reads[i].hints = &hints[i]; }
 		reads[i].name = T + q.name;
 		reads[i].comment = copy_comment && q.has_comment ? T + q.comment : nullptr;
@@ -619,11 +803,15 @@ int main(int argc, char *argv[])
 		if (dense > 0) { int rc = bwagpu_densify_sa(gpu, dense); if (rc != BWAGPU_OK && g_verbose >= 2) fprintf(stderr, "[W::%s] SA not densified: %s\n", "main_mem", bwagpu_strerror(rc)); }
 	}
 
-	Reader r1, r2; Reader *pr2 = nullptr;
-	if (!r1.open(argv[optind + 1])) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", "main_mem", argv[optind + 1]); return 1; }
+	// input: BWAGPU_CLI_PARSE_THREADS parser threads for plain FASTQ files (0: the streaming reader alone; the default when one device takes the batches)
+	int n_devices_env = 1; if (const char *dl = getenv("BWAGPU_DEVICES")) for (const char *q = dl; *q; ++q) if (*q == ',') ++n_devices_env;
+	const int n_parse = getenv("BWAGPU_CLI_PARSE_THREADS") ? atoi(getenv("BWAGPU_CLI_PARSE_THREADS")) : (n_devices_env > 1 ? 4 : 0);
+	std::unique_ptr<ParPool> parse_pool(n_parse > 0 ? new ParPool(n_parse) : nullptr);
+	Source r1, r2; Source *pr2 = nullptr;
+	if (!r1.open(argv[optind + 1], parse_pool.get())) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", "main_mem", argv[optind + 1]); return 1; }
 	if (optind + 2 < argc) {
 		if (opt.flag & F_PE) { if (g_verbose >= 2) fprintf(stderr, "[W::%s] when '-p' is in use, the second query file is ignored.\n", "main_mem"); }
-		else { if (!r2.open(argv[optind + 2])) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", "main_mem", argv[optind + 2]); return 1; } pr2 = &r2; opt.flag |= F_PE; }
+		else { if (!r2.open(argv[optind + 2], parse_pool.get())) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", "main_mem", argv[optind + 2]); return 1; } pr2 = &r2; opt.flag |= F_PE; }
 	}
 	// SAM header (bwa_print_sam_hdr, bwa.c:407-439)
 	{
@@ -638,7 +826,14 @@ int main(int argc, char *argv[])
 	const double t_start = now_s();
 	if (getenv("BWAGPU_CLI_PARSE_ONLY")) {   // diagnostics: speed of the input stage alone
 		Batch b; long n = 0, bp = 0;
-		while (read_batch(r1, pr2, chunk, b)) { n += (long)b.seqs.size(); for (auto &q : b.seqs) bp += q.l_seq; }
+		const bool dump = atoi(getenv("BWAGPU_CLI_PARSE_ONLY")) == 2;      // (tests: what the input stage delivers, batch by batch)
+		while (read_batch(r1, pr2, chunk, b)) {
+			n += (long)b.seqs.size(); for (auto &q : b.seqs) bp += q.l_seq;
+			if (dump) {
+				printf("#batch %zu\n", b.seqs.size());
+				for (auto &q : b.seqs) { const char *T = b.T(q); printf("%s\t%s\t%s\t%s\n", T + q.name, q.has_comment ? T + q.comment : "-", T + q.seq, q.has_qual ? T + q.qual : "-"); }
+			}
+		}
 		fprintf(stderr, "[M::%s] parsed %ld records (%ld bp) in %.3f s\n", "main_mem", n, bp, now_s() - t_start);
 		return 0;
 	}
@@ -702,7 +897,7 @@ int main(int argc, char *argv[])
 				Sub se, pe; bool has_last = true; int i;
 				for (i = 1; i < n; ++i) {
 					if (has_last) {
-						if (strcmp(w->in.text.data() + w->in.seqs[i].name, w->in.text.data() + w->in.seqs[i - 1].name) == 0) { pe.idx.push_back(i - 1); pe.idx.push_back(i); has_last = false; }
+						if (strcmp(w->in.T(w->in.seqs[i]) + w->in.seqs[i].name, w->in.T(w->in.seqs[i - 1]) + w->in.seqs[i - 1].name) == 0) { pe.idx.push_back(i - 1); pe.idx.push_back(i); has_last = false; }
 						else se.idx.push_back(i - 1);
 					} else has_last = true;
 				}
@@ -770,6 +965,7 @@ int main(int argc, char *argv[])
 		busy_fin += now_s() - tf;
 		{
 			std::lock_guard<std::mutex> l(pool_m);
+			w->in.blocks.clear();                 // (the parsed blocks go back to their pool now, not when the batch is next used)
 			if (batch_pool.size() < 4) batch_pool.push_back(std::move(w->in));
 			for (Sub &u : w->subs) if (flat_pool.size() < 6) flat_pool.push_back(std::move(u.flat));
 		}

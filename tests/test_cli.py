@@ -216,3 +216,72 @@ def test_cli_hostsim_two_devices(tmp_path):
     assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], dict(env, BWAGPU_OCC32="0", BWAGPU_SEED_COOP="1")), "paired-end, 2 devices, 64-byte blocks fetched quad-cooperatively"
     env3 = dict(env, MOCK_HIP_DEVICES="3", BWAGPU_DEVICES="0,1,2")
     assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], env3), "paired-end, 3 devices"
+
+
+def _parse_dump(cli, prefix, files, env, K="100000000"):
+    p = subprocess.run([cli, "mem", "-K", K, prefix] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(env, BWAGPU_CLI_PARSE_ONLY="2"))
+    assert p.returncode == 0, p.stderr.decode()[-1000:]
+    return b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@"))
+
+
+def test_cli_block_parallel_input_delivers_the_same_records(tmp_path):
+    """BWAGPU_CLI_PARSE_THREADS: plain FASTQ files are cut into blocks at record boundaries and parsed by a pool of threads; anything the
+    fast path declines, or a cut that was not a boundary, sends the rest of the file through the streaming reader.  The records and the
+    batch boundaries the input stage delivers (BWAGPU_CLI_PARSE_ONLY=2) must not depend on the number of threads or on where the cuts fall:
+    clean files, files that turn awkward in the middle (CRLF, multi-line records, FASTA records, quality lines that start with '@',
+    a truncated record, no newline at the end), two files in lockstep, an empty file, many small batches."""
+    prefix, g = testdata.small_index()
+    cli = _sim_cli()
+    rng = np.random.default_rng(77)
+    a = simdata._ASCII
+    r1, r2 = simdata.make_reads_pe(g, 300, seed=409)
+
+    def rec(name, bases, qual=None, comment=b""):
+        q = qual if qual is not None else bytes(33 + int(x) for x in rng.integers(0, 41, size=len(bases)))
+        return b"@" + name + (b" " + comment if comment else b"") + b"\n" + bases + b"\n+\n" + q + b"\n"
+
+    files = {}
+    clean1 = b"".join(rec(b"p%d/1" % i, a[r1[i]].tobytes(), comment=b"BC:Z:%d" % i if i % 3 == 0 else b"") for i in range(300))
+    clean2 = b"".join(rec(b"p%d/2" % i, a[r2[i][: 100 + i % 50]].tobytes()) for i in range(300))      # (other lengths than file 1: the batch boundary depends on both)
+    files["clean1"], files["clean2"] = clean1, clean2
+    # quality strings that start with '@' and with '+', names that look like bases
+    tricky = b"".join(rec(b"q%d" % i, a[r1[i]].tobytes(), qual=(b"@" if i % 2 else b"+") + b"I" * (r1.shape[1] - 1)) for i in range(120))
+    files["tricky"] = tricky
+    s = a[r1[5]].tobytes()
+    awkward = [rec(b"w0", s, comment=b"a comment").replace(b"\n", b"\r\n"),
+               b"@w1\n" + s[:60] + b"\n" + s[60:] + b"\n+w1\n" + b"5" * 100 + b"\n" + b"5" * (len(s) - 100) + b"\n\n",
+               b">w2 fasta\n" + s.lower()[:75] + b"\n" + s[75:] + b"\n",
+               rec(b"w3", s[:40] + b"-" + s[41:]),
+               rec(b"w4", s[:40] + b" " + s[41:])]
+    for k, piece in enumerate(awkward):      # 150 clean records, one awkward one, 100 more clean ones
+        files[f"mid{k}"] = clean1[: len(clean1) // 2] + piece + b"".join(rec(b"t%d" % i, a[r2[i]].tobytes()) for i in range(100))
+    files["no_final_newline"] = clean1[:-1]
+    files["truncated_qual"] = clean1[: len(clean1) // 3] + b"@bad\n" + s + b"\n+\n" + b"I" * 60 + b"\n" + clean2[: len(clean2) // 3]
+    files["empty"] = b""
+    files["one"] = rec(b"only", s)
+    paths = {}
+    for k, v in files.items():
+        paths[k] = str(tmp_path / (k + ".fq"))
+        open(paths[k], "wb").write(v)
+    base = dict(os.environ, BWAGPU_CLI_SERIALIZE="1", BWAGPU_PTAB_M="6")
+    cases = [([paths[k]], "100000000") for k in files] + [([paths["clean1"], paths["clean2"]], "100000000"), ([paths["clean1"], paths["clean2"]], "7000"),
+             ([paths["mid1"], paths["clean2"]], "20000"), ([paths["clean1"], paths["truncated_qual"]], "100000000"), ([paths["tricky"]], "3000")]
+    for fl, K in cases:
+        want = _parse_dump(cli, prefix, fl, dict(base, BWAGPU_CLI_PARSE_THREADS="0"), K)
+        if fl == [paths["clean1"]]:
+            assert want.count(b"\n") >= 300 and b"p7\tBC:Z:" not in want and b"p6\tBC:Z:6\t" in want       # (the dump is what it should be: /1 trimmed, comments kept)
+        for threads, blk in (("1", "4194304"), ("3", "700"), ("2", "1111"), ("3", "4096"), ("2", "50000")):
+            got = _parse_dump(cli, prefix, fl, dict(base, BWAGPU_CLI_PARSE_THREADS=threads, BWAGPU_CLI_PAR_BLOCK=blk), K)
+            assert got == want, f"{[os.path.basename(f) for f in fl]} -K {K}: {threads} parser threads, blocks of {blk} bytes"
+
+
+@pytest.mark.skipif(not refapi.have_ref(), reason="oracle/_ref not built")
+def test_cli_hostsim_block_parallel_input(tmp_path):
+    """The whole command line with the block-parallel input stage: same SAM as `bwa mem` (two files, many small batches; the awkward file)."""
+    prefix, g = testdata.small_index()
+    f1, f2, inter, fasta = _write_inputs(tmp_path, g, 10, seed=407)
+    weird = os.path.join(os.path.dirname(f1), "weird.fq")
+    cli = _sim_cli()
+    env = dict(os.environ, BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1", BWAGPU_PTAB_M="6", BWAGPU_CLI_PARSE_THREADS="3", BWAGPU_CLI_PAR_BLOCK="1500")
+    for args, what in ((["-K", "3000", "-t", "2", prefix, f1, f2], "two files, -K 3000"), (["-K", "100000000", "-t", "2", "-C", prefix, weird], "awkward file")):
+        assert _run(refapi.REF_BWA, args) == _run(cli, args, env), what
