@@ -161,6 +161,22 @@ def test_cli_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_gpu_block_parallel_input(tmp_path):
+    """`bwa-amd mem` with the block-parallel input stage (BWAGPU_CLI_PARSE_THREADS=4, blocks of 64 KiB so that the 20 000-pair files are
+    several hundred blocks each) on hardware: same SAM as `bwa mem`, one batch and many batches."""
+    assert refapi.have_ref(), "oracle/_ref (the compiled reference) is missing on the GPU box"
+    from bwa_amd import build as b
+    _, cli = b.build_host(verbose=False)
+    fa, g = testdata.medium_index()
+    f1, f2, inter, fasta = _write_inputs(tmp_path, g, 20000, seed=406)
+    env = dict(os.environ, BWAGPU_CLI_PARSE_THREADS="4", BWAGPU_CLI_PAR_BLOCK="65536")
+    for K in (["-K", "100000000", "-t", "4"], ["-K", "300000", "-t", "4"]):
+        assert _run(refapi.REF_BWA, K + [fa, f1, f2]) == _run(cli, K + [fa, f1, f2], env), f"paired-end, {K[1]} bases per batch"
+    weird = os.path.join(os.path.dirname(f1), "weird.fq")
+    assert _run(refapi.REF_BWA, ["-C", fa, weird]) == _run(cli, ["-C", fa, weird], env), "awkward file"
+
+
+@pytest.mark.gpu
 def test_cli_gpu_two_devices(tmp_path):
     """BWAGPU_DEVICES on hardware: when the box has at least two GPUs, `bwa-amd mem` with every batch split over devices
     0 and 1 (index copied device to device with hipMemcpyPeer, bwagpu_clone_to_device) must reproduce `bwa mem` -- paired-end (one
