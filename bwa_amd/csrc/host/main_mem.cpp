@@ -858,13 +858,13 @@ int main(int argc, char *argv[])
 		for (int i = 1; i < n_dev; ++i) { bwagpu_t *h2 = nullptr; int rc = bwagpu_clone(base, &h2); if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s\n", "main_mem", bwagpu_strerror(rc)); return 1; } bwagpu_set_taps(h2, 0); handles[(size_t)i].push_back(h2); }
 	}
 	if (g_verbose >= 3 && dev_ids.size() > 1) fprintf(stderr, "[M::%s] index copied to %zu devices; batches are split over them\n", "main_mem", dev_ids.size());
-	Chan to_dev(2), to_out(2);
+	Chan to_enc(1), to_dev(2), to_out(2);
 	// text arenas and base arrays of finished batches are handed back to the reader: re-using them saves a few hundred MB of
 	// first-touch page faults per batch on the one thread that paces the pipeline
 	std::mutex pool_m; std::vector<Batch> batch_pool; std::vector<std::vector<uint8_t>> flat_pool; std::vector<std::vector<std::string>> out_pool;   // (and the chunk strings of written batches)
 	std::mutex dm; std::condition_variable dcv; std::map<long, WorkP> done; long next_fin = 0;   // device -> finalize, re-ordered
 	std::atomic<long> n_works(-1), n_reads_total(0);
-	double busy_read = 0, busy_fin = 0, busy_write = 0; std::atomic<long> busy_dev_us(0);   // per-stage busy time (-v 3 summary)
+	double busy_read = 0, busy_enc = 0, busy_fin = 0, busy_write = 0; std::atomic<long> busy_dev_us(0);   // per-stage busy time (-v 3 summary)
 
 	// watchdog (BWAGPU_CLI_WATCHDOG=<seconds>): if no stage makes progress for that long, say where everything is and give up
 	std::atomic<long> progress(0); std::atomic<int> dev_no[16]; std::atomic<bool> all_done(false);
@@ -914,9 +914,27 @@ int main(int argc, char *argv[])
 			}
 			n_processed += n; ++no; ++progress;
 			busy_read += now_s() - tr;
-			to_dev.push(std::move(w));
+			to_enc.push(std::move(w));
 		}
 		n_works = no; n_reads_total = (long)n_processed;
+		to_enc.close();
+	});
+
+	// stage 1b: base codes (nst_nt4_table) of the batch's reads, flat.  A stage of its own: on the reader's thread it slowed the one stage
+	// nothing can hide (round 2), on the device threads (round 3) its 27 ms per batch were time a handle's stream sat idle -- and with
+	// three handles sharing one GPU the device stage is what bounds FASTQ -> SAM.
+	std::thread encoder([&] {
+		WorkP w;
+		while (to_enc.pop(w)) {
+			const double te = now_s();
+			for (Sub &u : w->subs) {
+				{ std::lock_guard<std::mutex> l(pool_m); if (!flat_pool.empty()) { u.flat = std::move(flat_pool.back()); flat_pool.pop_back(); } }
+				encode_sub(w->in, u);
+			}
+			busy_enc += now_s() - te;
+			++progress;
+			to_dev.push(std::move(w));
+		}
 		to_dev.close();
 		{ std::lock_guard<std::mutex> l(dm); dcv.notify_all(); }
 	});
@@ -931,12 +949,6 @@ int main(int argc, char *argv[])
 			{ std::unique_lock<std::mutex> l(dm); dcv.wait(l, [&] { return w->no - next_fin <= (long)n_dev; }); }   // do not run ahead of the host
 			if (d < 16) dev_no[d] = (int)w->no;
 			++progress;
-			const double te = now_s();
-			for (Sub &u : w->subs) {   // 2-bit encoding here rather than on the reader thread, which paces the pipeline
-				{ std::lock_guard<std::mutex> l(pool_m); if (!flat_pool.empty()) { u.flat = std::move(flat_pool.back()); flat_pool.pop_back(); } }
-				encode_sub(w->in, u);
-			}
-			busy_dev_us += (long)((now_s() - te) * 1e6);
 			for (Sub &u : w->subs) { device_sub(handles[d], u, ref, pes0); ++progress; busy_dev_us += (long)(u.t_dev * 1e6); }
 			std::lock_guard<std::mutex> l(dm);
 			const long no = w->no;
@@ -974,12 +986,13 @@ int main(int argc, char *argv[])
 		{ std::lock_guard<std::mutex> l(dm); ++next_fin; ++progress; dcv.notify_all(); }
 	}
 	reader.join();
+	encoder.join();
 	for (auto &t : devs) t.join();
 	to_out.close();
 	writer.join();
 	all_done = true; watchdog.join();
 	if (g_verbose >= 3) { const double dt = now_s() - t_start; fprintf(stderr, "[M::%s] %ld reads in %.3f sec after the index was loaded: %.0f reads/s\n", "main_mem", n_reads_total.load(), dt, dt > 0 ? n_reads_total.load() / dt : 0.);
-		fprintf(stderr, "[M::%s] stage busy time: read %.3f s, encode+device %.3f s (over %d handles), finalize %.3f s, write %.3f s\n", "main_mem", busy_read, busy_dev_us.load() * 1e-6, n_dev, busy_fin, busy_write); }
+		fprintf(stderr, "[M::%s] stage busy time: read %.3f s, encode %.3f s, device %.3f s (over %d handles), finalize %.3f s, write %.3f s\n", "main_mem", busy_read, busy_enc, busy_dev_us.load() * 1e-6, n_dev, busy_fin, busy_write); }
 	fflush(stdout);
 	for (auto &slot : handles) for (bwagpu_t *hh : slot) if (hh != gpu) bwagpu_destroy(hh);
 	bwagpu_destroy(gpu);
