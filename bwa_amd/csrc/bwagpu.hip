@@ -177,6 +177,7 @@ ResultPool g_results;
 }
 static void *result_alloc(size_t bytes) { return g_results.get(bytes); }
 extern "C" void bwagpu_free(void *p) { g_results.put(p); }
+extern "C" void *bwagpu_alloc_host(size_t bytes) { return g_results.get(bytes); }
 
 static int upload(bwagpu_t *h, DevBuf &b, const void *src, size_t bytes)
 {

@@ -29,6 +29,13 @@ DEVFN void wave_sync()
 #define DPP_WAVE_SHR1 0x138
 
 DEVFN int imax(int a, int b) { return a > b ? a : b; }
+// Sums and differences over columns a lane merely reads along with the live ones (the {H,E} slots past the band's end hold whatever the
+// LDS held before): the result is discarded, but it must be a defined one -- two's-complement wrap-around, the instruction the signed
+// forms compile to anyway (found by UBSan on the mock runtime in the multi-pass rows: stale slots of INT_MIN; the code object is the same
+// instruction for instruction.  The single-pass and two-column rows keep the signed forms: there the unsigned ones change the hot rows'
+// code, and no run has met such a slot in them).
+DEVFN int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+DEVFN int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
 // Inclusive prefix maximum over the 64 lanes; lane 63 ends up with the wave maximum.  `old` is INT_MIN, the identity
 // of signed max, which lets the compiler fold each mov_dpp + max pair into a single v_max_i32_dpp.
 #define I32_MIN ((int)0x80000000)
@@ -319,13 +326,13 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 				const int bnd_next = eh[EHI(b + 64)].x;             // next pass's diagonal for its lane 0, before lane 63 overwrites it
 				if (b != beg && lane == 0) old.x = bnd;
 				wave_sync();
-				const int M = old.x ? old.x + sc : 0;          // ksw.c:469: a dead diagonal cell stays dead
+				const int M = old.x ? wadd(old.x, sc) : 0;     // ksw.c:469: a dead diagonal cell stays dead
 				const int a = act ? imax(M - oe_ins, 0) + j * e_ins : W_NEG;
 				const int inc = wave_incl_scan_max(a);
 				const int exc = imax(wave_shift_up1(inc, W_NEG), carry);
 				const int f = j == beg ? 0 : exc - (j - 1) * e_ins;       // F(i,j): best insertion ending left of column j
 				const int h = imax(imax(M, old.y), f);                    // H(i,j) = max(M, E, F), ksw.c:470-471
-				const int e_new = imax(imax(old.y - e_del, M - oe_del), 0); // E(i+1,j), ksw.c:475-479
+				const int e_new = imax(imax(wsub(old.y, e_del), wsub(M, oe_del)), 0); // E(i+1,j), ksw.c:475-479
 				if (act) {
 					eh[EHI(j)].y = e_new;
 					eh[EHI(j + 1)].x = h;                                  // becomes the diagonal of column j+1 in row i+1

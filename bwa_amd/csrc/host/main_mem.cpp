@@ -443,9 +443,26 @@ static const Nt4 g_nt4;
 // ---- batches flow through a four-stage pipeline: read+encode | device (hot path) | finalize (host threads) | write -------------
 // (the reference overlaps input, compute and output the same way with kt_pipeline, kthread.c:119; here the compute step is
 // split once more so that the GPU works on batch i+1 while the host cores turn batch i's regions into SAM text)
+// base codes of a batch: page-locked (bwagpu_alloc_host) so that the upload is one DMA; kept from batch to batch
+struct HostBuf {
+	uint8_t *p = nullptr; size_t cap = 0;
+	HostBuf() = default;
+	HostBuf(const HostBuf&) = delete; HostBuf &operator=(const HostBuf&) = delete;
+	HostBuf(HostBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+	HostBuf &operator=(HostBuf &&o) noexcept { if (this != &o) { bwagpu_free(p); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
+	~HostBuf() { bwagpu_free(p); }
+	uint8_t *data() const { return p; }
+	void need(size_t n) {
+		if (n <= cap) return;
+		bwagpu_free(p);
+		cap = n + n / 8;
+		p = (uint8_t*)bwagpu_alloc_host(cap);
+		if (!p) { fprintf(stderr, "[E::%s] out of memory\n", "mem_process_seqs"); exit(EXIT_FAILURE); }
+	}
+};
 struct Sub {      // one mem_process_seqs call (bwamem.c:1235-1264) on the reads `idx` of its batch
 	std::vector<int> idx; bwagpu_opt_t opt; int64_t n_processed = 0;
-	std::vector<uint8_t> flat; std::vector<int64_t> off; std::vector<int32_t> counts;
+	HostBuf flat; std::vector<int64_t> off; std::vector<int32_t> counts;
 	bwagpu_alnreg_t *all = nullptr; int64_t tot = 0;
 	bwagpu_cigar_t *cigs = nullptr;           // device-side global alignments of the regions (bwagpu_batch_cigars)
 	uint32_t *cig_ops = nullptr;              // ... and the operation array its records with more than 6 operations point into
@@ -471,7 +488,7 @@ static void encode_sub(const Batch &in, Sub &u)
 	const int n = (int)u.idx.size();
 	u.off.assign((size_t)n + 1, 0);
 	for (int i = 0; i < n; ++i) u.off[i + 1] = u.off[i] + (int64_t)in.seqs[u.idx[i]].l_seq;
-	u.flat.resize((size_t)u.off[n] + 1);
+	u.flat.need((size_t)u.off[n] + 1);
 	// (100 MB of table look-ups per batch: a tenth of a second on one thread, inside the stage that feeds the device)
 	parallel_for(u.opt.n_threads < 4 ? u.opt.n_threads : 4, n, [&](long i) {
 		const Seq &q = in.seqs[u.idx[i]];
@@ -861,7 +878,7 @@ int main(int argc, char *argv[])
 	Chan to_enc(1), to_dev(2), to_out(2);
 	// text arenas and base arrays of finished batches are handed back to the reader: re-using them saves a few hundred MB of
 	// first-touch page faults per batch on the one thread that paces the pipeline
-	std::mutex pool_m; std::vector<Batch> batch_pool; std::vector<std::vector<uint8_t>> flat_pool; std::vector<std::vector<std::string>> out_pool;   // (and the chunk strings of written batches)
+	std::mutex pool_m; std::vector<Batch> batch_pool; std::vector<HostBuf> flat_pool; std::vector<std::vector<std::string>> out_pool;   // (and the chunk strings of written batches)
 	std::mutex dm; std::condition_variable dcv; std::map<long, WorkP> done; long next_fin = 0;   // device -> finalize, re-ordered
 	std::atomic<long> n_works(-1), n_reads_total(0);
 	double busy_read = 0, busy_enc = 0, busy_fin = 0, busy_write = 0; std::atomic<long> busy_dev_us(0);   // per-stage busy time (-v 3 summary)

@@ -322,6 +322,10 @@ int bwagpu_align_bseq(bwagpu_t *h, const bwagpu_opt_t *opt, int n, bwagpu_bseq1_
  *   BWAGPU_PINNED_RESULTS=0 turns that off); *n_regs_out = total. */
 int bwagpu_align_flat(bwagpu_t *h, const bwagpu_opt_t *opt, int n, const uint8_t *seqs, const int64_t *off,
 					  int32_t *counts, bwagpu_alnreg_t **regs_out, int64_t *n_regs_out);
+/* A host buffer for a batch's base codes (what bwagpu_batch_upload reads): page-locked when the runtime grants it, from the same pool as
+ * the result arrays, so that the upload is one DMA instead of a staged copy; plain memory otherwise.  Release with bwagpu_free.
+ * (No counterpart in the reference: bseq1_t::seq is malloc'ed by bseq_read, bwa.c:79-112.) */
+void *bwagpu_alloc_host(size_t bytes);
 void bwagpu_free(void *p);   /* releases any array an entry point of this library returned through an out-pointer (thread-safe) */
 
 /* Split form for callers that overlap transfers with compute, and for measuring the device path with the batch
