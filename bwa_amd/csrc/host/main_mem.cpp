@@ -440,6 +440,48 @@ struct Nt4 {   // nst_nt4_table (bntseq.c:46-63)
 };
 static const Nt4 g_nt4;
 
+// nst_nt4_table over a run of bases.  32 bytes per step where the CPU has AVX2: A/C/G/T in either case are found by comparing the byte
+// with bit 5 cleared, '-' by itself, everything else is 4 -- the same values as the table (checked for all 256 bytes at start-up).
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) static void nt4_encode_avx2(const unsigned char *src, uint8_t *d, int n)
+{
+	const __m256i up = _mm256_set1_epi8((char)0xDF), four = _mm256_set1_epi8(4);
+	const __m256i cA = _mm256_set1_epi8('A'), cC = _mm256_set1_epi8('C'), cG = _mm256_set1_epi8('G'), cT = _mm256_set1_epi8('T'), cD = _mm256_set1_epi8('-');
+	int j = 0;
+	for (; j + 32 <= n; j += 32) {
+		const __m256i c = _mm256_loadu_si256((const __m256i*)(src + j)), u = _mm256_and_si256(c, up);
+		// 4 minus: 4 for A, 3 for C, 2 for G, 1 for T (the compare masks are 0xFF = -1, ANDed down to the amount), plus 1 for '-'
+		__m256i r = four;
+		r = _mm256_sub_epi8(r, _mm256_and_si256(_mm256_cmpeq_epi8(u, cA), four));
+		r = _mm256_sub_epi8(r, _mm256_and_si256(_mm256_cmpeq_epi8(u, cC), _mm256_set1_epi8(3)));
+		r = _mm256_sub_epi8(r, _mm256_and_si256(_mm256_cmpeq_epi8(u, cG), _mm256_set1_epi8(2)));
+		r = _mm256_sub_epi8(r, _mm256_and_si256(_mm256_cmpeq_epi8(u, cT), _mm256_set1_epi8(1)));
+		r = _mm256_sub_epi8(r, _mm256_cmpeq_epi8(c, cD));                       // (minus -1)
+		_mm256_storeu_si256((__m256i*)(d + j), r);
+	}
+	for (; j < n; ++j) d[j] = g_nt4.t[src[j]];
+}
+static bool nt4_avx2_ok()
+{	// the vector form is used only if this CPU has AVX2 and the form reproduces the table for every byte value
+	if (!__builtin_cpu_supports("avx2")) return false;
+	unsigned char in[256]; uint8_t out[256];
+	for (int i = 0; i < 256; ++i) in[i] = (unsigned char)i;
+	nt4_encode_avx2(in, out, 256);
+	for (int i = 0; i < 256; ++i) if (out[i] != g_nt4.t[i]) return false;
+	return true;
+}
+static const bool g_nt4_avx2 = !getenv("BWAGPU_CLI_NO_AVX2") && nt4_avx2_ok();
+#else
+static const bool g_nt4_avx2 = false;
+static void nt4_encode_avx2(const unsigned char*, uint8_t*, int) {}
+#endif
+static inline void nt4_encode(const unsigned char *src, uint8_t *d, int n)
+{
+	if (g_nt4_avx2) nt4_encode_avx2(src, d, n);
+	else for (int j = 0; j < n; ++j) d[j] = g_nt4.t[src[j]];
+}
+
 // ---- batches flow through a four-stage pipeline: read+encode | device (hot path) | finalize (host threads) | write -------------
 // (the reference overlaps input, compute and output the same way with kt_pipeline, kthread.c:119; here the compute step is
 // split once more so that the GPU works on batch i+1 while the host cores turn batch i's regions into SAM text)
@@ -489,11 +531,10 @@ static void encode_sub(const Batch &in, Sub &u)
 	u.off.assign((size_t)n + 1, 0);
 	for (int i = 0; i < n; ++i) u.off[i + 1] = u.off[i] + (int64_t)in.seqs[u.idx[i]].l_seq;
 	u.flat.need((size_t)u.off[n] + 1);
-	// (100 MB of table look-ups per batch: a tenth of a second on one thread, inside the stage that feeds the device)
 	parallel_for(u.opt.n_threads < 4 ? u.opt.n_threads : 4, n, [&](long i) {
 		const Seq &q = in.seqs[u.idx[i]];
 		const unsigned char *src = (const unsigned char*)in.T(q) + q.seq; uint8_t *d = u.flat.data() + u.off[i];
-		for (int j = 0; j < q.l_seq; ++j) d[j] = g_nt4.t[src[j]];
+		nt4_encode(src, d, q.l_seq);
 	});
 	u.counts.assign((size_t)n, 0);
 }
@@ -844,14 +885,23 @@ int main(int argc, char *argv[])
 	if (getenv("BWAGPU_CLI_PARSE_ONLY")) {   // diagnostics: speed of the input stage alone
 		Batch b; long n = 0, bp = 0;
 		const bool dump = atoi(getenv("BWAGPU_CLI_PARSE_ONLY")) == 2;      // (tests: what the input stage delivers, batch by batch)
+		const bool enc = atoi(getenv("BWAGPU_CLI_PARSE_ONLY")) == 3;       // (and the encoding stage: seconds, and a digest of the codes)
+		double t_enc = 0; uint64_t dig = 1469598103934665603ull;
 		while (read_batch(r1, pr2, chunk, b)) {
 			n += (long)b.seqs.size(); for (auto &q : b.seqs) bp += q.l_seq;
+			if (enc) {
+				Sub u; u.idx.resize(b.seqs.size()); for (size_t i = 0; i < b.seqs.size(); ++i) u.idx[i] = (int)i;
+				u.opt = opt;
+				const double te = now_s(); encode_sub(b, u); t_enc += now_s() - te;
+				for (int64_t i = 0; i < u.off[b.seqs.size()]; ++i) dig = (dig ^ u.flat.data()[i]) * 1099511628211ull;
+			}
 			if (dump) {
 				printf("#batch %zu\n", b.seqs.size());
 				for (auto &q : b.seqs) { const char *T = b.T(q); printf("%s\t%s\t%s\t%s\n", T + q.name, q.has_comment ? T + q.comment : "-", T + q.seq, q.has_qual ? T + q.qual : "-"); }
 			}
 		}
 		fprintf(stderr, "[M::%s] parsed %ld records (%ld bp) in %.3f s\n", "main_mem", n, bp, now_s() - t_start);
+		if (enc) fprintf(stderr, "[M::%s] encoded in %.3f s (%s), digest %016llx\n", "main_mem", t_enc, g_nt4_avx2 ? "AVX2" : "table", (unsigned long long)dig);
 		return 0;
 	}
 	if (getenv("BWAGPU_CLI_SERIALIZE")) g_dev_serialize = atoi(getenv("BWAGPU_CLI_SERIALIZE")) != 0;
