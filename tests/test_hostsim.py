@@ -445,6 +445,22 @@ def test_hostsim_pooled_result_buffers(sim, monkeypatch):
         c, r = sim.align(opt, seqs, off)
         cg, ops = sim.cigars(opt), sim.cigar_ops()
         assert np.array_equal(c, c0) and r.tobytes() == r0.tobytes() and cg.tobytes() == g0.tobytes() and ops.tobytes() == o0.tobytes()
+    # bwagpu_alloc_host: input buffers from the same pool -- a block comes back after bwagpu_free, and a batch whose base codes lie in one
+    # aligns like any other
+    import ctypes as C
+    L = sim.L
+    L.bwagpu_alloc_host.restype = C.c_void_p; L.bwagpu_alloc_host.argtypes = [C.c_size_t]; L.bwagpu_free.argtypes = [C.c_void_p]
+    p1 = L.bwagpu_alloc_host(3 << 20)
+    assert p1
+    L.bwagpu_free(p1)
+    p2 = L.bwagpu_alloc_host(3 << 20)
+    assert p2 == p1, "a freed block of the pool is handed out again"
+    seqs, off = sets[0]
+    C.memmove(p2, seqs.ctypes.data, seqs.nbytes)
+    pinned = np.ctypeslib.as_array(C.cast(p2, C.POINTER(C.c_uint8)), shape=(seqs.nbytes,))
+    c, r = sim.align(opt, pinned, off)
+    assert np.array_equal(c, want[0][0]) and r.tobytes() == want[0][1].tobytes()
+    L.bwagpu_free(p2)
 
 
 def test_hostsim_long_segment_cigars(sim, monkeypatch):
