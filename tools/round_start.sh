@@ -16,7 +16,9 @@ cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag; mkdir -p $out
 timeout 900 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1 || { tail -30 $out/pytest_gpu.log; echo "GPU SUITE FAILED"; exit 1; }
 tail -3 $out/pytest_gpu.log
-timeout 700 python bench.py > $out/bench.json 2> $out/bench.log; echo "bench rc $?"; tail -c 800 $out/bench.json; echo
+# (--long-sample 2000: the long-read parity prefix and its CPU baseline on 2000 reads instead of the default 128 -- ~10 s of reference time,
+#  as the measurement contract asks; make it the default once it has passed here)
+timeout 800 python bench.py --long-sample 2000 > $out/bench.json 2> $out/bench.log; echo "bench rc $?"; tail -c 800 $out/bench.json; echo
 C=/tmp/bwa_amd_bench
 P=$(ls $C/*.bwt 2>/dev/null | head -1); P=${P%.bwt}
 if [ -n "$P" ] && [ $# -gt 0 ]; then
