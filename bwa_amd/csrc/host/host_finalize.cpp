@@ -378,6 +378,43 @@ static void add_cigar(const bwagpu_opt_t &opt, const std::vector<uint32_t> &ciga
 	} else s += '*';
 }
 
+// SEQ and QUAL columns: letters of the base codes ("ACGTN"[c]; code 5 gives the literal's NUL, as in the reference's table), reversed and
+// complemented for a reverse-strand record, qualities reversed.  Sixteen bytes per step with SSSE3 byte shuffles where the CPU has them.
+static void bases_fwd(const uint8_t *s, int n, char *d);
+static void bases_rc(const uint8_t *s, int n, char *d);
+static void bytes_rev(const char *s, int n, char *d);
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("ssse3"))) static void bases_fwd_v(const uint8_t *s, int n, char *d)
+{
+	const __m128i lut = _mm_setr_epi8('A', 'C', 'G', 'T', 'N', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+	int i = 0;
+	for (; i + 16 <= n; i += 16) _mm_storeu_si128((__m128i*)(d + i), _mm_shuffle_epi8(lut, _mm_loadu_si128((const __m128i*)(s + i))));
+	for (; i < n; ++i) d[i] = "ACGTN"[s[i]];
+}
+__attribute__((target("ssse3"))) static void bases_rc_v(const uint8_t *s, int n, char *d)
+{
+	const __m128i lut = _mm_setr_epi8('T', 'G', 'C', 'A', 'N', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), rev = _mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+	int k = 0;
+	for (; k + 16 <= n; k += 16) _mm_storeu_si128((__m128i*)(d + k), _mm_shuffle_epi8(lut, _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(s + n - 16 - k)), rev)));
+	for (; k < n; ++k) d[k] = "TGCAN"[s[n - 1 - k]];
+}
+__attribute__((target("ssse3"))) static void bytes_rev_v(const char *s, int n, char *d)
+{
+	const __m128i rev = _mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+	int k = 0;
+	for (; k + 16 <= n; k += 16) _mm_storeu_si128((__m128i*)(d + k), _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(s + n - 16 - k)), rev));
+	for (; k < n; ++k) d[k] = s[n - 1 - k];
+}
+static const bool g_ssse3 = __builtin_cpu_supports("ssse3") && !getenv("BWAGPU_CLI_NO_AVX2");
+#else
+static const bool g_ssse3 = false;
+static void bases_fwd_v(const uint8_t*, int, char*) {} static void bases_rc_v(const uint8_t*, int, char*) {} static void bytes_rev_v(const char*, int, char*) {}
+#endif
+static void bases_fwd(const uint8_t *s, int n, char *d) { if (g_ssse3) bases_fwd_v(s, n, d); else for (int i = 0; i < n; ++i) d[i] = "ACGTN"[s[i]]; }
+static void bases_rc(const uint8_t *s, int n, char *d) { if (g_ssse3) bases_rc_v(s, n, d); else for (int k = 0; k < n; ++k) d[k] = "TGCAN"[s[n - 1 - k]]; }
+static void bytes_rev(const char *s, int n, char *d) { if (g_ssse3) bytes_rev_v(s, n, d); else for (int k = 0; k < n; ++k) d[k] = s[n - 1 - k]; }
+
 void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, SamText &str, const Read &s, const std::vector<Aln> &list, int which, const Aln *m_, const char *rg_id)
 {
 	// The reference works on copies of the record and of the mate (bwamem.c:859-872) because it borrows coordinates from the
@@ -427,7 +464,7 @@ void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, SamText &str, const Re
 				if (((*p.cigar)[0] & 0xf) == 4 || ((*p.cigar)[0] & 0xf) == 3) qb += (*p.cigar)[0] >> 4;
 				if ((p.cigar->back() & 0xf) == 4 || (p.cigar->back() & 0xf) == 3) qe -= p.cigar->back() >> 4;
 			}
-			{ const size_t k = (size_t)(qe > qb ? qe - qb : 0); char *d = str.need(k); for (int i = qb; i < qe; ++i) *d++ = "ACGTN"[s.seq[i]]; str.n += k; }   // (written in place: a checked append per base was a fifth of the stage)
+			{ const size_t k = (size_t)(qe > qb ? qe - qb : 0); bases_fwd(s.seq + qb, (int)k, str.need(k)); str.n += k; }   // (written in place: a checked append per base was a fifth of the stage)
 			str += '\t';
 			if (s.qual) str.append(s.qual + qb, s.qual + qe); else str += '*';
 		} else {
@@ -435,9 +472,9 @@ void aln2sam(const bwagpu_opt_t &opt, const RefSeqs &ref, SamText &str, const Re
 				if (((*p.cigar)[0] & 0xf) == 4 || ((*p.cigar)[0] & 0xf) == 3) qe -= (*p.cigar)[0] >> 4;
 				if ((p.cigar->back() & 0xf) == 4 || (p.cigar->back() & 0xf) == 3) qb += p.cigar->back() >> 4;
 			}
-			{ const size_t k = (size_t)(qe > qb ? qe - qb : 0); char *d = str.need(k); for (int i = qe - 1; i >= qb; --i) *d++ = "TGCAN"[s.seq[i]]; str.n += k; }
+			{ const size_t k = (size_t)(qe > qb ? qe - qb : 0); bases_rc(s.seq + qb, (int)k, str.need(k)); str.n += k; }
 			str += '\t';
-			if (s.qual) { const size_t k = (size_t)(qe > qb ? qe - qb : 0); char *d = str.need(k); for (int i = qe - 1; i >= qb; --i) *d++ = s.qual[i]; str.n += k; } else str += '*';
+			if (s.qual) { const size_t k = (size_t)(qe > qb ? qe - qb : 0); bytes_rev(s.qual + qb, (int)k, str.need(k)); str.n += k; } else str += '*';
 		}
 	}
 	if (!p.cigar->empty()) { lit(str, "\tNM:i:"); put_int(str, p.NM); lit(str, "\tMD:Z:"); str += *p.md; }
