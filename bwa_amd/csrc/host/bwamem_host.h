@@ -104,7 +104,7 @@ void pestat_flat(const bwagpu_opt_t &opt, int64_t l_pac, int n, const bwagpu_aln
 void attach_matesw(int n, Read *reads, const bwagpu_matesw_t *recs, int64_t n_recs, std::vector<bwagpu_matesw_t> &sorted);
 int64_t host_matesw_records(const bwagpu_opt_t &opt, const RefSeqs &ref, int n, const uint8_t *seqs, const int64_t *off, const bwagpu_alnreg_t *all, const int64_t *roff,
 							const Pestat pes[4], bwagpu_matesw_t *out, int64_t cap);   // == bwagpu_batch_matesw, on the host   // bwamem_pair.c:72-135
-int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uint64_t id, const Read s[2], Regs a[2], SamText out[2], const char *rg_id);   // bwamem_pair.c:276-419
+int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uint64_t id, const Read s[2], Regs a[2], SamText *const out[2] /* may be one buffer twice: the first read's records all precede the second's */, const char *rg_id);   // bwamem_pair.c:276-419
 
 // DP kernels of the finalize stage
 int ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del, int o_ins, int e_ins, int w, std::vector<uint32_t> *cigar);   // ksw.c:540-642

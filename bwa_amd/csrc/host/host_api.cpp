@@ -26,7 +26,8 @@ void finalize_batch(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t n_proce
 			a[0].assign(all + roff[i << 1], all + roff[(i << 1) + 1]); a[1].assign(all + roff[(i << 1) + 1], all + roff[(i << 1) + 2]);
 			thread_local SamText out[2];
 			out[0].clear(); out[1].clear();
-			sam_pe(opt, ref, pes, (uint64_t)((n_processed >> 1) + i), &reads[i << 1], a, out, rg_id);
+			SamText *each[2] = { &out[0], &out[1] };
+			sam_pe(opt, ref, pes, (uint64_t)((n_processed >> 1) + i), &reads[i << 1], a, each, rg_id);
 			sam[i << 1].assign(out[0].data(), out[0].size()); sam[i << 1 | 1].assign(out[1].data(), out[1].size());
 		});
 	} else {
@@ -59,19 +60,38 @@ void finalize_batch_chunks(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t 
 	auto put = [](std::string &dst, const SamText &s) { dst.append(s.data(), strnlen(s.data(), s.size())); };
 	std::atomic<long> next(0);
 	auto work = [&]() {
-		Regs a[2]; SamText out[2];
+		Regs a[2]; SamText out[2], buf;
 		for (;;) {
 			const long c = next.fetch_add(1);
 			if (c >= n_chunks) break;
 			const int lo = (int)(c * chunk), hi = lo + chunk < n ? lo + chunk : n;
 			std::string &dst = text[(size_t)c];
+			// The chunk's records are written one after the other into one buffer that stays in this thread's cache and reach the string in one
+			// copy.  Only if some record holds a NUL (a base of code 5) is the chunk redone read by read, each read's text cut at its first NUL.
+			buf.clear();
+			if (pe) {
+				SamText *both[2] = { &buf, &buf };          // (mem_sam_pe emits all records of the first read, then all of the second)
+				for (int i = lo; i + 1 < hi; i += 2) {
+					a[0].assign(all + roff[i], all + roff[i + 1]); a[1].assign(all + roff[i + 1], all + roff[i + 2]);
+					sam_pe(opt, ref, pes, (uint64_t)((n_processed + i) >> 1), &reads[i], a, both, rg_id);
+				}
+			} else {
+				for (int i = lo; i < hi; ++i) {
+					a[0].assign(all + roff[i], all + roff[i + 1]);
+					mark_primary_se(opt, a[0], n_processed + i);
+					if (opt.flag & F_PRIMARY5) reorder_primary5(opt.T, a[0]);
+					reg2sam(opt, ref, buf, reads[i], a[0], 0, 0, rg_id);
+				}
+			}
+			if (!memchr(buf.data(), 0, buf.size())) { dst.assign(buf.data(), buf.size()); continue; }
 			dst.clear();
 			if (dst.capacity() < (size_t)(hi - lo) * 720) dst.reserve((size_t)(hi - lo) * 720);
 			if (pe) {
+				SamText *each[2] = { &out[0], &out[1] };
 				for (int i = lo; i + 1 < hi; i += 2) {
 					a[0].assign(all + roff[i], all + roff[i + 1]); a[1].assign(all + roff[i + 1], all + roff[i + 2]);
 					out[0].clear(); out[1].clear();
-					sam_pe(opt, ref, pes, (uint64_t)((n_processed + i) >> 1), &reads[i], a, out, rg_id);
+					sam_pe(opt, ref, pes, (uint64_t)((n_processed + i) >> 1), &reads[i], a, each, rg_id);
 					put(dst, out[0]); put(dst, out[1]);
 				}
 			} else {

@@ -335,11 +335,12 @@ bool gen_alt_for_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Regs &av,
 static inline int raw_mapq(int diff, int a) { return (int)(6.02 * diff / a + .499); }
 
 // ---- mem_sam_pe (bwamem_pair.c:276-419) ------------------------------------------------------------------------------------
-int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uint64_t id, const Read s[2], Regs a[2], SamText out[2], const char *rg_id)
+int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uint64_t id, const Read s[2], Regs a[2], SamText *const outp[2], const char *rg_id)
 {
 	int n = 0, z[2] = {0, 0}, o, subo, n_sub, extra_flag = 1, n_pri[2];
 	Aln h[2];
-	for (int i = 0; i < 2; ++i) out[i].reserve(out[i].size() + 2 * (size_t)s[i].l_seq + 320);      // one allocation instead of the five a growing string makes
+	SamText &out0 = *outp[0], &out1 = *outp[1];
+	out0.reserve(out0.size() + 2 * (size_t)s[0].l_seq + 320); out1.reserve(out1.size() + 2 * (size_t)s[1].l_seq + 320);      // one allocation instead of the five a growing string makes
 	if (!(opt.flag & F_NO_RESCUE)) {   // mate rescue from the best hits of each end
 		thread_local Regs b[2];
 		b[0].clear(); b[1].clear();
@@ -412,8 +413,8 @@ int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uin
 						aa[i].push_back(g);
 					}
 				}
-				for (int i = 0; i < (int)aa[0].size(); ++i) aln2sam(opt, ref, out[0], s[0], aa[0], i, &h[1], rg_id);
-				for (int i = 0; i < (int)aa[1].size(); ++i) aln2sam(opt, ref, out[1], s[1], aa[1], i, &h[0], rg_id);
+				for (int i = 0; i < (int)aa[0].size(); ++i) aln2sam(opt, ref, out0, s[0], aa[0], i, &h[1], rg_id);
+				for (int i = 0; i < (int)aa[1].size(); ++i) aln2sam(opt, ref, out1, s[1], aa[1], i, &h[0], rg_id);
 				return n;
 			}
 		} else no_pairing = true;
@@ -432,8 +433,8 @@ int sam_pe(const bwagpu_opt_t &opt, const RefSeqs &ref, const Pestat pes[4], uin
 		int d = infer_dir(ref.l_pac, a[0][0].rb, a[1][0].rb, &dist);
 		if (!pes[d].failed && dist >= pes[d].low && dist <= pes[d].high) extra_flag |= 2;
 	}
-	reg2sam(opt, ref, out[0], s[0], a[0], 0x41 | extra_flag, &h[1], rg_id);
-	reg2sam(opt, ref, out[1], s[1], a[1], 0x81 | extra_flag, &h[0], rg_id);
+	reg2sam(opt, ref, out0, s[0], a[0], 0x41 | extra_flag, &h[1], rg_id);
+	reg2sam(opt, ref, out1, s[1], a[1], 0x81 | extra_flag, &h[0], rg_id);
 	return n;
 }
 
