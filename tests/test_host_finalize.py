@@ -207,3 +207,25 @@ def test_ksw_align2_fuzz():
         H.bwamem_host_ksw_align2(qlen, q.ctypes.data_as(C.c_void_p), tlen, t.ctypes.data_as(C.c_void_p), C.cast(o.mat, C.c_void_p), o.o_del, o.e_del, o.o_ins, o.e_ins, xtra, out)
         want = [a.score, a.te, a.qe, a.score2, a.te2, a.tb, a.qb]
         assert want == list(out), f"case {it}: qlen {qlen} tlen {tlen} xtra {xtra:#x}: reference {want} host {list(out)}"
+
+
+def test_paired_end_reads_with_a_base_of_code_5(pair):
+    """A '-' among the bases is code 5 (nst_nt4_table), whose letter in the SAM record is the NUL that ends "ACGTN": the reference fputs() a
+    read's records, so that read's text stops there.  The chunked finalize writes a chunk's records into one buffer and falls back to
+    read-by-read text only for chunks that hold such a read: same bytes as the reference, for either mate, both mates and neither."""
+    ref, host, g = pair
+    opt = default_opt(); opt.flag |= 0x2
+    reads = _interleave(*simdata.make_reads_pe(g, 600, seed=331))
+    rng = np.random.default_rng(332)
+    for i in rng.choice(reads.shape[0], size=40, replace=False):
+        reads[i, int(rng.integers(0, reads.shape[1]))] = 5
+    reads[100, 7] = 5; reads[101, 140] = 5                     # (both mates of one pair)
+    seqs, off = testdata.flat(reads)
+    names = [f"q{i >> 1}" for i in range(reads.shape[0])]
+    quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
+    counts, regs = ref.align(opt, seqs, off)
+    want = ref.regs2sam(opt, names, seqs.tobytes(), quals, off, counts, regs)      # (the reference's worker2 on the same regions and base codes)
+    for threads in (1, 4):
+        got = host.regs2sam(opt, names, seqs, quals, off, counts, regs, n_threads=threads)
+        assert got == want, f"{threads} thread(s)"
+    assert want.count(b"\n") < 2 * 600 and b"\0" not in want    # (the cut records have no line end of their own)
