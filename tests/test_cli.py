@@ -301,3 +301,26 @@ def test_cli_hostsim_block_parallel_input(tmp_path):
     env = dict(os.environ, BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1", BWAGPU_PTAB_M="6", BWAGPU_CLI_PARSE_THREADS="3", BWAGPU_CLI_PAR_BLOCK="1500")
     for args, what in ((["-K", "3000", "-t", "2", prefix, f1, f2], "two files, -K 3000"), (["-K", "100000000", "-t", "2", "-C", prefix, weird], "awkward file")):
         assert _run(refapi.REF_BWA, args) == _run(cli, args, env), what
+
+
+@pytest.mark.skipif(not refapi.have_ref(), reason="oracle/_ref not built")
+def test_cli_hostsim_dashes_among_the_bases(tmp_path):
+    """'-' is base code 5 (nst_nt4_table): it indexes the scoring matrix one past a row's end in the reference's query profile and its
+    letter in the SAM record is a NUL.  Reads with one to three of them at random positions, single-end and paired: same SAM as `bwa mem`."""
+    prefix, g = testdata.small_index()
+    cli = _sim_cli()
+    rng = np.random.default_rng(5)
+    r1, r2 = simdata.make_reads_pe(g, 30, seed=77)
+    files = []
+    for k, r in ((1, r1), (2, r2)):
+        files.append(str(tmp_path / f"d{k}.fq"))
+        with open(files[-1], "wb") as f:
+            for i in range(r.shape[0]):
+                s = bytearray(simdata._ASCII[r[i]].tobytes())
+                for _ in range(int(rng.integers(1, 4))):
+                    s[int(rng.integers(0, len(s)))] = ord("-")
+                f.write(b"@d%d/%d\n" % (i, k) + bytes(s) + b"\n+\n" + b"I" * len(s) + b"\n")
+    env = dict(os.environ, BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1", BWAGPU_PTAB_M="6")
+    K = ["-K", "100000000", "-t", "2"]
+    for args in ([files[0]], files):
+        assert _run(refapi.REF_BWA, K + [prefix] + args) == _run(cli, K + [prefix] + args, env), f"{len(args)} file(s)"
