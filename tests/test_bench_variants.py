@@ -36,3 +36,17 @@ def test_bench_variants_object(monkeypatch, tmp_path):
     for r in short["runs"] + long_["runs"]:
         assert "error" not in r and r["same_result_as_defaults"] is True, r
     assert all("ms_per_step" in r and "stage_ms_solo" in r for r in short["runs"]) and all("ms_per_pass" in r for r in long_["runs"])
+
+
+def test_run_child_keeps_what_a_hung_child_printed():
+    """A variant that hangs must cost the bench line nothing but its own entries: the child is killed with its process group at the time
+    limit, the lines it had printed are kept, and the call returns at once."""
+    import sys
+    import time
+    import bench
+    leg = {}
+    t = time.time()
+    text, rc = bench.run_child([sys.executable, "-c", "import time,sys; print('{\"config\": \"x\"}', flush=True); sys.stderr.write('boom'); sys.stderr.flush(); time.sleep(60)"], 1.5, leg)
+    assert rc == "timeout" and '{"config": "x"}' in text and time.time() - t < 10 and "boom" in leg.get("stderr_tail", "") and not leg.get("unreaped")
+    text, rc = bench.run_child([sys.executable, "-c", "print('ok')"], 10, leg)
+    assert rc == 0 and text.strip() == "ok"
