@@ -213,6 +213,7 @@ def main():
     ap.add_argument("--long-len", type=int, default=10000)
     ap.add_argument("--long-steps", type=int, default=2)
     ap.add_argument("--long-sample", type=int, default=128, help="reads of the long-read CPU-baseline / parity prefix")
+    ap.add_argument("--e2e-handles", type=int, default=5, help="a second FASTQ->SAM run of the paired-end sample with this many batches in flight (BWAGPU_CLI_STREAMS; the default run uses 3); 0 = skip")
     ap.add_argument("--variants", default="BWAGPU_SEED_MRG=1;BWAGPU_SEED_MRG=2", help="';'-separated environment settings to A/B against the defaults in a child process (tools/variant_probe.py); '' = none")
     ap.add_argument("--variants-timeout", type=float, default=100.0, help="seconds for the short-read child process (the long-read one gets 0.8 of it)")
     args = ap.parse_args()
@@ -475,6 +476,13 @@ def main():
                                                 + (f", every batch split over devices {devices} (BWAGPU_DEVICES)" if world > 1 else "") + "; wall time after the index is loaded"}
                 if ref_pe:
                     out["end_to_end_pe"]["vs_cpu_baseline"] = round(e2e["reads_per_s"] / ref_pe["reads_per_s"], 1)
+                if world == 1 and args.e2e_handles > 0 and args.e2e_handles != e2e["handles"]:
+                    # the same command with more batches in flight: a handle's share of the chip idles while its batch is in the download /
+                    # mem_pestat / mate-rescue part of the device stage, which more handles fill (a measurement next to the default, not the default)
+                    alt = run_product(prefix, [f1, f2], threads, None, streams=args.e2e_handles, timeout=120)
+                    if alt:
+                        out["end_to_end_pe"]["more_handles"] = {"handles": alt["handles"], "value": round(alt["reads_per_s"] / 1e6, 4), "stages": alt["stages"],
+                                                                "device_stage_ms_per_batch": alt["device_stage_ms_per_batch"], "what": f"BWAGPU_CLI_STREAMS={args.e2e_handles}, otherwise the same command"}
             if world == 1:
                 e2e = run_product(prefix, [f1], threads, None)          # (the first file alone, as single-end reads: no second copy of the sample to write)
                 if e2e:
