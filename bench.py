@@ -216,6 +216,8 @@ def main():
     ap.add_argument("--e2e-handles", type=int, default=5, help="a second FASTQ->SAM run of the paired-end sample with this many batches in flight (BWAGPU_CLI_STREAMS; the default run uses 3); 0 = skip")
     ap.add_argument("--variants", default="BWAGPU_SEED_MRG=1;BWAGPU_SEED_MRG=2", help="';'-separated environment settings to A/B against the defaults in a child process (tools/variant_probe.py); '' = none")
     ap.add_argument("--variants-timeout", type=float, default=100.0, help="seconds for the short-read child process (the long-read one gets 0.8 of it)")
+    ap.add_argument("--wall-budget", type=float, default=330.0, help="seconds since start after which no variants child may still run: the two legs share what is left "
+                    "when the line's own measurements are done (they end first; a leg that gets less than 20 s is skipped)")
     args = ap.parse_args()
 
     import torch
@@ -497,14 +499,14 @@ def main():
             except Exception as e:   # (the long-read leg must not take the headline line with it)
                 out["longread"] = {"error": repr(e)}
     if world == 1 and args.variants.strip() and not args.no_cpu_baseline:      # (a full run only: the profiling runs pass --no-cpu-baseline)
-        out["variants"] = run_variants(args, prefix, variant_files)
+        out["variants"] = run_variants(args, prefix, variant_files, max(0.0, args.wall_budget - (time.time() - _T0)))
     out["bench_wall_s"] = round(time.time() - t_all, 1)
     sys.stdout.flush()
     print(json.dumps(out), flush=True)      # the one JSON line, last thing on stdout (RCCL prints a version banner of its own at start-up)
     sys.exit(rc_exit)
 
 
-def run_variants(args, prefix, batch_files=()):
+def run_variants(args, prefix, batch_files=(), wall_left=1e9):
     """Kernel variants that sit behind environment switches, A/B'd against the defaults on the headline's workload by tools/variant_probe.py
     in a CHILD process with a time limit: solo stage times, step time with the same batches in flight, and a digest of the regions that
     must equal the defaults'.  Informational -- `value` above is always the default configuration's; a variant that faults or hangs costs
@@ -519,7 +521,13 @@ def run_variants(args, prefix, batch_files=()):
         long_file = os.path.join(os.path.dirname(prefix), "long_reads.npy")       # (left there by the long-read leg)
         legs.append(("long_reads", ["--long-reads", str(args.long_reads), "--long-len", str(args.long_len), "--passes", "1"] +
                      (["--long-file", long_file] if os.path.exists(long_file) else []), args.variants_timeout * 0.8))
-    for name, extra, limit in legs:
+    t_legs = time.time()
+    for k_leg, (name, extra, limit) in enumerate(legs):
+        left = wall_left - (time.time() - t_legs)
+        limit = min(limit, left * 0.55 if k_leg + 1 < len(legs) else left)      # (the bench line must come out within --wall-budget whatever the children do)
+        if limit < 20.0:
+            res[name] = {"skipped": f"{left:.0f} s of --wall-budget left"}
+            continue
         if name == "long_reads":
             # the long-read switches, each alone and all together (they exist for long-read batches only; BWAGPU_SEED_MRG=2 is the last short-read entry)
             alone = [cfgs[-1], "BWAGPU_SEED_CHUNK=256", "BWAGPU_PUBLISH_BLK=1", "BWAGPU_LONG_QLDS=1", "BWAGPU_SEEDSW_LDS=1"]

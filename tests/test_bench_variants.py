@@ -50,3 +50,18 @@ def test_run_child_keeps_what_a_hung_child_printed():
     assert rc == "timeout" and '{"config": "x"}' in text and time.time() - t < 10 and "boom" in leg.get("stderr_tail", "") and not leg.get("unreaped")
     text, rc = bench.run_child([sys.executable, "-c", "print('ok')"], 10, leg)
     assert rc == 0 and text.strip() == "ok"
+
+
+def test_variants_share_the_wall_budget(tmp_path):
+    """The bench line must come out within --wall-budget: with little of it left no child is started at all, and the first leg never
+    gets more than 55 % of what is left."""
+    import time
+    import bench
+    args = argparse.Namespace(variants="BWAGPU_SEED_MRG=1", variants_timeout=600.0, reads=8, read_len=150, streams=1, dense_sa=0,
+                              no_longread=False, long_reads=1, long_len=1150)
+    t = time.time()
+    res = bench.run_variants(args, str(tmp_path / "none"), [], wall_left=15.0)
+    assert "skipped" in res["short_reads"] and "skipped" in res["long_reads"] and time.time() - t < 2
+    t = time.time()
+    res = bench.run_variants(args, str(tmp_path / "none"), [], wall_left=38.0)      # 20.9 s for the first leg (its probe fails at once: no index), < 20 s left for the second
+    assert res["short_reads"].get("rc") not in (None, 0) and time.time() - t < 25
