@@ -2,7 +2,7 @@
 # Companion of quick_gpu_check.sh: the switchable kernel forms on hardware, each against the same `bwa mem` digests (seconds per run).
 #   bash tools/quick_gpu_variants.sh            -> the round's switches;  extra arguments: "pe:ENV=1 ENV2=2" / "long:ENV=1"
 Q=tests/_data/quick; P=tests/golden/g200k; rc=0
-body() { grep -v '^@PG' | sha256sum | cut -d' ' -f1; }
+body() { grep -av '^@PG' | sha256sum | cut -d' ' -f1; }
 E1=$(sed -n 1p $Q/expected.txt); E2=$(sed -n 2p $Q/expected.txt)
 run() {  # leg, env settings
   local leg=$1; shift
