@@ -995,12 +995,13 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			int rc_ = 256; while (rc_ < need && rc_ < 4096) rc_ <<= 1;
 			if (getenv("BWAGPU_DEDUP_RING")) rc_ = atoi(getenv("BWAGPU_DEDUP_RING"));      // test hook: a power of two, 256..4096
 			if (rc_ < 256 || rc_ > 4096 || (rc_ & (rc_ - 1))) rc_ = 1024;
-			int q_cap = long_qlds ? (h->max_len + 15) & ~15 : 0;      // room for a patch alignment's query segment next to the ring (see k_extend_wave above)
+			const bool dedup_blk = getenv("BWAGPU_DEDUP_BLK") && atoi(getenv("BWAGPU_DEDUP_BLK")) != 0;   // four columns per lane in the patch alignments (wave_global2_score_ring_blk; opt-in until measured); needs the segment in LDS
+			int q_cap = long_qlds || dedup_blk ? (h->max_len + 15) & ~15 : 0;      // room for a patch alignment's query segment next to the ring (see k_extend_wave above)
 			if (8 * rc_ + 32 + q_cap > 65536) q_cap = 0;
 			int wpb = rc_ <= 1024 ? 4 : (rc_ <= 2048 ? 2 : 1);
 			while (wpb > 1 && (8 * rc_ + 32 + q_cap) * wpb > 65536) wpb >>= 1;
 			i64 nblk = ((i64)n + wpb - 1) / wpb, cap = B.dp_waves / wpb > 0 ? B.dp_waves / wpb : 1;   // dp_h/dp_e hold one scratch region per wave
-			hipLaunchKernelGGL(k_dedup_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)(8 * rc_ + 32 + q_cap) * wpb, h->stream, h->ix, *opt, B, rc_, q_cap);
+			hipLaunchKernelGGL(k_dedup_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)(8 * rc_ + 32 + q_cap) * wpb, h->stream, h->ix, *opt, B, rc_, q_cap, dedup_blk ? 1 : 0);
 		} else
 			hipLaunchKernelGGL(k_dedup, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
@@ -1359,7 +1360,8 @@ extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, i
 	DevBuf d_seq, d_pac, d_cases, d_out, d_scr, d_pac2;
 	int rc = BWAGPU_OK;
 	const int grid = n_cases < 2048 ? n_cases : 2048;
-	const bool dbg_qlds = getenv("BWAGPU_LONG_QLDS") && atoi(getenv("BWAGPU_LONG_QLDS")) != 0;   // kinds 1 and 3 with the LDS copy of the query (as the long-read kernels make it under the same switch)
+	const bool dbg_blk = getenv("BWAGPU_DEDUP_BLK") && atoi(getenv("BWAGPU_DEDUP_BLK")) != 0;      // kind 3 in its four-columns-per-lane form
+	const bool dbg_qlds = dbg_blk || (getenv("BWAGPU_LONG_QLDS") && atoi(getenv("BWAGPU_LONG_QLDS")) != 0);   // kinds 1 and 3 with the LDS copy of the query (as the long-read kernels make it under the same switch)
 	hipError_t e = hipSuccess;
 	if (d_seq.ensure((size_t)n_seq_bytes + 16) || d_pac.ensure((size_t)n_seq_bytes / 4 + 16) || d_cases.ensure((size_t)n_cases * sizeof(bwagpu_dp_case_t)) || d_out.ensure((size_t)n_cases * DBG_OUT_INTS * 4)) { h->err = "hipMalloc failed (debug)"; rc = BWAGPU_ENOMEM; goto done; }
 	e = hipMemcpyAsync(d_seq.p, seqs, (size_t)n_seq_bytes, hipMemcpyHostToDevice, h->stream);
@@ -1383,7 +1385,7 @@ extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, i
 			int ring_cols = 256; while (ring_cols < 2 * max_w + 4 + 128) ring_cols <<= 1;
 			if (ring_cols > 4096) { rc = BWAGPU_EINVAL; goto done; }
 			const int q_cap = dbg_qlds && 8 * ring_cols + 32 + ((max_q + 15) & ~15) <= 65536 ? (max_q + 15) & ~15 : 0;
-			hipLaunchKernelGGL(k_debug_global_ring, dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), ring_cols, d_out.as<i32>(), q_cap);
+			hipLaunchKernelGGL(k_debug_global_ring, dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), ring_cols, d_out.as<i32>(), q_cap, dbg_blk ? 1 : 0);
 		} else if (kind == 5) {
 			int max_t = 1; for (int i = 0; i < n_cases; ++i) if (cases[i].t_len > max_t) max_t = cases[i].t_len;
 			i64 z_cap = ((i64)max_t + 16) * ((CIGL_MAX_COLS + 15) & ~15); z_cap = (z_cap + 15) & ~(i64)15;

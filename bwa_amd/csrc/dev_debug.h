@@ -98,11 +98,11 @@ __global__ void __launch_bounds__(64) k_debug_global(DevIndex ix, bwagpu_opt_t o
 }
 
 // kind 3: the score-only ring form of k_dedup_wave
-__global__ void __launch_bounds__(64) k_debug_global_ring(DevIndex ix, bwagpu_opt_t opt, int n_cases, const bwagpu_dp_case_t *cases, const u8 *seqs, int ring_cols, i32 *out, int q_cap)
+__global__ void __launch_bounds__(64) k_debug_global_ring(DevIndex ix, bwagpu_opt_t opt, int n_cases, const bwagpu_dp_case_t *cases, const u8 *seqs, int ring_cols, i32 *out, int q_cap, int blk)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, dbg_lds)
 	const int lane = threadIdx.x & 63;
-	DedupLds L;
+	DedupLds L; L.blk = blk;
 	L.hd = (i32*)dbg_lds; L.e = L.hd + ring_cols; L.ring_mask = ring_cols - 1; L.H = nullptr; L.E = nullptr; L.qbuf = dbg_lds + (size_t)8 * ring_cols + 32; L.qcap = q_cap;
 	int8_t *m = (int8_t*)(dbg_lds + (size_t)8 * ring_cols);
 	if (lane < 25) m[lane] = opt.mat[lane];
@@ -115,7 +115,8 @@ __global__ void __launch_bounds__(64) k_debug_global_ring(DevIndex ix, bwagpu_op
 		i32 *o = out + (size_t)k * DBG_OUT_INTS;
 		if (2 * c.w + 4 + 128 > ring_cols) { if (lane == 0) { o[0] = 0; o[1] = -2; } continue; }
 		u64 cells = 0;
-		const int score = wave_global2_score_ring(ix, opt, seqs + c.q_off, q0, qdir, c.q_len, t0, tdir, c.t_len, c.w, L, cells);
+		const int score = L.blk && L.qcap >= c.q_len ? wave_global2_score_ring_blk(ix, opt, seqs + c.q_off, q0, qdir, c.q_len, t0, tdir, c.t_len, c.w, L, cells)
+													   : wave_global2_score_ring(ix, opt, seqs + c.q_off, q0, qdir, c.q_len, t0, tdir, c.t_len, c.w, L, cells);
 		if (lane == 0) { o[0] = score; o[1] = 0; o[7] = (i32)cells; }
 		wave_sync();
 	}

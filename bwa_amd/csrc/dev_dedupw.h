@@ -9,7 +9,8 @@
 #include "dev_extw.h"
 
 struct DedupLds { i32 *hd, *e; const int8_t *mat; int ring_mask; i32 *H, *E; /* lane 0's HBM scratch columns (dev_ksw_global2_score) for bands wider than the ring */
-	u8 *qbuf; int qcap; /* optional (BWAGPU_LONG_QLDS=1): room for a patch alignment's query segment in alignment order */ };
+	u8 *qbuf; int qcap; /* optional (BWAGPU_LONG_QLDS=1): room for a patch alignment's query segment in alignment order */
+	int blk; /* BWAGPU_DEDUP_BLK=1: four columns per lane (wave_global2_score_ring_blk); needs qbuf */ };
 
 // ksw_global2 without traceback (ksw.c:540-619), columns in a ring of ring_mask+1 entries, lazily initialised
 __device__ int wave_global2_score_ring(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen, i64 t0, int tdir, int tlen,
@@ -77,6 +78,89 @@ __device__ int wave_global2_score_ring(const DevIndex &ix, const bwagpu_opt_t &o
 	return score;
 }
 
+// The same with FOUR adjacent columns per lane (BWAGPU_DEDUP_BLK=1, opt-in until measured).  The patch alignments of a 10 kb read run in bands
+// of 200-800 columns, and in the form above every 64 of them cost a pass -- two ordering points, an LDS round trip and a six-step scan, each
+// waiting for the one before at one wave per SIMD.  Here a pass covers 256 columns: a lane computes its four diagonal terms, a local prefix
+// maximum of their insertion starts, ONE wave scan over the lanes' totals, then F, H and E of its columns (ksw.c:587-603).  Blocks are
+// aligned to multiples of four columns in the ring, so a lane reads {H(i-1, j-1)}, {E} as two 16-byte LDS reads and writes them back the
+// same way: ring slot j holds the diagonal for column j, which after this row is H(i, j-1) -- the lane's own h shifted by one column, with
+// the first slot filled from the lane below (a lane shift).  No lane touches another lane's slots within a row: one ordering point per row.
+// Slots a block covers outside [beg, end] receive defined but meaningless values: left of the band they are dead (beg never decreases),
+// right of `end` every slot is rewritten -- as H[end] = h1, E[end] = -inf of a later row, or by the lazy first-row initialisation -- before
+// a row reads it, and the ring is wider than the band plus these margins (2 w + 132 columns), so they alias no live slot.
+__device__ int wave_global2_score_ring_blk(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen, i64 t0, int tdir, int tlen,
+										   int w, const DedupLds &L, u64 &cells)
+{
+	const int lane = threadIdx.x & 63;
+	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+	i32 *hd = L.hd, *e_ = L.e; const int rm = L.ring_mask;
+	int init_hi = -1, treg = 0;
+	for (int j = lane; j < qlen; j += 64) L.qbuf[j] = q[q0 + j * qdir];       // the segment in alignment order (the caller checked L.qcap >= qlen)
+	wave_sync();
+	const u8 *qs = L.qbuf;
+	for (int i = 0; i < tlen; ++i) {
+		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
+		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
+		const int beg = i > w ? i - w : 0, end = i + w + 1 < qlen ? i + w + 1 : qlen;
+		{	// first-row values (ksw.c:566-570) of the columns this row can reach for the first time
+			const int hi = i + w + 2 < qlen ? i + w + 2 : qlen;
+			if (hi > init_hi) {
+				for (int j = init_hi + 1 + lane; j <= hi; j += 64) {
+					hd[j & rm] = j == 0 ? 0 : (j <= w ? -(o_ins + e_ins * j) : DEV_NEG_INF);
+					e_[j & rm] = DEV_NEG_INF;
+				}
+				init_hi = hi;
+				wave_sync();
+			}
+		}
+		const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : DEV_NEG_INF;
+		const int8_t *mrow = L.mat + tb * 5;
+		int carry = I32_MIN, hprev = h1_init;
+		cells += (u64)(end > beg ? end - beg : 0);
+		for (int b = beg & ~3; b <= end; b += 256) {            // (<=: slot `end` is written too, ksw.c:605)
+			const int j0 = b + 4 * lane, p = j0 & rm;          // the ring's size and j0 are multiples of four: the block is contiguous and 16-byte aligned
+			const int4 dg4 = *(const int4*)&hd[p], e4 = *(const int4*)&e_[p];
+			const u32 qw = j0 < qlen ? *(const u32*)&qs[j0] : 0x04040404u;     // (bytes of the word at or past qlen are not the segment's: masked below)
+			const int dgv[4] = { dg4.x, dg4.y, dg4.z, dg4.w }, ev[4] = { e4.x, e4.y, e4.z, e4.w };
+			int m[4], pre[4], run = I32_MIN;
+			#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const int j = j0 + c; const bool act = j >= beg && j < end;
+				const int qc = j < qlen ? (int)((qw >> (8 * c)) & 255u) : 4;
+				m[c] = wadd(dgv[c], mrow[qc]);                 // (slots outside the band hold anything: wrap-around arithmetic, results discarded)
+				pre[c] = run;
+				run = imax(run, act ? wadd(wsub(m[c], oe_ins), j * e_ins) : I32_MIN);
+			}
+			const int inc = wave_incl_scan_max(run);
+			const int exl = imax(wave_shift_up1(inc, I32_MIN), carry);     // best insertion start among the columns of the lanes below and of earlier passes
+			int hv[4], en[4];
+			#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const int j = j0 + c; const bool act = j >= beg && j < end;
+				int f = DEV_NEG_INF - (j - beg) * e_ins;
+				if (j > beg && act) f = imax(f, imax(exl, pre[c]) - (j - 1) * e_ins);
+				int h = m[c] >= ev[c] ? m[c] : ev[c];
+				if (h < f) h = f;
+				const int t = wsub(m[c], oe_del); int e2 = wsub(ev[c], e_del); if (e2 < t) e2 = t;
+				hv[c] = act ? h : h1_init;                     // (left of the band: slot `beg` receives h1, ksw.c:578)
+				en[c] = act ? e2 : DEV_NEG_INF;                // (column `end`: E = -inf, ksw.c:605)
+			}
+			const int hl = wave_shift_up1(hv[3], hprev);         // H(i, j0 - 1): the lane below's last column; lane 0: the pass before, or h1
+			if (j0 <= end) {
+				*(int4*)&hd[p] = make_int4(hl, hv[0], hv[1], hv[2]);
+				*(int4*)&e_[p] = make_int4(en[0], en[1], en[2], en[3]);
+			}
+			carry = imax(carry, __builtin_amdgcn_readlane(inc, 63));
+			hprev = __builtin_amdgcn_readlane(hv[3], 63);
+		}
+		wave_sync();
+	}
+	const int score = hd[qlen & rm];
+	wave_sync();
+	return score;
+}
+
 // bwa_gen_cigar2 in score-only mode (bwa.c:148-194).  A band that does not fit the ring (rare: the length difference of the two
 // segments exceeds 4 * opt.w) is computed by lane 0 alone with its columns in HBM scratch.
 __device__ int wave_global_score(const DevIndex &ix, const bwagpu_opt_t &opt, int w_, int l_query, const u8 *query, i64 rb, i64 re,
@@ -108,6 +192,7 @@ __device__ int wave_global_score(const DevIndex &ix, const bwagpu_opt_t &opt, in
 		wave_sync();
 		return sc;
 	}
+	if (L.blk && L.qcap >= l_query) return wave_global2_score_ring_blk(ix, opt, query, q0, qdir, l_query, t0, tdir, rlen, w, L, cells);
 	return wave_global2_score_ring(ix, opt, query, q0, qdir, l_query, t0, tdir, rlen, w, L, cells);
 }
 
@@ -217,7 +302,7 @@ __device__ void dedup_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 }
 
 // One wavefront per read.
-__global__ void __launch_bounds__(256) k_dedup_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int ring_cols, int q_cap)
+__global__ void __launch_bounds__(256) k_dedup_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int ring_cols, int q_cap, int blk)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, ddw_lds)
 	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -227,7 +312,7 @@ __global__ void __launch_bounds__(256) k_dedup_wave(DevIndex ix, bwagpu_opt_t op
 	int8_t *m = (int8_t*)(base + (size_t)8 * ring_cols);
 	if (lane < 25) m[lane] = opt.mat[lane];
 	L.mat = m;
-	L.qbuf = base + (size_t)8 * ring_cols + 32; L.qcap = q_cap;
+	L.qbuf = base + (size_t)8 * ring_cols + 32; L.qcap = q_cap; L.blk = blk;
 	{
 		const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_blk;
 		L.H = B.dp_h + wave * (B.max_len + 2) * DPS; L.E = B.dp_e + wave * (B.max_len + 2) * DPS;

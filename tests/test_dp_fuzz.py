@@ -201,7 +201,7 @@ def run_extend(dev, kind, n, max_len, seed, need_stale):
         assert stale > 0, "no case exercised the stale-cell rule"
 
 
-def global_cases(rng, n, max_len, max_cols, big_gaps=False):
+def global_cases(rng, n, max_len, max_cols, big_gaps=False, wide=()):
     cs = CaseSet()
     for it in range(n):
         tlen = int(rng.integers(1, max_len))
@@ -214,6 +214,8 @@ def global_cases(rng, n, max_len, max_cols, big_gaps=False):
         w = dl + 3 + int(rng.integers(0, 40)) if it % 3 else dl + 3
         if it % 5 == 0 and not big_gaps:     # bands of exactly 63 .. 65, 127 .. 129, 191 .. 193 columns: the widths at which a row takes another pass of the wave
             w = max(w, int(rng.choice([31, 32, 63, 64, 95, 96])))
+        if wide and it % 2 == 1:             # (the four-columns-per-lane form takes another pass every 256 columns)
+            w = max(w, int(rng.choice(wide)))
         if min(len(q), 2 * w + 1) > max_cols:
             w = max(dl + 3, (max_cols - 1) // 2)
         if min(len(q), 2 * w + 1) > max_cols:
@@ -231,11 +233,11 @@ def ref_global(o, q, t, w):
     return sc, ops
 
 
-def run_global(dev, kind, n, max_len, max_cols, seed):
+def run_global(dev, kind, n, max_len, max_cols, seed, wide=()):
     rng = np.random.default_rng(seed)
     served = 0
     for oi, o in enumerate(_opts()):
-        cs = global_cases(rng, n // 4, max_len, max_cols, big_gaps=kind == 5)
+        cs = global_cases(rng, n // 4, max_len, max_cols, big_gaps=kind == 5, wide=wide)
         cases, seqs = cs.arrays()
         out = dev.debug_dp(o, kind, cases, seqs)
         for k, (q, t, w, _, _) in enumerate(cs.py):
@@ -323,6 +325,15 @@ def test_sim_ring_forms_with_the_query_in_lds(sim, monkeypatch):
     monkeypatch.setenv("BWAGPU_LONG_QLDS", "1")
     run_extend(sim, 1, 48, 400, seed=17, need_stale=False)
     run_global(sim, 3, 32, 150, 90, seed=18)
+
+
+def test_sim_ring_global_four_columns_per_lane(sim, monkeypatch):
+    """BWAGPU_DEDUP_BLK=1: the score-only ring aligner of k_dedup_wave with four adjacent columns per lane (one scan and one ordering point per
+    256 columns of a row): same scores as the reference's ksw_global2 -- short segments, bands at the widths where a row takes a second
+    and a third pass (127..129, 255..257 columns on either side), segments of up to 900 bases, reverse-strand geometry and N bases included."""
+    monkeypatch.setenv("BWAGPU_DEDUP_BLK", "1")
+    run_global(sim, 3, 80, 150, 1 << 30, seed=31)
+    run_global(sim, 3, 48, 900, 1 << 30, seed=32, wide=(63, 64, 126, 127, 128, 129, 130, 200, 255, 256, 257, 300))
 
 
 def test_sim_global_fuzz(sim):

@@ -627,3 +627,24 @@ def test_hostsim_alt_contigs(tmp_path):
     c0, r0 = s_plain.align(opt, seqs, off)
     assert r.tobytes() != r0.tobytes()
     s_alt.close(); s_plain.close(); orc.close()
+
+
+def test_hostsim_long_read_patch_alignments_four_columns_per_lane(monkeypatch):
+    """BWAGPU_DEDUP_BLK=1: k_dedup_wave's score-only patch alignments (mem_patch_reg -> ksw_global2) with four adjacent columns per lane
+    (wave_global2_score_ring_blk).  A 7 kb -x pacbio read drifts out of the extension's band, so its regions are merged by a patch alignment
+    of ~7000 x 750 cells (three passes of 256 columns per row): the regions equal the compiled reference's, and the batch did run one."""
+    import refapi
+    if not refapi.have_ref():
+        pytest.skip("oracle/_ref not built (needed to index the 2 Mb genome)")
+    prefix, g = testdata.medium_index()
+    ref = refapi.RefIndex(prefix)
+    reads = simdata.make_reads_long(g, 1, length=7000, seed=78)
+    seqs, off = testdata.flat(reads)
+    want = ref.align(pacbio_opt(), seqs, off)
+    monkeypatch.setenv("BWAGPU_DEDUP_BLK", "1"); monkeypatch.setenv("BWAGPU_PTAB_M", "6")
+    s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+    s2.set_stats(True)
+    assert_regs_equal(*want, *s2.align(pacbio_opt(), seqs, off), "7 kb -x pacbio read, patch alignment with four columns per lane")
+    st = s2.stats()
+    assert st["n_glb_calls"] >= 1 and st["n_glb_cells"] > 4_000_000, st
+    s2.close()

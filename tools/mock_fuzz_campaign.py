@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-DP_ENVS = [{}, {"BWAGPU_LONG_QLDS": "1"}]
+DP_ENVS = [{}, {"BWAGPU_LONG_QLDS": "1"}, {"BWAGPU_DEDUP_BLK": "1"}]
 OPT_ENVS = [
     {},
     {"BWAGPU_SEED_MRG": "1"},
@@ -84,6 +84,7 @@ def main():
             attempt("extend_ring", env, lambda: dp.run_extend(sim, 1, 150, 400, seed, need_stale=False))
             attempt("global_lds", env, lambda: dp.run_global(sim, 2, 200, 160, 192, seed))
             attempt("global_ring", env, lambda: dp.run_global(sim, 3, 100, 200, 1 << 30, seed))
+            attempt("global_ring_wide", env, lambda: dp.run_global(sim, 3, 32, 900, 1 << 30, seed + 1, wide=(63, 64, 127, 128, 129, 200, 255, 256, 257, 300, 383, 384, 385)))
             attempt("global_long", env, lambda: dp.run_global(sim, 5, 40, 500, 1900, seed))
             attempt("align2", env, lambda: dp.run_align2(sim, 40, seed))
         if args.only != "dp":
