@@ -530,7 +530,7 @@ def run_variants(args, prefix, batch_files=(), wall_left=1e9):
             continue
         if name == "long_reads":
             # the long-read switches, all together and each alone (they exist for long-read batches only; BWAGPU_SEED_MRG=2 is the last short-read entry)
-            alone = [cfgs[-1], "BWAGPU_SEED_CHUNK=256", "BWAGPU_PUBLISH_BLK=1", "BWAGPU_LONG_QLDS=1", "BWAGPU_SEEDSW_LDS=1", "BWAGPU_DEDUP_BLK=1"]
+            alone = [cfgs[-1], "BWAGPU_SEED_CHUNK=256", "BWAGPU_PUBLISH_BLK=1", "BWAGPU_LONG_QLDS=1", "BWAGPU_SEEDSW_LDS=1", "BWAGPU_DEDUP_BLK=1", "BWAGPU_EXT_BLK=1"]
             cfgs = [" ".join(alone)] + alone          # (all together first: the entry to have if the leg runs out of its time)
         log(f"[bench] variants, {name} (child process, <= {limit:.0f} s): {cfgs}")
         t = time.time()

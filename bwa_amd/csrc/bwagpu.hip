@@ -980,7 +980,9 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			const int lds_wave = 8 * ring_cols + 32 + q_cap;
 			int wpb = 4; while (wpb > 1 && lds_wave * wpb > 65536) wpb >>= 1;
 			i64 nblk = ((i64)n + wpb - 1) / wpb, cap = 256 * 8 * (4 / wpb);
-			hipLaunchKernelGGL((k_extend_wave<true, 4>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, lds_wave, ring_cols, q_cap);
+			// BWAGPU_EXT_BLK=1: DP rows with four columns per lane (dev_extw.h; an instance of its own with the registers of two waves per SIMD -- the ring's LDS allows no more anyway; opt-in until measured)
+			if (getenv("BWAGPU_EXT_BLK") && atoi(getenv("BWAGPU_EXT_BLK")) != 0) hipLaunchKernelGGL((k_extend_wave<true, 2, true>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, lds_wave, ring_cols, q_cap);
+			else hipLaunchKernelGGL((k_extend_wave<true, 4>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, lds_wave, ring_cols, q_cap);
 		} else                                  // very wide bands: lane-per-read scalar DP with the columns in HBM scratch
 			hipLaunchKernelGGL(k_extend, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
@@ -1001,7 +1003,8 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			int wpb = rc_ <= 1024 ? 4 : (rc_ <= 2048 ? 2 : 1);
 			while (wpb > 1 && (8 * rc_ + 32 + q_cap) * wpb > 65536) wpb >>= 1;
 			i64 nblk = ((i64)n + wpb - 1) / wpb, cap = B.dp_waves / wpb > 0 ? B.dp_waves / wpb : 1;   // dp_h/dp_e hold one scratch region per wave
-			hipLaunchKernelGGL(k_dedup_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)(8 * rc_ + 32 + q_cap) * wpb, h->stream, h->ix, *opt, B, rc_, q_cap, dedup_blk ? 1 : 0);
+			if (dedup_blk && q_cap) hipLaunchKernelGGL(k_dedup_wave<true>, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)(8 * rc_ + 32 + q_cap) * wpb, h->stream, h->ix, *opt, B, rc_, q_cap);
+			else hipLaunchKernelGGL(k_dedup_wave<false>, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)(8 * rc_ + 32 + q_cap) * wpb, h->stream, h->ix, *opt, B, rc_, q_cap);
 		} else
 			hipLaunchKernelGGL(k_dedup, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
@@ -1378,14 +1381,16 @@ extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, i
 			int ring_cols = 256; while (ring_cols < 2 * max_w + 4 + 128) ring_cols <<= 1;
 			if (ring_cols > 4096) { rc = BWAGPU_EINVAL; goto done; }
 			const int q_cap = dbg_qlds && 8 * ring_cols + 32 + ((max_q + 15) & ~15) <= 65536 ? (max_q + 15) & ~15 : 0;
-			hipLaunchKernelGGL((k_debug_extend<true>), dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, ring_cols, d_out.as<i32>(), q_cap);
+			if (getenv("BWAGPU_EXT_BLK") && atoi(getenv("BWAGPU_EXT_BLK")) != 0) hipLaunchKernelGGL((k_debug_extend<true, true>), dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, ring_cols, d_out.as<i32>(), q_cap);
+			else hipLaunchKernelGGL((k_debug_extend<true>), dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, ring_cols, d_out.as<i32>(), q_cap);
 		} else if (kind == 2) {
 			hipLaunchKernelGGL(k_debug_global, dim3(grid), dim3(64), (size_t)CIG_LDS_BYTES(CIG_Z_BIG), h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), d_out.as<i32>());
 		} else if (kind == 3) {
 			int ring_cols = 256; while (ring_cols < 2 * max_w + 4 + 128) ring_cols <<= 1;
 			if (ring_cols > 4096) { rc = BWAGPU_EINVAL; goto done; }
 			const int q_cap = dbg_qlds && 8 * ring_cols + 32 + ((max_q + 15) & ~15) <= 65536 ? (max_q + 15) & ~15 : 0;
-			hipLaunchKernelGGL(k_debug_global_ring, dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), ring_cols, d_out.as<i32>(), q_cap, dbg_blk ? 1 : 0);
+			if (dbg_blk) hipLaunchKernelGGL(k_debug_global_ring<true>, dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), ring_cols, d_out.as<i32>(), q_cap);
+			else hipLaunchKernelGGL(k_debug_global_ring<false>, dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), ring_cols, d_out.as<i32>(), q_cap);
 		} else if (kind == 5) {
 			int max_t = 1; for (int i = 0; i < n_cases; ++i) if (cases[i].t_len > max_t) max_t = cases[i].t_len;
 			i64 z_cap = ((i64)max_t + 16) * ((CIGL_MAX_COLS + 15) & ~15); z_cap = (z_cap + 15) & ~(i64)15;

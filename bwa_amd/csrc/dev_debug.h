@@ -25,7 +25,7 @@ DEVFN void dbg_case_geometry(const bwagpu_dp_case_t &c, i64 l_pac, int &q0, int 
 }
 
 // kind 0 / 1: wave_ksw_extend2 as k_extend_wave sets it up (columns + read profile in LDS / ring mode)
-template <bool RING> __global__ void __launch_bounds__(64) k_debug_extend(DevIndex ix, bwagpu_opt_t opt, int n_cases, const bwagpu_dp_case_t *cases, const u8 *seqs,
+template <bool RING, bool BLK = false> __global__ void __launch_bounds__(64) k_debug_extend(DevIndex ix, bwagpu_opt_t opt, int n_cases, const bwagpu_dp_case_t *cases, const u8 *seqs,
 																			 int max_q, int ring_cols, i32 *out, int q_cap)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, dbg_lds)
@@ -60,7 +60,7 @@ template <bool RING> __global__ void __launch_bounds__(64) k_debug_extend(DevInd
 			if (L.qcap >= c.q_len && c.q_len > 0) { wave_sync(); for (int j = lane; j < c.q_len; j += 64) L.qbuf[j] = q[j]; wave_sync(); L.qlds = L.qbuf; }
 		}
 		u64 cells = 0, fast = 0;
-		const ExtRes r = wave_ksw_extend2<RING>(ix, opt, mat_max, q, q0, qdir, c.q_len, t0, tdir, c.t_len, c.w, c.end_bonus, c.h0, L, cells, fast);
+		const ExtRes r = wave_ksw_extend2<RING, BLK>(ix, opt, mat_max, q, q0, qdir, c.q_len, t0, tdir, c.t_len, c.w, c.end_bonus, c.h0, L, cells, fast);
 		wave_sync();
 		if (lane == 0) {
 			i32 *o = out + (size_t)k * DBG_OUT_INTS;
@@ -98,11 +98,11 @@ __global__ void __launch_bounds__(64) k_debug_global(DevIndex ix, bwagpu_opt_t o
 }
 
 // kind 3: the score-only ring form of k_dedup_wave
-__global__ void __launch_bounds__(64) k_debug_global_ring(DevIndex ix, bwagpu_opt_t opt, int n_cases, const bwagpu_dp_case_t *cases, const u8 *seqs, int ring_cols, i32 *out, int q_cap, int blk)
+template <bool BLK = false> __global__ void __launch_bounds__(64) k_debug_global_ring(DevIndex ix, bwagpu_opt_t opt, int n_cases, const bwagpu_dp_case_t *cases, const u8 *seqs, int ring_cols, i32 *out, int q_cap)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, dbg_lds)
 	const int lane = threadIdx.x & 63;
-	DedupLds L; L.blk = blk;
+	DedupLds L;
 	L.hd = (i32*)dbg_lds; L.e = L.hd + ring_cols; L.ring_mask = ring_cols - 1; L.H = nullptr; L.E = nullptr; L.qbuf = dbg_lds + (size_t)8 * ring_cols + 32; L.qcap = q_cap;
 	int8_t *m = (int8_t*)(dbg_lds + (size_t)8 * ring_cols);
 	if (lane < 25) m[lane] = opt.mat[lane];
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(64) k_debug_global_ring(DevIndex ix, bwagpu_op
 		i32 *o = out + (size_t)k * DBG_OUT_INTS;
 		if (2 * c.w + 4 + 128 > ring_cols) { if (lane == 0) { o[0] = 0; o[1] = -2; } continue; }
 		u64 cells = 0;
-		const int score = L.blk && L.qcap >= c.q_len ? wave_global2_score_ring_blk(ix, opt, seqs + c.q_off, q0, qdir, c.q_len, t0, tdir, c.t_len, c.w, L, cells)
+		const int score = BLK && L.qcap >= c.q_len ? wave_global2_score_ring_blk(ix, opt, seqs + c.q_off, q0, qdir, c.q_len, t0, tdir, c.t_len, c.w, L, cells)
 													   : wave_global2_score_ring(ix, opt, seqs + c.q_off, q0, qdir, c.q_len, t0, tdir, c.t_len, c.w, L, cells);
 		if (lane == 0) { o[0] = score; o[1] = 0; o[7] = (i32)cells; }
 		wave_sync();

@@ -9,8 +9,7 @@
 #include "dev_extw.h"
 
 struct DedupLds { i32 *hd, *e; const int8_t *mat; int ring_mask; i32 *H, *E; /* lane 0's HBM scratch columns (dev_ksw_global2_score) for bands wider than the ring */
-	u8 *qbuf; int qcap; /* optional (BWAGPU_LONG_QLDS=1): room for a patch alignment's query segment in alignment order */
-	int blk; /* BWAGPU_DEDUP_BLK=1: four columns per lane (wave_global2_score_ring_blk); needs qbuf */ };
+	u8 *qbuf; int qcap; /* optional (BWAGPU_LONG_QLDS=1 / BWAGPU_DEDUP_BLK=1): room for a patch alignment's query segment in alignment order */ };
 
 // ksw_global2 without traceback (ksw.c:540-619), columns in a ring of ring_mask+1 entries, lazily initialised
 __device__ int wave_global2_score_ring(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen, i64 t0, int tdir, int tlen,
@@ -163,7 +162,7 @@ __device__ int wave_global2_score_ring_blk(const DevIndex &ix, const bwagpu_opt_
 
 // bwa_gen_cigar2 in score-only mode (bwa.c:148-194).  A band that does not fit the ring (rare: the length difference of the two
 // segments exceeds 4 * opt.w) is computed by lane 0 alone with its columns in HBM scratch.
-__device__ int wave_global_score(const DevIndex &ix, const bwagpu_opt_t &opt, int w_, int l_query, const u8 *query, i64 rb, i64 re,
+template <bool BLK = false> __device__ int wave_global_score(const DevIndex &ix, const bwagpu_opt_t &opt, int w_, int l_query, const u8 *query, i64 rb, i64 re,
 								 const DedupLds &L, u64 &calls, u64 &cells)
 {
 	const int lane = threadIdx.x & 63;
@@ -192,12 +191,12 @@ __device__ int wave_global_score(const DevIndex &ix, const bwagpu_opt_t &opt, in
 		wave_sync();
 		return sc;
 	}
-	if (L.blk && L.qcap >= l_query) return wave_global2_score_ring_blk(ix, opt, query, q0, qdir, l_query, t0, tdir, rlen, w, L, cells);
+	if (BLK && L.qcap >= l_query) return wave_global2_score_ring_blk(ix, opt, query, q0, qdir, l_query, t0, tdir, rlen, w, L, cells);
 	return wave_global2_score_ring(ix, opt, query, q0, qdir, l_query, t0, tdir, rlen, w, L, cells);
 }
 
 // mem_patch_reg (bwamem.c:432-461); all arguments wave-uniform
-__device__ int wave_patch_reg(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *query, const bwagpu_alnreg_t &a, const bwagpu_alnreg_t &b,
+template <bool BLK = false> __device__ int wave_patch_reg(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *query, const bwagpu_alnreg_t &a, const bwagpu_alnreg_t &b,
 							  int *w_out, const DedupLds &L, u64 &calls, u64 &cells)
 {
 	if (a.rb < ix.l_pac && b.rb >= ix.l_pac) return 0;
@@ -208,7 +207,7 @@ __device__ int wave_patch_reg(const DevIndex &ix, const bwagpu_opt_t &opt, const
 	else if (w > opt.w << 2 || r >= 0.05f * 2) return 0;
 	w += a.w + b.w;
 	if (w > opt.w << 2) w = opt.w << 2;
-	int score = wave_global_score(ix, opt, w, b.qe - a.qb, query + a.qb, a.rb, b.re, L, calls, cells);
+	int score = wave_global_score<BLK>(ix, opt, w, b.qe - a.qb, query + a.qb, a.rb, b.re, L, calls, cells);
 	int q_s = (int)((double)(b.qe - a.qb) / ((b.qe - b.qb) + (a.qe - a.qb)) * (b.score + a.score) + .499);
 	int r_s = (int)((double)(b.re - a.rb) / ((b.re - b.rb) + (a.re - a.rb)) * (b.score + a.score) + .499);
 	if ((double)score / (q_s > r_s ? q_s : r_s) < 0.90f) return 0;
@@ -226,7 +225,7 @@ DEVFN bwagpu_alnreg_t uni_reg(const bwagpu_alnreg_t *p)
 
 // mem_sort_dedup_patch (bwamem.c:463-515) for one read.  Every store by lane 0 is bracketed by wave_sync: the other lanes read
 // the same records to take the same branches.
-__device__ void dedup_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const DedupLds &L, u64 &calls, u64 &cells)
+template <bool BLK = false> __device__ void dedup_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const DedupLds &L, u64 &calls, u64 &cells)
 {
 	const int lane = threadIdx.x & 63;
 	int n = uni(B.reg_n_raw[r]);
@@ -260,7 +259,7 @@ __device__ void dedup_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 					if (p.score < q.score) { p.qe = p.qb; p_dirty = true; break; }
 					else { wave_sync(); if (lane == 0) a[j].qe = q.qb; wave_sync(); }
 				} else if (q.rb < p.rb) {
-					score = wave_patch_reg(ix, opt, query, q, p, &w, L, calls, cells);
+					score = wave_patch_reg<BLK>(ix, opt, query, q, p, &w, L, calls, cells);
 					if (score > 0) {
 						p.n_comp += q.n_comp + 1;
 						if (q.seedcov > p.seedcov) p.seedcov = q.seedcov;
@@ -302,7 +301,8 @@ __device__ void dedup_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 }
 
 // One wavefront per read.
-__global__ void __launch_bounds__(256) k_dedup_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int ring_cols, int q_cap, int blk)
+// BLK (BWAGPU_DEDUP_BLK=1): patch alignments with four columns per lane; an instance of its own, so that the default kernel stays as measured
+template <bool BLK = false> __global__ void __launch_bounds__(256) k_dedup_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int ring_cols, int q_cap)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, ddw_lds)
 	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256) k_dedup_wave(DevIndex ix, bwagpu_opt_t op
 	int8_t *m = (int8_t*)(base + (size_t)8 * ring_cols);
 	if (lane < 25) m[lane] = opt.mat[lane];
 	L.mat = m;
-	L.qbuf = base + (size_t)8 * ring_cols + 32; L.qcap = q_cap; L.blk = blk;
+	L.qbuf = base + (size_t)8 * ring_cols + 32; L.qcap = q_cap;
 	{
 		const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_blk;
 		L.H = B.dp_h + wave * (B.max_len + 2) * DPS; L.E = B.dp_e + wave * (B.max_len + 2) * DPS;
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256) k_dedup_wave(DevIndex ix, bwagpu_opt_t op
 		const long long k = wave_fetch(&B.ctr->next_dedup);
 		if (k >= B.n_reads) break;
 		const int r = (int)k;
-		dedup_read_wave(ix, opt, B, r, L, calls, cells);
+		dedup_read_wave<BLK>(ix, opt, B, r, L, calls, cells);
 		nreg += B.reg_n[r];
 	}
 	if (B.stats && lane == 0) {

@@ -31,8 +31,8 @@ def test_bench_variants_object(monkeypatch, tmp_path):
     short, long_ = res["short_reads"], res["long_reads"]
     assert short["rc"] == 0 and long_["rc"] == 0, (short, long_)
     assert [r["config"] for r in short["runs"]] == ["defaults", "BWAGPU_SEED_MRG=1", "BWAGPU_SEED_MRG=2"]
-    assert [r["config"] for r in long_["runs"]] == ["defaults", "BWAGPU_SEED_MRG=2 BWAGPU_SEED_CHUNK=256 BWAGPU_PUBLISH_BLK=1 BWAGPU_LONG_QLDS=1 BWAGPU_SEEDSW_LDS=1 BWAGPU_DEDUP_BLK=1",
-                                                    "BWAGPU_SEED_MRG=2", "BWAGPU_SEED_CHUNK=256", "BWAGPU_PUBLISH_BLK=1", "BWAGPU_LONG_QLDS=1", "BWAGPU_SEEDSW_LDS=1", "BWAGPU_DEDUP_BLK=1"]
+    assert [r["config"] for r in long_["runs"]] == ["defaults", "BWAGPU_SEED_MRG=2 BWAGPU_SEED_CHUNK=256 BWAGPU_PUBLISH_BLK=1 BWAGPU_LONG_QLDS=1 BWAGPU_SEEDSW_LDS=1 BWAGPU_DEDUP_BLK=1 BWAGPU_EXT_BLK=1",
+                                                    "BWAGPU_SEED_MRG=2", "BWAGPU_SEED_CHUNK=256", "BWAGPU_PUBLISH_BLK=1", "BWAGPU_LONG_QLDS=1", "BWAGPU_SEEDSW_LDS=1", "BWAGPU_DEDUP_BLK=1", "BWAGPU_EXT_BLK=1"]
     for r in short["runs"] + long_["runs"]:
         assert "error" not in r and r["same_result_as_defaults"] is True, r
     assert all("ms_per_step" in r and "stage_ms_solo" in r for r in short["runs"]) and all("ms_per_pass" in r for r in long_["runs"])

@@ -118,6 +118,24 @@ def wide_band_cases(rng, n):
     return cs
 
 
+def very_wide_band_cases(rng, n):
+    """The same for the four-columns-per-lane rows of the ring form (BWAGPU_EXT_BLK=1), which take another pass every 256 columns: the band
+    grows through 255..257 (and, for the longest queries, 511..513) live columns; every other case has an unrelated stretch in the middle,
+    so that the zero-trimming cuts the band inside a pass and the stale-cell rule meets slots of a block the band has left."""
+    cs = CaseSet()
+    for it in range(n):
+        qlen = int(rng.choice([250, 256, 257, 258, 300, 513, 530]))
+        w = int(rng.choice([130, 200, 255, 256, 257, 300]))
+        tlen = int(rng.integers(qlen - 10, qlen + 30))
+        t = rng.integers(0, 4, size=tlen).astype(np.uint8)
+        q = _mutate(rng, np.resize(t, qlen), float(rng.choice([0.02, 0.1, 0.25])), 0.02)[:qlen]
+        if it % 2:
+            p0 = int(rng.integers(40, len(q) - 60)); q = q.copy(); q[p0:p0 + 40] = rng.integers(0, 4, size=40)
+        h0 = int(rng.integers(len(q) + 80, len(q) + 200)) if it % 3 else int(rng.integers(20, 120))
+        cs.add(q, t, w, h0, int(rng.choice([0, 5])), int(rng.integers(0, 8)))
+    return cs
+
+
 def ref_extend(o, q, t, w, h0, eb):
     R = refapi.lib()
     outs = [C.c_int() for _ in range(5)]
@@ -177,7 +195,7 @@ def py_extend_stale_differs(o, q, t, w, h0, eb):
     return hit
 
 
-def run_extend(dev, kind, n, max_len, seed, need_stale):
+def run_extend(dev, kind, n, max_len, seed, need_stale, very_wide=0):
     rng = np.random.default_rng(seed)
     fast = stale = 0
     for oi, o in enumerate(_opts()):
@@ -196,6 +214,13 @@ def run_extend(dev, kind, n, max_len, seed, need_stale):
         for k, (q, t, w, h0, eb) in enumerate(cs.py):
             exp = ref_extend(o, q, t, w, h0, eb)
             assert out[k, :6].tolist() == exp, f"kind {kind} opt {oi} wide-band case {k}: device {out[k, :8].tolist()} reference {exp} (qlen {len(q)} tlen {len(t)} w {w} h0 {h0} eb {eb} flags {cases['flags'][k]})"
+        if very_wide:
+            cs = very_wide_band_cases(rng, very_wide)
+            cases, seqs = cs.arrays()
+            out = dev.debug_dp(o, kind, cases, seqs)
+            for k, (q, t, w, h0, eb) in enumerate(cs.py):
+                exp = ref_extend(o, q, t, w, h0, eb)
+                assert out[k, :6].tolist() == exp, f"kind {kind} opt {oi} very wide case {k}: device {out[k, :8].tolist()} reference {exp} (qlen {len(q)} tlen {len(t)} w {w} h0 {h0} eb {eb} flags {cases['flags'][k]})"
     assert fast > 0, "no case took the diagonal shortcut"
     if need_stale:
         assert stale > 0, "no case exercised the stale-cell rule"
@@ -325,6 +350,17 @@ def test_sim_ring_forms_with_the_query_in_lds(sim, monkeypatch):
     monkeypatch.setenv("BWAGPU_LONG_QLDS", "1")
     run_extend(sim, 1, 48, 400, seed=17, need_stale=False)
     run_global(sim, 3, 32, 150, 90, seed=18)
+
+
+def test_sim_ring_extension_four_columns_per_lane(sim, monkeypatch):
+    """BWAGPU_EXT_BLK=1: every DP row of the ring-mode extension (long reads) with four adjacent columns per lane, 256 columns per pass, a lane
+    reading and writing only its own {H,E} slots: same outputs as the reference's ksw_extend2 -- the fuzz families of the ring form
+    (stale-cell constructions, collapsing bands, z-drop, N bases, both strands) plus bands that grow through 255..257 and 511..513 columns;
+    with and without the LDS copy of the query."""
+    monkeypatch.setenv("BWAGPU_EXT_BLK", "1")
+    run_extend(sim, 1, 200, 400, seed=41, need_stale=False, very_wide=10)
+    monkeypatch.setenv("BWAGPU_LONG_QLDS", "1")
+    run_extend(sim, 1, 120, 400, seed=42, need_stale=False, very_wide=6)
 
 
 def test_sim_ring_global_four_columns_per_lane(sim, monkeypatch):

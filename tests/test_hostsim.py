@@ -629,10 +629,12 @@ def test_hostsim_alt_contigs(tmp_path):
     s_alt.close(); s_plain.close(); orc.close()
 
 
-def test_hostsim_long_read_patch_alignments_four_columns_per_lane(monkeypatch):
-    """BWAGPU_DEDUP_BLK=1: k_dedup_wave's score-only patch alignments (mem_patch_reg -> ksw_global2) with four adjacent columns per lane
-    (wave_global2_score_ring_blk).  A 7 kb -x pacbio read drifts out of the extension's band, so its regions are merged by a patch alignment
-    of ~7000 x 750 cells (three passes of 256 columns per row): the regions equal the compiled reference's, and the batch did run one."""
+def test_hostsim_long_read_four_columns_per_lane(monkeypatch):
+    """The long-read DP kernels with four adjacent columns per lane.  BWAGPU_DEDUP_BLK=1: k_dedup_wave's score-only patch alignments
+    (mem_patch_reg -> ksw_global2; wave_global2_score_ring_blk) -- a 7 kb -x pacbio read drifts out of the extension's band, so its regions
+    are merged by a patch alignment of ~7000 x 750 cells (three passes of 256 columns per row).  BWAGPU_EXT_BLK=1: every DP row of
+    k_extend_wave's ring form (here with the LDS copy of the read).  The regions equal the compiled reference's either way, and the batch
+    did run a patch alignment."""
     import refapi
     if not refapi.have_ref():
         pytest.skip("oracle/_ref not built (needed to index the 2 Mb genome)")
@@ -641,10 +643,13 @@ def test_hostsim_long_read_patch_alignments_four_columns_per_lane(monkeypatch):
     reads = simdata.make_reads_long(g, 1, length=7000, seed=78)
     seqs, off = testdata.flat(reads)
     want = ref.align(pacbio_opt(), seqs, off)
-    monkeypatch.setenv("BWAGPU_DEDUP_BLK", "1"); monkeypatch.setenv("BWAGPU_PTAB_M", "6")
-    s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
-    s2.set_stats(True)
-    assert_regs_equal(*want, *s2.align(pacbio_opt(), seqs, off), "7 kb -x pacbio read, patch alignment with four columns per lane")
-    st = s2.stats()
-    assert st["n_glb_calls"] >= 1 and st["n_glb_cells"] > 4_000_000, st
-    s2.close()
+    monkeypatch.setenv("BWAGPU_PTAB_M", "6")
+    for env in ({"BWAGPU_DEDUP_BLK": "1"}, {"BWAGPU_EXT_BLK": "1", "BWAGPU_LONG_QLDS": "1"}):
+        for k in ("BWAGPU_DEDUP_BLK", "BWAGPU_EXT_BLK", "BWAGPU_LONG_QLDS"):
+            monkeypatch.setenv(k, env.get(k, "0"))
+        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+        s2.set_stats(True)
+        assert_regs_equal(*want, *s2.align(pacbio_opt(), seqs, off), f"7 kb -x pacbio read, {env}")
+        st = s2.stats()
+        assert st["n_glb_calls"] >= 1 and st["n_glb_cells"] > 4_000_000 and st["n_ext_cells"] > 1_000_000, st
+        s2.close()

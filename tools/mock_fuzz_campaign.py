@@ -17,12 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-DP_ENVS = [{}, {"BWAGPU_LONG_QLDS": "1"}, {"BWAGPU_DEDUP_BLK": "1"}]
+DP_ENVS = [{}, {"BWAGPU_LONG_QLDS": "1"}, {"BWAGPU_DEDUP_BLK": "1", "BWAGPU_EXT_BLK": "1"}, {"BWAGPU_EXT_BLK": "1", "BWAGPU_LONG_QLDS": "1"}]
 OPT_ENVS = [
     {},
     {"BWAGPU_SEED_MRG": "1"},
     {"BWAGPU_SEED_MRG": "2", "BWAGPU_SEED_LDS_ENT": "2"},
-    {"BWAGPU_SEED_MRG": "2", "BWAGPU_PUBLISH_BLK": "1", "BWAGPU_LONG_QLDS": "1", "BWAGPU_SEEDSW_LDS": "1", "BWAGPU_SEED_CHUNK": "128"},
+    {"BWAGPU_SEED_MRG": "2", "BWAGPU_PUBLISH_BLK": "1", "BWAGPU_LONG_QLDS": "1", "BWAGPU_SEEDSW_LDS": "1", "BWAGPU_SEED_CHUNK": "128", "BWAGPU_DEDUP_BLK": "1", "BWAGPU_EXT_BLK": "1"},
     {"BWAGPU_SEED_CHUNK": "256", "BWAGPU_SEEDSW_LDS": "1"},
     {"BWAGPU_OCC32": "0"},
     {"BWAGPU_PTAB_M": "6", "BWAGPU_SEED_LDS_ENT": "3"},
@@ -81,7 +81,7 @@ def main():
         if args.only != "opt":
             env = DP_ENVS[rounds % len(DP_ENVS)]
             attempt("extend", env, lambda: dp.run_extend(sim, 0, 400, 200, seed, need_stale=False))
-            attempt("extend_ring", env, lambda: dp.run_extend(sim, 1, 150, 400, seed, need_stale=False))
+            attempt("extend_ring", env, lambda: dp.run_extend(sim, 1, 150, 400, seed, need_stale=False, very_wide=6))
             attempt("global_lds", env, lambda: dp.run_global(sim, 2, 200, 160, 192, seed))
             attempt("global_ring", env, lambda: dp.run_global(sim, 3, 100, 200, 1 << 30, seed))
             attempt("global_ring_wide", env, lambda: dp.run_global(sim, 3, 32, 900, 1 << 30, seed + 1, wide=(63, 64, 127, 128, 129, 200, 255, 256, 257, 300, 383, 384, 385)))

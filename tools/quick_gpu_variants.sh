@@ -23,5 +23,7 @@ run long BWAGPU_PUBLISH_BLK=1
 run long BWAGPU_LONG_QLDS=1
 run long BWAGPU_SEEDSW_LDS=1
 run long BWAGPU_DEDUP_BLK=1
-run long BWAGPU_SEED_MRG=2 BWAGPU_SEED_CHUNK=256 BWAGPU_PUBLISH_BLK=1 BWAGPU_LONG_QLDS=1 BWAGPU_SEEDSW_LDS=1 BWAGPU_DEDUP_BLK=1
+run long BWAGPU_EXT_BLK=1
+run long BWAGPU_EXT_BLK=1 BWAGPU_LONG_QLDS=1
+run long BWAGPU_SEED_MRG=2 BWAGPU_SEED_CHUNK=256 BWAGPU_PUBLISH_BLK=1 BWAGPU_LONG_QLDS=1 BWAGPU_SEEDSW_LDS=1 BWAGPU_DEDUP_BLK=1 BWAGPU_EXT_BLK=1
 exit $rc
