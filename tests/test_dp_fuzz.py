@@ -412,3 +412,15 @@ def test_gpu_global_fuzz(gpu):
 @pytest.mark.gpu
 def test_gpu_align2_fuzz(gpu):
     run_align2(gpu, 5000, 26)
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="BWAGPU_EXT_BLK / BWAGPU_DEDUP_BLK are opt-in kernel forms written after the round's last GPU second: mock runtime, "
+                                        "sanitizers and static ISA only so far.  Their first hardware run is informational (xpassed = same outputs as the reference's "
+                                        "ksw_extend2 / ksw_global2 on the device) and must not take the suite of the product's default kernels with it.")
+def test_gpu_ring_forms_four_columns_per_lane(gpu, monkeypatch):
+    monkeypatch.setenv("BWAGPU_EXT_BLK", "1"); monkeypatch.setenv("BWAGPU_DEDUP_BLK", "1")
+    run_extend(gpu, 1, 3000, 400, 43, need_stale=True, very_wide=40)
+    run_global(gpu, 3, 2000, 1000, 1 << 30, 44, wide=(63, 64, 127, 128, 129, 200, 255, 256, 257, 300, 383, 384, 385, 500))
+    monkeypatch.setenv("BWAGPU_LONG_QLDS", "1")
+    run_extend(gpu, 1, 1000, 400, 45, need_stale=False, very_wide=20)
