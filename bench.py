@@ -212,10 +212,13 @@ def main():
     ap.add_argument("--long-reads", type=int, default=6000)
     ap.add_argument("--long-len", type=int, default=10000)
     ap.add_argument("--long-steps", type=int, default=2)
-    ap.add_argument("--long-sample", type=int, default=128, help="reads of the long-read CPU-baseline / parity prefix")
+    ap.add_argument("--long-sample", type=int, default=2000, help="reads of the long-read CPU-baseline / parity prefix (the reference does ~200 reads/s on 16 threads: ~10 s); "
+                    "the product aligns them in >= 9 batches, three per device handle")
     ap.add_argument("--e2e-handles", type=int, default=5, help="a second FASTQ->SAM run of the paired-end sample with this many batches in flight (BWAGPU_CLI_STREAMS; the default run uses 3); 0 = skip")
-    ap.add_argument("--variants", default="BWAGPU_SEED_MRG=1;BWAGPU_SEED_MRG=2", help="';'-separated environment settings to A/B against the defaults in a child process (tools/variant_probe.py); '' = none")
-    ap.add_argument("--variants-timeout", type=float, default=100.0, help="seconds for the short-read child process (the long-read one gets 0.8 of it)")
+    ap.add_argument("--variants", default="seed_mrg=2", help="';'-separated library option settings (bwagpu_set_option names) to A/B against the defaults in a child process (tools/variant_probe.py); '' = none")
+    ap.add_argument("--timed-sample", type=int, default=20000, help="reads of timed batch 0 whose regions are compared with the compiled reference's mem_align1_core (parity.timed_batch); 0 = skip")
+    ap.add_argument("--instr-pairs", type=int, default=30000, help="pairs the counter-instrumented reference runs on (b_alg_per_read)")
+    ap.add_argument("--variants-timeout", type=float, default=70.0, help="seconds for the short-read child process (the long-read one gets 0.8 of it)")
     ap.add_argument("--wall-budget", type=float, default=330.0, help="seconds since start after which no variants child may still run: the two legs share what is left "
                     "when the line's own measurements are done (they end first; a leg that gets less than 20 s is skipped)")
     args = ap.parse_args()
@@ -349,14 +352,27 @@ def main():
     dur = {"k_seed": stage_ms["ms_seed"], "k_sa": stage_ms["ms_sa"], "k_chain": stage_ms["ms_chain"], "k_extend_wave": stage_ms["ms_extend"], "k_dedup": stage_ms["ms_dedup"]}
     roof_k = max(dur, key=lambda k: dur[k])           # the longest kernel, whatever it is
     achieved = alg[roof_k] / (dur[roof_k] * 1e-3) / 1e9
-    traffic, traffic_src = None, None
+    # HBM-side traffic of that kernel from the PMC counters of an earlier profiling run of the same workload (tools/profile_round.sh; separate
+    # --pmc passes).  FETCH_SIZE counts 64 bytes per request whatever its size on this chip (profiles/r03_fetch_calibration.md: 64-byte reads
+    # 1.00x, 32-byte reads 2.00x), so for a kernel whose fetches are 32-byte index blocks and 16-byte table entries the raw figure over-counts:
+    # `traffic` is the corrected one (fetch / 2 + write for the 32-byte layout), the raw counters and the request count are beside it.
+    traffic, traffic_src, traffic_detail = None, None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
-            traffic = pj.get(roof_k, {}).get("hbm_bytes_per_launch")
-            if roof_k == "k_seed" and traffic and "k_seed3" in pj:     # the seeding stage is two kernels since round 2 (pass 3 runs first)
-                traffic += pj["k_seed3"].get("hbm_bytes_per_launch", 0.0)
+            names = [roof_k] + (["k_seed3"] if roof_k == "k_seed" else [])     # the seeding stage is two kernels since round 2 (pass 3 runs first)
+            fetch = sum(pj.get(k_, {}).get("FETCH_SIZE_KB", 0.0) / max(1, pj.get(k_, {}).get("launches_seen", 1)) for k_ in names) * 1024.0
+            write = sum(pj.get(k_, {}).get("WRITE_SIZE_KB", 0.0) / max(1, pj.get(k_, {}).get("launches_seen", 1)) for k_ in names) * 1024.0
+            if fetch > 0:
+                factor = 0.5 if (roof_k in ("k_seed", "k_sa") and occ32) else 1.0
+                traffic = fetch * factor + write
+                traffic_detail = {"raw_bytes": fetch + write, "fetch_raw_bytes": fetch, "write_bytes": write, "fetch_correction": factor,
+                                  "fetch_requests": fetch / 64.0, "corrected_over_device_layout_alg": None,
+                                  "why": "FETCH_SIZE counts 64 bytes per request; this kernel's requests are 32-byte blocks and 16-byte entries (profiles/r03_fetch_calibration.md)" if factor != 1.0 else "64-byte requests: counter taken as is"}
+            if traffic_detail:
+                dev_alg = alg[roof_k] - (64.0 - blk_bytes) * work["n_occ_blocks"] if roof_k == "k_seed" else alg[roof_k]
+                traffic_detail["corrected_over_device_layout_alg"] = round(traffic / dev_alg, 3) if dev_alg > 0 else None
             traffic_src = ("NOT measured in this run: read from profiles/pmc_latest.json (" + str(pj.get("_meta", {}).get("what", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes")) +
                            ", taken " + str(pj.get("_meta", {}).get("date", "in an earlier run of the same workload")) + ")")
         except Exception:
@@ -368,7 +384,8 @@ def main():
     n_blk, n_tab = work["n_occ_blocks"], work["n_tab_lookups"]
     seed_s = stage_ms["ms_seed"] * 1e-3
     out = {
-        "metric": "Mreads/s (whole job), 2x150 bp vs GRCh38-scale index, resident hot path (mem_align1_core of every read); SAM parity gate vs bwa mem; FASTQ->SAM rate under end_to_end_pe",
+        "metric": "Mreads/s (whole job) 2x150 bp vs GRCh38-scale index; SAM bit-identical to bwa mem (gate: `parity`).  `value` = the hot path (mem_align1_core of every read) on batches resident in HBM, "
+                  "as the bench contract times it; the SAM-producing FASTQ->SAM rate of the same build is `end_to_end_pe.value` (also in `summary`)",
         "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int32/u64 (integer DP + FM-index ranks)", "data": "synthetic",
@@ -378,7 +395,7 @@ def main():
                    "sharding": f"reads x{world}, no collective", "batches_in_flight": S, "result_sha256_16": digest,
                    "timed": "kernels of the hot path on batches resident in HBM (no PCIe, no host finalize); see end_to_end_* for FASTQ->SAM"},
         "roofline": {"bound": "hbm", "kernel": roof_k + (" (+ k_seed3: the seeding stage)" if roof_k == "k_seed" else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_detail": traffic_detail, "traffic_source": traffic_src,
                      "alg_bytes_per_launch": alg[roof_k], "kernel_ms": round(dur[roof_k], 3),
                      "alg_bytes_note": "SURVEY 8(d)'s unit: 64 bytes per Occ block of the REFERENCE layout (N_blk counted per rank-query pair exactly as bwt_2occ4 does, 1 if k and l share a 128-base block else 2), "
                                        f"16 bytes per prefix-table entry, l_seq/2 for the read; the device's own index blocks are {int(blk_bytes)} bytes, see achieved_device_layout",
@@ -437,10 +454,16 @@ def main():
             par["pe_product_Mreads_s"] = round(our_pe["reads_per_s"] / 1e6, 4)
             if world > 1:
                 par["devices"] = devices
+        if args.timed_sample > 0:
+            log(f"[bench] parity of the timed batch: {args.timed_sample} reads of batch 0 vs the compiled reference's mem_align1_core")
+            try:
+                par["timed_batch"] = timed_batch_parity(prefix, opt, batches[0], counts, regs, args.timed_sample, threads)
+            except Exception as e:
+                par["timed_batch"] = {"ok": False, "error": repr(e)}
         out["parity"] = par
         # B_alg per read: the reference's own counts on a prefix of the paired-end sample next to what the device path does for
         # the same result (prefix tables replace short-match steps: N_blk falls, 16-byte look-ups appear; the SA is denser: N_lf falls)
-        n_i = min(n_mb, 100_000)
+        n_i = min(n_mb, max(1000, args.instr_pairs))
         fi1, fi2 = os.path.join(cache, "instr_1.fq"), os.path.join(cache, "instr_2.fq")
         simdata.write_fastq(fi1, p1[:n_i], suffix="/1"); simdata.write_fastq(fi2, p2[:n_i], suffix="/2")
         ins = run_instrumented(prefix, [fi1, fi2], threads)
@@ -455,7 +478,7 @@ def main():
             out["b_alg_per_read"]["reference"] = {"bytes": round(ref_b, 0), **{k_: round(v_, 2) for k_, v_ in ins.items() if k_ != "n_reads"}, "sa_intv": 32,
                                                   "how": f"oracle/_ref/bwa_instr (counters patched into a scratch copy of bwt.c/ksw.c/bwamem.c at build time) on {ins['n_reads']} reads of the paired-end sample; "
                                                          "B_alg = 64 N_blk + 64 N_lf + 8 N_sa + W_ref/4 + l_seq + 88 n_regs"}
-        if not (par["se"] and par["pe"] and par["multibatch"]):
+        if not (par["se"] and par["pe"] and par["multibatch"]) or (par.get("timed_batch") is not None and not par["timed_batch"].get("ok")):
             rc_exit = 3
             log("[bench] PARITY GATE FAILED:", par)
         note = f"`bwa mem -t {threads}`, whole mem_process_seqs incl. SAM text, rate from its own per-batch real-time lines; the box exposes {os.cpu_count()} hardware threads but its cgroup quota is {threads} CPUs"
@@ -493,7 +516,7 @@ def main():
         if world == 1 and not args.no_longread:
             try:
                 out["longread"] = longread_bench(args, prefix, g, threads, cache)
-                if out["longread"].get("parity") is False:
+                if out["longread"].get("parity") is False or out["longread"].get("multibatch") is False:
                     rc_exit = 3
                     log("[bench] LONG-READ PARITY GATE FAILED")
             except Exception as e:   # (the long-read leg must not take the headline line with it)
@@ -501,13 +524,50 @@ def main():
     if world == 1 and args.variants.strip() and not args.no_cpu_baseline:      # (a full run only: the profiling runs pass --no-cpu-baseline)
         out["variants"] = run_variants(args, prefix, variant_files, max(0.0, args.wall_budget - (time.time() - _T0)))
     out["bench_wall_s"] = round(time.time() - t_all, 1)
+    # last on the line (a truncated tail of stdout still shows it) and once more on stderr: the numbers and the gates in one small object
+    par_ = out.get("parity", {}); lr_ = out.get("longread", {}) if isinstance(out.get("longread"), dict) else {}
+    out["summary"] = {"value_hot_path_Mreads_s": out["value"], "end_to_end_pe_Mreads_s": out.get("end_to_end_pe", {}).get("value"), "roofline_frac": out["roofline"]["frac"],
+                      "cpu_baseline_Mreads_s": out.get("cpu_baseline", {}).get("value"),
+                      "parity": {"se": par_.get("se"), "pe": par_.get("pe"), "multibatch": par_.get("multibatch"), "timed_batch": (par_.get("timed_batch") or {}).get("ok"),
+                                 "long": lr_.get("parity"), "long_reads": lr_.get("parity_reads"), "long_multibatch": lr_.get("multibatch")},
+                      "longread_reads_s": lr_.get("reads_per_s"), "rc": rc_exit}
+    log("[bench] SUMMARY " + json.dumps(out["summary"]))
     sys.stdout.flush()
     print(json.dumps(out), flush=True)      # the one JSON line, last thing on stdout (RCCL prints a version banner of its own at start-up)
     sys.exit(rc_exit)
 
 
+def timed_batch_parity(prefix, opt, reads, counts, regs, n_s, threads):
+    """The regions the TIMED loop left for the first n_s reads of batch 0 against the compiled reference's mem_align1_core on the same reads
+    (tests/refapi.py -> oracle/_ref/libbwaref.so; the reference's call is per read, so the slices run on `threads` host threads)."""
+    import threading
+    import refapi
+    if not refapi.have_ref() or n_s <= 0:
+        return None
+    t = time.time()
+    ref = refapi.RefIndex(prefix)
+    t_load = time.time() - t
+    n_s = min(n_s, reads.shape[0])
+    L = reads.shape[1]
+    cuts = np.linspace(0, n_s, max(1, min(threads, n_s // 64 or 1)) + 1).astype(np.int64)
+    parts = [None] * (len(cuts) - 1)
+
+    def work(i):
+        a, b = int(cuts[i]), int(cuts[i + 1])
+        sub = np.ascontiguousarray(reads[a:b].reshape(-1))
+        parts[i] = ref.align(opt, sub, np.arange(0, b - a + 1, dtype=np.int64) * L)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(parts))]
+    [x.start() for x in th]; [x.join() for x in th]
+    ref.close()
+    rc = np.concatenate([p_[0] for p_ in parts]); rr = np.concatenate([p_[1] for p_ in parts])
+    n_regs = int(counts[:n_s].sum())
+    same = bool(np.array_equal(rc, counts[:n_s]) and rr.tobytes() == regs[:n_regs].tobytes())
+    return {"ok": same, "reads": int(n_s), "regions": n_regs, "seconds": round(time.time() - t, 1), "index_load_s": round(t_load, 1),
+            "how": "first reads of timed batch 0: counts + 88-byte mem_alnreg_t records downloaded after the timed loop == the compiled reference's mem_align1_core (refshim_align) on the same reads, byte for byte"}
+
+
 def run_variants(args, prefix, batch_files=(), wall_left=1e9):
-    """Kernel variants that sit behind environment switches, A/B'd against the defaults on the headline's workload by tools/variant_probe.py
+    """Kernel variants that sit behind library options (bwagpu_set_option), A/B'd against the defaults on the headline's workload by tools/variant_probe.py
     in a CHILD process with a time limit: solo stage times, step time with the same batches in flight, and a digest of the regions that
     must equal the defaults'.  Informational -- `value` above is always the default configuration's; a variant that faults or hangs costs
     this object its entries and nothing else."""
@@ -529,8 +589,8 @@ def run_variants(args, prefix, batch_files=(), wall_left=1e9):
             res[name] = {"skipped": f"{left:.0f} s of --wall-budget left"}
             continue
         if name == "long_reads":
-            # the long-read switches, all together and each alone (they exist for long-read batches only; BWAGPU_SEED_MRG=2 is the last short-read entry)
-            alone = [cfgs[-1], "BWAGPU_SEED_CHUNK=256", "BWAGPU_PUBLISH_BLK=1", "BWAGPU_LONG_QLDS=1", "BWAGPU_SEEDSW_LDS=1", "BWAGPU_DEDUP_BLK=1", "BWAGPU_EXT_BLK=1"]
+            # the long-read defaults of round 4 against the forms they replaced: all of round 3's together (what BENCH_r03's `longread` ran), then each alone
+            alone = ["seed_mrg=0", "seed_chunk=0", "publish_blk=0", "seedsw_lds=0", "dedup_blk=0"]
             cfgs = [" ".join(alone)] + alone          # (all together first: the entry to have if the leg runs out of its time)
         log(f"[bench] variants, {name} (child process, <= {limit:.0f} s): {cfgs}")
         t = time.time()
@@ -606,18 +666,22 @@ def longread_bench(args, prefix, g, threads, cache):
            "gcups": round(cells / (dp_ms * 1e-3) / 1e9, 1) if dp_ms > 0 else None,
            "gcups_note": "extension + patch (score-only global) + seed re-scoring cells / the three kernels' time; the final CIGARs' cells are counted under end_to_end"}
     # ---- reference and product command lines on a prefix ----
+    # (-K a tenth of the prefix's bases: the product's three device handles each see three or four batches -- arenas, learnt sizes, the long CIGAR
+    # tier's scratch re-used from batch to batch; single-end SAM does not depend on the batching, the reference gets the same -K anyway)
     n_p = min(args.long_sample, n)
+    K_long = max(L + 1, n_p * L // 10)
     fq = os.path.join(cache, "long_sample.fq")
     simdata.write_fastq(fq, reads[:n_p])
-    ref = run_reference(prefix, [fq], threads, os.path.join(cache, "ref_long.sam"), extra=["-x", "pacbio"], timeout=150)
-    our = run_product(prefix, [fq], threads, os.path.join(cache, "our_long.sam"), extra=["-x", "pacbio"], timeout=150)
+    ref = run_reference(prefix, [fq], threads, os.path.join(cache, "ref_long.sam"), K=K_long, extra=["-x", "pacbio"], timeout=150)
+    our = run_product(prefix, [fq], threads, os.path.join(cache, "our_long.sam"), K=K_long, extra=["-x", "pacbio"], timeout=150)
     if ref:
         res["cpu_baseline"] = {"value": round(ref["reads_per_s"], 1), "unit": "reads/s", "cores": threads, "kind": "reference",
                                "sample": f"first {n_p} reads, `bwa mem -x pacbio -t {threads} -K 100000000`, rate from its own per-batch real-time lines; {ref['wall_s']:.1f}s wall"}
     # ---- the product on the whole batch: FASTQ -> SAM rate with the CIGARs, NM and MD of the long alignments computed on the device ----
     fq_all = os.path.join(cache, "long_all.fq")
     simdata.write_fastq(fq_all, reads)
-    e2e = run_product(prefix, [fq_all], threads, None, extra=["-x", "pacbio"], timeout=200, K=max(1000000, n * L // 3 + L))      # one batch per device handle: the long-read kernels are latency-bound (a 1000-read batch takes what a 6000-read one does)
+    e2e_sam = os.path.join(cache, "our_long_all.sam")
+    e2e = run_product(prefix, [fq_all], threads, e2e_sam, extra=["-x", "pacbio"], timeout=200, K=max(1000000, n * L // 3 + L))      # one batch per device handle
     if e2e:
         res["end_to_end"] = {"reads_per_s": round(e2e["reads_per_s"], 1), "Mbp_per_s": round(e2e["reads_per_s"] * L / 1e6, 2), "stages": e2e["stages"],
                              "device_stage_ms_per_batch": e2e["device_stage_ms_per_batch"],
@@ -625,7 +689,31 @@ def longread_bench(args, prefix, g, threads, cache):
     if ref and our:
         a, b = sam_body_digest(os.path.join(cache, "ref_long.sam")), sam_body_digest(os.path.join(cache, "our_long.sam"))
         res["parity"] = bool(a == b and a[1] >= n_p)
-        res["parity_records"] = a[1]
+        res["parity_records"] = a[1]; res["parity_reads"] = n_p
+        res["parity_batches"] = our["n_batches"]; res["parity_handles"] = our["handles"]
+        res["multibatch"] = bool(res["parity"] and our["n_batches"] >= 3 * (our["handles"] or 3))
+        res["parity_how"] = f"sha256 of the SAM text minus @PG: oracle/_ref/bwa mem -x pacbio vs bwa-amd mem -x pacbio on the first {n_p} reads, -K {K_long} on both sides"
+        if e2e and res["parity"]:
+            # the whole batch's FASTQ -> SAM run (three batches of n/3 reads, full-size arenas): its records for the first n_p reads must be the reference's too
+            def body(path, limit):
+                out_ = []
+                with open(path, "rb") as f:
+                    for line in f:
+                        if line[:1] != b"@":
+                            out_.append(line)
+                            if len(out_) >= limit:
+                                break
+                return out_
+            want = body(os.path.join(cache, "ref_long.sam"), 1 << 60)
+            got = body(e2e_sam, len(want))
+            res["parity_full_run_prefix"] = bool(want == got)
+            if not res["parity_full_run_prefix"]:
+                res["parity"] = False
+    if e2e:
+        try:
+            os.remove(e2e_sam)
+        except OSError:
+            pass
     return res
 
 

@@ -56,6 +56,7 @@ EXPORTS = [
     "bwagpu_free", "bwagpu_batch_upload", "bwagpu_batch_run", "bwagpu_batch_download", "bwagpu_set_taps", "bwagpu_tap_intervals",
     "bwagpu_tap_chains", "bwagpu_tap_regs_raw", "bwagpu_index_buffers", "bwagpu_index_export", "bwagpu_clone", "bwagpu_index_ready",
     "bwagpu_batch_cigars", "bwagpu_batch_cigar_ops", "bwagpu_debug_phase", "bwagpu_batch_matesw", "bwagpu_clone_to_device", "bwagpu_index_build", "bwagpu_built_free", "bwagpu_abi_sizes", "bwagpu_debug_prof", "bwagpu_debug_dp", "bwagpu_set_cigar_filter", "bwagpu_batch_reserve",
+    "bwagpu_set_option", "bwagpu_get_option", "bwagpu_set_default_option", "bwagpu_clear_default_options", "bwagpu_option_name",
 ]
 
 
@@ -102,16 +103,38 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.bwagpu_index_buffers.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     L.bwagpu_index_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bwagpu_debug_dp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.bwagpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
+    L.bwagpu_get_option.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+    L.bwagpu_set_default_option.argtypes = [C.c_char_p, C.c_longlong]
+    L.bwagpu_clear_default_options.restype = None
+    L.bwagpu_option_name.argtypes = [C.c_int, C.c_void_p]
     return L
+
+
+def option_names(L: C.CDLL) -> list:
+    """The library's option list (bwa_amd/csrc/bwagpu_config.h), as bwagpu_option_name enumerates it."""
+    out, i, p = [], 0, C.c_char_p()
+    while L.bwagpu_option_name(i, C.byref(p)) == 0:
+        out.append(p.value.decode()); i += 1
+    return out
 
 
 class BwaGpu:
     """One handle = one GPU with the index resident in HBM."""
 
-    def __init__(self, prefix: str, device: int = 0, lib_path: str | None = None):
+    def __init__(self, prefix: str, device: int = 0, lib_path: str | None = None, options: dict | None = None):
+        """options: {name: integer} of include/bwagpu.h's option list -- given to the library as defaults for the handle being created (so
+        that the ones shaping what is derived from the index at load time -- occ32, occ32_sb_shift, ptab_m -- apply) and forgotten again."""
         self.L = load_library(lib_path)
         self.h = C.c_void_p()
-        rc = self.L.bwagpu_create_from_files(C.byref(self.h), prefix.encode(), device)
+        try:
+            for k, v in (options or {}).items():
+                if self.L.bwagpu_set_default_option(k.encode(), int(v)) != 0:
+                    raise BwaGpuError(f"unknown option {k!r}")
+            rc = self.L.bwagpu_create_from_files(C.byref(self.h), prefix.encode(), device)
+        finally:
+            if options:
+                self.L.bwagpu_clear_default_options()
         if rc != 0:
             raise BwaGpuError(f"bwagpu_create_from_files({prefix}) failed: {self.L.bwagpu_strerror(rc).decode()}")
         self.set_taps(True)     # the library's default is off (a second region arena per batch); the tests read the stage taps, bench.py turns them off
@@ -173,6 +196,15 @@ class BwaGpu:
 
     def set_stats(self, on=True):
         self._chk(self.L.bwagpu_set_stats(self.h, int(on)))
+
+    def set_option(self, name: str, value: int):
+        """bwagpu_set_option: one of the handle's tuning / test options (bwa_amd/csrc/bwagpu_config.h), between batches."""
+        self._chk(self.L.bwagpu_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_longlong()
+        self._chk(self.L.bwagpu_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def set_taps(self, on=True):
         self._chk(self.L.bwagpu_set_taps(self.h, int(on)))

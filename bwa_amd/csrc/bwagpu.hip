@@ -22,6 +22,7 @@
 #include <vector>
 #include <chrono>
 
+#include "bwagpu_config.h"
 #include "dev_common.h"
 #include "dev_fm.h"
 #include "dev_sort.h"
@@ -59,6 +60,7 @@ struct bwagpu_s {
 	hipEvent_t ev[8] = {};
 	hipEvent_t ev_wait = nullptr;    // blocking-sync event: waiting for the stream must not spin on a host core (see wait_stream)
 	std::string err;
+	BwagpuConfig cfg;               // tuning and test options (bwagpu_config.h): environment read once at creation, then bwagpu_set_option
 	// index
 	DevIndex ix = {};
 	struct IndexBufs {
@@ -133,11 +135,14 @@ struct ResultPool {
 	std::map<void*, size_t> live;                   // blocks handed out -> capacity
 	std::multimap<size_t, void*> idle;              // capacity -> block
 	size_t pinned = 0;
+	std::atomic<long long> on{1}, min_kb{1024};
+	std::atomic<bool> inited{false};                // settings taken from a handle's options (init_config) or, for a block asked for before any handle exists, from the environment
 	const size_t cap_total = (size_t)4 << 30;
 	void *get(size_t bytes)
 	{
-		const bool enabled = !(getenv("BWAGPU_PINNED_RESULTS") && atoi(getenv("BWAGPU_PINNED_RESULTS")) == 0);
-		const size_t min_bytes = getenv("BWAGPU_PINNED_MIN_KB") ? (size_t)atoll(getenv("BWAGPU_PINNED_MIN_KB")) << 10 : (size_t)1 << 20;   // (tests: 0 pools everything)
+		if (!inited.exchange(true)) { BwagpuConfig c; c.from_env(); on = c.pinned_results; min_kb = c.pinned_min_kb < 0 ? 0 : c.pinned_min_kb; }
+		const bool enabled = on.load() != 0;                       // (options pinned_results / pinned_min_kb: process-wide, set whenever a handle is created or the option is set)
+		const size_t min_bytes = (size_t)min_kb.load() << 10;
 		if (!enabled || bytes < min_bytes) return malloc(bytes ? bytes : 1);
 		size_t step = (size_t)1 << 20;                 // block sizes: multiples of 1 MiB up to 8 MiB, then of a quarter of the power of two below
 		while (step * 8 <= bytes) step <<= 1;
@@ -184,6 +189,61 @@ static int upload(bwagpu_t *h, DevBuf &b, const void *src, size_t bytes)
 	if (b.ensure(bytes ? bytes : 16)) { h->err = "hipMalloc failed"; return BWAGPU_ENOMEM; }
 	if (bytes) HIPCHK(h, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
 	return 0;
+}
+
+// ---- options (bwagpu_config.h) ----------------------------------------------------------------------------------------------
+namespace {
+std::mutex g_cfg_m;
+std::map<std::string, long long> g_cfg_defaults;     // bwagpu_set_default_option: applied to handles created afterwards, on top of the environment
+}
+static void init_config(BwagpuConfig &c)
+{
+	c = BwagpuConfig();
+	c.from_env();
+	std::lock_guard<std::mutex> l(g_cfg_m);
+	for (auto &kv : g_cfg_defaults) if (long long *f = c.field(kv.first.c_str())) *f = kv.second;
+	g_results.on = c.pinned_results; g_results.min_kb = c.pinned_min_kb < 0 ? 0 : c.pinned_min_kb; g_results.inited = true;
+}
+extern "C" int bwagpu_set_default_option(const char *key, long long value)
+{
+	BwagpuConfig probe;
+	if (!probe.field(key)) return BWAGPU_EINVAL;
+	std::lock_guard<std::mutex> l(g_cfg_m);
+	g_cfg_defaults[key] = value;
+	return BWAGPU_OK;
+}
+extern "C" void bwagpu_clear_default_options(void) { std::lock_guard<std::mutex> l(g_cfg_m); g_cfg_defaults.clear(); }
+extern "C" int bwagpu_set_option(bwagpu_t *h, const char *key, long long value)
+{
+	if (!h) return BWAGPU_EINVAL;
+	long long *f = h->cfg.field(key);
+	if (!f) return BWAGPU_EINVAL;
+	// the index-side options shape what bwagpu_create / bwagpu_index_ready derive from the index: per handle they can only be set before that
+	// happens (a handle created with NULL arrays, ahead of the broadcast); otherwise use bwagpu_set_default_option before creating the handle
+	if ((f == &h->cfg.occ32 || f == &h->cfg.occ32_sb_shift || f == &h->cfg.ptab_m) && (h->ix.occ32 || h->ix.ptab) && *f != value) return BWAGPU_EINVAL;
+	*f = value;
+	if (f == &h->cfg.pinned_results) g_results.on = value;
+	if (f == &h->cfg.pinned_min_kb) g_results.min_kb = value < 0 ? 0 : value;
+	return BWAGPU_OK;
+}
+extern "C" int bwagpu_get_option(const bwagpu_t *h, const char *key, long long *value)
+{
+	if (!h || !value) return BWAGPU_EINVAL;
+	const long long *f = const_cast<bwagpu_t*>(h)->cfg.field(key);
+	if (!f) return BWAGPU_EINVAL;
+	*value = *f;
+	return BWAGPU_OK;
+}
+extern "C" int bwagpu_option_name(int i, const char **name)
+{
+	static const char *const names[] = {
+#define X(n, d) #n,
+		BWAGPU_OPTION_LIST(X)
+#undef X
+	};
+	if (!name || i < 0 || i >= (int)(sizeof names / sizeof names[0])) return BWAGPU_EINVAL;
+	*name = names[i];
+	return BWAGPU_OK;
 }
 
 // ---- prefix tables (DevIndex::ptab): level j from level j-1 with the sweep's own extension ----------------------------------
@@ -264,14 +324,13 @@ __global__ void __launch_bounds__(256) k_occ32_blocks(DevIndex ix, const u64 *sb
 // The seeding and SA kernels read this layout (default; BWAGPU_OCC32=0 keeps them on the reference-format blocks): built from the resident
 // reference-format blocks, which stay the interchange format (files, index broadcast, bwagpu_index_buffers).  Measured at 3.1 Gbp
 // (profiles/r03_seed_variants.md): k_seed 94.6 ms on the 64-byte blocks, 84.6 ms on these -- and 134.5 ms with the 64-byte blocks fetched
-// quad-cooperatively (BWAGPU_SEED_COOP=1), although that fetch pattern moves the chip's random-block ceiling from 22.9e9 to 51.3e9 per second
-// (tools/randbw3.hip): the kernel asks for 14.6e9 blocks per second, it is bound by its ~1000 vector instructions per wave iteration and by the
-// latency of the dependent chain at 4 waves per SIMD, and the cooperative form adds instructions and registers (3 waves per SIMD) to both.
+// quad-cooperatively (a round-3 variant, deleted in round 4), although that fetch pattern moves the chip's random-block ceiling from 22.9e9 to
+// 51.3e9 per second (tools/randbw3.hip): the cooperative form adds instructions and registers (3 waves per SIMD) in front of every trip.
 static int build_occ32(bwagpu_t *h)
 {
 	h->ix.occ32 = nullptr; h->ix.occ_sb = nullptr; h->ix.occ_sbx = nullptr; h->ix.occ_sb_shift = 32; h->ix.occ32_bytes = h->ix.occ_sbx_bytes = 0;
-	if ((getenv("BWAGPU_OCC32") && atoi(getenv("BWAGPU_OCC32")) == 0) || h->bwt_blocks == 0) return 0;   // (BWAGPU_OCC32=0: keep to the reference-format blocks)
-	int shift = getenv("BWAGPU_OCC32_SB_SHIFT") ? atoi(getenv("BWAGPU_OCC32_SB_SHIFT")) : 32;      // (tests: small superblocks on small genomes)
+	if (h->cfg.occ32 == 0 || h->bwt_blocks == 0) return 0;   // (option occ32 = 0: keep to the reference-format blocks)
+	int shift = (int)h->cfg.occ32_sb_shift;      // (tests: small superblocks on small genomes)
 	if (shift < 8) shift = 8; if (shift > 32) shift = 32;
 	const int sh = shift - 6;
 	const u64 n_new = (u64)h->bwt_blocks * 2, n_sb = (n_new >> sh) + 1;
@@ -323,6 +382,7 @@ extern "C" int bwagpu_create(bwagpu_t **out, const bwagpu_index_desc_t *d, int d
 	bwagpu_t *h = new bwagpu_s();
 	h->device = device;
 	h->ibuf = new bwagpu_s::IndexBufs();
+	init_config(h->cfg);
 	int rc;
 	if (hipStreamCreate(&h->stream) != hipSuccess) { h->stream = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
 	for (int i = 0; i < 8; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { h->ev[i] = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
@@ -358,9 +418,8 @@ extern "C" int bwagpu_create(bwagpu_t **out, const bwagpu_index_desc_t *d, int d
 	h->h_ctg_alt.assign(d->ctg_is_alt, d->ctg_is_alt + d->n_seqs);
 	h->ix.ptab = nullptr; h->ix.ptab_m = 0; h->ix.ptab_bytes = 0; h->ix.occ32 = nullptr; h->ix.occ_sb = nullptr; h->ix.occ_sbx = nullptr; h->ix.occ32_bytes = h->ix.occ_sbx_bytes = 0;
 	if (!alloc_only) {   // (a handle that receives its index by broadcast builds them in bwagpu_index_ready)
-		int m = getenv("BWAGPU_PTAB_M") ? atoi(getenv("BWAGPU_PTAB_M")) : 10;
 		if ((rc = build_occ32(h))) goto fail;
-		if ((rc = build_prefix_tables(h, m))) goto fail;
+		if ((rc = build_prefix_tables(h, (int)h->cfg.ptab_m))) goto fail;
 	}
 	*out = h;
 	return BWAGPU_OK;
@@ -470,7 +529,7 @@ extern "C" int bwagpu_clone(bwagpu_t *src, bwagpu_t **out)
 	h->bwt_blocks = src->bwt_blocks; h->bwt_bytes = src->bwt_bytes; h->sa_bytes = src->sa_bytes; h->pac_bytes = src->pac_bytes;
 	h->bwt_size = src->bwt_size; h->n_sa = src->n_sa;
 	h->h_ctg_off = src->h_ctg_off; h->h_ctg_len = src->h_ctg_len; h->h_ctg_alt = src->h_ctg_alt;
-	h->stats_on = src->stats_on; h->taps_on = src->taps_on; h->cigar_filter = src->cigar_filter;
+	h->stats_on = src->stats_on; h->taps_on = src->taps_on; h->cigar_filter = src->cigar_filter; h->cfg = src->cfg;
 	*out = h;
 	return BWAGPU_OK;
 }
@@ -488,6 +547,7 @@ static int clone_to_device_impl(bwagpu_t *src, int device, bwagpu_t **out)
 	bwagpu_t *h = new bwagpu_s();
 	h->device = device;
 	h->ibuf = new bwagpu_s::IndexBufs();
+	h->cfg = src->cfg;
 	if (hipStreamCreate(&h->stream) != hipSuccess) { h->stream = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
 	for (int i = 0; i < 8; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { h->ev[i] = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
 	if (hipEventCreateWithFlags(&h->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) h->ev_wait = nullptr;
@@ -538,9 +598,8 @@ extern "C" int bwagpu_index_ready(bwagpu_t *h)
 {
 	if (!h) return BWAGPU_EINVAL;
 	HIPCHK(h, hipSetDevice(h->device));
-	int m = getenv("BWAGPU_PTAB_M") ? atoi(getenv("BWAGPU_PTAB_M")) : 10;
 	if (int rc = build_occ32(h)) return rc;
-	return build_prefix_tables(h, m);
+	return build_prefix_tables(h, (int)h->cfg.ptab_m);
 }
 
 extern "C" int bwagpu_index_export(const bwagpu_t *h, bwagpu_index_desc_t *d, int64_t *ctg_offset, int32_t *ctg_len, int32_t *ctg_is_alt)
@@ -630,7 +689,6 @@ extern "C" int bwagpu_densify_sa(bwagpu_t *h, int new_intv)
 static const int BLOCK = 256;
 static const int MAX_RESIDENT_THREADS = 256 * 2048;   // 256 CUs x 32 waves x 64 lanes
 static const int WAVE_EXT_MAX_LEN = 1100;
-static const int SEED_MRG_DEFAULT = 0;                  // k_seed / k_seed3 variant when BWAGPU_SEED_MRG is not set (dev_seed.h)
 static const int SEED_LDS_ENT = 10;                     // 10 x 16 B x 256 lanes = 40 KiB of LDS per block -> 4 blocks (16 waves) per CU; measured best of {4,7,10,15}               // 4 waves x (8+5) B/column must fit the 64 KiB dynamic-LDS limit
 
 // first guess of a batch's arena sizes from its shape (n_reads, n_bases, max_len); grown on overflow
@@ -655,7 +713,7 @@ static void size_arenas(bwagpu_t *h)
 	if ((i64)(h->need_node * nb) > h->node_cap) h->node_cap = (i64)(h->need_node * nb);
 	if ((i64)(h->need_reg * nb) > h->reg_cap) h->reg_cap = (i64)(h->need_reg * nb);
 	if (h->need_mem > h->mem_cap) h->mem_cap = h->need_mem;
-	if (getenv("BWAGPU_MEM_CAP")) h->mem_cap = atoi(getenv("BWAGPU_MEM_CAP"));   // test hook: force the overflow/retry path
+	if (h->cfg.mem_cap > 0) h->mem_cap = (int)h->cfg.mem_cap;   // test hook: force the overflow/retry path
 }
 
 // resident lanes of the lane-per-read kernels: enough to fill the chip, bounded by the seeding scratch budget (2 interval stacks per lane)
@@ -697,7 +755,7 @@ extern "C" int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, cons
 		hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)(pb < 65536 ? pb : 65536)), dim3(BLOCK), 0, h->stream, P, n_words);
 		HIPCHK(h, hipGetLastError());
 		// reads of up to 256 bases: a 2-bit copy per read for the seeding kernel's LDS
-		h->rd_words = (h->max_len <= 256 && !(getenv("BWAGPU_SEED_RD_LDS") && atoi(getenv("BWAGPU_SEED_RD_LDS")) == 0)) ? (((h->max_len + 15) / 16 + 3) & ~3) : 0;
+		h->rd_words = (h->max_len <= 256 && h->cfg.seed_rd_lds != 0) ? (((h->max_len + 15) / 16 + 3) & ~3) : 0;
 		if (h->rd_words) {
 			if (h->d_seq_2b.ensure((size_t)n * h->rd_words * 4 + 64) || h->d_seq_flags.ensure((size_t)n + 16)) { h->err = "hipMalloc failed (reads)"; return BWAGPU_ENOMEM; }
 			HIPCHK(h, hipMemsetAsync(h->d_seq_flags.p, 0, (size_t)n, h->stream));
@@ -803,10 +861,16 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log((double)l);
 		if (!(min_l > 0.05f * l)) { minhsp[l] = (int)(opt->a * min_l + .499); any_seedsw = true; }
 	}
-	const bool dbg_sync = getenv("BWAGPU_DEBUG_SYNC") && atoi(getenv("BWAGPU_DEBUG_SYNC")) != 0;   // diagnostics: wait and report after every stage
-	// Chunk-parallel pass 1 of long-read batches (BWAGPU_SEED_CHUNK=<bases per chunk>, opt-in until measured; dev_seed.h, k_seed's LR): one task per
+	const BwagpuConfig &cfg = h->cfg;            // (no batch call reads the environment: bwagpu_config.h)
+	const bool dbg_sync = cfg.debug_sync != 0;   // diagnostics: wait and report after every stage
+	// Long-read batches (a read beyond the short-read extension kernel's columns) default to the kernel forms BENCH_r03's `variants` measured
+	// fastest for them, identical regions: seeding by chunks with one memory round trip per iteration, workgroup-per-read interval sort, LDS
+	// seed re-scoring, four columns per lane in the patch alignments.  An explicit option (>= 0) overrides either way.
+	const bool long_batch = h->max_len > WAVE_EXT_MAX_LEN;
+	auto pick = [&](long long v, long long dflt_long) { return v >= 0 ? v : (long_batch ? dflt_long : 0); };
+	// Chunk-parallel pass 1 of long-read batches (option seed_chunk = bases per chunk; dev_seed.h, k_seed's LR): one task per
 	// (read, chunk); the tables go up once per batch, the per-task results live in HBM between the two launches.
-	int chunk_len = getenv("BWAGPU_SEED_CHUNK") ? atoi(getenv("BWAGPU_SEED_CHUNK")) : 0, n_vreads = 0, chunk_lanes = 0, vr_cap = 0;
+	int chunk_len = (int)pick(cfg.seed_chunk, 256), n_vreads = 0, chunk_lanes = 0, vr_cap = 0;
 	if (chunk_len < 32 || chunk_len > 32768 || h->max_len <= WAVE_EXT_MAX_LEN || h->max_len >= 65536 || h->ix.occ32 == nullptr || h->ix.ptab == nullptr || h->rd_words != 0) chunk_len = 0;
 	if (chunk_len) {
 		std::vector<i32> tab; tab.reserve((size_t)(h->n_bases / chunk_len) * 2 + 3 * (size_t)n + 16);
@@ -825,7 +889,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		}
 		memcpy(tab.data() + (size_t)2 * n_vreads, first.data(), ((size_t)n + 1) * 4);
 		vr_cap = 2 * chunk_len < 64 ? 64 : 2 * chunk_len;
-		if (getenv("BWAGPU_SEED_CHUNK_CAP") && atoi(getenv("BWAGPU_SEED_CHUNK_CAP")) > 0) vr_cap = atoi(getenv("BWAGPU_SEED_CHUNK_CAP"));   // (tests: tasks whose lists overflow are recomputed by the stitcher)
+		if (cfg.seed_chunk_cap > 0) vr_cap = (int)cfg.seed_chunk_cap;   // (tests: tasks whose lists overflow are recomputed by the stitcher)
 		chunk_lanes = (n_vreads + BLOCK - 1) / BLOCK * BLOCK; if (chunk_lanes > 65536) chunk_lanes = 65536;   // persistent lanes, tasks drawn from a counter
 		if (n_vreads == 0) chunk_len = 0;
 		else if (h->d_vr_tab.ensure(tab.size() * 4) || h->d_vr_chain.ensure((size_t)n_vreads * chunk_len * 4) || h->d_vr_meta.ensure((size_t)n_vreads * 4 * 4) ||
@@ -846,11 +910,9 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.tmp_intv = h->d_tmp_intv.as<BiIntv>(); B.mem_cap = h->mem_cap;
 		B.rd_words = h->rd_words; B.seq_2b = h->d_seq_2b.as<u32>(); B.seq_flags = h->d_seq_flags.as<u8>();
 		// LDS per lane: 160 bytes at four blocks per CU -- the read's 2-bit copy first, interval-stack entries with the rest
-		// (three blocks per CU -- the register allocation of the cooperative seeding kernel for 3 waves per SIMD, BWAGPU_SEED_OCC=3 -- leave each lane 208 bytes)
-		const int seed_occ = getenv("BWAGPU_SEED_OCC") ? atoi(getenv("BWAGPU_SEED_OCC")) : 3;
-		const int lane_lds = seed_occ == 3 && h->ix.occ32 == nullptr && getenv("BWAGPU_SEED_COOP") && atoi(getenv("BWAGPU_SEED_COOP")) != 0 ? 208 : 160, ent_max = lane_lds == 208 ? 13 : SEED_LDS_ENT;
+		const int lane_lds = 160, ent_max = SEED_LDS_ENT;
 		const int lds_ent_dflt = h->rd_words ? ((lane_lds - 4 * h->rd_words) / 16 < ent_max ? (lane_lds - 4 * h->rd_words) / 16 : ent_max) : ent_max;
-		B.seed_lds_ent = (h->seq_len < ((u64)1 << 37) && h->max_len < 65536) ? (getenv("BWAGPU_SEED_LDS_ENT") ? atoi(getenv("BWAGPU_SEED_LDS_ENT")) : lds_ent_dflt) : 0;
+		B.seed_lds_ent = (h->seq_len < ((u64)1 << 37) && h->max_len < 65536) ? (cfg.seed_lds_ent >= 0 ? (int)cfg.seed_lds_ent : lds_ent_dflt) : 0;
 		if (((size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * 16 + (size_t)B.rd_words * 4) * BLOCK > 65536) B.rd_words = 0;   // (an LDS_ENT override too large for both)
 		B.intv_n = h->d_intv_n.as<i32>(); B.intv_off = h->d_intv_off.as<i64>(); B.intv = h->d_intv.as<Intv3>();
 		B.seed_n = h->d_seed_n.as<i32>(); B.seed_off = h->d_seed_off.as<i64>(); B.slot_cap = h->slot_cap;
@@ -862,21 +924,19 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.dp_h = h->d_dp_h.as<i32>(); B.dp_e = h->d_dp_e.as<i32>(); B.dp_waves = dp_wave_count(h, n_threads);
 		B.seedsw_minhsp = h->d_minhsp.as<i32>();
 		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>(); B.chain_todo = h->d_chain_todo.as<i32>(); B.chain_todo2 = B.chain_todo + n + 4; B.seed_w = h->d_seed_w.as<i32>(); B.seed_order = nullptr;
-		B.seed_prio = !(getenv("BWAGPU_SEED_PRIO") && atoi(getenv("BWAGPU_SEED_PRIO")) == 0);
-		B.seed_no_virt = getenv("BWAGPU_SEED_NO_VIRT") && atoi(getenv("BWAGPU_SEED_NO_VIRT")) != 0;
-		B.seed_coop = h->ix.occ32 == nullptr && getenv("BWAGPU_SEED_COOP") && atoi(getenv("BWAGPU_SEED_COOP")) != 0;   // (opt-in: a measured loss, see build_occ32)
-		B.seed_pass3_inline = getenv("BWAGPU_SEED_PASS3_INLINE") && atoi(getenv("BWAGPU_SEED_PASS3_INLINE")) != 0;
-		B.chain_lds_off = getenv("BWAGPU_CHAIN_LDS") && atoi(getenv("BWAGPU_CHAIN_LDS")) == 0;
+		B.seed_prio = cfg.seed_prio != 0;
+		B.seed_no_virt = cfg.seed_no_virt != 0;
+		B.seed_pass3_inline = cfg.seed_pass3_inline != 0;
+		B.chain_lds_off = cfg.chain_lds == 0;
 		B.chunk_len = chunk_len; B.n_vreads = n_vreads; B.vr_cap = vr_cap;
 		if (chunk_len) {
 			B.vr_read = h->d_vr_tab.as<i32>(); B.vr_beg = B.vr_read + n_vreads; B.vr_first = B.vr_beg + n_vreads;
 			B.vr_chain = h->d_vr_chain.as<i32>(); B.vr_nchain = h->d_vr_meta.as<i32>(); B.vr_exit = B.vr_nchain + n_vreads; B.vr_nintv = B.vr_exit + n_vreads; B.vr_from = B.vr_nintv + n_vreads;
 			B.vr_intv = h->d_vr_intv.as<Intv3>();
 		}
-		// memory round trips per iteration of the seeding kernels (dev_seed.h, k_seed's MRG): 0 = as compiled, 1 = table entries and whole index
-		// blocks in one trip, 2 = plus the next interval-stack entry a step ahead
-		int seed_mrg = getenv("BWAGPU_SEED_MRG") ? atoi(getenv("BWAGPU_SEED_MRG")) : SEED_MRG_DEFAULT;
-		const bool long_qlds = getenv("BWAGPU_LONG_QLDS") && atoi(getenv("BWAGPU_LONG_QLDS")) != 0;   // long-read DP kernels: query bases from an LDS copy
+		// memory round trips per iteration of the seeding kernels (dev_seed.h, k_seed's MRG): 0 = as compiled, 2 = table entries, whole index
+		// blocks and the next interval-stack entry in one trip (any other non-zero value selects 2 as well)
+		int seed_mrg = pick(cfg.seed_mrg, 2) ? 2 : 0;
 		if (h->ix.occ32 == nullptr || h->ix.ptab == nullptr || h->ix.occ32_bytes > BUF_MAX_BYTES || h->ix.ptab_bytes > BUF_MAX_BYTES) seed_mrg = 0;   // (its loads address 32-bit offsets into buffers of < 4 GiB: a genome beyond ~8.5 Gbp of index keeps the plain kernels)
 		B.seq_nib_bytes = (((u64)h->n_bases + 15) / 16) * 8;
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
@@ -885,25 +945,23 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		if (!B.seed_pass3_inline) {   // pass 3 first (cheap), then passes 1-2 on the reads ordered by the repetitiveness it measured
 			if (h->ix.occ32 != nullptr && seed_mrg) hipLaunchKernelGGL((k_seed3<1, true>), grid, block, 0, h->stream, h->ix, *opt, B);
 			else if (h->ix.occ32 != nullptr) hipLaunchKernelGGL(k_seed3<1>, grid, block, 0, h->stream, h->ix, *opt, B);
-			else if (B.seed_coop) hipLaunchKernelGGL(k_seed3<2>, grid, block, 0, h->stream, h->ix, *opt, B);
 			else hipLaunchKernelGGL(k_seed3<0>, grid, block, 0, h->stream, h->ix, *opt, B);
-			if (!getenv("BWAGPU_SEED_INPUT_ORDER")) {
+			if (!cfg.seed_input_order) {
 				i32 *keep = B.order; B.order = h->d_seed_order.as<i32>();
 				if (int rc2 = order_reads(h, B, B.seed_w)) return rc2;
 				B.seed_order = B.order; B.order = keep;
 			}
 		}
 		const size_t seed_lds = ((size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * sizeof(uint4) + (size_t)B.rd_words * 4) * BLOCK;
-		dim3 sgrid = grid;                    // (BWAGPU_SEED_GRID, measurements: fewer resident workgroups of the seeding kernel; it stays within 5 % down to two per CU -- it is bound by memory requests, not by waves -- but step time with three batches in flight did not move either, nor did making the batches' seeding kernels take turns)
-		if (getenv("BWAGPU_SEED_GRID") && atoi(getenv("BWAGPU_SEED_GRID")) > 0 && (unsigned)atoi(getenv("BWAGPU_SEED_GRID")) < grid.x) sgrid = dim3((unsigned)atoi(getenv("BWAGPU_SEED_GRID")));
-		// (twelve instances: with/without the LDS copy of the reads, the work counters -- which cost registers -- and the three ways of reading the index)
+		dim3 sgrid = grid;                    // (option seed_grid, measurements: fewer resident workgroups of the seeding kernel; it stays within 5 % down to two per CU -- it is bound by memory requests, not by waves -- but step time with three batches in flight did not move either, nor did making the batches' seeding kernels take turns)
+		if (cfg.seed_grid > 0 && (unsigned long long)cfg.seed_grid < grid.x) sgrid = dim3((unsigned)cfg.seed_grid);
+		// (instances: with/without the LDS copy of the reads, the work counters -- which cost registers --, the two index layouts, one or several trips per iteration)
 #define SEED_LAUNCH(RD_, ST_, B_, O_, M_) hipLaunchKernelGGL((k_seed<RD_, ST_, B_, O_, M_>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B)
-#define SEED_LAUNCH_B(RD_, ST_) do { if (blk == 2 && socc == 3) SEED_LAUNCH(RD_, ST_, 2, 3, 0); else if (blk == 2) SEED_LAUNCH(RD_, ST_, 2, 4, 0); else if (blk == 1 && mrg == 2) SEED_LAUNCH(RD_, ST_, 1, (RD_ ? 4 : 3), 2);   /* (no LDS copy of the reads: long reads, few lanes -- registers instead of spills) */ \
-		else if (blk == 1 && mrg == 1) SEED_LAUNCH(RD_, ST_, 1, 4, 1); else if (blk == 1) SEED_LAUNCH(RD_, ST_, 1, 4, 0); else SEED_LAUNCH(RD_, ST_, 0, 4, 0); } while (0)
+#define SEED_LAUNCH_B(RD_, ST_) do { if (blk == 1 && mrg == 2) SEED_LAUNCH(RD_, ST_, 1, (RD_ ? 4 : 3), 2);   /* (no LDS copy of the reads: long reads, few lanes -- registers instead of spills) */ \
+		else if (blk == 1) SEED_LAUNCH(RD_, ST_, 1, 4, 0); else SEED_LAUNCH(RD_, ST_, 0, 4, 0); } while (0)
 		{
 			const bool rd = B.rd_words != 0, st = B.stats != 0;
-			const int blk = h->ix.occ32 != nullptr ? 1 : (B.seed_coop ? 2 : 0);
-			const int socc = seed_occ;   // (measurements: register allocation of the cooperative form for 3 or 4 waves per SIMD)
+			const int blk = h->ix.occ32 != nullptr ? 1 : 0;
 			const int mrg = seed_mrg;
 			if (chunk_len && blk == 1 && !rd) {
 				// long reads, pass 1 by chunks: the workers (persistent lanes drawing tasks), then the lane-per-read kernel as stitcher (+ pass 2)
@@ -922,7 +980,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 #undef SEED_LAUNCH
 		HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_seed3+k_seed", hipGetErrorString(e_)); }
-		if (h->max_len > WAVE_EXT_MAX_LEN && getenv("BWAGPU_PUBLISH_BLK") && atoi(getenv("BWAGPU_PUBLISH_BLK")) != 0)    // long reads: one workgroup per read sorts, counts and expands (opt-in until measured)
+		if (long_batch && pick(cfg.publish_blk, 1))    // long reads: one workgroup per read sorts, counts and expands (167 -> 47 ms per 6000 x 10 kb reads, BENCH_r03 variants)
 			hipLaunchKernelGGL(k_publish_blk, dim3((unsigned)(n < (int)grid.x ? (n > 0 ? n : 1) : (int)grid.x)), block, 0, h->stream, *opt, B);
 		else {
 			hipLaunchKernelGGL(k_publish, grid, block, 0, h->stream, *opt, B);
@@ -948,8 +1006,8 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		if (any_seedsw && h->max_len > WAVE_EXT_MAX_LEN) {   // long reads: one wavefront per read, one lane per seed
 			int sc_max = 0; for (int k = 0; k < 25; ++k) if (opt->mat[k] > sc_max) sc_max = opt->mat[k];
 			const i64 wcap = B.dp_waves > 0 ? B.dp_waves : 1;
-			if (getenv("BWAGPU_SEEDSW_LDS") && atoi(getenv("BWAGPU_SEEDSW_LDS")) != 0 && SEEDSW_LDS_COLS * sc_max < 65536) {
-				// the cell loop's state in LDS (dev_local_score_lds), one wave per workgroup; opt-in until measured
+			if (pick(cfg.seedsw_lds, 1) && SEEDSW_LDS_COLS * sc_max < 65536) {
+				// the cell loop's state in LDS (dev_local_score_lds), one wave per workgroup (165 -> 26 ms per 6000 x 10 kb reads, BENCH_r03 variants)
 				if (SEEDSW_LDS_COLS * sc_max < 256) hipLaunchKernelGGL((k_seedsw_wave<8>), dim3((unsigned)(n < wcap ? n : wcap)), dim3(64), (size_t)SEEDSW_LDS_COLS * 64 * 3, h->stream, h->ix, *opt, B);
 				else hipLaunchKernelGGL((k_seedsw_wave<16>), dim3((unsigned)(n < wcap ? n : wcap)), dim3(64), (size_t)SEEDSW_LDS_COLS * 64 * 5, h->stream, h->ix, *opt, B);
 			} else {
@@ -967,27 +1025,22 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		if (h->max_len <= WAVE_EXT_MAX_LEN && max_score < (1 << 24)) {
 			int lds_wave = (8 * (h->max_len + 2 + 64) + 5 * ((h->max_len + 64 + 3) & ~3) + 32 + 15) & ~15;   // {H,E} columns, query profile, scoring matrix
 			i64 nblk = ((i64)n + 3) / 4, cap = 256 * 8;
-			const int occ = getenv("BWAGPU_EXT_OCC") ? atoi(getenv("BWAGPU_EXT_OCC")) : 6;   // waves per SIMD the register allocation aims at (measured at 3.1 Gbp: 4 -> 63 ms, 5 -> 58 ms, 6 -> 56 ms)
+			const int occ = (int)cfg.ext_occ;   // waves per SIMD the register allocation aims at (measured at 3.1 Gbp: 4 -> 63 ms, 5 -> 58 ms, 6 -> 56 ms)
 			const dim3 g((unsigned)(nblk < cap ? nblk : cap));
-			if (occ == 6) hipLaunchKernelGGL((k_extend_wave<false, 6>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0, 0);
-			else if (occ == 5) hipLaunchKernelGGL((k_extend_wave<false, 5>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0, 0);
-			else hipLaunchKernelGGL((k_extend_wave<false, 4>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0, 0);
+			if (occ == 5) hipLaunchKernelGGL((k_extend_wave<false, 5>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
+			else if (occ == 4) hipLaunchKernelGGL((k_extend_wave<false, 4>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
+			else hipLaunchKernelGGL((k_extend_wave<false, 6>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
 		} else if (max_score < (1 << 24) && ring_cols <= 2048) {
-			// the band's columns only: independent of the read length -- plus, optionally, a copy of the read (BWAGPU_LONG_QLDS=1, opt-in until
-			// measured: the rows' query-base look-ups then stay in LDS), with fewer waves per workgroup where four copies exceed its 64 KiB
-			int q_cap = long_qlds ? (h->max_len + 15) & ~15 : 0;
-			if (8 * ring_cols + 32 + q_cap > 65536) q_cap = 0;
-			const int lds_wave = 8 * ring_cols + 32 + q_cap;
+			// the band's columns only: independent of the read length
+			const int lds_wave = 8 * ring_cols + 32;
 			int wpb = 4; while (wpb > 1 && lds_wave * wpb > 65536) wpb >>= 1;
 			i64 nblk = ((i64)n + wpb - 1) / wpb, cap = 256 * 8 * (4 / wpb);
-			// BWAGPU_EXT_BLK=1: DP rows with four columns per lane (dev_extw.h; an instance of its own with the registers of two waves per SIMD -- the ring's LDS allows no more anyway; opt-in until measured)
-			if (getenv("BWAGPU_EXT_BLK") && atoi(getenv("BWAGPU_EXT_BLK")) != 0) hipLaunchKernelGGL((k_extend_wave<true, 2, true>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, lds_wave, ring_cols, q_cap);
-			else hipLaunchKernelGGL((k_extend_wave<true, 4>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, lds_wave, ring_cols, q_cap);
+			hipLaunchKernelGGL((k_extend_wave<true, 4>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, lds_wave, ring_cols);
 		} else                                  // very wide bands: lane-per-read scalar DP with the columns in HBM scratch
 			hipLaunchKernelGGL(k_extend, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_extend", hipGetErrorString(e_)); }
-		if (h->max_len > WAVE_EXT_MAX_LEN || getenv("BWAGPU_DEDUP_WAVE")) {     // long reads: few reads, long patch alignments -> one wavefront per read
+		if (long_batch || cfg.dedup_wave) {     // long reads: few reads, long patch alignments -> one wavefront per read
 			// Ring of {H,E} columns for the patch alignments' band: 2 w + 132 columns, where w = max(min(.., 4 opt.w), |rlen - l_query| + 3) (bwa.c:180-187)
 			// and the length difference of two merged regions of a 10 kb read with 13 % indels runs to several hundred bases.  A band the ring
 			// cannot hold falls back to one lane with its columns in HBM -- 10^7 cells at one lane's pace: measured 0.6 s per call, 58 s of a
@@ -995,10 +1048,10 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			// wave's LDS share allows; wider rings mean fewer waves per workgroup (the dynamic LDS of a workgroup is 64 KiB).
 			int need = 8 * opt->w + 4 + 128; if (need < h->max_len / 4 + 132) need = h->max_len / 4 + 132;
 			int rc_ = 256; while (rc_ < need && rc_ < 4096) rc_ <<= 1;
-			if (getenv("BWAGPU_DEDUP_RING")) rc_ = atoi(getenv("BWAGPU_DEDUP_RING"));      // test hook: a power of two, 256..4096
+			if (cfg.dedup_ring > 0) rc_ = (int)cfg.dedup_ring;      // test hook: a power of two, 256..4096
 			if (rc_ < 256 || rc_ > 4096 || (rc_ & (rc_ - 1))) rc_ = 1024;
-			const bool dedup_blk = getenv("BWAGPU_DEDUP_BLK") && atoi(getenv("BWAGPU_DEDUP_BLK")) != 0;   // four columns per lane in the patch alignments (wave_global2_score_ring_blk; opt-in until measured); needs the segment in LDS
-			int q_cap = long_qlds || dedup_blk ? (h->max_len + 15) & ~15 : 0;      // room for a patch alignment's query segment next to the ring (see k_extend_wave above)
+			const bool dedup_blk = (cfg.dedup_blk >= 0 ? cfg.dedup_blk : 1) != 0;   // four columns per lane in the patch alignments (wave_global2_score_ring_blk: 381 -> 207 ms per 6000 x 10 kb reads, BENCH_r03 variants); needs the segment in LDS
+			int q_cap = dedup_blk ? (h->max_len + 15) & ~15 : 0;      // room for a patch alignment's query segment next to the ring
 			if (8 * rc_ + 32 + q_cap > 65536) q_cap = 0;
 			int wpb = rc_ <= 1024 ? 4 : (rc_ <= 2048 ? 2 : 1);
 			while (wpb > 1 && (8 * rc_ + 32 + q_cap) * wpb > 65536) wpb >>= 1;
@@ -1032,7 +1085,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			if (h->slot_cap / nbd > h->need_slot) h->need_slot = h->slot_cap / nbd;
 			if (h->node_cap / nbd > h->need_node) h->need_node = h->node_cap / nbd;
 			if (h->reg_cap / nbd > h->need_reg) h->need_reg = h->reg_cap / nbd;
-			if (h->mem_cap > h->need_mem && !getenv("BWAGPU_MEM_CAP")) h->need_mem = h->mem_cap;
+			if (h->mem_cap > h->need_mem && cfg.mem_cap <= 0) h->need_mem = h->mem_cap;
 			std::lock_guard<std::mutex> l(h->ibuf->m);
 			if (h->need_slot > h->ibuf->need_slot) h->ibuf->need_slot = h->need_slot;
 			if (h->need_node > h->ibuf->need_node) h->ibuf->need_node = h->need_node;
@@ -1150,19 +1203,19 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		Batch B = {}; B.seq = h->d_seq.as<u8>(); B.off = h->d_off.as<i64>(); B.n_reads = h->n_reads; B.max_len = h->max_len;
 		unsigned long long *next = &h->d_ctr.as<Counters>()->next_ext, *ext_used = &h->d_ctr.as<Counters>()->cig_ext_used;
 		const int zc[2] = { CIG_Z_SMALL, CIG_Z_BIG };
-		const int n_tier = getenv("BWAGPU_CIG_TIERS") ? atoi(getenv("BWAGPU_CIG_TIERS")) : 2;   // diagnostics
+		const int n_tier = (int)h->cfg.cig_tiers;   // diagnostics
 		// operation array: sized for a typical batch; one that needs more (gap-rich reads) reports the total it reserved and is
 		// redone once with exactly that much
 		i64 ext_cap = tot * 4 + 65536;
 		if (h->max_len > CIG_MAX_LEN && h->n_bases / 2 + 65536 > ext_cap) ext_cap = h->n_bases / 2 + 65536;   // (long reads: ~0.37 entries per base at 13 % indels -- operations and MD characters)
-		if (getenv("BWAGPU_CIG_OPS_CAP")) ext_cap = atoll(getenv("BWAGPU_CIG_OPS_CAP"));   // (tests of the second attempt)
+		if (h->cfg.cig_ops_cap > 0) ext_cap = h->cfg.cig_ops_cap;   // (tests of the second attempt)
 		if (ext_cap < 1) ext_cap = 1;
 		// third tier (k_cigar_long): segments, bands and operation counts beyond the LDS tiers' limits; one 64-thread workgroup per region at a time,
 		// each with a direction matrix of its own in HBM.  A sizing pass (k_cigar_long_plan) counts the regions the LDS tiers left and the largest
-		// matrix any of them can ask for; the scratch is as many such matrices as there are regions, at most 1024 and at most BWAGPU_CIGL_GIB (16).
-		const bool long_tier = !(getenv("BWAGPU_CIG_LONG") && atoi(getenv("BWAGPU_CIG_LONG")) == 0);
-		const i64 cigl_budget = (i64)((getenv("BWAGPU_CIGL_GIB") ? atof(getenv("BWAGPU_CIGL_GIB")) : 16.) * (double)((i64)1 << 30));
-		const bool cig_trace = getenv("BWAGPU_CIG_TRACE") != nullptr;
+		// matrix any of them can ask for; the scratch is as many such matrices as there are regions, at most 1024 and at most option cigl_mib (16 GiB).
+		const bool long_tier = h->cfg.cig_long != 0;
+		const i64 cigl_budget = (i64)h->cfg.cigl_mib << 20;
+		const bool cig_trace = h->cfg.cig_trace != 0;
 		auto t_last = std::chrono::steady_clock::now();
 		auto lap = [&](const char *what) {
 			if (!cig_trace) return;
@@ -1363,8 +1416,7 @@ extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, i
 	DevBuf d_seq, d_pac, d_cases, d_out, d_scr, d_pac2;
 	int rc = BWAGPU_OK;
 	const int grid = n_cases < 2048 ? n_cases : 2048;
-	const bool dbg_blk = getenv("BWAGPU_DEDUP_BLK") && atoi(getenv("BWAGPU_DEDUP_BLK")) != 0;      // kind 3 in its four-columns-per-lane form
-	const bool dbg_qlds = dbg_blk || (getenv("BWAGPU_LONG_QLDS") && atoi(getenv("BWAGPU_LONG_QLDS")) != 0);   // kinds 1 and 3 with the LDS copy of the query (as the long-read kernels make it under the same switch)
+	const bool dbg_blk = (h->cfg.dedup_blk >= 0 ? h->cfg.dedup_blk : 1) != 0;      // kind 3 in its four-columns-per-lane form (the product's default) or, option dedup_blk = 0, one column per lane
 	hipError_t e = hipSuccess;
 	if (d_seq.ensure((size_t)n_seq_bytes + 16) || d_pac.ensure((size_t)n_seq_bytes / 4 + 16) || d_cases.ensure((size_t)n_cases * sizeof(bwagpu_dp_case_t)) || d_out.ensure((size_t)n_cases * DBG_OUT_INTS * 4)) { h->err = "hipMalloc failed (debug)"; rc = BWAGPU_ENOMEM; goto done; }
 	e = hipMemcpyAsync(d_seq.p, seqs, (size_t)n_seq_bytes, hipMemcpyHostToDevice, h->stream);
@@ -1376,19 +1428,17 @@ extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, i
 		if (kind == 0) {
 			if (max_q > WAVE_EXT_MAX_LEN) { rc = BWAGPU_EINVAL; goto done; }
 			const size_t lds = (8 * (size_t)(max_q + 2 + 64) + 5 * (size_t)((max_q + 64 + 3) & ~3) + 32 + 15) & ~(size_t)15;
-			hipLaunchKernelGGL((k_debug_extend<false>), dim3(grid), dim3(64), lds, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, 0, d_out.as<i32>(), 0);
+			hipLaunchKernelGGL((k_debug_extend<false>), dim3(grid), dim3(64), lds, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, 0, d_out.as<i32>());
 		} else if (kind == 1) {
 			int ring_cols = 256; while (ring_cols < 2 * max_w + 4 + 128) ring_cols <<= 1;
 			if (ring_cols > 4096) { rc = BWAGPU_EINVAL; goto done; }
-			const int q_cap = dbg_qlds && 8 * ring_cols + 32 + ((max_q + 15) & ~15) <= 65536 ? (max_q + 15) & ~15 : 0;
-			if (getenv("BWAGPU_EXT_BLK") && atoi(getenv("BWAGPU_EXT_BLK")) != 0) hipLaunchKernelGGL((k_debug_extend<true, true>), dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, ring_cols, d_out.as<i32>(), q_cap);
-			else hipLaunchKernelGGL((k_debug_extend<true>), dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, ring_cols, d_out.as<i32>(), q_cap);
+			hipLaunchKernelGGL((k_debug_extend<true>), dim3(grid), dim3(64), (size_t)8 * ring_cols + 32, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, ring_cols, d_out.as<i32>());
 		} else if (kind == 2) {
 			hipLaunchKernelGGL(k_debug_global, dim3(grid), dim3(64), (size_t)CIG_LDS_BYTES(CIG_Z_BIG), h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), d_out.as<i32>());
 		} else if (kind == 3) {
 			int ring_cols = 256; while (ring_cols < 2 * max_w + 4 + 128) ring_cols <<= 1;
 			if (ring_cols > 4096) { rc = BWAGPU_EINVAL; goto done; }
-			const int q_cap = dbg_qlds && 8 * ring_cols + 32 + ((max_q + 15) & ~15) <= 65536 ? (max_q + 15) & ~15 : 0;
+			const int q_cap = dbg_blk && 8 * ring_cols + 32 + ((max_q + 15) & ~15) <= 65536 ? (max_q + 15) & ~15 : 0;
 			if (dbg_blk) hipLaunchKernelGGL(k_debug_global_ring<true>, dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), ring_cols, d_out.as<i32>(), q_cap);
 			else hipLaunchKernelGGL(k_debug_global_ring<false>, dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), ring_cols, d_out.as<i32>(), q_cap);
 		} else if (kind == 5) {

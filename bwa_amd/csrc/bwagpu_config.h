@@ -1,0 +1,72 @@
+// bwagpu_config.h -- the tuning and test options of a handle (host code; bwagpu_set_option / bwagpu_get_option / bwagpu_set_default_option,
+// include/bwagpu.h).
+//
+// Until round 3 every one of these was a getenv() inside the batch calls -- a dozen per batch, and nothing a reference-side caller could bind.
+// Now they are fields of a plain struct that every handle owns: filled when the handle is created -- compiled-in defaults, then the process
+// environment (BWAGPU_<NAME IN CAPITALS>, read ONCE per bwagpu_create*; the tools' and tests' old switches keep working), then whatever
+// bwagpu_set_default_option() was given -- copied by bwagpu_clone*(), and changed per handle with bwagpu_set_option().  No batch call reads the
+// environment.  None of the options changes a result: they choose between kernel forms that the tests hold to the same output, size scratch
+// areas, or force the overflow/retry paths.
+//
+// -1 ("auto") for the long-read kernel forms means: on for batches whose longest read exceeds the short-read extension kernel's limit
+// (1100 bp), off otherwise -- the setting BENCH_r03's `variants` measured as the fastest for each class of batch.
+#pragma once
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+#include <string>
+
+//      name               default   meaning
+#define BWAGPU_OPTION_LIST(X) \
+	X(occ32,             1)    /* index: kernels read the 32-byte block layout derived at load time (0: the reference-format 64-byte blocks)          */ \
+	X(occ32_sb_shift,    32)   /* index: log2 bases per superblock of that layout (tests: small superblocks on small genomes)                           */ \
+	X(ptab_m,            10)   /* index: depth of the prefix tables (0: none)                                                                           */ \
+	X(seed_mrg,          -1)   /* seeding: 0 = loads as the compiler schedules them, 2 = one memory round trip per iteration; auto: 2 for long reads     */ \
+	X(seed_chunk,        -1)   /* seeding: pass 1 of long reads by chunks of this many bases (0: off); auto: 256 for long reads                         */ \
+	X(seed_chunk_cap,    0)    /* seeding: capacity of a chunk task's SMEM list (0: 2 x chunk; tests: tiny lists force the stitcher's recomputation)    */ \
+	X(publish_blk,       -1)   /* interval sort + SA-row expansion by one workgroup per read; auto: on for long reads                                   */ \
+	X(seedsw_lds,        -1)   /* mem_flt_chained_seeds' local alignments with their state in LDS; auto: on for long reads                              */ \
+	X(dedup_blk,         -1)   /* patch alignments of k_dedup_wave with four columns per lane; auto: on (the wave kernel only runs for long reads)      */ \
+	X(seed_lds_ent,      -1)   /* seeding: interval-stack entries per lane kept in LDS; auto: 10, or what the read copy leaves                          */ \
+	X(seed_rd_lds,       1)    /* seeding: short reads copied to LDS at 2 bits per base                                                                 */ \
+	X(seed_no_virt,      0)    /* seeding: keep matches shorter than the prefix tables' depth in the stack too (diagnostics)                            */ \
+	X(seed_prio,         1)    /* seeding: raised issue priority for the waves holding the heaviest reads                                               */ \
+	X(seed_input_order,  0)    /* seeding: reads in input order instead of heaviest first (diagnostics)                                                 */ \
+	X(seed_pass3_inline, 0)    /* seeding: pass 3 inside k_seed's state machine instead of k_seed3 (A/B)                                                */ \
+	X(seed_grid,         0)    /* seeding: resident workgroups of k_seed (0: fill the chip; measurements)                                               */ \
+	X(chain_lds,         1)    /* chaining: 0 = the LDS tiers defer every read to the HBM tier (test hook)                                              */ \
+	X(ext_occ,           6)    /* extension: waves per SIMD the short-read kernel's register allocation aims at (4, 5, 6)                               */ \
+	X(dedup_wave,        0)    /* 1 = the wave-per-read de-duplication kernel for short reads as well (test hook)                                       */ \
+	X(dedup_ring,        0)    /* ring columns of that kernel (0: from the batch; test hook: a power of two, 256..4096)                                 */ \
+	X(mem_cap,           0)    /* capacity of a read's interval list (0: from the batch; test hook: a small value forces the retry path)                */ \
+	X(cig_tiers,         2)    /* CIGAR stage: LDS tiers to run (diagnostics)                                                                           */ \
+	X(cig_ops_cap,       0)    /* CIGAR stage: entries of the operation array (0: from the batch; test hook: forces the second attempt)                 */ \
+	X(cig_long,          1)    /* CIGAR stage: the long-segment tier (k_cigar_long)                                                                     */ \
+	X(cigl_mib,          16384)/* CIGAR stage: scratch budget of that tier in MiB                                                                       */ \
+	X(cig_trace,         0)    /* CIGAR stage: print the launches' times (waits for the stream after each)                                              */ \
+	X(debug_sync,        0)    /* wait and report after every stage of bwagpu_batch_run                                                                 */ \
+	X(pinned_results,    1)    /* PROCESS-WIDE (the result pool is shared by all handles): large results in pooled page-locked blocks (0: plain malloc)  */ \
+	X(pinned_min_kb,     1024) /* PROCESS-WIDE: results below this size come from malloc (tests: 0 pools everything)                                    */
+
+struct BwagpuConfig {
+#define X(name, dflt) long long name = dflt;
+	BWAGPU_OPTION_LIST(X)
+#undef X
+	long long *field(const char *key)
+	{
+		if (!key) return nullptr;
+#define X(name, dflt) if (!strcmp(key, #name)) return &name;
+		BWAGPU_OPTION_LIST(X)
+#undef X
+		return nullptr;
+	}
+	// BWAGPU_<NAME>=<integer> for every option present in the environment (BWAGPU_CIGL_GIB, a possibly fractional number of GiB, is
+	// accepted for cigl_mib as well)
+	void from_env()
+	{
+#define X(name, dflt) { std::string e = "BWAGPU_"; for (const char *p = #name; *p; ++p) e += (char)toupper((unsigned char)*p); if (const char *v = getenv(e.c_str())) if (*v) name = atoll(v); }
+		BWAGPU_OPTION_LIST(X)
+#undef X
+		if (const char *v = getenv("BWAGPU_CIGL_GIB")) if (*v) cigl_mib = (long long)(atof(v) * 1024.);
+	}
+};

@@ -177,17 +177,16 @@ struct Batch {
 	u8 *slot_blob;
 	i32 *chain_n;              // per read: chains after filtering
 	i32 *chain_todo, *chain_todo2; // reads deferred by tier 0 / tier 1 of k_chain_wave to the next tier
-	// --- chunk-parallel pass 1 of long-read batches (k_seed<LR>, BWAGPU_SEED_CHUNK): one task per (read, chunk of chunk_len bases); a read's tasks are consecutive
+	// --- chunk-parallel pass 1 of long-read batches (k_seed<LR>, option seed_chunk): one task per (read, chunk of chunk_len bases); a read's tasks are consecutive
 	int chunk_len, n_vreads, vr_cap;
 	const i32 *vr_read, *vr_beg;    // per task: its read, the first base of its chunk
 	const i32 *vr_first;            // per read: its first task
 	i32 *vr_chain;                  // [n_vreads][chunk_len]: the positions the task's chain visited inside its chunk, ascending
 	i32 *vr_nchain, *vr_exit, *vr_nintv, *vr_from;   // per task: chain length (0: unusable), where the chain left the chunk, SMEMs found, and (stitcher) the chunk-relative position its results are valid from (-1: not at all)
 	Intv3 *vr_intv;                 // [n_vreads][vr_cap]: the SMEMs, x2's bits 48.. = chunk-relative position of the search that found them
-	int seed_prio;             // waves holding the heaviest 3 % of k_seed's reads run at raised issue priority (BWAGPU_SEED_PRIO=0 turns it off)
-	int seed_coop;             // the seeding kernels fetch index blocks quad-cooperatively (fm_occ_coop; off with BWAGPU_SEED_COOP=0 or when the 32-byte layout is in use)
-	int seed_pass3_inline;     // A/B switch (BWAGPU_SEED_PASS3_INLINE=1): pass 3 inside k_seed's state machine as in round 1, instead of k_seed3
-	int chain_lds_off;         // test hook (BWAGPU_CHAIN_LDS=0): the LDS tiers defer every read
+	int seed_prio;             // waves holding the heaviest 3 % of k_seed's reads run at raised issue priority (option seed_prio = 0 turns it off)
+	int seed_pass3_inline;     // A/B switch (option seed_pass3_inline = 1): pass 3 inside k_seed's state machine as in round 1, instead of k_seed3
+	int chain_lds_off;         // test hook (option chain_lds = 0): the LDS tiers defer every read
 	// --- B-tree nodes
 	i64 *node_off;             // per read
 	i32 *nodes; i64 node_cap;  // 21 ints per node

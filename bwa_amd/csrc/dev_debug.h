@@ -25,13 +25,12 @@ DEVFN void dbg_case_geometry(const bwagpu_dp_case_t &c, i64 l_pac, int &q0, int 
 }
 
 // kind 0 / 1: wave_ksw_extend2 as k_extend_wave sets it up (columns + read profile in LDS / ring mode)
-template <bool RING, bool BLK = false> __global__ void __launch_bounds__(64) k_debug_extend(DevIndex ix, bwagpu_opt_t opt, int n_cases, const bwagpu_dp_case_t *cases, const u8 *seqs,
-																			 int max_q, int ring_cols, i32 *out, int q_cap)
+template <bool RING> __global__ void __launch_bounds__(64) k_debug_extend(DevIndex ix, bwagpu_opt_t opt, int n_cases, const bwagpu_dp_case_t *cases, const u8 *seqs,
+																			 int max_q, int ring_cols, i32 *out)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, dbg_lds)
 	const int lane = threadIdx.x & 63;
 	WaveLds L;
-	L.qbuf = RING && q_cap ? dbg_lds + (size_t)8 * ring_cols + 32 : nullptr; L.qcap = RING ? q_cap : 0; L.qlds = nullptr;     // (q_cap: the LDS copy of the query, as ext_read_wave makes it)
 	L.eh = (int2*)dbg_lds;
 	if (RING) {
 		int8_t *m = (int8_t*)(dbg_lds + (size_t)8 * ring_cols);
@@ -55,12 +54,8 @@ template <bool RING, bool BLK = false> __global__ void __launch_bounds__(64) k_d
 			for (int j = lane; j < c.q_len; j += 64) { const int qc = q[j]; for (int b = 0; b < 5; ++b) L.qp[b * L.qstride + j] = L.mat[b * 5 + qc]; }
 			wave_sync();
 		}
-		if (RING) {
-			L.qlds = nullptr;
-			if (L.qcap >= c.q_len && c.q_len > 0) { wave_sync(); for (int j = lane; j < c.q_len; j += 64) L.qbuf[j] = q[j]; wave_sync(); L.qlds = L.qbuf; }
-		}
 		u64 cells = 0, fast = 0;
-		const ExtRes r = wave_ksw_extend2<RING, BLK>(ix, opt, mat_max, q, q0, qdir, c.q_len, t0, tdir, c.t_len, c.w, c.end_bonus, c.h0, L, cells, fast);
+		const ExtRes r = wave_ksw_extend2<RING>(ix, opt, mat_max, q, q0, qdir, c.q_len, t0, tdir, c.t_len, c.w, c.end_bonus, c.h0, L, cells, fast);
 		wave_sync();
 		if (lane == 0) {
 			i32 *o = out + (size_t)k * DBG_OUT_INTS;

@@ -9,7 +9,7 @@
 #include "dev_extw.h"
 
 struct DedupLds { i32 *hd, *e; const int8_t *mat; int ring_mask; i32 *H, *E; /* lane 0's HBM scratch columns (dev_ksw_global2_score) for bands wider than the ring */
-	u8 *qbuf; int qcap; /* optional (BWAGPU_LONG_QLDS=1 / BWAGPU_DEDUP_BLK=1): room for a patch alignment's query segment in alignment order */ };
+	u8 *qbuf; int qcap; /* four-columns-per-lane form (option dedup_blk, the default): room for a patch alignment's query segment in alignment order */ };
 
 // ksw_global2 without traceback (ksw.c:540-619), columns in a ring of ring_mask+1 entries, lazily initialised
 __device__ int wave_global2_score_ring(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen, i64 t0, int tdir, int tlen,
@@ -20,14 +20,6 @@ __device__ int wave_global2_score_ring(const DevIndex &ix, const bwagpu_opt_t &o
 	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
 	i32 *hd = L.hd, *e_ = L.e; const int rm = L.ring_mask;
 	int init_hi = -1, treg = 0;
-	// the segment's bases in alignment order, in LDS when there is room: every pass of every row looks its lanes' bases up, and from the
-	// batch's array that is a dependent memory round trip in a loop that runs one wave per SIMD (see ext_read_wave)
-	const u8 *qs = nullptr;
-	if (L.qcap >= qlen && qlen > 0) {
-		for (int j = lane; j < qlen; j += 64) L.qbuf[j] = q[q0 + j * qdir];
-		wave_sync();
-		qs = L.qbuf;
-	}
 	for (int i = 0; i < tlen; ++i) {
 		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
 		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
@@ -49,7 +41,7 @@ __device__ int wave_global2_score_ring(const DevIndex &ix, const bwagpu_opt_t &o
 		for (int b = beg; b < end; b += 64) {
 			const int j = b + lane; const bool act = j < end;
 			int dg = hd[j & rm]; const int ec = e_[j & rm];
-			const int qc = j < qlen ? (qs ? (int)qs[j] : (int)q[q0 + j * qdir]) : 4;
+			const int qc = j < qlen ? (int)q[q0 + j * qdir] : 4;
 			const int sc = L.mat[tb * 5 + qc];
 			const int bnd_next = hd[(b + 64) & rm];
 			if (b != beg && lane == 0) dg = bnd;
@@ -77,7 +69,7 @@ __device__ int wave_global2_score_ring(const DevIndex &ix, const bwagpu_opt_t &o
 	return score;
 }
 
-// The same with FOUR adjacent columns per lane (BWAGPU_DEDUP_BLK=1, opt-in until measured).  The patch alignments of a 10 kb read run in bands
+// The same with FOUR adjacent columns per lane (option dedup_blk; the default since round 4: 381 -> 207 ms per 6000 x 10 kb reads, BENCH_r03 variants).  The patch alignments of a 10 kb read run in bands
 // of 200-800 columns, and in the form above every 64 of them cost a pass -- two ordering points, an LDS round trip and a six-step scan, each
 // waiting for the one before at one wave per SIMD.  Here a pass covers 256 columns: a lane computes its four diagonal terms, a local prefix
 // maximum of their insertion starts, ONE wave scan over the lanes' totals, then F, H and E of its columns (ksw.c:587-603).  Blocks are
@@ -301,7 +293,7 @@ template <bool BLK = false> __device__ void dedup_read_wave(const DevIndex &ix, 
 }
 
 // One wavefront per read.
-// BLK (BWAGPU_DEDUP_BLK=1): patch alignments with four columns per lane; an instance of its own, so that the default kernel stays as measured
+// BLK (option dedup_blk, default on): patch alignments with four columns per lane
 template <bool BLK = false> __global__ void __launch_bounds__(256) k_dedup_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int ring_cols, int q_cap)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, ddw_lds)

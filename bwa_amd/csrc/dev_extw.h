@@ -100,10 +100,11 @@ DEVFN bwagpu_seed_t uni_seed(bwagpu_seed_t s) { s.rbeg = uni64(s.rbeg); s.qbeg =
 // ksw_extend2 only touches columns i-w .. i+w+1, columns left of the band are dead and columns right of it still hold their
 // first-row values, so eh[] is a ring of ring_mask+1 columns that is initialised lazily as the band advances, and scores come
 // from a 25-entry copy of the matrix (mat) and the query bases in global memory.
-// qbuf/qcap (RING, optional): room for a copy of the read; qlds: that copy once ext_read_wave has made it (null: bases come from the batch in HBM)
-struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t *mat; u8 *qbuf; int qcap; const u8 *qlds; };
+// (Round 3 also had an optional per-wave LDS copy of a long read and a four-columns-per-lane row form for long reads behind switches; on hardware the copy
+// made both long-read DP kernels 14-18 % slower -- its LDS halves the resident waves -- and the row form gained nothing, BENCH_r03 variants: both deleted.)
+struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t *mat; };
 
-template <bool RING, bool BLK = false> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, int mat_max, const u8 *q, int q0, const int qdir, int qlen,
+template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, int mat_max, const u8 *q, int q0, const int qdir, int qlen,
 								   i64 t0, const int tdir, int tlen, int w, int end_bonus, int h0, const WaveLds &L, u64 &cells, u64 &fast)
 {
 	const int lane = threadIdx.x & 63;
@@ -125,7 +126,7 @@ template <bool RING, bool BLK = false> __device__ ExtRes wave_ksw_extend2(const 
 	// most extensions of a read's true locus: a couple of wave steps instead of ~60 rows.
 	// score of reference base b against column j's query base: the read's profile (built once per read, indexed in the read's own
 	// coordinates whichever way the extension runs), or for long reads the matrix copy and the base itself
-	#define QBASE(idx) (L.qlds ? (int)L.qlds[idx] : (int)q[idx])       // (wave-uniform choice)
+	#define QBASE(idx) ((int)q[idx])
 	#define SCORE_AT(b, j) (RING ? (int)L.mat[(b) * 5 + QBASE(q0 + (j) * qdir)] : (int)qp[(b) * qs + q0 + (j) * qdir])
 	if (tlen >= qlen && qlen > 0) {
 		const int oe_min = oe_del < oe_ins ? oe_del : oe_ins;
@@ -175,7 +176,6 @@ template <bool RING, bool BLK = false> __device__ ExtRes wave_ksw_extend2(const 
 	u32 cells32 = 0;
 	int beg = 0, end = qlen, max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, treg = 0;
 	const bool two_col_ok = h0 + qlen * mat_max < (1 << 23);      // (score << 7 | column) must fit the scan's 31 bits
-	const bool blk_ok = h0 + qlen * mat_max < (1 << 22);          // (score << 8 | column of a 256-column pass) likewise
 	const int lane_e = lane * e_ins;
 	// Deferred bookkeeping of the single-pass rows.  What a row contributes to the running maximum (ksw.c:491-493), to the z-drop test
 	// (:494-500) and to the to-end score (:486-489) are three numbers -- its maximum m, that maximum's column mj, and H(i, end-1) when the
@@ -316,71 +316,6 @@ template <bool RING, bool BLK = false> __device__ ExtRes wave_ksw_extend2(const 
 			const int lastc = nact - 1;
 			hprev = (lastc & 1) ? __builtin_amdgcn_readlane(hB, lastc >> 1) : __builtin_amdgcn_readlane(hA, lastc >> 1);
 			wave_sync();
-		} else if (RING && BLK && blk_ok && beg < end) {
-			// Long reads, BWAGPU_EXT_BLK=1 (opt-in until measured): FOUR adjacent columns per lane, 256 per pass.  A band of 2 w + 1 = 201 columns
-			// costs the loop below four passes per row -- each with two ordering points, an LDS round trip and two six-step scans that wait for
-			// one another at one or two waves per SIMD -- and this form one: a lane computes M of its columns, the local prefix maximum of their
-			// insertion starts, ONE scan over the lanes' totals for F and one for the row maximum.  Blocks are aligned to multiples of four
-			// columns of the ring, so a lane's {H(i-1,j-1), E(i,j)} slots are two 16-byte LDS reads, and since slot j becomes {H(i,j-1), E(i+1,j)}
-			// -- the lane's own h one column over, the first from the lane below by a lane shift -- the lane writes the same two 16 bytes back.
-			// No lane touches another lane's slots within a row: one ordering point per row.  Slots outside [beg, end] are written back
-			// unchanged (the stale-cell rule: the reference never clears them).
-			for (int b = beg & ~3; b <= end; b += 256) {                 // (<=: slot `end` receives {H(i,end-1), 0}, ksw.c:485)
-				const int j0 = b + 4 * lane;
-				int4 *pp = (int4*)&eh[EHI(j0)];
-				const int4 s01 = pp[0], s23 = pp[1];
-				const int ox[4] = { s01.x, s01.z, s23.x, s23.z }, oy[4] = { s01.y, s01.w, s23.y, s23.w };
-				int M[4], pre[4], run = W_NEG;
-				#pragma unroll
-				for (int c = 0; c < 4; ++c) {
-					const int j = j0 + c; const bool act = j >= beg && j < end;
-					const int qc = j < qlen ? QBASE(q0 + j * qdir) : 4;
-					M[c] = ox[c] ? wadd(ox[c], L.mat[tb * 5 + qc]) : 0;      // ksw.c:469: a dead diagonal cell stays dead
-					pre[c] = run;
-					run = imax(run, act ? imax(wsub(M[c], oe_ins), 0) + j * e_ins : W_NEG);
-				}
-				const int inc = wave_incl_scan_max(run);
-				const int exl = imax(wave_shift_up1(inc, W_NEG), carry);      // best insertion start left of the lane's columns
-				int hv[4], en[4], lm = -1, lc = 0;
-				#pragma unroll
-				for (int c = 0; c < 4; ++c) {
-					const int j = j0 + c; const bool act = j >= beg && j < end;
-					const int f = j == beg ? 0 : imax(exl, pre[c]) - (j - 1) * e_ins;     // F(i,j), ksw.c:480-484
-					hv[c] = imax(imax(M[c], oy[c]), f);                                 // H(i,j) = max(M, E, F), ksw.c:470-471
-					en[c] = imax(imax(wsub(oy[c], e_del), wsub(M[c], oe_del)), 0);      // E(i+1,j), ksw.c:475-479
-					if (act && hv[c] >= lm) { lm = hv[c]; lc = c; }                     // last column wins ties (ksw.c:473-474)
-				}
-				const int hl0 = wave_shift_up1(hv[3], hprev);                         // H(i, j0-1): the lane below's last column; lane 0: the pass before
-				int nx[4], ny[4]; bool nzf[4];
-				#pragma unroll
-				for (int c = 0; c < 4; ++c) {
-					const int j = j0 + c; const bool in = j >= beg && j <= end;
-					const int hl = j == beg ? h1_init : (c == 0 ? hl0 : hv[c > 0 ? c - 1 : 0]);
-					nx[c] = in ? hl : ox[c];
-					ny[c] = in ? (j < end ? en[c] : 0) : oy[c];
-					nzf[c] = j >= beg && j < end && (hl | en[c]) != 0;
-				}
-				pp[0] = make_int4(nx[0], ny[0], nx[1], ny[1]);
-				pp[1] = make_int4(nx[2], ny[2], nx[3], ny[3]);
-				#pragma unroll
-				for (int c = 0; c < 4; ++c) {
-					const u64 bal = __ballot(nzf[c]);
-					if (bal) {
-						const int fc = b + 4 * (__ffsll((unsigned long long)bal) - 1) + c, lcn = b + 4 * (63 - __clzll((long long)bal)) + c;
-						if (first_nz < 0 || fc < first_nz) first_nz = fc;
-						if (lcn > last_nz) last_nz = lcn;
-					}
-				}
-				const int key = __builtin_amdgcn_readlane(wave_incl_scan_max(lm >= 0 ? (lm << 8 | (4 * lane + lc)) : -1), 63);
-				if (key >= 0 && (key >> 8) >= m) { m = key >> 8; mj = b + (key & 255); }
-				carry = imax(carry, __builtin_amdgcn_readlane(inc, 63));
-				if (end - b < 256) {                                                  // this pass holds slot `end`: h1 = H(i, end-1)
-					const int ce = (end - b) & 3;
-					const int xe = ce == 0 ? nx[0] : ce == 1 ? nx[1] : ce == 2 ? nx[2] : nx[3];
-					hprev = __builtin_amdgcn_readlane(xe, (end - b) >> 2);
-				} else hprev = __builtin_amdgcn_readlane(hv[3], 63);
-			}
-			wave_sync();
 		} else {
 			for (int b = beg; b < end; b += 64) {
 				const int j = b + lane; const bool act = j < end;
@@ -450,7 +385,7 @@ template <bool RING, bool BLK = false> __device__ ExtRes wave_ksw_extend2(const 
 }
 
 // mem_chain2aln for all chains of one read, executed by one wavefront.
-template <bool RING, bool BLK = false> __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const WaveLds &L0,
+template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const WaveLds &L0,
 							  u64 &n_calls, u64 &n_cells, u64 &n_refb, u64 &n_fast)
 {
 	const int lane = threadIdx.x & 63;
@@ -474,16 +409,6 @@ template <bool RING, bool BLK = false> __device__ void ext_read_wave(const DevIn
 			for (int k = 0; k < 5; ++k) L.qp[k * L.qstride + j] = L.mat[k * 5 + qc];
 		}
 		wave_sync();
-	} else {
-		// Long reads (BWAGPU_LONG_QLDS=1): every pass of every DP row looks up its lanes' query bases, and from the batch's array in HBM that
-		// is a dependent memory round trip in a loop that runs one or two waves per SIMD -- nothing hides it.  One copy of the read per
-		// wave (1 byte per base, the read's own coordinates) turns it into an LDS look-up next to the matrix's.
-		L.qlds = nullptr;
-		if (L.qcap >= l_query && l_query > 0) {
-			for (int j = lane; j < l_query; j += 64) L.qbuf[j] = query[j];
-			wave_sync();
-			L.qlds = L.qbuf;
-		}
 	}
 	for (int ci = 0; ci < n_ch; ++ci) {
 		const bwagpu_chain_t c = chains[ci];
@@ -573,7 +498,7 @@ template <bool RING, bool BLK = false> __device__ void ext_read_wave(const DevIn
 				for (int i = 0; i < 2; ++i) {
 					int prev = a.score;
 					aw0 = opt.w << i;
-					x = wave_ksw_extend2<RING, BLK>(ix, opt, mat_max, query, s.qbeg - 1, -1, s.qbeg, s.rbeg - 1, -1, tl, aw0, opt.pen_clip5, s.len * opt.a, L, n_cells, n_fast);
+					x = wave_ksw_extend2<RING>(ix, opt, mat_max, query, s.qbeg - 1, -1, s.qbeg, s.rbeg - 1, -1, tl, aw0, opt.pen_clip5, s.len * opt.a, L, n_cells, n_fast);
 					++n_calls;
 					a.score = x.score;
 					if (a.score == prev || x.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
@@ -588,7 +513,7 @@ template <bool RING, bool BLK = false> __device__ void ext_read_wave(const DevIn
 				for (int i = 0; i < 2; ++i) {
 					int prev = a.score;
 					aw1 = opt.w << i;
-					x = wave_ksw_extend2<RING, BLK>(ix, opt, mat_max, query, qe, 1, l_query - qe, re, 1, (int)(rmax1 - re), aw1, opt.pen_clip3, sc0, L, n_cells, n_fast);
+					x = wave_ksw_extend2<RING>(ix, opt, mat_max, query, qe, 1, l_query - qe, re, 1, (int)(rmax1 - re), aw1, opt.pen_clip3, sc0, L, n_cells, n_fast);
 					++n_calls;
 					a.score = x.score;
 					if (a.score == prev || x.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
@@ -616,23 +541,18 @@ template <bool RING, bool BLK = false> __device__ void ext_read_wave(const DevIn
 
 // One wavefront per read, 4 waves per workgroup; dynamic LDS = 4 private regions of
 // 8*(max_len+2+64) bytes of {H,E} columns + 5*qstride bytes of query profile, or (RING, long reads) of ring_cols*8 + 32 bytes.
-// q_cap (RING): bytes per wave behind the ring and the matrix for a copy of the read (0: none)
-// BLK (RING only, BWAGPU_EXT_BLK=1): DP rows with four columns per lane; an instance of its own, so that the default kernels' code and registers stay as measured
-template <bool RING, int OCC, bool BLK = false> __global__ void __launch_bounds__(256, OCC) k_extend_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int lds_per_wave, int ring_cols, int q_cap)
+template <bool RING, int OCC> __global__ void __launch_bounds__(256, OCC) k_extend_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int lds_per_wave, int ring_cols)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, dyn_lds)
 	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	WaveLds L;
-	L.qlds = nullptr;
 	unsigned char *base = dyn_lds + (size_t)wave_in_blk * lds_per_wave;
 	L.eh = (int2*)base;                                      // max_len + 2 columns + 64 of read-only padding
 	if (RING) {
 		int8_t *m = (int8_t*)(base + (size_t)8 * ring_cols);
 		if (lane < 25) m[lane] = opt.mat[lane];
 		L.mat = m; L.ring_mask = ring_cols - 1; L.qp = nullptr; L.qstride = 0;
-		L.qbuf = base + (size_t)8 * ring_cols + 32; L.qcap = q_cap;
 	} else {
-		L.qbuf = nullptr; L.qcap = 0;
 		L.qstride = (B.max_len + 64 + 3) & ~3;
 		L.qp = (int8_t*)(base + (size_t)8 * (B.max_len + 2 + 64));
 		int8_t *m = L.qp + 5 * L.qstride;                  // (the scoring matrix: dynamic indexing of the kernel argument would go through scratch memory)
@@ -648,7 +568,7 @@ template <bool RING, int OCC, bool BLK = false> __global__ void __launch_bounds_
 		long long k;
 		if (!wq_next(wq, &B.ctr->next_ext, B.n_reads, k)) break;
 		const int r = B.order[k];
-		ext_read_wave<RING, BLK>(ix, opt, B, r, L, calls, cells, refb, fast);
+		ext_read_wave<RING>(ix, opt, B, r, L, calls, cells, refb, fast);
 		wave_sync();
 		nraw += B.reg_n_raw[r];
 	}

@@ -194,83 +194,6 @@ template <int O32 = -1> DEVFN int fm_extend1(const DevIndex &ix, const BiIntv &i
 	return nblk;
 }
 
-// ---- quad-cooperative rank queries -------------------------------------------------------------------------------------------------
-// Measured (tools/randbw3.hip, profiles/r03_randbw3.md): when every lane fetches its own 64-byte block as 4 x dwordx4, each load
-// instruction touches 64 different lines for 16 bytes apiece and the chip serves 22.9e9 blocks/s; when the four lanes of a quad fetch ONE
-// block together -- lane p its p-th 16 bytes, one fully used 64-byte segment per quad and instruction -- it serves 51.3e9.  The index
-// is the reference's .bwt as it is (bwtindex.c:150-172): what changes is who loads which 16 bytes.
-//
-// One call answers, for every lane that asks (need), the two rank queries of bwt_extend (bwt.c:262-275) at its positions kk and ll
-// (primary-adjusted) for its symbol c: tk = Occ(c, kk), x2 = Occ(c, ll) - Occ(c, kk) and d = sum over symbols i > c of
-// Occ(i, ll) - Occ(i, kk).  The quad serves its four lanes in four steps.  In step s lanes 0,1 load the two count words of lane s's
-// kk-block and the two base words of its ll-block, lanes 2,3 the base words of the kk-block and the count words of the ll-block: every
-// lane then holds one count word and 64 bases, does the same work -- select its count, popcount its half block -- and the three
-// results are sums over the quad (two DPP quad_perm exchanges each).  Eight loads in flight per lane, as before.
-template <int CTRL> DEVFN u32 quad_perm32(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
-template <int CTRL> DEVFN u64 quad_perm64(u64 v) { return (u64)quad_perm32<CTRL>((u32)(v >> 32)) << 32 | quad_perm32<CTRL>((u32)v); }
-DEVFN u64 quad_sum64(u64 v) { v += quad_perm64<0xB1>(v); v += quad_perm64<0x4E>(v); return v; }    // lanes 0<->1, 2<->3; then pairs 01<->23
-template <int S> DEVFN u64 quad_bcast64(u64 v) { return quad_perm64<S * 0x55>(v); }                // the value of the quad's lane S
-template <int S> DEVFN u32 quad_bcast32(u32 v) { return quad_perm32<S * 0x55>(v); }
-
-struct CoopOcc { u64 tk, x2, d; };
-
-template <int S> DEVFN void coop_issue(const DevIndex &ix, u64 kk, u64 ll, u32 cn, int r, bool kcnt, uint4 &P, uint4 &Q)
-{
-	const u64 kks = quad_bcast64<S>(kk), lls = quad_bcast64<S>(ll);
-	P = make_uint4(0, 0, 0, 0); Q = P;
-	if (quad_bcast32<S>(cn) & 4u) {          // (uniform over the quad: the loads of a lane that does not ask are not issued)
-		const uint4 *bc = ix.bwt + ((kcnt ? kks : lls) >> 7) * 4, *bb = ix.bwt + ((kcnt ? lls : kks) >> 7) * 4;
-		P = bc[r]; Q = bb[2 + r];
-	}
-}
-template <int S> DEVFN void coop_reduce(u64 kk, u64 ll, u32 cn, int sub, int r, bool kcnt, const uint4 &P, const uint4 &Q, CoopOcc &res)
-{
-	const u64 kks = quad_bcast64<S>(kk), lls = quad_bcast64<S>(ll);
-	const int cs = (int)(quad_bcast32<S>(cn) & 3u);
-	const int n = (int)((kcnt ? lls : kks) & 127) + 1 - 64 * r;        // bases of this lane's half block that lie at or below the position
-	u32 c1 = 0, c2 = 0, c3 = 0;
-	count_pair_bf(Q.x, Q.y, n, c1, c2, c3); count_pair_bf(Q.z, Q.w, n - 32, c1, c2, c3);
-	const u32 cA = (u32)(n < 0 ? 0 : (n > 64 ? 64 : n)) - c1 - c2 - c3;
-	const u64 vpop = cs == 0 ? cA : cs == 1 ? c1 : cs == 2 ? c2 : c3;
-	const u64 dpop = (cs < 1 ? c1 : 0u) + (cs < 2 ? c2 : 0u) + (cs < 3 ? c3 : 0u);
-	const u64 lo = (u64)P.y << 32 | P.x, hi = (u64)P.w << 32 | P.z;    // running counts of symbols 2r and 2r+1 at the block's start
-	const u64 vcnt = (cs >> 1) == r ? ((cs & 1) ? hi : lo) : 0;
-	const u64 dcnt = (2 * r > cs ? lo : 0) + (2 * r + 1 > cs ? hi : 0);
-	// this lane's share of tk[c], of tl[c] - tk[c] and of sum_{i>c} (tl[i] - tk[i]); differences are taken modulo 2^64 and come out right in the sums
-	const u64 tk = quad_sum64(kcnt ? vcnt : vpop);
-	const u64 x2 = quad_sum64(kcnt ? vpop - vcnt : vcnt - vpop);
-	const u64 d = quad_sum64(kcnt ? dpop - dcnt : dcnt - dpop);
-	if (sub == S) { res.tk = tk; res.x2 = x2; res.d = d; }
-}
-// To be called by all lanes of the wave together (lanes that do not ask pass need = false and still load and count for their quad).
-DEVFN CoopOcc fm_occ_coop(const DevIndex &ix, bool need, u64 kk, u64 ll, int c)
-{
-	const int sub = (int)(threadIdx.x & 3), r = sub & 1; const bool kcnt = sub < 2;
-	const u32 cn = (u32)(c & 3) | (need ? 4u : 0u);
-	uint4 P0, P1, P2, P3, Q0, Q1, Q2, Q3;
-	coop_issue<0>(ix, kk, ll, cn, r, kcnt, P0, Q0); coop_issue<1>(ix, kk, ll, cn, r, kcnt, P1, Q1);
-	coop_issue<2>(ix, kk, ll, cn, r, kcnt, P2, Q2); coop_issue<3>(ix, kk, ll, cn, r, kcnt, P3, Q3);
-	CoopOcc res; res.tk = res.x2 = res.d = 0;
-	coop_reduce<0>(kk, ll, cn, sub, r, kcnt, P0, Q0, res); coop_reduce<1>(kk, ll, cn, sub, r, kcnt, P1, Q1, res);
-	coop_reduce<2>(kk, ll, cn, sub, r, kcnt, P2, Q2, res); coop_reduce<3>(kk, ll, cn, sub, r, kcnt, P3, Q3, res);
-	return res;
-}
-// bwt_extend for one child (fm_extend1's arithmetic) on top of it; returns the number of distinct blocks the lane's own queries touch
-DEVFN int fm_extend1_coop(const DevIndex &ix, bool need, const BiIntv &ik, int c, int is_back, BiIntv &out)
-{
-	const u64 a = is_back ? ik.x0 : ik.x1, other = is_back ? ik.x1 : ik.x0;
-	const u64 k = a - 1, l = a - 1 + ik.x2;
-	const u64 kk = k - (k >= ix.primary), ll = l - (l >= ix.primary);
-	const CoopOcc q = fm_occ_coop(ix, need, kk, ll, c);
-	const u64 o = other + (a <= ix.primary && a + ik.x2 - 1 >= ix.primary) + q.d;
-	const u64 L2c = c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
-	const u64 na = L2c + 1 + q.tk;
-	out.x2 = q.x2;
-	out.x0 = is_back ? na : o;
-	out.x1 = is_back ? o : na;
-	return (kk >> 7) == (ll >> 7) ? 1 : 2;
-}
-
 DEVFN void fm_init(const DevIndex &ix, int c, BiIntv &ik)
 {	// bwt_set_intv (bwt.h:82)
 	ik.x0 = ix.L2[c] + 1; ik.x2 = ix.L2[c + 1] - ix.L2[c]; ik.x1 = ix.L2[3 - c] + 1; ik.info = 0;

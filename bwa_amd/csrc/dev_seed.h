@@ -408,14 +408,17 @@ __global__ void __launch_bounds__(256) k_publish_blk(bwagpu_opt_t opt, Batch B)
 
 // RD: the batch's reads are short enough for an LDS copy (Batch::rd_words > 0)
 // BLK: how the extension reads the index -- 1 (default): the 32-byte layout (DevIndex::occ32), each lane fetching its own blocks; 0: the
-//      reference-format 64-byte blocks, per lane (BWAGPU_OCC32=0); 2: those blocks fetched quad-cooperatively (fm_occ_coop; BWAGPU_OCC32=0
-//      BWAGPU_SEED_COOP=1 -- a measured loss at this kernel's instruction count, kept for the day that count has come down).
-//      A compile-time choice, so that no path pays for another's registers.
-// OCC: waves per SIMD the register allocation aims at (the cooperative form holds more live values: 4 spills a little, 3 does not)
+//      reference-format 64-byte blocks, per lane (option occ32 = 0).  A compile-time choice, so that no path pays for another's registers.
+//      (A third form -- the 64-byte blocks fetched by quads of lanes -- raised the micro-benchmark's request ceiling 2.2x and made this kernel
+//      1.6x slower, profiles/r03_seed_variants.md; deleted in round 4.)
+// OCC: waves per SIMD the register allocation aims at
 // MRG (BLK == 1 only): memory round trips per wave iteration.  0: as the compiler schedules them -- interval-stack entry from HBM scratch,
 //      then the table look-ups, then the index blocks, then the blocks' first words for the lanes extending by A: up to four dependent
-//      trips.  1: table entries and whole blocks are issued together and waited for once (ext_one_trip).  2: additionally, a backward
-//      row's next interval-stack entry, when it lives in HBM scratch, is fetched in the same trip, one step ahead: one trip per iteration.
+//      trips.  2: table entries and whole blocks are issued together and waited for once (ext_one_trip), and a backward row's next
+//      interval-stack entry, when it lives in HBM scratch, is fetched in the same trip, one step ahead: one trip per iteration.  Measured
+//      (BENCH_r03 variants): short reads 83.3 -> 87.6 ms (the kernel is bound by the request rate of its live lanes, not by trips per
+//      iteration), long reads 515 -> 451 ms (few lanes, every trip exposed): the default for long-read batches only.  (The intermediate
+//      form without the prefetch, MRG = 1, was slower than both and is gone.)
 // LR (long-read batches, BWAGPU_SEED_CHUNK): pass 1 of a read is a chain of searches x -> ret(x) (bwamem.c:147-157), ~40 000 dependent index look-ups
 //      for a 10 kb read, and a batch has fewer reads than the chip has SIMDs.  The searches are pure functions of x, and chains started at different
 //      positions merge as soon as they share one (ret is monotone; a match that ends at a read error ends there for every start inside it).  So:
@@ -468,7 +471,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 		bf.stk = buf_rsrc((const u8*)B.tmp_intv + (size_t)blockIdx.x * blockDim.x * (size_t)cap * sizeof(BiIntv), MRG == 2 ? (u64)blockDim.x * (u64)cap * sizeof(BiIntv) : 0);
 		bf.nib = buf_rsrc(B.seq_nib, MRG == 2 && !RD ? B.seq_nib_bytes : 0);
 	}
-	while (__ballot(L.st != SS_DONE)) {       // (a lane that has run out of reads stays in the loop: its quad still needs it to fetch and count, fm_occ_coop)
+	while (__ballot(L.st != SS_DONE)) {
 		if (STATS) ++n_iter;
 		const bool slow = L.st < SS_FWD || L.st == SS_FINAL;
 		const u64 sm = __ballot(slow);
@@ -637,9 +640,6 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 		// entry instead of two index blocks.  That covers the first steps of every forward search and, in the first
 		// backward rows, the short change-point intervals, whose match q[i..end) is still short.
 		const bool blocks = ext && tl > ix.ptab_m;
-		if (BLK == 2) {           // all lanes together: the quad of a lane that needs blocks fetches them with it (the only extension site of the kernel)
-			const u32 nb = fm_extend1_coop(ix, blocks, src, cb, back, ok); if (STATS && blocks) nblk += nb;
-		}
 		if (MRG && BLK == 1) {
 			u32 pf_off = BUF_OOB;       // byte offset of the lane's next stack entry in the spill area (SeedStack::glob_col, packed entries)
 			if (MRG == 2 && back && !short_ent && S.n_lds && L.j + 1 < L.nprev && L.j + 1 >= S.n_lds)
@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 		if (ext) {
 			if (MRG && BLK == 1) ;
 			else if (!blocks) { ptab_load(ix, tl, L.code, ok); if (STATS) ++ntab; }
-			else if (BLK != 2) { const u32 nb = fm_extend1<BLK>(ix, src, cb, back, ok); if (STATS) nblk += nb; }
+			else { const u32 nb = fm_extend1<BLK>(ix, src, cb, back, ok); if (STATS) nblk += nb; }
 			if (st == SS_FWD) {           // forward sweep of bwt_smem1a (bwt.c:304-320)
 				bool stop = false;
 				if (ok.x2 != L.ik.x2) {
@@ -732,7 +732,7 @@ template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k
 	u32 nblk = 0, ntab = 0, weight = 0;
 	SeedBufs bf;
 	if (MRG && BLK == 1) { bf.occ = occ32_bufs(ix); bf.ptab = buf_rsrc(ix.ptab, ix.ptab_bytes); bf.stk = buf_rsrc(nullptr, 0); bf.nib = bf.stk; }
-	while (__ballot(st != T_DONE)) {          // (a lane without reads stays: its quad needs it, fm_occ_coop)
+	while (__ballot(st != T_DONE)) {
 		const u64 wm = __ballot(st == T_FETCH);
 		if (wm) {
 			if (pool_cnt == 0) {
@@ -773,7 +773,6 @@ template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k
 		const bool blocks = ext && tl > ix.ptab_m;
 		const int cb = blocks ? 3 - seed_q(L, nib, L.i) : 0;
 		BiIntv ok; ok.x0 = ok.x1 = ok.x2 = ok.info = 0;
-		if (BLK == 2) { const int nb = fm_extend1_coop(ix, blocks, L.ik, cb, 0, ok); if (blocks) nblk += nb; }   // (all lanes together)
 		if (MRG && BLK == 1) {
 			uint4 none;
 			BiIntv srcv = L.ik; if (!ext) srcv.x0 = srcv.x1 = srcv.x2 = 0;
@@ -783,7 +782,7 @@ template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k
 		if (ext) {
 			if (MRG && BLK == 1) ;
 			else if (!blocks) { ptab_load(ix, tl, L.code, ok); ++ntab; }
-			else if (BLK != 2) nblk += fm_extend1<BLK>(ix, L.ik, cb, 0, ok);
+			else nblk += fm_extend1<BLK>(ix, L.ik, cb, 0, ok);
 			if (tl == opt.min_seed_len) weight += (u32)(ok.x2 > 65535 ? 65535 : ok.x2);   // occurrences of the seed-length match: the read's repetitiveness
 			if (ok.x2 < opt.max_mem_intv && L.i - L.sx >= opt.min_seed_len) {
 				if (ok.x2 > 0) L.em.add(ok.x0, ok.x2, L.sx, L.i + 1);

@@ -107,7 +107,10 @@ void finalize_batch_chunks(const bwagpu_opt_t &opt, const RefSeqs &ref, int64_t 
 		}
 	};
 	if (n_threads <= 1 || n_chunks <= 1) work();
-	else { std::vector<std::thread> th; for (int t = 0; t < n_threads; ++t) th.emplace_back(work); for (auto &t : th) t.join(); }
+	else {      // (never more threads than chunks: a 100-read batch under -t 64 is two chunks)
+		const int nt = n_threads < n_chunks ? n_threads : n_chunks;
+		std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(work); for (auto &t : th) t.join();
+	}
 }
 
 // group bwagpu_batch_matesw records by the read they align and attach the slices to the reads

@@ -544,7 +544,12 @@ static std::mutex g_dev_mutex;
 static bool g_dev_serialize = false;   // BWAGPU_CLI_SERIALIZE=1: one device call at a time (the mock HIP runtime of the CPU tests is not thread-safe)
 
 // (_exit: this runs on a device thread while sibling threads may be inside HIP calls -- no atexit handlers / static destructors under them)
-static void device_fail(bwagpu_t *gpu, int rc) { fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu)); fflush(stderr); fflush(stdout); _exit(EXIT_FAILURE); }
+static void device_fail(bwagpu_t *gpu, int rc, const char *what = nullptr)
+{
+	if (rc == BWAGPU_OK) fprintf(stderr, "[E::%s] device results inconsistent: %s\n", "mem_process_seqs", what ? what : "record count mismatch");   // (a call that returned BWAGPU_OK with the wrong number of records)
+	else fprintf(stderr, "[E::%s] %s: %s\n", "mem_process_seqs", bwagpu_strerror(rc), bwagpu_last_error(gpu));
+	fflush(stderr); fflush(stdout); _exit(EXIT_FAILURE);
+}
 
 // One mem_process_seqs call's device work on the GPUs of `gpus` (one handle per device).  With several devices
 // the reads are split into contiguous ranges of whole pairs, every device runs the hot path -- and the device-side CIGARs and
@@ -626,7 +631,7 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 		if (s.tot == 0) return;
 		int64_t nc = 0;
 		int rc = bwagpu_batch_cigars(gpus[d], &u.opt, &s.cigs, &nc);
-		if (rc != BWAGPU_OK || nc != s.tot) device_fail(gpus[d], rc);
+		if (rc != BWAGPU_OK || nc != s.tot) device_fail(gpus[d], rc, "bwagpu_batch_cigars returned another number of records than bwagpu_batch_download");
 		rc = bwagpu_batch_cigar_ops(gpus[d], &s.ops, &s.n_ops);
 		if (rc != BWAGPU_OK) device_fail(gpus[d], rc);
 	});
@@ -887,6 +892,7 @@ int main(int argc, char *argv[])
 		printf("%s\n", pg.c_str());
 	}
 	const int chunk = fixed_chunk > 0 ? fixed_chunk : opt.chunk_size * opt.n_threads;
+	const bool long_preset = mode && (strcmp(mode, "pacbio") == 0 || strcmp(mode, "pbref") == 0 || strcmp(mode, "ont2d") == 0);
 	const double t_start = now_s();
 	if (getenv("BWAGPU_CLI_PARSE_ONLY")) {   // diagnostics: speed of the input stage alone
 		Batch b; long n = 0, bp = 0;
@@ -1014,9 +1020,14 @@ int main(int argc, char *argv[])
 
 	std::vector<std::thread> devs;
 	for (int d = 0; d < n_dev; ++d) devs.emplace_back([&, d] {      // stage 2: one host thread per device handle
-		// while the reader parses the first batch: the arenas of a batch of -K bases (150 bp reads assumed; anything else grows them later)
-		if (!g_dev_serialize && !(getenv("BWAGPU_CLI_RESERVE") && atoi(getenv("BWAGPU_CLI_RESERVE")) == 0))      // (not under the mock runtime of the CPU tests)
-			for (bwagpu_t *hh : handles[d]) (void)bwagpu_batch_reserve(hh, (int)((int64_t)chunk / 150 / (int64_t)handles[d].size()) + 1024, (int64_t)chunk / (int64_t)handles[d].size() + (1 << 20), 256);
+		// while the reader parses the first batch: the arenas of a batch of -K bases of short reads (150 bp assumed; anything else grows them
+		// later).  Not for the long-read presets: the short-read shape asks for ~4 GB per handle that a long-read run never uses and -- device
+		// buffers only ever grow -- never gets back.
+		if (!g_dev_serialize && !long_preset && !(getenv("BWAGPU_CLI_RESERVE") && atoi(getenv("BWAGPU_CLI_RESERVE")) == 0))      // (not under the mock runtime of the CPU tests)
+			for (bwagpu_t *hh : handles[d]) {
+				const int rc = bwagpu_batch_reserve(hh, (int)((int64_t)chunk / 150 / (int64_t)handles[d].size()) + 1024, (int64_t)chunk / (int64_t)handles[d].size() + (1 << 20), 256);
+				if (rc != BWAGPU_OK && g_verbose >= 2) fprintf(stderr, "[W::%s] could not reserve the batch arenas ahead of the first batch (%s: %s); they are grown batch by batch instead\n", "main_mem", bwagpu_strerror(rc), bwagpu_last_error(hh));
+			}
 		WorkP w;
 		while (to_dev.pop(w)) {
 			{ std::unique_lock<std::mutex> l(dm); dcv.wait(l, [&] { return w->no - next_fin <= (long)n_dev; }); }   // do not run ahead of the host

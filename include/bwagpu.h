@@ -301,6 +301,22 @@ int bwagpu_index_info(const bwagpu_t *h, int64_t *l_pac, int32_t *n_seqs, uint64
  * HBM capacity to delete dependent loads. */
 int bwagpu_densify_sa(bwagpu_t *h, int new_intv);
 
+/* ---- options ------------------------------------------------------------------------------------------------
+ * Tuning and test options of a handle, by name (the list with defaults and meanings: bwa_amd/csrc/bwagpu_config.h; bwagpu_option_name(i)
+ * enumerates it).  None of them changes a result -- they pick between kernel forms that the tests hold to identical output, size scratch
+ * areas, or force the overflow/retry paths.  A handle's options are fixed when it is created: compiled-in defaults, then the environment
+ * (BWAGPU_<NAME IN CAPITALS>, read once per bwagpu_create*), then bwagpu_set_default_option(); bwagpu_clone*() copies them;
+ * bwagpu_set_option() changes one between batches.  No batch call reads the environment.  (The reference has no counterpart: its tuning
+ * lives in mem_opt_t, which this library takes as it is.)
+ *   bwagpu_set_default_option: for handles created afterwards by this process -- the way to set the options that shape what is derived from
+ *   the index at load time (occ32, occ32_sb_shift, ptab_m); bwagpu_clear_default_options() forgets them all.
+ *   Unknown name -> BWAGPU_EINVAL.  -1 means "automatic" for the options that have such a setting. */
+int bwagpu_set_option(bwagpu_t *h, const char *name, long long value);
+int bwagpu_get_option(const bwagpu_t *h, const char *name, long long *value);
+int bwagpu_set_default_option(const char *name, long long value);
+void bwagpu_clear_default_options(void);
+int bwagpu_option_name(int i, const char **name);    /* i = 0, 1, ... until BWAGPU_EINVAL */
+
 /* Enable (1) / disable (0) collection of the algorithmic work counters in bwagpu_stats_t. */
 int bwagpu_set_stats(bwagpu_t *h, int enable);
 int bwagpu_get_stats(const bwagpu_t *h, bwagpu_stats_t *out);

@@ -21,7 +21,7 @@ def test_bench_variants_object(monkeypatch, tmp_path):
         os.symlink(prefix + ext, str(tmp_path / ("idx" + ext)))
     np.save(str(tmp_path / "idx.codes.npy"), g)
     monkeypatch.setenv("BWA_AMD_PROBE_LIB", hostsim_build.build())
-    args = argparse.Namespace(variants="BWAGPU_SEED_MRG=1;BWAGPU_SEED_MRG=2", variants_timeout=600.0, reads=8, read_len=150, streams=1, dense_sa=0,
+    args = argparse.Namespace(variants="seed_mrg=2;BWAGPU_SEED_LDS_ENT=3", variants_timeout=600.0, reads=8, read_len=150, streams=1, dense_sa=0,
                               no_longread=False, long_reads=1, long_len=1150)
     from bwa_amd import simdata
     short = simdata.make_reads_se(g, 8, seed=3)                   # bench.py hands its own batches over as files
@@ -30,9 +30,9 @@ def test_bench_variants_object(monkeypatch, tmp_path):
     res = bench.run_variants(args, str(tmp_path / "idx"), [str(tmp_path / "variant_batch0.npy")])
     short, long_ = res["short_reads"], res["long_reads"]
     assert short["rc"] == 0 and long_["rc"] == 0, (short, long_)
-    assert [r["config"] for r in short["runs"]] == ["defaults", "BWAGPU_SEED_MRG=1", "BWAGPU_SEED_MRG=2"]
-    assert [r["config"] for r in long_["runs"]] == ["defaults", "BWAGPU_SEED_MRG=2 BWAGPU_SEED_CHUNK=256 BWAGPU_PUBLISH_BLK=1 BWAGPU_LONG_QLDS=1 BWAGPU_SEEDSW_LDS=1 BWAGPU_DEDUP_BLK=1 BWAGPU_EXT_BLK=1",
-                                                    "BWAGPU_SEED_MRG=2", "BWAGPU_SEED_CHUNK=256", "BWAGPU_PUBLISH_BLK=1", "BWAGPU_LONG_QLDS=1", "BWAGPU_SEEDSW_LDS=1", "BWAGPU_DEDUP_BLK=1", "BWAGPU_EXT_BLK=1"]
+    assert [r["config"] for r in short["runs"]] == ["defaults", "seed_mrg=2", "BWAGPU_SEED_LDS_ENT=3"]      # (the round-3 spelling of an option is still accepted)
+    assert [r["config"] for r in long_["runs"]] == ["defaults", "seed_mrg=0 seed_chunk=0 publish_blk=0 seedsw_lds=0 dedup_blk=0",
+                                                    "seed_mrg=0", "seed_chunk=0", "publish_blk=0", "seedsw_lds=0", "dedup_blk=0"]
     for r in short["runs"] + long_["runs"]:
         assert "error" not in r and r["same_result_as_defaults"] is True, r
     assert all("ms_per_step" in r and "stage_ms_solo" in r for r in short["runs"]) and all("ms_per_pass" in r for r in long_["runs"])
@@ -57,7 +57,7 @@ def test_variants_share_the_wall_budget(tmp_path):
     gets more than 55 % of what is left."""
     import time
     import bench
-    args = argparse.Namespace(variants="BWAGPU_SEED_MRG=1", variants_timeout=600.0, reads=8, read_len=150, streams=1, dense_sa=0,
+    args = argparse.Namespace(variants="seed_mrg=2", variants_timeout=600.0, reads=8, read_len=150, streams=1, dense_sa=0,
                               no_longread=False, long_reads=1, long_len=1150)
     t = time.time()
     res = bench.run_variants(args, str(tmp_path / "none"), [], wall_left=15.0)

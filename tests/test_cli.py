@@ -226,10 +226,10 @@ def test_cli_hostsim_two_devices(tmp_path):
     simdata.write_fastq(noisy, simdata.make_reads_se(g, 16, seed=404, sub=0.02, dele=0.03, ins=0.03))
     assert _run(refapi.REF_BWA, K + [prefix, noisy]) == _run(cli, K + [prefix, noisy], env), "gap-rich reads, 2 devices"
     # the 32-byte block layout of the BWT is rebuilt on every device the index is copied to (here with small superblocks, so that the
-    # superblock table is in play); and the same run on the reference-format blocks, fetched quad-cooperatively
+    # superblock table is in play); and the same run on the reference-format blocks
     env_occ = dict(env, BWAGPU_OCC32="1", BWAGPU_OCC32_SB_SHIFT="10")
     assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], env_occ), "paired-end, 2 devices, 32-byte blocks with 2^10-base superblocks"
-    assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], dict(env, BWAGPU_OCC32="0", BWAGPU_SEED_COOP="1")), "paired-end, 2 devices, 64-byte blocks fetched quad-cooperatively"
+    assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], dict(env, BWAGPU_OCC32="0")), "paired-end, 2 devices, reference-format 64-byte blocks"
     env3 = dict(env, MOCK_HIP_DEVICES="3", BWAGPU_DEVICES="0,1,2")
     assert _run(refapi.REF_BWA, K + [prefix, f1, f2]) == _run(cli, K + [prefix, f1, f2], env3), "paired-end, 3 devices"
 

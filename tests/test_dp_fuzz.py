@@ -119,7 +119,7 @@ def wide_band_cases(rng, n):
 
 
 def very_wide_band_cases(rng, n):
-    """The same for the four-columns-per-lane rows of the ring form (BWAGPU_EXT_BLK=1), which take another pass every 256 columns: the band
+    """The same for the ring form's multi-pass rows at widths beyond 256 columns: the band
     grows through 255..257 (and, for the longest queries, 511..513) live columns; every other case has an unrelated stretch in the middle,
     so that the zero-trimming cuts the band inside a pass and the stale-cell rule meets slots of a block the band has left."""
     cs = CaseSet()
@@ -344,32 +344,26 @@ def test_sim_extend_ring_fuzz(sim):
     run_extend(sim, 1, 120, 160, 12, need_stale=False)
 
 
-def test_sim_ring_forms_with_the_query_in_lds(sim, monkeypatch):
-    """BWAGPU_LONG_QLDS=1: the ring-mode extension and the score-only ring aligner read their query bases from an LDS copy (the switchable
-    form of the long-read kernels); same outputs as the reference's ksw_extend2 / ksw_global2."""
-    monkeypatch.setenv("BWAGPU_LONG_QLDS", "1")
-    run_extend(sim, 1, 48, 400, seed=17, need_stale=False)
-    run_global(sim, 3, 32, 150, 90, seed=18)
-
-
-def test_sim_ring_extension_four_columns_per_lane(sim, monkeypatch):
-    """BWAGPU_EXT_BLK=1: every DP row of the ring-mode extension (long reads) with four adjacent columns per lane, 256 columns per pass, a lane
-    reading and writing only its own {H,E} slots: same outputs as the reference's ksw_extend2 -- the fuzz families of the ring form
-    (stale-cell constructions, collapsing bands, z-drop, N bases, both strands) plus bands that grow through 255..257 and 511..513 columns;
-    with and without the LDS copy of the query."""
-    monkeypatch.setenv("BWAGPU_EXT_BLK", "1")
-    run_extend(sim, 1, 200, 400, seed=41, need_stale=False, very_wide=10)
-    monkeypatch.setenv("BWAGPU_LONG_QLDS", "1")
-    run_extend(sim, 1, 120, 400, seed=42, need_stale=False, very_wide=6)
-
-
-def test_sim_ring_global_four_columns_per_lane(sim, monkeypatch):
-    """BWAGPU_DEDUP_BLK=1: the score-only ring aligner of k_dedup_wave with four adjacent columns per lane (one scan and one ordering point per
-    256 columns of a row): same scores as the reference's ksw_global2 -- short segments, bands at the widths where a row takes a second
-    and a third pass (127..129, 255..257 columns on either side), segments of up to 900 bases, reverse-strand geometry and N bases included."""
-    monkeypatch.setenv("BWAGPU_DEDUP_BLK", "1")
+def test_sim_ring_global_both_forms(sim):
+    """The score-only ring aligner of k_dedup_wave.  Default (option dedup_blk): four adjacent columns per lane, one scan and one ordering
+    point per 256 columns of a row; dedup_blk = 0: one column per lane, a pass per 64 columns.  Same scores as the reference's ksw_global2 either
+    way -- short segments, bands at the widths where a row takes a second and a third pass (127..129, 255..257 columns on either side),
+    segments of up to 900 bases, reverse-strand geometry and N bases included."""
+    assert sim.get_option("dedup_blk") == -1
     run_global(sim, 3, 80, 150, 1 << 30, seed=31)
     run_global(sim, 3, 48, 900, 1 << 30, seed=32, wide=(63, 64, 126, 127, 128, 129, 130, 200, 255, 256, 257, 300))
+    sim.set_option("dedup_blk", 0)
+    try:
+        run_global(sim, 3, 40, 150, 1 << 30, seed=33)
+        run_global(sim, 3, 16, 900, 1 << 30, seed=34, wide=(63, 64, 127, 128, 129, 255, 256, 257))
+    finally:
+        sim.set_option("dedup_blk", -1)
+
+
+def test_sim_ring_extension_wide_bands(sim):
+    """The ring-mode extension (long reads) with bands that grow through 255..257 and 511..513 live columns -- five to nine passes of 64
+    columns per row, the zero-trimming cutting the band inside a pass, stale slots of passes the band has left."""
+    run_extend(sim, 1, 60, 400, seed=41, need_stale=False, very_wide=10)
 
 
 def test_sim_global_fuzz(sim):
@@ -415,34 +409,18 @@ def test_gpu_align2_fuzz(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason="BWAGPU_EXT_BLK / BWAGPU_DEDUP_BLK are opt-in kernel forms written after the round's last GPU second: mock runtime, "
-                                        "sanitizers and static ISA only so far.  Their first hardware run is informational (xpassed = same outputs as the reference's "
-                                        "ksw_extend2 / ksw_global2 on the device) and must not take the suite of the product's default kernels with it.")
-def test_gpu_ring_forms_four_columns_per_lane():
-    """In a child process with a time limit: kernels that have never met hardware get no chance to hang the suite's own process."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BWAGPU_EXT_BLK="1", BWAGPU_DEDUP_BLK="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    p = subprocess.run([sys.executable, os.path.abspath(__file__), "blk-child"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
-    assert p.returncode == 0, p.stdout[-3000:]
+def test_gpu_ring_global_both_forms(gpu):
+    """k_dedup_wave's score-only aligner on hardware in both forms -- four columns per lane (the product's default since round 4) and one column
+    per lane (option dedup_blk = 0) -- against the reference's ksw_global2, with bands through every width at which a row takes another pass.
+    (Round 3 ran the four-column form as a non-strict expected failure in a child process; it is the product now and gates the suite.)"""
+    run_global(gpu, 3, 3000, 1000, 1 << 30, 44, wide=(63, 64, 127, 128, 129, 200, 255, 256, 257, 300, 383, 384, 385, 500))
+    gpu.set_option("dedup_blk", 0)
+    try:
+        run_global(gpu, 3, 2000, 1000, 1 << 30, 46, wide=(63, 64, 127, 128, 129, 255, 256, 257, 383, 384, 385))
+    finally:
+        gpu.set_option("dedup_blk", -1)
 
 
-def _blk_child():
-    dev = BwaGpu(testdata.small_index()[0])
-    run_extend(dev, 1, 3000, 400, 43, need_stale=True, very_wide=40)
-    run_global(dev, 3, 2000, 1000, 1 << 30, 44, wide=(63, 64, 127, 128, 129, 200, 255, 256, 257, 300, 383, 384, 385, 500))
-    os.environ["BWAGPU_LONG_QLDS"] = "1"
-    run_extend(dev, 1, 1000, 400, 45, need_stale=False, very_wide=20)
-    dev.close()
-    print("four columns per lane: same outputs as the reference")
-
-
-if __name__ == "__main__":
-    import sys
-    if len(sys.argv) > 1 and sys.argv[1] == "blk-child":
-        if os.environ.get("BWA_AMD_PROBE_LIB"):      # (the mock runtime, to try the child itself without a GPU)
-            _lib = os.environ["BWA_AMD_PROBE_LIB"]
-            _orig = BwaGpu
-            BwaGpu = lambda prefix: _orig(prefix, lib_path=_lib)      # noqa: E731
-        _blk_child()
+@pytest.mark.gpu
+def test_gpu_ring_extension_wide_bands(gpu):
+    run_extend(gpu, 1, 2000, 400, 43, need_stale=True, very_wide=40)

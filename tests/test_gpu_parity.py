@@ -163,10 +163,10 @@ def test_dense_sa_gives_identical_results(medium):
     g2.close()
 
 
-def test_index_access_variants_give_identical_results(medium, monkeypatch):
-    """Seeding, SA look-ups, SA densification and the prefix tables read the 32-byte layout of the BWT by default; BWAGPU_OCC32=0 keeps them
-    on the reference-format 64-byte blocks, BWAGPU_SEED_COOP=1 lets the seeding kernels fetch those quad-cooperatively: same regions and
-    interval taps in every variant, with the SA at the reference's interval and densified."""
+def test_index_access_variants_give_identical_results(medium):
+    """Seeding, SA look-ups, SA densification and the prefix tables read the 32-byte layout of the BWT by default; option occ32 = 0 keeps them
+    on the reference-format 64-byte blocks; prefix tables off or shallow; the one-round-trip seeding kernel (seed_mrg = 2, the long-read
+    default) on short reads: same regions and interval taps in every variant, with the SA at the reference's interval and densified."""
     from bwa_amd.api import BwaGpu
     gpu, orc, ref, g = medium
     fa, _ = testdata.medium_index()
@@ -174,18 +174,14 @@ def test_index_access_variants_give_identical_results(medium, monkeypatch):
     base = gpu.align(default_opt(), seqs, off)
     n0, iv0 = gpu.tap_intervals()
     assert_regs_equal(*ref.align(default_opt(), seqs, off), *base, "32-byte blocks vs compiled reference")
-    for env in ({"BWAGPU_OCC32": "0"}, {"BWAGPU_OCC32": "0", "BWAGPU_SEED_COOP": "1"}, {"BWAGPU_OCC32": "0", "BWAGPU_SEED_COOP": "1", "BWAGPU_SEED_OCC": "4"}, {"BWAGPU_PTAB_M": "0"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        g2 = BwaGpu(fa)
+    for env in ({"occ32": 0}, {"occ32": 0, "ptab_m": 0}, {"ptab_m": 0}, {"ptab_m": 7}, {"seed_mrg": 2}, {"seed_mrg": 2, "seed_lds_ent": 2}):
+        g2 = BwaGpu(fa, options=env)
         assert_regs_equal(*base, *g2.align(default_opt(), seqs, off), f"{env}, sa_intv 32")
         n1, iv1 = g2.tap_intervals()
         assert np.array_equal(n0, n1) and iv0.tobytes() == iv1.tobytes(), env
         g2.densify_sa(2)
         assert_regs_equal(*base, *g2.align(default_opt(), seqs, off), f"{env}, sa_intv 2")
         g2.close()
-        for k in env:
-            monkeypatch.delenv(k)
 
 
 def test_properties_at_scale(medium):
@@ -376,3 +372,43 @@ def test_pacbio_10kb_reads(medium):
     sub = reads[:24]
     seqs, off = testdata.flat(sub)
     assert_regs_equal(*ref.align(o2, seqs, off), *gpu.align(o2, seqs, off), "pacbio 10 kb, w = 700 (k_extend fallback)")
+
+
+def _ref_align_threads(ref, opt, reads, n_threads=16):
+    """ref.align over slices of `reads` on host threads (the compiled reference's call is per read and ctypes drops the GIL)."""
+    import threading
+    n = reads.shape[0]
+    cuts = np.linspace(0, n, min(n_threads, n) + 1).astype(int)
+    parts = [None] * (len(cuts) - 1)
+
+    def work(i):
+        parts[i] = ref.align(opt, *testdata.flat(reads[cuts[i]:cuts[i + 1]]))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(parts))]
+    [t.start() for t in th]; [t.join() for t in th]
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+
+def test_pacbio_10kb_reads_at_scale_under_the_long_read_defaults(medium):
+    """600 reads of 10 kb, -x pacbio, in two batches of 300 on one handle (arenas, chunk-task tables and scratch re-used), under the kernel
+    forms that became the long-read defaults in round 4 -- pass 1 of the seeding by chunks of 256 bases with one memory round trip per
+    iteration, workgroup-per-read interval sort, seed re-scoring in LDS, four columns per lane in the patch alignments: regions equal the
+    compiled reference's mem_align1_core, read by read.  A third batch runs the forms they replaced on the same handle (options set
+    through the API between batches): the same regions again."""
+    gpu, orc, ref, g = medium
+    for k in ("seed_mrg", "seed_chunk", "publish_blk", "seedsw_lds", "dedup_blk"):
+        assert gpu.get_option(k) == -1, f"{k} is not on its automatic setting"
+    reads = simdata.make_reads_long(g, 600, length=10000, seed=66)
+    want = _ref_align_threads(ref, pacbio_opt(), reads)
+    got = [gpu.align(pacbio_opt(), *testdata.flat(reads[a:a + 300])) for a in (0, 300)]
+    assert_regs_equal(*want, np.concatenate([x[0] for x in got]), np.concatenate([x[1] for x in got]), "pacbio 10 kb x 600, long-read defaults, two batches")
+    assert int(want[0].sum()) > 600
+    old = {"seed_mrg": 0, "seed_chunk": 0, "publish_blk": 0, "seedsw_lds": 0, "dedup_blk": 0}
+    try:
+        for k, v in old.items():
+            gpu.set_option(k, v)
+        c3, r3 = gpu.align(pacbio_opt(), *testdata.flat(reads[:120]))
+    finally:
+        for k in old:
+            gpu.set_option(k, -1)
+    n120 = int(want[0][:120].sum())
+    assert_regs_equal(want[0][:120], want[1][:n120], c3, r3, "pacbio 10 kb x 120, round-3 kernel forms")

@@ -22,6 +22,12 @@ def sim():
     s.close()
 
 
+def sim_handle(prefix, **options):
+    """A fresh handle on the mock runtime with the given library options (bwagpu_set_option's names, bwa_amd/csrc/bwagpu_config.h): the tests
+    select kernel forms and test hooks through the API, not through the environment."""
+    return BwaGpu(prefix, lib_path=hostsim_build.build(), options=options)
+
+
 # The mock runs every lane as a fiber and every wave collective as a rendezvous, so the wave-cooperative extension
 # kernel costs ~0.1 s per read here; the CPU suite therefore checks a prefix of each golden set (the GPU suite
 # checks all of it).
@@ -37,21 +43,21 @@ def test_hostsim_regs_match_golden(sim):
         assert_regs_equal(counts[:k], regs.astype(ALNREG_DTYPE)[: int(counts[:k].sum())], c, r, f"golden {name}")
 
 
-def test_hostsim_long_read_dedup_ring_sizes(monkeypatch):
+def test_hostsim_long_read_dedup_ring_sizes():
     """k_dedup_wave's ring of {H,E} columns is sized by the batch's longest read, and its workgroups shrink to two waves (2048 columns) or one
     (4096) to stay within a workgroup's LDS; a ring too small for a patch alignment's band sends that alignment to the one-lane fall-back
-    (256 columns): same regions in every case (2048 columns / two waves: the GPU suite's long-read tests).  The second run also takes the
-    one-round-trip seeding kernel in its long-read form (BWAGPU_SEED_MRG=2: stack entries and read windows fetched a step ahead) and the
-    workgroup-per-read form of the interval sort and SA-row expansion (BWAGPU_PUBLISH_BLK=1), and keeps the query bases of the extension and
-    patch-alignment rows in LDS (BWAGPU_LONG_QLDS=1)."""
+    (256 columns): same regions in every case (2048 columns / two waves: the GPU suite's long-read tests).  The first run takes the round-3
+    kernel forms (lane-per-read seeding with the compiler's load schedule, one-lane interval sort, one column per lane in the patch alignments),
+    the second the long-read defaults: the one-round-trip seeding kernel (seed_mrg = 2: stack entries and read windows fetched a step ahead),
+    the workgroup-per-read interval sort and SA-row expansion, four columns per lane."""
     prefix, g = testdata.small_index()
     orc = orcapi.OrcIndex(prefix)
     reads = simdata.make_reads_long(g, 1, length=1800, seed=23)
     seqs, off = testdata.flat(reads)
     want = orc.align(pacbio_opt(), seqs, off)
     for ring, mrg in (("256", "0"), ("4096", "2")):
-        monkeypatch.setenv("BWAGPU_DEDUP_RING", ring); monkeypatch.setenv("BWAGPU_SEED_MRG", mrg); monkeypatch.setenv("BWAGPU_PUBLISH_BLK", "1" if mrg == "2" else "0"); monkeypatch.setenv("BWAGPU_LONG_QLDS", "1" if mrg == "2" else "0")
-        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+        s2 = sim_handle(prefix, dedup_ring=int(ring), **({"seed_mrg": 0, "publish_blk": 0, "dedup_blk": 0, "seed_chunk": 0, "seedsw_lds": 0} if mrg == "0" else {"seed_chunk": 0}))
+        assert s2.get_option("seed_mrg") == (0 if mrg == "0" else -1)
         s2.set_stats(True)
         assert_regs_equal(*want, *s2.align(pacbio_opt(), seqs, off), f"1.8 kb -x pacbio read, dedup ring {ring}, seeding variant {mrg}")
         if mrg == "2":       # a read too long for an LDS copy: its 16-base windows arrive one step ahead, with the index blocks
@@ -64,8 +70,8 @@ def test_hostsim_long_read_dedup_ring_sizes(monkeypatch):
     orc.close()
 
 
-def test_hostsim_publish_per_workgroup(monkeypatch):
-    """BWAGPU_PUBLISH_BLK=1 (long-read batches): one workgroup per read sorts the interval list (bitonic network in LDS; equal keys are
+def test_hostsim_publish_per_workgroup():
+    """Option publish_blk (long-read batches; their default): one workgroup per read sorts the interval list (bitonic network in LDS; equal keys are
     identical intervals), counts the SA rows and expands them from a block-wide prefix sum.  With -k 9 on the repeat-rich 2 Mb genome a
     1.3 kb read leaves ~800 intervals -- several 256-interval chunks -- next to a read with a handful and one with none: interval lists
     (order included), slot counts and regions equal the one-lane-per-read kernels'."""
@@ -78,8 +84,7 @@ def test_hostsim_publish_per_workgroup(monkeypatch):
     opt = pacbio_opt(); opt.min_seed_len = 9; opt.max_occ = 7
     got = {}
     for blk in ("0", "1"):
-        monkeypatch.setenv("BWAGPU_PUBLISH_BLK", blk)
-        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+        s2 = sim_handle(prefix, publish_blk=int(blk))
         s2.set_stats(True)
         c, r = s2.align(opt, seqs, off)
         ic, iv = s2.tap_intervals()
@@ -91,8 +96,8 @@ def test_hostsim_publish_per_workgroup(monkeypatch):
 
 
 @pytest.mark.parametrize("scale", [1, 2])
-def test_hostsim_seed_rescoring_in_lds(monkeypatch, scale):
-    """BWAGPU_SEEDSW_LDS=1 (long-read batches): mem_seed_sw's local alignments (bwamem.c:597-621) with their DP rows, the window's query bases
+def test_hostsim_seed_rescoring_in_lds(scale):
+    """Option seedsw_lds (long-read batches; their default): mem_seed_sw's local alignments (bwamem.c:597-621) with their DP rows, the window's query bases
     and the scoring matrix in LDS / registers -- 8-bit cells for a = 1, 16-bit cells for scaled scores: the seeds' scores after
     mem_flt_chained_seeds, the surviving seeds and the regions equal the HBM-scratch form's."""
     from bwa_amd.structs import fill_scmat
@@ -107,8 +112,7 @@ def test_hostsim_seed_rescoring_in_lds(monkeypatch, scale):
         fill_scmat(opt)
     got = {}
     for lds in ("0", "1"):
-        monkeypatch.setenv("BWAGPU_SEEDSW_LDS", lds)
-        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+        s2 = sim_handle(prefix, seedsw_lds=int(lds))
         s2.set_stats(True)
         c, r = s2.align(opt, seqs, off)
         cc, ch, sd = s2.tap_chains()
@@ -119,10 +123,10 @@ def test_hostsim_seed_rescoring_in_lds(monkeypatch, scale):
     assert got["0"] == got["1"]
 
 
-def test_hostsim_seeding_variants_same_intervals(monkeypatch):
+def test_hostsim_seeding_variants_same_intervals():
     """Seeding alone, in bulk: with a chain-weight threshold nothing passes, the stages after seeding have no work, so a few thousand reads
     of the repeat-rich 2 Mb genome (substitutions, indels, Ns) cost seconds on the mock runtime.  The interval lists (order included) of the
-    one-round-trip kernels -- BWAGPU_SEED_MRG=1, =2, =2 on a two-entry LDS stack, =2 without the LDS copy of the reads -- equal the default
+    one-round-trip kernels -- seed_mrg = 2, the same on a two-entry LDS stack, and without the LDS copy of the reads -- equal the default
     kernel's, whose intervals the golden-fixture tests pin to the reference."""
     import refapi
     if not refapi.have_ref():
@@ -134,13 +138,9 @@ def test_hostsim_seeding_variants_same_intervals(monkeypatch):
     seqs, off = testdata.ragged(reads)
     opt = default_opt(); opt.min_chain_weight = 1 << 20
     got = {}
-    for name, env in (("default", {}), ("mrg1", {"BWAGPU_SEED_MRG": "1"}), ("mrg2", {"BWAGPU_SEED_MRG": "2"}),
-                      ("mrg2 small stack", {"BWAGPU_SEED_MRG": "2", "BWAGPU_SEED_LDS_ENT": "2"}), ("mrg2 no read copy", {"BWAGPU_SEED_MRG": "2", "BWAGPU_SEED_RD_LDS": "0"})):
-        for k in ("BWAGPU_SEED_MRG", "BWAGPU_SEED_LDS_ENT", "BWAGPU_SEED_RD_LDS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+    for name, options in (("default", {}), ("mrg2", {"seed_mrg": 2}),
+                          ("mrg2 small stack", {"seed_mrg": 2, "seed_lds_ent": 2}), ("mrg2 no read copy", {"seed_mrg": 2, "seed_rd_lds": 0})):
+        s2 = sim_handle(prefix, **options)
         c, r = s2.align(opt, seqs, off)
         ic, iv = s2.tap_intervals()
         assert int(c.sum()) == 0 and int(ic.sum()) > 5 * len(reads)
@@ -150,8 +150,8 @@ def test_hostsim_seeding_variants_same_intervals(monkeypatch):
         assert got[name] == got["default"], name
 
 
-def test_hostsim_long_read_pass1_by_chunks(monkeypatch):
-    """BWAGPU_SEED_CHUNK=<n> (long-read batches): pass 1 of mem_collect_intv split into tasks of n bases -- chunk workers record the chain of
+def test_hostsim_long_read_pass1_by_chunks():
+    """Option seed_chunk = n (long-read batches; their default is 256): pass 1 of mem_collect_intv split into tasks of n bases -- chunk workers record the chain of
     search positions they walk and the SMEMs they find, the lane-per-read kernel jumps from chunk to chunk wherever its own position lies on a
     worker's chain and recomputes where it does not (k_seed's LR modes).  Noisy 3 kb reads, reads with N runs, nearly exact reads whose matches
     span several chunks, a read of one chunk, an all-N and an empty read; chunk sizes that do and do not divide the reads, with the
@@ -170,13 +170,9 @@ def test_hostsim_long_read_pass1_by_chunks(monkeypatch):
     seqs, off = testdata.ragged(reads)
     opt = pacbio_opt(); opt.min_chain_weight = 1 << 20          # (nothing passes the chain filter: the stages after seeding have no work)
     got, blocks = {}, {}
-    for name, env in (("serial", {}), ("64", {"BWAGPU_SEED_CHUNK": "64"}), ("256 + one trip", {"BWAGPU_SEED_CHUNK": "256", "BWAGPU_SEED_MRG": "2"}),
-                      ("100", {"BWAGPU_SEED_CHUNK": "100"}), ("128, lists of 6", {"BWAGPU_SEED_CHUNK": "128", "BWAGPU_SEED_CHUNK_CAP": "6"})):
-        for k in ("BWAGPU_SEED_CHUNK", "BWAGPU_SEED_MRG", "BWAGPU_SEED_CHUNK_CAP"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+    for name, options in (("serial", {"seed_chunk": 0, "seed_mrg": 0}), ("64", {"seed_chunk": 64, "seed_mrg": 0}), ("256 + one trip", {}),
+                          ("100", {"seed_chunk": 100, "seed_mrg": 0}), ("128, lists of 6", {"seed_chunk": 128, "seed_chunk_cap": 6, "seed_mrg": 0})):
+        s2 = sim_handle(prefix, **options)
         s2.set_stats(True)
         c, r = s2.align(opt, seqs, off)
         ic, iv = s2.tap_intervals()
@@ -254,31 +250,28 @@ def _n_rich_reads(g, n, max_len, seed):
     return out
 
 
-@pytest.mark.parametrize("max_len,env", [(150, {}), (250, {}), (120, {"BWAGPU_SEED_NO_VIRT": "1"}), (150, {"BWAGPU_SEED_RD_LDS": "0"}),
-                                         (150, {"BWAGPU_PTAB_M": "5", "BWAGPU_SEED_LDS_ENT": "2"}), (150, {"BWAGPU_OCC32": "0"}), (150, {"BWAGPU_OCC32": "0", "BWAGPU_PTAB_M": "0"}), (150, {"BWAGPU_PTAB_M": "0"}),
-                                         (150, {"BWAGPU_OCC32": "0", "BWAGPU_SEED_COOP": "1"}),
-                                         (150, {"BWAGPU_SEED_MRG": "1"}), (150, {"BWAGPU_SEED_MRG": "2"}), (250, {"BWAGPU_SEED_MRG": "2", "BWAGPU_SEED_LDS_ENT": "2"}),
-                                         (150, {"BWAGPU_SEED_MRG": "2", "BWAGPU_SEED_RD_LDS": "0", "BWAGPU_PTAB_M": "5"}), (150, {"BWAGPU_SEED_MRG": "2", "BWAGPU_SEED_NO_VIRT": "1", "BWAGPU_SEED_LDS_ENT": "1"})])
-def test_hostsim_seeding_paths_with_n_reads(monkeypatch, max_len, env):
+@pytest.mark.parametrize("max_len,env", [(150, {}), (250, {}), (120, {"seed_no_virt": 1}), (150, {"seed_rd_lds": 0}),
+                                         (150, {"ptab_m": 5, "seed_lds_ent": 2}), (150, {"occ32": 0}), (150, {"occ32": 0, "ptab_m": 0}), (150, {"ptab_m": 0}),
+                                         (150, {"seed_mrg": 2}), (250, {"seed_mrg": 2, "seed_lds_ent": 2}),
+                                         (150, {"seed_mrg": 2, "seed_rd_lds": 0, "ptab_m": 5}), (150, {"seed_mrg": 2, "seed_no_virt": 1, "seed_lds_ent": 1})])
+def test_hostsim_seeding_paths_with_n_reads(max_len, env):
     """The seeding kernel's read copy in LDS (2 bits per base; 8, 12 or 16 words per lane by the batch's longest read; reads with an N
-    take their bases from global memory), the short stack entries kept as a bit mask (off with BWAGPU_SEED_NO_VIRT, and narrower with
-    shallow prefix tables), a two-entry LDS stack that spills almost everything, and the three ways of reading the index -- the 32-byte
-    layout (the default), the reference-format 64-byte blocks fetched by each lane for itself (BWAGPU_OCC32=0) or quad-cooperatively
-    (BWAGPU_SEED_COOP=1 on top) -- with and without prefix tables; and the one-round-trip forms of the 32-byte layout (BWAGPU_SEED_MRG=1:
-    table entries and whole blocks through range-checked buffer loads; 2: the next interval-stack entry fetched a step ahead, with LDS
-    stacks so small that nearly every backward step takes a prefetched entry): same regions as the oracle for ragged reads with Ns."""
+    take their bases from global memory), the short stack entries kept as a bit mask (off with option seed_no_virt, and narrower with
+    shallow prefix tables), a two-entry LDS stack that spills almost everything, and the two ways of reading the index -- the 32-byte
+    layout (the default) and the reference-format 64-byte blocks (occ32 = 0) -- with and without prefix tables; and the one-round-trip form
+    of the 32-byte layout (seed_mrg = 2: table entries and whole blocks through range-checked buffer loads, the next interval-stack entry
+    fetched a step ahead, with LDS stacks so small that nearly every backward step takes a prefetched entry): same regions as the oracle for
+    ragged reads with Ns.  (Options are given through the API: bwagpu_set_default_option before the handle is created.)"""
     prefix, g = testdata.small_index()
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+    s2 = sim_handle(prefix, **env)
     orc = orcapi.OrcIndex(prefix)
     seqs, off = testdata.ragged(_n_rich_reads(g, 14, max_len, seed=300 + max_len))
     assert_regs_equal(*orc.align(default_opt(), seqs, off), *s2.align(default_opt(), seqs, off), f"N-rich ragged reads up to {max_len} bp, {env}")
     s2.close(); orc.close()
 
 
-def test_hostsim_occ32_layout_across_superblocks(monkeypatch):
-    """BWAGPU_OCC32=1 on the 2 Mb genome with superblocks of 2^12 bases (a thousand of them, so the relative counts and the superblock
+def test_hostsim_occ32_layout_across_superblocks():
+    """The 32-byte block layout on the 2 Mb genome with superblocks of 2^12 bases (a thousand of them, so the relative counts and the superblock
     table are both in play; the default of 2^32 bases gives a genome this size one): same regions as the oracle, with the prefix tables
     (filled through the new layout) and without."""
     import refapi
@@ -288,26 +281,23 @@ def test_hostsim_occ32_layout_across_superblocks(monkeypatch):
     orc = orcapi.OrcIndex(prefix)
     seqs, off = testdata.flat(simdata.make_reads_se(g, 16, seed=88, sub=0.02))
     want = orc.align(default_opt(), seqs, off)
-    monkeypatch.setenv("BWAGPU_OCC32", "1")
-    for m, shift, mrg in (("6", "12", "0"), ("0", "12", "0"), ("6", "32", "0"), ("6", "12", "2"), ("6", "32", "1")):      # (BWAGPU_SEED_MRG: the per-symbol form of the superblock table)
-        monkeypatch.setenv("BWAGPU_PTAB_M", m); monkeypatch.setenv("BWAGPU_OCC32_SB_SHIFT", shift); monkeypatch.setenv("BWAGPU_SEED_MRG", mrg)
-        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+    for m, shift, mrg in (("6", "12", "0"), ("0", "12", "0"), ("6", "32", "0"), ("6", "12", "2"), ("6", "32", "2")):      # (seed_mrg = 2: the per-symbol form of the superblock table)
+        s2 = sim_handle(prefix, occ32=1, ptab_m=int(m), occ32_sb_shift=int(shift), seed_mrg=int(mrg))
+        assert s2.get_option("occ32_sb_shift") == int(shift)
         assert_regs_equal(*want, *s2.align(default_opt(), seqs, off), f"32-byte blocks, prefix tables {m}, superblock shift {shift}")
         s2.close()
     orc.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"BWAGPU_OCC32": "0"}])
-def test_hostsim_densified_sa_equals_the_walk(monkeypatch, env):
+@pytest.mark.parametrize("env", [{}, {"occ32": 0}])
+def test_hostsim_densified_sa_equals_the_walk(env):
     """bwagpu_densify_sa fills the new samples from one LF walk per OLD sample (k_densify); every kept row must hold what the oracle's
     bwt_sa returns for it (bwt.c:91-103), including row 0 (-1), the primary row and the last row, at intervals 8, 2 and 1."""
     import ctypes as C
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
     prefix, _ = testdata.small_index()
     orc = orcapi.OrcIndex(prefix)
     for intv in (8, 2, 1):
-        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+        s2 = sim_handle(prefix, **env)
         meta0 = s2.index_meta()
         s2.densify_sa(intv)
         meta = s2.index_meta()
@@ -350,13 +340,12 @@ def test_hostsim_cloned_handle_shares_index(sim):
     assert_regs_equal(*a, *sim.align(opt, seqs, off), "original after the clone is destroyed")
 
 
-def test_hostsim_interval_list_overflow_retries(monkeypatch):
+def test_hostsim_interval_list_overflow_retries():
     """A deliberately tiny per-read interval capacity: the seeding kernel flags the overflow and the batch is re-run with a
     larger capacity; results are unchanged."""
     import hostsim_build
     prefix, g = testdata.small_index()
-    monkeypatch.setenv("BWAGPU_MEM_CAP", "3")
-    s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+    s2 = sim_handle(prefix, mem_cap=3)
     seqs, off = testdata.flat(simdata.make_reads_se(g, 24, seed=92))
     orc = orcapi.OrcIndex(prefix)
     assert_regs_equal(*orc.align(default_opt(), seqs, off), *s2.align(default_opt(), seqs, off), "interval overflow")
@@ -365,12 +354,11 @@ def test_hostsim_interval_list_overflow_retries(monkeypatch):
 
 
 @pytest.mark.parametrize("ent,mrg", [("1", "0"), ("3", "0"), ("1", "2"), ("3", "2")])
-def test_hostsim_lds_stack_ring_eviction(monkeypatch, ent, mrg):
+def test_hostsim_lds_stack_ring_eviction(ent, mrg):
     """A tiny LDS interval stack: the forward sweep's ring wraps and evicts to the HBM spill area, and the backward sweep
     reads deep entries back from it; the seeds (and everything downstream) are unchanged."""
     prefix, g = testdata.small_index()
-    monkeypatch.setenv("BWAGPU_SEED_LDS_ENT", ent); monkeypatch.setenv("BWAGPU_SEED_MRG", mrg)   # (2: deep entries arrive one step ahead of their use)
-    s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+    s2 = sim_handle(prefix, seed_lds_ent=int(ent), seed_mrg=int(mrg))   # (2: deep entries arrive one step ahead of their use)
     seqs, off = testdata.flat(simdata.make_reads_se(g, 14, seed=93))
     orc = orcapi.OrcIndex(prefix)
     s2.set_stats(True)
@@ -380,7 +368,7 @@ def test_hostsim_lds_stack_ring_eviction(monkeypatch, ent, mrg):
     s2.L.bwagpu_debug_prof.argtypes = [C.c_void_p, C.c_void_p]
     s2.L.bwagpu_debug_prof(s2.h, prof)
     assert prof[10] > 20, "the test's reads no longer spill their interval stacks"
-    assert prof[11] == (prof[10] if mrg == "2" else 0), "every deep entry of a backward row is fetched one step ahead (and only with BWAGPU_SEED_MRG=2)"
+    assert prof[11] == (prof[10] if mrg == "2" else 0), "every deep entry of a backward row is fetched one step ahead (and only with seed_mrg = 2)"
     s2.close(); orc.close()
 
 
@@ -419,10 +407,10 @@ def test_hostsim_device_cigars_give_the_same_sam(sim, monkeypatch):
     want, want_ops = host.region_cigars(opt, seqs, off, counts, regs, with_ops=True)
     assert hostapi.decode_cigars(cigs, ops) == hostapi.decode_cigars(want, want_ops)
     assert int((cigs["n_cigar"] > 6).sum()) >= 4, cigs["n_cigar"]
-    monkeypatch.setenv("BWAGPU_CIG_OPS_CAP", "10")       # an operation array that is too small: the pass is redone with the size it asked for
+    sim.set_option("cig_ops_cap", 10)       # an operation array that is too small: the pass is redone with the size it asked for
     cigs2, ops2 = sim.cigars(opt), sim.cigar_ops()
     assert hostapi.decode_cigars(cigs2, ops2) == hostapi.decode_cigars(want, want_ops) and ops2.shape[0] == want_ops.shape[0]
-    monkeypatch.delenv("BWAGPU_CIG_OPS_CAP")
+    sim.set_option("cig_ops_cap", 0)
     names = [f"q{i}" for i in range(off.shape[0] - 1)]
     quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
     assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs, cig_ops=ops) == host.regs2sam(opt, names, seqs, quals, off, counts, regs)
@@ -436,11 +424,11 @@ def test_hostsim_pooled_result_buffers(sim, monkeypatch):
     opt = default_opt()
     sets = [testdata.flat(simdata.make_reads_se(g, n, seed=170 + n, sub=0.03, dele=0.004, ins=0.004)) for n in (10, 4, 10)]
     want = []
-    monkeypatch.setenv("BWAGPU_PINNED_RESULTS", "0")
+    sim.set_option("pinned_results", 0)
     for seqs, off in sets:
         c, r = sim.align(opt, seqs, off)
         want.append((c.copy(), r.copy(), sim.cigars(opt).copy(), sim.cigar_ops().copy()))
-    monkeypatch.delenv("BWAGPU_PINNED_RESULTS"); monkeypatch.setenv("BWAGPU_PINNED_MIN_KB", "0")
+    sim.set_option("pinned_results", 1); sim.set_option("pinned_min_kb", 0)
     for (seqs, off), (c0, r0, g0, o0) in zip(sets, want):
         c, r = sim.align(opt, seqs, off)
         cg, ops = sim.cigars(opt), sim.cigar_ops()
@@ -461,6 +449,7 @@ def test_hostsim_pooled_result_buffers(sim, monkeypatch):
     c, r = sim.align(opt, pinned, off)
     assert np.array_equal(c, want[0][0]) and r.tobytes() == want[0][1].tobytes()
     L.bwagpu_free(p2)
+    sim.set_option("pinned_min_kb", 1024)
 
 
 def test_hostsim_long_segment_cigars(sim, monkeypatch):
@@ -479,10 +468,10 @@ def test_hostsim_long_segment_cigars(sim, monkeypatch):
     assert hostapi.decode_cigars(cigs, ops) == hostapi.decode_cigars(want, want_ops), "device records differ from the host's"
     ok = regs["score"] >= opt.T
     assert (cigs["n_cigar"][ok] > 64).sum() >= 2 and (cigs["n_cigar"][ok] >= 0).all(), cigs["n_cigar"]
-    monkeypatch.setenv("BWAGPU_CIGL_GIB", "0.000001")       # a scratch budget below one direction matrix: one workgroup takes the tier's whole work list
+    sim.set_option("cigl_mib", 0)       # a scratch budget below one direction matrix: one workgroup takes the tier's whole work list
     cigs1, ops1 = sim.cigars(opt), sim.cigar_ops()
     assert hostapi.decode_cigars(cigs1, ops1) == hostapi.decode_cigars(cigs, ops)
-    monkeypatch.delenv("BWAGPU_CIGL_GIB")
+    sim.set_option("cigl_mib", 16384)
     names = [f"q{i}" for i in range(off.shape[0] - 1)]
     quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
     assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs, cig_ops=ops) == host.regs2sam(opt, names, seqs, quals, off, counts, regs)
@@ -570,8 +559,7 @@ def test_hostsim_wave_chaining_heavy_reads(monkeypatch, heavy_case, lds):
     LDS (reads that outgrow it fall through to the HBM tier) and with the LDS tier switched off (every read in the HBM tier)."""
     fa, orc, reads = heavy_case
     opt = default_opt()
-    monkeypatch.setenv("BWAGPU_CHAIN_LDS", lds)
-    s2 = BwaGpu(fa, lib_path=hostsim_build.build())
+    s2 = sim_handle(fa, chain_lds=int(lds))
     s2.set_taps(True); s2.set_stats(True)
     seqs, off = testdata.flat(reads)
     c, r = s2.align(opt, seqs, off)
@@ -629,12 +617,11 @@ def test_hostsim_alt_contigs(tmp_path):
     s_alt.close(); s_plain.close(); orc.close()
 
 
-def test_hostsim_long_read_four_columns_per_lane(monkeypatch):
-    """The long-read DP kernels with four adjacent columns per lane.  BWAGPU_DEDUP_BLK=1: k_dedup_wave's score-only patch alignments
-    (mem_patch_reg -> ksw_global2; wave_global2_score_ring_blk) -- a 7 kb -x pacbio read drifts out of the extension's band, so its regions
-    are merged by a patch alignment of ~7000 x 750 cells (three passes of 256 columns per row).  BWAGPU_EXT_BLK=1: every DP row of
-    k_extend_wave's ring form (here with the LDS copy of the read).  The regions equal the compiled reference's either way, and the batch
-    did run a patch alignment."""
+def test_hostsim_long_read_four_columns_per_lane():
+    """k_dedup_wave's score-only patch alignments (mem_patch_reg -> ksw_global2) with four adjacent columns per lane (wave_global2_score_ring_blk,
+    the default) and with one (option dedup_blk = 0): a 7 kb -x pacbio read drifts out of the extension's band, so its regions are merged by a
+    patch alignment of ~7000 x 750 cells (three passes of 256 columns per row, or twelve of 64).  The regions equal the compiled reference's
+    either way, and the batch did run a patch alignment."""
     import refapi
     if not refapi.have_ref():
         pytest.skip("oracle/_ref not built (needed to index the 2 Mb genome)")
@@ -643,11 +630,8 @@ def test_hostsim_long_read_four_columns_per_lane(monkeypatch):
     reads = simdata.make_reads_long(g, 1, length=7000, seed=78)
     seqs, off = testdata.flat(reads)
     want = ref.align(pacbio_opt(), seqs, off)
-    monkeypatch.setenv("BWAGPU_PTAB_M", "6")
-    for env in ({"BWAGPU_DEDUP_BLK": "1"}, {"BWAGPU_EXT_BLK": "1", "BWAGPU_LONG_QLDS": "1"}):
-        for k in ("BWAGPU_DEDUP_BLK", "BWAGPU_EXT_BLK", "BWAGPU_LONG_QLDS"):
-            monkeypatch.setenv(k, env.get(k, "0"))
-        s2 = BwaGpu(prefix, lib_path=hostsim_build.build())
+    for env in ({}, {"dedup_blk": 0}):
+        s2 = sim_handle(prefix, ptab_m=6, **env)
         s2.set_stats(True)
         assert_regs_equal(*want, *s2.align(pacbio_opt(), seqs, off), f"7 kb -x pacbio read, {env}")
         st = s2.stats()

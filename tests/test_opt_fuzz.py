@@ -154,21 +154,20 @@ def test_sim_option_fuzz():
         sim.close(); ref.close()
 
 
-def test_sim_option_fuzz_one_trip_seeding(monkeypatch):
-    """The same draws' kind through the switchable kernel forms of this round: seeding with one memory round trip per iteration
-    (BWAGPU_SEED_MRG=2, on LDS stacks of two entries so that nearly every backward step takes a prefetched entry) and, for the long-read
-    presets, the workgroup-per-read interval sort (BWAGPU_PUBLISH_BLK=1) the LDS copy of the query in the DP kernels (BWAGPU_LONG_QLDS=1), the LDS form of the seed re-scoring (BWAGPU_SEEDSW_LDS=1) and pass 1 by
-    chunks of 128 bases (BWAGPU_SEED_CHUNK)."""
+def test_sim_option_fuzz_kernel_forms():
+    """The same draws' kind through the other kernel forms.  First: seeding with one memory round trip per iteration for short reads as well
+    (seed_mrg = 2, on LDS stacks of two entries so that nearly every backward step takes a prefetched entry) and pass 1 of the long reads by
+    chunks of 128 bases instead of 256.  Second: the round-3 forms the long-read defaults replaced (lane-per-read seeding, one-lane interval
+    sort, HBM-scratch seed re-scoring, one column per lane in the patch alignments)."""
     import hostsim_build
     from bwa_amd.api import BwaGpu
-    for k, v in (("BWAGPU_SEED_MRG", "2"), ("BWAGPU_SEED_LDS_ENT", "2"), ("BWAGPU_PUBLISH_BLK", "1"), ("BWAGPU_LONG_QLDS", "1"), ("BWAGPU_SEEDSW_LDS", "1"), ("BWAGPU_SEED_CHUNK", "128")):
-        monkeypatch.setenv(k, v)
     prefix, g = testdata.small_index()
-    sim, ref = BwaGpu(prefix, lib_path=hostsim_build.build()), refapi.RefIndex(prefix)
-    try:
-        run_region_fuzz(sim, ref, g, draws=12, n_short=10, n_long=1, long_len=1200, seed=53)
-    finally:
-        sim.close(); ref.close()
+    for seed, options in ((53, {"seed_mrg": 2, "seed_lds_ent": 2, "seed_chunk": 128}), (54, {"seed_mrg": 0, "seed_chunk": 0, "publish_blk": 0, "seedsw_lds": 0, "dedup_blk": 0})):
+        sim, ref = BwaGpu(prefix, lib_path=hostsim_build.build(), options=options), refapi.RefIndex(prefix)
+        try:
+            run_region_fuzz(sim, ref, g, draws=6, n_short=10, n_long=1, long_len=1200, seed=seed)
+        finally:
+            sim.close(); ref.close()
 
 
 def test_sim_cli_option_fuzz(tmp_path):
@@ -189,6 +188,20 @@ def test_gpu_option_fuzz():
         run_region_fuzz(gpu, ref, g, draws=42, n_short=2000, n_long=200, long_len=1500, seed=52)
     finally:
         gpu.close(); ref.close()
+
+
+@pytest.mark.gpu
+def test_gpu_option_fuzz_kernel_forms():
+    """On hardware, strictly: the kernel forms that are not the default for their class of batch -- one-trip seeding for short reads and small
+    chunks for long ones; and the round-3 long-read forms (lane-per-read seeding, one-lane sort, HBM re-scoring, one column per lane)."""
+    from bwa_amd.api import BwaGpu
+    fa, g = testdata.medium_index()
+    for seed, options in ((55, {"seed_mrg": 2, "seed_lds_ent": 2, "seed_chunk": 128}), (56, {"seed_mrg": 0, "seed_chunk": 0, "publish_blk": 0, "seedsw_lds": 0, "dedup_blk": 0})):
+        gpu, ref = BwaGpu(fa, options=options), refapi.RefIndex(fa)
+        try:
+            run_region_fuzz(gpu, ref, g, draws=10, n_short=1000, n_long=150, long_len=1500, seed=seed)
+        finally:
+            gpu.close(); ref.close()
 
 
 @pytest.mark.gpu

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""A/B runs of kernel variants that sit behind environment switches (GPU).  bench.py starts this as a child process with a time limit
+"""A/B runs of kernel variants that sit behind library options (bwagpu_set_option, bwa_amd/csrc/bwagpu_config.h) on the GPU.  bench.py starts this as a child process with a time limit
 and copies what it prints into the `variants` object of its JSON line -- a variant that faults or hangs takes this process with it,
 never the headline measurement.
 
-Every argument is one configuration: space-separated NAME=VALUE settings ("" = the library's defaults, always run first).  For each
+Every argument is one configuration: space-separated name=value option settings, e.g. "seed_mrg=2 seed_lds_ent=4" ("" = the library's
+defaults, always run first; the round-3 spelling BWAGPU_SEED_MRG=2 is accepted too).  For each
 one: the resident hot path of one batch alone on the chip (stage times from the library's HIP events, best of `--passes`), the
 step time with `--streams` batches in flight (the headline's timing loop), and a digest of the batch's regions, which must equal the
 default configuration's -- a variant may only change when things are computed, never what.
@@ -68,13 +69,13 @@ def main():
     base_digest = None
     shared = None
     for cfg in [""] + [c for c in args.configs if c.strip()]:
-        sets = dict(kv.split("=", 1) for kv in cfg.split())
-        for k, v in sets.items():
-            os.environ[k] = v
+        sets = parse_config(cfg)
         t0 = time.time()
         res = {"config": cfg or "defaults"}
+        restore = {}
         try:
             gpu, shared = open_index(args, sets, shared)
+            restore = apply_options(gpu, sets)
             handles = [gpu] + [gpu.clone() for _ in range(S - 1)]
             for hdl, (flat, off) in zip(handles, batches):
                 hdl.set_taps(False)
@@ -109,24 +110,45 @@ def main():
                 hdl.close()
             if gpu is not shared:
                 gpu.close()
+            else:
+                apply_options(gpu, restore)
         except Exception as e:       # (a configuration the library refuses must not take the others with it)
             res["error"] = repr(e)
         res["wall_s"] = round(time.time() - t0, 1)
         print(json.dumps(res), flush=True)
-        for k in sets:
-            del os.environ[k]
 
 
-LAYOUT_KEYS = ("BWAGPU_OCC32", "BWAGPU_OCC32_SB_SHIFT", "BWAGPU_PTAB_M")      # switches read when the index is laid out in HBM: such a configuration gets a handle of its own
+LAYOUT_KEYS = ("occ32", "occ32_sb_shift", "ptab_m")      # options that shape what is derived from the index at load time: such a configuration gets a handle of its own
+
+
+def parse_config(cfg):
+    """'seed_mrg=2 BWAGPU_PTAB_M=8' -> {'seed_mrg': 2, 'ptab_m': 8}"""
+    out = {}
+    for kv in cfg.split():
+        k, v = kv.split("=", 1)
+        k = k.lower()
+        out[k[7:] if k.startswith("bwagpu_") else k] = int(v)
+    return out
+
+
+def apply_options(gpu, sets):
+    """Set the per-batch options on the handle; returns the values they had (to put back on a shared handle)."""
+    old = {}
+    for k, v in sets.items():
+        if k in LAYOUT_KEYS:
+            continue
+        old[k] = gpu.get_option(k)
+        gpu.set_option(k, v)
+    return old
 
 
 def open_index(args, sets, shared):
-    """The handle a configuration runs on: one shared by all configurations whose switches are read per batch, a fresh one otherwise."""
+    """The handle a configuration runs on: one shared by all configurations whose options apply per batch, a fresh one otherwise."""
     from bwa_amd.api import BwaGpu
     own = any(k in LAYOUT_KEYS for k in sets)
     if not own and shared is not None:
         return shared, shared
-    gpu = BwaGpu(args.prefix, lib_path=args.lib)
+    gpu = BwaGpu(args.prefix, lib_path=args.lib, options={k: v for k, v in sets.items() if k in LAYOUT_KEYS})
     if args.dense_sa:
         gpu.densify_sa(args.dense_sa)
     gpu.set_taps(False)
@@ -146,13 +168,12 @@ def long_mode(args, g):
     opt = pacbio_opt()
     base_digest, shared = None, None
     for cfg in [""] + [c for c in args.configs if c.strip()]:
-        sets = dict(kv.split("=", 1) for kv in cfg.split())
-        for k, v in sets.items():
-            os.environ[k] = v
+        sets = parse_config(cfg)
         t0 = time.time()
         res = {"config": cfg or "defaults", "mode": f"{n} reads of {L} bp, -x pacbio"}
         try:
             gpu, shared = open_index(args, sets, shared)
+            restore = apply_options(gpu, sets)
             gpu.upload(flat, off)
             gpu.run(opt)                                          # warm-up: arenas learn their sizes
             runs = []
@@ -169,12 +190,12 @@ def long_mode(args, g):
             res["same_result_as_defaults"] = res["result_sha256_16"] == base_digest
             if gpu is not shared:
                 gpu.close()
+            else:
+                apply_options(gpu, restore)
         except Exception as e:
             res["error"] = repr(e)
         res["wall_s"] = round(time.time() - t0, 1)
         print(json.dumps(res), flush=True)
-        for k in sets:
-            del os.environ[k]
 
 
 if __name__ == "__main__":
