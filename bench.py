@@ -168,6 +168,10 @@ def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: 
             dev_ms[name] = round(sum(float(d[k_ + 1]) for d in rows) / len(rows) * 1e3, 1)
         dev_ms["matesw_alignments"] = int(sum(int(d[6]) for d in rows) / len(rows))
         dev_ms["reads_per_batch"] = full
+    after = re.findall(r"after the hot path, ms: pack ([\d.]+) download copy ([\d.]+) cigar kernels ([\d.]+) cigar copies ([\d.]+)", p.stderr)
+    if after and dev_ms:      # download_cigars split by the library's own HIP events (kernels vs copies), averaged over the batches
+        for k_, name in enumerate(("pack_kernel", "download_copy", "cigar_kernels", "cigar_copies")):
+            dev_ms[name] = round(sum(float(a_[k_]) for a_ in after) / len(after), 1)
     return {"reads_per_s": float(m.group(3)), "n": n_reads, "wall_s": wall, "stages": busy.group(1) if busy else "", "stage_us_per_read": stage_us, "handles": int(hm.group(1)) if hm else None, "device_stage_ms_per_batch": dev_ms,
             "n_batches": len(re.findall(r"\[M::process\] read \d+ sequences", p.stderr))}
 

@@ -44,7 +44,8 @@ class Stats(C.Structure):
         "n_ext_calls", "n_ext_cells", "n_glb_calls", "n_glb_cells", "ref_bases", "n_sw_calls", "n_sw_cells")] + [
         (n, C.c_float) for n in ("ms_seed", "ms_sa", "ms_chain", "ms_seedsw", "ms_extend", "ms_dedup", "ms_total")] + [
         ("n_retries", C.c_int32), ("ms_publish", C.c_float), ("n_tab_lookups", C.c_int64), ("n_bt_nodes", C.c_int64), ("n_chain_recs", C.c_int64),
-        ("n_chain_deferred", C.c_int64), ("n_ext_fast", C.c_int64), ("n_chain_deferred2", C.c_int64)]
+        ("n_chain_deferred", C.c_int64), ("n_ext_fast", C.c_int64), ("n_chain_deferred2", C.c_int64),
+        ("ms_pack", C.c_float), ("ms_download_copy", C.c_float), ("ms_cigar_kernels", C.c_float), ("ms_cigar_copy", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved_"}

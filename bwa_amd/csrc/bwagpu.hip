@@ -1172,6 +1172,7 @@ extern "C" int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg
 	if (tot) {
 		if (h->d_pack_off.ensure((size_t)n * 8) || h->d_regs_packed.ensure((size_t)tot * sizeof(bwagpu_alnreg_t)) || h->d_pack_read.ensure((size_t)tot * 4)) { bwagpu_free(res); h->err = "hipMalloc failed (packed regions)"; return BWAGPU_ENOMEM; }
 		h->phase = 32;
+		(void)hipEventRecord(h->ev[0], h->stream);
 		hipError_t e = hipMemcpyAsync(h->d_pack_off.p, dst.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream);
 		if (e == hipSuccess) {
 			int nb = (n + BLOCK - 1) / BLOCK; if (nb > 8192) nb = 8192;
@@ -1179,9 +1180,12 @@ extern "C" int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg
 							   h->d_pack_off.as<i64>(), h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_pack_read.as<i32>());
 			e = hipGetLastError();
 		}
+		(void)hipEventRecord(h->ev[1], h->stream);
 		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_regs_packed.p, (size_t)tot * sizeof(bwagpu_alnreg_t), hipMemcpyDeviceToHost, h->stream);
+		(void)hipEventRecord(h->ev[2], h->stream);
 		if (e == hipSuccess) e = wait_stream(h);
 		if (e != hipSuccess) { bwagpu_free(res); HIPCHK(h, e); }
+		(void)hipEventElapsedTime(&h->stats.ms_pack, h->ev[0], h->ev[1]); (void)hipEventElapsedTime(&h->stats.ms_download_copy, h->ev[1], h->ev[2]);
 	}
 	h->packed_tot = tot; h->phase = 39;
 	*regs_out = res; *n_regs_out = tot;
@@ -1226,6 +1230,7 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		};
 		unsigned long long used = 0;
 		hipError_t e = hipSuccess;
+		(void)hipEventRecord(h->ev[0], h->stream);
 		for (int attempt = 0; attempt < 2; ++attempt) {
 			if (h->d_cig_ext.ensure((size_t)ext_cap * 4)) { bwagpu_free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
 			e = hipMemsetAsync(ext_used, 0, sizeof(unsigned long long), h->stream);
@@ -1281,9 +1286,12 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 			ext_cap = (i64)used;
 		}
 		h->phase = 45;
+		(void)hipEventRecord(h->ev[1], h->stream);
 		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_cigs.p, (size_t)tot * sizeof(bwagpu_cigar_t), hipMemcpyDeviceToHost, h->stream);
+		(void)hipEventRecord(h->ev[2], h->stream);
 		if (e == hipSuccess) e = wait_stream(h);
 		if (e != hipSuccess) { bwagpu_free(res); h->cig_ext_n = -1; HIPCHK(h, e); }
+		(void)hipEventElapsedTime(&h->stats.ms_cigar_kernels, h->ev[0], h->ev[1]); (void)hipEventElapsedTime(&h->stats.ms_cigar_copy, h->ev[1], h->ev[2]);     // (kernels: includes the plan's small D2H and, after an overflow, the second attempt)
 		h->cig_ext_n = (i64)used < ext_cap ? (i64)used : ext_cap;
 	}
 	if (tot == 0) h->cig_ext_n = 0;
@@ -1298,7 +1306,14 @@ extern "C" int bwagpu_batch_cigar_ops(bwagpu_t *h, uint32_t **ops, int64_t *n_op
 	const i64 n = h->cig_ext_n;
 	uint32_t *res = (uint32_t*)result_alloc((size_t)(n ? n : 1) * 4);
 	if (!res) return BWAGPU_ENOMEM;
-	if (n) { hipError_t e = hipMemcpyAsync(res, h->d_cig_ext.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream); if (e == hipSuccess) e = wait_stream(h); if (e != hipSuccess) { bwagpu_free(res); HIPCHK(h, e); } }
+	if (n) {
+		(void)hipEventRecord(h->ev[0], h->stream);
+		hipError_t e = hipMemcpyAsync(res, h->d_cig_ext.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream);
+		(void)hipEventRecord(h->ev[1], h->stream);
+		if (e == hipSuccess) e = wait_stream(h);
+		if (e != hipSuccess) { bwagpu_free(res); HIPCHK(h, e); }
+		float ms = 0; (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]); h->stats.ms_cigar_copy += ms;
+	}
 	*ops = res; *n_ops = n;
 	return BWAGPU_OK;
 }

@@ -460,6 +460,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	// wave then runs that code once for all of them.
 	int deferred = 0;
 	u32 n_iter = 0, n_slow = 0, n_ext_lanes = 0, n_deep = 0, n_deep_l = 0, n_pf_l = 0, n_win_l = 0;
+	u32 n_done_l = 0, n_wait_l = 0, n_slowrun_l = 0, n_first_done = 0;      // STATS: where the lane-slots that do not extend go (prof[2..7])
 	// MRG == 2: the stack entry this lane's next backward step will read, fetched a step ahead (pf.w != 0: valid -- an entry's `info`, its
 	// match's end position >= 1, sits in the top half of w).  A backward step that is not the last of its row is always followed by the
 	// step for entry j + 1 of the same row, and the steps in between write survivors at depths <= j only (SeedStack::store).
@@ -479,6 +480,12 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 		if (sm) {
 			const u64 am = __ballot(1);
 			run_slow = __popcll(sm) >= 8 || sm == am || ++deferred >= 3;
+		}
+		if (STATS) {
+			const u64 dm = __ballot(L.st == SS_DONE);
+			n_done_l += (u32)__popcll(dm);
+			if (dm && n_first_done == 0) n_first_done = n_iter;
+			if (run_slow) n_slowrun_l += (u32)__popcll(sm); else n_wait_l += (u32)__popcll(sm);
 		}
 		if (run_slow) {
 			deferred = 0; if (STATS) ++n_slow;
@@ -708,7 +715,11 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	if (STATS) {
 		atomicAdd(&B.ctr->occ_blocks, (unsigned long long)nblk); atomicAdd(&B.ctr->tab_lookups, (unsigned long long)ntab);
 		atomicAdd(&B.ctr->prof[9], (unsigned long long)n_win_l); atomicAdd(&B.ctr->prof[10], (unsigned long long)n_deep_l); atomicAdd(&B.ctr->prof[11], (unsigned long long)n_pf_l);
-		if ((threadIdx.x & 63) == 0) { atomicAdd(&B.ctr->prof[12], (unsigned long long)n_deep); atomicAdd(&B.ctr->prof[13], (unsigned long long)n_iter); atomicAdd(&B.ctr->prof[14], (unsigned long long)n_slow); atomicAdd(&B.ctr->prof[15], (unsigned long long)n_ext_lanes); }
+		if ((threadIdx.x & 63) == 0) { atomicAdd(&B.ctr->prof[12], (unsigned long long)n_deep); atomicAdd(&B.ctr->prof[13], (unsigned long long)n_iter); atomicAdd(&B.ctr->prof[14], (unsigned long long)n_slow); atomicAdd(&B.ctr->prof[15], (unsigned long long)n_ext_lanes);
+			// lane-slots of lanes that have run out of reads, of lanes waiting in a bookkeeping state for the wave to run that code, of lanes running it; the
+			// iteration at which a wave's first lane ran out (summed), the longest wave, and the waves that did any work
+			atomicAdd(&B.ctr->prof[2], (unsigned long long)n_done_l); atomicAdd(&B.ctr->prof[3], (unsigned long long)n_wait_l); atomicAdd(&B.ctr->prof[4], (unsigned long long)n_slowrun_l);
+			atomicAdd(&B.ctr->prof[5], (unsigned long long)(n_first_done ? n_first_done : n_iter)); atomicMax(&B.ctr->prof[6], (unsigned long long)n_iter); if (n_iter > 1) atomicAdd(&B.ctr->prof[7], 1ull); }
 	}
 }
 

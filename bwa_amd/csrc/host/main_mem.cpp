@@ -683,6 +683,11 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 	u.t_dev = t5 - t0;
 	if (trace) fprintf(stderr, "[D::device_sub] %d reads on %d device(s) -> %ld regions (flag 0x%x): upload %.3f run %.3f download+cigars %.3f pestat+matesw %.3f s (pestat %.3f, %ld mate-rescue alignments)\n", n, D, (long)u.tot, u.opt.flag,
 					   t1 - t0, t2 - t1, t3 - t2, t5 - t4, t_pes, (long)u.n_msw);
+	if (trace) {       // the part after the hot path by the library's own HIP events (device 0's share)
+		bwagpu_stats_t st;
+		if (bwagpu_get_stats(gpus[0], &st) == BWAGPU_OK)
+			fprintf(stderr, "[D::device_sub] after the hot path, ms: pack %.2f download copy %.2f cigar kernels %.2f cigar copies %.2f\n", st.ms_pack, st.ms_download_copy, st.ms_cigar_kernels, st.ms_cigar_copy);
+	}
 }
 
 // stage 3: mem_pestat + kt_for(worker2) (bwamem.c:1254-1260) on the host cores
@@ -921,8 +926,14 @@ int main(int argc, char *argv[])
 	if (getenv("BWAGPU_CLI_CIGARS")) g_device_cigars = atoi(getenv("BWAGPU_CLI_CIGARS"));
 	int n_dev = getenv("BWAGPU_CLI_STREAMS") ? atoi(getenv("BWAGPU_CLI_STREAMS")) : 3;      // batches in flight on the device
 	if (n_dev < 1) n_dev = 1;
-	// devices: BWAGPU_DEVICES=0,1,... (default: the one of BWAGPU_DEVICE); every batch is split over all of them.  The index reaches
-	// the other devices by device-to-device copies (bwagpu_clone_to_device); handles[slot][device], one slot per batch in flight.
+	// devices: BWAGPU_DEVICES=0,1,... (default: the one of BWAGPU_DEVICE).  The index reaches the other devices by device-to-device copies over
+	// xGMI (bwagpu_clone_to_device: one process drives all devices, so a peer copy is the direct route; the RCCL broadcast of bwa_amd/dist.py is
+	// its counterpart between processes); handles[slot][device], one slot per batch in flight and device.
+	// How the batches meet the devices (BWAGPU_CLI_MULTI): "split" cuts EVERY batch into one contiguous range of whole pairs per device (one
+	// mem_pestat over the gathered regions, device_sub) -- right for large batches, but at the default -K a device's share of a batch is a
+	// fraction of what fills it (k_seed alone has a ~35 ms floor per launch, every stage pays its heaviest read); "batch" hands WHOLE batches to
+	// the devices round-robin, each device thread owning one device -- the batch, hence mem_pestat (bwamem.c:1258), is what a single device
+	// sees, so the SAM is the same either way.  Default: whole batches unless a device's share of a split batch would still be >= 300 k reads.
 	std::vector<int> dev_ids(1, device);
 	if (const char *dl = getenv("BWAGPU_DEVICES")) {
 		dev_ids.clear();
@@ -936,8 +947,16 @@ int main(int argc, char *argv[])
 		handles[0].push_back(base);
 		for (int i = 1; i < n_dev; ++i) { bwagpu_t *h2 = nullptr; int rc = bwagpu_clone(base, &h2); if (rc != BWAGPU_OK) { fprintf(stderr, "[E::%s] %s\n", "main_mem", bwagpu_strerror(rc)); return 1; } bwagpu_set_taps(h2, 0); handles[(size_t)i].push_back(h2); }
 	}
-	if (g_verbose >= 3 && dev_ids.size() > 1) fprintf(stderr, "[M::%s] index copied to %zu devices; batches are split over them\n", "main_mem", dev_ids.size());
-	Chan to_enc(1), to_dev(2), to_out(2);
+	bool whole_batches = dev_ids.size() > 1 && (int64_t)chunk / 150 / (int64_t)dev_ids.size() < 300000;
+	if (const char *mm = getenv("BWAGPU_CLI_MULTI")) { if (!strcmp(mm, "batch")) whole_batches = dev_ids.size() > 1; else if (!strcmp(mm, "split")) whole_batches = false; }
+	// the device threads: one per slot driving all devices (split), or one per slot and device driving that device alone (whole batches)
+	std::vector<std::vector<bwagpu_t*>> workers;
+	if (!whole_batches) workers = handles;
+	else for (int i = 0; i < n_dev; ++i) for (size_t di = 0; di < dev_ids.size(); ++di) workers.push_back(std::vector<bwagpu_t*>(1, handles[(size_t)i][di]));   // (the first D threads: one per device)
+	const int n_work = (int)workers.size();
+	if (g_verbose >= 3 && dev_ids.size() > 1) fprintf(stderr, "[M::%s] index copied to %zu devices; %s (%d device threads)\n", "main_mem", dev_ids.size(),
+													   whole_batches ? "whole batches go to the devices in turn" : "every batch is split over them", n_work);
+	Chan to_enc(1), to_dev((size_t)(n_work / 4 > 2 ? n_work / 4 : 2)), to_out(2);
 	// text arenas and base arrays of finished batches are handed back to the reader: re-using them saves a few hundred MB of
 	// first-touch page faults per batch on the one thread that paces the pipeline
 	std::mutex pool_m; std::vector<Batch> batch_pool; std::vector<HostBuf> flat_pool; std::vector<std::vector<std::string>> out_pool;   // (and the chunk strings of written batches)
@@ -957,7 +976,7 @@ int main(int argc, char *argv[])
 			if (p != last) { last = p; idle = 0; continue; }
 			if (++idle < wd_secs * 4) continue;
 			fprintf(stderr, "[E::%s] no progress for %d s: next batch to finalize %ld, batches read %ld, done-but-waiting %zu\n", "main_mem", wd_secs, next_fin, n_works.load(), done.size());
-			for (int d = 0; d < n_dev && d < 16; ++d) fprintf(stderr, "[E::%s]   device thread %d: batch %d, library phase %d\n", "main_mem", d, dev_no[d].load(), bwagpu_debug_phase(handles[d][0]));
+			for (int d = 0; d < n_work && d < 16; ++d) fprintf(stderr, "[E::%s]   device thread %d: batch %d, library phase %d\n", "main_mem", d, dev_no[d].load(), bwagpu_debug_phase(workers[(size_t)d][0]));
 			_exit(3);
 		}
 	});
@@ -1019,21 +1038,21 @@ int main(int argc, char *argv[])
 	});
 
 	std::vector<std::thread> devs;
-	for (int d = 0; d < n_dev; ++d) devs.emplace_back([&, d] {      // stage 2: one host thread per device handle
+	for (int d = 0; d < n_work; ++d) devs.emplace_back([&, d] {      // stage 2: one host thread per slot (and, with whole batches, device)
 		// while the reader parses the first batch: the arenas of a batch of -K bases of short reads (150 bp assumed; anything else grows them
 		// later).  Not for the long-read presets: the short-read shape asks for ~4 GB per handle that a long-read run never uses and -- device
 		// buffers only ever grow -- never gets back.
 		if (!g_dev_serialize && !long_preset && !(getenv("BWAGPU_CLI_RESERVE") && atoi(getenv("BWAGPU_CLI_RESERVE")) == 0))      // (not under the mock runtime of the CPU tests)
-			for (bwagpu_t *hh : handles[d]) {
-				const int rc = bwagpu_batch_reserve(hh, (int)((int64_t)chunk / 150 / (int64_t)handles[d].size()) + 1024, (int64_t)chunk / (int64_t)handles[d].size() + (1 << 20), 256);
+			for (bwagpu_t *hh : workers[(size_t)d]) {
+				const int rc = bwagpu_batch_reserve(hh, (int)((int64_t)chunk / 150 / (int64_t)workers[(size_t)d].size()) + 1024, (int64_t)chunk / (int64_t)workers[(size_t)d].size() + (1 << 20), 256);
 				if (rc != BWAGPU_OK && g_verbose >= 2) fprintf(stderr, "[W::%s] could not reserve the batch arenas ahead of the first batch (%s: %s); they are grown batch by batch instead\n", "main_mem", bwagpu_strerror(rc), bwagpu_last_error(hh));
 			}
 		WorkP w;
 		while (to_dev.pop(w)) {
-			{ std::unique_lock<std::mutex> l(dm); dcv.wait(l, [&] { return w->no - next_fin <= (long)n_dev; }); }   // do not run ahead of the host
+			{ std::unique_lock<std::mutex> l(dm); dcv.wait(l, [&] { return w->no - next_fin <= (long)n_work; }); }   // do not run ahead of the host
 			if (d < 16) dev_no[d] = (int)w->no;
 			++progress;
-			for (Sub &u : w->subs) { device_sub(handles[d], u, ref, pes0); ++progress; busy_dev_us += (long)(u.t_dev * 1e6); }
+			for (Sub &u : w->subs) { device_sub(workers[(size_t)d], u, ref, pes0); ++progress; busy_dev_us += (long)(u.t_dev * 1e6); }
 			std::lock_guard<std::mutex> l(dm);
 			const long no = w->no;
 			done[no] = std::move(w);
@@ -1076,7 +1095,7 @@ int main(int argc, char *argv[])
 	writer.join();
 	all_done = true; watchdog.join();
 	if (g_verbose >= 3) { const double dt = now_s() - t_start; fprintf(stderr, "[M::%s] %ld reads in %.3f sec after the index was loaded: %.0f reads/s\n", "main_mem", n_reads_total.load(), dt, dt > 0 ? n_reads_total.load() / dt : 0.);
-		fprintf(stderr, "[M::%s] stage busy time: read %.3f s, encode %.3f s, device %.3f s (over %d handles), finalize %.3f s, write %.3f s\n", "main_mem", busy_read, busy_enc, busy_dev_us.load() * 1e-6, n_dev, busy_fin, busy_write); }
+		fprintf(stderr, "[M::%s] stage busy time: read %.3f s, encode %.3f s, device %.3f s (over %d handles), finalize %.3f s, write %.3f s\n", "main_mem", busy_read, busy_enc, busy_dev_us.load() * 1e-6, n_work, busy_fin, busy_write); }
 	fflush(stdout);
 	for (auto &slot : handles) for (bwagpu_t *hh : slot) if (hh != gpu) bwagpu_destroy(hh);
 	bwagpu_destroy(gpu);

@@ -189,6 +189,11 @@ typedef struct {
 	int64_t n_chain_deferred;/* reads whose chaining outgrew tier 0 of k_chain_wave (LDS-resident seeds, 32 chains) */
 	int64_t n_ext_fast;      /* ksw_extend2 calls answered without DP (diagonal rule, dev_extw.h)              */
 	int64_t n_chain_deferred2;/* ... and tier 1 (96 chains in LDS): chained in the read's HBM region           */
+	/* the calls after bwagpu_batch_run, filled by them (HIP events on the handle's stream; 0 until the call has run for this batch): */
+	float ms_pack;           /* bwagpu_batch_download: packing the used region records on the device          */
+	float ms_download_copy;  /* ... and their device-to-host copy                                              */
+	float ms_cigar_kernels;  /* bwagpu_batch_cigars: all its launches (the three tiers, NM/MD)                 */
+	float ms_cigar_copy;     /* ... and the copies of the records and (bwagpu_batch_cigar_ops) the operation array */
 } bwagpu_stats_t;
 
 /* Diagnostics: a marker of the step the handle's current (or last) batch call has reached; safe to call from another

@@ -196,7 +196,11 @@ def test_cli_gpu_two_devices(tmp_path):
     assert p.returncode == 0 and b"index copied to 2 devices" in p.stderr, p.stderr.decode()[-800:]
     assert _run(refapi.REF_BWA, K + [fa, f1, f2]) == _body(p.stdout), "paired-end, 2 GPUs"
     assert _run(refapi.REF_BWA, K + [fa, f1]) == _run(cli, K + [fa, f1], env), "single-end, 2 GPUs"
-    assert _run(refapi.REF_BWA, ["-K", "300000", "-t", "4", fa, f1, f2]) == _run(cli, ["-K", "300000", "-t", "4", fa, f1, f2], env), "20 batches, 2 GPUs"
+    assert _run(refapi.REF_BWA, ["-K", "300000", "-t", "4", fa, f1, f2]) == _run(cli, ["-K", "300000", "-t", "4", fa, f1, f2], dict(env, BWAGPU_CLI_MULTI="split")), "20 batches, each split over 2 GPUs"
+    # whole batches handed to the devices in turn (the default at this -K: a device's share of a split batch would be far below what fills it)
+    p = subprocess.run([cli, "mem", "-K", "300000", "-t", "4", "-v", "3", fa, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0 and b"whole batches go to the devices in turn" in p.stderr, p.stderr.decode()[-800:]
+    assert _run(refapi.REF_BWA, ["-K", "300000", "-t", "4", fa, f1, f2]) == _body(p.stdout), "20 whole batches over 2 GPUs"
     if n >= 3:
         env3 = dict(os.environ, BWAGPU_DEVICES=",".join(str(i) for i in range(min(n, 8))))
         assert _run(refapi.REF_BWA, K + [fa, f1, f2]) == _run(cli, K + [fa, f1, f2], env3), f"paired-end, {min(n, 8)} GPUs"
@@ -219,7 +223,13 @@ def test_cli_hostsim_two_devices(tmp_path):
     assert _run(refapi.REF_BWA, K + [prefix, f1]) == _run(cli, K + [prefix, f1], env), "single-end, 2 devices"
     x = ["-p", "-C"]
     assert _run(refapi.REF_BWA, K + x + [prefix, inter]) == _run(cli, K + x + [prefix, inter], env), "smart pairing, 2 devices"
-    assert _run(refapi.REF_BWA, ["-K", "9000", "-t", "2", prefix, f1, f2]) == _run(cli, ["-K", "9000", "-t", "2", prefix, f1, f2], env), "small batches, 2 devices"
+    assert _run(refapi.REF_BWA, ["-K", "9000", "-t", "2", prefix, f1, f2]) == _run(cli, ["-K", "9000", "-t", "2", prefix, f1, f2], dict(env, BWAGPU_CLI_MULTI="split")), "small batches, each split over 2 devices"
+    # whole batches to the devices in turn (BWAGPU_CLI_MULTI=batch; the default when a device's share of a split batch is small): four device
+    # threads -- two slots on each device -- take the batches as they come; the batch, hence mem_pestat, is what a single device sees
+    p = subprocess.run([cli, "mem", "-K", "9000", "-t", "2", "-v", "3", prefix, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0 and b"whole batches go to the devices in turn (4 device threads)" in p.stderr, p.stderr.decode()[-800:]
+    assert _run(refapi.REF_BWA, ["-K", "9000", "-t", "2", prefix, f1, f2]) == _body(p.stdout), "small whole batches over 2 devices"
+    assert _run(refapi.REF_BWA, ["-K", "9000", "-t", "2"] + x + [prefix, inter]) == _run(cli, ["-K", "9000", "-t", "2"] + x + [prefix, inter], dict(env, BWAGPU_CLI_MULTI="batch")), "smart pairing, whole batches over 2 devices"
     # gap-rich reads: many alignments of 7..64 CIGAR operations, whose records point into each device's operation array -- the
     # offsets of the second device's records must move with its part of the merged array
     noisy = str(tmp_path / "noisy.fq")

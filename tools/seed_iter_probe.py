@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Diagnostics (GPU): wave iterations of k_seed, how many ran the bookkeeping code, lanes extending per iteration."""
+"""Diagnostics (GPU): where k_seed's lane-slots go.  Per configuration (arguments: space-separated option settings, "" = defaults) and per
+batch size (READS=250000,500000,1000000,2000000): the kernel's time without and with its work counters, wave iterations, lanes extending per
+iteration, and the lane-slots that do NOT extend split into lanes that have run out of reads (the kernel's tail), lanes waiting in a bookkeeping
+state for the wave to run that code, and lanes running it; the iteration at which a wave's first lane runs out of reads against the wave's length."""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,31 +13,39 @@ from bwa_amd.api import BwaGpu
 from bwa_amd.structs import default_opt
 prefix, g, _ = bench.build_or_load_index(float(os.environ.get("MBP", "3100")), "/tmp/bwa_amd_bench", 0, lambda: None)
 opt = default_opt(); opt.flag |= 2
-r1, r2 = simdata.make_reads_pe(g, 500_000, seed=1000)
-rd = bench.interleave(r1, r2)
-flat = np.ascontiguousarray(rd.reshape(-1)); off = np.arange(0, rd.shape[0] + 1, dtype=np.int64) * 150
-# every argument is one configuration: space-separated NAME=VALUE environment settings ("" = defaults)
+sizes = [int(x) for x in os.environ.get("READS", "1000000").split(",")]
+r1, r2 = simdata.make_reads_pe(g, max(sizes) // 2, seed=1000)
+rd_all = bench.interleave(r1, r2)
+gpu = BwaGpu(prefix); gpu.densify_sa(4); gpu.set_taps(False)
+gpu.L.bwagpu_debug_prof.argtypes = [C.c_void_p, C.c_void_p]
 for cfg in (sys.argv[1:] or [""]):
-    sets = dict(kv.split("=", 1) for kv in cfg.split())
+    sets = {}
+    for kv in cfg.split():
+        k, v = kv.split("=", 1); k = k.lower(); sets[k[7:] if k.startswith("bwagpu_") else k] = int(v)
+    old = {k: gpu.get_option(k) for k in sets}
     for k, v in sets.items():
-        os.environ[k] = v
-    gpu = BwaGpu(prefix); gpu.densify_sa(4); gpu.set_taps(False)
-    gpu.upload(flat, off)
-    gpu.set_stats(False); gpu.run(opt)
-    runs = []
-    for _ in range(4):
-        gpu.run(opt); runs.append(gpu.stats())
-    ms_plain = {k: min(r[k] for r in runs) for k in ("ms_seed", "ms_chain", "ms_extend", "ms_dedup", "ms_total")}
-    gpu.set_stats(True); gpu.run(opt)
-    s = gpu.stats()
-    out = (C.c_ulonglong * 16)()
-    gpu.L.bwagpu_debug_prof.argtypes = [C.c_void_p, C.c_void_p]
-    gpu.L.bwagpu_debug_prof(gpu.h, out)
-    it, slow, ext, deep = out[13], out[14], out[15], out[12]
-    print(f"[{cfg or 'defaults'}] k_seed {ms_plain['ms_seed']:.1f} ms (with counters {s['ms_seed']:.1f}), chain {ms_plain['ms_chain']:.1f} extend {ms_plain['ms_extend']:.1f} dedup {ms_plain['ms_dedup']:.1f} total {ms_plain['ms_total']:.1f}: "
-          f"wave iterations {it:.4g}, reading the stack from HBM {deep:.4g} ({100.0 * deep / max(it, 1):.1f}%), with bookkeeping {slow:.4g} ({100.0 * slow / max(it, 1):.1f}%), "
-          f"lanes extending per iteration {ext / max(it, 1):.1f} of 64; lane steps {s['n_occ_blocks']} blocks + {s['n_tab_lookups']} table look-ups; regs {s['n_regs']}; "
-          f"extension calls {s['n_ext_calls']} (diagonal rule {s['n_ext_fast']}); cells {s['n_ext_cells']}", flush=True)
-    gpu.close()
-    for k in sets:
-        del os.environ[k]
+        gpu.set_option(k, v)
+    for n in sizes:
+        rd = rd_all[:n]
+        flat = np.ascontiguousarray(rd.reshape(-1)); off = np.arange(0, rd.shape[0] + 1, dtype=np.int64) * rd.shape[1]
+        gpu.upload(flat, off)
+        gpu.set_stats(False); gpu.run(opt)
+        runs = []
+        for _ in range(3):
+            gpu.run(opt); runs.append(gpu.stats())
+        ms = {k: min(r[k] for r in runs) for k in ("ms_seed", "ms_publish", "ms_sa", "ms_chain", "ms_extend", "ms_dedup", "ms_total")}
+        gpu.set_stats(True); gpu.run(opt)
+        s = gpu.stats()
+        out = (C.c_ulonglong * 16)()
+        gpu.L.bwagpu_debug_prof(gpu.h, out)
+        it, slow, ext, deep = out[13], out[14], out[15], out[12]
+        done_l, wait_l, run_l, first_done, longest, waves = out[2], out[3], out[4], out[5], out[6], max(out[7], 1)
+        slots = 64.0 * max(it, 1)
+        print(f"[{cfg or 'defaults'}] {n} reads: k_seed(+k_seed3) {ms['ms_seed']:.1f} ms (with counters {s['ms_seed']:.1f}), sa {ms['ms_sa']:.1f} chain {ms['ms_chain']:.1f} extend {ms['ms_extend']:.1f} dedup {ms['ms_dedup']:.1f} "
+              f"total {ms['ms_total']:.1f} | wave iterations {it:.4g} over {waves} waves (mean {it / waves:.0f}, longest {longest}; first lane out of reads at {first_done / waves:.0f} on average), "
+              f"with bookkeeping {100.0 * slow / max(it, 1):.1f}%, stack from HBM {100.0 * deep / max(it, 1):.1f}% | lane-slots: extending {100.0 * ext / slots:.1f}% ({ext / max(it, 1):.1f} of 64), "
+              f"out of reads {100.0 * done_l / slots:.1f}%, waiting for bookkeeping {100.0 * wait_l / slots:.1f}%, in bookkeeping {100.0 * run_l / slots:.1f}% | "
+              f"{s['n_occ_blocks'] / n:.0f} blocks + {s['n_tab_lookups'] / n:.0f} table look-ups per read", flush=True)
+    for k, v in old.items():
+        gpu.set_option(k, v)
+gpu.close()
