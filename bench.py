@@ -366,8 +366,8 @@ def main():
         try:
             pj = json.load(open(pmc))
             names = [roof_k] + (["k_seed3"] if roof_k == "k_seed" else [])     # the seeding stage is two kernels since round 2 (pass 3 runs first)
-            fetch = sum(pj.get(k_, {}).get("FETCH_SIZE_KB", 0.0) / max(1, pj.get(k_, {}).get("launches_seen", 1)) for k_ in names) * 1024.0
-            write = sum(pj.get(k_, {}).get("WRITE_SIZE_KB", 0.0) / max(1, pj.get(k_, {}).get("launches_seen", 1)) for k_ in names) * 1024.0
+            fetch = sum(pj.get(k_, {}).get("FETCH_SIZE_KB", 0.0) for k_ in names) * 1024.0       # (tools/pmc_summary.py's figures are per launch already)
+            write = sum(pj.get(k_, {}).get("WRITE_SIZE_KB", 0.0) for k_ in names) * 1024.0
             if fetch > 0:
                 factor = 0.5 if (roof_k in ("k_seed", "k_sa") and occ32) else 1.0
                 traffic = fetch * factor + write
@@ -594,7 +594,7 @@ def run_variants(args, prefix, batch_files=(), wall_left=1e9):
             continue
         if name == "long_reads":
             # the long-read defaults of round 4 against the forms they replaced: all of round 3's together (what BENCH_r03's `longread` ran), then each alone
-            alone = ["seed_mrg=0", "seed_chunk=0", "publish_blk=0", "seedsw_lds=0", "dedup_blk=0"]
+            alone = ["seed_mrg=0", "seed_tasks=0", "publish_blk=0", "seedsw_lds=0", "dedup_blk=0"]
             cfgs = [" ".join(alone)] + alone          # (all together first: the entry to have if the leg runs out of its time)
         log(f"[bench] variants, {name} (child process, <= {limit:.0f} s): {cfgs}")
         t = time.time()

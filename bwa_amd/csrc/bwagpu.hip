@@ -85,7 +85,7 @@ struct bwagpu_s {
 	i64 cigl_z_cap = 0;                          // bytes per direction matrix of the long CIGAR tier's scratch (grows with the batches)
 	DevBuf d_cigl_z, d_cigl_ops, d_cigl_md, d_cigl_list;      // scratch of the long-segment CIGAR tier (k_cigar_long): direction matrices, operations, MD strings per workgroup
 	DevBuf d_cig_ext; i64 cig_ext_n = -1;   // operation array of the last bwagpu_batch_cigars (records with 7..64 operations point into it)
-	DevBuf d_vr_tab, d_vr_chain, d_vr_meta, d_vr_intv;   // chunk-parallel pass 1 of long-read batches (k_seed<LR>): task tables, chains, per-task counters, SMEM lists
+	DevBuf d_vr_tab, d_vr_ovf, d_intv_n3;   // pass 1 of long-read batches as tasks (k_seed<LR>): the reads' first tasks, the list of tasks to redo on full-size stacks, pass 3's entries per read
 	DevBuf d_seq_2b, d_seq_flags; int rd_words = 0;   // per-read 2-bit copies for k_seed's LDS (k_pack_reads2b)
 	DevBuf d_pack_off, d_regs_packed, d_pack_read, d_cigs, d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
 	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_blob;
@@ -167,6 +167,14 @@ struct ResultPool {
 		live[p] = want;
 		return p;
 	}
+	// release the idle blocks (bwagpu_trim; also when the process's last handle is destroyed: an embedding program gets the page-locked
+	// memory back with the device)
+	void trim()
+	{
+		std::lock_guard<std::mutex> l(m);
+		for (auto &b : idle) { (void)hipHostFree(b.second); pinned -= b.first; }
+		idle.clear();
+	}
 	void put(void *p)
 	{
 		if (!p) return;
@@ -183,6 +191,8 @@ ResultPool g_results;
 static void *result_alloc(size_t bytes) { return g_results.get(bytes); }
 extern "C" void bwagpu_free(void *p) { g_results.put(p); }
 extern "C" void *bwagpu_alloc_host(size_t bytes) { return g_results.get(bytes); }
+extern "C" void bwagpu_trim(void) { g_results.trim(); }
+static std::atomic<int> g_live_handles{0};
 
 static int upload(bwagpu_t *h, DevBuf &b, const void *src, size_t bytes)
 {
@@ -379,7 +389,7 @@ extern "C" int bwagpu_create(bwagpu_t **out, const bwagpu_index_desc_t *d, int d
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BWAGPU_ENODEV;
 	if (hipSetDevice(device) != hipSuccess) return BWAGPU_ENODEV;
-	bwagpu_t *h = new bwagpu_s();
+	bwagpu_t *h = new bwagpu_s(); ++g_live_handles;
 	h->device = device;
 	h->ibuf = new bwagpu_s::IndexBufs();
 	init_config(h->cfg);
@@ -431,12 +441,13 @@ fail:
 extern "C" void bwagpu_destroy(bwagpu_t *h)
 {
 	if (!h) return;
+	struct LastOut { ~LastOut() { if (--g_live_handles == 0) g_results.trim(); } } last_out;      // (after the handle's own buffers are gone)
 	if (h->ibuf && --h->ibuf->refs == 0) {
 		DevBuf *ib[] = { &h->ibuf->d_bwt, &h->ibuf->d_sa, &h->ibuf->d_pac, &h->ibuf->d_ctg_off, &h->ibuf->d_ctg_len, &h->ibuf->d_ctg_alt, &h->ibuf->d_ptab, &h->ibuf->d_occ32, &h->ibuf->d_occ_sb };
 		for (DevBuf *b : ib) b->release();
 		delete h->ibuf;
 	}
-	DevBuf *all[] = { &h->d_vr_tab, &h->d_vr_chain, &h->d_vr_meta, &h->d_vr_intv, &h->d_cigl_list, &h->d_cigl_z, &h->d_cigl_ops, &h->d_cigl_md, &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
+	DevBuf *all[] = { &h->d_vr_tab, &h->d_vr_ovf, &h->d_intv_n3, &h->d_cigl_list, &h->d_cigl_z, &h->d_cigl_ops, &h->d_cigl_md, &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_chain_todo, &h->d_seed_w, &h->d_seed_order, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
@@ -519,7 +530,7 @@ extern "C" int bwagpu_clone(bwagpu_t *src, bwagpu_t **out)
 {
 	if (!src || !out) return BWAGPU_EINVAL;
 	if (hipSetDevice(src->device) != hipSuccess) return BWAGPU_ENODEV;
-	bwagpu_t *h = new bwagpu_s();
+	bwagpu_t *h = new bwagpu_s(); ++g_live_handles;
 	h->device = src->device;
 	h->ibuf = src->ibuf; ++h->ibuf->refs;     // (bwagpu_destroy drops the reference again on every failure path below)
 	if (hipStreamCreate(&h->stream) != hipSuccess) { h->stream = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
@@ -544,7 +555,7 @@ static int clone_to_device_impl(bwagpu_t *src, int device, bwagpu_t **out)
 	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return BWAGPU_ENODEV;
 	if (device == src->device) return bwagpu_clone(src, out);
 	if (hipSetDevice(device) != hipSuccess) return BWAGPU_ENODEV;
-	bwagpu_t *h = new bwagpu_s();
+	bwagpu_t *h = new bwagpu_s(); ++g_live_handles;
 	h->device = device;
 	h->ibuf = new bwagpu_s::IndexBufs();
 	h->cfg = src->cfg;
@@ -632,6 +643,7 @@ extern "C" int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16])
 	Counters c;
 	if (hipMemcpy(&c, h->d_ctr.p, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return BWAGPU_EHIP;
 	for (int i = 0; i < 16; ++i) out[i] = c.prof[i];
+	out[8] = c.n_vr_ovf;       // tasks of a long-read batch's pass 1 that were redone on full-size interval stacks
 	return BWAGPU_OK;
 }
 
@@ -868,39 +880,29 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 	// seed re-scoring, four columns per lane in the patch alignments.  An explicit option (>= 0) overrides either way.
 	const bool long_batch = h->max_len > WAVE_EXT_MAX_LEN;
 	auto pick = [&](long long v, long long dflt_long) { return v >= 0 ? v : (long_batch ? dflt_long : 0); };
-	// Chunk-parallel pass 1 of long-read batches (option seed_chunk = bases per chunk; dev_seed.h, k_seed's LR): one task per
-	// (read, chunk); the tables go up once per batch, the per-task results live in HBM between the two launches.
-	int chunk_len = (int)pick(cfg.seed_chunk, 256), n_vreads = 0, chunk_lanes = 0, vr_cap = 0;
-	if (chunk_len < 32 || chunk_len > 32768 || h->max_len <= WAVE_EXT_MAX_LEN || h->max_len >= 65536 || h->ix.occ32 == nullptr || h->ix.ptab == nullptr || h->rd_words != 0) chunk_len = 0;
-	if (chunk_len) {
-		std::vector<i32> tab; tab.reserve((size_t)(h->n_bases / chunk_len) * 2 + 3 * (size_t)n + 16);
+	// Pass 1 of long-read batches as independent tasks (option seed_tasks; dev_seed.h, k_seed's LR): one task per read and min_seed_len-th
+	// position.  The host only says where each read's tasks begin; a task finds its read by bisection.
+	bool seed_tasks = pick(cfg.seed_tasks, 1) != 0;
+	int n_vreads = 0, task_lanes = 0;
+	const int TASK_STACK_CAP = PTAB_MAX + (cfg.seed_task_stack > 0 ? (int)((cfg.seed_task_stack + 1) / 2) : 128);          // BiIntv-sized entries of a task lane's spill area (default: 256 packed entries; a full stack hands the task to the second launch)
+	if (!long_batch || h->max_len >= 65536 || h->seq_len >= ((u64)1 << 37) || h->ix.occ32 == nullptr || h->ix.ptab == nullptr || h->rd_words != 0 || opt->min_seed_len < 1 || cfg.seed_pass3_inline) seed_tasks = false;
+	if (seed_tasks) {
 		std::vector<i32> first((size_t)n + 1);
-		for (int r = 0; r < n; ++r) {
-			first[r] = n_vreads;
-			const i64 len = h->h_off[r + 1] - h->h_off[r];
-			n_vreads += (int)((len + chunk_len - 1) / chunk_len);
+		i64 tot = 0;
+		for (int r = 0; r < n; ++r) { first[r] = (i32)tot; tot += (h->h_off[r + 1] - h->h_off[r] + opt->min_seed_len - 1) / opt->min_seed_len; }
+		first[n] = (i32)tot;
+		if (tot <= 0 || tot > 0x7fffffff) seed_tasks = false;
+		else {
+			n_vreads = (int)tot;
+			task_lanes = (int)((tot + BLOCK - 1) / BLOCK * BLOCK); if (task_lanes > 256 * 3 * BLOCK) task_lanes = 256 * 3 * BLOCK;   // persistent lanes (three workgroups per CU), tasks drawn from a counter
+			if (h->d_vr_tab.ensure(((size_t)n + 1) * 4) || h->d_vr_ovf.ensure((size_t)n_vreads * 4 + 16) || h->d_intv_n3.ensure((size_t)n * 4 + 16)) { h->err = "hipMalloc failed (seeding tasks)"; return BWAGPU_ENOMEM; }
+			HIPCHK(h, hipMemcpyAsync(h->d_vr_tab.p, first.data(), first.size() * 4, hipMemcpyHostToDevice, h->stream));   // (pageable source: staged before the call returns)
 		}
-		first[n] = n_vreads;
-		// layout of d_vr_tab: vr_read[n_vreads], vr_beg[n_vreads], vr_first[n + 1]
-		tab.resize((size_t)2 * n_vreads + (size_t)n + 1);
-		for (int r = 0, v = 0; r < n; ++r) {
-			const i64 len = h->h_off[r + 1] - h->h_off[r];
-			for (i64 b = 0; b < len; b += chunk_len, ++v) { tab[v] = r; tab[(size_t)n_vreads + v] = (i32)b; }
-		}
-		memcpy(tab.data() + (size_t)2 * n_vreads, first.data(), ((size_t)n + 1) * 4);
-		vr_cap = 2 * chunk_len < 64 ? 64 : 2 * chunk_len;
-		if (cfg.seed_chunk_cap > 0) vr_cap = (int)cfg.seed_chunk_cap;   // (tests: tasks whose lists overflow are recomputed by the stitcher)
-		chunk_lanes = (n_vreads + BLOCK - 1) / BLOCK * BLOCK; if (chunk_lanes > 65536) chunk_lanes = 65536;   // persistent lanes, tasks drawn from a counter
-		if (n_vreads == 0) chunk_len = 0;
-		else if (h->d_vr_tab.ensure(tab.size() * 4) || h->d_vr_chain.ensure((size_t)n_vreads * chunk_len * 4) || h->d_vr_meta.ensure((size_t)n_vreads * 4 * 4) ||
-				 h->d_vr_intv.ensure((size_t)n_vreads * vr_cap * sizeof(Intv3))) { h->err = "hipMalloc failed (chunk tasks)"; return BWAGPU_ENOMEM; }
-		else HIPCHK(h, hipMemcpyAsync(h->d_vr_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, h->stream));   // (pageable source: staged before the call returns)
 	}
-	if (!chunk_len) { n_vreads = 0; chunk_lanes = 0; }
-	if (dbg_sync) fprintf(stderr, "[bwagpu] pass 1 by chunks: %d bases per chunk, %d tasks on %d lanes (max_len %d, rd_words %d)\n", chunk_len, n_vreads, chunk_lanes, h->max_len, h->rd_words);
+	if (dbg_sync) fprintf(stderr, "[bwagpu] pass 1 by tasks: %d tasks on %d lanes (max_len %d, step %d)\n", n_vreads, task_lanes, h->max_len, opt->min_seed_len);
 	for (int attempt = 0; attempt < 12; ++attempt) {
 		h->phase = 20 + attempt * 100;
-		int rc = alloc_batch(h, n_threads, chunk_lanes);
+		int rc = alloc_batch(h, n_threads, seed_tasks ? (int)(((size_t)task_lanes * TASK_STACK_CAP + (size_t)(h->max_len + PTAB_MAX)) / (size_t)(h->max_len + 1 + PTAB_MAX)) : 0);   // (the tasks' small spill areas, in units of a full-size one)
 		if (rc) return rc;
 		HIPCHK(h, hipMemcpyAsync(h->d_minhsp.p, minhsp.data(), minhsp.size() * 4, hipMemcpyHostToDevice, h->stream));
 		HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
@@ -928,12 +930,8 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.seed_no_virt = cfg.seed_no_virt != 0;
 		B.seed_pass3_inline = cfg.seed_pass3_inline != 0;
 		B.chain_lds_off = cfg.chain_lds == 0;
-		B.chunk_len = chunk_len; B.n_vreads = n_vreads; B.vr_cap = vr_cap;
-		if (chunk_len) {
-			B.vr_read = h->d_vr_tab.as<i32>(); B.vr_beg = B.vr_read + n_vreads; B.vr_first = B.vr_beg + n_vreads;
-			B.vr_chain = h->d_vr_chain.as<i32>(); B.vr_nchain = h->d_vr_meta.as<i32>(); B.vr_exit = B.vr_nchain + n_vreads; B.vr_nintv = B.vr_exit + n_vreads; B.vr_from = B.vr_nintv + n_vreads;
-			B.vr_intv = h->d_vr_intv.as<Intv3>();
-		}
+		B.task_step = opt->min_seed_len; B.n_vreads = n_vreads; B.vr_ovf_run = 0; B.vr_room = 0; B.seed_stack_cap = 0; B.intv_n3 = nullptr;
+		if (seed_tasks) { B.vr_first = h->d_vr_tab.as<i32>(); B.vr_ovf = h->d_vr_ovf.as<i32>(); B.intv_n3 = h->d_intv_n3.as<i32>(); }
 		// memory round trips per iteration of the seeding kernels (dev_seed.h, k_seed's MRG): 0 = as compiled, 2 = table entries, whole index
 		// blocks and the next interval-stack entry in one trip (any other non-zero value selects 2 as well)
 		int seed_mrg = pick(cfg.seed_mrg, 2) ? 2 : 0;
@@ -963,11 +961,15 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			const bool rd = B.rd_words != 0, st = B.stats != 0;
 			const int blk = h->ix.occ32 != nullptr ? 1 : 0;
 			const int mrg = seed_mrg;
-			if (chunk_len && blk == 1 && !rd) {
-				// long reads, pass 1 by chunks: the workers (persistent lanes drawing tasks), then the lane-per-read kernel as stitcher (+ pass 2)
-				Batch BA = B; BA.seed_order = nullptr;
-				const dim3 agrid((unsigned)(chunk_lanes / BLOCK));
+			if (seed_tasks && blk == 1 && !rd) {
+				// long reads: pass 1 as independent tasks on small interval stacks; the few tasks whose stack filled up once more, on full-size
+				// stacks (its work list is known on the device only: the launch is sized for the lane-per-read kernel and usually finds nothing);
+				// then the lane-per-read kernel from pass 2 on
+				Batch BA = B; BA.seed_order = nullptr; BA.seed_stack_cap = TASK_STACK_CAP; BA.vr_room = B.seed_lds_ent + 2 * (TASK_STACK_CAP - PTAB_MAX) - 2;
+				Batch BO = B; BO.seed_order = nullptr; BO.vr_ovf_run = 1; BO.vr_room = 0x7fffffff;
+				const dim3 agrid((unsigned)(task_lanes / BLOCK));
 #define SEED_LAUNCH_LR(ST_, M_) do { hipLaunchKernelGGL((k_seed<false, ST_, 1, 3, M_, 1>), agrid, block, seed_lds, h->stream, h->ix, *opt, BA); \
+					hipLaunchKernelGGL((k_seed<false, ST_, 1, 3, M_, 1>), sgrid, block, seed_lds, h->stream, h->ix, *opt, BO); \
 					hipLaunchKernelGGL((k_seed<false, ST_, 1, 3, M_, 2>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B); } while (0)
 				if (mrg == 2) { if (st) SEED_LAUNCH_LR(true, 2); else SEED_LAUNCH_LR(false, 2); }
 				else { if (st) SEED_LAUNCH_LR(true, 0); else SEED_LAUNCH_LR(false, 0); }

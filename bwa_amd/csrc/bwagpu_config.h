@@ -22,8 +22,8 @@
 	X(occ32_sb_shift,    32)   /* index: log2 bases per superblock of that layout (tests: small superblocks on small genomes)                           */ \
 	X(ptab_m,            10)   /* index: depth of the prefix tables (0: none)                                                                           */ \
 	X(seed_mrg,          -1)   /* seeding: 0 = loads as the compiler schedules them, 2 = one memory round trip per iteration; auto: 2 for long reads     */ \
-	X(seed_chunk,        -1)   /* seeding: pass 1 of long reads by chunks of this many bases (0: off); auto: 256 for long reads                         */ \
-	X(seed_chunk_cap,    0)    /* seeding: capacity of a chunk task's SMEM list (0: 2 x chunk; tests: tiny lists force the stitcher's recomputation)    */ \
+	X(seed_tasks,        -1)   /* seeding: pass 1 of long reads as independent tasks, one per min_seed_len-th position (0: the lane-per-read chain); auto: on for long reads */ \
+	X(seed_task_stack,   0)    /* seeding: packed interval-stack entries a task lane may spill (0: 256; tests: tiny stacks force the second launch)      */ \
 	X(publish_blk,       -1)   /* interval sort + SA-row expansion by one workgroup per read; auto: on for long reads                                   */ \
 	X(seedsw_lds,        -1)   /* mem_flt_chained_seeds' local alignments with their state in LDS; auto: on for long reads                              */ \
 	X(dedup_blk,         -1)   /* patch alignments of k_dedup_wave with four columns per lane; auto: on (the wave kernel only runs for long reads)      */ \

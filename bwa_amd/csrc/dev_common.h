@@ -87,7 +87,8 @@ struct alignas(128) HotCounter { unsigned long long v; unsigned long long pad_[1
 struct Counters {          // device-side bump allocators + flags
 	HotCounter seed_used_, node_used_, reg_used_;
 	HotCounter next_read_, next_read3_;   // work counters of the seeding kernels (passes 1-2, pass 3)
-	HotCounter next_vread_;               // ... and of the chunk workers of long-read batches (k_seed<LR = 1>)
+	HotCounter next_vread_;               // ... and of the pass-1 tasks of long-read batches (k_seed<LR = 1>)
+	HotCounter n_vr_ovf_, next_vovf_;     // ... tasks whose interval stack outgrew the task lanes' small spill areas (redone on full-size stacks), and the work counter of that second launch
 	HotCounter next_ext_;    // work counter of the wave extension kernel (position in Batch::order)
 	HotCounter next_seedsw_; // work counter of the wave-per-read seed re-scoring kernel (long reads)
 	HotCounter next_chain_, next_dedup_;       // work counters of the chaining and de-duplication kernels
@@ -110,6 +111,8 @@ struct Counters {          // device-side bump allocators + flags
 #define next_read next_read_.v
 #define next_read3 next_read3_.v
 #define next_vread next_vread_.v
+#define n_vr_ovf n_vr_ovf_.v
+#define next_vovf next_vovf_.v
 #define next_ext next_ext_.v
 #define next_seedsw next_seedsw_.v
 #define next_chain next_chain_.v
@@ -154,6 +157,7 @@ struct Batch {
 	Counters *ctr;
 	// --- seeding scratch: per resident lane one interval stack (first entries in LDS, see SeedStack)
 	BiIntv *tmp_intv;          // [n_seed_threads][max_len+1]: spill area of the lanes' interval stacks
+	int seed_stack_cap;        // entries of a lane's spill area (0: max_len + 1 + PTAB_MAX, the worst case; the task launch of long-read batches: small)
 	int seed_lds_ent;          // stack entries per lane kept in LDS (0 when seq_len >= 2^37 or max_len >= 2^16: the packing would not fit)
 	int seed_no_virt;          // diagnostics: keep short matches in the stack as well (see SeedLane::smask)
 	int mem_cap;               // capacity of one read's interval list
@@ -177,13 +181,12 @@ struct Batch {
 	u8 *slot_blob;
 	i32 *chain_n;              // per read: chains after filtering
 	i32 *chain_todo, *chain_todo2; // reads deferred by tier 0 / tier 1 of k_chain_wave to the next tier
-	// --- chunk-parallel pass 1 of long-read batches (k_seed<LR>, option seed_chunk): one task per (read, chunk of chunk_len bases); a read's tasks are consecutive
-	int chunk_len, n_vreads, vr_cap;
-	const i32 *vr_read, *vr_beg;    // per task: its read, the first base of its chunk
-	const i32 *vr_first;            // per read: its first task
-	i32 *vr_chain;                  // [n_vreads][chunk_len]: the positions the task's chain visited inside its chunk, ascending
-	i32 *vr_nchain, *vr_exit, *vr_nintv, *vr_from;   // per task: chain length (0: unusable), where the chain left the chunk, SMEMs found, and (stitcher) the chunk-relative position its results are valid from (-1: not at all)
-	Intv3 *vr_intv;                 // [n_vreads][vr_cap]: the SMEMs, x2's bits 48.. = chunk-relative position of the search that found them
+	// --- pass 1 of long-read batches as independent tasks (k_seed<LR = 1>, option seed_tasks): task t of read r searches position (t - vr_first[r]) * task_step
+	int task_step, n_vreads;        // min_seed_len; number of tasks of the batch
+	const i32 *vr_first;            // per read: its first task (n_reads + 1 entries)
+	i32 *vr_ovf;                    // tasks to be redone on full-size interval stacks (n_vr_ovf of them)
+	int vr_ovf_run, vr_room;        // this launch: 1 = redo the tasks of vr_ovf; interval-stack entries a lane may hold before its task counts as overflowed
+	i32 *intv_n3;                   // per read: the entries pass 3 (k_seed3, run first) left at the head of its interval list
 	int seed_prio;             // waves holding the heaviest 3 % of k_seed's reads run at raised issue priority (option seed_prio = 0 turns it off)
 	int seed_pass3_inline;     // A/B switch (option seed_pass3_inline = 1): pass 3 inside k_seed's state machine as in round 1, instead of k_seed3
 	int chain_lds_off;         // test hook (option chain_lds = 0): the LDS tiers defer every read

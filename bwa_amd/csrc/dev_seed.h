@@ -16,15 +16,20 @@
 struct SeedEmit {        // the MEM list of the read being seeded (lane-private scratch)
 	Intv3 *intv; int r, n, cap; bool overflow;      // the list is intv[r * cap ..] (the address is rebuilt on use: two registers less per lane)
 	int min_seed_len;
+	i32 *shared_n;  // k_seed<LR = 1>: several lanes (tasks) append to read r's list at once -- the entry's index comes from an atomic add on the read's count (null elsewhere)
 	DEVFN Intv3 *mem() const { return intv + (size_t)r * (size_t)cap; }
 	// pass 2 (bwamem.c:160-168) walks pass 1's SMEMs looking for the long and rare ones; re-reading the list costs a memory round
 	// trip per entry with the whole wave waiting, so the test is made here and remembered: bit k = entry base + k qualifies
 	int split_len, base; u64 split_width, cand;
-	u64 tag;        // k_seed<LR = 1>: the position of the search that reports, relative to its chunk, << 48 -- kept in the spare top bits of x2 (0 elsewhere)
 	DEVFN void add(u64 x0, u64 x2, int start, int end) {
 		if (end - start < min_seed_len) return;
+		Intv3 v; v.x0 = x0; v.x2 = x2; v.info = (u64)start << 32 | (u32)end;
+		if (shared_n) {
+			const int k = atomicAdd(&shared_n[r], 1);
+			if (k >= cap) overflow = true; else mem()[k] = v;      // (the count keeps running past the capacity: the kernel that follows sees that and flags the batch)
+			return;
+		}
 		if (n == cap) { overflow = true; return; }
-		Intv3 v; v.x0 = x0; v.x2 = x2 | tag; v.info = (u64)start << 32 | (u32)end;
 		if (end - start >= split_len && x2 <= split_width && n - base < 64) cand |= 1ull << (n - base);
 		mem()[n++] = v;
 	}
@@ -55,6 +60,7 @@ struct SeedLane {
 	// current SMEM search (bwt_smem1a, bwt.c:289-351)
 	u64 min_intv, last_x2;
 	int sx, i, n0, nprev, nc, j, c, ret, last_start;
+	int lo;                   // the backward sweep runs rows i >= lo (-1: all of them, bwt.c:326; a pass-1 task of a long read stops where the next task to the left reports)
 	bool any;
 	BiIntv ik;
 	u32 code;                 // prefix-table window: forward sweep, q[sx..sx+ptab_m); backward sweep, q[i..i+ptab_m) (window_code)
@@ -191,7 +197,7 @@ DEVFN void smem_finish(SeedLane &L) { if (L.pass == 1) { L.x = L.ret; L.st = SS_
 DEVFN void bwd_begin_row(SeedLane &L, const SeedStack &S, const u64 *nib, int m)
 {
 	for (;;) {
-		if (L.i < -1) { smem_finish(L); return; }
+		if (L.i < L.lo) { smem_finish(L); return; }
 		L.c = L.i < 0 ? -1 : seed_q(L, nib, L.i);
 		if (L.c > 3) L.c = -1;
 		L.j = 0; L.nc = 0; L.ncl = 0; L.last_x2 = 0; L.srem = L.smask; L.snew = 0;
@@ -419,21 +425,24 @@ __global__ void __launch_bounds__(256) k_publish_blk(bwagpu_opt_t opt, Batch B)
 //      (BENCH_r03 variants): short reads 83.3 -> 87.6 ms (the kernel is bound by the request rate of its live lanes, not by trips per
 //      iteration), long reads 515 -> 451 ms (few lanes, every trip exposed): the default for long-read batches only.  (The intermediate
 //      form without the prefetch, MRG = 1, was slower than both and is gone.)
-// LR (long-read batches, BWAGPU_SEED_CHUNK): pass 1 of a read is a chain of searches x -> ret(x) (bwamem.c:147-157), ~40 000 dependent index look-ups
-//      for a 10 kb read, and a batch has fewer reads than the chip has SIMDs.  The searches are pure functions of x, and chains started at different
-//      positions merge as soon as they share one (ret is monotone; a match that ends at a read error ends there for every start inside it).  So:
-//      1 = chunk worker: a lane takes a TASK (read, chunk of Batch::chunk_len bases), walks the chain from the chunk's first base until it leaves the
-//          chunk, and records the positions it visited, where it left, and the SMEMs it found, each tagged with its search's position (vr_*).
-//      2 = stitcher: the ordinary lane-per-read kernel, except that in pass 1, standing at x, it first looks x up in the chain recorded for x's
-//          chunk: found -> everything that worker did from x on is what this lane would do, so it notes "chunk valid from x" and jumps to where
-//          the worker left; not found -> it runs the search itself, as ever, and tries again at the next position.  When pass 1 is over it
-//          appends the valid part of every chunk's SMEMs to the read's list (order is immaterial: k_publish sorts) and goes on to pass 2.
-//      Exact whatever happens: a chunk that never merges is simply recomputed by the stitcher.
+// LR (long-read batches, option seed_tasks): pass 1 of a 10 kb read (bwamem.c:147-157) is a chain of ~500 searches x -> ret(x), ~40 000 dependent index
+//      look-ups, and a batch has fewer reads than the chip has SIMDs.  Round 3 cut the chain into chunks whose chains were to merge with the
+//      read's own; on noisy reads they almost never do (two chains meet only where a match's suffix is already unique: measured 38 ms of chunk
+//      workers + 316 ms of a lane-per-read kernel recomputing nearly everything, profiles/r04_longread_kernel_stats.csv).  The chain is not needed:
+//      bwt_smem1(x) with min_intv 1 returns exactly the matches through x that can be extended neither way (each change point of the forward
+//      sweep that survives the backward rows down to its own left end, bwt.c:326-345) -- a property of the read, whoever asks -- and the chain only
+//      makes sure that every such match is asked for once.  A match of at least min_seed_len bases covers a multiple of s = min_seed_len, so:
+//      1 = TASK (read, position g = k s): the search at g, reporting the matches whose start lies in (g - s, g] -- each match is reported by
+//          the first multiple of s it covers, once -- which also ends the backward sweep after s rows.  Tasks append to the read's list through an
+//          atomic count (k_publish sorts; equal keys are identical intervals).  Their interval stacks are small (Batch::vr_room entries; a forward
+//          sweep with more change points than that hands its task to a second launch of this instance on full-size stacks, Batch::vr_ovf_run).
+//      2 = the ordinary lane-per-read kernel entered at pass 2 (bwamem.c:160-168), over the entries the tasks left behind pass 3's (k_seed3 runs first).
+//      Exact by construction, no stitching; shorter matches are dropped by the length filter as ever.
 template<bool RD, bool STATS, int BLK, int OCC, int MRG = 0, int LR = 0>
 __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
 	HIP_DYNAMIC_SHARED(uint4, seed_lds)
-	const int cap = B.max_len + 1 + PTAB_MAX;
+	const int cap = B.seed_stack_cap > 0 ? B.seed_stack_cap : B.max_len + 1 + PTAB_MAX;      // entries of a lane's spill area (tasks of long reads: small ones, see LR)
 	const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
 	SeedLane L;
 	SeedStack S;
@@ -442,9 +451,10 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	S.virt_m = (ix.ptab_m >= 2 && opt.min_seed_len > ix.ptab_m && !B.seed_no_virt) ? ix.ptab_m : 0;
 	L.smask = L.srem = L.snew = 0; L.ncl = 0;
 	L.em.intv = B.intv; L.em.r = -1; L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len;
-	L.em.split_len = split_len; L.em.split_width = (u64)opt.split_width; L.em.cand = 0; L.em.base = 0; L.em.tag = 0;
-	if (LR == 1) { L.em.intv = B.vr_intv; L.em.cap = B.vr_cap; }
-	int vr_beg = 0, vr_end = 0, vr_nch = 0;       // LR == 1: the task's chunk [vr_beg, vr_end) and the number of chain positions recorded (the task itself is L.em.r)
+	L.em.split_len = split_len; L.em.split_width = (u64)opt.split_width; L.em.cand = 0; L.em.base = 0; L.em.shared_n = LR == 1 ? B.intv_n : nullptr;
+	L.lo = -1;
+	int vr_task = -1, vr_run = 0;       // LR == 1: the lane's task and whether its search has been started
+	const unsigned long long n_tasks = LR == 1 ? (B.vr_ovf_run ? B.ctr->n_vr_ovf : (unsigned long long)B.n_vreads) : 0;
 	L.st = SS_FETCH; L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u; L.win2 = 0; L.win2_w = ~0u;
 	u32 *rd_lds = (u32*)(seed_lds + (size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * blockDim.x);   // (after the stacks)
 	L.rd = rd_lds; L.rd_on = 0; L.raw = B.seq; L.off = B.off;
@@ -490,9 +500,8 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 		if (run_slow) {
 			deferred = 0; if (STATS) ++n_slow;
 			if (L.st == SS_FINAL) {
-				if (LR == 1) {       // (a task whose list overflowed is marked unusable: the stitcher recomputes its chunk)
-					B.vr_nintv[L.em.r] = L.em.overflow ? 0 : L.em.n; B.vr_nchain[L.em.r] = L.em.overflow ? 0 : vr_nch; B.vr_exit[L.em.r] = L.x; B.vr_from[L.em.r] = -1;
-				} else if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull); else B.intv_n[L.em.r] = L.em.n;
+				if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull);
+				else if (LR != 1) B.intv_n[L.em.r] = L.em.n;       // (tasks counted their entries as they went)
 				L.st = SS_FETCH;
 			}
 			const bool want = L.st == SS_FETCH;
@@ -500,7 +509,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 			if (wm) {
 				if (pool_cnt == 0) {
 					const int first = __ffsll((unsigned long long)__ballot(1)) - 1;        // lane 0 may already have left the loop
-					const unsigned long long old = atomicAdd(LR == 1 ? &B.ctr->next_vread : &B.ctr->next_read, (threadIdx.x & 63) == first ? 64ull : 0ull);
+					const unsigned long long old = atomicAdd(LR == 1 ? (B.vr_ovf_run ? &B.ctr->next_vovf : &B.ctr->next_vread) : &B.ctr->next_read, (threadIdx.x & 63) == first ? 64ull : 0ull);
 					pool_base = __shfl((int)old, first); pool_cnt = 64;
 					// lane l looks up the pool's read number l now: a lane taking a read later gets it from a register of the wave
 					// instead of a memory round trip of its own in front of the reads of the read's data
@@ -516,14 +525,18 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 				const int r = __shfl(pool_r, (64 - pool_cnt + rank) & 63);
 				if (want && rank < pool_cnt) {
 					const int idx = pool_base + rank;
-					if (idx >= (LR == 1 ? B.n_vreads : B.n_reads)) L.st = SS_DONE;
-					else if (LR == 1) {       // a task: chunk [vr_beg, vr_end) of read rr; its results go to the task's own lists
-						const int rr = B.vr_read[r];
-						L.em.r = r; L.qoff = (u64)B.off[rr]; L.len = (int)(B.off[rr + 1] - B.off[rr]);
-						L.win_w = ~0u;
-						vr_beg = B.vr_beg[r]; vr_end = vr_beg + B.chunk_len < L.len ? vr_beg + B.chunk_len : L.len; vr_nch = 0;
-						L.em.n = 0; L.em.base = 0; L.em.overflow = false; L.em.cand = 0;
-						L.x = vr_beg; L.st = SS_PASS1;
+					if (LR == 1 ? (unsigned long long)idx >= n_tasks : idx >= B.n_reads) L.st = SS_DONE;
+					else if (LR == 1) {       // a task: its read by bisection of the reads' first tasks, its position from its rank among the read's tasks
+						const int t = B.vr_ovf_run ? B.vr_ovf[r] : r;
+						int lo = 0, hi = B.n_reads;
+						while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (B.vr_first[mid] <= t) lo = mid; else hi = mid; }
+						const int g = (t - B.vr_first[lo]) * B.task_step;
+						L.em.r = lo; L.qoff = (u64)B.off[lo]; L.len = (int)(B.off[lo + 1] - B.off[lo]);
+						L.win_w = ~0u; L.win2_w = ~0u;
+						L.em.overflow = false;
+						vr_task = t; vr_run = 0;
+						L.lo = g - B.task_step > -1 ? g - B.task_step : -1;
+						L.x = g; L.st = L.len >= opt.min_seed_len ? SS_PASS1 : SS_FINAL;       // (mem_chain returns at once for shorter reads, bwamem.c:286)
 					} else {
 						L.em.r = r; L.qoff = (u64)B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
 						L.win_w = ~0u;
@@ -542,6 +555,12 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 						if (B.seed_pass3_inline) B.intv_n[r] = 0;
 						L.em.n = B.seed_pass3_inline ? 0 : B.intv_n[r]; L.em.base = L.em.n; L.em.overflow = false;   // (base: the entries after pass 3's)
 						L.em.cand = 0;
+						if (LR == 2) {       // pass 2 only: the tasks' entries follow pass 3's; every one of them is looked at (no emitter's bit mask: base - 64)
+							const int n3 = B.intv_n3[r];
+							if (L.em.n > L.em.cap) { atomicOr(&B.ctr->overflow, 16ull); L.em.n = n3; B.intv_n[r] = n3; }      // (a task ran out of room: the batch is redone with longer lists)
+							L.em.base = n3 - 64; L.old_n = L.em.n; L.k2 = n3;
+							if (L.len >= opt.min_seed_len) L.st = SS_PASS2;
+						} else
 						if (L.len >= opt.min_seed_len) { L.x = 0; L.st = SS_PASS1; }   // else mem_chain returns at once (bwamem.c:286): draw the next read
 					}
 				}
@@ -552,35 +571,13 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 			for (int rep = 0; rep < 3; ++rep) {
 				switch (L.st) {
 				case SS_PASS1:   // pass 1: all SMEMs, left to right (bwamem.c:147-157)
-					while (L.x < L.len && seed_q(L, nib, L.x) > 3) ++L.x;
-					if (LR == 1) {       // chunk worker: stop at the first position beyond the chunk (L.x is then where the chain left it)
-						if (L.x >= vr_end) L.st = SS_FINAL;
-						else { B.vr_chain[(size_t)L.em.r * (u32)B.chunk_len + (u32)vr_nch++] = L.x; L.em.tag = (u64)(u32)(L.x - vr_beg) << 48; smem_start(ix, L, S, nib, L.x, 1, 1); }
+					if (LR == 1) {       // a task is ONE search, at its own position (nothing to do where the read holds an N: no match covers it)
+						if (vr_run || L.x >= L.len || seed_q(L, nib, L.x) > 3) L.st = SS_FINAL;
+						else { vr_run = 1; smem_start(ix, L, S, nib, L.x, 1, 1); }
 						break;
 					}
-					if (LR == 2 && L.x < L.len) {       // stitcher: did the worker of this position's chunk come by here?
-						const int v = B.vr_first[L.em.r] + L.x / B.chunk_len, nch = B.vr_nchain[v];
-						const i32 *ch = B.vr_chain + (size_t)v * (u32)B.chunk_len;
-						int lo = 0, hi = nch;              // (the recorded positions ascend)
-						while (lo < hi) { const int mid = (lo + hi) >> 1; if (ch[mid] < L.x) lo = mid + 1; else hi = mid; }
-						if (lo < nch && ch[lo] == L.x) { B.vr_from[v] = L.x - B.vr_beg[v]; L.x = B.vr_exit[v]; break; }   // (stays in SS_PASS1: the next round looks at the next chunk)
-					}
-					if (L.x >= L.len) {
-						if (LR == 2) {       // the valid part of every chunk's SMEMs joins the read's list
-							const int v0 = B.vr_first[L.em.r], nv = (L.len + B.chunk_len - 1) / B.chunk_len;
-							for (int v = v0; v < v0 + nv; ++v) {
-								const int from = B.vr_from[v];
-								if (from < 0) continue;
-								const Intv3 *src = B.vr_intv + (size_t)v * (u32)B.vr_cap;
-								const int ne = B.vr_nintv[v];
-								for (int e = 0; e < ne; ++e) {
-									const Intv3 t = src[e];
-									if ((int)(t.x2 >> 48) >= from) L.em.add(t.x0, t.x2 & (((u64)1 << 48) - 1), (int)(t.info >> 32), (int)(u32)t.info);
-								}
-							}
-						}
-						L.old_n = L.em.n; L.k2 = L.em.base; L.st = SS_PASS2;   // pass 2 re-seeds pass 1's SMEMs (the entries after pass 3's)
-					}
+					while (L.x < L.len && seed_q(L, nib, L.x) > 3) ++L.x;
+					if (L.x >= L.len) { L.old_n = L.em.n; L.k2 = L.em.base; L.st = SS_PASS2; }   // pass 2 re-seeds pass 1's SMEMs (the entries after pass 3's)
 					else smem_start(ix, L, S, nib, L.x, 1, 1);
 					break;
 				case SS_PASS2: { // pass 2: re-seed from the middle of long, rare SMEMs (bwamem.c:160-168)
@@ -672,6 +669,13 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 			if (MRG && BLK == 1) ;
 			else if (!blocks) { ptab_load(ix, tl, L.code, ok); if (STATS) ++ntab; }
 			else { const u32 nb = fm_extend1<BLK>(ix, src, cb, back, ok); if (STATS) nblk += nb; }
+			if (LR == 1 && st == SS_FWD && L.n0 >= B.vr_room) {
+				// the task's interval stack is full (a forward sweep with hundreds of change points: tandem repeats): nothing has been reported yet --
+				// reports come from the backward rows -- so the task is handed to the second launch, which has full-size stacks, as it is
+				const unsigned long long k = atomicAdd(&B.ctr->n_vr_ovf, 1ull);
+				B.vr_ovf[k] = vr_task;
+				L.st = SS_FINAL;
+			} else
 			if (st == SS_FWD) {           // forward sweep of bwt_smem1a (bwt.c:304-320)
 				bool stop = false;
 				if (ok.x2 != L.ik.x2) {
@@ -733,7 +737,7 @@ template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k
 {
 	SeedLane L;                   // only the read window (qoff, win, win_w, len), x, sx, i, ik, code and the emitter are used
 	L.em.cap = B.mem_cap; L.em.min_seed_len = opt.min_seed_len; L.em.intv = B.intv; L.em.r = -1; L.em.n = 0; L.em.overflow = false;
-	L.em.split_len = 0x7fffffff; L.em.split_width = 0; L.em.cand = 0; L.em.base = 0; L.em.tag = 0;
+	L.em.split_len = 0x7fffffff; L.em.split_width = 0; L.em.cand = 0; L.em.base = 0; L.em.shared_n = nullptr;
 	L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u; L.win2 = 0; L.win2_w = ~0u; L.x = 0; L.sx = 0; L.i = 0; L.code = 0; L.rd = nullptr; L.rd_on = 0; L.raw = nullptr; L.off = nullptr;
 	L.ik.x0 = L.ik.x1 = L.ik.x2 = L.ik.info = 0;
 	const u64 *nib = B.seq_nib;
@@ -759,6 +763,7 @@ template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k
 					L.em.r = r; L.qoff = (u64)B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
 					L.em.n = 0; L.em.overflow = false;
 					B.intv_n[r] = 0; B.seed_w[r] = 0; weight = 0;
+					if (B.intv_n3) B.intv_n3[r] = 0;
 					if (L.len >= opt.min_seed_len && opt.max_mem_intv > 0) { L.x = 0; st = T_START; }   // mem_chain returns at once for shorter reads (bwamem.c:286)
 				}
 			}
@@ -768,7 +773,7 @@ template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k
 		if (st == T_START) {
 			while (L.x < L.len && seed_q(L, nib, L.x) > 3) ++L.x;
 			if (L.x >= L.len) {
-				if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull); else B.intv_n[L.em.r] = L.em.n;
+				if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull); else { B.intv_n[L.em.r] = L.em.n; if (B.intv_n3) B.intv_n3[L.em.r] = L.em.n; }
 				B.seed_w[L.em.r] = (i32)(weight > 0x3fffffffu ? 0x3fffffffu : weight);
 				st = T_FETCH;
 			} else {

@@ -348,6 +348,10 @@ int bwagpu_align_flat(bwagpu_t *h, const bwagpu_opt_t *opt, int n, const uint8_t
  * (No counterpart in the reference: bseq1_t::seq is malloc'ed by bseq_read, bwa.c:79-112.) */
 void *bwagpu_alloc_host(size_t bytes);
 void bwagpu_free(void *p);   /* releases any array an entry point of this library returned through an out-pointer (thread-safe) */
+/* The pool behind bwagpu_alloc_host and the large result arrays keeps up to 4 GiB of page-locked blocks for re-use (options pinned_results,
+ * pinned_min_kb).  bwagpu_trim() gives the idle ones back to the system; it happens by itself when the process's last handle is destroyed.
+ * Blocks are pinned under the calling thread's current device (the batch calls set their handle's); they are portable across devices. */
+void bwagpu_trim(void);
 
 /* Split form for callers that overlap transfers with compute, and for measuring the device path with the batch
  * already resident in HBM: upload -> run (device only, asynchronous kernels + one final sync) -> download. */

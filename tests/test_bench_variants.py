@@ -31,8 +31,8 @@ def test_bench_variants_object(monkeypatch, tmp_path):
     short, long_ = res["short_reads"], res["long_reads"]
     assert short["rc"] == 0 and long_["rc"] == 0, (short, long_)
     assert [r["config"] for r in short["runs"]] == ["defaults", "seed_mrg=2", "BWAGPU_SEED_LDS_ENT=3"]      # (the round-3 spelling of an option is still accepted)
-    assert [r["config"] for r in long_["runs"]] == ["defaults", "seed_mrg=0 seed_chunk=0 publish_blk=0 seedsw_lds=0 dedup_blk=0",
-                                                    "seed_mrg=0", "seed_chunk=0", "publish_blk=0", "seedsw_lds=0", "dedup_blk=0"]
+    assert [r["config"] for r in long_["runs"]] == ["defaults", "seed_mrg=0 seed_tasks=0 publish_blk=0 seedsw_lds=0 dedup_blk=0",
+                                                    "seed_mrg=0", "seed_tasks=0", "publish_blk=0", "seedsw_lds=0", "dedup_blk=0"]
     for r in short["runs"] + long_["runs"]:
         assert "error" not in r and r["same_result_as_defaults"] is True, r
     assert all("ms_per_step" in r and "stage_ms_solo" in r for r in short["runs"]) and all("ms_per_pass" in r for r in long_["runs"])

@@ -395,14 +395,14 @@ def test_pacbio_10kb_reads_at_scale_under_the_long_read_defaults(medium):
     compiled reference's mem_align1_core, read by read.  A third batch runs the forms they replaced on the same handle (options set
     through the API between batches): the same regions again."""
     gpu, orc, ref, g = medium
-    for k in ("seed_mrg", "seed_chunk", "publish_blk", "seedsw_lds", "dedup_blk"):
+    for k in ("seed_mrg", "seed_tasks", "publish_blk", "seedsw_lds", "dedup_blk"):
         assert gpu.get_option(k) == -1, f"{k} is not on its automatic setting"
     reads = simdata.make_reads_long(g, 600, length=10000, seed=66)
     want = _ref_align_threads(ref, pacbio_opt(), reads)
     got = [gpu.align(pacbio_opt(), *testdata.flat(reads[a:a + 300])) for a in (0, 300)]
     assert_regs_equal(*want, np.concatenate([x[0] for x in got]), np.concatenate([x[1] for x in got]), "pacbio 10 kb x 600, long-read defaults, two batches")
     assert int(want[0].sum()) > 600
-    old = {"seed_mrg": 0, "seed_chunk": 0, "publish_blk": 0, "seedsw_lds": 0, "dedup_blk": 0}
+    old = {"seed_mrg": 0, "seed_tasks": 0, "publish_blk": 0, "seedsw_lds": 0, "dedup_blk": 0}
     try:
         for k, v in old.items():
             gpu.set_option(k, v)

@@ -56,7 +56,7 @@ def test_hostsim_long_read_dedup_ring_sizes():
     seqs, off = testdata.flat(reads)
     want = orc.align(pacbio_opt(), seqs, off)
     for ring, mrg in (("256", "0"), ("4096", "2")):
-        s2 = sim_handle(prefix, dedup_ring=int(ring), **({"seed_mrg": 0, "publish_blk": 0, "dedup_blk": 0, "seed_chunk": 0, "seedsw_lds": 0} if mrg == "0" else {"seed_chunk": 0}))
+        s2 = sim_handle(prefix, dedup_ring=int(ring), **({"seed_mrg": 0, "publish_blk": 0, "dedup_blk": 0, "seed_tasks": 0, "seedsw_lds": 0} if mrg == "0" else {"seed_tasks": 0}))
         assert s2.get_option("seed_mrg") == (0 if mrg == "0" else -1)
         s2.set_stats(True)
         assert_regs_equal(*want, *s2.align(pacbio_opt(), seqs, off), f"1.8 kb -x pacbio read, dedup ring {ring}, seeding variant {mrg}")
@@ -150,38 +150,52 @@ def test_hostsim_seeding_variants_same_intervals():
         assert got[name] == got["default"], name
 
 
-def test_hostsim_long_read_pass1_by_chunks():
-    """Option seed_chunk = n (long-read batches; their default is 256): pass 1 of mem_collect_intv split into tasks of n bases -- chunk workers record the chain of
-    search positions they walk and the SMEMs they find, the lane-per-read kernel jumps from chunk to chunk wherever its own position lies on a
-    worker's chain and recomputes where it does not (k_seed's LR modes).  Noisy 3 kb reads, reads with N runs, nearly exact reads whose matches
-    span several chunks, a read of one chunk, an all-N and an empty read; chunk sizes that do and do not divide the reads, with the
-    one-round-trip fetch, and with task lists so small that most tasks overflow and are recomputed: the interval lists (order included) equal
-    the serial kernel's."""
+def test_hostsim_long_read_pass1_by_tasks():
+    """Option seed_tasks (long-read batches; their default): pass 1 of mem_collect_intv as independent tasks -- one bwt_smem1 search per read and
+    min_seed_len-th position, each reporting the matches that START within the min_seed_len positions up to its own (so that every match of at
+    least min_seed_len bases is reported exactly once, by the first multiple it covers), appended to the read's list through an atomic count --
+    then the lane-per-read kernel from pass 2 on (k_seed's LR modes).  Noisy 3 kb reads, reads with N runs (on and off the task positions),
+    nearly exact reads whose matches span dozens of task positions and feed pass 2, a read shorter than min_seed_len, an all-N and an empty read;
+    several -k; with and without the one-round-trip fetch; with task stacks so small that most tasks are redone by the second launch; and with
+    interval lists so short that the batch is redone: the interval lists equal the lane-per-read chain's (after the sort; equal keys are
+    identical intervals), and so do the counts of index blocks' users downstream (slots)."""
     import refapi
     if not refapi.have_ref():
         pytest.skip("oracle/_ref not built (needed to index the 2 Mb genome)")
     prefix, g = testdata.medium_index()
     reads = list(simdata.make_reads_long(g, 3, length=3000, seed=5))
     rng = np.random.default_rng(3)
-    reads[1] = reads[1][:1700].copy(); reads[1][rng.integers(0, 1700, 12)] = 4; reads[1][500:530] = 4
+    reads[1] = reads[1][:1700].copy(); reads[1][rng.integers(0, 1700, 12)] = 4; reads[1][500:530] = 4; reads[1][17 * 40] = 4; reads[1][17 * 41 - 1] = 4
     reads[2] = reads[2][:1151]
-    reads += [reads[0][:90], np.full(200, 4, dtype=np.uint8), np.zeros(0, dtype=np.uint8)]
+    reads += [reads[0][:90], reads[0][:12], np.full(200, 4, dtype=np.uint8), np.zeros(0, dtype=np.uint8)]
     reads += list(simdata.make_reads_se(g, 2, length=1300, seed=9, sub=0.002))
     seqs, off = testdata.ragged(reads)
-    opt = pacbio_opt(); opt.min_chain_weight = 1 << 20          # (nothing passes the chain filter: the stages after seeding have no work)
-    got, blocks = {}, {}
-    for name, options in (("serial", {"seed_chunk": 0, "seed_mrg": 0}), ("64", {"seed_chunk": 64, "seed_mrg": 0}), ("256 + one trip", {}),
-                          ("100", {"seed_chunk": 100, "seed_mrg": 0}), ("128, lists of 6", {"seed_chunk": 128, "seed_chunk_cap": 6, "seed_mrg": 0})):
-        s2 = sim_handle(prefix, **options)
-        s2.set_stats(True)
-        c, r = s2.align(opt, seqs, off)
-        ic, iv = s2.tap_intervals()
-        got[name] = (ic.tobytes(), iv.tobytes()); blocks[name] = s2.stats()["n_occ_blocks"]
-        assert int(ic.max()) > 40
-        s2.close()
-    for name in got:
-        assert got[name] == got["serial"], name
-    assert blocks["64"] > blocks["256 + one trip"] > blocks["serial"], blocks      # (the workers' overlap is real work: smaller chunks, more of it)
+    for k in (17, 12, 23):
+        opt = pacbio_opt(); opt.min_seed_len = k; opt.min_chain_weight = 1 << 20          # (nothing passes the chain filter: the stages after seeding have no work)
+        if k == 23:
+            opt.split_factor = 1.5                         # pass 2 in force: the nearly exact reads' long matches are re-seeded
+        got = {}
+        for name, options in (("chain", {"seed_tasks": 0, "seed_mrg": 0}), ("tasks", {"seed_mrg": 0}), ("tasks + one trip", {}), ("tiny stacks", {"seed_task_stack": 2, "seed_lds_ent": 3}),
+                              ("short lists", {"mem_cap": 24})):
+            if k != 17 and name in ("tasks", "short lists"):
+                continue
+            s2 = sim_handle(prefix, **options)
+            s2.set_stats(True)
+            c, r = s2.align(opt, seqs, off)
+            ic, iv = s2.tap_intervals()
+            st = s2.stats()
+            got[name] = (ic.tobytes(), iv.tobytes(), st["n_seeds"])
+            assert int(ic.max()) > 40
+            if name == "short lists":
+                assert st["n_retries"] >= 1
+            import ctypes as C
+            prof = (C.c_ulonglong * 16)()
+            s2.L.bwagpu_debug_prof.argtypes = [C.c_void_p, C.c_void_p]
+            s2.L.bwagpu_debug_prof(s2.h, prof)
+            assert (prof[8] > 20) if name == "tiny stacks" else (prof[8] == 0), (name, prof[8])      # tasks handed to the second launch
+            s2.close()
+        for name in got:
+            assert got[name] == got["chain"], (k, name)
 
 
 def test_hostsim_stage_taps_match_golden(sim):

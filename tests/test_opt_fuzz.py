@@ -162,7 +162,7 @@ def test_sim_option_fuzz_kernel_forms():
     import hostsim_build
     from bwa_amd.api import BwaGpu
     prefix, g = testdata.small_index()
-    for seed, options in ((53, {"seed_mrg": 2, "seed_lds_ent": 2, "seed_chunk": 128}), (54, {"seed_mrg": 0, "seed_chunk": 0, "publish_blk": 0, "seedsw_lds": 0, "dedup_blk": 0})):
+    for seed, options in ((53, {"seed_mrg": 2, "seed_lds_ent": 2, "seed_task_stack": 4}), (54, {"seed_mrg": 0, "seed_tasks": 0, "publish_blk": 0, "seedsw_lds": 0, "dedup_blk": 0})):
         sim, ref = BwaGpu(prefix, lib_path=hostsim_build.build(), options=options), refapi.RefIndex(prefix)
         try:
             run_region_fuzz(sim, ref, g, draws=6, n_short=10, n_long=1, long_len=1200, seed=seed)
@@ -196,7 +196,7 @@ def test_gpu_option_fuzz_kernel_forms():
     chunks for long ones; and the round-3 long-read forms (lane-per-read seeding, one-lane sort, HBM re-scoring, one column per lane)."""
     from bwa_amd.api import BwaGpu
     fa, g = testdata.medium_index()
-    for seed, options in ((55, {"seed_mrg": 2, "seed_lds_ent": 2, "seed_chunk": 128}), (56, {"seed_mrg": 0, "seed_chunk": 0, "publish_blk": 0, "seedsw_lds": 0, "dedup_blk": 0})):
+    for seed, options in ((55, {"seed_mrg": 2, "seed_lds_ent": 2, "seed_task_stack": 4}), (56, {"seed_mrg": 0, "seed_tasks": 0, "publish_blk": 0, "seedsw_lds": 0, "dedup_blk": 0})):
         gpu, ref = BwaGpu(fa, options=options), refapi.RefIndex(fa)
         try:
             run_region_fuzz(gpu, ref, g, draws=10, n_short=1000, n_long=150, long_len=1500, seed=seed)
