@@ -90,6 +90,7 @@ struct Counters {          // device-side bump allocators + flags
 	HotCounter next_vread_;               // ... and of the pass-1 tasks of long-read batches (k_seed<LR = 1>)
 	HotCounter n_vr_ovf_, next_vovf_;     // ... tasks whose interval stack outgrew the task lanes' small spill areas (redone on full-size stacks), and the work counter of that second launch
 	HotCounter next_ext_;    // work counter of the wave extension kernel (position in Batch::order)
+	HotCounter n_ext_tasks_, next_ext_task_, n_ext_heavy_, next_ext_heavy_;   // chain-parallel extension of heavy reads: entries of the task and read lists, and the work counters over them
 	HotCounter next_seedsw_; // work counter of the wave-per-read seed re-scoring kernel (long reads)
 	HotCounter next_chain_, next_dedup_;       // work counters of the chaining and de-duplication kernels
 	HotCounter next_chain_b_, n_chain_todo_;   // second tier of the wave-per-read chaining kernel: its work counter and the length of its work list
@@ -114,6 +115,10 @@ struct Counters {          // device-side bump allocators + flags
 #define n_vr_ovf n_vr_ovf_.v
 #define next_vovf next_vovf_.v
 #define next_ext next_ext_.v
+#define n_ext_tasks n_ext_tasks_.v
+#define next_ext_task next_ext_task_.v
+#define n_ext_heavy n_ext_heavy_.v
+#define next_ext_heavy next_ext_heavy_.v
 #define next_seedsw next_seedsw_.v
 #define next_chain next_chain_.v
 #define next_dedup next_dedup_.v
@@ -187,9 +192,14 @@ struct Batch {
 	i32 *vr_ovf;                    // tasks to be redone on full-size interval stacks (n_vr_ovf of them)
 	int vr_ovf_run, vr_room;        // this launch: 1 = redo the tasks of vr_ovf; interval-stack entries a lane may hold before its task counts as overflowed
 	i32 *intv_n3;                   // per read: the entries pass 3 (k_seed3, run first) left at the head of its interval list
+	int seed_w_err;            // what a seed-length stretch without occurrences (a read error) adds to k_seed3's weight of the read (option seed_w_err)
 	int seed_prio;             // waves holding the heaviest 3 % of k_seed's reads run at raised issue priority (option seed_prio = 0 turns it off)
 	int seed_pass3_inline;     // A/B switch (option seed_pass3_inline = 1): pass 3 inside k_seed's state machine as in round 1, instead of k_seed3
 	int chain_lds_off;         // test hook (option chain_lds = 0): the LDS tiers defer every read
+	// --- chain-parallel extension of reads with many chains (k_extend_chains / k_extend_merge, option ext_par)
+	int ext_par_min;           // reads with at least this many kept chains take that route (0: none do)
+	i64 *ext_tasks; long long ext_task_cap;   // (read << 32 | chain), filled by k_extend_wave; -1 = no-op
+	i32 *ext_heavy;            // the reads whose chains are in the task list
 	// --- B-tree nodes
 	i64 *node_off;             // per read
 	i32 *nodes; i64 node_cap;  // 21 ints per node

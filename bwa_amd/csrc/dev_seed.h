@@ -799,7 +799,11 @@ template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k
 			if (MRG && BLK == 1) ;
 			else if (!blocks) { ptab_load(ix, tl, L.code, ok); ++ntab; }
 			else nblk += fm_extend1<BLK>(ix, L.ik, cb, 0, ok);
-			if (tl == opt.min_seed_len) weight += (u32)(ok.x2 > 65535 ? 65535 : ok.x2);   // occurrences of the seed-length match: the read's repetitiveness
+			// occurrences of the seed-length match: the read's repetitiveness -- and a seed-length stretch that occurs nowhere is a read error, i.e. one more
+			// search of pass 1 (~200 iterations of k_seed): k_seed draws its reads heaviest first so that the LAST ones drawn are the cheapest and most
+			// alike (error-free, unique: one search), because when the pool runs dry every wave waits for its slowest lane (measured at 1 M reads:
+			// 40 % of k_seed's lane-slots were lanes out of reads, profiles/r04_seed_lane_slots.md)
+			if (tl == opt.min_seed_len) weight += ok.x2 == 0 ? (u32)B.seed_w_err : (u32)(ok.x2 > 65535 ? 65535 : ok.x2);
 			if (ok.x2 < opt.max_mem_intv && L.i - L.sx >= opt.min_seed_len) {
 				if (ok.x2 > 0) L.em.add(ok.x0, ok.x2, L.sx, L.i + 1);
 				L.x = L.i + 1; st = T_START;
