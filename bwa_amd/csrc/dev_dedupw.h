@@ -227,7 +227,8 @@ template <bool BLK = false> __device__ void dedup_read_wave(const DevIndex &ix, 
 	if (n > 1) {
 		wave_sync();
 		if (lane == 0) {
-			dev_introsort(a, n, RegEndLess());
+			RegKey *keys = n >= DEDUP_KEYSORT_MIN ? (RegKey*)region_of(B.slot_blob, B.seed_off[r], B.seed_n[r]).chain : nullptr;     // (see dev_sort_regs_by_key)
+			if (keys) dev_sort_regs_by_key(a, n, keys, true, KeyEndLess()); else dev_introsort(a, n, RegEndLess());
 			for (int i = 0; i < n; ++i) a[i].n_comp = 1;
 		}
 		wave_sync();
@@ -274,7 +275,7 @@ template <bool BLK = false> __device__ void dedup_read_wave(const DevIndex &ix, 
 			int m = 0;
 			for (int i = 0; i < n; ++i) if (a[i].qe > a[i].qb) { if (m != i) a[m] = a[i]; ++m; }
 			n = m;
-			dev_introsort(a, n, RegBestLess());
+			if (n >= DEDUP_KEYSORT_MIN) dev_sort_regs_by_key(a, n, (RegKey*)region_of(B.slot_blob, B.seed_off[r], B.seed_n[r]).chain, false, KeyBestLess()); else dev_introsort(a, n, RegBestLess());
 			for (int i = 1; i < n; ++i)
 				if (a[i].score == a[i - 1].score && a[i].rb == a[i - 1].rb && a[i].qb == a[i - 1].qb) a[i].qe = a[i].qb;
 			m = n > 0 ? 1 : 0;
