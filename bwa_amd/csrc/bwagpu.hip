@@ -648,6 +648,15 @@ extern "C" int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16])
 	return BWAGPU_OK;
 }
 
+// ... and the histogram of k_seed's iterations per read (stats runs): out[b] = reads that took [2^(b-1), 2^b) iterations, out[32 + b] = their iterations summed
+extern "C" int bwagpu_debug_hist(bwagpu_t *h, unsigned long long out[64])
+{
+	if (!h || !out || !h->d_ctr.p) return BWAGPU_EINVAL;
+	Counters c;
+	if (hipMemcpy(&c, h->d_ctr.p, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return BWAGPU_EHIP;
+	for (int i = 0; i < 64; ++i) out[i] = c.seed_hist[i];
+	return BWAGPU_OK;
+}
 extern "C" int bwagpu_set_stats(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->stats_on = enable ? 1 : 0; return BWAGPU_OK; }
 extern "C" int bwagpu_set_cigar_filter(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->cigar_filter = enable ? 1 : 0; return BWAGPU_OK; }
 extern "C" int bwagpu_set_taps(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->taps_on = enable ? 1 : 0; return BWAGPU_OK; }

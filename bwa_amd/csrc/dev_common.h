@@ -104,6 +104,7 @@ struct Counters {          // device-side bump allocators + flags
 	unsigned long long prof[16];                   // diagnostics (bwagpu_debug_prof): k_seed's stats instance: [2] lane-slots of lanes out of reads, [3] of lanes waiting in a bookkeeping state, [4] of lanes running it, [5] sum over waves of the iteration at which the first lane ran out of reads, [6] iterations of the longest wave, [7] waves that did any work; [9] read windows k_seed fetched a step ahead (MRG 2, reads without an LDS copy), [10] k_seed lane steps that take an interval-stack entry from HBM scratch, [11] those served by an entry fetched a step ahead (MRG 2), [12] k_seed iterations that read the interval stack from HBM, [13..15] its wave iterations, bookkeeping iterations, extending lanes (stats runs)
 	unsigned long long ext_fast;                   // ksw_extend2 calls answered by the diagonal rule (no DP)
 	unsigned long long bt_nodes, chain_recs;       // B-tree nodes visited by look-ups / chain records touched (k_chain's algorithmic bytes)
+	unsigned long long seed_hist[64];              // k_seed's stats instance: reads by floor(log2(iterations spent on the read)) + 1, then the iterations summed per bin (bwagpu_debug_hist)
 	unsigned long long cigl_plan[2];               // k_cigar_long_plan: regions left to the long CIGAR tier, bytes of the largest direction matrix among them
 };
 #define seed_used seed_used_.v

@@ -384,6 +384,30 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 	return r;
 }
 
+// minimum / maximum of a 64-bit value over the wave (every lane receives it)
+DEVFN i64 wave_min_i64(i64 v) { for (int o = 32; o > 0; o >>= 1) { const int lo = __shfl_xor((int)(u32)(u64)v, o), hi = __shfl_xor((int)(u32)((u64)v >> 32), o); const i64 t = (i64)((u64)(u32)hi << 32 | (u32)lo); v = t < v ? t : v; } return v; }
+DEVFN i64 wave_max_i64(i64 v) { for (int o = 32; o > 0; o >>= 1) { const int lo = __shfl_xor((int)(u32)(u64)v, o), hi = __shfl_xor((int)(u32)((u64)v >> 32), o); const i64 t = (i64)((u64)(u32)hi << 32 | (u32)lo); v = t > v ? t : v; } return v; }
+
+// Ascending sort of n DISTINCT 64-bit keys by the whole wave: a bitonic network in its all-ascending form (the first step of every merge stage
+// pairs i with i ^ (2k - 1), the others i with i ^ j), so that positions past n behave as +infinity and pairs reaching there are skipped.  For
+// mem_chain2aln's seed order (bwamem.c:684-685: score << 32 | index, unique keys) any correct sort gives what ks_introsort gives; one lane's
+// introsort of a long read's ~2500 keys in global memory was tens of milliseconds per chain.
+DEVFN void wave_sort_u64(u64 *a, int n)
+{
+	const int lane = threadIdx.x & 63;
+	int N = 1; while (N < n) N <<= 1;
+	for (int k = 2; k <= N; k <<= 1) {
+		for (int j = k >> 1; j > 0; j >>= 1) {
+			const int mask = j == (k >> 1) ? k - 1 : j;
+			for (int i = lane; i < n; i += 64) {
+				const int p = i ^ mask;
+				if (p > i && p < n) { const u64 x = a[i], y = a[p]; if (x > y) { a[i] = y; a[p] = x; } }
+			}
+			wave_sync();
+		}
+	}
+}
+
 // "is the seed already covered by an earlier alignment of this read?" (bwamem.c:697-713) is an existence query -- the reference only uses
 // whether its scan stopped early -- so 64 earlier regions are tested per step
 DEVFN bool wave_seed_covered(const bwagpu_opt_t &opt, const bwagpu_seed_t &s, int l_query, const bwagpu_alnreg_t *av, int n_av)
@@ -421,13 +445,14 @@ template <bool RING, bool SPEC> __device__ void ext_chain_wave(const DevIndex &i
 	const int lane = threadIdx.x & 63;
 	const i64 l_pac = ix.l_pac;
 	i64 rmax0 = l_pac << 1, rmax1 = 0;
-	for (int i = 0; i < n; ++i) {
-		bwagpu_seed_t t = uni_seed(seeds[i]);
+	for (int i = lane; i < n; i += 64) {      // (bwamem.c:671-678: the chain's reference window; lanes stride over the seeds -- a long read's chain has thousands)
+		const bwagpu_seed_t t = seeds[i];
 		i64 b = t.rbeg - (t.qbeg + dev_max_gap(opt, t.qbeg));
 		i64 e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + dev_max_gap(opt, l_query - t.qbeg - t.len));
 		if (b < rmax0) rmax0 = b;
 		if (e > rmax1) rmax1 = e;
 	}
+	rmax0 = wave_min_i64(rmax0); rmax1 = wave_max_i64(rmax1);
 	if (rmax0 < 0) rmax0 = 0;
 	if (rmax1 > l_pac << 1) rmax1 = l_pac << 1;
 	if (rmax0 < l_pac && l_pac < rmax1) { if (seeds[0].rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac; }
@@ -440,16 +465,42 @@ template <bool RING, bool SPEC> __device__ void ext_chain_wave(const DevIndex &i
 	}
 	rmax0 = uni64(rmax0); rmax1 = uni64(rmax1);
 	n_refb += (u64)(rmax1 - rmax0);
-	if (lane == 0) {
-		for (int i = 0; i < n; ++i) srt[i] = (u64)seeds[i].score << 32 | (u32)i;
-		dev_introsort(srt, n, U64Less());
+	// the seeds by score (bwamem.c:684-685): keys score << 32 | index are distinct, so the order is the keys' own whatever sorts them
+	if (n <= 32) {
+		if (lane == 0) {
+			for (int i = 0; i < n; ++i) srt[i] = (u64)seeds[i].score << 32 | (u32)i;
+			dev_introsort(srt, n, U64Less());
+		}
+		wave_sync();
+	} else {
+		for (int i = lane; i < n; i += 64) srt[i] = (u64)seeds[i].score << 32 | (u32)i;
+		wave_sync();
+		wave_sort_u64(srt, n);
 	}
-	wave_sync();
+	// The seeds of this chain extended so far (not skipped: srt[] != 0 among the entries behind k), KS * 64 of them in registers, lane by lane.
+	// The "other diagonal" rule below asks whether ANY of them overlaps the seed at hand: the reference walks srt[k+1 .. n) and skips the
+	// zeroed entries (bwamem.c:716-717) -- for a long read's chain of ~2500 seeds, nearly all of them skipped, that walk was n^2 / 64 steps
+	// of two dependent global loads each, most of the long-read kernel's time; the extended ones are a handful.  More than KS * 64 of them: the
+	// chain falls back to the walk (srt[] is kept up to date for that).
+	constexpr int KS = RING ? 2 : 1;
+	int kq[KS], kl[KS]; i64 kr[KS]; int n_kept = 0; bool walk = false;
+	#pragma unroll
+	for (int t_ = 0; t_ < KS; ++t_) { kq[t_] = 0; kl[t_] = 0; kr[t_] = 0; }
 	for (int k = n - 1; k >= 0; --k) {
 		bwagpu_seed_t s = uni_seed(seeds[(u32)srt[k]]);
 		const bool covered = wave_seed_covered(opt, s, l_query, av, n_av);
 		if (covered) {   // extend anyway only if an overlapping seed sits on another diagonal (bwamem.c:714-732): also an existence query
 			bool other = false;
+			if (!walk) {
+				bool hit = false;
+				#pragma unroll
+				for (int t_ = 0; t_ < KS; ++t_)
+					if (t_ * 64 + lane < n_kept && !(kl[t_] < s.len * .95)) {
+						if (s.qbeg <= kq[t_] && s.qbeg + s.len - kq[t_] >= s.len >> 2 && kq[t_] - s.qbeg != kr[t_] - s.rbeg) hit = true;
+						else if (kq[t_] <= s.qbeg && kq[t_] + kl[t_] - s.qbeg >= s.len >> 2 && s.qbeg - kq[t_] != s.rbeg - kr[t_]) hit = true;
+					}
+				other = __ballot(hit) != 0;
+			} else
 			for (int base = k + 1; base < n && !other; base += 64) {
 				const int i = base + lane;
 				bool hit = false;
@@ -463,11 +514,18 @@ template <bool RING, bool SPEC> __device__ void ext_chain_wave(const DevIndex &i
 				other = __ballot(hit) != 0;
 			}
 			if (!other) {
-				wave_sync();                       // every lane has finished reading srt[k..] before it is modified
+				if (walk) wave_sync();             // every lane has finished reading srt[k..] before it is modified
 				if (lane == 0) srt[k] = 0;
-				wave_sync();
+				if (walk) wave_sync();
 				continue;
 			}
+		}
+		if (!walk) {       // this seed is extended: it joins the list (its srt[] entry stays non-zero)
+			if (n_kept < KS * 64) {
+				#pragma unroll
+				for (int t_ = 0; t_ < KS; ++t_) if (n_kept == t_ * 64 + lane) { kq[t_] = s.qbeg; kl[t_] = s.len; kr[t_] = s.rbeg; }
+				++n_kept;
+			} else { walk = true; wave_sync(); }       // (lane 0's zero stores so far are visible to the walks from here on)
 		}
 		bwagpu_alnreg_t a;
 		a.rb = a.re = 0; a.qb = a.qe = 0; a.rid = c.rid; a.score = a.truesc = -1; a.sub = a.alt_sc = a.csub = a.sub_n = 0;

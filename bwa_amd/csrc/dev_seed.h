@@ -471,6 +471,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	int deferred = 0;
 	u32 n_iter = 0, n_slow = 0, n_ext_lanes = 0, n_deep = 0, n_deep_l = 0, n_pf_l = 0, n_win_l = 0;
 	u32 n_done_l = 0, n_wait_l = 0, n_slowrun_l = 0, n_first_done = 0;      // STATS: where the lane-slots that do not extend go (prof[2..7])
+	u32 my_iter = 0;                                                        // STATS: iterations this lane has spent on its current read (Counters::seed_hist)
 	// MRG == 2: the stack entry this lane's next backward step will read, fetched a step ahead (pf.w != 0: valid -- an entry's `info`, its
 	// match's end position >= 1, sits in the top half of w).  A backward step that is not the last of its row is always followed by the
 	// step for entry j + 1 of the same row, and the steps in between write survivors at depths <= j only (SeedStack::store).
@@ -492,6 +493,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 			run_slow = __popcll(sm) >= 8 || sm == am || ++deferred >= 3;
 		}
 		if (STATS) {
+			if (L.st != SS_DONE && L.st != SS_FETCH) ++my_iter;
 			const u64 dm = __ballot(L.st == SS_DONE);
 			n_done_l += (u32)__popcll(dm);
 			if (dm && n_first_done == 0) n_first_done = n_iter;
@@ -500,6 +502,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 		if (run_slow) {
 			deferred = 0; if (STATS) ++n_slow;
 			if (L.st == SS_FINAL) {
+				if (STATS && LR == 0) { const int bin = my_iter ? 32 - __clz((int)my_iter) : 0; atomicAdd(&B.ctr->seed_hist[bin & 31], 1ull); atomicAdd(&B.ctr->seed_hist[32 + (bin & 31)], (unsigned long long)my_iter); my_iter = 0; }
 				if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull);
 				else if (LR != 1) B.intv_n[L.em.r] = L.em.n;       // (tasks counted their entries as they went)
 				L.st = SS_FETCH;

@@ -203,6 +203,9 @@ int bwagpu_debug_phase(const bwagpu_t *h);
 /* Diagnostics: sixteen event counters of the last batch_run; with stats on, [13..15] = wave iterations of the seeding kernel, those that
  * ran its bookkeeping code, and the lanes extending summed over iterations (tools/seed_iter_probe.py). */
 int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16]);
+/* Diagnostics (stats on): the seeding kernel's iterations per read as a histogram -- out[b] = reads that took [2^(b-1), 2^b) wave iterations,
+ * out[32 + b] = their iterations summed (tools/seed_iter_probe.py). */
+int bwagpu_debug_hist(bwagpu_t *h, unsigned long long out[64]);
 
 /* ---- differential tests of the device DP routines ----------------------------------------------------------------------- */
 /* One case of bwagpu_debug_dp.  Sequences are nt4 codes in the call's `seqs` array: the query may hold 0..4, the target 0..3 (the

@@ -49,6 +49,10 @@ def main():
                 if m2:
                     print("[e2e]    " + m2.group(0), flush=True)
                 steps = re.findall(r"upload ([\d.]+) run ([\d.]+) download\+cigars ([\d.]+) pestat\+matesw ([\d.]+) s", p.stderr)
+                after = re.findall(r"after the hot path, ms: pack ([\d.]+) download copy ([\d.]+) cigar kernels ([\d.]+) cigar copies ([\d.]+)", p.stderr)
+                if after:
+                    print("[e2e]    after the hot path (ms per batch, HIP events, mean of %d): pack %.1f, download copy %.1f, CIGAR kernels %.1f, CIGAR copies %.1f" %
+                          ((len(after),) + tuple(sum(float(x[i]) for x in after) / len(after) for i in range(4))), flush=True)
                 if steps:
                     k = len(steps)
                     print("[e2e]    device stage per batch (ms, mean of %d): upload %.1f, hot path %.1f, download + CIGARs %.1f, pestat + mate rescue %.1f" %
