@@ -999,7 +999,11 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_seed3+k_seed", hipGetErrorString(e_)); }
 		if (long_batch && pick(cfg.publish_blk, 1))    // long reads: one workgroup per read sorts, counts and expands (167 -> 47 ms per 6000 x 10 kb reads, BENCH_r03 variants)
-			hipLaunchKernelGGL(k_publish_blk, dim3((unsigned)(n < (int)grid.x ? (n > 0 ? n : 1) : (int)grid.x)), block, 0, h->stream, *opt, B);
+		{
+			size_t pb = h->d_tmp_intv.cap / ((size_t)PUB_MAX * sizeof(Intv3));      // workgroups the spill area has scratch for (PUB_MAX records each)
+			if (pb > 2048) pb = 2048; if (pb > (size_t)n) pb = (size_t)n; if (pb < 1) pb = 1;
+			hipLaunchKernelGGL(k_publish_blk, dim3((unsigned)pb), block, 0, h->stream, *opt, B);
+		}
 		else {
 			hipLaunchKernelGGL(k_publish, grid, block, 0, h->stream, *opt, B);
 			hipLaunchKernelGGL(k_expand, grid, block, 0, h->stream, *opt, B);

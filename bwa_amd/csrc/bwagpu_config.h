@@ -44,7 +44,7 @@
 	X(cig_tiers,         2)    /* CIGAR stage: LDS tiers to run (diagnostics)                                                                           */ \
 	X(cig_ops_cap,       0)    /* CIGAR stage: entries of the operation array (0: from the batch; test hook: forces the second attempt)                 */ \
 	X(cig_long,          1)    /* CIGAR stage: the long-segment tier (k_cigar_long)                                                                     */ \
-	X(cigl_mib,          16384)/* CIGAR stage: scratch budget of that tier in MiB                                                                       */ \
+	X(cigl_mib,          32768)/* CIGAR stage: scratch budget of that tier in MiB (32 GiB: 1024 direction matrices of a 10 kb read's widest band)                                                                      */ \
 	X(cig_trace,         0)    /* CIGAR stage: print the launches' times (waits for the stream after each)                                              */ \
 	X(debug_sync,        0)    /* wait and report after every stage of bwagpu_batch_run                                                                 */ \
 	X(pinned_results,    1)    /* PROCESS-WIDE (the result pool is shared by all handles): large results in pooled page-locked blocks (0: plain malloc)  */ \

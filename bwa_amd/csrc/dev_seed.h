@@ -315,7 +315,8 @@ __global__ void __launch_bounds__(256) k_publish(bwagpu_opt_t opt, Batch B)
 // a floor, not a rate.  Here the keys are sorted in LDS (bitonic network over {info, index}; equal keys are identical intervals, so any
 // sorting order gives the reference's result), the records are permuted through the block's share of the seeding scratch area, the slot
 // counts are a block reduction and every interval writes its SA rows from its own prefix sum.  A read with more than PUB_MAX intervals
-// takes the serial path inside this kernel.
+// takes the serial path inside this kernel.  (Round 3 launched it with one workgroup per 256 lanes of the lane-per-read seeding kernel -- 24 workgroups
+// for a 6000-read batch, 48 ms; it needs 96 KB of scratch per workgroup, not a seeding block's 80 MB: up to 2048 workgroups now.)
 #define PUB_MAX 4096
 __global__ void __launch_bounds__(256) k_publish_blk(bwagpu_opt_t opt, Batch B)
 {
@@ -324,9 +325,8 @@ __global__ void __launch_bounds__(256) k_publish_blk(bwagpu_opt_t opt, Batch B)
 	__shared__ u32 s_part[256];
 	__shared__ u64 s_bcast[2];
 	const int tid = threadIdx.x;
-	const int cap = B.max_len + 1 + PTAB_MAX;
-	Intv3 *tmp = (Intv3*)(B.tmp_intv + (size_t)blockIdx.x * blockDim.x * (size_t)cap);       // this block's lanes' interval stacks: free since k_seed ended
-	const size_t tmp_recs = (size_t)blockDim.x * (size_t)cap * sizeof(BiIntv) / sizeof(Intv3);
+	Intv3 *tmp = (Intv3*)B.tmp_intv + (size_t)blockIdx.x * PUB_MAX;       // PUB_MAX records of the seeding kernels' spill area (free since k_seed ended) per workgroup: the launch is sized for that
+	const size_t tmp_recs = PUB_MAX;
 	u64 nintv = 0;
 	for (int r = blockIdx.x; r < B.n_reads; r += gridDim.x) {
 		const int n = B.intv_n[r];

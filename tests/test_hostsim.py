@@ -482,10 +482,11 @@ def test_hostsim_long_segment_cigars(sim, monkeypatch):
     assert hostapi.decode_cigars(cigs, ops) == hostapi.decode_cigars(want, want_ops), "device records differ from the host's"
     ok = regs["score"] >= opt.T
     assert (cigs["n_cigar"][ok] > 64).sum() >= 2 and (cigs["n_cigar"][ok] >= 0).all(), cigs["n_cigar"]
+    budget = sim.get_option("cigl_mib")
     sim.set_option("cigl_mib", 0)       # a scratch budget below one direction matrix: one workgroup takes the tier's whole work list
     cigs1, ops1 = sim.cigars(opt), sim.cigar_ops()
     assert hostapi.decode_cigars(cigs1, ops1) == hostapi.decode_cigars(cigs, ops)
-    sim.set_option("cigl_mib", 16384)
+    sim.set_option("cigl_mib", budget)
     names = [f"q{i}" for i in range(off.shape[0] - 1)]
     quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
     assert host.regs2sam(opt, names, seqs, quals, off, counts, regs, cigs=cigs, cig_ops=ops) == host.regs2sam(opt, names, seqs, quals, off, counts, regs)
