@@ -85,7 +85,6 @@ struct bwagpu_s {
 	i64 cigl_z_cap = 0;                          // bytes per direction matrix of the long CIGAR tier's scratch (grows with the batches)
 	DevBuf d_cigl_z, d_cigl_ops, d_cigl_md, d_cigl_list;      // scratch of the long-segment CIGAR tier (k_cigar_long): direction matrices, operations, MD strings per workgroup
 	DevBuf d_cig_ext; i64 cig_ext_n = -1;   // operation array of the last bwagpu_batch_cigars (records with 7..64 operations point into it)
-	DevBuf d_ext_tasks, d_ext_heavy;        // chain-parallel extension of heavy reads: (read, chain) tasks and the reads they belong to
 	DevBuf d_vr_tab, d_vr_ovf, d_intv_n3;   // pass 1 of long-read batches as tasks (k_seed<LR>): the reads' first tasks, the list of tasks to redo on full-size stacks, pass 3's entries per read
 	DevBuf d_seq_2b, d_seq_flags; int rd_words = 0;   // per-read 2-bit copies for k_seed's LDS (k_pack_reads2b)
 	DevBuf d_pack_off, d_regs_packed, d_pack_read, d_cigs, d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
@@ -448,7 +447,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 		for (DevBuf *b : ib) b->release();
 		delete h->ibuf;
 	}
-	DevBuf *all[] = { &h->d_ext_tasks, &h->d_ext_heavy, &h->d_vr_tab, &h->d_vr_ovf, &h->d_intv_n3, &h->d_cigl_list, &h->d_cigl_z, &h->d_cigl_ops, &h->d_cigl_md, &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
+	DevBuf *all[] = { &h->d_vr_tab, &h->d_vr_ovf, &h->d_intv_n3, &h->d_cigl_list, &h->d_cigl_z, &h->d_cigl_ops, &h->d_cigl_md, &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_chain_todo, &h->d_seed_w, &h->d_seed_order, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
@@ -649,12 +648,13 @@ extern "C" int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16])
 }
 
 // ... and the histogram of k_seed's iterations per read (stats runs): out[b] = reads that took [2^(b-1), 2^b) iterations, out[32 + b] = their iterations summed
-extern "C" int bwagpu_debug_hist(bwagpu_t *h, unsigned long long out[64])
+extern "C" int bwagpu_debug_hist(bwagpu_t *h, unsigned long long out[256])
 {
 	if (!h || !out || !h->d_ctr.p) return BWAGPU_EINVAL;
 	Counters c;
 	if (hipMemcpy(&c, h->d_ctr.p, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return BWAGPU_EHIP;
 	for (int i = 0; i < 64; ++i) out[i] = c.seed_hist[i];
+	for (int i = 0; i < 96; ++i) { out[64 + i] = c.wave_hist[0][i]; out[160 + i] = c.wave_hist[1][i]; }
 	return BWAGPU_OK;
 }
 extern "C" int bwagpu_set_stats(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->stats_on = enable ? 1 : 0; return BWAGPU_OK; }
@@ -823,7 +823,6 @@ static int alloc_batch(bwagpu_t *h, int n_threads, int seed_lanes)
 	bad |= h->d_dp_h.ensure((size_t)n_waves * (h->max_len + 2) * DPS * 4);
 	bad |= h->d_dp_e.ensure((size_t)n_waves * (h->max_len + 2) * DPS * 4);
 	bad |= h->d_minhsp.ensure((size_t)(h->max_len + 2) * 4);
-	bad |= h->d_ext_tasks.ensure(((size_t)n * 4 + 65536) * 8); bad |= h->d_ext_heavy.ensure((size_t)n * 4 + 16);
 	bad |= h->d_order.ensure((size_t)n * 4 + 16); bad |= h->d_bin_cnt.ensure(2 * ORDER_BINS * 4); bad |= h->d_chain_todo.ensure((size_t)n * 8 + 32); bad |= h->d_seed_w.ensure((size_t)n * 4 + 16); bad |= h->d_seed_order.ensure((size_t)n * 4 + 16);
 	if (bad) { h->err = "hipMalloc failed (batch arenas)"; return BWAGPU_ENOMEM; }
 	return 0;
@@ -936,10 +935,6 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.regs_raw = h->taps_on ? h->d_regs_raw.as<bwagpu_alnreg_t>() : nullptr;
 		B.dp_h = h->d_dp_h.as<i32>(); B.dp_e = h->d_dp_e.as<i32>(); B.dp_waves = dp_wave_count(h, n_threads);
 		B.seedsw_minhsp = h->d_minhsp.as<i32>();
-		// reads with many chains are extended chain-parallel (k_extend_chains + k_extend_merge, dev_extw.h): from 16 chains for short reads (a
-		// chain there is a couple of ~60-row extensions: below that the detour costs what it saves), from 3 for long reads (a chain is millions of cells)
-		B.ext_par_min = (int)(cfg.ext_par >= 0 ? cfg.ext_par : (long_batch ? 3 : 16));
-		B.ext_tasks = h->d_ext_tasks.as<i64>(); B.ext_task_cap = (long long)n * 4 + 65536; B.ext_heavy = h->d_ext_heavy.as<i32>();
 		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>(); B.chain_todo = h->d_chain_todo.as<i32>(); B.chain_todo2 = B.chain_todo + n + 4; B.seed_w = h->d_seed_w.as<i32>(); B.seed_order = nullptr;
 		B.seed_prio = cfg.seed_prio != 0;
 		B.seed_w_err = (int)cfg.seed_w_err;
@@ -1052,20 +1047,12 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			if (occ == 5) hipLaunchKernelGGL((k_extend_wave<false, 5>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
 			else if (occ == 4) hipLaunchKernelGGL((k_extend_wave<false, 4>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
 			else hipLaunchKernelGGL((k_extend_wave<false, 6>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
-			if (B.ext_par_min > 0) {     // the heavy reads' chains, then their replay (the lists are known on the device only: grids for a full chip, or for every read of a small batch)
-				hipLaunchKernelGGL((k_extend_chains<false, 6>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
-				hipLaunchKernelGGL((k_extend_merge<false, 6>), dim3(g.x < 256 ? g.x : 256), block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
-			}
 		} else if (max_score < (1 << 24) && ring_cols <= 2048) {
 			// the band's columns only: independent of the read length
 			const int lds_wave = 8 * ring_cols + 32;
 			int wpb = 4; while (wpb > 1 && lds_wave * wpb > 65536) wpb >>= 1;
 			i64 nblk = ((i64)n + wpb - 1) / wpb, cap = 256 * 8 * (4 / wpb);
 			hipLaunchKernelGGL((k_extend_wave<true, 4>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, lds_wave, ring_cols);
-			if (B.ext_par_min > 0) {
-				hipLaunchKernelGGL((k_extend_chains<true, 4>), dim3((unsigned)cap), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, lds_wave, ring_cols);
-				hipLaunchKernelGGL((k_extend_merge<true, 4>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, lds_wave, ring_cols);
-			}
 		} else                                  // very wide bands: lane-per-read scalar DP with the columns in HBM scratch
 			hipLaunchKernelGGL(k_extend, grid, block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[5], h->stream));

@@ -30,14 +30,13 @@
 	X(seed_lds_ent,      -1)   /* seeding: interval-stack entries per lane kept in LDS; auto: 10, or what the read copy leaves                          */ \
 	X(seed_rd_lds,       1)    /* seeding: short reads copied to LDS at 2 bits per base                                                                 */ \
 	X(seed_no_virt,      0)    /* seeding: keep matches shorter than the prefix tables' depth in the stack too (diagnostics)                            */ \
-	X(seed_w_err,        512)  /* seeding: weight of a read error in the heavy-first order of k_seed's reads (0: repetitiveness alone, as in round 3)                    */ \
+	X(seed_w_err,        1)    /* seeding: k_seed's heavy-first order by 12-mer repetitiveness, then error count (0: round 3's weight, seed-length occurrences)                */ \
 	X(seed_prio,         1)    /* seeding: raised issue priority for the waves holding the heaviest reads                                               */ \
 	X(seed_input_order,  0)    /* seeding: reads in input order instead of heaviest first (diagnostics)                                                 */ \
 	X(seed_pass3_inline, 0)    /* seeding: pass 3 inside k_seed's state machine instead of k_seed3 (A/B)                                                */ \
 	X(seed_grid,         0)    /* seeding: resident workgroups of k_seed (0: fill the chip; measurements)                                               */ \
 	X(chain_lds,         1)    /* chaining: 0 = the LDS tiers defer every read to the HBM tier (test hook)                                              */ \
 	X(ext_occ,           6)    /* extension: waves per SIMD the short-read kernel's register allocation aims at (4, 5, 6)                               */ \
-	X(ext_par,           -1)   /* extension: reads with at least this many kept chains are extended chain-parallel + replayed (0: none); auto: 16 short, 3 long */ \
 	X(dedup_wave,        0)    /* 1 = the wave-per-read de-duplication kernel for short reads as well (test hook)                                       */ \
 	X(dedup_ring,        0)    /* ring columns of that kernel (0: from the batch; test hook: a power of two, 256..4096)                                 */ \
 	X(mem_cap,           0)    /* capacity of a read's interval list (0: from the batch; test hook: a small value forces the retry path)                */ \

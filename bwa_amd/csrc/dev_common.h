@@ -90,7 +90,6 @@ struct Counters {          // device-side bump allocators + flags
 	HotCounter next_vread_;               // ... and of the pass-1 tasks of long-read batches (k_seed<LR = 1>)
 	HotCounter n_vr_ovf_, next_vovf_;     // ... tasks whose interval stack outgrew the task lanes' small spill areas (redone on full-size stacks), and the work counter of that second launch
 	HotCounter next_ext_;    // work counter of the wave extension kernel (position in Batch::order)
-	HotCounter n_ext_tasks_, next_ext_task_, n_ext_heavy_, next_ext_heavy_;   // chain-parallel extension of heavy reads: entries of the task and read lists, and the work counters over them
 	HotCounter next_seedsw_; // work counter of the wave-per-read seed re-scoring kernel (long reads)
 	HotCounter next_chain_, next_dedup_;       // work counters of the chaining and de-duplication kernels
 	HotCounter next_chain_b_, n_chain_todo_;   // second tier of the wave-per-read chaining kernel: its work counter and the length of its work list
@@ -104,6 +103,7 @@ struct Counters {          // device-side bump allocators + flags
 	unsigned long long prof[16];                   // diagnostics (bwagpu_debug_prof): k_seed's stats instance: [2] lane-slots of lanes out of reads, [3] of lanes waiting in a bookkeeping state, [4] of lanes running it, [5] sum over waves of the iteration at which the first lane ran out of reads, [6] iterations of the longest wave, [7] waves that did any work; [9] read windows k_seed fetched a step ahead (MRG 2, reads without an LDS copy), [10] k_seed lane steps that take an interval-stack entry from HBM scratch, [11] those served by an entry fetched a step ahead (MRG 2), [12] k_seed iterations that read the interval stack from HBM, [13..15] its wave iterations, bookkeeping iterations, extending lanes (stats runs)
 	unsigned long long ext_fast;                   // ksw_extend2 calls answered by the diagonal rule (no DP)
 	unsigned long long bt_nodes, chain_recs;       // B-tree nodes visited by look-ups / chain records touched (k_chain's algorithmic bytes)
+	unsigned long long wave_hist[2][96];           // stats runs of k_extend_wave [0] / k_dedup_wave [1]: reads by floor(log2(time the wave spent on the read, in 10 ns units)) + 1; then, per bin, the DP calls and the DP cells (>> 10) of those reads (bwagpu_debug_hist)
 	unsigned long long seed_hist[64];              // k_seed's stats instance: reads by floor(log2(iterations spent on the read)) + 1, then the iterations summed per bin (bwagpu_debug_hist)
 	unsigned long long cigl_plan[2];               // k_cigar_long_plan: regions left to the long CIGAR tier, bytes of the largest direction matrix among them
 };
@@ -116,10 +116,6 @@ struct Counters {          // device-side bump allocators + flags
 #define n_vr_ovf n_vr_ovf_.v
 #define next_vovf next_vovf_.v
 #define next_ext next_ext_.v
-#define n_ext_tasks n_ext_tasks_.v
-#define next_ext_task next_ext_task_.v
-#define n_ext_heavy n_ext_heavy_.v
-#define next_ext_heavy next_ext_heavy_.v
 #define next_seedsw next_seedsw_.v
 #define next_chain next_chain_.v
 #define next_dedup next_dedup_.v
@@ -197,10 +193,6 @@ struct Batch {
 	int seed_prio;             // waves holding the heaviest 3 % of k_seed's reads run at raised issue priority (option seed_prio = 0 turns it off)
 	int seed_pass3_inline;     // A/B switch (option seed_pass3_inline = 1): pass 3 inside k_seed's state machine as in round 1, instead of k_seed3
 	int chain_lds_off;         // test hook (option chain_lds = 0): the LDS tiers defer every read
-	// --- chain-parallel extension of reads with many chains (k_extend_chains / k_extend_merge, option ext_par)
-	int ext_par_min;           // reads with at least this many kept chains take that route (0: none do)
-	i64 *ext_tasks; long long ext_task_cap;   // (read << 32 | chain), filled by k_extend_wave; -1 = no-op
-	i32 *ext_heavy;            // the reads whose chains are in the task list
 	// --- B-tree nodes
 	i64 *node_off;             // per read
 	i32 *nodes; i64 node_cap;  // 21 ints per node

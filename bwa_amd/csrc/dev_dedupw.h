@@ -316,7 +316,13 @@ template <bool BLK = false> __global__ void __launch_bounds__(256) k_dedup_wave(
 		const long long k = wave_fetch(&B.ctr->next_dedup);
 		if (k >= B.n_reads) break;
 		const int r = (int)k;
+		const long long t_0 = B.stats ? wall_clock64() : 0; const u64 c_0 = calls, x_0 = cells;
 		dedup_read_wave<BLK>(ix, opt, B, r, L, calls, cells);
+		if (B.stats && lane == 0) {
+			const long long dt = wall_clock64() - t_0;
+			const int bin = dt > 0 ? (64 - __clzll(dt) < 31 ? 64 - __clzll(dt) : 31) : 0;
+			atomicAdd(&B.ctr->wave_hist[1][bin], 1ull); atomicAdd(&B.ctr->wave_hist[1][32 + bin], (unsigned long long)(calls - c_0)); atomicAdd(&B.ctr->wave_hist[1][64 + bin], (unsigned long long)((cells - x_0) >> 10));
+		}
 		nreg += B.reg_n[r];
 	}
 	if (B.stats && lane == 0) {

@@ -437,8 +437,11 @@ DEVFN bool wave_seed_covered(const bwagpu_opt_t &opt, const bwagpu_seed_t &s, in
 }
 
 // mem_chain2aln (bwamem.c:658-812) for ONE chain of a read: regions are appended at av[n_av ..]; "is the seed already covered" is asked of av[0 .. n_av).
-// SPEC: the chain is extended ahead of its turn (ext_chain_task), with only its own regions before it -- see k_extend_chains.
-template <bool RING, bool SPEC> __device__ void ext_chain_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const WaveLds &L, const u8 *query, int l_query, int mat_max,
+// (Round 4 also extended the chains of reads with many chains by a wave each, ahead of their turn, and replayed the order-dependent decisions over
+// the results -- exact, tested, and a loss on hardware: for 1 M short reads the kernel is throughput-bound (49.6 ms without, 55-61 ms with the two
+// extra launches and the serial replay of the 640-chain read), and the long-read kernel's slow reads have ONE chain with many extended seeds
+// (348 ms without, 800 ms with: profiles/r04_chain_parallel_*.jsonl).  Deleted; what stayed are the wave-parallel forms of the chain's serial steps.)
+template <bool RING> __device__ void ext_chain_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const WaveLds &L, const u8 *query, int l_query, int mat_max,
 															   const bwagpu_chain_t &c, const bwagpu_seed_t *seeds, u64 *srt, int n, bwagpu_alnreg_t *av, int &n_av,
 															   u64 &n_calls, u64 &n_cells, u64 &n_refb, u64 &n_fast)
 {
@@ -571,7 +574,6 @@ template <bool RING, bool SPEC> __device__ void ext_chain_wave(const DevIndex &i
 		a.w = aw0 > aw1 ? aw0 : aw1;
 		a.seedlen0 = s.len;
 		a.frac_rep = c.frac_rep;
-		if (SPEC) a.hash = (u64)(covered ? 1u : 0u) << 32 | (u32)srt[k];     // (stashed for the replay, which puts the field back to 0: which seed this is, and whether it was extended although covered)
 		if (lane == 0) av[n_av] = a;
 		++n_av;
 		wave_sync();
@@ -586,20 +588,6 @@ template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwa
 	r = uni(r);
 	int n_ch = uni(B.chain_n[r]);
 	if (n_ch == 0) { if (lane == 0) B.reg_n_raw[r] = 0; return; }
-	if (B.ext_par_min > 0 && n_ch >= B.ext_par_min) {
-		// A read with many chains (inside a repeat family: hundreds; a long read across several loci) is a long serial job for one wave -- the
-		// kernel's tail, measured: one read of 640 chains = 48 of the short-read kernel's 50 ms, and most of the long-read kernel's 360 ms is a
-		// handful of such reads.  Its chains go to a task list instead: k_extend_chains extends every chain by a wave of its own, ahead of its
-		// turn, and k_extend_merge replays mem_chain2aln's order-dependent decisions over the results (see there).
-		const long long base = wave_fetch_n(&B.ctr->n_ext_tasks, n_ch);
-		if (base + n_ch <= B.ext_task_cap) {
-			for (int ci = lane; ci < n_ch; ci += 64) B.ext_tasks[base + ci] = (i64)r << 32 | (u32)ci;
-			const long long hb = wave_fetch(&B.ctr->n_ext_heavy);
-			if (lane == 0) { B.ext_heavy[hb] = r; B.reg_n_raw[r] = 0; }
-			return;
-		}
-		for (long long t = base + lane; t < base + n_ch && t < B.ext_task_cap; t += 64) B.ext_tasks[t] = -1;      // (the list is full: no-op entries, and the read is extended here after all)
-	}
 	const i64 qoff = uni64(B.off[r]);
 	const u8 *query = B.seq + qoff;
 	int l_query = uni((int)(B.off[r + 1] - qoff));
@@ -624,174 +612,13 @@ template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwa
 		int n = uni(c.n_seeds);
 		sbeg += n;
 		if (n == 0) continue;
-		ext_chain_wave<RING, false>(ix, opt, L, query, l_query, mat_max, c, seeds, srt, n, av, n_av, n_calls, n_cells, n_refb, n_fast);
+		ext_chain_wave<RING>(ix, opt, L, query, l_query, mat_max, c, seeds, srt, n, av, n_av, n_calls, n_cells, n_refb, n_fast);
 	}
-	if (lane == 0) B.reg_n_raw[r] = n_av;
-}
-
-// One chain of a heavy read, ahead of its turn: mem_chain2aln's loop over the chain's seeds with only the chain's own regions before it.  The
-// regions go where no other chain's can be -- a chain yields at most one region per seed, so chain ci owns av[sbeg .. sbeg + n_seeds), sbeg = the
-// seeds of the chains before it -- and their number into R.ord[ci] (the chaining stage's scratch, free by now).
-template <bool RING> __device__ void ext_chain_task(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, int ci, const WaveLds &L0,
-													u64 &n_calls, u64 &n_cells, u64 &n_refb, u64 &n_fast)
-{
-	const int lane = threadIdx.x & 63;
-	WaveLds L = L0;
-	r = uni(r); ci = uni(ci);
-	const i64 qoff = uni64(B.off[r]);
-	const u8 *query = B.seq + qoff;
-	const int l_query = uni((int)(B.off[r + 1] - qoff));
-	const RegionView R = region_of(B.slot_blob, uni64(B.seed_off[r]), uni(B.seed_n[r]));
-	int sbeg = 0;
-	for (int b = 0; b < ci; b += 64) { int v = b + lane < ci ? R.cchain[b + lane].n_seeds : 0; for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); sbeg += v; }
-	sbeg = uni(sbeg);
-	const bwagpu_chain_t c = R.cchain[ci];
-	const int n = uni(c.n_seeds);
-	int n_loc = 0;
-	if (n > 0) {
-		if (!RING) {     // the read's query profile (see ext_read_wave)
-			for (int j = lane; j < l_query; j += 64) {
-				const int qc = query[j];
-				for (int k = 0; k < 5; ++k) L.qp[k * L.qstride + j] = L.mat[k * 5 + qc];
-			}
-			wave_sync();
-		}
-		ext_chain_wave<RING, true>(ix, opt, L, query, l_query, opt_mat_max(opt), c, R.cseed + sbeg, R.srt + sbeg, n, B.regs + uni64(B.reg_off[r]) + sbeg, n_loc, n_calls, n_cells, n_refb, n_fast);
-	}
-	wave_sync();
-	if (lane == 0) R.ord[ci] = n_loc;
-}
-
-// The replay for one heavy read: chains in their order, regions packed to the front of the read's range.  What a chain's early extension
-// could not know is whether one of its seeds was already covered by a region of an EARLIER chain (bwamem.c:697-713).  Within the chain every
-// decision of the early run is the reference's as long as no such seed exists: a seed it skipped was covered by the chain's own regions and is
-// covered all the more now; a seed it extended although covered (an overlapping seed on another diagonal, :714-732) takes the same branch; a seed
-// it extended because nothing covered it is the case to check -- one existence query per region against the regions of the chains before.  The
-// extension itself (window, band, scores) depends on the seed and the chain alone.  If the query hits, the chain is extended again, in its turn,
-// by this wave (rare: two chains of one locus that chaining did not merge); it cannot overwrite a later chain's early regions, for the same
-// counting argument as above.
-template <bool RING> __device__ void ext_read_merge(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const WaveLds &L0,
-													u64 &n_calls, u64 &n_cells, u64 &n_refb, u64 &n_fast, u64 &n_redo)
-{
-	const int lane = threadIdx.x & 63;
-	WaveLds L = L0;
-	r = uni(r);
-	const int n_ch = uni(B.chain_n[r]);
-	const i64 qoff = uni64(B.off[r]);
-	const u8 *query = B.seq + qoff;
-	const int l_query = uni((int)(B.off[r + 1] - qoff));
-	const RegionView R = region_of(B.slot_blob, uni64(B.seed_off[r]), uni(B.seed_n[r]));
-	bwagpu_alnreg_t *av = B.regs + uni64(B.reg_off[r]);
-	int n_av = 0, sbeg = 0;
-	bool have_profile = false;
-	for (int ci = 0; ci < n_ch; ++ci) {
-		const bwagpu_chain_t c = R.cchain[ci];
-		const int n = uni(c.n_seeds), cnt = uni(R.ord[ci]);
-		const bwagpu_seed_t *seeds = R.cseed + sbeg;
-		const bwagpu_alnreg_t *early = av + sbeg;
-		bool redo = false;
-		for (int j = 0; j < cnt && !redo; ++j) {
-			const u64 st = (u64)uni64((i64)early[j].hash);      // (seed index | extended-although-covered << 32)
-			if (st >> 32) continue;
-			const bwagpu_seed_t s = uni_seed(seeds[(u32)st]);
-			redo = wave_seed_covered(opt, s, l_query, av, n_av);
-		}
-		if (!redo) {
-			// move the chain's regions down to av[n_av ..] (never up: n_av <= sbeg), 64 at a time; the stash goes back to 0
-			for (int j0 = 0; j0 < cnt; j0 += 64) {
-				bwagpu_alnreg_t t; const bool have = j0 + lane < cnt;
-				if (have) { t = early[j0 + lane]; t.hash = 0; }
-				wave_sync();
-				if (have) av[n_av + j0 + lane] = t;
-				wave_sync();
-			}
-			n_av += cnt;
-		} else if (n > 0) {
-			++n_redo;
-			if (!RING && !have_profile) {
-				for (int j = lane; j < l_query; j += 64) {
-					const int qc = query[j];
-					for (int k = 0; k < 5; ++k) L.qp[k * L.qstride + j] = L.mat[k * 5 + qc];
-				}
-				wave_sync();
-				have_profile = true;
-			}
-			ext_chain_wave<RING, false>(ix, opt, L, query, l_query, opt_mat_max(opt), c, seeds, R.srt + sbeg, n, av, n_av, n_calls, n_cells, n_refb, n_fast);
-		}
-		sbeg += n;
-	}
-	wave_sync();
 	if (lane == 0) B.reg_n_raw[r] = n_av;
 }
 
 // One wavefront per read, 4 waves per workgroup; dynamic LDS = 4 private regions of
 // 8*(max_len+2+64) bytes of {H,E} columns + 5*qstride bytes of query profile, or (RING, long reads) of ring_cols*8 + 32 bytes.
-template <bool RING> DEVFN WaveLds ext_wave_lds(unsigned char *dyn_lds, const bwagpu_opt_t &opt, const Batch &B, int lds_per_wave, int ring_cols)
-{
-	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	WaveLds L;
-	unsigned char *base = dyn_lds + (size_t)wave_in_blk * lds_per_wave;
-	L.eh = (int2*)base;                                      // max_len + 2 columns + 64 of read-only padding
-	if (RING) {
-		int8_t *m = (int8_t*)(base + (size_t)8 * ring_cols);
-		if (lane < 25) m[lane] = opt.mat[lane];
-		L.mat = m; L.ring_mask = ring_cols - 1; L.qp = nullptr; L.qstride = 0;
-	} else {
-		L.qstride = (B.max_len + 64 + 3) & ~3;
-		L.qp = (int8_t*)(base + (size_t)8 * (B.max_len + 2 + 64));
-		int8_t *m = L.qp + 5 * L.qstride;                  // (the scoring matrix: dynamic indexing of the kernel argument would go through scratch memory)
-		if (lane < 25) m[lane] = opt.mat[lane];
-		L.mat = m; L.ring_mask = 0;
-	}
-	wave_sync();
-	return L;
-}
-
-// The chains of the heavy reads, one wavefront each (ext_chain_task); the list was filled by k_extend_wave.
-template <bool RING, int OCC> __global__ void __launch_bounds__(256, OCC) k_extend_chains(DevIndex ix, bwagpu_opt_t opt, Batch B, int lds_per_wave, int ring_cols)
-{
-	HIP_DYNAMIC_SHARED(unsigned char, dyn_lds)
-	const int lane = threadIdx.x & 63;
-	const WaveLds L = ext_wave_lds<RING>(dyn_lds, opt, B, lds_per_wave, ring_cols);
-	long long n = (long long)B.ctr->n_ext_tasks; if (n > B.ext_task_cap) n = B.ext_task_cap;
-	u64 calls = 0, cells = 0, refb = 0, fast = 0;
-	for (;;) {
-		const long long k = wave_fetch(&B.ctr->next_ext_task);
-		if (k >= n) break;
-		const i64 t = B.ext_tasks[k];
-		if (t < 0) continue;
-		ext_chain_task<RING>(ix, opt, B, (int)(t >> 32), (int)(u32)t, L, calls, cells, refb, fast);
-		wave_sync();
-	}
-	if (B.stats && lane == 0) {
-		atomicAdd(&B.ctr->ext_calls, (unsigned long long)calls); atomicAdd(&B.ctr->ext_cells, (unsigned long long)cells);
-		atomicAdd(&B.ctr->ext_fast, (unsigned long long)fast); atomicAdd(&B.ctr->ref_bases, (unsigned long long)refb);
-	}
-}
-
-// ... and the replay of their reads (ext_read_merge), one wavefront per heavy read.
-template <bool RING, int OCC> __global__ void __launch_bounds__(256, OCC) k_extend_merge(DevIndex ix, bwagpu_opt_t opt, Batch B, int lds_per_wave, int ring_cols)
-{
-	HIP_DYNAMIC_SHARED(unsigned char, dyn_lds)
-	const int lane = threadIdx.x & 63;
-	const WaveLds L = ext_wave_lds<RING>(dyn_lds, opt, B, lds_per_wave, ring_cols);
-	const long long n = (long long)B.ctr->n_ext_heavy;
-	u64 calls = 0, cells = 0, refb = 0, fast = 0, redo = 0, nraw = 0;
-	for (;;) {
-		const long long k = wave_fetch(&B.ctr->next_ext_heavy);
-		if (k >= n) break;
-		const int r = B.ext_heavy[k];
-		ext_read_merge<RING>(ix, opt, B, r, L, calls, cells, refb, fast, redo);
-		wave_sync();
-		nraw += B.reg_n_raw[r];
-	}
-	if (B.stats && lane == 0) {
-		atomicAdd(&B.ctr->ext_calls, (unsigned long long)calls); atomicAdd(&B.ctr->ext_cells, (unsigned long long)cells);
-		atomicAdd(&B.ctr->ext_fast, (unsigned long long)fast); atomicAdd(&B.ctr->ref_bases, (unsigned long long)refb);
-		atomicAdd(&B.ctr->n_regs_raw, (unsigned long long)nraw); atomicAdd(&B.ctr->prof[1], (unsigned long long)redo);
-	}
-}
-
 template <bool RING, int OCC> __global__ void __launch_bounds__(256, OCC) k_extend_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int lds_per_wave, int ring_cols)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, dyn_lds)
@@ -819,8 +646,14 @@ template <bool RING, int OCC> __global__ void __launch_bounds__(256, OCC) k_exte
 		long long k;
 		if (!wq_next(wq, &B.ctr->next_ext, B.n_reads, k)) break;
 		const int r = B.order[k];
+		const long long t_0 = B.stats ? wall_clock64() : 0; const u64 c_0 = calls, x_0 = cells;
 		ext_read_wave<RING>(ix, opt, B, r, L, calls, cells, refb, fast);
 		wave_sync();
+		if (B.stats && lane == 0) {      // where the kernel's time goes, read by read (bwagpu_debug_hist)
+			const long long dt = wall_clock64() - t_0;
+			const int bin = dt > 0 ? (64 - __clzll(dt) < 31 ? 64 - __clzll(dt) : 31) : 0;
+			atomicAdd(&B.ctr->wave_hist[0][bin], 1ull); atomicAdd(&B.ctr->wave_hist[0][32 + bin], (unsigned long long)(calls - c_0)); atomicAdd(&B.ctr->wave_hist[0][64 + bin], (unsigned long long)((cells - x_0) >> 10));
+		}
 		nraw += B.reg_n_raw[r];
 	}
 	if (B.stats && lane == 0) {

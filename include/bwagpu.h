@@ -203,9 +203,11 @@ int bwagpu_debug_phase(const bwagpu_t *h);
 /* Diagnostics: sixteen event counters of the last batch_run; with stats on, [13..15] = wave iterations of the seeding kernel, those that
  * ran its bookkeeping code, and the lanes extending summed over iterations (tools/seed_iter_probe.py). */
 int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16]);
-/* Diagnostics (stats on): the seeding kernel's iterations per read as a histogram -- out[b] = reads that took [2^(b-1), 2^b) wave iterations,
- * out[32 + b] = their iterations summed (tools/seed_iter_probe.py). */
-int bwagpu_debug_hist(bwagpu_t *h, unsigned long long out[64]);
+/* Diagnostics (stats on): where three kernels' time goes, read by read.  out[0..64): the seeding kernel -- out[b] = reads that took [2^(b-1), 2^b)
+ * wave iterations, out[32 + b] = their iterations summed (tools/seed_iter_probe.py).  out[64..160): the wave-per-read extension kernel -- reads by
+ * the time their wave spent on them (bin b: [2^(b-1), 2^b) x 10 ns), then per bin the ksw_extend2 calls and the DP cells (>> 10) of those reads;
+ * out[160..256): the same for the wave-per-read de-duplication kernel (long reads) and its patch alignments. */
+int bwagpu_debug_hist(bwagpu_t *h, unsigned long long out[256]);
 
 /* ---- differential tests of the device DP routines ----------------------------------------------------------------------- */
 /* One case of bwagpu_debug_dp.  Sequences are nt4 codes in the call's `seqs` array: the query may hold 0..4, the target 0..3 (the

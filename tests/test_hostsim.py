@@ -652,42 +652,3 @@ def test_hostsim_long_read_four_columns_per_lane():
         st = s2.stats()
         assert st["n_glb_calls"] >= 1 and st["n_glb_cells"] > 4_000_000 and st["n_ext_cells"] > 1_000_000, st
         s2.close()
-
-
-def test_hostsim_chain_parallel_extension():
-    """Option ext_par = n: the chains of a read with at least n kept chains are extended by a wave each, ahead of their turn (k_extend_chains), and
-    mem_chain2aln's order-dependent decisions are replayed over the results (k_extend_merge): a chain whose seed turns out to be covered by an earlier
-    chain's region is extended again in its turn.  With n = 1 every read takes that route: short reads of the repeat-rich 2 Mb genome (dozens of
-    chains per read), noisy reads, 2.5 kb -x pacbio reads (ring-mode kernel; chains of one locus that chaining left apart -- the case the replay
-    exists for) -- regions before and after de-duplication equal the serial route's and the oracle's; and the replay did redo some chains."""
-    import ctypes as C
-    import refapi
-    if not refapi.have_ref():
-        pytest.skip("oracle/_ref not built (needed to index the 2 Mb genome)")
-    prefix, g = testdata.medium_index()
-    orc = orcapi.OrcIndex(prefix)
-    sets = [("short", default_opt(), testdata.flat(simdata.make_reads_se(g, 24, seed=501, sub=0.03, dele=0.004, ins=0.004))),
-            ("long", pacbio_opt(), testdata.flat(simdata.make_reads_long(g, 3, length=2500, seed=502)))]
-    o9 = default_opt(); o9.min_seed_len = 11; o9.max_occ = 60
-    sets.append(("short, -k 11 -c 60", o9, testdata.flat(simdata.make_reads_se(g, 10, seed=503, sub=0.02))))
-    redo_total = 0
-    for name, opt, (seqs, off) in sets:
-        want = orc.align(opt, seqs, off)
-        for par in (1, 0, 2):
-            s2 = sim_handle(prefix, ext_par=par)
-            s2.set_stats(True)
-            c, r = s2.align(opt, seqs, off)
-            assert_regs_equal(*want, c, r, f"{name}, ext_par {par}")
-            rc, rr = s2.tap_regs_raw()
-            if par == 0:
-                raw0 = (rc.tobytes(), rr.tobytes())
-            elif par == 1:
-                raw1 = (rc.tobytes(), rr.tobytes())
-                prof = (C.c_ulonglong * 16)()
-                s2.L.bwagpu_debug_prof.argtypes = [C.c_void_p, C.c_void_p]
-                s2.L.bwagpu_debug_prof(s2.h, prof)
-                redo_total += prof[1]
-            s2.close()
-        assert raw0 == raw1, f"{name}: regions before de-duplication differ between the serial and the chain-parallel route"
-    assert redo_total > 0, "no chain was extended again by the replay: the test's reads no longer exercise that path"
-    orc.close()

@@ -33,6 +33,13 @@ def main():
           f"seed-SW calls {w['n_sw_calls'] / a.reads:.0f} ({w['n_sw_cells'] / a.reads / 1e6:.2f} M cells), extension calls {w['n_ext_calls'] / a.reads:.1f} ({w['n_ext_cells'] / a.reads / 1e6:.2f} M cells), "
           f"patch alignments {w['n_glb_calls'] / a.reads:.1f} ({w['n_glb_cells'] / a.reads / 1e6:.2f} M cells), regions {w['n_regs_raw'] / a.reads:.1f} -> {w['n_regs'] / a.reads:.1f}; "
           "stage ms: " + ", ".join(f"{k[3:]} {w[k]:.0f}" for k in ("ms_seed", "ms_sa", "ms_chain", "ms_seedsw", "ms_extend", "ms_dedup")), flush=True)
+    import ctypes as C
+    hist = (C.c_ulonglong * 256)()
+    gpu.L.bwagpu_debug_hist.argtypes = [C.c_void_p, C.c_void_p]
+    gpu.L.bwagpu_debug_hist(gpu.h, hist)
+    for name, base in (("k_extend_wave", 64), ("k_dedup_wave", 160)):      # reads by the time their wave spent on them, with the DP calls and cells of each class
+        rows = [(b, hist[base + b], hist[base + 32 + b], hist[base + 64 + b]) for b in range(32) if hist[base + b]]
+        print(f"[longread] {name}, reads by wave time: " + "; ".join(f"<{(1 << b) / 1e5:.3g} ms: {n} reads, {c / n:.1f} DP calls and {x * 1024 / n / 1e6:.2f} M cells each" for b, n, c, x in rows), flush=True)
     gpu.set_stats(False)
     t = time.time(); gpu.run(opt); dt = time.time() - t
     st = gpu.stats()

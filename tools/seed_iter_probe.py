@@ -46,7 +46,7 @@ for cfg in (sys.argv[1:] or [""]):
               f"with bookkeeping {100.0 * slow / max(it, 1):.1f}%, stack from HBM {100.0 * deep / max(it, 1):.1f}% | lane-slots: extending {100.0 * ext / slots:.1f}% ({ext / max(it, 1):.1f} of 64), "
               f"out of reads {100.0 * done_l / slots:.1f}%, waiting for bookkeeping {100.0 * wait_l / slots:.1f}%, in bookkeeping {100.0 * run_l / slots:.1f}% | "
               f"{s['n_occ_blocks'] / n:.0f} blocks + {s['n_tab_lookups'] / n:.0f} table look-ups per read", flush=True)
-        hist = (C.c_ulonglong * 64)()
+        hist = (C.c_ulonglong * 256)()
         gpu.L.bwagpu_debug_hist.argtypes = [C.c_void_p, C.c_void_p]
         gpu.L.bwagpu_debug_hist(gpu.h, hist)
         tot_r = max(sum(hist[:32]), 1); tot_i = max(sum(hist[32:]), 1)
