@@ -88,6 +88,7 @@ struct Counters {          // device-side bump allocators + flags
 	HotCounter seed_used_, node_used_, reg_used_;
 	HotCounter next_read_, next_read3_;   // work counters of the seeding kernels (passes 1-2, pass 3)
 	HotCounter next_vread_;               // ... and of the pass-1 tasks of long-read batches (k_seed<LR = 1>)
+	HotCounter n_heavy_, n_p2_tasks_, next_p2_;   // short-read batches: the heavy reads at the head of the seeding order; their pass-2 searches as tasks (k_seed<LR = 3>) and the work counter over them
 	HotCounter n_vr_ovf_, next_vovf_;     // ... tasks whose interval stack outgrew the task lanes' small spill areas (redone on full-size stacks), and the work counter of that second launch
 	HotCounter next_ext_;    // work counter of the wave extension kernel (position in Batch::order)
 	HotCounter next_seedsw_; // work counter of the wave-per-read seed re-scoring kernel (long reads)
@@ -114,6 +115,9 @@ struct Counters {          // device-side bump allocators + flags
 #define next_read3 next_read3_.v
 #define next_vread next_vread_.v
 #define n_vr_ovf n_vr_ovf_.v
+#define n_heavy n_heavy_.v
+#define n_p2_tasks n_p2_tasks_.v
+#define next_p2 next_p2_.v
 #define next_vovf next_vovf_.v
 #define next_ext next_ext_.v
 #define next_seedsw next_seedsw_.v
@@ -185,6 +189,8 @@ struct Batch {
 	i32 *chain_todo, *chain_todo2; // reads deferred by tier 0 / tier 1 of k_chain_wave to the next tier
 	// --- pass 1 of long-read batches as independent tasks (k_seed<LR = 1>, option seed_tasks): task t of read r searches position (t - vr_first[r]) * task_step
 	int task_step, n_vreads;        // min_seed_len; number of tasks of the batch
+	int task_tpr;                   // > 0 (short-read batches, the heavy reads only): task t = position (t % task_tpr) * task_step of read seed_order[t / task_tpr], for t < n_heavy * task_tpr
+	i64 *p2_tasks; long long p2_cap; // pass-2 searches of the heavy reads as tasks (k_seed<LR = 3>): read << 32 | index of the pass-1 entry to re-seed
 	const i32 *vr_first;            // per read: its first task (n_reads + 1 entries)
 	i32 *vr_ovf;                    // tasks to be redone on full-size interval stacks (n_vr_ovf of them)
 	int vr_ovf_run, vr_room;        // this launch: 1 = redo the tasks of vr_ovf; interval-stack entries a lane may hold before its task counts as overflowed

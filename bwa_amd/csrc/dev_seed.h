@@ -286,7 +286,8 @@ __global__ void __launch_bounds__(256) k_publish(bwagpu_opt_t opt, Batch B)
 {
 	u64 nintv = 0;
 	for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < B.n_reads; r += gridDim.x * blockDim.x) {
-		const int n = B.intv_n[r];
+		int n = B.intv_n[r];
+		if (n > B.mem_cap) { atomicOr(&B.ctr->overflow, 16ull); B.intv_n[r] = 0; n = 0; }      // (seeding tasks count past a full list: the batch is redone with longer lists)
 		B.intv_off[r] = (i64)r * B.mem_cap;
 		B.seed_n[r] = 0; B.seed_off[r] = 0; B.node_off[r] = 0;
 		if (n == 0) continue;
@@ -329,8 +330,10 @@ __global__ void __launch_bounds__(256) k_publish_blk(bwagpu_opt_t opt, Batch B)
 	const size_t tmp_recs = PUB_MAX;
 	u64 nintv = 0;
 	for (int r = blockIdx.x; r < B.n_reads; r += gridDim.x) {
-		const int n = B.intv_n[r];
-		if (tid == 0) { B.intv_off[r] = (i64)r * B.mem_cap; B.seed_n[r] = 0; B.seed_off[r] = 0; B.node_off[r] = 0; }
+		int n = B.intv_n[r];
+		if (n > B.mem_cap) { n = 0; if (tid == 0) atomicOr(&B.ctr->overflow, 16ull); }      // (seeding tasks count past a full list: the batch is redone with longer lists)
+		__syncthreads();
+		if (tid == 0) { B.intv_off[r] = (i64)r * B.mem_cap; B.seed_n[r] = 0; B.seed_off[r] = 0; B.node_off[r] = 0; if (n == 0) B.intv_n[r] = 0; }
 		if (n == 0) continue;                      // (uniform over the block)
 		Intv3 *iv = B.intv + (size_t)r * B.mem_cap;
 		if (n > PUB_MAX || (size_t)n > tmp_recs) { if (tid == 0) dev_introsort(iv, n, IntvInfoLess()); }
@@ -437,7 +440,12 @@ __global__ void __launch_bounds__(256) k_publish_blk(bwagpu_opt_t opt, Batch B)
 //          atomic count (k_publish sorts; equal keys are identical intervals).  Their interval stacks are small (Batch::vr_room entries; a forward
 //          sweep with more change points than that hands its task to a second launch of this instance on full-size stacks, Batch::vr_ovf_run).
 //      2 = the ordinary lane-per-read kernel entered at pass 2 (bwamem.c:160-168), over the entries the tasks left behind pass 3's (k_seed3 runs first).
+//      3 = TASK (read, pass-1 entry): ONE search of pass 2 -- bwt_smem1 from the middle of that entry with min_intv = its occurrences + 1 -- every
+//          match it returns appended like a pass-1 task's (pass 2's searches depend on pass 1's list, not on one another).
 //      Exact by construction, no stitching; shorter matches are dropped by the length filter as ever.
+//      SHORT-read batches use 1 and 3 for their HEAVY reads only (Batch::task_tpr; the first n_heavy reads of the seeding order): measured at 1 M
+//      reads (profiles/r04_seed_iterations_per_read.log), the lane-per-read kernel's 87 ms were ONE read -- a repeat-family read of 42 000
+//      iterations at ~2 us of dependent memory latency each -- while a million reads' worth of requests take the chip ~35 ms.
 template<bool RD, bool STATS, int BLK, int OCC, int MRG = 0, int LR = 0>
 __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
@@ -454,7 +462,10 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	L.em.split_len = split_len; L.em.split_width = (u64)opt.split_width; L.em.cand = 0; L.em.base = 0; L.em.shared_n = LR == 1 ? B.intv_n : nullptr;
 	L.lo = -1;
 	int vr_task = -1, vr_run = 0;       // LR == 1: the lane's task and whether its search has been started
-	const unsigned long long n_tasks = LR == 1 ? (B.vr_ovf_run ? B.ctr->n_vr_ovf : (unsigned long long)B.n_vreads) : 0;
+	const unsigned long long n_tasks = LR == 1 ? (B.vr_ovf_run ? B.ctr->n_vr_ovf : B.task_tpr > 0 ? B.ctr->n_heavy * (unsigned long long)B.task_tpr : (unsigned long long)B.n_vreads)
+									 : LR == 3 ? (B.ctr->n_p2_tasks < (unsigned long long)B.p2_cap ? B.ctr->n_p2_tasks : (unsigned long long)B.p2_cap) : 0;
+	if (LR == 3) L.em.shared_n = B.intv_n;
+	int p2_entry = 0;                   // LR == 3: the pass-1 entry the task re-seeds
 	L.st = SS_FETCH; L.len = 0; L.qoff = 0; L.win = 0; L.win_w = ~0u; L.win2 = 0; L.win2_w = ~0u;
 	u32 *rd_lds = (u32*)(seed_lds + (size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * blockDim.x);   // (after the stacks)
 	L.rd = rd_lds; L.rd_on = 0; L.raw = B.seq; L.off = B.off;
@@ -504,7 +515,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 			if (L.st == SS_FINAL) {
 				if (STATS && LR == 0) { const int bin = my_iter ? 32 - __clz((int)my_iter) : 0; atomicAdd(&B.ctr->seed_hist[bin & 31], 1ull); atomicAdd(&B.ctr->seed_hist[32 + (bin & 31)], (unsigned long long)my_iter); my_iter = 0; }
 				if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull);
-				else if (LR != 1) B.intv_n[L.em.r] = L.em.n;       // (tasks counted their entries as they went)
+				else if (LR != 1 && LR != 3) B.intv_n[L.em.r] = L.em.n;       // (tasks counted their entries as they went)
 				L.st = SS_FETCH;
 			}
 			const bool want = L.st == SS_FETCH;
@@ -512,11 +523,11 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 			if (wm) {
 				if (pool_cnt == 0) {
 					const int first = __ffsll((unsigned long long)__ballot(1)) - 1;        // lane 0 may already have left the loop
-					const unsigned long long old = atomicAdd(LR == 1 ? (B.vr_ovf_run ? &B.ctr->next_vovf : &B.ctr->next_vread) : &B.ctr->next_read, (threadIdx.x & 63) == first ? 64ull : 0ull);
+					const unsigned long long old = atomicAdd(LR == 1 ? (B.vr_ovf_run ? &B.ctr->next_vovf : &B.ctr->next_vread) : LR == 3 ? &B.ctr->next_p2 : &B.ctr->next_read, (threadIdx.x & 63) == first ? 64ull : 0ull);
 					pool_base = __shfl((int)old, first); pool_cnt = 64;
 					// lane l looks up the pool's read number l now: a lane taking a read later gets it from a register of the wave
 					// instead of a memory round trip of its own in front of the reads of the read's data
-					{ const int idx = pool_base + (int)(threadIdx.x & 63); pool_r = LR == 1 ? idx : (idx < B.n_reads ? (B.seed_order ? B.seed_order[idx] : idx) : 0); }
+					{ const int idx = pool_base + (int)(threadIdx.x & 63); pool_r = LR == 1 || LR == 3 ? idx : (idx < B.n_reads ? (B.seed_order ? B.seed_order[idx] : idx) : 0); }
 					// the waves holding the (predicted) heaviest reads get issue priority: a lane's long chain of dependent extensions then
 					// advances at the pace of the wave alone on its SIMD instead of a quarter of it
 					if (B.seed_order && B.seed_prio) { if (pool_base < B.n_reads / 32) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
@@ -528,12 +539,22 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 				const int r = __shfl(pool_r, (64 - pool_cnt + rank) & 63);
 				if (want && rank < pool_cnt) {
 					const int idx = pool_base + rank;
-					if (LR == 1 ? (unsigned long long)idx >= n_tasks : idx >= B.n_reads) L.st = SS_DONE;
-					else if (LR == 1) {       // a task: its read by bisection of the reads' first tasks, its position from its rank among the read's tasks
+					if (LR == 1 || LR == 3 ? (unsigned long long)idx >= n_tasks : idx >= B.n_reads) L.st = SS_DONE;
+					else if (LR == 3) {       // one search of pass 2: from the middle of pass-1 entry p2_entry of its read, every match of at least its occurrences + 1
+						const i64 t = B.p2_tasks[r];
+						const int rr = (int)(t >> 32);
+						p2_entry = (int)(u32)t;
+						L.em.r = rr; L.qoff = (u64)B.off[rr]; L.len = (int)(B.off[rr + 1] - B.off[rr]);
+						L.win_w = ~0u; L.win2_w = ~0u;
+						L.em.overflow = false;
+						vr_task = r; vr_run = 0; L.lo = -1;
+						L.st = SS_PASS1;
+					} else if (LR == 1) {       // a task: its read by bisection of the reads' first tasks (or, short reads, by its rank among the heavy ones), its position from its rank among the read's tasks
 						const int t = B.vr_ovf_run ? B.vr_ovf[r] : r;
 						int lo = 0, hi = B.n_reads;
-						while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (B.vr_first[mid] <= t) lo = mid; else hi = mid; }
-						const int g = (t - B.vr_first[lo]) * B.task_step;
+						if (B.task_tpr > 0) lo = B.seed_order[t / B.task_tpr];
+						else while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (B.vr_first[mid] <= t) lo = mid; else hi = mid; }
+						const int g = B.task_tpr > 0 ? (t % B.task_tpr) * B.task_step : (t - B.vr_first[lo]) * B.task_step;
 						L.em.r = lo; L.qoff = (u64)B.off[lo]; L.len = (int)(B.off[lo + 1] - B.off[lo]);
 						L.win_w = ~0u; L.win2_w = ~0u;
 						L.em.overflow = false;
@@ -577,6 +598,16 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 					if (LR == 1) {       // a task is ONE search, at its own position (nothing to do where the read holds an N: no match covers it)
 						if (vr_run || L.x >= L.len || seed_q(L, nib, L.x) > 3) L.st = SS_FINAL;
 						else { vr_run = 1; smem_start(ix, L, S, nib, L.x, 1, 1); }
+						break;
+					}
+					if (LR == 3) {       // (bwamem.c:163-167)
+						if (vr_run) L.st = SS_FINAL;
+						else {
+							vr_run = 1;
+							const Intv3 p = L.em.mem()[p2_entry];
+							const int start = (int)(p.info >> 32), end = (int)(u32)p.info;
+							smem_start(ix, L, S, nib, (start + end) >> 1, p.x2 + 1, 1);       // (pass "1": when the search is over the lane comes back here, not to SS_PASS2)
+						}
 						break;
 					}
 					while (L.x < L.len && seed_q(L, nib, L.x) > 3) ++L.x;
@@ -727,6 +758,27 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 			// iteration at which a wave's first lane ran out (summed), the longest wave, and the waves that did any work
 			atomicAdd(&B.ctr->prof[2], (unsigned long long)n_done_l); atomicAdd(&B.ctr->prof[3], (unsigned long long)n_wait_l); atomicAdd(&B.ctr->prof[4], (unsigned long long)n_slowrun_l);
 			atomicAdd(&B.ctr->prof[5], (unsigned long long)(n_first_done ? n_first_done : n_iter)); atomicMax(&B.ctr->prof[6], (unsigned long long)n_iter); if (n_iter > 1) atomicAdd(&B.ctr->prof[7], 1ull); }
+	}
+}
+
+// Pass 2 of the heavy reads of a short-read batch as tasks: one per pass-1 entry that qualifies (bwamem.c:163-164) -- the entries the pass-1 tasks
+// left behind pass 3's.  One lane per heavy read; the searches themselves are k_seed<LR = 3>'s.
+__global__ void __launch_bounds__(256) k_seed_p2_tasks(bwagpu_opt_t opt, Batch B)
+{
+	const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
+	const unsigned long long nh = B.ctr->n_heavy;
+	for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < nh; k += (unsigned long long)gridDim.x * blockDim.x) {
+		const int r = B.seed_order[k];
+		const int n3 = B.intv_n3[r], n = B.intv_n[r];
+		if (n > B.mem_cap) { atomicOr(&B.ctr->overflow, 16ull); B.intv_n[r] = n3; continue; }      // (a pass-1 task ran out of room: the batch is redone with longer lists)
+		const Intv3 *iv = B.intv + (size_t)r * (size_t)B.mem_cap;
+		for (int e = n3; e < n; ++e) {
+			const Intv3 p = iv[e];
+			const int start = (int)(p.info >> 32), end = (int)(u32)p.info;
+			if (end - start < split_len || p.x2 > (u64)opt.split_width) continue;
+			const unsigned long long t = atomicAdd(&B.ctr->n_p2_tasks, 1ull);
+			if ((long long)t < B.p2_cap) B.p2_tasks[t] = (i64)r << 32 | (u32)e; else atomicOr(&B.ctr->overflow, 32ull);      // (bit 5: the task list is redone larger)
+		}
 	}
 }
 

@@ -652,3 +652,46 @@ def test_hostsim_long_read_four_columns_per_lane():
         st = s2.stats()
         assert st["n_glb_calls"] >= 1 and st["n_glb_cells"] > 4_000_000 and st["n_ext_cells"] > 1_000_000, st
         s2.close()
+
+
+def test_hostsim_heavy_reads_seeded_by_tasks():
+    """Short-read batches: the heaviest reads of k_seed's order (option seed_heavy = how many at most; by default 1/64 of the batch) take pass 1 as
+    independent searches at every min_seed_len-th position and pass 2 as one task per qualifying pass-1 entry, on a second stream beside the
+    lane-per-read kernel, whose read pool starts behind them.  Here every read the weight calls repetitive takes that route (repeat-rich 2 Mb
+    genome; ragged reads with Ns, reads shorter than the seed length, -k 19 and -k 11 with -r 1 so that pass 2 is busy): interval lists, regions
+    and slot counts equal the lane-per-read route's and the oracle's; a pass-2 task list of two entries forces the retry."""
+    import ctypes as C
+    import refapi
+    if not refapi.have_ref():
+        pytest.skip("oracle/_ref not built (needed to index the 2 Mb genome)")
+    prefix, g = testdata.medium_index()
+    orc = orcapi.OrcIndex(prefix)
+    reads = list(simdata.make_reads_se(g, 60, seed=601, sub=0.02, dele=0.003, ins=0.003, n_frac=0.002))
+    reads += [r_[: 30 + (i * 11) % 120] for i, r_ in enumerate(simdata.make_reads_se(g, 30, seed=602, sub=0.04))]
+    reads += [reads[0][:12], np.full(60, 4, dtype=np.uint8), np.zeros(0, dtype=np.uint8)]
+    seqs, off = testdata.ragged(reads)
+    o11 = default_opt(); o11.min_seed_len = 11; o11.split_factor = 1.0
+    for name, opt in (("-k 19", default_opt()), ("-k 11 -r 1", o11)):
+        want = orc.align(opt, seqs, off)
+        got = {}
+        for cfg_name, options in (("lane per read", {"seed_heavy": 0}), ("tasks", {"seed_heavy": 1000}), ("tasks, tiny pass-2 list", {"seed_heavy": 1000, "seed_p2_cap": 2})):
+            s2 = sim_handle(prefix, **options)
+            s2.set_stats(True)
+            c, r = s2.align(opt, seqs, off)
+            assert_regs_equal(*want, c, r, f"{name}, {cfg_name}")
+            ic, iv = s2.tap_intervals()
+            st = s2.stats()
+            got[cfg_name] = (ic.tobytes(), iv.tobytes(), st["n_seeds"])
+            prof = (C.c_ulonglong * 16)()
+            s2.L.bwagpu_debug_prof.argtypes = [C.c_void_p, C.c_void_p]
+            s2.L.bwagpu_debug_prof(s2.h, prof)
+            if cfg_name == "lane per read":
+                assert prof[0] == 0
+            else:
+                assert prof[0] >= 5 and prof[1] >= 5, (name, cfg_name, prof[0], prof[1])      # heavy reads, pass-2 tasks
+            if cfg_name == "tasks, tiny pass-2 list":
+                assert st["n_retries"] >= 1
+            s2.close()
+        for k in got:
+            assert got[k] == got["lane per read"], (name, k)
+    orc.close()
