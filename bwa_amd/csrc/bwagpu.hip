@@ -57,8 +57,7 @@ struct DevBuf {
 struct bwagpu_s {
 	int device = 0;
 	hipStream_t stream = nullptr;
-	hipStream_t stream2 = nullptr; bool have_stream2 = false; hipEvent_t ev_h[2] = {};      // the heavy reads' seeding tasks of a short-read batch run beside the lane-per-read kernel (bwagpu_batch_run)
-	hipEvent_t ev[8] = {};
+hipEvent_t ev[8] = {};
 	hipEvent_t ev_wait = nullptr;    // blocking-sync event: waiting for the stream must not spin on a host core (see wait_stream)
 	std::string err;
 	BwagpuConfig cfg;               // tuning and test options (bwagpu_config.h): environment read once at creation, then bwagpu_set_option
@@ -86,6 +85,7 @@ struct bwagpu_s {
 	i64 cigl_z_cap = 0;                          // bytes per direction matrix of the long CIGAR tier's scratch (grows with the batches)
 	DevBuf d_cigl_z, d_cigl_ops, d_cigl_md, d_cigl_list;      // scratch of the long-segment CIGAR tier (k_cigar_long): direction matrices, operations, MD strings per workgroup
 	DevBuf d_cig_ext; i64 cig_ext_n = -1;   // operation array of the last bwagpu_batch_cigars (records with 7..64 operations point into it)
+	DevBuf d_heavy;                             // short-read batches: the reads the lane-per-read seeding kernel gave up (their passes 1-2 run as tasks)
 	DevBuf d_p2_tasks; double p2_factor = 1.;   // pass-2 tasks of a short-read batch's heavy reads (grown on overflow bit 5)
 	DevBuf d_vr_tab, d_vr_ovf, d_intv_n3;   // pass 1 of long-read batches as tasks (k_seed<LR>): the reads' first tasks, the list of tasks to redo on full-size stacks, pass 3's entries per read
 	DevBuf d_seq_2b, d_seq_flags; int rd_words = 0;   // per-read 2-bit copies for k_seed's LDS (k_pack_reads2b)
@@ -399,8 +399,6 @@ extern "C" int bwagpu_create(bwagpu_t **out, const bwagpu_index_desc_t *d, int d
 	if (hipStreamCreate(&h->stream) != hipSuccess) { h->stream = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
 	for (int i = 0; i < 8; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { h->ev[i] = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
 	if (hipEventCreateWithFlags(&h->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) h->ev_wait = nullptr;
-	h->have_stream2 = hipStreamCreate(&h->stream2) == hipSuccess;
-	for (int i = 0; i < 2; ++i) if (hipEventCreateWithFlags(&h->ev_h[i], hipEventDisableTiming) != hipSuccess) h->ev_h[i] = nullptr;
 	// the last Occ record of the .bwt is a trailing 32-byte half block; pad the upload to whole 64-byte blocks
 	u64 nblk = (d->bwt_size + 15) / 16;
 	std::vector<uint32_t> padded;
@@ -451,15 +449,13 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 		for (DevBuf *b : ib) b->release();
 		delete h->ibuf;
 	}
-	DevBuf *all[] = { &h->d_p2_tasks, &h->d_vr_tab, &h->d_vr_ovf, &h->d_intv_n3, &h->d_cigl_list, &h->d_cigl_z, &h->d_cigl_ops, &h->d_cigl_md, &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
+	DevBuf *all[] = { &h->d_heavy, &h->d_p2_tasks, &h->d_vr_tab, &h->d_vr_ovf, &h->d_intv_n3, &h->d_cigl_list, &h->d_cigl_z, &h->d_cigl_ops, &h->d_cigl_md, &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_chain_todo, &h->d_seed_w, &h->d_seed_order, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
 	for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
 	if (h->ev_wait) (void)hipEventDestroy(h->ev_wait);
-	for (int i = 0; i < 2; ++i) if (h->ev_h[i]) (void)hipEventDestroy(h->ev_h[i]);
-	if (h->have_stream2) (void)hipStreamDestroy(h->stream2);
-	if (h->stream) (void)hipStreamDestroy(h->stream);
+if (h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
 }
 
@@ -542,8 +538,6 @@ extern "C" int bwagpu_clone(bwagpu_t *src, bwagpu_t **out)
 	if (hipStreamCreate(&h->stream) != hipSuccess) { h->stream = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
 	for (int i = 0; i < 8; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { h->ev[i] = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
 	if (hipEventCreateWithFlags(&h->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) h->ev_wait = nullptr;
-	h->have_stream2 = hipStreamCreate(&h->stream2) == hipSuccess;
-	for (int i = 0; i < 2; ++i) if (hipEventCreateWithFlags(&h->ev_h[i], hipEventDisableTiming) != hipSuccess) h->ev_h[i] = nullptr;
 	h->ix = src->ix; h->l_pac = src->l_pac; h->n_seqs = src->n_seqs; h->seq_len = src->seq_len; h->sa_intv = src->sa_intv;
 	h->bwt_blocks = src->bwt_blocks; h->bwt_bytes = src->bwt_bytes; h->sa_bytes = src->sa_bytes; h->pac_bytes = src->pac_bytes;
 	h->bwt_size = src->bwt_size; h->n_sa = src->n_sa;
@@ -570,8 +564,6 @@ static int clone_to_device_impl(bwagpu_t *src, int device, bwagpu_t **out)
 	if (hipStreamCreate(&h->stream) != hipSuccess) { h->stream = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
 	for (int i = 0; i < 8; ++i) if (hipEventCreate(&h->ev[i]) != hipSuccess) { h->ev[i] = nullptr; bwagpu_destroy(h); return BWAGPU_ENODEV; }
 	if (hipEventCreateWithFlags(&h->ev_wait, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) h->ev_wait = nullptr;
-	h->have_stream2 = hipStreamCreate(&h->stream2) == hipSuccess;
-	for (int i = 0; i < 2; ++i) if (hipEventCreateWithFlags(&h->ev_h[i], hipEventDisableTiming) != hipSuccess) h->ev_h[i] = nullptr;
 	struct { DevBuf *dst; const DevBuf *from; size_t bytes; } parts[] = {
 		{ &h->ibuf->d_bwt, &src->ibuf->d_bwt, (size_t)src->bwt_bytes }, { &h->ibuf->d_sa, &src->ibuf->d_sa, (size_t)src->sa_bytes },
 		{ &h->ibuf->d_pac, &src->ibuf->d_pac, (size_t)src->pac_bytes }, { &h->ibuf->d_ctg_off, &src->ibuf->d_ctg_off, (size_t)src->n_seqs * 8 },
@@ -840,13 +832,13 @@ static int alloc_batch(bwagpu_t *h, int n_threads, int seed_lanes)
 }
 
 // heavy-first processing order of the batch by a per-read weight array (device)
-static int order_reads(bwagpu_t *h, const Batch &B, const i32 *weight, int heavy_bin = 0, int heavy_max = 0)
+static int order_reads(bwagpu_t *h, const Batch &B, const i32 *weight)
 {
 	HIPCHK(h, hipMemsetAsync(B.bin_cnt, 0, 2 * ORDER_BINS * 4, h->stream));
 	int nb = (B.n_reads + BLOCK - 1) / BLOCK; if (nb > 1024) nb = 1024;
 	int chunk = (B.n_reads + nb - 1) / nb;
 	hipLaunchKernelGGL(k_order_count, dim3(nb), dim3(BLOCK), 0, h->stream, B, weight);
-	hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(64), 0, h->stream, B, heavy_bin, heavy_max);
+	hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(64), 0, h->stream, B);
 	hipLaunchKernelGGL(k_order_fill, dim3(nb), dim3(BLOCK), 0, h->stream, B, weight, chunk);
 	return 0;
 }
@@ -921,18 +913,18 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		}
 	}
 	if (dbg_sync) fprintf(stderr, "[bwagpu] pass 1 by tasks: %d tasks on %d lanes (max_len %d, step %d)\n", n_vreads, task_lanes, h->max_len, opt->min_seed_len);
-	// Short-read batches: the HEAVIEST reads of the seeding order (repeat-family reads: by k_seed3's weight, at most 1/64 of the batch) take passes 1
-	// and 2 as tasks on a second stream, beside the lane-per-read kernel, which starts its pool behind them (option seed_heavy; dev_seed.h, LR).
-	const int heavy_max = cfg.seed_heavy < 0 ? n / 64 : (int)(cfg.seed_heavy < n ? cfg.seed_heavy : n);
+	// Short-read batches: a read on which a lane of the lane-per-read kernel has spent more than option seed_budget iterations (default 4096: 2.5 % of
+	// the bench's reads, and the whole of that kernel's critical path) is given up there and seeded by the task kernels afterwards (dev_seed.h, LR).
+	const int seed_budget = (int)(cfg.seed_budget < 0 ? 4096 : cfg.seed_budget);
 	const int heavy_tpr = opt->min_seed_len > 0 ? (h->max_len + opt->min_seed_len - 1) / opt->min_seed_len : 0;
-	const bool heavy_tasks = !long_batch && h->rd_words != 0 && heavy_max > 0 && heavy_tpr > 0 && h->have_stream2 && h->ev_h[0] && h->ev_h[1] && h->ix.occ32 != nullptr && h->ix.ptab != nullptr &&
-							 h->seq_len < ((u64)1 << 37) && !cfg.seed_input_order && !cfg.seed_pass3_inline && cfg.seed_w_err != 0 && opt->max_mem_intv > 0;
-	const int heavy_lanes = heavy_tasks ? (int)(((i64)heavy_max * heavy_tpr + BLOCK - 1) / BLOCK * BLOCK < 65536 ? ((i64)heavy_max * heavy_tpr + BLOCK - 1) / BLOCK * BLOCK : 65536) : 0;
-	if (heavy_tasks && h->d_intv_n3.ensure((size_t)n * 4 + 16)) { h->err = "hipMalloc failed (seeding tasks)"; return BWAGPU_ENOMEM; }
+	const bool heavy_tasks = !long_batch && h->rd_words != 0 && seed_budget > 0 && heavy_tpr > 0 && h->ix.occ32 != nullptr && h->ix.ptab != nullptr &&
+							 h->seq_len < ((u64)1 << 37) && !cfg.seed_pass3_inline && opt->max_mem_intv > 0;
+	const int heavy_lanes = heavy_tasks ? (int)(((i64)n * heavy_tpr + BLOCK - 1) / BLOCK * BLOCK < 256 * 3 * BLOCK ? ((i64)n * heavy_tpr + BLOCK - 1) / BLOCK * BLOCK : 256 * 3 * BLOCK) : 0;
+	if (heavy_tasks && (h->d_intv_n3.ensure((size_t)n * 4 + 16) || h->d_heavy.ensure((size_t)n * 4 + 16))) { h->err = "hipMalloc failed (seeding tasks)"; return BWAGPU_ENOMEM; }
 	for (int attempt = 0; attempt < 12; ++attempt) {
 		h->phase = 20 + attempt * 100;
 		int rc = alloc_batch(h, n_threads, seed_tasks ? (int)(((size_t)task_lanes * TASK_STACK_CAP + (size_t)(h->max_len + PTAB_MAX)) / (size_t)(h->max_len + 1 + PTAB_MAX))   // (the tasks' small spill areas, in units of a full-size one)
-											: heavy_tasks ? n_threads + heavy_lanes : 0);      // (the heavy reads' task lanes spill behind the lane-per-read kernel's lanes)
+											: heavy_lanes);      // (the heavy reads' task lanes use the spill area after the lane-per-read kernel)
 		if (rc) return rc;
 		HIPCHK(h, hipMemcpyAsync(h->d_minhsp.p, minhsp.data(), minhsp.size() * 4, hipMemcpyHostToDevice, h->stream));
 		HIPCHK(h, hipMemsetAsync(h->d_ctr.p, 0, sizeof(Counters), h->stream));
@@ -963,9 +955,10 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.chain_lds_off = cfg.chain_lds == 0;
 		B.task_step = opt->min_seed_len; B.n_vreads = n_vreads; B.vr_ovf_run = 0; B.vr_room = 0; B.seed_stack_cap = 0; B.intv_n3 = nullptr;
 		if (seed_tasks) { B.vr_first = h->d_vr_tab.as<i32>(); B.vr_ovf = h->d_vr_ovf.as<i32>(); B.intv_n3 = h->d_intv_n3.as<i32>(); }
-		B.task_tpr = 0; B.p2_tasks = nullptr; B.p2_cap = 0;
+		B.task_tpr = 0; B.p2_tasks = nullptr; B.p2_cap = 0; B.heavy_list = nullptr; B.seed_budget = 0;
 		if (heavy_tasks) {
-			const i64 p2_cap = cfg.seed_p2_cap > 0 ? cfg.seed_p2_cap * (i64)h->p2_factor : (i64)((double)heavy_max * 16. * h->p2_factor) + 4096;      // (grown fourfold when a batch overflows it)
+			const i64 p2_cap = cfg.seed_p2_cap > 0 ? cfg.seed_p2_cap * (i64)h->p2_factor : (i64)((double)n * .5 * h->p2_factor) + 4096;      // (grown fourfold when a batch overflows it)
+			B.heavy_list = h->d_heavy.as<i32>(); B.seed_budget = seed_budget;
 			if (h->d_p2_tasks.ensure((size_t)p2_cap * 8)) { h->err = "hipMalloc failed (seeding tasks)"; return BWAGPU_ENOMEM; }
 			B.intv_n3 = h->d_intv_n3.as<i32>(); B.p2_tasks = h->d_p2_tasks.as<i64>(); B.p2_cap = p2_cap;
 		}
@@ -983,8 +976,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			else hipLaunchKernelGGL(k_seed3<0>, grid, block, 0, h->stream, h->ix, *opt, B);
 			if (!cfg.seed_input_order) {
 				i32 *keep = B.order; B.order = h->d_seed_order.as<i32>();
-				// (heavy: weight >= 64 * 25, the reads k_seed3 found repetitive -- bin 11 and up of the log2 bins)
-				if (int rc2 = order_reads(h, B, B.seed_w, heavy_tasks ? 11 : 0, heavy_max)) return rc2;
+				if (int rc2 = order_reads(h, B, B.seed_w)) return rc2;
 				B.seed_order = B.order; B.order = keep;
 			}
 		}
@@ -1014,25 +1006,19 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 #undef SEED_LAUNCH_LR
 			}
 			else {
-				if (heavy_tasks && blk == 1 && B.seed_order) {
-					// the heavy reads: pass-1 tasks, the list of their pass-2 searches, those searches -- on the second stream, after the order is known
-					// and beside the lane-per-read kernel below (whose pool starts behind them: k_order_scan); the interval sort waits for both
-					Batch BT = B; BT.rd_words = 0; BT.task_tpr = heavy_tpr; BT.vr_room = 0x7fffffff; BT.seed_stack_cap = 0;
-					BT.tmp_intv = B.tmp_intv + (size_t)n_threads * (size_t)(h->max_len + 1 + PTAB_MAX);
-					const size_t lds_t = (size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * sizeof(uint4) * BLOCK;
-					const dim3 hgrid((unsigned)(heavy_lanes / BLOCK));
-					HIPCHK(h, hipEventRecord(h->ev_h[0], h->stream));
-					HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_h[0], 0));
-					if (st) hipLaunchKernelGGL((k_seed<false, true, 1, 3, 2, 1>), hgrid, block, lds_t, h->stream2, h->ix, *opt, BT);
-					else hipLaunchKernelGGL((k_seed<false, false, 1, 3, 2, 1>), hgrid, block, lds_t, h->stream2, h->ix, *opt, BT);
-					hipLaunchKernelGGL(k_seed_p2_tasks, dim3((unsigned)((heavy_max + BLOCK - 1) / BLOCK)), block, 0, h->stream2, *opt, BT);
-					if (st) hipLaunchKernelGGL((k_seed<false, true, 1, 3, 2, 3>), hgrid, block, lds_t, h->stream2, h->ix, *opt, BT);
-					else hipLaunchKernelGGL((k_seed<false, false, 1, 3, 2, 3>), hgrid, block, lds_t, h->stream2, h->ix, *opt, BT);
-					HIPCHK(h, hipEventRecord(h->ev_h[1], h->stream2));
-				}
 				if (rd) { if (st) SEED_LAUNCH_B(true, true); else SEED_LAUNCH_B(true, false); }
 				else { if (st) SEED_LAUNCH_B(false, true); else SEED_LAUNCH_B(false, false); }
-				if (heavy_tasks && blk == 1 && B.seed_order) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_h[1], 0));
+				if (heavy_tasks && blk == 1) {
+					// the reads the kernel above gave up: pass-1 tasks, the list of their pass-2 searches, those searches (all sized on the device)
+					Batch BT = B; BT.rd_words = 0; BT.seed_order = nullptr; BT.task_tpr = heavy_tpr; BT.vr_room = 0x7fffffff; BT.seed_stack_cap = 0; BT.seed_budget = 0;
+					const size_t lds_t = (size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * sizeof(uint4) * BLOCK;
+					const dim3 hgrid((unsigned)(heavy_lanes / BLOCK));
+					if (st) hipLaunchKernelGGL((k_seed<false, true, 1, 3, 2, 1>), hgrid, block, lds_t, h->stream, h->ix, *opt, BT);
+					else hipLaunchKernelGGL((k_seed<false, false, 1, 3, 2, 1>), hgrid, block, lds_t, h->stream, h->ix, *opt, BT);
+					hipLaunchKernelGGL(k_seed_p2_tasks, dim3((unsigned)(n < 256 * 64 ? (n + BLOCK - 1) / BLOCK : 64)), block, 0, h->stream, *opt, BT);
+					if (st) hipLaunchKernelGGL((k_seed<false, true, 1, 3, 2, 3>), hgrid, block, lds_t, h->stream, h->ix, *opt, BT);
+					else hipLaunchKernelGGL((k_seed<false, false, 1, 3, 2, 3>), hgrid, block, lds_t, h->stream, h->ix, *opt, BT);
+				}
 			}
 		}
 #undef SEED_LAUNCH_B

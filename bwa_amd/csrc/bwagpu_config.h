@@ -23,7 +23,7 @@
 	X(ptab_m,            10)   /* index: depth of the prefix tables (0: none)                                                                           */ \
 	X(seed_mrg,          -1)   /* seeding: 0 = loads as the compiler schedules them, 2 = one memory round trip per iteration; auto: 2 for long reads     */ \
 	X(seed_tasks,        -1)   /* seeding: pass 1 of long reads as independent tasks, one per min_seed_len-th position (0: the lane-per-read chain); auto: on for long reads */ \
-	X(seed_heavy,        -1)   /* seeding, short reads: the heaviest reads of a batch (by k_seed3's weight) whose passes 1-2 run as tasks beside the lane-per-read kernel; auto: up to 1/64 of the batch, 0: none */ \
+	X(seed_budget,       -1)   /* seeding, short reads: iterations after which the lane-per-read kernel gives a read up to the task kernels; auto: 4096, 0: never           */ \
 	X(seed_p2_cap,       0)    /* seeding: entries of the heavy reads' pass-2 task list (0: 16 per heavy read; tests: a tiny list forces the retry)                             */ \
 	X(seed_task_stack,   0)    /* seeding: packed interval-stack entries a task lane may spill (0: 256; tests: tiny stacks force the second launch)      */ \
 	X(publish_blk,       -1)   /* interval sort + SA-row expansion by one workgroup per read; auto: on for long reads                                   */ \

@@ -30,17 +30,11 @@ __global__ void __launch_bounds__(256) k_order_count(Batch B, const i32 *weight)
 	__syncthreads();
 	if (threadIdx.x < ORDER_BINS && hist[threadIdx.x]) atomicAdd(&B.bin_cnt[threadIdx.x], hist[threadIdx.x]);
 }
-// heavy_bin > 0 (the seeding order only): the reads of bins >= heavy_bin, at most heavy_max of them, are the batch's HEAVY reads -- the first
-// n_heavy entries of the order.  k_seed's lane-per-read kernel starts its read pool behind them (next_read); their passes 1 and 2 run as tasks.
-__global__ void k_order_scan(Batch B, int heavy_bin, int heavy_max)
+__global__ void k_order_scan(Batch B)
 {
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		u32 acc = 0, heavy = 0;
-		for (int b = ORDER_BINS - 1; b >= 0; --b) { u32 c = B.bin_cnt[b]; B.bin_cnt[ORDER_BINS + b] = acc; acc += c; if (heavy_bin > 0 && b >= heavy_bin) heavy = acc; }   // heaviest bin first
-		if (heavy_bin > 0) {
-			if (heavy > (u32)heavy_max) heavy = (u32)heavy_max;
-			B.ctr->n_heavy = heavy; B.ctr->next_read = heavy;
-		}
+		u32 acc = 0;
+		for (int b = ORDER_BINS - 1; b >= 0; --b) { u32 c = B.bin_cnt[b]; B.bin_cnt[ORDER_BINS + b] = acc; acc += c; }   // heaviest bin first
 	}
 }
 // each block handles one contiguous chunk of reads: local histogram -> one global reservation per bin -> scatter

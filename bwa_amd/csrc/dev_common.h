@@ -88,7 +88,7 @@ struct Counters {          // device-side bump allocators + flags
 	HotCounter seed_used_, node_used_, reg_used_;
 	HotCounter next_read_, next_read3_;   // work counters of the seeding kernels (passes 1-2, pass 3)
 	HotCounter next_vread_;               // ... and of the pass-1 tasks of long-read batches (k_seed<LR = 1>)
-	HotCounter n_heavy_, n_p2_tasks_, next_p2_;   // short-read batches: the heavy reads at the head of the seeding order; their pass-2 searches as tasks (k_seed<LR = 3>) and the work counter over them
+	HotCounter n_heavy_, n_p2_tasks_, next_p2_;   // short-read batches: the heavy reads -- given up by the lane-per-read kernel when they exceeded its iteration budget --; their pass-2 searches as tasks (k_seed<LR = 3>) and the work counter over them
 	HotCounter n_vr_ovf_, next_vovf_;     // ... tasks whose interval stack outgrew the task lanes' small spill areas (redone on full-size stacks), and the work counter of that second launch
 	HotCounter next_ext_;    // work counter of the wave extension kernel (position in Batch::order)
 	HotCounter next_seedsw_; // work counter of the wave-per-read seed re-scoring kernel (long reads)
@@ -189,7 +189,9 @@ struct Batch {
 	i32 *chain_todo, *chain_todo2; // reads deferred by tier 0 / tier 1 of k_chain_wave to the next tier
 	// --- pass 1 of long-read batches as independent tasks (k_seed<LR = 1>, option seed_tasks): task t of read r searches position (t - vr_first[r]) * task_step
 	int task_step, n_vreads;        // min_seed_len; number of tasks of the batch
-	int task_tpr;                   // > 0 (short-read batches, the heavy reads only): task t = position (t % task_tpr) * task_step of read seed_order[t / task_tpr], for t < n_heavy * task_tpr
+	int task_tpr;                   // > 0 (short-read batches, the heavy reads only): task t = position (t % task_tpr) * task_step of read heavy_list[t / task_tpr], for t < n_heavy * task_tpr
+	i32 *heavy_list;                // the reads the lane-per-read kernel gave up after seed_budget iterations (n_heavy of them); their passes 1-2 run as tasks
+	int seed_budget;                // ... that budget (0: none)
 	i64 *p2_tasks; long long p2_cap; // pass-2 searches of the heavy reads as tasks (k_seed<LR = 3>): read << 32 | index of the pass-1 entry to re-seed
 	const i32 *vr_first;            // per read: its first task (n_reads + 1 entries)
 	i32 *vr_ovf;                    // tasks to be redone on full-size interval stacks (n_vr_ovf of them)

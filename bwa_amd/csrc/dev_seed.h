@@ -443,9 +443,14 @@ __global__ void __launch_bounds__(256) k_publish_blk(bwagpu_opt_t opt, Batch B)
 //      3 = TASK (read, pass-1 entry): ONE search of pass 2 -- bwt_smem1 from the middle of that entry with min_intv = its occurrences + 1 -- every
 //          match it returns appended like a pass-1 task's (pass 2's searches depend on pass 1's list, not on one another).
 //      Exact by construction, no stitching; shorter matches are dropped by the length filter as ever.
-//      SHORT-read batches use 1 and 3 for their HEAVY reads only (Batch::task_tpr; the first n_heavy reads of the seeding order): measured at 1 M
-//      reads (profiles/r04_seed_iterations_per_read.log), the lane-per-read kernel's 87 ms were ONE read -- a repeat-family read of 42 000
-//      iterations at ~2 us of dependent memory latency each -- while a million reads' worth of requests take the chip ~35 ms.
+//      SHORT-read batches use 1 and 3 for their HEAVY reads only (Batch::task_tpr, heavy_list).  Measured at 1 M reads
+//      (profiles/r04_seed_iterations_per_read.log): 19 % of the reads take under 512 iterations of the lane-per-read kernel, 2.5 % over 4096, one 42 000
+//      -- a read inside a tandem array, where EVERY forward step changes the interval size and every backward row walks ~150 stack entries -- and
+//      that one read's dependent chain was the kernel's 87 ms, while a million reads' worth of requests keep the chip busy for ~35 ms.  No weight
+//      k_seed3 can compute from its forward walk found those reads (12-mer repetitiveness put the 42 000-iteration read outside the top 1.5 %:
+//      profiles/r04_seed_heavy_by_weight_ab.jsonl), so the lane-per-read kernel finds them itself: a lane that has spent Batch::seed_budget
+//      iterations on a read gives it up -- nothing of it has been published: a read's count is written when it is done -- and lists it; the
+//      listed reads' pass 1 then runs as tasks (critical path: one search with at most min_seed_len backward rows) and their pass 2 as tasks.
 template<bool RD, bool STATS, int BLK, int OCC, int MRG = 0, int LR = 0>
 __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
@@ -482,7 +487,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	int deferred = 0;
 	u32 n_iter = 0, n_slow = 0, n_ext_lanes = 0, n_deep = 0, n_deep_l = 0, n_pf_l = 0, n_win_l = 0;
 	u32 n_done_l = 0, n_wait_l = 0, n_slowrun_l = 0, n_first_done = 0;      // STATS: where the lane-slots that do not extend go (prof[2..7])
-	u32 my_iter = 0;                                                        // STATS: iterations this lane has spent on its current read (Counters::seed_hist)
+	u32 my_iter = 0;                                                        // iterations this lane has spent on its current read (the budget of short-read batches; STATS: Counters::seed_hist)
 	// MRG == 2: the stack entry this lane's next backward step will read, fetched a step ahead (pf.w != 0: valid -- an entry's `info`, its
 	// match's end position >= 1, sits in the top half of w).  A backward step that is not the last of its row is always followed by the
 	// step for entry j + 1 of the same row, and the steps in between write survivors at depths <= j only (SeedStack::store).
@@ -496,6 +501,16 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	}
 	while (__ballot(L.st != SS_DONE)) {
 		if (STATS) ++n_iter;
+		if (LR == 0 && (STATS || B.seed_budget > 0)) {
+			if (L.st != SS_DONE && L.st != SS_FETCH) ++my_iter;
+			if (B.seed_budget > 0 && my_iter > (u32)B.seed_budget && L.st != SS_DONE && L.st != SS_FETCH && L.st != SS_FINAL) {
+				// this read is one of the batch's heavy ones: given up here (its interval count still says "pass 3 only"), finished by the task kernels
+				const unsigned long long k = atomicAdd(&B.ctr->n_heavy, 1ull);
+				B.heavy_list[k] = L.em.r;
+				if (STATS) { atomicAdd(&B.ctr->seed_hist[31], 1ull); atomicAdd(&B.ctr->seed_hist[63], (unsigned long long)my_iter); }
+				my_iter = 0; L.st = SS_FETCH;
+			}
+		}
 		const bool slow = L.st < SS_FWD || L.st == SS_FINAL;
 		const u64 sm = __ballot(slow);
 		bool run_slow = false;
@@ -504,7 +519,6 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 			run_slow = __popcll(sm) >= 8 || sm == am || ++deferred >= 3;
 		}
 		if (STATS) {
-			if (L.st != SS_DONE && L.st != SS_FETCH) ++my_iter;
 			const u64 dm = __ballot(L.st == SS_DONE);
 			n_done_l += (u32)__popcll(dm);
 			if (dm && n_first_done == 0) n_first_done = n_iter;
@@ -513,7 +527,8 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 		if (run_slow) {
 			deferred = 0; if (STATS) ++n_slow;
 			if (L.st == SS_FINAL) {
-				if (STATS && LR == 0) { const int bin = my_iter ? 32 - __clz((int)my_iter) : 0; atomicAdd(&B.ctr->seed_hist[bin & 31], 1ull); atomicAdd(&B.ctr->seed_hist[32 + (bin & 31)], (unsigned long long)my_iter); my_iter = 0; }
+				if (STATS && LR == 0) { const int bin = my_iter ? 32 - __clz((int)my_iter) : 0; atomicAdd(&B.ctr->seed_hist[bin & 31], 1ull); atomicAdd(&B.ctr->seed_hist[32 + (bin & 31)], (unsigned long long)my_iter); }
+				my_iter = 0;
 				if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull);
 				else if (LR != 1 && LR != 3) B.intv_n[L.em.r] = L.em.n;       // (tasks counted their entries as they went)
 				L.st = SS_FETCH;
@@ -552,7 +567,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 					} else if (LR == 1) {       // a task: its read by bisection of the reads' first tasks (or, short reads, by its rank among the heavy ones), its position from its rank among the read's tasks
 						const int t = B.vr_ovf_run ? B.vr_ovf[r] : r;
 						int lo = 0, hi = B.n_reads;
-						if (B.task_tpr > 0) lo = B.seed_order[t / B.task_tpr];
+						if (B.task_tpr > 0) lo = B.heavy_list[t / B.task_tpr];
 						else while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (B.vr_first[mid] <= t) lo = mid; else hi = mid; }
 						const int g = B.task_tpr > 0 ? (t % B.task_tpr) * B.task_step : (t - B.vr_first[lo]) * B.task_step;
 						L.em.r = lo; L.qoff = (u64)B.off[lo]; L.len = (int)(B.off[lo + 1] - B.off[lo]);
@@ -768,7 +783,7 @@ __global__ void __launch_bounds__(256) k_seed_p2_tasks(bwagpu_opt_t opt, Batch B
 	const int split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
 	const unsigned long long nh = B.ctr->n_heavy;
 	for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < nh; k += (unsigned long long)gridDim.x * blockDim.x) {
-		const int r = B.seed_order[k];
+		const int r = B.heavy_list[k];
 		const int n3 = B.intv_n3[r], n = B.intv_n[r];
 		if (n > B.mem_cap) { atomicOr(&B.ctr->overflow, 16ull); B.intv_n[r] = n3; continue; }      // (a pass-1 task ran out of room: the batch is redone with longer lists)
 		const Intv3 *iv = B.intv + (size_t)r * (size_t)B.mem_cap;

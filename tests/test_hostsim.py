@@ -655,9 +655,9 @@ def test_hostsim_long_read_four_columns_per_lane():
 
 
 def test_hostsim_heavy_reads_seeded_by_tasks():
-    """Short-read batches: the heaviest reads of k_seed's order (option seed_heavy = how many at most; by default 1/64 of the batch) take pass 1 as
-    independent searches at every min_seed_len-th position and pass 2 as one task per qualifying pass-1 entry, on a second stream beside the
-    lane-per-read kernel, whose read pool starts behind them.  Here every read the weight calls repetitive takes that route (repeat-rich 2 Mb
+    """Short-read batches: a read on which a lane of the lane-per-read seeding kernel has spent more than option seed_budget iterations (4096 by
+    default) is given up there and listed; the listed reads take pass 1 as independent searches at every min_seed_len-th position and pass 2 as
+    one task per qualifying pass-1 entry.  With a budget of 150 iterations every read that is not trivially cheap takes that route (repeat-rich 2 Mb
     genome; ragged reads with Ns, reads shorter than the seed length, -k 19 and -k 11 with -r 1 so that pass 2 is busy): interval lists, regions
     and slot counts equal the lane-per-read route's and the oracle's; a pass-2 task list of two entries forces the retry."""
     import ctypes as C
@@ -674,7 +674,7 @@ def test_hostsim_heavy_reads_seeded_by_tasks():
     for name, opt in (("-k 19", default_opt()), ("-k 11 -r 1", o11)):
         want = orc.align(opt, seqs, off)
         got = {}
-        for cfg_name, options in (("lane per read", {"seed_heavy": 0}), ("tasks", {"seed_heavy": 1000}), ("tasks, tiny pass-2 list", {"seed_heavy": 1000, "seed_p2_cap": 2})):
+        for cfg_name, options in (("lane per read", {"seed_budget": 0}), ("tasks", {"seed_budget": 150}), ("tasks, tiny pass-2 list", {"seed_budget": 150, "seed_p2_cap": 2})):
             s2 = sim_handle(prefix, **options)
             s2.set_stats(True)
             c, r = s2.align(opt, seqs, off)
