@@ -913,9 +913,9 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		}
 	}
 	if (dbg_sync) fprintf(stderr, "[bwagpu] pass 1 by tasks: %d tasks on %d lanes (max_len %d, step %d)\n", n_vreads, task_lanes, h->max_len, opt->min_seed_len);
-	// Short-read batches: a read on which a lane of the lane-per-read kernel has spent more than option seed_budget iterations (default 4096: 2.5 % of
-	// the bench's reads, and the whole of that kernel's critical path) is given up there and seeded by the task kernels afterwards (dev_seed.h, LR).
-	const int seed_budget = (int)(cfg.seed_budget < 0 ? 4096 : cfg.seed_budget);
+	// Short-read batches: a read on which a lane of the lane-per-read kernel has spent more than option seed_budget iterations (default 8192: 0.15 % of
+	// the bench's reads -- and the whole of that kernel's critical path; measured over budgets 2048..8192: profiles/r04_seed_budget_ab.jsonl) is given up there and seeded by the task kernels afterwards (dev_seed.h, LR).
+	const int seed_budget = (int)(cfg.seed_budget < 0 ? 8192 : cfg.seed_budget);
 	const int heavy_tpr = opt->min_seed_len > 0 ? (h->max_len + opt->min_seed_len - 1) / opt->min_seed_len : 0;
 	const bool heavy_tasks = !long_batch && h->rd_words != 0 && seed_budget > 0 && heavy_tpr > 0 && h->ix.occ32 != nullptr && h->ix.ptab != nullptr &&
 							 h->seq_len < ((u64)1 << 37) && !cfg.seed_pass3_inline && opt->max_mem_intv > 0;
@@ -949,7 +949,6 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.seedsw_minhsp = h->d_minhsp.as<i32>();
 		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>(); B.chain_todo = h->d_chain_todo.as<i32>(); B.chain_todo2 = B.chain_todo + n + 4; B.seed_w = h->d_seed_w.as<i32>(); B.seed_order = nullptr;
 		B.seed_prio = cfg.seed_prio != 0;
-		B.seed_w_err = (int)cfg.seed_w_err;
 		B.seed_no_virt = cfg.seed_no_virt != 0;
 		B.seed_pass3_inline = cfg.seed_pass3_inline != 0;
 		B.chain_lds_off = cfg.chain_lds == 0;

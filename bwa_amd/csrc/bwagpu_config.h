@@ -23,7 +23,7 @@
 	X(ptab_m,            10)   /* index: depth of the prefix tables (0: none)                                                                           */ \
 	X(seed_mrg,          -1)   /* seeding: 0 = loads as the compiler schedules them, 2 = one memory round trip per iteration; auto: 2 for long reads     */ \
 	X(seed_tasks,        -1)   /* seeding: pass 1 of long reads as independent tasks, one per min_seed_len-th position (0: the lane-per-read chain); auto: on for long reads */ \
-	X(seed_budget,       -1)   /* seeding, short reads: iterations after which the lane-per-read kernel gives a read up to the task kernels; auto: 4096, 0: never           */ \
+	X(seed_budget,       -1)   /* seeding, short reads: iterations after which the lane-per-read kernel gives a read up to the task kernels; auto: 8192, 0: never           */ \
 	X(seed_p2_cap,       0)    /* seeding: entries of the heavy reads' pass-2 task list (0: 16 per heavy read; tests: a tiny list forces the retry)                             */ \
 	X(seed_task_stack,   0)    /* seeding: packed interval-stack entries a task lane may spill (0: 256; tests: tiny stacks force the second launch)      */ \
 	X(publish_blk,       -1)   /* interval sort + SA-row expansion by one workgroup per read; auto: on for long reads                                   */ \
@@ -32,7 +32,6 @@
 	X(seed_lds_ent,      -1)   /* seeding: interval-stack entries per lane kept in LDS; auto: 10, or what the read copy leaves                          */ \
 	X(seed_rd_lds,       1)    /* seeding: short reads copied to LDS at 2 bits per base                                                                 */ \
 	X(seed_no_virt,      0)    /* seeding: keep matches shorter than the prefix tables' depth in the stack too (diagnostics)                            */ \
-	X(seed_w_err,        1)    /* seeding: k_seed's heavy-first order by 12-mer repetitiveness, then error count (0: round 3's weight, seed-length occurrences)                */ \
 	X(seed_prio,         1)    /* seeding: raised issue priority for the waves holding the heaviest reads                                               */ \
 	X(seed_input_order,  0)    /* seeding: reads in input order instead of heaviest first (diagnostics)                                                 */ \
 	X(seed_pass3_inline, 0)    /* seeding: pass 3 inside k_seed's state machine instead of k_seed3 (A/B)                                                */ \

@@ -197,7 +197,6 @@ struct Batch {
 	i32 *vr_ovf;                    // tasks to be redone on full-size interval stacks (n_vr_ovf of them)
 	int vr_ovf_run, vr_room;        // this launch: 1 = redo the tasks of vr_ovf; interval-stack entries a lane may hold before its task counts as overflowed
 	i32 *intv_n3;                   // per read: the entries pass 3 (k_seed3, run first) left at the head of its interval list
-	int seed_w_err;            // what a seed-length stretch without occurrences (a read error) adds to k_seed3's weight of the read (option seed_w_err)
 	int seed_prio;             // waves holding the heaviest 3 % of k_seed's reads run at raised issue priority (option seed_prio = 0 turns it off)
 	int seed_pass3_inline;     // A/B switch (option seed_pass3_inline = 1): pass 3 inside k_seed's state machine as in round 1, instead of k_seed3
 	int chain_lds_off;         // test hook (option chain_lds = 0): the LDS tiers defer every read

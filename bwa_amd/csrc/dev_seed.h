@@ -814,10 +814,7 @@ template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k
 	const int lane = threadIdx.x & 63;
 	enum { T_FETCH = 0, T_START, T_EXT, T_DONE };
 	int st = T_FETCH, pool_base = 0, pool_cnt = 0;
-	u32 nblk = 0, ntab = 0, weight = 0, n_err = 0;
-	// the read's weight for k_seed's heavy-first order (see below): occurrences of its 12-mers relative to what chance gives a genome this size
-	const int w_len = opt.min_seed_len > 12 ? 12 : opt.min_seed_len;
-	const u32 w_chance = (u32)((ix.seq_len >> (2 * w_len)) > 0 ? (ix.seq_len >> (2 * w_len)) : 1);
+	u32 nblk = 0, ntab = 0, weight = 0;
 	SeedBufs bf;
 	if (MRG && BLK == 1) { bf.occ = occ32_bufs(ix); bf.ptab = buf_rsrc(ix.ptab, ix.ptab_bytes); bf.stk = buf_rsrc(nullptr, 0); bf.nib = bf.stk; }
 	while (__ballot(st != T_DONE)) {
@@ -835,7 +832,7 @@ template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k
 				else {
 					L.em.r = r; L.qoff = (u64)B.off[r]; L.len = (int)(B.off[r + 1] - B.off[r]);
 					L.em.n = 0; L.em.overflow = false;
-					B.intv_n[r] = 0; B.seed_w[r] = 0; weight = 0; n_err = 0;
+					B.intv_n[r] = 0; B.seed_w[r] = 0; weight = 0;
 					if (B.intv_n3) B.intv_n3[r] = 0;
 					if (L.len >= opt.min_seed_len && opt.max_mem_intv > 0) { L.x = 0; st = T_START; }   // mem_chain returns at once for shorter reads (bwamem.c:286)
 				}
@@ -847,11 +844,7 @@ template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k
 			while (L.x < L.len && seed_q(L, nib, L.x) > 3) ++L.x;
 			if (L.x >= L.len) {
 				if (L.em.overflow) atomicOr(&B.ctr->overflow, 16ull); else { B.intv_n[L.em.r] = L.em.n; if (B.intv_n3) B.intv_n3[L.em.r] = L.em.n; }
-				{	// repetitive reads first, by how repetitive; then the others by their number of errors, error-free ones last (B.seed_w_err = 0: round 3's weight)
-					const u32 norm = weight / w_chance;
-					const u32 w = B.seed_w_err ? (norm > 24 ? (norm > 0x00ffffffu ? 0x3fffffffu : norm * 64) : 0) + (16u << (n_err < 5 ? n_err : 5)) : weight;
-					B.seed_w[L.em.r] = (i32)(w > 0x3fffffffu ? 0x3fffffffu : w);
-				}
+				B.seed_w[L.em.r] = (i32)(weight > 0x3fffffffu ? 0x3fffffffu : weight);
 				st = T_FETCH;
 			} else {
 				fm_init(ix, seed_q(L, nib, L.x), L.ik); L.sx = L.x; L.i = L.x + 1;
@@ -876,16 +869,10 @@ template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k
 			if (MRG && BLK == 1) ;
 			else if (!blocks) { ptab_load(ix, tl, L.code, ok); ++ntab; }
 			else nblk += fm_extend1<BLK>(ix, L.ik, cb, 0, ok);
-			// What a read costs k_seed (measured, profiles/r04_seed_iterations_per_read.log: 19 % of the reads take under 512 wave iterations, 10 % over
-			// 2048 and a third of all iterations) is the depth of its interval stacks -- how often its SHORT substrings occur: a read from a diverged
-			// repeat copy has seed-length matches as rare as a unique read's (round 3's weight could not tell them apart: the heavy reads were started
-			// late and 40 % of the kernel's lane-slots were lanes out of reads waiting for them), but its 12-mers occur thousands of times -- and, for
-			// the others, the number of its errors (a seed-length stretch that occurs nowhere = one more search of pass 1, ~250 iterations).  k_seed
-			// draws its reads heaviest first so that the LAST ones drawn are the cheapest and most alike.
-			if (B.seed_w_err) {
-				if (tl == w_len) { const u32 add = (u32)(ok.x2 > 65535 ? 65535 : ok.x2); weight = weight + add < weight ? 0xffffffffu : weight + add; }
-				if (tl == opt.min_seed_len && ok.x2 == 0) ++n_err;
-			} else if (tl == opt.min_seed_len) weight += (u32)(ok.x2 > 65535 ? 65535 : ok.x2);
+			// occurrences of the seed-length match: the read's repetitiveness.  (Round 4 tried two richer weights -- 12-mer occurrences relative to chance,
+			// then the number of seed-length stretches without occurrence, i.e. read errors -- to start the costly reads earlier: neither moved the
+			// kernel, profiles/r04_seed_order_ab.log; what did is the iteration budget, k_seed's LR comment.)
+			if (tl == opt.min_seed_len) weight += (u32)(ok.x2 > 65535 ? 65535 : ok.x2);
 			if (ok.x2 < opt.max_mem_intv && L.i - L.sx >= opt.min_seed_len) {
 				if (ok.x2 > 0) L.em.add(ok.x0, ok.x2, L.sx, L.i + 1);
 				L.x = L.i + 1; st = T_START;
