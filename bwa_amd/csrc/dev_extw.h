@@ -170,6 +170,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		wave_sync();
 	}
 	int init_hi = -1;                                  // RING: columns 0..init_hi hold valid (initial or computed) values
+	int q_pre = 4, q_pre_beg = -1;                     // RING: the query bases of columns q_pre_beg + lane, asked for a row ahead (see the multi-pass rows)
 	int lim = trunc_div_add(qlen * mat_max + end_bonus - o_ins, e_ins, 1); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	lim = trunc_div_add(qlen * mat_max + end_bonus - o_del, e_del, 1); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	w = uni(w);
@@ -317,12 +318,28 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			hprev = (lastc & 1) ? __builtin_amdgcn_readlane(hB, lastc >> 1) : __builtin_amdgcn_readlane(hA, lastc >> 1);
 			wave_sync();
 		} else {
+			// RING: a lane's query base comes from the batch's array in HBM -- a dependent global load (an L1/L2 hit: 200-500 cycles) in front of every
+			// pass of every row, at one wave per SIMD where nothing hides it (measured: ~100 ms of wave time per 10 kb read, profiles/r04_longread_wave_time_per_read.log).
+			// The addresses are known long before: the base of pass b + 64 is asked for when pass b starts, the first pass's base when the ROW BEFORE
+			// starts (for the usual case that the band moves on by one column; anything else loads it here).
+			int qc_next = 4;
+			if (RING) {
+				const int j0 = beg + lane;
+				qc_next = (beg == q_pre_beg) ? q_pre : (j0 < qlen ? QBASE(q0 + j0 * qdir) : 4);
+				const int jn = beg + 1 + lane;                      // (the next row's first pass, if its band starts one column on)
+				q_pre = jn < qlen ? QBASE(q0 + jn * qdir) : 4; q_pre_beg = beg + 1;
+			}
 			for (int b = beg; b < end; b += 64) {
 				const int j = b + lane; const bool act = j < end;
 				// the LDS region is padded by 64 columns, so inactive lanes may read (never write) past `end`
 				int2 old = eh[EHI(j)];
 				int sc;
-				if (RING) { const int qc = j < qlen ? QBASE(q0 + j * qdir) : 4; sc = L.mat[tb * 5 + qc]; }
+				if (RING) {
+					const int qc = qc_next;
+					const int j2 = j + 64;                          // (the next pass's base: in flight while this pass computes)
+					qc_next = (b + 64 < end && j2 < qlen) ? QBASE(q0 + j2 * qdir) : 4;
+					sc = L.mat[tb * 5 + qc];
+				}
 				else sc = qrow[(act ? j : beg) * qdir];
 				const int bnd_next = eh[EHI(b + 64)].x;             // next pass's diagonal for its lane 0, before lane 63 overwrites it
 				if (b != beg && lane == 0) old.x = bnd;
