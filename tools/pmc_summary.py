@@ -26,7 +26,7 @@ def main():
     dst = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(__file__), "..", "profiles", "pmc_latest.json")
     F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
     import datetime
-    res = {"_note": note, "_meta": {"what": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, round-3 kernels", "date": datetime.date.today().isoformat()}}
+    res = {"_note": note, "_meta": {"what": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes; raw counters (FETCH_SIZE counts 64 bytes per request whatever its size, profiles/r03_fetch_calibration.md)", "date": datetime.date.today().isoformat()}}
     for k in sorted(F, key=lambda k: -max(F[k])):
         if not k.startswith("k_"):
             continue
@@ -41,11 +41,18 @@ def main():
     for k in list(res):
         if k.startswith("k_extend_wave<"):
             res["k_extend_wave"] = res[k]
-    # the seeding kernel has an instance with work counters (one launch per bench run) and one without (the timed launches)
-    seeds = sorted(k for k in res if k.startswith("k_seed<"))
-    if seeds:
-        plain = [k for k in seeds if [a.strip() for a in k[k.index("<") + 1:-1].split(",")][1:2] == ["false"]]   # second template argument: work counters
-        res["k_seed"] = res[(plain or seeds)[0]]
+    # the seeding stage's lane-per-read kernel has an instance with work counters (one launch per bench run) and one without (the timed
+    # launches); since round 4 the reads it gives up are seeded by task kernels (other instances of the same template: RD = false).  k_seed = the
+    # counter-free lane-per-read instance + the counter-free task instances; k_seed3 = pass 3
+    def targs(k):
+        return [a.strip() for a in k[k.index("<") + 1:-1].split(",")]
+    plain = [k for k in res if k.startswith("k_seed<") and targs(k)[1:2] == ["false"]]
+    if plain:
+        res["k_seed"] = {"FETCH_SIZE_KB": sum(res[k]["FETCH_SIZE_KB"] for k in plain), "WRITE_SIZE_KB": sum(res[k]["WRITE_SIZE_KB"] for k in plain),
+                         "launches_seen": min(res[k]["launches_seen"] for k in plain), "hbm_bytes_per_launch": sum(res[k]["hbm_bytes_per_launch"] for k in plain), "instances": plain}
+    for k in list(res):
+        if k.startswith("k_seed3<") and "k_seed3" not in res:
+            res["k_seed3"] = res[k]
     json.dump(res, open(dst, "w"), indent=1)
     for k, v in res.items():
         if not k.startswith("_"):
