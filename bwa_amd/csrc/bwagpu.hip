@@ -892,6 +892,11 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 	// fastest for them, identical regions: seeding by chunks with one memory round trip per iteration, workgroup-per-read interval sort, LDS
 	// seed re-scoring, four columns per lane in the patch alignments.  An explicit option (>= 0) overrides either way.
 	const bool long_batch = h->max_len > WAVE_EXT_MAX_LEN;
+	// Option share (percent; short-read batches): the persistent kernels of the hot path launch with that share of the workgroups that would fill
+	// the chip.  A kernel whose workgroups live until its work runs out holds every slot it got: launched to fill the chip, the kernels of the
+	// batches in flight take turns; launched for a share, kernels of different batches -- the memory-bound seeding of one, the issue-bound
+	// extension of another -- run side by side.
+	auto share = [&](long long g) { if (long_batch || cfg.share >= 100 || cfg.share <= 0) return g; const long long v = g * cfg.share / 100; return v < 1 ? 1ll : v; };
 	auto pick = [&](long long v, long long dflt_long) { return v >= 0 ? v : (long_batch ? dflt_long : 0); };
 	// Pass 1 of long-read batches as independent tasks (option seed_tasks; dev_seed.h, k_seed's LR): one task per read and min_seed_len-th
 	// position.  The host only says where each read's tasks begin; a task finds its read by bisection.
@@ -982,6 +987,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		const size_t seed_lds = ((size_t)(B.seed_lds_ent ? B.seed_lds_ent : 1) * sizeof(uint4) + (size_t)B.rd_words * 4) * BLOCK;
 		dim3 sgrid = grid;                    // (option seed_grid, measurements: fewer resident workgroups of the seeding kernel; it stays within 5 % down to two per CU -- it is bound by memory requests, not by waves -- but step time with three batches in flight did not move either, nor did making the batches' seeding kernels take turns)
 		if (cfg.seed_grid > 0 && (unsigned long long)cfg.seed_grid < grid.x) sgrid = dim3((unsigned)cfg.seed_grid);
+		else if (!long_batch) sgrid = dim3((unsigned)share(grid.x));
 		// (instances: with/without the LDS copy of the reads, the work counters -- which cost registers --, the two index layouts, one or several trips per iteration)
 #define SEED_LAUNCH(RD_, ST_, B_, O_, M_) hipLaunchKernelGGL((k_seed<RD_, ST_, B_, O_, M_>), sgrid, block, seed_lds, h->stream, h->ix, *opt, B)
 #define SEED_LAUNCH_B(RD_, ST_) do { if (blk == 1 && mrg == 2) SEED_LAUNCH(RD_, ST_, 1, (RD_ ? 4 : 3), 2);   /* (no LDS copy of the reads: long reads, few lanes -- registers instead of spills) */ \
@@ -1043,11 +1049,11 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_sa", hipGetErrorString(e_)); }
 		{	// wave per read, heaviest reads (most seeds) first; reads that outgrow the LDS tier are redone by the HBM tier
 			if (int rc2 = order_reads(h, B, B.seed_n)) return rc2;
-			i64 nblk = ((i64)n + 3) / 4, cap = 256 * 8;
+			i64 nblk = ((i64)n + 3) / 4, cap = share(256 * 8);
 			hipLaunchKernelGGL((k_chain_wave<0, 10, 32, 128>), dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)CW_LDS_BYTES(10, 32, 128) * 4, h->stream, h->ix, *opt, B);
 			// (the deferred reads are known on the device only: the grids of tiers 1 and 2 are sized for a full chip, or for every read of a small batch)
-			hipLaunchKernelGGL((k_chain_wave<1, 16, 64, 0>), dim3((unsigned)(nblk < 256 * 5 ? nblk : 256 * 5)), block, (size_t)CW_LDS_BYTES(16, 64, 0) * 4, h->stream, h->ix, *opt, B);
-			hipLaunchKernelGGL((k_chain_wave<2, 0, 0, 0>), dim3((unsigned)(nblk < 256 * 7 ? nblk : 256 * 7)), block, (size_t)CW_LDS_BYTES(0, 0, 0) * 4, h->stream, h->ix, *opt, B);
+			hipLaunchKernelGGL((k_chain_wave<1, 16, 64, 0>), dim3((unsigned)(nblk < share(256 * 5) ? nblk : share(256 * 5))), block, (size_t)CW_LDS_BYTES(16, 64, 0) * 4, h->stream, h->ix, *opt, B);
+			hipLaunchKernelGGL((k_chain_wave<2, 0, 0, 0>), dim3((unsigned)(nblk < share(256 * 7) ? nblk : share(256 * 7))), block, (size_t)CW_LDS_BYTES(0, 0, 0) * 4, h->stream, h->ix, *opt, B);
 		}
 		HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_chain", hipGetErrorString(e_)); }
@@ -1072,7 +1078,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		while (ring_cols < 4 * opt->w + 4 + 128) ring_cols <<= 1;
 		if (h->max_len <= WAVE_EXT_MAX_LEN && max_score < (1 << 24)) {
 			int lds_wave = (8 * (h->max_len + 2 + 64) + 5 * ((h->max_len + 64 + 3) & ~3) + 32 + 15) & ~15;   // {H,E} columns, query profile, scoring matrix
-			i64 nblk = ((i64)n + 3) / 4, cap = 256 * 8;
+			i64 nblk = ((i64)n + 3) / 4, cap = share(256 * 6);       // (six workgroups per CU are resident at 6 waves per SIMD)
 			const int occ = (int)cfg.ext_occ;   // waves per SIMD the register allocation aims at (measured at 3.1 Gbp: 4 -> 63 ms, 5 -> 58 ms, 6 -> 56 ms)
 			const dim3 g((unsigned)(nblk < cap ? nblk : cap));
 			if (occ == 5) hipLaunchKernelGGL((k_extend_wave<false, 5>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
@@ -1107,7 +1113,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			if (dedup_blk && q_cap) hipLaunchKernelGGL(k_dedup_wave<true>, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)(8 * rc_ + 32 + q_cap) * wpb, h->stream, h->ix, *opt, B, rc_, q_cap);
 			else hipLaunchKernelGGL(k_dedup_wave<false>, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)(8 * rc_ + 32 + q_cap) * wpb, h->stream, h->ix, *opt, B, rc_, q_cap);
 		} else
-			hipLaunchKernelGGL(k_dedup, grid, block, 0, h->stream, h->ix, *opt, B);
+			hipLaunchKernelGGL(k_dedup, dim3((unsigned)share(grid.x)), block, 0, h->stream, h->ix, *opt, B);
 		HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_dedup", hipGetErrorString(e_)); }
 		HIPCHK(h, hipGetLastError());
