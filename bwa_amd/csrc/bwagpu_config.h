@@ -38,7 +38,7 @@
 	X(seed_grid,         0)    /* seeding: resident workgroups of k_seed (0: fill the chip; measurements)                                               */ \
 	X(share,             100)  /* short reads: percent of a chip-filling launch that the hot path's persistent kernels take (kernels of different batches side by side)  */ \
 	X(chain_lds,         1)    /* chaining: 0 = the LDS tiers defer every read to the HBM tier (test hook)                                              */ \
-	X(ext_occ,           6)    /* extension: waves per SIMD the short-read kernel's register allocation aims at (4, 5, 6)                               */ \
+	X(ext_occ,           6)    /* extension: waves per SIMD the short-read kernel's register allocation aims at (4 or 6)                                */ \
 	X(dedup_wave,        0)    /* 1 = the wave-per-read de-duplication kernel for short reads as well (test hook)                                       */ \
 	X(dedup_ring,        0)    /* ring columns of that kernel (0: from the batch; test hook: a power of two, 256..4096)                                 */ \
 	X(mem_cap,           0)    /* capacity of a read's interval list (0: from the batch; test hook: a small value forces the retry path)                */ \

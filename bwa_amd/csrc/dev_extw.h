@@ -52,6 +52,13 @@ DEVFN int wave_incl_scan_max(int v)
 // value of the lane below (lane 0 receives `fill`)
 DEVFN int wave_shift_up1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHR1, 0xf, 0xf, false); }
 DEVFN int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }   // pin a wave-uniform value into an SGPR
+// __ballot() of a comparison costs two extra vector instructions (the predicate is turned into 0/1 and compared again); the w64 builtin hands back the
+// compare's own mask
+#ifdef __HIP_DEVICE_COMPILE__
+DEVFN u64 wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+#else
+DEVFN u64 wave_ballot(bool p) { return __ballot(p); }
+#endif
 DEVFN i64 uni64(i64 v)
 {
 	int lo = __builtin_amdgcn_readfirstlane((int)(u32)(u64)v), hi = __builtin_amdgcn_readfirstlane((int)(u32)((u64)v >> 32));
@@ -112,7 +119,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = opt.zdrop;
 	int2 *eh = L.eh; int8_t *qp = L.qp; const int qs = L.qstride;
 	// every argument is wave-uniform: keep it in SGPRs so that the row loop's control flow and address arithmetic are scalar
-	q0 = uni(q0); qlen = uni(qlen); tlen = uni(tlen); w = uni(w); h0 = uni(h0); end_bonus = uni(end_bonus); t0 = uni64(t0);
+	q0 = uni(q0); qlen = uni(qlen); tlen = uni(tlen); w = uni(w); h0 = uni(h0); end_bonus = uni(end_bonus); t0 = uni64(t0); mat_max = uni(mat_max);
 	// ---- the extension that stays on the diagonal needs no DP ------------------------------------------------------------
 	// Let P be the score the first qlen diagonal cells lose against an all-match diagonal (mismatches, Ns).  Any cell (i,j) off
 	// the diagonal lies on a path with a gap, hence H(i,j) <= h0 + mat_max * (min(i,j)+1) - (o + e*|i-j|), while the diagonal
@@ -178,28 +185,44 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 	int beg = 0, end = qlen, max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, treg = 0;
 	const bool two_col_ok = h0 + qlen * mat_max < (1 << 23);      // (score << 7 | column) must fit the scan's 31 bits
 	const int lane_e = lane * e_ins;
-	// Deferred bookkeeping of the single-pass rows.  What a row contributes to the running maximum (ksw.c:491-493), to the z-drop test
-	// (:494-500) and to the to-end score (:486-489) are three numbers -- its maximum m, that maximum's column mj, and H(i, end-1) when the
-	// band touches the query's end -- and none of them steers the next row (the band's trimming does, and stays in the row).  Kept per row in
-	// scalar registers this bookkeeping was ~45 of a row's ~90 scalar instructions, and the kernel is bound by exactly those (one scalar
-	// issue slot per SIMD every four cycles).  So a row only parks its three numbers in lane `hist_n` of three vector registers, and every
-	// 32 rows -- or when the extension ends, or before a row of another form -- the parked rows are evaluated together, one lane per row:
-	// prefix maxima give every row the (max, max_i, max_j) it would have seen, the first z-drop hit ends the extension there (the rows computed
-	// past it are simply not counted; the next call re-initialises the columns they wrote), and the survivors update the state.
-	int hist_m = 0, hist_j = 0, hist_h1 = 0, hist_n = 0, hist_row0 = 0;
+	// The single-pass rows ("window rows", the form 150 bp reads spend most of their rows in).  The kernel is bound by instruction issue, the
+	// scalar unit first (round 3: 85 scalar and 62 vector instructions per row, one scalar unit per CU against four vector units), so the form is
+	// written for few of both:
+	//  * lanes keep their columns.  While the band fits the 64 columns [base, base + 64) lane L owns column base + L and keeps its {H, E} slot
+	//    in two registers from row to row -- the slot is read and written by that lane only (H(i,j) reaches column j + 1 by a lane shift) -- so a
+	//    row touches LDS once, for its score.  Lanes outside the band leave their registers alone, which IS the reference's stale-cell rule;
+	//    when the band leaves the window (it drifts right by about a column a row) the registers go back to eh[] and the window is re-based.
+	//  * the band is a pair of lane numbers [lo, hi) and the trimming (ksw.c:502-505) two bit scans of ONE ballot: bit L = column base + L holds
+	//    a non-zero {h, e}, the column `end` (lane hi, which stores {H(i,end-1), 0}, ksw.c:485) included.
+	//  * F's offsets j * e_ins shrink to lane * e_ins: the row's common term cancels between the scan's input and output.  Lanes below the band
+	//    feed the scan its identity, so the first column's F is far below zero instead of the reference's 0 -- H = max(M, E, F) is the same
+	//    number, because E >= 0 everywhere.  Lanes outside the band shift out H = 0, the reference's h1 for beg > 0.
+	//  * the row maximum is taken over max(M, E) instead of H = max(M, E, F): F(i,j) <= max(0, max_k M(i,k) - oe_ins) lies strictly below a
+	//    positive row maximum, so neither the maximum nor the "last column wins" choice (ksw.c:473-474) changes, and the two six-step DPP
+	//    chains interleave instead of idling between dependent steps.  The scan's key carries the ABSOLUTE column (score << 11 | column).
+	//  * deferred bookkeeping.  What a row contributes to the running maximum (ksw.c:491-493), to the z-drop test (:494-500) and to the to-end
+	//    score (:486-489) are two numbers -- the key of its maximum, and H(i, end-1) when the band touches the query's end -- and neither
+	//    steers the next row (the band's trimming does, and stays in the row).  A row parks them in lane `hist_n` of two vector registers,
+	//    and every 32 rows -- or when the extension ends, or before a row of another form -- the parked rows are evaluated
+	//    together, one lane per row: prefix maxima give every row the (max, max_i, max_j) it would have seen, the first z-drop hit ends the
+	//    extension there (the rows computed past it are simply not counted; the next call re-initialises the columns they wrote), and the
+	//    survivors update the state.
+	const bool win_ok = !RING && qlen < 2048 && h0 + qlen * mat_max < (1 << 20);      // (score << 11 | column) must fit the scan's 31 bits
+	int hist_k = 0, hist_h1 = -1, hist_n = 0, hist_row0 = 0;
 	auto hist_flush = [&]() -> bool {       // returns true when a parked row ended the extension by z-drop
 		const int cnt = hist_n;
 		if (cnt == 0) return false;
 		const bool val = lane < cnt;
 		const int r = hist_row0 + lane;
-		const int pm = imax(wave_shift_up1(wave_incl_scan_max(val ? hist_m : I32_MIN), I32_MIN), max);     // the maximum before row r
-		const bool imp = val && hist_m > pm;                                                           // row r raises it
-		const int lk = wave_shift_up1(wave_incl_scan_max(imp ? ((lane + 1) << 16 | hist_j) : 0), 0);  // the latest raising row before r (0: none among the parked ones)
+		const int hm = hist_k >> 11, hj = hist_k & 2047;                                                  // this lane's row: its maximum and that maximum's column
+		const int pm = imax(wave_shift_up1(wave_incl_scan_max(val ? hm : I32_MIN), I32_MIN), max);     // the maximum before row r
+		const bool imp = val && hm > pm;                                                               // row r raises it
+		const int lk = wave_shift_up1(wave_incl_scan_max(imp ? ((lane + 1) << 16 | hj) : 0), 0);      // the latest raising row before r (0: none among the parked ones)
 		bool zb = false;
 		if (zdrop > 0 && val && !imp) {
 			const int pmi = lk ? hist_row0 + (lk >> 16) - 1 : max_i, pmj = lk ? (lk & 0xffff) : max_j;
-			const int di = r - pmi, dj = hist_j - pmj;
-			zb = di > dj ? pm - hist_m - (di - dj) * e_del > zdrop : pm - hist_m - (dj - di) * e_ins > zdrop;
+			const int di = r - pmi, dj = hj - pmj;
+			zb = di > dj ? pm - hm - (di - dj) * e_del > zdrop : pm - hm - (dj - di) * e_ins > zdrop;
 		}
 		const u64 zm = __ballot(zb);
 		const int last = zm ? __builtin_ctzll(zm) : cnt - 1;                 // the last row that counts
@@ -207,24 +230,93 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		const u64 im = __ballot(imp && use);
 		if (im) {
 			const int l = 63 - __builtin_clzll(im);                          // the raises are strictly increasing: the last one holds the maximum
-			max = __builtin_amdgcn_readlane(hist_m, l); max_i = hist_row0 + l; max_j = __builtin_amdgcn_readlane(hist_j, l);
-			int off = hist_j - r; off = off < 0 ? -off : off;
+			max = __builtin_amdgcn_readlane(hm, l); max_i = hist_row0 + l; max_j = __builtin_amdgcn_readlane(hj, l);
+			int off = hj - r; off = off < 0 ? -off : off;
 			const int mo = __builtin_amdgcn_readlane(wave_incl_scan_max(imp && use ? off : 0), 63);
 			max_off = mo > max_off ? mo : max_off;
 		}
 		const int g = __builtin_amdgcn_readlane(wave_incl_scan_max(use && hist_h1 >= 0 ? (hist_h1 << 6 | lane) : -1), 63);   // the best to-end score, latest row on ties
 		if (g >= 0 && (g >> 6) >= gscore) { max_ie = hist_row0 + (g & 63); gscore = g >> 6; }
-		hist_row0 += cnt; hist_n = 0;
+		hist_row0 += cnt; hist_n = 0; hist_h1 = -1;
 		return zm != 0;
 	};
-	for (int i = 0; i < tlen; ++i) {
-		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
-		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
-		const int8_t *qrow = qp + tb * qs + q0;        // column j's score is qrow[j * qdir]
+	int i = 0;
+	while (i < tlen) {
 		if (beg < i - w) beg = i - w;
 		if (end > i + w + 1) end = i + w + 1;
 		if (end > qlen) end = qlen;
 		beg = uni(beg); end = uni(end);
+		bool stop = false;
+		if (win_ok && end > beg && end - beg <= 63) {
+			const int base = beg, jcol = base + lane;
+			int sth, ste; { const int2 t = eh[jcol]; sth = t.x; ste = t.y; }      // this lane's {H, E} slot (the LDS region is padded by 64 columns)
+			const int8_t *qcol = qp + q0 + jcol * qdir;       // column jcol's score is qcol[tb * qs] (lanes past the band read the profile's padding or its neighbourhood, never past the wave's LDS)
+			const int e_lane = lane == 0 ? W_NEG : e_ins - lane_e;           // (lane 0 has no column to its left: the shift hands it 0, this makes its F the scan's identity)
+			const int qhi = qlen - base;
+			// H(i,-1) = max(h0 - (o_del + e_del * (i + 1)), 0) (ksw.c:452-455), the value column 0's left neighbour hands over: lane 0 of a window that starts at
+			// column 0 counts it down; every other lane, and every lane of a window further right, shifts in H = 0
+			int hdl = lane == 0 && base == 0 ? h0 - (o_del + e_del * (i + 1)) : W_NEG;
+			const int edel0 = lane == 0 ? e_del : 0;
+			int lo = 0, hi = end - base, lo_min = i - w - base, hi_max = i + w + 1 - base;
+			hi = uni(hi);                                     // (without the pin the compiler carries the row loop's control in vector registers and branches on exec masks)
+			int why = 0;                                      // 1: the extension ends (m == 0 or z-drop), 2: the band has left the window
+			do {
+				// a segment: rows up to the next multiple of 64 (the reference bases in treg), the 32nd parked row, or the last row
+				if ((i & 63) == 0) { const int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
+				int i_end = (i | 63) + 1; if (i_end > tlen) i_end = tlen; if (i_end > i + 32 - hist_n) i_end = i + 32 - hist_n;
+				i_end = uni(i_end);
+				int sc_next = qcol[__builtin_amdgcn_readlane(treg, i & 63) * qs];
+				int key;
+				for (;;) {
+					const int sc = sc_next;
+					sc_next = qcol[__builtin_amdgcn_readlane(treg, (i + 1) & 63) * qs];   // the next row's score, in flight while this row computes (past the segment's end: read and dropped)
+					const int nact = hi - lo;
+					const unsigned rel = (unsigned)(lane - lo);
+					const bool act = rel < (unsigned)nact, wr = rel <= (unsigned)nact;
+					const int M = sth ? sth + sc : 0;          // ksw.c:469: a dead diagonal cell stays dead
+					const int hme = imax(M, ste);
+					const int kmax = wave_incl_scan_max(act ? (hme << 11 | jcol) : -1);
+					const int inc = wave_incl_scan_max(act ? imax(M - oe_ins, 0) + lane_e : W_NEG);
+					const int exc = __builtin_amdgcn_update_dpp(0, inc, DPP_WAVE_SHR1, 0xf, 0xf, true);     // best insertion start left of this column
+					const int h = act ? imax(hme, exc + e_lane) : 0;             // H(i,j) = max(M, E, F), ksw.c:470-471
+					const int e_new = act ? imax(imax(ste - e_del, M - oe_del), 0) : 0;   // E(i+1,j), ksw.c:475-479
+					const int hleft = imax(__builtin_amdgcn_update_dpp(0, h, DPP_WAVE_SHR1, 0xf, 0xf, true), hdl);   // eh[j].h after this row = H(i,j-1)
+					hdl -= edel0;
+					sth = wr ? hleft : sth; ste = wr ? e_new : ste;
+					const u64 nz = wave_ballot((hleft | e_new) != 0) & wave_ballot(wr);      // (two compare masks and a scalar AND: the ballot of a conjunction is rebuilt from 0/1 values)
+					key = __builtin_amdgcn_readlane(kmax, 63);
+					hist_k = lane == hist_n ? key : hist_k;
+					if (hi == qhi) {                                  // H(i, end-1) feeds the to-end score (ksw.c:486-489); rows that do not touch the query's end leave the -1 of the last flush
+						const int h1 = __builtin_amdgcn_readlane(hleft, hi);
+						hist_h1 = lane == hist_n ? h1 : hist_h1;
+					}
+					++hist_n; ++i; cells32 += (u32)nact;
+					if (key < 2048) break;                           // m == 0 (ksw.c:490)
+					// band for the next row (ksw.c:502-505): skip leading / trailing columns whose {h,e} are both zero (m > 0, so nz != 0), then its clamps
+					lo = __builtin_ctzll(nz | 1ull << hi);
+					hi = 65 - __builtin_clzll(nz); if (hi > qhi) hi = qhi;
+					++lo_min; ++hi_max;
+					if (lo < lo_min) lo = lo_min;
+					if (hi > hi_max) hi = hi_max;
+					if (hi > 63) break;
+					if (hi <= lo) break;
+					if (i == i_end) break;
+				}
+				if (key < 2048) why = 1;
+				else {
+					if (hi > 63 || hi <= lo) why = 2;
+					if (hist_n == 32 && hist_flush()) why = 1;
+				}
+			} while (why == 0 && i < tlen);
+			if (why == 1) break;
+			eh[jcol] = make_int2(sth, ste);
+			wave_sync();
+			beg = base + lo; end = base + hi;
+			continue;
+		}
+		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
+		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
+		const int8_t *qrow = qp + tb * qs + q0;        // column j's score is qrow[j * qdir]
 		if (RING) {      // first-row values (ksw.c:430-433) for the columns this row can reach for the first time
 			int hi = i + w + 2 < qlen ? i + w + 2 : qlen;
 			if (hi > init_hi) {
@@ -239,47 +331,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		int h1_init = 0;
 		if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
 		cells32 += (u32)(end > beg ? end - beg : 0);
-		bool stop;
-		if (!RING && end - beg <= 63) {
-			// The band fits one pass of the wave with a lane to spare (always, for 150 bp reads).  The kernel is bound by instruction issue --
-			// scalar instructions first (one issue slot per SIMD and four cycles, like the vector ones) -- so this form is written for few of both:
-			//  * a lane reads and writes only its own column: H(i,j) reaches column j+1 by a lane shift, lane 0 takes H(i,beg-1) = h1 as the
-			//    shift's fill value, and the spare lane nact stores column `end` = {H(i,end-1), 0} (ksw.c:485);
-			//  * F's offsets j * e_ins shrink to lane * e_ins: the row's common term beg * e_ins cancels between the scan's input and output;
-			//  * the row maximum is taken over max(M, E) instead of H = max(M, E, F).  F(i,j) <= max(0, max_k M(i,k) - oe_ins) lies strictly
-			//    below a positive row maximum, so neither the maximum nor the "last column wins" choice (ksw.c:473-474) changes -- but the
-			//    maximum's scan no longer waits for F's, and the two six-step DPP chains interleave instead of idling between dependent steps;
-			//  * the band's trimming (ksw.c:502-505) reads one ballot: bit L = column beg+L holds a non-zero {h, e}, column `end` included.
-			const int nact = end - beg;                       // (can be negative: the band has moved past the last live column)
-			const int j = beg + lane; const bool act = lane < nact, wr = lane <= nact;
-			const int2 old = eh[j];                           // (the LDS region is padded by 64 columns)
-			const int sc = qrow[j * qdir];                    // (inactive lanes read the profile's padding or its neighbourhood, never past the wave's LDS)
-			const int M = old.x ? old.x + sc : 0;          // ksw.c:469: a dead diagonal cell stays dead
-			const int hme = imax(M, old.y);
-			const int kmax = wave_incl_scan_max(act ? (hme << 6 | lane) : -1);
-			const int inc = wave_incl_scan_max(act ? imax(M - oe_ins, 0) + lane_e : W_NEG);
-			const int exc = wave_shift_up1(inc, W_NEG);
-			const int f = lane == 0 ? 0 : exc - lane_e + e_ins;         // F(i,j): best insertion ending left of column j
-			const int h = imax(hme, f);                               // H(i,j) = max(M, E, F), ksw.c:470-471
-			const int e_new = act ? imax(imax(old.y - e_del, M - oe_del), 0) : 0;   // E(i+1,j), ksw.c:475-479
-			const int hleft = wave_shift_up1(h, h1_init);             // eh[j].h after this row = H(i,j-1)
-			if (wr) eh[j] = make_int2(hleft, e_new);
-			const u64 nzm = __ballot(wr && (hleft | e_new) != 0);
-			const int key = __builtin_amdgcn_readlane(kmax, 63);
-			wave_sync();
-			int h1 = -1;                                      // H(i, end-1) as left in h1 by the reference's column loop, when it feeds the to-end score (ksw.c:486-489)
-			if ((nact > 0 ? end : beg) == qlen) h1 = nact > 0 ? __builtin_amdgcn_readlane(h, nact - 1) : h1_init;
-			stop = key < 64;                                  // m == 0 (ksw.c:490)
-			{ const bool mine = lane == hist_n; hist_m = mine ? key >> 6 : hist_m; hist_j = mine ? beg + (key & 63) : hist_j; hist_h1 = mine ? h1 : hist_h1; }
-			++hist_n;
-			// band for the next row (ksw.c:502-505): skip leading / trailing columns whose {h,e} are both zero
-			const u64 nz_lo = nzm & ((1ull << (nact & 63)) - 1);
-			const int nbeg = nz_lo ? beg + __builtin_ctzll(nz_lo) : end;
-			const int jl = nzm ? beg + 63 - __builtin_clzll(nzm) : nbeg - 1;
-			beg = nbeg;
-			end = jl + 2 < qlen ? jl + 2 : qlen;
-			if (hist_n == 32 || stop) stop = hist_flush() || stop;
-		} else {
+		{
 		if (hist_flush()) break;                         // (rows of the other forms keep their bookkeeping per row: bring the state up to date first)
 		hist_row0 = i + 1;
 		int m = 0, mj = -1, carry = W_NEG, hprev = h1_init, first_nz = -1, last_nz = -1, bnd = 0;
@@ -391,6 +443,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		end = jl + 2 < qlen ? jl + 2 : qlen;
 		}
 		if (stop) break;
+		++i;
 	}
 	hist_flush();
 	#undef EHI
