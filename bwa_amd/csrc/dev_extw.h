@@ -314,6 +314,86 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			beg = base + lo; end = base + hi;
 			continue;
 		}
+		if (win_ok && end - beg > 63 && end - beg <= 127) {
+			// The same with two adjacent columns per lane (64..127 columns: the longer half of a 150 bp read's extensions): lane L owns columns base + 2L ("A") and
+			// base + 2L + 1 ("B"), so a row still takes ONE prefix scan for F and one for the row maximum.  H(i, A) reaches column B inside the lane, H(i, B) reaches
+			// the next lane's A by the shift.  The band's bits come as two ballots (even and odd columns); the trimming reads them lane-wise.
+			const int base = beg, jA = base + 2 * lane, jB = jA + 1;
+			int shA = 0, seA = 0, shB = 0, seB = 0;          // the lane's two {H, E} slots (columns past the query's end: never in a band, neither loaded nor stored)
+			if (jA <= qlen) { const int2 t = eh[jA]; shA = t.x; seA = t.y; }
+			if (jB <= qlen) { const int2 t = eh[jB]; shB = t.x; seB = t.y; }
+			const int8_t *qcA = qp + q0 + (jA < qlen ? jA : qlen - 1) * qdir, *qcB = qp + q0 + (jB < qlen ? jB : qlen - 1) * qdir;
+			const int lane_e2 = 2 * lane_e;
+			const int e_laneA = lane == 0 ? W_NEG : e_ins - lane_e2;
+			const int qhi = qlen - base;
+			int hdl = lane == 0 && base == 0 ? h0 - (o_del + e_del * (i + 1)) : W_NEG;
+			const int edel0 = lane == 0 ? e_del : 0;
+			int lo = 0, hi = end - base, lo_min = i - w - base, hi_max = i + w + 1 - base;
+			hi = uni(hi);
+			int why = 0;
+			do {
+				if ((i & 63) == 0) { const int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
+				int i_end = (i | 63) + 1; if (i_end > tlen) i_end = tlen; if (i_end > i + 32 - hist_n) i_end = i + 32 - hist_n;
+				i_end = uni(i_end);
+				int scA_next, scB_next; { const int o = __builtin_amdgcn_readlane(treg, i & 63) * qs; scA_next = qcA[o]; scB_next = qcB[o]; }
+				int key;
+				for (;;) {
+					const int scA = scA_next, scB = scB_next;
+					{ const int o = __builtin_amdgcn_readlane(treg, (i + 1) & 63) * qs; scA_next = qcA[o]; scB_next = qcB[o]; }
+					const int nact = hi - lo;
+					const unsigned relA = (unsigned)(2 * lane - lo), relB = relA + 1;
+					const bool actA = relA < (unsigned)nact, wrA = relA <= (unsigned)nact, actB = relB < (unsigned)nact, wrB = relB <= (unsigned)nact;
+					const int MA = shA ? shA + scA : 0, MB = shB ? shB + scB : 0;          // ksw.c:469
+					const int hmA = imax(MA, seA), hmB = imax(MB, seB);
+					const int kmax = wave_incl_scan_max(imax(actA ? (hmA << 11 | jA) : -1, actB ? (hmB << 11 | jB) : -1));   // last column wins ties (ksw.c:473-474)
+					const int aA = actA ? imax(MA - oe_ins, 0) + lane_e2 : W_NEG, aB = actB ? imax(MB - oe_ins, 0) + lane_e2 + e_ins : W_NEG;
+					const int exc = __builtin_amdgcn_update_dpp(0, wave_incl_scan_max(imax(aA, aB)), DPP_WAVE_SHR1, 0xf, 0xf, true);   // best insertion start among the columns of the lanes below
+					const int hA = actA ? imax(hmA, exc + e_laneA) : 0;                         // ksw.c:470-471
+					const int hB = actB ? imax(hmB, imax(exc, aA) - lane_e2) : 0;
+					const int eA = actA ? imax(imax(seA - e_del, MA - oe_del), 0) : 0, eB = actB ? imax(imax(seB - e_del, MB - oe_del), 0) : 0;   // ksw.c:475-479
+					const int hleftA = imax(__builtin_amdgcn_update_dpp(0, hB, DPP_WAVE_SHR1, 0xf, 0xf, true), hdl);   // H(i, A - 1): the lane below's column B
+					hdl -= edel0;
+					shA = wrA ? hleftA : shA; seA = wrA ? eA : seA;
+					shB = wrB ? hA : shB; seB = wrB ? eB : seB;
+					const u64 mwA = wave_ballot(wrA), mwB = wave_ballot(wrB);
+					const u64 nzA = wave_ballot((hleftA | eA) != 0) & mwA, nzB = wave_ballot((hA | eB) != 0) & mwB;
+					// column `end` (in one of the two write masks, in neither set of live columns) stands in for "none" in the search from the left
+					const u64 xA = nzA | (mwA & ~wave_ballot(actA)), xB = nzB | (mwB & ~wave_ballot(actB));
+					key = __builtin_amdgcn_readlane(kmax, 63);
+					hist_k = lane == hist_n ? key : hist_k;
+					if (hi == qhi) {                                  // H(i, end-1), what column `end` has just stored (ksw.c:485-489)
+						const int h1 = (hi & 1) ? __builtin_amdgcn_readlane(hA, hi >> 1) : __builtin_amdgcn_readlane(hleftA, hi >> 1);
+						hist_h1 = lane == hist_n ? h1 : hist_h1;
+					}
+					++hist_n; ++i; cells32 += (u32)nact;
+					if (key < 2048) break;                           // m == 0 (ksw.c:490)
+					// band for the next row (ksw.c:502-505), lane-wise: the first lane with a non-zero column (or column `end`) and whether that is its A, the last
+					// lane with a non-zero column and whether that is its B (m > 0, so there is one)
+					{
+						const int lf = __builtin_ctzll(xA | xB), ll = 63 - __builtin_clzll(nzA | nzB);
+						lo = 2 * lf + 1 - (int)(xA >> lf & 1);
+						hi = 2 * ll + (int)(nzB >> ll & 1) + 2; if (hi > qhi) hi = qhi;
+					}
+					++lo_min; ++hi_max;
+					if (lo < lo_min) lo = lo_min;
+					if (hi > hi_max) hi = hi_max;
+					if (hi > 127) break;
+					if (hi - lo <= 63) break;                        // (narrow enough for a column per lane, or empty)
+					if (i == i_end) break;
+				}
+				if (key < 2048) why = 1;
+				else {
+					if (hi > 127 || hi - lo <= 63) why = 2;
+					if (hist_n == 32 && hist_flush()) why = 1;
+				}
+			} while (why == 0 && i < tlen);
+			if (why == 1) break;
+			if (jA <= qlen) eh[jA] = make_int2(shA, seA);
+			if (jB <= qlen) eh[jB] = make_int2(shB, seB);
+			wave_sync();
+			beg = base + lo; end = base + hi;
+			continue;
+		}
 		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
 		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
 		const int8_t *qrow = qp + tb * qs + q0;        // column j's score is qrow[j * qdir]

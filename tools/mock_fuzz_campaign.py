@@ -2,7 +2,7 @@
 """Long seeded fuzz of the device code on the mock runtime (CPU only; tests/hostsim): the suite's own fuzz drivers -- kernel-level DP
 cases vs the reference's ksw_* (tests/test_dp_fuzz.py) and random mem_opt_t draws through the whole hot path vs the reference's
 mem_align1_core (tests/test_opt_fuzz.py) -- with fresh seeds, round after round, under the default configuration and under the
-switchable kernel forms.  Every switch is read per call, so one process covers them all.  A failure prints the seed and the
+switchable kernel forms (library options, set per handle and batch).  A failure prints the seed and the
 configuration and the campaign goes on; the summary line at the end counts them.
 
 usage: mock_fuzz_campaign.py [--minutes M] [--seed0 S] [--only dp|opt]
@@ -17,31 +17,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-DP_ENVS = [{}, {"BWAGPU_LONG_QLDS": "1"}, {"BWAGPU_DEDUP_BLK": "1", "BWAGPU_EXT_BLK": "1"}, {"BWAGPU_EXT_BLK": "1", "BWAGPU_LONG_QLDS": "1"}]
-OPT_ENVS = [
+DP_SETS = [{}, {"dedup_blk": 0}, {"seedsw_lds": 0}]
+OPT_SETS = [
     {},
-    {"BWAGPU_SEED_MRG": "1"},
-    {"BWAGPU_SEED_MRG": "2", "BWAGPU_SEED_LDS_ENT": "2"},
-    {"BWAGPU_SEED_MRG": "2", "BWAGPU_PUBLISH_BLK": "1", "BWAGPU_LONG_QLDS": "1", "BWAGPU_SEEDSW_LDS": "1", "BWAGPU_SEED_CHUNK": "128", "BWAGPU_DEDUP_BLK": "1", "BWAGPU_EXT_BLK": "1"},
-    {"BWAGPU_SEED_CHUNK": "256", "BWAGPU_SEEDSW_LDS": "1"},
-    {"BWAGPU_OCC32": "0"},
-    {"BWAGPU_PTAB_M": "6", "BWAGPU_SEED_LDS_ENT": "3"},
-    {"BWAGPU_CHAIN_LDS": "0"},
+    {"seed_mrg": 0},
+    {"seed_mrg": 2, "seed_lds_ent": 2},
+    {"seed_budget": 150, "seed_p2_cap": 2},
+    {"seed_tasks": 0, "publish_blk": 0, "seedsw_lds": 0, "dedup_blk": 0},
+    {"seed_task_stack": 2, "seed_lds_ent": 3},
+    {"occ32": 0},
+    {"ptab_m": 6, "seed_lds_ent": 3},
+    {"chain_lds": 0},
+    {"ext_occ": 4},
 ]
-LAYOUT = ("BWAGPU_OCC32", "BWAGPU_OCC32_SB_SHIFT", "BWAGPU_PTAB_M")     # read when the index is laid out: such a set gets a handle of its own
+LAYOUT = ("occ32", "occ32_sb_shift", "ptab_m")     # applied when the index is laid out: such a set gets a handle of its own
 
 
-def with_env(env, fn):
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
+def with_options(dev, sets, fn):
+    """Run fn with the per-batch options of `sets` set on the handle (bwagpu_set_option), then put the old values back."""
+    old = {k: dev.get_option(k) for k in sets if k not in LAYOUT}
+    for k in old:
+        dev.set_option(k, sets[k])
     try:
         return fn()
     finally:
         for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
+            dev.set_option(k, v)
 
 
 def main():
@@ -65,7 +66,7 @@ def main():
 
     def attempt(what, env, fn):
         try:
-            with_env(env, fn)
+            with_options(sim, env, fn)
         except Exception as e:
             if isinstance(e, AssertionError) and (not str(e) or str(e).startswith("no case")):     # the drivers' own coverage checks ("no case took the
                 print(f"note {what} seed {seed}: a draw without one of the covered situations", flush=True)      # diagonal shortcut"): not a difference
@@ -79,7 +80,7 @@ def main():
         seed += 1
         rounds += 1
         if args.only != "opt":
-            env = DP_ENVS[rounds % len(DP_ENVS)]
+            env = DP_SETS[rounds % len(DP_SETS)]
             attempt("extend", env, lambda: dp.run_extend(sim, 0, 400, 200, seed, need_stale=False))
             attempt("extend_ring", env, lambda: dp.run_extend(sim, 1, 150, 400, seed, need_stale=False, very_wide=6))
             attempt("global_lds", env, lambda: dp.run_global(sim, 2, 200, 160, 192, seed))
@@ -88,11 +89,11 @@ def main():
             attempt("global_long", env, lambda: dp.run_global(sim, 5, 40, 500, 1900, seed))
             attempt("align2", env, lambda: dp.run_align2(sim, 40, seed))
         if args.only != "dp":
-            env = OPT_ENVS[rounds % len(OPT_ENVS)]
+            env = OPT_SETS[rounds % len(OPT_SETS)]
 
             def opt_round():
                 own = any(k in LAYOUT for k in env)
-                dev = BwaGpu(prefix, lib_path=lib) if own else sim
+                dev = BwaGpu(prefix, lib_path=lib, options={k: v for k, v in env.items() if k in LAYOUT}) if own else sim
                 try:
                     of.run_region_fuzz(dev, ref, g, draws=12, n_short=24, n_long=2, long_len=1500, seed=seed)
                 finally:
