@@ -453,7 +453,8 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			// RING: a lane's query base comes from the batch's array in HBM -- a dependent global load (an L1/L2 hit: 200-500 cycles) in front of every
 			// pass of every row, at one wave per SIMD where nothing hides it (measured: ~100 ms of wave time per 10 kb read, profiles/r04_longread_wave_time_per_read.log).
 			// The addresses are known long before: the base of pass b + 64 is asked for when pass b starts, the first pass's base when the ROW BEFORE
-			// starts (for the usual case that the band moves on by one column; anything else loads it here).
+			// starts (for the usual case that the band moves on by one column; anything else loads it here).  (Measured on 6000 x 10 kb reads: the stage's
+			// time did not move, 361-411 ms either way -- the row's dependent DPP/LDS chain at one wave per SIMD is the longer wait; kept because it is never slower.)
 			int qc_next = 4;
 			if (RING) {
 				const int j0 = beg + lane;

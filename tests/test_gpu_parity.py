@@ -174,7 +174,7 @@ def test_index_access_variants_give_identical_results(medium):
     base = gpu.align(default_opt(), seqs, off)
     n0, iv0 = gpu.tap_intervals()
     assert_regs_equal(*ref.align(default_opt(), seqs, off), *base, "32-byte blocks vs compiled reference")
-    for env in ({"occ32": 0}, {"occ32": 0, "ptab_m": 0}, {"ptab_m": 0}, {"ptab_m": 7}, {"seed_mrg": 2}, {"seed_mrg": 2, "seed_lds_ent": 2}):
+    for env in ({"occ32": 0}, {"occ32": 0, "ptab_m": 0}, {"ptab_m": 0}, {"ptab_m": 7}, {"seed_mrg": 0}, {"seed_mrg": 2}, {"seed_mrg": 2, "seed_lds_ent": 2}):
         g2 = BwaGpu(fa, options=env)
         assert_regs_equal(*base, *g2.align(default_opt(), seqs, off), f"{env}, sa_intv 32")
         n1, iv1 = g2.tap_intervals()

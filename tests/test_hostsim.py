@@ -138,7 +138,7 @@ def test_hostsim_seeding_variants_same_intervals():
     seqs, off = testdata.ragged(reads)
     opt = default_opt(); opt.min_chain_weight = 1 << 20
     got = {}
-    for name, options in (("default", {}), ("mrg2", {"seed_mrg": 2}),
+    for name, options in (("default", {}), ("mrg0", {"seed_mrg": 0}), ("mrg2", {"seed_mrg": 2}),
                           ("mrg2 small stack", {"seed_mrg": 2, "seed_lds_ent": 2}), ("mrg2 no read copy", {"seed_mrg": 2, "seed_rd_lds": 0})):
         s2 = sim_handle(prefix, **options)
         c, r = s2.align(opt, seqs, off)
