@@ -2,6 +2,7 @@
 // Mirrors the reference's `bwa mem` (fastmap.c:141-406): same option letters and meaning, same batching rule
 // (chunk_size * n_threads bases per batch unless -K, fastmap.c:394), same SAM header (bwa.c:407-439), so that for the same
 // input and the same -K the output equals `bwa mem`'s except for the @PG line.
+#include <signal.h>
 #include <ctype.h>
 #include <errno.h>
 #include <fcntl.h>
@@ -336,6 +337,17 @@ struct ParFile {
 		{ std::lock_guard<std::mutex> l(m); io_done = true; }
 		cv.notify_all();
 	}
+	// A mapped file that is truncated while it is being read raises SIGBUS in whichever thread touches the missing pages; without a handler that is a
+	// silent crash of a long run.  The handler can only say so and leave (async-signal-safe calls only).
+	static void on_sigbus(int) {
+		static const char msg[] = "[bwa-amd] SIGBUS: an input file shrank while it was being read (plain FASTQ files are mapped); no SAM after this point is valid\n";
+		if (::write(2, msg, sizeof msg - 1) < 0) {}
+		_exit(74);                                                   // EX_IOERR
+	}
+	static void guard_mapped_input() {
+		static std::once_flag once;
+		std::call_once(once, [] { struct sigaction sa; memset(&sa, 0, sizeof sa); sa.sa_handler = on_sigbus; sigemptyset(&sa.sa_mask); sigaction(SIGBUS, &sa, nullptr); });
+	}
 	bool open(const char *fn, ParPool *pl) {      // true: this file is read in blocks
 		const int f = ::open(fn, O_RDONLY);
 		if (f < 0) return false;
@@ -347,6 +359,8 @@ struct ParFile {
 			if (mp == MAP_FAILED) { ::close(f); return false; }
 			madvise(mp, size, MADV_SEQUENTIAL);
 			map = (const char*)mp;
+			guard_mapped_input();
+			if (getenv("BWAGPU_CLI_TEST_SHRINK") && truncate(fn, (off_t)(size / 8192 * 4096)) != 0) {}   // (tests: the file loses its second half under the mapping)
 		}
 		fd = f; path = fn; pool = pl;
 		if (getenv("BWAGPU_CLI_PAR_BLOCK")) { blk = (size_t)atoll(getenv("BWAGPU_CLI_PAR_BLOCK")); if (blk < 16) blk = 16; }   // (tests: cuts in every position)

@@ -334,3 +334,23 @@ def test_cli_hostsim_dashes_among_the_bases(tmp_path):
     K = ["-K", "100000000", "-t", "2"]
     for args in ([files[0]], files):
         assert _run(refapi.REF_BWA, K + [prefix] + args) == _run(cli, K + [prefix] + args, env), f"{len(args)} file(s)"
+
+
+def test_cli_input_file_that_shrinks_under_the_mapping(tmp_path):
+    """Plain FASTQ files are mapped by the block-parallel input stage; a file truncated while it is being read raises SIGBUS in whichever parser
+    thread touches the missing pages.  The command line must say so and leave with EX_IOERR instead of dying silently.  The test
+    hook BWAGPU_CLI_TEST_SHRINK cuts the file in half right after it has been mapped."""
+    prefix, g = testdata.small_index()
+    cli = _sim_cli()
+    a = simdata._ASCII
+    rng = np.random.default_rng(5)
+    fq = os.path.join(str(tmp_path), "big.fq")
+    with open(fq, "wb") as f:
+        for i in range(3000):
+            seq = bytes(a[rng.integers(0, 4, 150)])
+            f.write(b"@r%d\n" % i + seq + b"\n+\n" + b"I" * 150 + b"\n")
+    assert os.path.getsize(fq) > 4 * 8192
+    env = dict(os.environ, BWAGPU_CLI_PARSE_ONLY="1", BWAGPU_CLI_PARSE_THREADS="2", BWAGPU_CLI_PAR_BLOCK="65536", BWAGPU_CLI_TEST_SHRINK="1")
+    p = subprocess.run([cli, "mem", prefix, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert p.returncode == 74, (p.returncode, p.stderr.decode()[-500:])
+    assert b"SIGBUS" in p.stderr and b"shrank" in p.stderr
