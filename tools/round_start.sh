@@ -1,26 +1,23 @@
 #!/bin/bash
 # First GPU call of a round (run through gpurun, ~20 box-minutes): what was built behind switches without a GPU at hand gets its
 # numbers in one go.  Results land under gpurun_out/<tag>/; copy what is to be kept into profiles/.
-#   /usr/local/graft/bin/gpurun --timeout 2100 -- 'bash tools/round_start.sh r04'
+#   /usr/local/graft/bin/gpurun --timeout 2100 -- 'bash tools/round_start.sh r05'
 # 0. if tools/quick_gpu_prepare.py has been run on the CPU box: the defaults and every switchable kernel form against `bwa mem` digests (seconds)
 # 1. the -m gpu suite (parity first: a failing test ends the script -- fix that before anything is timed)
-# 2. the full default bench line; its `variants` object A/Bs the switchable kernel forms against the defaults on the same batches
-#    (short reads: BWAGPU_SEED_MRG=1 / 2; long reads: BWAGPU_SEED_MRG=2, BWAGPU_SEED_CHUNK=256, BWAGPU_PUBLISH_BLK=1,
-#    BWAGPU_LONG_QLDS=1, BWAGPU_SEEDSW_LDS=1, BWAGPU_DEDUP_BLK=1, BWAGPU_EXT_BLK=1, all together and each alone) with a digest that must equal the defaults'
+# 2. the full default bench line; its `variants` object A/Bs option settings (bwagpu_set_option names) against the defaults on the same batches
+#    (short reads: seed_mrg=0, ext_occ=4; long reads: the round-3 kernel forms together and each alone) with a digest that must equal the defaults'
 # 3. kernel trace + FETCH_SIZE / WRITE_SIZE + SQ counters of the default configuration (tools/profile_round.sh); to profile a
-#    variant that won in step 2, run e.g.  BWAGPU_SEED_MRG=2 bash tools/profile_round.sh r04_mrg2  in a later call
+#    variant that won in step 2, run e.g.  BWAGPU_SEED_MRG=0 bash tools/profile_round.sh r05_mrg0  in a later call
 # 4. kernel stats of `bwa-amd mem` itself on the bench's FASTQ files (hot path + CIGAR + mate-rescue kernels side by side)
-# Further configurations for step 2's probe can be given as extra arguments, e.g.  "BWAGPU_SEED_MRG=2 BWAGPU_PTAB_M=12".
-tag=${1:-r04}; shift
+# Further configurations for step 2's probe can be given as extra arguments, e.g.  "seed_mrg=0 ptab_m=12".
+tag=${1:-r05}; shift
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag; mkdir -p $out
 if [ -e tests/_data/quick/expected.txt ]; then bash tools/quick_gpu_check.sh > $out/quick.log 2>&1; bash tools/quick_gpu_variants.sh >> $out/quick.log 2>&1; grep -c OK $out/quick.log; grep MISMATCH $out/quick.log; fi
 timeout 900 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1 || { tail -30 $out/pytest_gpu.log; echo "GPU SUITE FAILED"; exit 1; }
 tail -3 $out/pytest_gpu.log
-# (--long-sample 2000: the long-read parity prefix and its CPU baseline on 2000 reads instead of the default 128 -- ~10 s of reference time,
-#  as the measurement contract asks; make it the default once it has passed here)
-timeout 800 python bench.py --long-sample 2000 > $out/bench.json 2> $out/bench.log; echo "bench rc $?"; tail -c 800 $out/bench.json; echo
+timeout 800 python bench.py > $out/bench.json 2> $out/bench.log; echo "bench rc $?"; tail -c 800 $out/bench.json; echo
 C=/tmp/bwa_amd_bench
 P=$(ls $C/*.bwt 2>/dev/null | head -1); P=${P%.bwt}
 if [ -n "$P" ] && [ $# -gt 0 ]; then
