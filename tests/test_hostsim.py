@@ -695,3 +695,52 @@ def test_hostsim_heavy_reads_seeded_by_tasks():
         for k in got:
             assert got[k] == got["lane per read"], (name, k)
     orc.close()
+
+
+def test_hostsim_option_api_semantics(monkeypatch):
+    """include/bwagpu.h's option calls: the names enumerate (bwagpu_option_name) and match bwagpu_config.h's list; an unknown name is
+    BWAGPU_EINVAL for all three setters/getters; a handle takes compiled-in default <- BWAGPU_<NAME> in the environment AT CREATION <-
+    bwagpu_set_default_option; a clone copies its parent's values; bwagpu_set_option changes one handle only; and the environment is not
+    read again after creation (no batch call may depend on it)."""
+    import ctypes as C
+    lib = hostsim_build.build()
+    prefix, g = testdata.small_index()
+    a = BwaGpu(prefix, lib_path=lib)
+    L = a.L
+    L.bwagpu_option_name.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+    names = []
+    for i in range(200):
+        p = C.c_char_p()
+        if L.bwagpu_option_name(i, C.byref(p)) != 0:
+            break
+        names.append(p.value.decode())
+    import re
+    listed = re.findall(r"^\s*X\((\w+),", open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bwa_amd", "csrc", "bwagpu_config.h")).read(), flags=re.M)
+    assert names == listed and "seed_budget" in names and len(set(names)) == len(names)
+    v = C.c_longlong()
+    assert L.bwagpu_get_option(a.h, b"no_such_option", C.byref(v)) != 0
+    assert L.bwagpu_set_option(a.h, b"no_such_option", 1) != 0
+    assert L.bwagpu_set_default_option(b"no_such_option", 1) != 0
+    assert a.get_option("seed_budget") == -1 and a.get_option("ext_occ") == 6
+    # environment: read when a handle is created, never afterwards
+    monkeypatch.setenv("BWAGPU_EXT_OCC", "4")
+    assert a.get_option("ext_occ") == 6
+    b = BwaGpu(prefix, lib_path=lib)
+    assert b.get_option("ext_occ") == 4
+    monkeypatch.delenv("BWAGPU_EXT_OCC")
+    assert b.get_option("ext_occ") == 4
+    # defaults given through the API win over the environment's absence, reach later handles only, and can be forgotten
+    assert L.bwagpu_set_default_option(b"seed_budget", 1234) == 0
+    c = BwaGpu(prefix, lib_path=lib)
+    assert c.get_option("seed_budget") == 1234 and a.get_option("seed_budget") == -1
+    L.bwagpu_clear_default_options()
+    d = BwaGpu(prefix, lib_path=lib)
+    assert d.get_option("seed_budget") == -1
+    # per handle; clones copy
+    c.set_option("dedup_ring", 512)
+    c2 = c.clone()
+    assert c2.get_option("dedup_ring") == 512 and c2.get_option("seed_budget") == 1234 and d.get_option("dedup_ring") == 0
+    c2.set_option("dedup_ring", 1024)
+    assert c.get_option("dedup_ring") == 512
+    for h_ in (c2, c, d, b, a):
+        h_.close()
