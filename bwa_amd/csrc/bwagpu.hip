@@ -660,6 +660,15 @@ extern "C" int bwagpu_debug_hist(bwagpu_t *h, unsigned long long out[256])
 	for (int i = 0; i < 96; ++i) { out[64 + i] = c.wave_hist[0][i]; out[160 + i] = c.wave_hist[1][i]; }
 	return BWAGPU_OK;
 }
+// ... and of the chaining tiers: out[t * 64 + b] = reads that finished in tier t with 16 b .. 16 b + 15 chains (b = 31: more), out[t * 64 + 32 + b] = with 32 b .. 32 b + 31 seeds
+extern "C" int bwagpu_debug_chain_hist(bwagpu_t *h, unsigned long long out[192])
+{
+	if (!h || !out || !h->d_ctr.p) return BWAGPU_EINVAL;
+	Counters c;
+	if (hipMemcpy(&c, h->d_ctr.p, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return BWAGPU_EHIP;
+	for (int t = 0; t < 3; ++t) for (int i = 0; i < 32; ++i) { out[t * 64 + i] = c.chain_hist[t][i]; out[t * 64 + 32 + i] = c.chain_seeds[t][i]; }
+	return BWAGPU_OK;
+}
 extern "C" int bwagpu_set_stats(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->stats_on = enable ? 1 : 0; return BWAGPU_OK; }
 extern "C" int bwagpu_set_cigar_filter(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->cigar_filter = enable ? 1 : 0; return BWAGPU_OK; }
 extern "C" int bwagpu_set_taps(bwagpu_t *h, int enable) { if (!h) return BWAGPU_EINVAL; h->taps_on = enable ? 1 : 0; return BWAGPU_OK; }

@@ -293,6 +293,10 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 		}
 	}
 	n_visits += visits; n_recs += recs;
+	if (B.stats && lane == 0) {      // (diagnostics: the reads that finish in this tier, by chains and by seeds -- bwagpu_debug_chain_hist)
+		const int t = NC == 0 ? 2 : SC > 0 ? 0 : 1, cb = n_ch / 16 < 31 ? n_ch / 16 : 31, sb = ns / 32 < 31 ? ns / 32 : 31;
+		atomicAdd(&B.ctr->chain_hist[t][cb], 1ull); atomicAdd(&B.ctr->chain_seeds[t][sb], 1ull);
+	}
 	if (lane == 0) { B.chain_n[r] = 0; B.reg_off[r] = 0; B.reg_cap_r[r] = 0; B.reg_n_raw[r] = 0; B.reg_n[r] = 0; }
 	if (n_ch == 0) return true;
 	// Fraction of the read covered by over-abundant seeds (bwamem.c:291-298).  The reference merges the intervals -- sorted by

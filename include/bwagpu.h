@@ -208,6 +208,9 @@ int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16]);
  * the time their wave spent on them (bin b: [2^(b-1), 2^b) x 10 ns), then per bin the ksw_extend2 calls and the DP cells (>> 10) of those reads;
  * out[160..256): the same for the wave-per-read de-duplication kernel (long reads) and its patch alignments. */
 int bwagpu_debug_hist(bwagpu_t *h, unsigned long long out[256]);
+/* Diagnostics (stats on): the chaining tiers' reads by size.  out[t * 64 + b] = reads that finished in tier t (0, 1: the LDS tiers, 2: the HBM tier)
+ * with 16 b .. 16 b + 15 chains (before the chain filter) (b = 31: more); out[t * 64 + 32 + b] = with 32 b .. 32 b + 31 seeds (tools/seed_iter_probe.py). */
+int bwagpu_debug_chain_hist(bwagpu_t *h, unsigned long long out[192]);
 
 /* ---- differential tests of the device DP routines ----------------------------------------------------------------------- */
 /* One case of bwagpu_debug_dp.  Sequences are nt4 codes in the call's `seqs` array: the query may hold 0..4, the target 0..3 (the

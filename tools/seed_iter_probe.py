@@ -50,6 +50,13 @@ for cfg in (sys.argv[1:] or [""]):
         gpu.L.bwagpu_debug_hist.argtypes = [C.c_void_p, C.c_void_p]
         gpu.L.bwagpu_debug_hist(gpu.h, hist)
         tot_r = max(sum(hist[:32]), 1); tot_i = max(sum(hist[32:]), 1)
+        ch = (C.c_ulonglong * 192)()
+        gpu.L.bwagpu_debug_chain_hist.argtypes = [C.c_void_p, C.c_void_p]
+        gpu.L.bwagpu_debug_chain_hist(gpu.h, ch)
+        for t in range(3):
+            tot = max(sum(ch[t * 64: t * 64 + 32]), 1)
+            print(f"    chaining tier {t}: {tot} reads; by chains (x16): " + " ".join(f"{b}:{ch[t * 64 + b]}" for b in range(32) if ch[t * 64 + b])
+                  + " | by seeds (x32): " + " ".join(f"{b}:{ch[t * 64 + 32 + b]}" for b in range(32) if ch[t * 64 + 32 + b]), flush=True)
         print("    iterations per read: " + ", ".join(f"<{1 << b}: {100.0 * hist[b] / tot_r:.1f}% of reads / {100.0 * hist[32 + b] / tot_i:.1f}% of iterations" for b in range(32) if hist[b]), flush=True)
     for k, v in old.items():
         gpu.set_option(k, v)
