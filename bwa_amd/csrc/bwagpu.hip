@@ -1088,7 +1088,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		if (h->max_len <= WAVE_EXT_MAX_LEN && max_score < (1 << 24)) {
 			int lds_wave = (8 * (h->max_len + 2 + 64) + 5 * ((h->max_len + 64 + 3) & ~3) + 32 + 15) & ~15;   // {H,E} columns, query profile, scoring matrix
 			i64 nblk = ((i64)n + 3) / 4, cap = share(256 * 6);       // (six workgroups per CU are resident at 6 waves per SIMD)
-			const int occ = (int)cfg.ext_occ;   // waves per SIMD the register allocation aims at (measured at 3.1 Gbp in round 2: 4 -> 63 ms, 5 -> 58 ms, 6 -> 56 ms; the instance for 5 is gone -- hipcc 7.2 fails on it with an unaligned 64-bit spill reload)
+			const int occ = (int)cfg.ext_occ;   // waves per SIMD the register allocation aims at (measured at 3.1 Gbp in round 2: 4 -> 63 ms, 5 -> 58 ms, 6 -> 56 ms; round 4, with the window rows: 4 -> 37.9, 5 -> 37.0-38.3, 6 -> 35.4-36.1 ms; the instance for 5 is not built -- one state of the source made hipcc 7.2 fail on it with an unaligned 64-bit spill reload, and it never won)
 			const dim3 g((unsigned)(nblk < cap ? nblk : cap));
 			if (occ == 4) hipLaunchKernelGGL((k_extend_wave<false, 4>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
 			else hipLaunchKernelGGL((k_extend_wave<false, 6>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
