@@ -54,9 +54,10 @@ DEVFN int cw_search(const NodeRegs &nr, i64 pos, int lane, int &r)
 	const int n = nr_n(nr);
 	if (n == 0) return -1;
 	const bool in = lane < n;
-	const int lo = __popcll(__ballot(in && nr.key < pos));    // keys are sorted: lower bound = number of smaller keys
+	const u64 m_in = wave_ballot(in);                         // (two compare masks and a scalar AND: the ballot of a conjunction is rebuilt from 0/1 values)
+	const int lo = __popcll(wave_ballot(nr.key < pos) & m_in);    // keys are sorted: lower bound = number of smaller keys
 	if (lo == n) { r = 1; return n - 1; }
-	const bool eq = (__ballot(in && nr.key == pos) >> lo) & 1;
+	const bool eq = ((wave_ballot(nr.key == pos) & m_in) >> lo) & 1;
 	r = eq ? 0 : -1;
 	return eq ? lo : lo - 1;
 }

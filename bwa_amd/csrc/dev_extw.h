@@ -230,7 +230,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		const u64 zm = __ballot(zb);
 		const int last = zm ? __builtin_ctzll(zm) : cnt - 1;                 // the last row that counts
 		const bool use = lane <= last;
-		const u64 im = __ballot(imp && use);
+		const u64 im = wave_ballot(imp) & wave_ballot(use);
 		if (im) {
 			const int l = 63 - __builtin_clzll(im);                          // the raises are strictly increasing: the last one holds the maximum
 			max = __builtin_amdgcn_readlane(hm, l); max_i = hist_row0 + l; max_j = __builtin_amdgcn_readlane(hj, l);
@@ -441,7 +441,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			const int hleftA = wave_shift_up1(hB, h1_init);                       // H(i, jA-1): the lane below's second column
 			if (jA <= end) eh[jA] = make_int2(hleftA, actA ? eA : 0);                 // (column `end` gets {h1, 0}, ksw.c:485)
 			if (jB <= end) eh[jB] = make_int2(hA, actB ? eB : 0);
-			const u64 nzA = __ballot(actA && (hleftA | eA) != 0), nzB = __ballot(actB && (hA | eB) != 0);
+			const u64 nzA = wave_ballot((hleftA | eA) != 0) & wave_ballot(actA), nzB = wave_ballot((hA | eB) != 0) & wave_ballot(actB);
 			if (nzA | nzB) {
 				const int fa = nzA ? 2 * __builtin_ctzll(nzA) : 1 << 20, fb = nzB ? 2 * __builtin_ctzll(nzB) + 1 : 1 << 20;
 				const int la = nzA ? 2 * (63 - __builtin_clzll(nzA)) : -1, lb = nzB ? 2 * (63 - __builtin_clzll(nzB)) + 1 : -1;
@@ -493,7 +493,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 				}
 				if (j == beg) eh[EHI(j)].x = h1_init;
 				const int hleft = wave_shift_up1(h, hprev);               // eh[j].h after this row = H(i,j-1)
-				const u64 nzm = __ballot(act && (hleft | e_new) != 0);
+				const u64 nzm = wave_ballot((hleft | e_new) != 0) & wave_ballot(act);
 				if (nzm) { if (first_nz < 0) first_nz = b + __ffsll((unsigned long long)nzm) - 1; last_nz = b + 63 - __clzll((long long)nzm); }
 				// row maximum with "last column wins ties" (ksw.c:473-474): one scan over (h << 6 | lane)
 				const int key = __builtin_amdgcn_readlane(wave_incl_scan_max(act ? (h << 6 | lane) : -1), 63);
