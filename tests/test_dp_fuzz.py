@@ -118,6 +118,29 @@ def wide_band_cases(rng, n):
     return cs
 
 
+def window_cases(rng, n, max_len):
+    """Long, good diagonals for the register-resident row forms of the short-read kernel (dev_extw.h, "window rows"): hundreds of rows, so that a
+    window of 64 (or 128) columns is re-based several times, the parked rows are evaluated every 32 rows and at the 64-row boundaries of the
+    reference bases, and the last rows touch the query's end (to-end score).  Narrow bands (w 4..40) make the band's clamps move it by exactly one
+    column per row; h0 and the divergence set how wide the live band is, so the rows drift between the one-column and the two-column form; a
+    diverged stretch in the middle lets the zero-trimming bite and, with the option sets that have a small zdrop, ends the extension inside a
+    run of parked rows."""
+    cs = CaseSet()
+    for it in range(n):
+        qlen = int(rng.integers(max_len // 2, max_len - 1))
+        tlen = qlen + int(rng.integers(-30, 60))
+        t = rng.integers(0, 4, size=max(tlen, 40)).astype(np.uint8)
+        q = _mutate(rng, t, float(rng.choice([0.0, 0.01, 0.03, 0.06])), float(rng.choice([0.0, 0.004, 0.015])))
+        q = np.resize(q, qlen) if len(q) < qlen else q[:qlen]
+        if it % 3 == 1 and qlen > 90:        # an unrelated stretch: scores decay, the band shrinks, possibly z-drop
+            a = int(rng.integers(30, qlen - 50)); b = a + int(rng.integers(8, 40))
+            q[a:b] = rng.integers(0, 4, size=b - a)
+        w = int(rng.choice([4, 8, 20, 33, 40, 64, 100]))
+        h0 = int(rng.choice([15, 25, 40, 70, 120]))
+        cs.add(q, t, w, h0, int(rng.choice([0, 5, 9])), int(rng.integers(0, 8)))
+    return cs
+
+
 def very_wide_band_cases(rng, n):
     """The same for the ring form's multi-pass rows at widths beyond 256 columns: the band
     grows through 255..257 (and, for the longest queries, 511..513) live columns; every other case has an unrelated stretch in the middle,
@@ -214,6 +237,12 @@ def run_extend(dev, kind, n, max_len, seed, need_stale, very_wide=0):
         for k, (q, t, w, h0, eb) in enumerate(cs.py):
             exp = ref_extend(o, q, t, w, h0, eb)
             assert out[k, :6].tolist() == exp, f"kind {kind} opt {oi} wide-band case {k}: device {out[k, :8].tolist()} reference {exp} (qlen {len(q)} tlen {len(t)} w {w} h0 {h0} eb {eb} flags {cases['flags'][k]})"
+        cs = window_cases(rng, max(24, n // 8), max_len)
+        cases, seqs = cs.arrays()
+        out = dev.debug_dp(o, kind, cases, seqs)
+        for k, (q, t, w, h0, eb) in enumerate(cs.py):
+            exp = ref_extend(o, q, t, w, h0, eb)
+            assert out[k, :6].tolist() == exp, f"kind {kind} opt {oi} window case {k}: device {out[k, :8].tolist()} reference {exp} (qlen {len(q)} tlen {len(t)} w {w} h0 {h0} eb {eb} flags {cases['flags'][k]})"
         if very_wide:
             cs = very_wide_band_cases(rng, very_wide)
             cases, seqs = cs.arrays()
