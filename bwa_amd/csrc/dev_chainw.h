@@ -33,6 +33,13 @@ DEVFN i64 readlane_i64(i64 v, int l)
 	return (i64)((u64)(u32)hi << 32 | (u32)lo);
 }
 
+// a 64-bit field of a record held one int per lane: ints l and l + 1
+DEVFN i64 readlane_i64x(i32 v, int l)
+{
+	const int lo = __builtin_amdgcn_readlane(v, l), hi = __builtin_amdgcn_readlane(v, l + 1);
+	return (i64)((u64)(u32)hi << 32 | (u32)lo);
+}
+
 // A node as the wave holds it after ONE memory round trip (two loads in flight, whether the tree is in LDS or in HBM): lane l < 22
 // has int l of the record -- n, internal flag, the nine chain indices, the ten children --, lanes 0..8 the nine positions.
 struct NodeRegs { i32 hdr; i64 key; };
@@ -40,8 +47,10 @@ DEVFN NodeRegs cw_load(i32 *nd, int x, int lane)
 {
 	i32 *node = nd + x * BT_NODE_INTS;
 	NodeRegs r;
-	r.hdr = lane < 22 ? node[lane] : 0;
-	r.key = lane < BT_MAXK ? cw_pos(node)[lane] : 0;
+	// (every lane loads: the lanes past the record's 22 header ints / nine positions repeat its last one -- nobody reads their copy, and a clamped index
+	// costs one instruction where a guarded load costs an exec-mask region of six)
+	r.hdr = node[lane < 22 ? lane : 21];
+	r.key = cw_pos(node)[lane < BT_MAXK ? lane : BT_MAXK - 1];
 	return r;
 }
 DEVFN int nr_n(const NodeRegs &r) { return __builtin_amdgcn_readlane(r.hdr, 0); }
@@ -52,14 +61,14 @@ DEVFN int nr_child(const NodeRegs &r, int i) { return __builtin_amdgcn_readlane(
 DEVFN int cw_search(const NodeRegs &nr, i64 pos, int lane, int &r)
 {
 	const int n = nr_n(nr);
-	if (n == 0) return -1;
 	const bool in = lane < n;
 	const u64 m_in = wave_ballot(in);                         // (two compare masks and a scalar AND: the ballot of a conjunction is rebuilt from 0/1 values)
 	const int lo = __popcll(wave_ballot(nr.key < pos) & m_in);    // keys are sorted: lower bound = number of smaller keys
-	if (lo == n) { r = 1; return n - 1; }
-	const bool eq = ((wave_ballot(nr.key == pos) & m_in) >> lo) & 1;
-	r = eq ? 0 : -1;
-	return eq ? lo : lo - 1;
+	const bool eq = ((wave_ballot(nr.key == pos) & m_in) >> (lo & 63)) & 1;
+	// straight-line selects instead of early returns (an empty node: lo == n == 0 gives -1, and r is not looked at)
+	const bool past = lo == n;
+	r = past ? 1 : eq ? 0 : -1;
+	return past ? n - 1 : eq ? lo : lo - 1;
 }
 // kb_intervalp, lower side (kbtree.h:152-168).  The walk also remembers where it ended: when it reaches a leaf without meeting a
 // full node, a following insertion of the same position (the seed did not merge into the chain found) would descend along exactly
@@ -67,22 +76,22 @@ DEVFN int cw_search(const NodeRegs &nr, i64 pos, int lane, int &r)
 struct LowerPath { int leaf, i; bool direct; NodeRegs nr; };
 DEVFN int cw_lower(i32 *nd, int root, i64 pos, int lane, u32 &visits, LowerPath &P)
 {
-	int x = root, low = -1;
-	bool full = false;
-	P.direct = false;
+	int x = root, low = -1, i;
+	bool full = false, leaf;
+	NodeRegs nr;
 	for (;;) {
-		const NodeRegs nr = cw_load(nd, x, lane);
+		nr = cw_load(nd, x, lane);
 		int r = 0;
-		const int i = cw_search(nr, pos, lane, r);
+		i = cw_search(nr, pos, lane, r);
 		++visits;
 		full = full || nr_n(nr) == BT_MAXK;
-		const bool leaf = !nr_internal(nr);
-		if (leaf) { P.leaf = x; P.i = i; P.nr = nr; P.direct = !full; }
-		if (i >= 0 && r == 0) return nr_key(nr, i);
+		leaf = !nr_internal(nr);
 		if (i >= 0) low = nr_key(nr, i);
-		if (leaf) return low;
+		if ((i >= 0 && r == 0) || leaf) break;             // an equal key, or the walk's end
 		x = nr_child(nr, i + 1);
 	}
+	P.leaf = x; P.i = i; P.nr = nr; P.direct = leaf && !full;  // (the last node visited: only a leaf reached without a full node on the way serves the direct insertion)
+	return low;
 }
 // the leaf step of __kb_putp_aux (kbtree.h:199-206) on a leaf already in registers: key k / position pos go in after entry i
 DEVFN void cw_insert_at(i32 *nd, const LowerPath &P, int k, i64 pos, int lane)
@@ -255,8 +264,11 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 				if (lo >= 0) {   // test_and_merge (bwamem.c:216-237)
 					ChainRec *c = ch + lo;
 					++recs;
-					const i64 c_pos = uni64(c->pos), c_lrb = uni64(c->last_rbeg);
-					const int c_fqb = uni(c->first_qbeg), c_lqb = uni(c->last_qbeg), c_ll = uni(c->last_len), c_rid = uni(c->rid);
+					// the record's sixteen ints by sixteen lanes, one load; its fields are then lane reads (ints 0-1 pos, 2-3 last_rbeg, 5 last, 6 first_qbeg,
+					// 7 last_qbeg, 8 last_len, 10 rid)
+					const i32 cv = ((const i32*)c)[lane & 15];
+					const i64 c_pos = readlane_i64x(cv, 0), c_lrb = readlane_i64x(cv, 2);
+					const int c_last = __builtin_amdgcn_readlane(cv, 5), c_fqb = __builtin_amdgcn_readlane(cv, 6), c_lqb = __builtin_amdgcn_readlane(cv, 7), c_ll = __builtin_amdgcn_readlane(cv, 8), c_rid = __builtin_amdgcn_readlane(cv, 10);
 					wave_sync();                               // every lane holds the record before lane 0 may update it
 					const i64 qend = c_lqb + c_ll, rend = c_lrb + c_ll;
 					if (rid == c_rid) {
@@ -266,7 +278,7 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 							const i64 x = qbeg - c_lqb, y = rbeg - c_lrb;
 							if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - c_ll < opt.max_chain_gap && y - c_ll < opt.max_chain_gap) {
 								if (lane == 0) {
-									next[c->last] = s; next[s] = -1;
+									next[c_last] = s; next[s] = -1;
 									c->last = s; c->last_qbeg = qbeg; c->last_len = slen; c->last_rbeg = rbeg; ++c->n;
 								}
 								wave_sync();
