@@ -57,7 +57,7 @@ struct DevBuf {
 struct bwagpu_s {
 	int device = 0;
 	hipStream_t stream = nullptr;
-hipEvent_t ev[8] = {};
+	hipEvent_t ev[8] = {};
 	hipEvent_t ev_wait = nullptr;    // blocking-sync event: waiting for the stream must not spin on a host core (see wait_stream)
 	std::string err;
 	BwagpuConfig cfg;               // tuning and test options (bwagpu_config.h): environment read once at creation, then bwagpu_set_option
@@ -455,7 +455,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 	for (DevBuf *b : all) b->release();
 	for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
 	if (h->ev_wait) (void)hipEventDestroy(h->ev_wait);
-if (h->stream) (void)hipStreamDestroy(h->stream);
+	if (h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
 }
 
@@ -931,7 +931,12 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 	// the bench's reads -- and the whole of that kernel's critical path; measured over budgets 2048..8192: profiles/r04_seed_budget_ab.jsonl) is given up there and seeded by the task kernels afterwards (dev_seed.h, LR).
 	const int seed_budget = (int)(cfg.seed_budget < 0 ? 8192 : cfg.seed_budget);
 	const int heavy_tpr = opt->min_seed_len > 0 ? (h->max_len + opt->min_seed_len - 1) / opt->min_seed_len : 0;
-	const bool heavy_tasks = !long_batch && h->rd_words != 0 && seed_budget > 0 && heavy_tpr > 0 && h->ix.occ32 != nullptr && h->ix.ptab != nullptr &&
+	// The one-trip seeding kernels (MRG = 2) address the index through buffer descriptors: 32-bit byte offsets into tables of less than 4 GiB.  The heavy
+	// reads' task kernels exist in that form only, so an index beyond a descriptor's reach (occ32 above 4 GiB: a genome of more than ~4.3 Gbp; a deep
+	// prefix table) keeps every read on the lane-per-read kernel, without a budget (option idx_desc_max_mb lowers the limit: test hook).
+	const u64 desc_max = cfg.idx_desc_max_mb > 0 && ((u64)cfg.idx_desc_max_mb << 20) < BUF_MAX_BYTES ? (u64)cfg.idx_desc_max_mb << 20 : BUF_MAX_BYTES;
+	const bool idx_in_desc = h->ix.occ32 != nullptr && h->ix.ptab != nullptr && h->ix.occ32_bytes <= desc_max && h->ix.ptab_bytes <= desc_max;
+	const bool heavy_tasks = !long_batch && h->rd_words != 0 && seed_budget > 0 && heavy_tpr > 0 && idx_in_desc &&
 							 h->seq_len < ((u64)1 << 37) && !cfg.seed_pass3_inline && opt->max_mem_intv > 0;
 	const int heavy_lanes = heavy_tasks ? (int)(((i64)n * heavy_tpr + BLOCK - 1) / BLOCK * BLOCK < 256 * 3 * BLOCK ? ((i64)n * heavy_tpr + BLOCK - 1) / BLOCK * BLOCK : 256 * 3 * BLOCK) : 0;
 	if (heavy_tasks && (h->d_intv_n3.ensure((size_t)n * 4 + 16) || h->d_heavy.ensure((size_t)n * 4 + 16))) { h->err = "hipMalloc failed (seeding tasks)"; return BWAGPU_ENOMEM; }
@@ -978,7 +983,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		// memory round trips per iteration of the seeding kernels (dev_seed.h, k_seed's MRG): 0 = as compiled, 2 = table entries, whole index
 		// blocks and the next interval-stack entry in one trip (any other non-zero value selects 2 as well)
 		int seed_mrg = (cfg.seed_mrg >= 0 ? cfg.seed_mrg : 2) ? 2 : 0;      // (auto: 2 for every batch since round 4 -- 2 % faster in step time for short reads as well, every time it was measured)
-		if (h->ix.occ32 == nullptr || h->ix.ptab == nullptr || h->ix.occ32_bytes > BUF_MAX_BYTES || h->ix.ptab_bytes > BUF_MAX_BYTES) seed_mrg = 0;   // (its loads address 32-bit offsets into buffers of < 4 GiB: a genome beyond ~8.5 Gbp of index keeps the plain kernels)
+		if (!idx_in_desc) seed_mrg = 0;   // (its loads address 32-bit offsets into buffers of < 4 GiB: an index beyond that keeps the plain kernels, see idx_in_desc above)
 		B.seq_nib_bytes = (((u64)h->n_bases + 15) / 16) * 8;
 		dim3 grid(n_threads / BLOCK), block(BLOCK);
 		HIPCHK(h, hipEventRecord(h->ev[0], h->stream));

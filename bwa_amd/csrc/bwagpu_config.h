@@ -21,6 +21,7 @@
 	X(occ32,             1)    /* index: kernels read the 32-byte block layout derived at load time (0: the reference-format 64-byte blocks)          */ \
 	X(occ32_sb_shift,    32)   /* index: log2 bases per superblock of that layout (tests: small superblocks on small genomes)                           */ \
 	X(ptab_m,            10)   /* index: depth of the prefix tables (0: none)                                                                           */ \
+	X(idx_desc_max_mb,   0)    /* index: tables above this many MiB count as beyond a buffer descriptor's reach (0: the hardware's 4 GiB; test hook for the fallback kernels) */ \
 	X(seed_mrg,          -1)   /* seeding: 0 = loads as the compiler schedules them, 2 = one memory round trip per iteration; auto: 2                    */ \
 	X(seed_tasks,        -1)   /* seeding: pass 1 of long reads as independent tasks, one per min_seed_len-th position (0: the lane-per-read chain); auto: on for long reads */ \
 	X(seed_budget,       -1)   /* seeding, short reads: iterations after which the lane-per-read kernel gives a read up to the task kernels; auto: 8192, 0: never           */ \

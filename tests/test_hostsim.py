@@ -674,7 +674,10 @@ def test_hostsim_heavy_reads_seeded_by_tasks():
     for name, opt in (("-k 19", default_opt()), ("-k 11 -r 1", o11)):
         want = orc.align(opt, seqs, off)
         got = {}
-        for cfg_name, options in (("lane per read", {"seed_budget": 0}), ("tasks", {"seed_budget": 150}), ("tasks, tiny pass-2 list", {"seed_budget": 150, "seed_p2_cap": 2})):
+        # (last: an index that counts as beyond a buffer descriptor's reach -- option idx_desc_max_mb, the 2 Mb genome's 32-byte blocks are 2 MiB --
+        # has no task kernels to hand reads to: the budget must be off with it, whatever seed_budget says, and the plain-load kernels run)
+        for cfg_name, options in (("lane per read", {"seed_budget": 0}), ("tasks", {"seed_budget": 150}), ("tasks, tiny pass-2 list", {"seed_budget": 150, "seed_p2_cap": 2}),
+                                  ("index beyond a descriptor", {"seed_budget": 150, "idx_desc_max_mb": 1})):
             s2 = sim_handle(prefix, **options)
             s2.set_stats(True)
             c, r = s2.align(opt, seqs, off)
@@ -685,8 +688,8 @@ def test_hostsim_heavy_reads_seeded_by_tasks():
             prof = (C.c_ulonglong * 16)()
             s2.L.bwagpu_debug_prof.argtypes = [C.c_void_p, C.c_void_p]
             s2.L.bwagpu_debug_prof(s2.h, prof)
-            if cfg_name == "lane per read":
-                assert prof[0] == 0
+            if cfg_name in ("lane per read", "index beyond a descriptor"):
+                assert prof[0] == 0, (name, cfg_name, prof[0])
             else:
                 assert prof[0] >= 5 and prof[1] >= 5, (name, cfg_name, prof[0], prof[1])      # heavy reads, pass-2 tasks
             if cfg_name == "tasks, tiny pass-2 list":
