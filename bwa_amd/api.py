@@ -45,7 +45,8 @@ class Stats(C.Structure):
         (n, C.c_float) for n in ("ms_seed", "ms_sa", "ms_chain", "ms_seedsw", "ms_extend", "ms_dedup", "ms_total")] + [
         ("n_retries", C.c_int32), ("ms_publish", C.c_float), ("n_tab_lookups", C.c_int64), ("n_bt_nodes", C.c_int64), ("n_chain_recs", C.c_int64),
         ("n_chain_deferred", C.c_int64), ("n_ext_fast", C.c_int64), ("n_chain_deferred2", C.c_int64),
-        ("ms_pack", C.c_float), ("ms_download_copy", C.c_float), ("ms_cigar_kernels", C.c_float), ("ms_cigar_copy", C.c_float)]
+        ("ms_pack", C.c_float), ("ms_download_copy", C.c_float), ("ms_cigar_kernels", C.c_float), ("ms_cigar_copy", C.c_float),
+        ("n_cig_cells", C.c_int64), ("n_cig_dp", C.c_int64), ("retry_mask", C.c_int32), ("reserved_", C.c_int32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved_"}
@@ -56,7 +57,7 @@ EXPORTS = [
     "bwagpu_index_info", "bwagpu_densify_sa", "bwagpu_set_stats", "bwagpu_get_stats", "bwagpu_align_bseq", "bwagpu_align_flat",
     "bwagpu_free", "bwagpu_batch_upload", "bwagpu_batch_run", "bwagpu_batch_download", "bwagpu_set_taps", "bwagpu_tap_intervals",
     "bwagpu_tap_chains", "bwagpu_tap_regs_raw", "bwagpu_index_buffers", "bwagpu_index_export", "bwagpu_clone", "bwagpu_index_ready",
-    "bwagpu_batch_cigars", "bwagpu_batch_cigar_ops", "bwagpu_debug_phase", "bwagpu_batch_matesw", "bwagpu_clone_to_device", "bwagpu_index_build", "bwagpu_built_free", "bwagpu_abi_sizes", "bwagpu_debug_prof", "bwagpu_debug_hist", "bwagpu_debug_chain_hist", "bwagpu_debug_dp", "bwagpu_set_cigar_filter", "bwagpu_batch_reserve",
+    "bwagpu_batch_cigars", "bwagpu_batch_cigar_ops", "bwagpu_debug_phase", "bwagpu_batch_matesw", "bwagpu_clone_to_device", "bwagpu_index_build", "bwagpu_built_free", "bwagpu_abi_sizes", "bwagpu_debug_prof", "bwagpu_debug_hist", "bwagpu_debug_seed_x2", "bwagpu_debug_chain_hist", "bwagpu_debug_dp", "bwagpu_set_cigar_filter", "bwagpu_batch_reserve",
     "bwagpu_trim", "bwagpu_set_option", "bwagpu_get_option", "bwagpu_set_default_option", "bwagpu_clear_default_options", "bwagpu_option_name",
 ]
 

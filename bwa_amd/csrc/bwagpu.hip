@@ -650,6 +650,15 @@ extern "C" int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16])
 	return BWAGPU_OK;
 }
 
+// ... its index look-ups by interval size (Counters::seed_x2)
+extern "C" int bwagpu_debug_seed_x2(bwagpu_t *h, unsigned long long out[8])
+{
+	if (!h || !out || !h->d_ctr.p) return BWAGPU_EINVAL;
+	Counters c;
+	if (hipMemcpy(&c, h->d_ctr.p, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return BWAGPU_EHIP;
+	for (int i = 0; i < 8; ++i) out[i] = c.seed_x2[i];
+	return BWAGPU_OK;
+}
 // ... and the histogram of k_seed's iterations per read (stats runs): out[b] = reads that took [2^(b-1), 2^b) iterations, out[32 + b] = their iterations summed
 extern "C" int bwagpu_debug_hist(bwagpu_t *h, unsigned long long out[256])
 {
@@ -734,7 +743,9 @@ static void size_arenas(bwagpu_t *h)
 	h->node_cap = h->slot_cap / 4 + 2 * (i64)n + 64;
 	h->reg_cap = nb / 5 + 4096;
 	// capacity of one read's interval list: reads keep ~10-30 intervals whatever their length class; grown x4 on overflow
-	h->mem_cap = h->max_len / 3 < 64 ? 64 : h->max_len / 3;
+	// (256 at least: with 64, one read in ten thousand of a repeat-rich genome -- a 150 bp read inside a tandem array leaves well over a hundred
+	// intervals -- made the first batch of every handle run twice, profiles/r04_e2e_split.log)
+	h->mem_cap = h->max_len / 3 < 256 ? 256 : h->max_len / 3;
 	// what earlier batches -- of this handle or of another handle on the same index -- turned out to need carries over
 	{
 		std::lock_guard<std::mutex> l(h->ibuf->m);
@@ -1145,7 +1156,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			if (c.overflow & 8) { const i64 want = (i64)(c.reg_used + c.reg_used / 10) + 4096; h->reg_cap = (c.overflow & 2) || want <= h->reg_cap * 5 / 4 ? h->reg_cap * 2 : want; }
 			if (c.overflow & 16) h->mem_cap = h->mem_cap * 4;
 			if (c.overflow & 32) h->p2_factor *= 4.;
-			++h->stats.n_retries;
+			++h->stats.n_retries; h->stats.retry_mask |= (int32_t)c.overflow;
 			continue;
 		}
 		{	// remember the sizes that sufficed, per base

@@ -108,6 +108,7 @@ struct Counters {          // device-side bump allocators + flags
 	unsigned long long chain_hist[3][32];          // stats runs of k_chain_wave: per tier, reads that finished there by min(31, chains before the filter / 16) (bwagpu_debug_chain_hist)
 	unsigned long long chain_seeds[3][32];         // ... and by min(31, seeds / 32)
 	unsigned long long seed_hist[64];              // k_seed's stats instance: reads by floor(log2(iterations spent on the read)) + 1, then the iterations summed per bin (bwagpu_debug_hist)
+	unsigned long long seed_x2[8];                 // k_seed's stats instance: extension steps that read index blocks, [0] forward / [1] backward in all, [2] / [3] those on an interval of ONE row (a unique match: the step is a comparison with the next text base), [4] / [5] forward / backward runs of such steps (maximal, per search), [6] prefix-table steps (bwagpu_debug_seed_x2)
 	unsigned long long cigl_plan[2];               // k_cigar_long_plan: regions left to the long CIGAR tier, bytes of the largest direction matrix among them
 };
 #define seed_used seed_used_.v

@@ -487,6 +487,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	int deferred = 0;
 	u32 n_iter = 0, n_slow = 0, n_ext_lanes = 0, n_deep = 0, n_deep_l = 0, n_pf_l = 0, n_win_l = 0;
 	u32 n_done_l = 0, n_wait_l = 0, n_slowrun_l = 0, n_first_done = 0;      // STATS: where the lane-slots that do not extend go (prof[2..7])
+	u32 n_x2[6] = { 0, 0, 0, 0, 0, 0 }; bool run_f = false, run_b = false;   // STATS: Counters::seed_x2
 	u32 my_iter = 0;                                                        // iterations this lane has spent on its current read (the budget of short-read batches; STATS: Counters::seed_hist)
 	// MRG == 2: the stack entry this lane's next backward step will read, fetched a step ahead (pf.w != 0: valid -- an entry's `info`, its
 	// match's end position >= 1, sits in the top half of w).  A backward step that is not the last of its row is always followed by the
@@ -714,6 +715,12 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 			} else nb = (u32)ext_one_trip(ix, bf, ext, blocks, src, cb, back, tl, L.code, ok, pf_off, pf);
 			if (STATS && ext) { if (blocks) nblk += nb; else ++ntab; }
 		}
+		if (STATS && ext && blocks) {      // how many of the index look-ups are on a unique match (an interval of one row)
+			const bool one = src.x2 == 1;
+			++n_x2[back ? 1 : 0]; if (one) ++n_x2[back ? 3 : 2];
+			if (one && !(back ? run_b : run_f)) ++n_x2[back ? 5 : 4];
+			if (back) run_b = one; else run_f = one;
+		}
 		if (ext) {
 			if (MRG && BLK == 1) ;
 			else if (!blocks) { ptab_load(ix, tl, L.code, ok); if (STATS) ++ntab; }
@@ -767,6 +774,7 @@ __global__ void __launch_bounds__(256, OCC) k_seed(DevIndex ix, bwagpu_opt_t opt
 	}
 	if (STATS) {
 		atomicAdd(&B.ctr->occ_blocks, (unsigned long long)nblk); atomicAdd(&B.ctr->tab_lookups, (unsigned long long)ntab);
+		for (int k = 0; k < 6; ++k) atomicAdd(&B.ctr->seed_x2[k], (unsigned long long)n_x2[k]);
 		atomicAdd(&B.ctr->prof[9], (unsigned long long)n_win_l); atomicAdd(&B.ctr->prof[10], (unsigned long long)n_deep_l); atomicAdd(&B.ctr->prof[11], (unsigned long long)n_pf_l);
 		if ((threadIdx.x & 63) == 0) { atomicAdd(&B.ctr->prof[12], (unsigned long long)n_deep); atomicAdd(&B.ctr->prof[13], (unsigned long long)n_iter); atomicAdd(&B.ctr->prof[14], (unsigned long long)n_slow); atomicAdd(&B.ctr->prof[15], (unsigned long long)n_ext_lanes);
 			// lane-slots of lanes that have run out of reads, of lanes waiting in a bookkeeping state for the wave to run that code, of lanes running it; the

@@ -605,8 +605,8 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 		if (d == 0 && trace && rc == BWAGPU_OK) {      // the hot path's stages by the library's own HIP events
 			bwagpu_stats_t st;
 			if (bwagpu_get_stats(gpus[d], &st) == BWAGPU_OK)
-				fprintf(stderr, "[D::device_sub] stage ms: seed %.2f publish %.2f sa %.2f chain %.2f seedsw %.2f extend %.2f dedup %.2f total %.2f (retries %d)\n",
-						st.ms_seed, st.ms_publish, st.ms_sa, st.ms_chain, st.ms_seedsw, st.ms_extend, st.ms_dedup, st.ms_total, st.n_retries);
+				fprintf(stderr, "[D::device_sub] stage ms: seed %.2f publish %.2f sa %.2f chain %.2f seedsw %.2f extend %.2f dedup %.2f total %.2f (retries %d, overflow mask 0x%x)\n",
+						st.ms_seed, st.ms_publish, st.ms_sa, st.ms_chain, st.ms_seedsw, st.ms_extend, st.ms_dedup, st.ms_total, st.n_retries, (unsigned)st.retry_mask);
 		}
 		if (rc == BWAGPU_OK) rc = bwagpu_batch_download(gpus[d], u.counts.data() + s.lo, &s.all, &s.tot);
 		if (rc != BWAGPU_OK) device_fail(gpus[d], rc);

@@ -194,6 +194,10 @@ typedef struct {
 	float ms_download_copy;  /* ... and their device-to-host copy                                              */
 	float ms_cigar_kernels;  /* bwagpu_batch_cigars: all its launches (the three tiers, NM/MD)                 */
 	float ms_cigar_copy;     /* ... and the copies of the records and (bwagpu_batch_cigar_ops) the operation array */
+	int64_t n_cig_cells;     /* bwagpu_batch_cigars (stats only): DP cells of the ksw_global2 fills with traceback, every band-doubling attempt counted */
+	int64_t n_cig_dp;        /* ... and the number of such fills (regions answered by the gap-free comparison, bwa.c:171-174, do not count) */
+	int32_t retry_mask;      /* OR of the overflow bits that made bwagpu_batch_run redo the batch: 2 slots, 4 B-tree nodes, 8 regions, 16 interval lists, 32 pass-2 task list */
+	int32_t reserved_;
 } bwagpu_stats_t;
 
 /* Diagnostics: a marker of the step the handle's current (or last) batch call has reached; safe to call from another
@@ -208,6 +212,9 @@ int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16]);
  * the time their wave spent on them (bin b: [2^(b-1), 2^b) x 10 ns), then per bin the ksw_extend2 calls and the DP cells (>> 10) of those reads;
  * out[160..256): the same for the wave-per-read de-duplication kernel (long reads) and its patch alignments. */
 int bwagpu_debug_hist(bwagpu_t *h, unsigned long long out[256]);
+/* Diagnostics (stats on): the seeding kernel's index-block look-ups by interval size.  out[0] / out[1] = forward / backward extension steps that read
+ * index blocks, out[2] / out[3] = those whose interval is a single row (a unique match), out[4] / out[5] = maximal runs of such steps. */
+int bwagpu_debug_seed_x2(bwagpu_t *h, unsigned long long out[8]);
 /* Diagnostics (stats on): the chaining tiers' reads by size.  out[t * 64 + b] = reads that finished in tier t (0, 1: the LDS tiers, 2: the HBM tier)
  * with 16 b .. 16 b + 15 chains (before the chain filter) (b = 31: more); out[t * 64 + 32 + b] = with 32 b .. 32 b + 31 seeds (tools/seed_iter_probe.py). */
 int bwagpu_debug_chain_hist(bwagpu_t *h, unsigned long long out[192]);

@@ -50,6 +50,8 @@ def main():
                     print("[e2e]    " + m2.group(0), flush=True)
                 steps = re.findall(r"upload ([\d.]+) run ([\d.]+) download\+cigars ([\d.]+) pestat\+matesw ([\d.]+) s", p.stderr)
                 after = re.findall(r"after the hot path, ms: pack ([\d.]+) download copy ([\d.]+) cigar kernels ([\d.]+) cigar copies ([\d.]+)", p.stderr)
+                for ln in re.findall(r"\[D::device_sub\] stage ms:.*", p.stderr):
+                    print("[e2e]    " + ln, flush=True)
                 if after:
                     print("[e2e]    after the hot path (ms per batch, HIP events, mean of %d): pack %.1f, download copy %.1f, CIGAR kernels %.1f, CIGAR copies %.1f" %
                           ((len(after),) + tuple(sum(float(x[i]) for x in after) / len(after) for i in range(4))), flush=True)

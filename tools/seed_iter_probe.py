@@ -57,6 +57,11 @@ for cfg in (sys.argv[1:] or [""]):
             tot = max(sum(ch[t * 64: t * 64 + 32]), 1)
             print(f"    chaining tier {t}: {tot} reads; by chains (x16): " + " ".join(f"{b}:{ch[t * 64 + b]}" for b in range(32) if ch[t * 64 + b])
                   + " | by seeds (x32): " + " ".join(f"{b}:{ch[t * 64 + 32 + b]}" for b in range(32) if ch[t * 64 + 32 + b]), flush=True)
+        x2 = (C.c_ulonglong * 8)()
+        gpu.L.bwagpu_debug_seed_x2.argtypes = [C.c_void_p, C.c_void_p]
+        gpu.L.bwagpu_debug_seed_x2(gpu.h, x2)
+        print(f"    index-block steps per read: forward {x2[0] / n:.1f} ({x2[2] / n:.1f} on one-row intervals, in {x2[4] / n:.2f} runs), backward {x2[1] / n:.1f} "
+              f"({x2[3] / n:.1f} on one-row intervals, in {x2[5] / n:.2f} runs); one-row share of all block steps {100.0 * (x2[2] + x2[3]) / max(x2[0] + x2[1], 1):.1f}%", flush=True)
         print("    iterations per read: " + ", ".join(f"<{1 << b}: {100.0 * hist[b] / tot_r:.1f}% of reads / {100.0 * hist[32 + b] / tot_i:.1f}% of iterations" for b in range(32) if hist[b]), flush=True)
     for k, v in old.items():
         gpu.set_option(k, v)
