@@ -1284,6 +1284,7 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 	if (tot) {
 		if (h->d_cigs.ensure((size_t)tot * sizeof(bwagpu_cigar_t)) || h->d_ctr.ensure(sizeof(Counters))) { bwagpu_free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
 		Batch B = {}; B.seq = h->d_seq.as<u8>(); B.off = h->d_off.as<i64>(); B.n_reads = h->n_reads; B.max_len = h->max_len;
+		B.ctr = h->d_ctr.as<Counters>(); B.stats = h->stats_on;      // (stats: the fills' DP cells, counted in glb_cells / glb_calls -- the batch's run is over, its counters have been read)
 		unsigned long long *next = &h->d_ctr.as<Counters>()->next_ext, *ext_used = &h->d_ctr.as<Counters>()->cig_ext_used;
 		const int zc[2] = { CIG_Z_SMALL, CIG_Z_BIG };
 		const int n_tier = (int)h->cfg.cig_tiers;   // diagnostics
@@ -1313,14 +1314,20 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		for (int attempt = 0; attempt < 2; ++attempt) {
 			if (h->d_cig_ext.ensure((size_t)ext_cap * 4)) { bwagpu_free(res); h->err = "hipMalloc failed (cigars)"; return BWAGPU_ENOMEM; }
 			e = hipMemsetAsync(ext_used, 0, sizeof(unsigned long long), h->stream);
+			if (e == hipSuccess && h->stats_on) e = hipMemsetAsync(&h->d_ctr.as<Counters>()->glb_calls, 0, 2 * sizeof(unsigned long long), h->stream);      // (glb_calls, glb_cells: adjacent)
 			for (int tier = 0; tier < n_tier && e == hipSuccess; ++tier) {   // narrow bands at high occupancy, then the deferred wide ones
 				e = hipMemsetAsync(next, 0, sizeof(unsigned long long), h->stream);
 				if (e != hipSuccess) break;
 				h->phase = 41 + tier;
-				const int lds_wave = CIG_LDS_BYTES(zc[tier]);
+				// tier 0: the diag form only (bands of up to 64 columns whose direction nibbles fit CIG_Z_SMALL; no {H,E} columns in LDS: 6.3 KB per wave);
+				// tier 1: both forms with CIG_Z_BIG nibbles, for what tier 0 deferred
+				const int lds_wave = tier == 0 ? CIG_LDS_BYTES_DIAG(zc[tier]) : CIG_LDS_BYTES(zc[tier]);
 				const int wpb = tier == 0 ? 4 : 2;                 // waves per workgroup: the wide tier stays below 64 KiB of LDS per group
 				i64 nblk = (tot + wpb - 1) / wpb, cap = 256 * 6;
-				hipLaunchKernelGGL(k_cigar, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, tot,
+				if (tier == 0) hipLaunchKernelGGL(k_cigar<true>, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, tot,
+								   h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_pack_read.as<i32>(), h->d_cigs.as<bwagpu_cigar_t>(), next, zc[tier], tier,
+								   h->d_cig_ext.as<u32>(), ext_used, ext_cap, h->cigar_filter ? h->d_pack_off.as<i64>() : (const i64*)nullptr);
+				else hipLaunchKernelGGL(k_cigar<false>, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, tot,
 								   h->d_regs_packed.as<bwagpu_alnreg_t>(), h->d_pack_read.as<i32>(), h->d_cigs.as<bwagpu_cigar_t>(), next, zc[tier], tier,
 								   h->d_cig_ext.as<u32>(), ext_used, ext_cap, h->cigar_filter ? h->d_pack_off.as<i64>() : (const i64*)nullptr);
 				e = hipGetLastError();
@@ -1366,6 +1373,12 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		}
 		h->phase = 45;
 		(void)hipEventRecord(h->ev[1], h->stream);
+		if (e == hipSuccess && h->stats_on) {
+			unsigned long long cc[2] = { 0, 0 };
+			e = hipMemcpyAsync(cc, &h->d_ctr.as<Counters>()->glb_calls, sizeof cc, hipMemcpyDeviceToHost, h->stream);
+			if (e == hipSuccess) e = wait_stream(h);
+			h->stats.n_cig_dp = (i64)cc[0]; h->stats.n_cig_cells = (i64)cc[1];
+		}
 		if (e == hipSuccess) e = hipMemcpyAsync(res, h->d_cigs.p, (size_t)tot * sizeof(bwagpu_cigar_t), hipMemcpyDeviceToHost, h->stream);
 		(void)hipEventRecord(h->ev[2], h->stream);
 		if (e == hipSuccess) e = wait_stream(h);

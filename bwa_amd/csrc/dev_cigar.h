@@ -23,31 +23,157 @@
 #define CIG_MD_CAP 1024        // longest MD string kept (bytes of LDS per wave)
 
 struct CigLds { i32 *hd, *e; int8_t *qp; u8 *z; u32 *ops; u8 *md; int qstride, z_cells; };
+#define CIG_LDS_BYTES_DIAG(zc) ((5 * (CIG_MAX_LEN + 64) + (zc) / 2 + CIG_MAX_COLS + CIG_TMP_OPS * 4 + CIG_MD_CAP + 15) & ~15)   // per wave, first tier (diag form only)
 #define CIG_LDS_BYTES(zc) ((2 * (CIG_MAX_LEN + 2 + 64) * 4 + 5 * (CIG_MAX_LEN + 64) + (zc) / 2 + CIG_MAX_COLS + CIG_TMP_OPS * 4 + CIG_MD_CAP + 15) & ~15)   // per wave
 
-// ksw_global2 (ksw.c:540-642).  Returns the score; *n_ops < 0 when the traceback does not fit CIG_TMP_OPS.  Operations are
-// left in L.ops in traceback (reversed) order, run-length merged.
-__device__ int wave_ksw_global2(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen, i64 t0, int tdir, int tlen,
-								int w, const CigLds &L, int *n_ops)
+// The query profile of a region's query segment (ksw.c:552-556), qp[b * qstride + j] = score of reference base b against column j: the same for
+// every band-doubling attempt of the region, so it is built once per region.
+DEVFN void cig_build_profile(const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen, const CigLds &L)
+{
+	const int lane = threadIdx.x & 63;
+	for (int j = lane; j < qlen; j += 64) {
+		const int qc = q[q0 + j * qdir];
+		for (int k = 0; k < 5; ++k) L.qp[k * L.qstride + j] = opt.mat[k * 5 + qc];
+	}
+	wave_sync();
+}
+
+// ---- ksw_global2's matrix fill and traceback (ksw.c:566-639) in two forms ------------------------------------------------------------------------
+// "diag": bands of up to 64 columns (2 w + 1 <= 64: nearly every region of a 150 bp read, whose band comes from infer_bw, bwamem.c:818-825).  Lane L owns
+//   the band's DIAGONAL L = j - i + w.  The diagonal term H(i-1,j-1) is then the lane's own H of the row before -- it never moves --, E(i,j) comes
+//   from the lane above (E(i,j) was computed in row i-1 by the lane that owned column j there), F is the usual max-plus prefix scan over the row, and the
+//   band is a pair of lane numbers that changes by at most one per row.  No {H,E} arrays, no LDS round trip and no wave fence per row: the only LDS
+//   traffic is the row's score and, every eighth row, one word of direction nibbles per lane (a lane packs its eight rows in a register; round 4's
+//   form read and wrote hd[], e[] and a direction byte per cell, with two fences per 64-column pass).  The traceback reads those words by diagonal:
+//   a run of matches stays on its diagonal, so lane 0 takes a whole word's worth of "came from the diagonal" steps at once.
+// "lds": wider bands (up to CIG_MAX_COLS columns), the round-2 form: columns in LDS, 64 per pass, direction nibbles two rows per byte.
+// Both leave the operations in L.ops in traceback (reversed) order, run-length merged; all integers are the scalar recurrence's.
+DEVFN bool cig_diag_form(int qlen, int tlen, int w) { return 2 * w + 1 <= 64 && qlen > 0 && tlen > 0; }
+// direction nibbles of the diag form: word (i >> 3) * (2 w + 1) + L holds rows 8 (i >> 3) .. + 7 of diagonal L
+DEVFN int cig_diag_cells(int tlen, int w) { return ((tlen + 7) & ~7) * (2 * w + 1); }
+
+#define DPP_WAVE_SHL1 0x130
+// value of the lane above (lane 63 receives `fill`)
+DEVFN int wave_shift_down1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHL1, 0xf, 0xf, false); }
+
+__device__ int wave_global2_fill_diag(const DevIndex &ix, const bwagpu_opt_t &opt, int qlen, i64 t0, int tdir, int tlen, int w, const CigLds &L, u64 &cells)
+{
+	const int lane = threadIdx.x & 63;
+	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
+	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+	qlen = uni(qlen); tlen = uni(tlen); w = uni(w); t0 = uni64(t0);
+	const int ncl = 2 * w + 1, qs = L.qstride;
+	const int8_t *qp = L.qp; u32 *zw = (u32*)L.z;
+	const int lane_e = lane * e_ins;
+	int j = lane - w;                                     // this lane's column in the current row (one more every row)
+	int hcur = j == 0 ? 0 : -(o_ins + e_ins * j);          // H(i-1, j-1): the first row's values (ksw.c:566-570; only the lanes of row 0's band, 0 <= j <= w, use theirs)
+	int eout = CIG_NEG_INF;                               // E(i, .) as this lane left it in the row before: the lane below reads it
+	int lo = w, hi = qlen + w < ncl ? qlen + w : ncl;     // the row's live lanes [lo, hi): columns max(0, i - w) .. min(qlen, i + w + 1) - 1
+	u32 zacc = 0, cells32 = 0;
+	int treg = 0;
+	{ treg = lane < tlen ? ref_base(ix, t0 + (i64)lane * tdir) : 0; }
+	auto score_at = [&](int tb, int jj) -> int { const int jc = jj < 0 ? 0 : (jj < qlen ? jj : qlen - 1); return (int)qp[tb * qs + jc]; };      // (lanes outside the band read a neighbour's score and drop it)
+	int sc_next = score_at(__builtin_amdgcn_readlane(treg, 0), j);
+	for (int i = 0; i < tlen; ++i) {
+		const int sc = sc_next;
+		if (i + 1 < tlen) {                               // the next row's score, in flight while this row computes
+			if (((i + 1) & 63) == 0) { const int ii = i + 1 + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
+			sc_next = score_at(__builtin_amdgcn_readlane(treg, (i + 1) & 63), j + 1);
+		}
+		const bool act = lane >= lo && lane < hi;
+		const int dg = (j == 0 && i > 0) ? -(o_del + e_del * i) : hcur;        // column 0's diagonal term is H(i-1,-1) (ksw.c:578)
+		const int ec = wave_shift_down1(eout, CIG_NEG_INF);                      // (past the band's right edge: -inf, ksw.c:619)
+		const int m = dg + sc;
+		const int a = act ? m - oe_ins + lane_e : I32_MIN;
+		const int exc = wave_shift_up1(wave_incl_scan_max(a), I32_MIN);
+		int f = CIG_NEG_INF - (lane - lo) * e_ins;                             // F(i, beg) = -inf, then f <- max(f - e, m - oe) (ksw.c:596-599)
+		if (lane > lo && act) f = imax(f, exc - (lane_e - e_ins));
+		int d = m >= ec ? 0 : 1, h = m >= ec ? m : ec;                          // ksw.c:587-590
+		if (h < f) { d = 2; h = f; }
+		int t = m - oe_del, en = ec - e_del;
+		if (en > t) d |= 4; else en = t;                                       // E continues (ksw.c:592-595)
+		t = m - oe_ins;
+		if (f - e_ins > t) d |= 8;                                            // F continues (ksw.c:596-599)
+		hcur = act ? h : hcur;
+		eout = act ? en : CIG_NEG_INF;
+		const int sh = (i & 7) << 2;
+		zacc = sh == 0 ? (u32)d : zacc | (u32)d << sh;
+		if ((sh == 28 || i == tlen - 1) && lane < ncl) zw[(i >> 3) * ncl + lane] = zacc;
+		cells32 += (u32)(hi > lo ? hi - lo : 0);
+		++j;
+		lo = lo > 0 ? lo - 1 : 0;
+		{ const int nh = qlen + w - (i + 1); hi = nh < ncl ? nh : ncl; }
+	}
+	cells += cells32;
+	wave_sync();                                                               // the direction words are read back by lane 0
+	// H(tlen-1, qlen-1), if the last row's band holds that cell (it does whenever w >= |tlen - qlen|); else what eh[qlen].h still holds: -inf (ksw.c:570,619)
+	const int ls = uni((qlen - 1) - (tlen - 1) + w), lo_l = w - (tlen - 1) > 0 ? w - (tlen - 1) : 0, hi_l = qlen + w - (tlen - 1) < ncl ? qlen + w - (tlen - 1) : ncl;
+	return ls >= lo_l && ls < hi_l ? __builtin_amdgcn_readlane(hcur, ls) : CIG_NEG_INF;
+}
+
+// traceback of the diag form (ksw.c:624-639), lane 0; *n_ops < 0: more than CIG_TMP_OPS operations
+__device__ void wave_global2_trace_diag(int qlen, int tlen, int w, const CigLds &L, int *n_ops)
+{
+	const int lane = threadIdx.x & 63;
+	int n = 0;
+	if (lane == 0) {
+		const int ncl = 2 * w + 1;
+		const u32 *zw = (const u32*)L.z;
+		u32 *ops = L.ops;
+		int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, which = 0;
+		auto push = [&](int op, int len) {
+			if (n > 0 && (int)(ops[n - 1] & 0xf) == op) ops[n - 1] += (u32)len << 4;
+			else if (n < CIG_TMP_OPS) ops[n++] = (u32)len << 4 | (u32)op;
+			else n = CIG_TMP_OPS + 1;
+		};
+		int cw_row = -1, cw_l = -1; u32 cw = 0;           // the cached word: rows 8 cw_row .. + 7 of diagonal cw_l
+		while (i >= 0 && k >= 0 && n <= CIG_TMP_OPS) {
+			const int ld = k - i + w;
+			if ((i >> 3) != cw_row || ld != cw_l) { cw_row = i >> 3; cw_l = ld; cw = (ld >= 0 && ld < ncl) ? zw[cw_row * ncl + ld] : 0; }
+			const int p = i & 7;
+			if (which == 0) {
+				// in H: rows p, p-1, .. of this word whose H came from the diagonal (low two bits 0) are match steps on this very diagonal: take them at once
+				const u32 low = cw & 0x33333333u & (p == 7 ? ~0u : (1u << ((p + 1) << 2)) - 1u);
+				int run = low ? p - ((31 - __clz((int)low)) >> 2) : p + 1;
+				if (run > k + 1) run = k + 1;
+				if (run > 0) { push(0, run); i -= run; k -= run; continue; }
+			}
+			const u32 nib = cw >> (p << 2) & 15u;
+			// states: 0 = in H (take its source), 1 = in E (continue the deletion?), 2 = in F (continue the insertion?)
+			which = which == 0 ? (int)(nib & 3) : which == 1 ? (int)(nib >> 2 & 1) : (int)(nib >> 3 & 1) << 1;
+			if (which == 0) { push(0, 1); --i; --k; }
+			else if (which == 1) { push(2, 1); --i; }
+			else { push(1, 1); --k; }
+		}
+		if (n <= CIG_TMP_OPS && i >= 0) push(2, i + 1);
+		if (n <= CIG_TMP_OPS && k >= 0) push(1, k + 1);
+	}
+	n = __builtin_amdgcn_readlane(n, 0);
+	wave_sync();
+	*n_ops = n > CIG_TMP_OPS ? -1 : n;
+}
+
+// the lds form's matrix fill (ksw.c:566-619); returns the score
+__device__ int wave_global2_fill_lds(const DevIndex &ix, const bwagpu_opt_t &opt, int qlen, i64 t0, int tdir, int tlen, int w, const CigLds &L, u64 &cells)
 {
 	const int lane = threadIdx.x & 63;
 	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
 	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
 	const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
 	i32 *hd = L.hd, *e_ = L.e; int8_t *qp = L.qp; u8 *z = L.z; const int qs = L.qstride;
-	for (int k = 0; k < 5; ++k)
-		for (int j = lane; j < qlen; j += 64) qp[k * qs + j] = opt.mat[k * 5 + q[q0 + j * qdir]];
 	for (int j = lane; j <= qlen; j += 64) {      // first row (ksw.c:566-570)
 		hd[j] = j == 0 ? 0 : (j <= w ? -(o_ins + e_ins * j) : CIG_NEG_INF);
 		e_[j] = CIG_NEG_INF;
 	}
 	wave_sync();
 	int treg = 0;
+	u32 cells32 = 0;
 	for (int i = 0; i < tlen; ++i) {
 		if ((i & 63) == 0) { int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
 		const int tb = __builtin_amdgcn_readlane(treg, i & 63);
 		const int beg = i > w ? i - w : 0, end = i + w + 1 < qlen ? i + w + 1 : qlen;
 		const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : CIG_NEG_INF;
+		cells32 += (u32)(end > beg ? end - beg : 0);
 		int carry = I32_MIN, bnd = 0;
 		for (int b = beg; b < end; b += 64) {
 			const int j = b + lane; const bool act = j < end;
@@ -88,8 +214,16 @@ __device__ int wave_ksw_global2(const DevIndex &ix, const bwagpu_opt_t &opt, con
 		if (lane == 0) e_[end] = CIG_NEG_INF;            // hd[end] = H(i,end-1) was written by the last active lane
 		wave_sync();
 	}
-	const int score = hd[qlen];
-	// traceback (ksw.c:624-639), lane 0; the other lanes wait at the barrier below
+	cells += cells32;
+	return hd[qlen];
+}
+
+// ... and its traceback (ksw.c:624-639), lane 0; the other lanes wait at the barrier below
+__device__ void wave_global2_trace_lds(int qlen, int tlen, int w, const CigLds &L, int *n_ops)
+{
+	const int lane = threadIdx.x & 63;
+	const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+	const u8 *z = L.z;
 	int n = 0;
 	if (lane == 0) {
 		u32 *ops = L.ops;
@@ -113,6 +247,25 @@ __device__ int wave_ksw_global2(const DevIndex &ix, const bwagpu_opt_t &opt, con
 	n = __builtin_amdgcn_readlane(n, 0);
 	wave_sync();
 	*n_ops = n > CIG_TMP_OPS ? -1 : n;
+}
+
+// fill + traceback in whichever form the band takes; the profile of the query segment must be in place (cig_build_profile)
+DEVFN int wave_global2_fill(const DevIndex &ix, const bwagpu_opt_t &opt, int qlen, i64 t0, int tdir, int tlen, int w, const CigLds &L, u64 &cells)
+{
+	return cig_diag_form(qlen, tlen, w) ? wave_global2_fill_diag(ix, opt, qlen, t0, tdir, tlen, w, L, cells) : wave_global2_fill_lds(ix, opt, qlen, t0, tdir, tlen, w, L, cells);
+}
+DEVFN void wave_global2_trace(int qlen, int tlen, int w, const CigLds &L, int *n_ops)
+{
+	if (cig_diag_form(qlen, tlen, w)) wave_global2_trace_diag(qlen, tlen, w, L, n_ops); else wave_global2_trace_lds(qlen, tlen, w, L, n_ops);
+}
+// ksw_global2 (ksw.c:540-642) as one call (bwagpu_debug_dp's entry).  Returns the score; *n_ops < 0 when the traceback does not fit CIG_TMP_OPS.
+__device__ int wave_ksw_global2(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen, i64 t0, int tdir, int tlen,
+								int w, const CigLds &L, int *n_ops)
+{
+	u64 cells = 0;
+	cig_build_profile(opt, q, q0, qdir, qlen, L);
+	const int score = wave_global2_fill(ix, opt, qlen, t0, tdir, tlen, w, L, cells);
+	wave_global2_trace(qlen, tlen, w, L, n_ops);
 	return score;
 }
 
@@ -171,8 +324,10 @@ DEVFN int dev_infer_bw(int l1, int l2, int score, int a, int q, int r)
 }
 
 // One region: the band-doubling loop of mem_reg2aln (bwamem.c:1143-1152) around bwa_gen_cigar2 (bwa.c:148-195).
-__device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *query, const bwagpu_alnreg_t &p, const CigLds &L, bwagpu_cigar_t *out,
-							 u32 *ext, unsigned long long *ext_used, i64 ext_cap)
+// DIAG_ONLY (the first tier): only the diag form is compiled in -- no {H,E} arrays in LDS, fewer registers, more waves per CU --; a band of more
+// than 64 columns is deferred to the second tier like one whose directions do not fit.
+template <bool DIAG_ONLY> __device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *query, const bwagpu_alnreg_t &p, const CigLds &L, bwagpu_cigar_t *out,
+							 u32 *ext, unsigned long long *ext_used, i64 ext_cap, u64 &cells, u64 &n_dp)
 {
 	const int lane = threadIdx.x & 63;
 	const i64 rb = uni64(p.rb), re = uni64(p.re), l_pac = ix.l_pac;
@@ -190,9 +345,11 @@ __device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const 
 		w2 = w2 > tmp ? w2 : tmp;
 		if (w2 > opt.w) w2 = w2 < pw ? w2 : pw;
 		int i = 0, score = 0, last_sc = -(1 << 30), n_ops = -1;
-		bool give_up = false, defer = false;
+		bool give_up = false, defer = false, have_qp = false;
+		int w_fill = -1;                                  // band of the last matrix fill, whose traceback is still owed (the reference traces every attempt back and keeps the last one's CIGAR)
 		do {
 			w2 = w2 < opt.w << 2 ? w2 : opt.w << 2;
+			w_fill = -1;
 			if (l_query == rlen && w2 == 0) {     // no gap possible: one M run, score by direct comparison (bwa.c:171-174)
 				int s = 0;
 				for (int j = lane; j < l_query; j += 64) s += opt.mat[ref_base(ix, t0 + (i64)j * tdir) * 5 + query[q0 + j * qdir]];
@@ -209,15 +366,24 @@ __device__ void cigar_region(const DevIndex &ix, const bwagpu_opt_t &opt, const 
 				int w = (max_gap + dl + 1) >> 1; w = w < w2 ? w : w2;
 				const int min_w = dl + 3; w = w > min_w ? w : min_w;
 				const int n_col = l_query < 2 * w + 1 ? l_query : 2 * w + 1;
-				if (n_col > CIG_MAX_COLS || n_col * ((rlen + 1) & ~1) > CIG_Z_BIG) { give_up = true; break; }
-				if (n_col * ((rlen + 1) & ~1) > L.z_cells) { defer = true; break; }     // needs the second tier's LDS
-				score = wave_ksw_global2(ix, opt, query, q0, qdir, l_query, t0, tdir, rlen, w, L, &n_ops);
-				if (n_ops < 0) { give_up = true; break; }
+				const bool diag = cig_diag_form(l_query, rlen, w);
+				const int z_need = diag ? cig_diag_cells(rlen, w) : n_col * ((rlen + 1) & ~1);      // direction nibbles of this fill
+				if (!diag && n_col > CIG_MAX_COLS) { give_up = true; break; }
+				if (z_need > CIG_Z_BIG) { give_up = true; break; }
+				if (z_need > L.z_cells || (DIAG_ONLY && !diag)) { defer = true; break; }     // needs the second tier's LDS (or its other form)
+				if (!have_qp) { cig_build_profile(opt, query, q0, qdir, l_query, L); have_qp = true; }
+				score = DIAG_ONLY ? wave_global2_fill_diag(ix, opt, l_query, t0, tdir, rlen, w, L, cells) : wave_global2_fill(ix, opt, l_query, t0, tdir, rlen, w, L, cells);
+				++n_dp;
+				w_fill = w;
 			}
 			if (score == last_sc || w2 == opt.w << 2) break;
 			last_sc = score;
 			w2 <<= 1;
 		} while (++i < 3 && score < truesc - opt.a);
+		if (!give_up && !defer && w_fill >= 0) {
+			if (DIAG_ONLY) wave_global2_trace_diag(l_query, rlen, w_fill, L, &n_ops); else wave_global2_trace(l_query, rlen, w_fill, L, &n_ops);
+			if (n_ops < 0) give_up = true;
+		}
 		if (defer) res_n = -2;
 		else if (!give_up) {
 			int md_len = 0;
@@ -551,20 +717,21 @@ __global__ void __launch_bounds__(64) k_cigar_long(DevIndex ix, bwagpu_opt_t opt
 // and score below XA_drop_ratio times its score are left uncomputed (reason 1) -- the finalize stage hardly ever asks for them (they are
 // neither a line of their own nor within reach of an XA list, bwamem_extra.c:118-134), and should it ask, it computes them itself.  They are the
 // expensive ones: diverged repeat copies whose low score means a wide band (bwamem.c:818-825).
-__global__ void __launch_bounds__(256) k_cigar(DevIndex ix, bwagpu_opt_t opt, Batch B, i64 n_regs, const bwagpu_alnreg_t *regs, const i32 *reg_read, bwagpu_cigar_t *out,
+template <bool DIAG_ONLY> __global__ void __launch_bounds__(256, DIAG_ONLY ? 5 : 2) k_cigar(DevIndex ix, bwagpu_opt_t opt, Batch B, i64 n_regs, const bwagpu_alnreg_t *regs, const i32 *reg_read, bwagpu_cigar_t *out,
 											   unsigned long long *next, int z_cells, int tier, u32 *ext, unsigned long long *ext_used, i64 ext_cap, const i64 *best_of)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, cig_lds)
 	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	unsigned char *base = cig_lds + (size_t)wave_in_blk * CIG_LDS_BYTES(z_cells);
+	unsigned char *base = cig_lds + (size_t)wave_in_blk * (DIAG_ONLY ? CIG_LDS_BYTES_DIAG(z_cells) : CIG_LDS_BYTES(z_cells));
 	CigLds L;
 	L.hd = (i32*)base; L.e = L.hd + (CIG_MAX_LEN + 2 + 64);
 	L.qstride = CIG_MAX_LEN + 64; L.z_cells = z_cells;
-	L.qp = (int8_t*)(L.e + (CIG_MAX_LEN + 2 + 64));
+	L.qp = DIAG_ONLY ? (int8_t*)base : (int8_t*)(L.e + (CIG_MAX_LEN + 2 + 64));      // (the diag form keeps no {H,E} columns in LDS)
 	L.z = (u8*)(L.qp + 5 * L.qstride);
 	L.ops = (u32*)(L.z + z_cells / 2 + CIG_MAX_COLS);
 	L.md = (u8*)(L.ops + CIG_TMP_OPS);
 	WaveQueue wq; wq_init(wq);
+	u64 cells = 0, n_dp = 0;
 	for (;;) {
 		long long g;
 		if (!wq_next(wq, next, n_regs, g)) break;
@@ -580,7 +747,8 @@ __global__ void __launch_bounds__(256) k_cigar(DevIndex ix, bwagpu_opt_t opt, Ba
 				continue;
 			}
 		}
-		cigar_region(ix, opt, B.seq + B.off[r], p, L, out + g, ext, ext_used, ext_cap);
+		cigar_region<DIAG_ONLY>(ix, opt, B.seq + B.off[r], p, L, out + g, ext, ext_used, ext_cap, cells, n_dp);
 		if (tier > 0 && lane == 0 && out[g].n_cigar == -2) out[g].n_cigar = -1;
 	}
+	if (B.stats && lane == 0) { atomicAdd(&B.ctr->glb_cells, (unsigned long long)cells); atomicAdd(&B.ctr->glb_calls, (unsigned long long)n_dp); }      // (bwagpu_batch_cigars zeroes the two counters first: the batch's run is over)
 }

@@ -110,6 +110,7 @@ static inline int mock_update_dpp(int old, int src, int ctrl, int row_mask, int 
 	if (ctrl >= 0 && ctrl <= 0xff) s = (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3);      // quad_perm
 	else if (ctrl >= 0x111 && ctrl <= 0x11f) { int n = ctrl - 0x110; s = (l & 15) >= n ? l - n : -1; }
 	else if (ctrl == 0x138) s = l >= 1 ? l - 1 : -1;
+	else if (ctrl == 0x130) s = l < 63 ? l + 1 : -1;                                   // wave_shl:1 (the lane above)
 	else if (ctrl == 0x142) s = row >= 1 ? row * 16 - 1 : -1;
 	else if (ctrl == 0x143) s = row >= 2 ? 31 : -1;
 	else abort();
