@@ -121,6 +121,10 @@ def option_names(L: C.CDLL) -> list:
     return out
 
 
+import threading
+_CREATE_LOCK = threading.Lock()
+
+
 class BwaGpu:
     """One handle = one GPU with the index resident in HBM."""
 
@@ -129,14 +133,15 @@ class BwaGpu:
         that the ones shaping what is derived from the index at load time -- occ32, occ32_sb_shift, ptab_m -- apply) and forgotten again."""
         self.L = load_library(lib_path)
         self.h = C.c_void_p()
-        try:
-            for k, v in (options or {}).items():
-                if self.L.bwagpu_set_default_option(k.encode(), int(v)) != 0:
-                    raise BwaGpuError(f"unknown option {k!r}")
-            rc = self.L.bwagpu_create_from_files(C.byref(self.h), prefix.encode(), device)
-        finally:
-            if options:
-                self.L.bwagpu_clear_default_options()
+        with _CREATE_LOCK:      # (the defaults are process-wide: two handles created from two threads must not see each other's, or have theirs cleared)
+            try:
+                for k, v in (options or {}).items():
+                    if self.L.bwagpu_set_default_option(k.encode(), int(v)) != 0:
+                        raise BwaGpuError(f"unknown option {k!r}")
+                rc = self.L.bwagpu_create_from_files(C.byref(self.h), prefix.encode(), device)
+            finally:
+                if options:
+                    self.L.bwagpu_clear_default_options()
         if rc != 0:
             raise BwaGpuError(f"bwagpu_create_from_files({prefix}) failed: {self.L.bwagpu_strerror(rc).decode()}")
         self.set_taps(True)     # the library's default is off (a second region arena per batch); the tests read the stage taps, bench.py turns them off
