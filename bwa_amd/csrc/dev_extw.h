@@ -124,21 +124,25 @@ struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t 
 //      pass before (`bnd`) needs no handling --, forms M, the scan input and E(i+1,j), and runs its scan: NP independent chains the hardware interleaves;
 //   B  the carries are a running maximum of the NP scan totals; every pass then finishes F and H, writes its slots and takes part in the row maximum.
 // The arithmetic is the sequential form's, operation for operation; one fence per row instead of two per pass.
-template <int NP> DEVFN void ring_row_phased(int2 *eh, const int rmask, const int lane, const int beg, const int end, const int (&qc)[NP], const int (&srow)[5],
+template <int NP> DEVFN void ring_row_phased(int2 *eh, const int rmask, const int lane, const int beg, const int end, const int (&qc)[NP], const u64 spack,
 											 const int oe_ins, const int e_ins, const int oe_del, const int e_del, const int h1_init,
 											 int &m, int &mj, int &first_nz, int &last_nz, int &hprev)
 {
+	// (spack: the row's five scores -- reference base against query base 0..4 -- one per byte: a lane's score is a shift and a sign extension;
+	// an array indexed by the base went to scratch memory, with a branch around every load)
+	int2 old[NP];
+	#pragma unroll
+	for (int p = 0; p < NP; ++p) old[p] = eh[(beg + 64 * p + lane) & rmask];
 	int hm[NP], inc[NP], en[NP];
 	#pragma unroll
 	for (int p = 0; p < NP; ++p) {
 		const int j = beg + 64 * p + lane; const bool act = j < end;
-		const int2 old = eh[j & rmask];
-		const int c = qc[p];
-		const int sc = c == 0 ? srow[0] : c == 1 ? srow[1] : c == 2 ? srow[2] : c == 3 ? srow[3] : srow[4];
-		const int Mp = old.x ? wadd(old.x, sc) : 0;                    // ksw.c:469: a dead diagonal cell stays dead
+		const int sc = (int)(int8_t)(u8)(spack >> (8 * qc[p]));
+		const int Ms = wadd(old[p].x, sc);
+		const int Mp = old[p].x != 0 ? Ms : 0;                        // ksw.c:469: a dead diagonal cell stays dead
 		inc[p] = wave_incl_scan_max(act ? imax(Mp - oe_ins, 0) + j * e_ins : W_NEG);
-		en[p] = imax(imax(wsub(old.y, e_del), wsub(Mp, oe_del)), 0);  // E(i+1,j), ksw.c:475-479
-		hm[p] = imax(Mp, old.y);
+		en[p] = imax(imax(wsub(old[p].y, e_del), wsub(Mp, oe_del)), 0);   // E(i+1,j), ksw.c:475-479
+		hm[p] = imax(Mp, old[p].y);
 	}
 	int carry = W_NEG;
 	#pragma unroll
@@ -521,9 +525,9 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			if constexpr (RING) { if (n_pass >= 2 && n_pass <= 2 * PHASED_NP) {
 				phased = true;
 				// all passes of the row at once (ring_row_phased): NP = 4 for bands of up to 256 columns, 8 up to 512
-				int srow[5];
+				u64 srow = 0;
 				#pragma unroll
-				for (int k = 0; k < 5; ++k) srow[k] = __builtin_amdgcn_readlane(matv, tb * 5 + k);
+				for (int k = 0; k < 5; ++k) srow |= (u64)(u8)__builtin_amdgcn_readlane(matv, tb * 5 + k) << (8 * k);
 				const bool have_pre = beg == qv_beg;              // the bases asked for a row ago are this row's (the band moved on by one column)
 				if (n_pass <= PHASED_NP) {
 					int qc[PHASED_NP];
