@@ -114,62 +114,6 @@ DEVFN bwagpu_seed_t uni_seed(bwagpu_seed_t s) { s.rbeg = uni64(s.rbeg); s.qbeg =
 // made both long-read DP kernels 14-18 % slower -- its LDS halves the resident waves -- and the row form gained nothing, BENCH_r03 variants: both deleted.)
 struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t *mat; };
 
-// One multi-pass row of ring mode with ALL its passes computed together (long reads; bands of 65 .. 64 NP columns).
-// The pass loop of wave_ksw_extend2 below handles 64 columns at a time, each pass a dependent chain -- LDS read, diagonal term, six-step scan, carry
-// from the pass before, H, LDS write, fence -- and a long-read batch runs one or two waves per SIMD, so nothing hides any of it: ~600 ns per pass,
-// 4 to 7 passes per row of a 10 kb read's 201- or 401-column bands (profiles/r04_longread_sq_counters.md: ~10 cycles per instruction).  Only two
-// things really tie a pass to the one before: the carry of the F scan (a maximum over the earlier passes' scan totals) and H of the previous pass's
-// last column (which feeds nothing but the zero-trimming test).  So the row is written in two phases over register arrays indexed by pass:
-//   A  every pass reads its {H(i-1,j-1), E(i,j)} slots -- all reads before any write, so the boundary value the sequential form has to save from the
-//      pass before (`bnd`) needs no handling --, forms M, the scan input and E(i+1,j), and runs its scan: NP independent chains the hardware interleaves;
-//   B  the carries are a running maximum of the NP scan totals; every pass then finishes F and H, writes its slots and takes part in the row maximum.
-// The arithmetic is the sequential form's, operation for operation; one fence per row instead of two per pass.
-template <int NP> DEVFN void ring_row_phased(int2 *eh, const int rmask, const int lane, const int beg, const int end, const int (&qc)[NP], const u64 spack,
-											 const int oe_ins, const int e_ins, const int oe_del, const int e_del, const int h1_init,
-											 int &m, int &mj, int &first_nz, int &last_nz, int &hprev)
-{
-	// (spack: the row's five scores -- reference base against query base 0..4 -- one per byte: a lane's score is a shift and a sign extension;
-	// an array indexed by the base went to scratch memory, with a branch around every load)
-	int2 old[NP];
-	#pragma unroll
-	for (int p = 0; p < NP; ++p) old[p] = eh[(beg + 64 * p + lane) & rmask];
-	int hm[NP], inc[NP], en[NP];
-	#pragma unroll
-	for (int p = 0; p < NP; ++p) {
-		const int j = beg + 64 * p + lane; const bool act = j < end;
-		const int sc = (int)(int8_t)(u8)(spack >> (8 * qc[p]));
-		const int Ms = wadd(old[p].x, sc);
-		const int Mp = old[p].x != 0 ? Ms : 0;                        // ksw.c:469: a dead diagonal cell stays dead
-		inc[p] = wave_incl_scan_max(act ? imax(Mp - oe_ins, 0) + j * e_ins : W_NEG);
-		en[p] = imax(imax(wsub(old[p].y, e_del), wsub(Mp, oe_del)), 0);   // E(i+1,j), ksw.c:475-479
-		hm[p] = imax(Mp, old[p].y);
-	}
-	int carry = W_NEG;
-	#pragma unroll
-	for (int p = 0; p < NP; ++p) {
-		const int b = beg + 64 * p, j = b + lane; const bool act = j < end;
-		const bool live = b < end;                                    // (wave-uniform: a pass past the row's end writes nothing and counts for nothing)
-		const int exc = imax(wave_shift_up1(inc[p], W_NEG), carry);
-		const int f = j == beg ? 0 : exc - (j - 1) * e_ins;           // F(i,j): best insertion ending left of column j
-		const int h = imax(hm[p], f);                                 // H(i,j) = max(M, E, F), ksw.c:470-471
-		if (act) {
-			eh[j & rmask].y = en[p];
-			eh[(j + 1) & rmask].x = h;                                 // becomes the diagonal of column j+1 in row i+1
-		}
-		if (j == beg) eh[j & rmask].x = h1_init;
-		const int hleft = wave_shift_up1(h, hprev);                   // eh[j].h after this row = H(i,j-1)
-		const u64 nzm = wave_ballot((hleft | en[p]) != 0) & wave_ballot(act);
-		if (nzm) { if (first_nz < 0) first_nz = b + __ffsll((unsigned long long)nzm) - 1; last_nz = b + 63 - __clzll((long long)nzm); }
-		// row maximum with "last column wins ties" (ksw.c:473-474): one scan over (h << 6 | lane)
-		const int key = __builtin_amdgcn_readlane(wave_incl_scan_max(act ? (h << 6 | lane) : -1), 63);
-		if ((key >> 6) >= m && live) { m = key >> 6; mj = b + (key & 63); }
-		carry = imax(carry, __builtin_amdgcn_readlane(inc[p], 63));
-		const int nact = end - b < 64 ? end - b : 64;
-		const int hl = __builtin_amdgcn_readlane(h, live ? nact - 1 : 0);
-		hprev = live ? hl : hprev;
-	}
-}
-
 template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, int mat_max, const u8 *q, int q0, const int qdir, int qlen,
 								   i64 t0, const int tdir, int tlen, int w, int end_bonus, int h0, const WaveLds &L, u64 &cells, u64 &fast)
 {
@@ -237,11 +181,6 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 	}
 	int init_hi = -1;                                  // RING: columns 0..init_hi hold valid (initial or computed) values
 	int q_pre = 4, q_pre_beg = -1;                     // RING: the query bases of columns q_pre_beg + lane, asked for a row ahead (see the multi-pass rows)
-	constexpr int PHASED_NP = 4;                       // ring_row_phased (ring mode): rows of up to 4 / 8 passes at once
-	int qv[RING ? 8 : 1]; int qv_beg = -1;             // ... and its bases, pass by pass, asked for a row ahead
-	#pragma unroll
-	for (int p = 0; p < (RING ? 8 : 1); ++p) qv[p] = 4;
-	const int matv = RING ? (int)L.mat[lane < 25 ? lane : 24] : 0;      // the scoring matrix, entry k in lane k (a row's five scores are lane reads)
 	int lim = trunc_div_add(qlen * mat_max + end_bonus - o_ins, e_ins, 1); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	lim = trunc_div_add(qlen * mat_max + end_bonus - o_del, e_del, 1); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	w = uni(w);
@@ -520,36 +459,6 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			// starts (for the usual case that the band moves on by one column; anything else loads it here).  (Measured on 6000 x 10 kb reads: the stage's
 			// time did not move, 361-411 ms either way -- the row's dependent DPP/LDS chain at one wave per SIMD is the longer wait; kept because it is never slower.)
 			int qc_next = 4;
-			const int n_pass = (end - beg + 63) >> 6;
-			bool phased = false;
-			if constexpr (RING) { if (n_pass >= 2 && n_pass <= 2 * PHASED_NP) {
-				phased = true;
-				// all passes of the row at once (ring_row_phased): NP = 4 for bands of up to 256 columns, 8 up to 512
-				u64 srow = 0;
-				#pragma unroll
-				for (int k = 0; k < 5; ++k) srow |= (u64)(u8)__builtin_amdgcn_readlane(matv, tb * 5 + k) << (8 * k);
-				const bool have_pre = beg == qv_beg;              // the bases asked for a row ago are this row's (the band moved on by one column)
-				if (n_pass <= PHASED_NP) {
-					int qc[PHASED_NP];
-					#pragma unroll
-					for (int p = 0; p < PHASED_NP; ++p) { const int j = beg + 64 * p + lane; qc[p] = have_pre ? qv[p] : (j < qlen ? QBASE(q0 + j * qdir) : 4); }
-					#pragma unroll
-					for (int p = 0; p < 2 * PHASED_NP; ++p) { const int j = beg + 1 + 64 * p + lane; qv[p] = (p <= n_pass && j < qlen) ? QBASE(q0 + j * qdir) : 4; }
-					qv_beg = beg + 1;
-					ring_row_phased<PHASED_NP>(eh, L.ring_mask, lane, beg, end, qc, srow, oe_ins, e_ins, oe_del, e_del, h1_init, m, mj, first_nz, last_nz, hprev);
-				} else {
-					int qc[2 * PHASED_NP];
-					#pragma unroll
-					for (int p = 0; p < 2 * PHASED_NP; ++p) { const int j = beg + 64 * p + lane; qc[p] = have_pre ? qv[p] : (j < qlen ? QBASE(q0 + j * qdir) : 4); }
-					#pragma unroll
-					for (int p = 0; p < 2 * PHASED_NP; ++p) { const int j = beg + 1 + 64 * p + lane; qv[p] = (p <= n_pass && j < qlen) ? QBASE(q0 + j * qdir) : 4; }
-					qv_beg = beg + 1;
-					ring_row_phased<2 * PHASED_NP>(eh, L.ring_mask, lane, beg, end, qc, srow, oe_ins, e_ins, oe_del, e_del, h1_init, m, mj, first_nz, last_nz, hprev);
-				}
-				if (lane == 0) { eh[EHI(end)].x = beg < end ? hprev : h1_init; eh[EHI(end)].y = 0; }
-				wave_sync();
-			} }
-			if (!phased) {
 			if (RING) {
 				const int j0 = beg + lane;
 				qc_next = (beg == q_pre_beg) ? q_pre : (j0 < qlen ? QBASE(q0 + j0 * qdir) : 4);
@@ -597,7 +506,6 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			}
 			if (lane == 0) { eh[EHI(end)].x = beg < end ? hprev : h1_init; eh[EHI(end)].y = 0; }
 			wave_sync();
-			}
 		}
 		const int h1 = beg < end ? hprev : h1_init;      // H(i, end-1) as left in h1 by the reference's column loop
 		const int jfin = beg < end ? end : beg;

@@ -17,11 +17,15 @@ def main():
     ap.add_argument("--reads", type=int, default=20000)
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--cigars", action="store_true")
+    ap.add_argument("--options", default="", help="library options for this run, e.g. 'ext_phased=0'")
+    ap.add_argument("--passes", type=int, default=1, help="timed passes (the best is reported)")
     ap.add_argument("--cache", default=os.environ.get("BWA_AMD_CACHE", "/tmp/bwa_amd_bench"))
     a = ap.parse_args()
     import torch
     fa, g, _ = bench.build_or_load_index(a.genome_mbp, a.cache, 0, lambda: torch.cuda.synchronize())
     gpu = BwaGpu(fa); gpu.densify_sa(4); gpu.set_taps(False)
+    for kv in a.options.split():
+        k, v = kv.split("=", 1); gpu.set_option(k, int(v))
     rd = simdata.make_reads_long(g, a.reads, length=a.read_len, seed=7)      # SURVEY 8d's PacBio-like model: 1.5 % sub, 4 % del, 9 % ins
     off = np.arange(0, a.reads + 1, dtype=np.int64) * a.read_len
     opt = pacbio_opt()
@@ -41,8 +45,11 @@ def main():
         rows = [(b, hist[base + b], hist[base + 32 + b], hist[base + 64 + b]) for b in range(32) if hist[base + b]]
         print(f"[longread] {name}, reads by wave time: " + "; ".join(f"<{(1 << b) / 1e5:.3g} ms: {n} reads, {c / n:.1f} DP calls and {x * 1024 / n / 1e6:.2f} M cells each" for b, n, c, x in rows), flush=True)
     gpu.set_stats(False)
-    t = time.time(); gpu.run(opt); dt = time.time() - t
-    st = gpu.stats()
+    dt, st = 1e9, None
+    for _ in range(max(1, a.passes)):
+        t = time.time(); gpu.run(opt); d_ = time.time() - t
+        if d_ < dt:
+            dt, st = d_, gpu.stats()
     counts, regs = gpu.download()
     if a.cigars:       # the CIGAR stage as `bwa-amd mem` drives it; BWAGPU_CIG_TRACE=1 splits it into its launches on stderr
         for k in range(2):
