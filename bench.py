@@ -130,7 +130,7 @@ def run_instrumented(prefix: str, files, threads: int):
     return {"n_reads": n, "n_2occ4": k[0] / n, "N_blk": k[1] / n, "N_sa": k[2] / n, "N_lf": k[3] / n, "W_ref": k[4] / n, "ext_calls": k[5] / n, "ext_cells": k[6] / n, "glb_cells": k[7] / n}
 
 
-def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: int | None = None, K: int = 100000000, extra=(), devices=None, timeout: float = 240.0):
+def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: int | None = None, K: int = 100000000, extra=(), devices=None, timeout: float = 240.0, out_from_batch: int = 0):
     """The stand-alone `bwa-amd mem` (FASTQ in -> device hot path + device CIGARs / mate rescue -> host finalize -> SAM text).
     devices: device ids for BWAGPU_DEVICES (every batch is split over them), None = device 0."""
     cli = os.path.join(ROOT, "bwa_amd", "bwa-amd")
@@ -138,6 +138,8 @@ def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: 
     env = dict(os.environ, BWAGPU_CLI_TRACE="1")      # (per-batch timings of the device stage on stderr, averaged below)
     if streams:
         env["BWAGPU_CLI_STREAMS"] = str(streams)
+    if out_from_batch > 0:
+        env["BWAGPU_CLI_OUT_FROM_BATCH"] = str(out_from_batch)
     if devices and len(devices) > 1:
         env["BWAGPU_DEVICES"] = ",".join(str(d) for d in devices)
     t = time.time()
@@ -158,6 +160,14 @@ def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: 
     if busy and n_reads:     # busy seconds of each pipeline stage -> microseconds per read (a stage's share of one host core, or of the device)
         for name, sec in re.findall(r"([a-z+]+) ([\d.]+) s", busy.group(1)):
             stage_us[name] = round(float(sec) / n_reads * 1e6, 3)
+    retries = [int(x) for x in re.findall(r"\(retries (\d+)", p.stderr)]
+    cpu = re.search(r"stage CPU time: total ([\d.]+) s = ([\d.]+) us per read; read ([\d.]+) s, encode ([\d.]+) s, device threads ([\d.]+) s, finalize\+pestat pools ([\d.]+) s, write ([\d.]+) s; one process on (\d+) threads tops out near ([\d.]+) Mreads/s .* single reader thread near ([\d.]+)", p.stderr)
+    cpu_us = {}
+    if cpu and n_reads:
+        names = ("total", "read", "encode", "device_threads", "finalize_pestat_pools", "write")
+        vals = (cpu.group(1),) + cpu.groups()[2:7]
+        cpu_us = {k_: round(float(v_) / n_reads * 1e6, 4) for k_, v_ in zip(names, vals)}
+        cpu_us["one_process_ceiling_Mreads_s"] = float(cpu.group(9)); cpu_us["single_reader_ceiling_Mreads_s"] = float(cpu.group(10)); cpu_us["threads"] = int(cpu.group(8))
     hm = re.search(r"over (\d+) handles", p.stderr)
     dev = re.findall(r"\[D::device_sub\] (\d+) reads .*: upload ([\d.]+) run ([\d.]+) download\+cigars ([\d.]+) pestat\+matesw ([\d.]+) s \(pestat ([\d.]+), (\d+) mate", p.stderr)
     dev_ms = {}
@@ -173,7 +183,52 @@ def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: 
         for k_, name in enumerate(("pack_kernel", "download_copy", "cigar_kernels", "cigar_copies")):
             dev_ms[name] = round(sum(float(a_[k_]) for a_ in after) / len(after), 1)
     return {"reads_per_s": float(m.group(3)), "n": n_reads, "wall_s": wall, "stages": busy.group(1) if busy else "", "stage_us_per_read": stage_us, "handles": int(hm.group(1)) if hm else None, "device_stage_ms_per_batch": dev_ms,
-            "n_batches": len(re.findall(r"\[M::process\] read \d+ sequences", p.stderr))}
+            "n_batches": len(re.findall(r"\[M::process\] read \d+ sequences", p.stderr)), "retries": sum(retries) if retries else 0, "cpu_us_per_read": cpu_us}
+
+
+def measure_traffic(prefix: str, batch_file: str, dense_sa: int, layout: str, cache: str, limit_s: float = 45.0):
+    """HBM-side traffic of every hot-path kernel, measured IN THIS RUN: two child processes under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE` (separate passes: the TCC block cannot count both at once) over one solo batch of the headline's reads (tools/pmc_child.py), each under
+    `timeout -s KILL` (rocprofv3 7.2 can hang in its own finalisation).  Returns (tools/pmc_summary.py's per-kernel dict, seconds) or (None, reason)."""
+    import shutil
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    t = time.time()
+    dirs = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(cache, "pmc_" + ctr.lower())
+        shutil.rmtree(d, ignore_errors=True)
+        cmd = ["timeout", "-s", "KILL", str(int(limit_s)), prof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "c", "--",
+               sys.executable, os.path.join(ROOT, "tools", "pmc_child.py"), "--prefix", prefix, "--batch", batch_file, "--dense-sa", str(dense_sa), "--layout", layout]
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=limit_s + 15, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        except subprocess.TimeoutExpired:
+            return None, f"{ctr} pass did not end within {limit_s + 15:.0f} s"
+        if p.returncode != 0 or "pmc_child done" not in p.stdout:
+            return None, f"{ctr} pass failed (rc {p.returncode}): {p.stdout[-200:]}"
+        dirs[ctr] = d
+    try:
+        res = pmc_summary.summarize("bench.py in-run passes", dirs["FETCH_SIZE"], dirs["WRITE_SIZE"])
+    except Exception as e:
+        return None, "summary failed: " + repr(e)
+    for d in dirs.values():
+        shutil.rmtree(d, ignore_errors=True)
+    return res, round(time.time() - t, 1)
+
+
+def kernel_traffic(pj, k, alg_bytes):
+    """Counter traffic of kernel k (raw: FETCH_SIZE counts 64 bytes per request whatever its size) and how many times its algorithmic bytes that is."""
+    if not pj:
+        return {}
+    names = [k] + (["k_seed3"] if k == "k_seed" else [])
+    f = sum(pj.get(n, {}).get("FETCH_SIZE_KB", 0.0) for n in names) * 1024.0
+    w = sum(pj.get(n, {}).get("WRITE_SIZE_KB", 0.0) for n in names) * 1024.0
+    if f + w <= 0:
+        return {}
+    return {"traffic_raw_GB": round((f + w) / 1e9, 3), "fetch_raw_GB": round(f / 1e9, 3), "write_GB": round(w / 1e9, 3), "wasted_traffic": round((f + w) / alg_bytes, 2) if alg_bytes > 0 else None}
 
 
 def effective_cpus() -> int:
@@ -211,6 +266,9 @@ def main():
     ap.add_argument("--e2e-reads", type=int, default=12_000_000, help="reads of the end-to-end runs (pipeline fill and drain cost ~0.8 s whatever the length)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference runs (and with them the parity gate)")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (roofline.traffic then comes from profiles/pmc_latest.json and says so)")
+    ap.add_argument("--long-extra", default="10000,20000", help="further long-read batch sizes whose hot-path rate is reported (10 000 reads of 10 kb = the reference's -K of 100 Mbase); '' = none")
+    ap.add_argument("--tail-batches", type=int, default=3, help="full-size batches at the END of the end-to-end run whose SAM is compared with the reference's (arena re-use at depth); 0 = skip")
     ap.add_argument("--parity-pairs", type=int, default=800_000, help="pairs of the multi-batch paired-end parity / CPU-baseline sample (twelve batches)")
     ap.add_argument("--no-longread", action="store_true", help="skip the BASELINE configs[4] leg (10 kb reads, -x pacbio)")
     ap.add_argument("--long-reads", type=int, default=6000)
@@ -288,10 +346,11 @@ def main():
         batches.append(rd)
     n_batch = batches[0].shape[0]
     variant_files = []
-    if world == 1 and args.variants.strip() and not args.no_cpu_baseline:       # the variants leg (a child process at the end) runs on these very batches
+    if world == 1 and ((args.variants.strip() and not args.no_cpu_baseline) or not args.no_pmc):       # the variants leg and the counter passes (child processes at the end) run on these very batches
         for si, rd in enumerate(batches):
-            variant_files.append(os.path.join(os.path.dirname(prefix), f"variant_batch{si}.npy"))
-            np.save(variant_files[-1], rd)
+            if si == 0 or (args.variants.strip() and not args.no_cpu_baseline):
+                variant_files.append(os.path.join(os.path.dirname(prefix), f"variant_batch{si}.npy"))
+                np.save(variant_files[-1], rd)
 
     log(f"[bench] index resident, {S} batches of {n_batch} reads uploaded")
     # one untimed instrumented solo pass: algorithmic work counters of batch 0 (roofline numerator) and solo kernel times
@@ -330,6 +389,23 @@ def main():
         dt = float(t.item())
     counts, regs = gpu.download()
     digest = hashlib.sha256(counts.tobytes() + regs.tobytes()).hexdigest()[:16]
+    cigar_stage = None
+    try:       # the CIGAR stage of the same batch, alone on the chip (bwagpu_batch_cigars with the command line's XA-aware filter): kernels' time, DP cells
+        import ctypes as C_
+        gpu.L.bwagpu_set_cigar_filter.argtypes = [C_.c_void_p, C_.c_int]
+        gpu.L.bwagpu_set_cigar_filter(gpu.h, 1)
+        gpu.set_stats(True); cg = gpu.cigars(opt); st_c = gpu.stats(); gpu.set_stats(False)
+        ms_c = []
+        for _ in range(2):
+            cg = gpu.cigars(opt); ms_c.append(gpu.stats()["ms_cigar_kernels"])
+        gpu.L.bwagpu_set_cigar_filter(gpu.h, 0)
+        cigar_stage = {"kernels_ms": round(min(ms_c), 3), "regions": int(regs.shape[0]), "served": int((cg["n_cigar"] > 0).sum()), "filtered": int(((cg["n_cigar"] < 0) & (cg["score"] == 1)).sum()),
+                       "left_to_host": int(((cg["n_cigar"] < 0) & (cg["score"] != 1)).sum()), "dp_fills": int(st_c["n_cig_dp"]), "cigar_cells_per_read": round(st_c["n_cig_cells"] / max(1, n_batch), 1),
+                       "gcups": round(st_c["n_cig_cells"] / (min(ms_c) * 1e-3) / 1e9, 1) if min(ms_c) > 0 else None,
+                       "what": "bwagpu_batch_cigars on timed batch 0 alone (k_cigar's two tiers + k_cigar_long, NM/MD included), with `bwa-amd mem`'s filter: regions that can appear neither as a record nor in an XA tag are skipped"}
+        del cg
+    except Exception as e:
+        cigar_stage = {"error": repr(e)}
     for hdl in handles[1:]:
         hdl.close()
     if dist is not None:
@@ -368,9 +444,20 @@ def main():
     # `traffic` is the corrected one (fetch / 2 + write for the 32-byte layout), the raw counters and the request count are beside it.
     traffic, traffic_src, traffic_detail = None, None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc):
+    pj, pmc_note = None, None
+    if world == 1 and not args.no_pmc and variant_files:
+        log("[bench] counter passes: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over one solo batch (two child processes)")
+        pj, pmc_note = measure_traffic(prefix, variant_files[0], args.dense_sa, args.layout, os.path.dirname(prefix))
+        if pj is None:
+            log("[bench] counter passes failed:", pmc_note)
+    measured_here = pj is not None
+    if pj is None and os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
+        except Exception:
+            pj = None
+    if pj is not None:
+        try:
             names = [roof_k] + (["k_seed3"] if roof_k == "k_seed" else [])     # the seeding stage is two kernels since round 2 (pass 3 runs first)
             fetch = sum(pj.get(k_, {}).get("FETCH_SIZE_KB", 0.0) for k_ in names) * 1024.0       # (tools/pmc_summary.py's figures are per launch already)
             write = sum(pj.get(k_, {}).get("WRITE_SIZE_KB", 0.0) for k_ in names) * 1024.0
@@ -383,8 +470,11 @@ def main():
             if traffic_detail:
                 dev_alg = alg[roof_k] - (64.0 - blk_bytes) * work["n_occ_blocks"] if roof_k == "k_seed" else alg[roof_k]
                 traffic_detail["corrected_over_device_layout_alg"] = round(traffic / dev_alg, 3) if dev_alg > 0 else None
-            traffic_src = ("NOT measured in this run: read from profiles/pmc_latest.json (" + str(pj.get("_meta", {}).get("what", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes")) +
-                           ", taken " + str(pj.get("_meta", {}).get("date", "in an earlier run of the same workload")) + ")")
+            if measured_here:
+                traffic_src = f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in two child processes over one solo batch of the headline's reads (tools/pmc_child.py, {pmc_note} s)"
+            else:
+                traffic_src = ("NOT measured in this run (" + str(pmc_note or "--no-pmc") + "): read from profiles/pmc_latest.json (" + str(pj.get("_meta", {}).get("what", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes")) +
+                               ", taken " + str(pj.get("_meta", {}).get("date", "in an earlier run of the same workload")) + ")")
         except Exception:
             traffic = None
     layout = f"{n_batch // 2} pairs of 2x{args.read_len} bp (mates interleaved)" if pe else f"{n_batch} single-end {args.read_len} bp reads"
@@ -413,7 +503,7 @@ def main():
                      "alg_bytes_note": "SURVEY 8(d)'s unit: 64 bytes per Occ block of the REFERENCE layout (N_blk counted per rank-query pair exactly as bwt_2occ4 does, 1 if k and l share a 128-base block else 2), "
                                        f"16 bytes per prefix-table entry, l_seq/2 for the read; the device's own index blocks are {int(blk_bytes)} bytes, see achieved_device_layout",
                      "achieved_device_layout": round((alg["k_seed"] - (64.0 - blk_bytes) * work["n_occ_blocks"]) / (dur["k_seed"] * 1e-3) / 1e9, 2) if roof_k == "k_seed" and dur["k_seed"] > 0 else None,
-                     "per_kernel": {k: {"ms": round(dur[k], 3), "alg_GB": round(alg[k] / 1e9, 3), "GB/s": round(alg[k] / (dur[k] * 1e-3) / 1e9, 1) if dur[k] > 0 else None} for k in dur},
+                     "per_kernel": {k: dict({"ms": round(dur[k], 3), "alg_GB": round(alg[k] / 1e9, 3), "GB/s": round(alg[k] / (dur[k] * 1e-3) / 1e9, 1) if dur[k] > 0 else None}, **kernel_traffic(pj, k, alg[k])) for k in dur},
                      "random_request_ceiling": {"requests_per_s_by_bytes": {str(k): v for k, v in ceil.items()},
                                                 "source": "tools/randbw2.hip on MI355X (profiles/r02_experiments.md): dependent random reads from a 4 GiB table saturate at 48.3 / 37.8 / 23.0 G/s for 16 / 32 / 64-byte requests",
                                                 # time the seeding stage's algorithmic requests alone would need at those ceilings (index blocks of the layout in use + 16-byte
@@ -422,6 +512,7 @@ def main():
                                                 "seeding_frac": round((n_blk / ceil[int(blk_bytes)] + n_tab / ceil[16]) / seed_s, 4) if seed_s > 0 else None},
                      "ext_gcups": round(work["n_ext_cells"] / (stage_ms["ms_extend"] * 1e-3) / 1e9, 1) if stage_ms["ms_extend"] > 0 else None},
         "stage_ms_solo": {k: round(v, 3) for k, v in stage_ms.items()},
+        "cigar_stage": cigar_stage,
         "work_per_read": {"N_blk": round(work["n_occ_blocks"] / nr, 1), "N_tab": round(work["n_tab_lookups"] / nr, 1), "N_lf": round(work["n_lf_steps"] / nr, 1),
                           "N_sa": round(work["n_seeds"] / nr, 2), "ext_cells": round(work["n_ext_cells"] / nr, 0), "ext_calls": round(work["n_ext_calls"] / nr, 2),
                           "ext_fast": round(work["n_ext_fast"] / nr, 2), "regs": round(work["n_regs"] / nr, 3)},
@@ -508,12 +599,37 @@ def main():
             e2e = run_product(prefix, [f1, f2], threads, None, devices=devices)
             if e2e:
                 out["end_to_end_pe"] = {"value": round(e2e["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "n_gpus": world, "stages": e2e["stages"], "stage_us_per_read": e2e["stage_us_per_read"],
-                                        "device_stage_ms_per_batch": e2e["device_stage_ms_per_batch"], "handles": e2e["handles"],
+                                        "device_stage_ms_per_batch": e2e["device_stage_ms_per_batch"], "handles": e2e["handles"], "retries": e2e["retries"], "cpu_us_per_read": e2e["cpu_us_per_read"],
                                         "what": f"`bwa-amd mem -t {threads}` on {n_e // 2} pairs as two FASTQ files (the BASELINE metric's layout, SAM discarded; the same command's SAM is what parity.pe compares): parsing + H2D + "
                                                 f"device hot path + device CIGARs and mate-rescue alignments + D2H + mem_pestat/pairing/SAM text on the host, batches of 100 Mbp"
                                                 + (f", every batch split over devices {devices} (BWAGPU_DEVICES)" if world > 1 else "") + "; wall time after the index is loaded"}
                 if ref_pe:
                     out["end_to_end_pe"]["vs_cpu_baseline"] = round(e2e["reads_per_s"] / ref_pe["reads_per_s"], 1)
+                if args.tail_batches > 0 and world == 1:
+                    # arena re-use at depth, at full batch size: the SAM of the LAST batches of this very input (every handle's last batch: its arenas, learnt sizes and packed
+                    # buffers have been through five or six batches by then) against the reference on exactly those reads -- same -K, so the batches and mem_pestat are the same
+                    per_batch = -(-100_000_000 // args.read_len); per_batch += per_batch & 1
+                    n_b = -(-n_e // per_batch)
+                    b0 = max(0, n_b - args.tail_batches)
+                    lo = b0 * per_batch // 2
+                    t1f, t2f = os.path.join(cache, "tail_1.fq"), os.path.join(cache, "tail_2.fq")
+                    simdata.write_fastq(t1f, r1[lo:], suffix="/1", start=lo); simdata.write_fastq(t2f, r2[lo:], suffix="/2", start=lo)
+                    ref_t = run_reference(prefix, [t1f, t2f], threads, os.path.join(cache, "ref_tail.sam"))
+                    our_t = run_product(prefix, [f1, f2], threads, os.path.join(cache, "our_tail.sam"), devices=devices, out_from_batch=b0)
+                    tail = {"batches": n_b - b0, "of": n_b, "reads": int(n_e - 2 * lo), "ok": False}
+                    if ref_t and our_t:
+                        a, b = sam_body_digest(os.path.join(cache, "ref_tail.sam")), sam_body_digest(os.path.join(cache, "our_tail.sam"))
+                        tail["ok"] = bool(a == b and a[1] >= n_e - 2 * lo); tail["records"] = a[1]
+                        tail["how"] = f"`bwa-amd mem` on all {n_e // 2} pairs writing only the records of its last {n_b - b0} batches (BWAGPU_CLI_OUT_FROM_BATCH={b0}) vs `bwa mem` on those reads alone, -K 100000000 on both sides: sha256 of the SAM text minus @PG"
+                    out["parity"]["e2e_tail"] = tail
+                    if not tail["ok"]:
+                        rc_exit = 3
+                        log("[bench] PARITY GATE FAILED (tail of the end-to-end run):", tail)
+                    for f_ in (t1f, t2f, os.path.join(cache, "ref_tail.sam"), os.path.join(cache, "our_tail.sam")):
+                        try:
+                            os.remove(f_)
+                        except OSError:
+                            pass
                 if world == 1 and args.e2e_handles > 0 and args.e2e_handles != e2e["handles"]:
                     # the same command with more batches in flight: a handle's share of the chip idles while its batch is in the download /
                     # mem_pestat / mate-rescue part of the device stage, which more handles fill (a measurement next to the default, not the default)
@@ -542,6 +658,7 @@ def main():
     out["summary"] = {"value_hot_path_Mreads_s": out["value"], "end_to_end_pe_Mreads_s": out.get("end_to_end_pe", {}).get("value"), "roofline_frac": out["roofline"]["frac"],
                       "cpu_baseline_Mreads_s": out.get("cpu_baseline", {}).get("value"),
                       "parity": {"se": par_.get("se"), "pe": par_.get("pe"), "multibatch": par_.get("multibatch"), "timed_batch": (par_.get("timed_batch") or {}).get("ok"),
+                                 "e2e_tail": (par_.get("e2e_tail") or {}).get("ok"),
                                  "long": lr_.get("parity"), "long_reads": lr_.get("parity_reads"), "long_multibatch": lr_.get("multibatch")},
                       "longread_reads_s": lr_.get("reads_per_s"), "rc": rc_exit}
     log("[bench] SUMMARY " + json.dumps(out["summary"]))
@@ -667,9 +784,24 @@ def longread_bench(args, prefix, g, threads, cache):
     ms, st = [], None
     for _ in range(args.long_steps):
         t = time.perf_counter(); gpu.run(opt); ms.append((time.perf_counter() - t) * 1e3); st = gpu.stats()
-    gpu.close()
     best = min(ms)
     log(f"[bench] long-read hot path: {best:.1f} ms per pass; stages {st}")
+    by_size = {}
+    for m_ in [int(x) for x in args.long_extra.split(",") if x.strip()]:      # other batch sizes (10 000 reads of 10 kb = the reference's -K of 100 Mbase, fastmap.c:394)
+        if m_ == n or time.time() - _T0 > args.wall_budget + 120:
+            continue
+        try:
+            rd2 = simdata.make_reads_long(g, m_, length=L, seed=7 + m_)
+            gpu.upload(np.ascontiguousarray(rd2.reshape(-1)), np.arange(0, m_ + 1, dtype=np.int64) * L)
+            del rd2
+            gpu.run(opt)
+            t = time.perf_counter(); gpu.run(opt); d_ = (time.perf_counter() - t) * 1e3
+            s2 = gpu.stats()
+            by_size[str(m_)] = {"reads_per_s": round(m_ / d_ * 1e3, 1), "ms_per_pass": round(d_, 1), "stage_ms": {k: round(s2[k], 1) for k in ("ms_seed", "ms_chain", "ms_seedsw", "ms_extend", "ms_dedup")}}
+            log(f"[bench] long-read hot path at {m_} reads per batch: {d_:.0f} ms per pass")
+        except Exception as e:
+            by_size[str(m_)] = {"error": repr(e)}
+    gpu.close()
     cells = work["n_ext_cells"] + work["n_glb_cells"] + work["n_sw_cells"]
     dp_ms = st["ms_extend"] + st["ms_dedup"] + st["ms_seedsw"]
     res = {"what": f"BASELINE configs[4] layout: {n} reads of {L} bp (1.5 % sub, 4 % del, 9 % ins), -x pacbio, same index; one batch resident in HBM, best of {args.long_steps} passes of the hot path",
@@ -677,6 +809,7 @@ def longread_bench(args, prefix, g, threads, cache):
            "stage_ms": {k: round(st[k], 2) for k in ("ms_seed", "ms_sa", "ms_chain", "ms_seedsw", "ms_extend", "ms_dedup", "ms_total")},
            "dp_cells_per_read": {"extend": round(work["n_ext_cells"] / n), "global_score": round(work["n_glb_cells"] / n), "seed_sw": round(work["n_sw_cells"] / n)},
            "gcups": round(cells / (dp_ms * 1e-3) / 1e9, 1) if dp_ms > 0 else None,
+           "by_batch_size": by_size,
            "gcups_note": "extension + patch (score-only global) + seed re-scoring cells / the three kernels' time; the final CIGARs' cells are counted under end_to_end"}
     # ---- reference and product command lines on a prefix ----
     # (-K a tenth of the prefix's bases: the product's three device handles each see three or four batches -- arenas, learnt sizes, the long CIGAR

@@ -538,6 +538,9 @@ struct Chan {     // bounded FIFO between two stages
 };
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// CPU seconds of the calling thread / of the whole process so far (the -v 3 summary: what the host stages cost per read, as opposed to how long they were busy)
+static double thread_cpu_s() { struct timespec ts; return clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0 ? (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec : 0.; }
+static double process_cpu_s() { struct timespec ts; return clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts) == 0 ? (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec : 0.; }
 
 static void encode_sub(const Batch &in, Sub &u)
 {
@@ -912,7 +915,7 @@ int main(int argc, char *argv[])
 	}
 	const int chunk = fixed_chunk > 0 ? fixed_chunk : opt.chunk_size * opt.n_threads;
 	const bool long_preset = mode && (strcmp(mode, "pacbio") == 0 || strcmp(mode, "pbref") == 0 || strcmp(mode, "ont2d") == 0);
-	const double t_start = now_s();
+	const double t_start = now_s(), cpu_start = process_cpu_s();
 	if (getenv("BWAGPU_CLI_PARSE_ONLY")) {   // diagnostics: speed of the input stage alone
 		Batch b; long n = 0, bp = 0;
 		const bool dump = atoi(getenv("BWAGPU_CLI_PARSE_ONLY")) == 2;      // (tests: what the input stage delivers, batch by batch)
@@ -977,6 +980,7 @@ int main(int argc, char *argv[])
 	std::mutex dm; std::condition_variable dcv; std::map<long, WorkP> done; long next_fin = 0;   // device -> finalize, re-ordered
 	std::atomic<long> n_works(-1), n_reads_total(0);
 	double busy_read = 0, busy_enc = 0, busy_fin = 0, busy_write = 0; std::atomic<long> busy_dev_us(0);   // per-stage busy time (-v 3 summary)
+	double cpu_read = 0, cpu_enc = 0, cpu_write = 0; std::atomic<long> cpu_dev_us(0);                    // ... and the CPU time of the single-thread stages (finalize = the process's rest)
 
 	// watchdog (BWAGPU_CLI_WATCHDOG=<seconds>): if no stage makes progress for that long, say where everything is and give up
 	std::atomic<long> progress(0); std::atomic<int> dev_no[16]; std::atomic<bool> all_done(false);
@@ -1029,6 +1033,7 @@ int main(int argc, char *argv[])
 			to_enc.push(std::move(w));
 		}
 		n_works = no; n_reads_total = (long)n_processed;
+		cpu_read = thread_cpu_s();
 		to_enc.close();
 	});
 
@@ -1047,6 +1052,7 @@ int main(int argc, char *argv[])
 			++progress;
 			to_dev.push(std::move(w));
 		}
+		cpu_enc = thread_cpu_s();
 		to_dev.close();
 		{ std::lock_guard<std::mutex> l(dm); dcv.notify_all(); }
 	});
@@ -1072,12 +1078,15 @@ int main(int argc, char *argv[])
 			done[no] = std::move(w);
 			dcv.notify_all();
 		}
+		cpu_dev_us += (long)(thread_cpu_s() * 1e6);
 	});
 
 	std::thread writer([&] {      // stage 4: output in input order
 		WorkP w;
-		while (to_out.pop(w)) { const double tw = now_s(); for (auto &t : w->out) fwrite(t.data(), 1, w->by_read ? strnlen(t.data(), t.size()) : t.size(), stdout);
+		const long out_from = getenv("BWAGPU_CLI_OUT_FROM_BATCH") ? atol(getenv("BWAGPU_CLI_OUT_FROM_BATCH")) : 0;      // (bench.py's tail check: only the records of batches out_from.. are written)
+		while (to_out.pop(w)) { const double tw = now_s(); if (w->no >= out_from) for (auto &t : w->out) fwrite(t.data(), 1, w->by_read ? strnlen(t.data(), t.size()) : t.size(), stdout);
 			if (!w->by_read) { std::lock_guard<std::mutex> l(pool_m); if (out_pool.size() < 4) out_pool.push_back(std::move(w->out)); } /* (the reference fputs() a read's records, fastmap.c:116: a NUL -- the letter of base code 5, a '-' in the input -- ends them) */ busy_write += now_s() - tw; }
+		cpu_write = thread_cpu_s();
 	});
 
 	for (;;) {                    // stage 3 (this thread drives the worker pool of finalize_batch)
@@ -1109,7 +1118,13 @@ int main(int argc, char *argv[])
 	writer.join();
 	all_done = true; watchdog.join();
 	if (g_verbose >= 3) { const double dt = now_s() - t_start; fprintf(stderr, "[M::%s] %ld reads in %.3f sec after the index was loaded: %.0f reads/s\n", "main_mem", n_reads_total.load(), dt, dt > 0 ? n_reads_total.load() / dt : 0.);
-		fprintf(stderr, "[M::%s] stage busy time: read %.3f s, encode %.3f s, device %.3f s (over %d handles), finalize %.3f s, write %.3f s\n", "main_mem", busy_read, busy_enc, busy_dev_us.load() * 1e-6, n_work, busy_fin, busy_write); }
+		fprintf(stderr, "[M::%s] stage busy time: read %.3f s, encode %.3f s, device %.3f s (over %d handles), finalize %.3f s, write %.3f s\n", "main_mem", busy_read, busy_enc, busy_dev_us.load() * 1e-6, n_work, busy_fin, busy_write);
+		// what the stages cost in CPU time (a stage's busy time says how long it held the pipeline, not how many cores it used): the reader, encoder and writer are one
+		// thread each, the device threads mostly sleep in event waits, everything else -- the finalize pool, mem_pestat's threads, the block parser -- is the rest
+		const double cpu_all = process_cpu_s() - cpu_start, cpu_dev = cpu_dev_us.load() * 1e-6, cpu_rest = cpu_all - cpu_read - cpu_enc - cpu_write - cpu_dev;
+		const long nr = n_reads_total.load() > 0 ? n_reads_total.load() : 1;
+		fprintf(stderr, "[M::%s] stage CPU time: total %.3f s = %.3f us per read; read %.3f s, encode %.3f s, device threads %.3f s, finalize+pestat pools %.3f s, write %.3f s; one process on %d threads tops out near %.1f Mreads/s (threads / CPU time per read), its single reader thread near %.1f\n",
+				"main_mem", cpu_all, cpu_all / nr * 1e6, cpu_read, cpu_enc, cpu_dev, cpu_rest > 0 ? cpu_rest : 0., cpu_write, opt.n_threads, cpu_all > 0 ? opt.n_threads / (cpu_all / nr * 1e6) : 0., cpu_read > 0 ? 1. / (cpu_read / nr * 1e6) : 0.); }
 	fflush(stdout);
 	for (auto &slot : handles) for (bwagpu_t *hh : slot) if (hh != gpu) bwagpu_destroy(hh);
 	bwagpu_destroy(gpu);

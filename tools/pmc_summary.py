@@ -21,9 +21,8 @@ def load(d, name):
     return out
 
 
-def main():
-    note, fd, wd = sys.argv[1:4]
-    dst = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(__file__), "..", "profiles", "pmc_latest.json")
+def summarize(note, fd, wd):
+    """{kernel: {FETCH_SIZE_KB, WRITE_SIZE_KB, ...}} from the two passes' output directories (bench.py's in-run passes use this too)."""
     F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
     import datetime
     res = {"_note": note, "_meta": {"what": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes; raw counters (FETCH_SIZE counts 64 bytes per request whatever its size, profiles/r03_fetch_calibration.md)", "date": datetime.date.today().isoformat()}}
@@ -53,6 +52,13 @@ def main():
     for k in list(res):
         if k.startswith("k_seed3<") and "k_seed3" not in res:
             res["k_seed3"] = res[k]
+    return res
+
+
+def main():
+    note, fd, wd = sys.argv[1:4]
+    dst = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(__file__), "..", "profiles", "pmc_latest.json")
+    res = summarize(note, fd, wd)
     json.dump(res, open(dst, "w"), indent=1)
     for k, v in res.items():
         if not k.startswith("_"):
