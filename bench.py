@@ -606,30 +606,13 @@ def main():
                 if ref_pe:
                     out["end_to_end_pe"]["vs_cpu_baseline"] = round(e2e["reads_per_s"] / ref_pe["reads_per_s"], 1)
                 if args.tail_batches > 0 and world == 1:
-                    # arena re-use at depth, at full batch size: the SAM of the LAST batches of this very input (every handle's last batch: its arenas, learnt sizes and packed
-                    # buffers have been through five or six batches by then) against the reference on exactly those reads -- same -K, so the batches and mem_pestat are the same
-                    per_batch = -(-100_000_000 // args.read_len); per_batch += per_batch & 1
-                    n_b = -(-n_e // per_batch)
-                    b0 = max(0, n_b - args.tail_batches)
-                    lo = b0 * per_batch // 2
-                    t1f, t2f = os.path.join(cache, "tail_1.fq"), os.path.join(cache, "tail_2.fq")
-                    simdata.write_fastq(t1f, r1[lo:], suffix="/1", start=lo); simdata.write_fastq(t2f, r2[lo:], suffix="/2", start=lo)
-                    ref_t = run_reference(prefix, [t1f, t2f], threads, os.path.join(cache, "ref_tail.sam"))
-                    our_t = run_product(prefix, [f1, f2], threads, os.path.join(cache, "our_tail.sam"), devices=devices, out_from_batch=b0)
-                    tail = {"batches": n_b - b0, "of": n_b, "reads": int(n_e - 2 * lo), "ok": False}
-                    if ref_t and our_t:
-                        a, b = sam_body_digest(os.path.join(cache, "ref_tail.sam")), sam_body_digest(os.path.join(cache, "our_tail.sam"))
-                        tail["ok"] = bool(a == b and a[1] >= n_e - 2 * lo); tail["records"] = a[1]
-                        tail["how"] = f"`bwa-amd mem` on all {n_e // 2} pairs writing only the records of its last {n_b - b0} batches (BWAGPU_CLI_OUT_FROM_BATCH={b0}) vs `bwa mem` on those reads alone, -K 100000000 on both sides: sha256 of the SAM text minus @PG"
-                    out["parity"]["e2e_tail"] = tail
-                    if not tail["ok"]:
+                    try:
+                        out["parity"]["e2e_tail"] = e2e_tail_parity(args, prefix, [f1, f2], r1, r2, n_e, threads, cache)
+                    except Exception as e:
+                        out["parity"]["e2e_tail"] = {"ok": False, "error": repr(e)}
+                    if not out["parity"]["e2e_tail"].get("ok"):
                         rc_exit = 3
-                        log("[bench] PARITY GATE FAILED (tail of the end-to-end run):", tail)
-                    for f_ in (t1f, t2f, os.path.join(cache, "ref_tail.sam"), os.path.join(cache, "our_tail.sam")):
-                        try:
-                            os.remove(f_)
-                        except OSError:
-                            pass
+                        log("[bench] PARITY GATE FAILED (tail of the end-to-end run):", out["parity"]["e2e_tail"])
                 if world == 1 and args.e2e_handles > 0 and args.e2e_handles != e2e["handles"]:
                     # the same command with more batches in flight: a handle's share of the chip idles while its batch is in the download /
                     # mem_pestat / mate-rescue part of the device stage, which more handles fill (a measurement next to the default, not the default)
@@ -665,6 +648,48 @@ def main():
     sys.stdout.flush()
     print(json.dumps(out), flush=True)      # the one JSON line, last thing on stdout (RCCL prints a version banner of its own at start-up)
     sys.exit(rc_exit)
+
+
+def e2e_tail_parity(args, prefix, files, r1, r2, n_e, threads, cache):
+    """Arena re-use at depth, at full batch size: the SAM of the LAST batches of the end-to-end input (every handle's last batch: its arenas, learnt sizes and
+    packed buffers have been through five or six batches by then) against the compiled reference's mem_process_seqs on exactly those batches.  The reference is
+    called per batch through tests/refapi.py with the batch's own n_processed -- mem_pair's tie-breaking hash takes the pair's number in the whole run
+    (bwamem_pair.c:208,248), so `bwa mem` on the tail's reads alone would not do -- and with the batches `bwa mem -K 100000000` forms (fastmap.c:394, bwa.c:bseq_read)."""
+    import refapi
+    from bwa_amd import simdata
+    from bwa_amd.structs import default_opt
+    if not refapi.have_ref():
+        return {"ok": False, "error": "oracle/_ref is missing"}
+    L = args.read_len
+    per_batch = -(-100_000_000 // L); per_batch += per_batch & 1
+    n_b = -(-n_e // per_batch)
+    b0 = max(0, n_b - args.tail_batches)
+    t = time.time()
+    our = run_product(prefix, files, threads, os.path.join(cache, "our_tail.sam"), out_from_batch=b0)
+    res = {"batches": n_b - b0, "of": n_b, "reads": int(n_e - b0 * per_batch), "ok": False}
+    if not our:
+        return res
+    h = hashlib.sha256(); got_n = 0
+    with open(os.path.join(cache, "our_tail.sam"), "rb") as f:
+        for line in f:
+            if line[:1] != b"@":
+                h.update(line); got_n += 1
+    os.remove(os.path.join(cache, "our_tail.sam"))
+    ref = refapi.RefIndex(prefix)
+    opt = default_opt(); opt.flag |= 0x2; opt.n_threads = threads
+    hw = hashlib.sha256(); want_n = 0
+    for bi in range(b0, n_b):
+        lo, hi = bi * per_batch, min(n_e, (bi + 1) * per_batch)
+        rd = interleave(r1[lo // 2: hi // 2], r2[lo // 2: hi // 2])
+        names = [f"r{(lo + i) >> 1}" for i in range(hi - lo)]
+        txt = ref.process_seqs(opt, names, simdata._ASCII[rd].tobytes(), b"I" * (rd.shape[0] * L), np.arange(0, rd.shape[0] + 1, dtype=np.int64) * L, n_processed=lo)
+        hw.update(txt); want_n += txt.count(b"\n")
+        del rd, names, txt
+    ref.close()
+    res["ok"] = bool(h.digest() == hw.digest() and want_n >= res["reads"]); res["records"] = want_n; res["product_records"] = got_n; res["seconds"] = round(time.time() - t, 1)
+    res["how"] = (f"`bwa-amd mem` on all {n_e // 2} pairs writing only the records of its last {n_b - b0} batches (BWAGPU_CLI_OUT_FROM_BATCH={b0}) vs the compiled reference's "
+                  "mem_process_seqs called batch by batch with each batch's own n_processed (the pair number enters mem_pair's tie-breaking hash): sha256 of the SAM records")
+    return res
 
 
 def timed_batch_parity(prefix, opt, reads, counts, regs, n_s, threads):

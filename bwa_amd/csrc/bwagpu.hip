@@ -1102,7 +1102,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		int ring_cols = 256;                     // long reads: ring of {H,E} columns wide enough for the widest band (2 * opt.w, bwamem.c:742)
 		while (ring_cols < 4 * opt->w + 4 + 128) ring_cols <<= 1;
 		if (h->max_len <= WAVE_EXT_MAX_LEN && max_score < (1 << 24)) {
-			int lds_wave = (8 * (h->max_len + 2 + 64) + 5 * ((h->max_len + 64 + 3) & ~3) + 32 + 15) & ~15;   // {H,E} columns, query profile, scoring matrix
+			int lds_wave = (8 * (h->max_len + 2 + 64) + 5 * ((h->max_len + 64 + 3) & ~3) + 64 + 15) & ~15;   // {H,E} columns, query profile, scoring matrix, the stats runs' counters
 			i64 nblk = ((i64)n + 3) / 4, cap = share(256 * 6);       // (six workgroups per CU are resident at 6 waves per SIMD)
 			const int occ = (int)cfg.ext_occ;   // waves per SIMD the register allocation aims at (measured at 3.1 Gbp in round 2: 4 -> 63 ms, 5 -> 58 ms, 6 -> 56 ms; round 4, with the window rows: 4 -> 37.9, 5 -> 37.0-38.3, 6 -> 35.4-36.1 ms; the instance for 5 is not built -- one state of the source made hipcc 7.2 fail on it with an unaligned 64-bit spill reload, and it never won)
 			const dim3 g((unsigned)(nblk < cap ? nblk : cap));
@@ -1110,7 +1110,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			else hipLaunchKernelGGL((k_extend_wave<false, 6>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
 		} else if (max_score < (1 << 24) && ring_cols <= 2048) {
 			// the band's columns only: independent of the read length
-			const int lds_wave = 8 * ring_cols + 32;
+			const int lds_wave = 8 * ring_cols + 64;      // (the ring, the scoring matrix, the stats runs' counters)
 			int wpb = 4; while (wpb > 1 && lds_wave * wpb > 65536) wpb >>= 1;
 			i64 nblk = ((i64)n + wpb - 1) / wpb, cap = 256 * 8 * (4 / wpb);
 			hipLaunchKernelGGL((k_extend_wave<true, 4>), dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)lds_wave * wpb, h->stream, h->ix, *opt, B, lds_wave, ring_cols);

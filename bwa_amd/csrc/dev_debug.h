@@ -31,6 +31,7 @@ template <bool RING> __global__ void __launch_bounds__(64) k_debug_extend(DevInd
 	HIP_DYNAMIC_SHARED(unsigned char, dbg_lds)
 	const int lane = threadIdx.x & 63;
 	WaveLds L;
+	L.stat = nullptr;
 	L.eh = (int2*)dbg_lds;
 	if (RING) {
 		int8_t *m = (int8_t*)(dbg_lds + (size_t)8 * ring_cols);

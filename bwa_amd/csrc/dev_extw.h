@@ -22,6 +22,11 @@ DEVFN void wave_sync()
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 }
+// The lane number as a value the optimizer cannot see through.  Everything a routine derives from threadIdx -- `seeds + lane`, `srt + lane`, LDS slots --
+// is loop-invariant for the kernel's outer loops, so LLVM hoists the address arithmetic of every inlined routine into the kernel's prologue and keeps the
+// results alive (in this kernel: spilled to scratch, 64-bit values a lane apiece) until the routine's next turn, reads later.  Behind this fence the
+// arithmetic stays where it is used: two instructions there instead of a scratch round trip.
+DEVFN int opaque_lane() { int l = (int)(threadIdx.x & 63); DEV_KEEP(l); return l; }
 // ---- cross-lane primitives on DPP (no LDS round trip) ----------------------------------------------------------
 // gfx9-family DPP controls: row_shr:n = 0x110+n (within a row of 16 lanes), row_bcast15 = 0x142 (lane 15 of each row
 // to the next row), row_bcast31 = 0x143 (lane 31 to rows 2-3), wave_shr:1 = 0x138 (whole-wave shift by one lane).
@@ -91,14 +96,14 @@ DEVFN long long wave_fetch_n(unsigned long long *ctr, int n)
 // not sit on several of the heaviest reads), the rest in chunks of WQ_CHUNK, which cuts the atomics on the counter eightfold.
 #define WQ_SINGLE 16384
 #define WQ_CHUNK 8
-struct WaveQueue { long long cur, end; int step; };
+struct WaveQueue { int cur, end, step; };      // (item numbers: a batch has fewer than 2^31 reads or regions)
 DEVFN void wq_init(WaveQueue &q) { q.cur = q.end = 0; q.step = 1; }
 DEVFN bool wq_next(WaveQueue &q, unsigned long long *ctr, long long n, long long &k)
 {
 	if (q.cur >= q.end) {
 		const long long b = wave_fetch_n(ctr, q.step);
 		if (b >= n) return false;
-		q.cur = b; q.end = b + q.step < n ? b + q.step : n;
+		q.cur = uni((int)b); q.end = uni((int)(b + q.step < n ? b + q.step : n));
 		if (b >= WQ_SINGLE) q.step = WQ_CHUNK;
 	}
 	k = q.cur++;
@@ -112,12 +117,22 @@ DEVFN bwagpu_seed_t uni_seed(bwagpu_seed_t s) { s.rbeg = uni64(s.rbeg); s.qbeg =
 // from a 25-entry copy of the matrix (mat) and the query bases in global memory.
 // (Round 3 also had an optional per-wave LDS copy of a long read and a four-columns-per-lane row form for long reads behind switches; on hardware the copy
 // made both long-read DP kernels 14-18 % slower -- its LDS halves the resident waves -- and the row form gained nothing, BENCH_r03 variants: both deleted.)
-struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t *mat; };
+struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t *mat;
+	u32 *stat; /* stats runs: the wave's work counters in LDS -- [0..1] DP cells, [2] calls, [3] calls answered by the diagonal rule, [4..5] reference bases --; null otherwise.
+	              (As u64 registers threaded through the call chain they were ten registers live across every extension of a kernel that spills.) */ };
+DEVFN void ext_stat_add(const WaveLds &L, u32 calls, u64 cells, u32 fast, u64 refb)
+{
+	if (L.stat && (threadIdx.x & 63) == 0) {
+		u64 c = (u64)L.stat[1] << 32 | L.stat[0]; c += cells; L.stat[0] = (u32)c; L.stat[1] = (u32)(c >> 32);
+		L.stat[2] += calls; L.stat[3] += fast;
+		u64 r = (u64)L.stat[5] << 32 | L.stat[4]; r += refb; L.stat[4] = (u32)r; L.stat[5] = (u32)(r >> 32);
+	}
+}
 
 template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, int mat_max, const u8 *q, int q0, const int qdir, int qlen,
 								   i64 t0, const int tdir, int tlen, int w, int end_bonus, int h0, const WaveLds &L, u64 &cells, u64 &fast)
 {
-	const int lane = threadIdx.x & 63;
+	const int lane = opaque_lane();
 	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
 	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = opt.zdrop;
 	int2 *eh = L.eh; int8_t *qp = L.qp; const int qs = L.qstride;
@@ -548,7 +563,7 @@ DEVFN i64 wave_max_i64(i64 v) { for (int o = 32; o > 0; o >>= 1) { const int lo 
 // introsort of a long read's ~2500 keys in global memory was tens of milliseconds per chain.
 DEVFN void wave_sort_u64(u64 *a, int n)
 {
-	const int lane = threadIdx.x & 63;
+	const int lane = opaque_lane();
 	int N = 1; while (N < n) N <<= 1;
 	for (int k = 2; k <= N; k <<= 1) {
 		for (int j = k >> 1; j > 0; j >>= 1) {
@@ -566,7 +581,7 @@ DEVFN void wave_sort_u64(u64 *a, int n)
 // whether its scan stopped early -- so 64 earlier regions are tested per step
 DEVFN bool wave_seed_covered(const bwagpu_opt_t &opt, const bwagpu_seed_t &s, int l_query, const bwagpu_alnreg_t *av, int n_av)
 {
-	const int lane = threadIdx.x & 63;
+	const int lane = opaque_lane();
 	bool covered = false;
 	for (int base = 0; base < n_av && !covered; base += 64) {
 		const int ii = base + lane;
@@ -596,10 +611,9 @@ DEVFN bool wave_seed_covered(const bwagpu_opt_t &opt, const bwagpu_seed_t &s, in
 // extra launches and the serial replay of the 640-chain read), and the long-read kernel's slow reads have ONE chain with many extended seeds
 // (348 ms without, 800 ms with: profiles/r04_chain_parallel_*.jsonl).  Deleted; what stayed are the wave-parallel forms of the chain's serial steps.)
 template <bool RING> __device__ void ext_chain_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const WaveLds &L, const u8 *query, int l_query, int mat_max,
-															   const bwagpu_chain_t &c, const bwagpu_seed_t *seeds, u64 *srt, int n, bwagpu_alnreg_t *av, int &n_av,
-															   u64 &n_calls, u64 &n_cells, u64 &n_refb, u64 &n_fast)
+															   const bwagpu_chain_t &c, const bwagpu_seed_t *seeds, u64 *srt, int n, bwagpu_alnreg_t *av, int &n_av)
 {
-	const int lane = threadIdx.x & 63;
+	const int lane = opaque_lane();
 	const i64 l_pac = ix.l_pac;
 	i64 rmax0 = l_pac << 1, rmax1 = 0;
 	for (int i = lane; i < n; i += 64) {      // (bwamem.c:671-678: the chain's reference window; lanes stride over the seeds -- a long read's chain has thousands)
@@ -621,7 +635,7 @@ template <bool RING> __device__ void ext_chain_wave(const DevIndex &ix, const bw
 		if (rmax1 > fe) rmax1 = fe;
 	}
 	rmax0 = uni64(rmax0); rmax1 = uni64(rmax1);
-	n_refb += (u64)(rmax1 - rmax0);
+	ext_stat_add(L, 0, 0, 0, (u64)(rmax1 - rmax0));
 	// the seeds by score (bwamem.c:684-685): keys score << 32 | index are distinct, so the order is the keys' own whatever sorts them
 	if (n <= 32) {
 		if (lane == 0) {
@@ -695,8 +709,9 @@ template <bool RING> __device__ void ext_chain_wave(const DevIndex &ix, const bw
 			for (int i = 0; i < 2; ++i) {
 				int prev = a.score;
 				aw0 = opt.w << i;
-				x = wave_ksw_extend2<RING>(ix, opt, mat_max, query, s.qbeg - 1, -1, s.qbeg, s.rbeg - 1, -1, tl, aw0, opt.pen_clip5, s.len * opt.a, L, n_cells, n_fast);
-				++n_calls;
+				u64 cells_ = 0, fast_ = 0;
+				x = wave_ksw_extend2<RING>(ix, opt, mat_max, query, s.qbeg - 1, -1, s.qbeg, s.rbeg - 1, -1, tl, aw0, opt.pen_clip5, s.len * opt.a, L, cells_, fast_);
+				ext_stat_add(L, 1, cells_, (u32)fast_, 0);
 				a.score = x.score;
 				if (a.score == prev || x.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
 			}
@@ -710,8 +725,9 @@ template <bool RING> __device__ void ext_chain_wave(const DevIndex &ix, const bw
 			for (int i = 0; i < 2; ++i) {
 				int prev = a.score;
 				aw1 = opt.w << i;
-				x = wave_ksw_extend2<RING>(ix, opt, mat_max, query, qe, 1, l_query - qe, re, 1, (int)(rmax1 - re), aw1, opt.pen_clip3, sc0, L, n_cells, n_fast);
-				++n_calls;
+				u64 cells_ = 0, fast_ = 0;
+				x = wave_ksw_extend2<RING>(ix, opt, mat_max, query, qe, 1, l_query - qe, re, 1, (int)(rmax1 - re), aw1, opt.pen_clip3, sc0, L, cells_, fast_);
+				ext_stat_add(L, 1, cells_, (u32)fast_, 0);
 				a.score = x.score;
 				if (a.score == prev || x.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
 			}
@@ -734,10 +750,9 @@ template <bool RING> __device__ void ext_chain_wave(const DevIndex &ix, const bw
 	}
 }
 
-template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const WaveLds &L0,
-							  u64 &n_calls, u64 &n_cells, u64 &n_refb, u64 &n_fast)
+template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const WaveLds &L0)
 {
-	const int lane = threadIdx.x & 63;
+	const int lane = opaque_lane();
 	WaveLds L = L0;
 	r = uni(r);
 	int n_ch = uni(B.chain_n[r]);
@@ -760,13 +775,14 @@ template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwa
 		wave_sync();
 	}
 	for (int ci = 0; ci < n_ch; ++ci) {
-		const bwagpu_chain_t c = chains[ci];
+		bwagpu_chain_t c = chains[ci];
+		c.rid = uni(c.rid); c.n_seeds = uni(c.n_seeds);      // (wave-uniform values loaded by a vector load: into scalar registers)
 		const bwagpu_seed_t *seeds = seeds_all + sbeg;
 		u64 *srt = srt_all + sbeg;
 		int n = uni(c.n_seeds);
 		sbeg += n;
 		if (n == 0) continue;
-		ext_chain_wave<RING>(ix, opt, L, query, l_query, mat_max, c, seeds, srt, n, av, n_av, n_calls, n_cells, n_refb, n_fast);
+		ext_chain_wave<RING>(ix, opt, L, query, l_query, mat_max, c, seeds, srt, n, av, n_av);
 	}
 	if (lane == 0) B.reg_n_raw[r] = n_av;
 }
@@ -791,8 +807,11 @@ template <bool RING, int OCC> __global__ void __launch_bounds__(256, OCC) k_exte
 		if (lane < 25) m[lane] = opt.mat[lane];
 		L.mat = m; L.ring_mask = 0;
 	}
+	// (the mat copy takes 25 of the 32 bytes behind the columns / the ring; the stats counters the 32 after that)
+	L.stat = B.stats ? (u32*)((unsigned char*)L.mat + 32) : nullptr;
+	if (B.stats && lane < 8) ((u32*)((unsigned char*)L.mat + 32))[lane] = 0;
 	wave_sync();
-	u64 calls = 0, cells = 0, refb = 0, nraw = 0, fast = 0;
+	u64 nraw = 0;
 	// Reads are handed out heaviest first from a global counter: a wave that drew light reads simply draws more of them, and
 	// the launch needs no particular relation between its grid and the number of resident workgroups.
 	WaveQueue wq; wq_init(wq);                       // (the heaviest reads one at a time, the bulk in chunks: an eighth of the atomics on the counter)
@@ -800,21 +819,23 @@ template <bool RING, int OCC> __global__ void __launch_bounds__(256, OCC) k_exte
 		long long k;
 		if (!wq_next(wq, &B.ctr->next_ext, B.n_reads, k)) break;
 		const int r = B.order[k];
-		const long long t_0 = B.stats ? wall_clock64() : 0; const u64 c_0 = calls, x_0 = cells;
-		ext_read_wave<RING>(ix, opt, B, r, L, calls, cells, refb, fast);
+		long long t_0 = 0; u64 c_0 = 0, x_0 = 0;
+		if (B.stats) { t_0 = wall_clock64(); c_0 = L.stat[2]; x_0 = (u64)L.stat[1] << 32 | L.stat[0]; }
+		ext_read_wave<RING>(ix, opt, B, r, L);
 		wave_sync();
-		if (B.stats && lane == 0) {      // where the kernel's time goes, read by read (bwagpu_debug_hist)
+		if (B.stats) {      // where the kernel's time goes, read by read (bwagpu_debug_hist)
 			const long long dt = wall_clock64() - t_0;
 			const int bin = dt > 0 ? (64 - __clzll(dt) < 31 ? 64 - __clzll(dt) : 31) : 0;
-			atomicAdd(&B.ctr->wave_hist[0][bin], 1ull); atomicAdd(&B.ctr->wave_hist[0][32 + bin], (unsigned long long)(calls - c_0)); atomicAdd(&B.ctr->wave_hist[0][64 + bin], (unsigned long long)((cells - x_0) >> 10));
+			const u64 calls = L.stat[2], cells = (u64)L.stat[1] << 32 | L.stat[0];
+			if (lane == 0) { atomicAdd(&B.ctr->wave_hist[0][bin], 1ull); atomicAdd(&B.ctr->wave_hist[0][32 + bin], (unsigned long long)(calls - c_0)); atomicAdd(&B.ctr->wave_hist[0][64 + bin], (unsigned long long)((cells - x_0) >> 10)); }
+			nraw += B.reg_n_raw[r];
 		}
-		nraw += B.reg_n_raw[r];
 	}
 	if (B.stats && lane == 0) {
-		atomicAdd(&B.ctr->ext_calls, (unsigned long long)calls);
-		atomicAdd(&B.ctr->ext_cells, (unsigned long long)cells);
-		atomicAdd(&B.ctr->ext_fast, (unsigned long long)fast);
-		atomicAdd(&B.ctr->ref_bases, (unsigned long long)refb);
+		atomicAdd(&B.ctr->ext_calls, (unsigned long long)L.stat[2]);
+		atomicAdd(&B.ctr->ext_cells, (unsigned long long)((u64)L.stat[1] << 32 | L.stat[0]));
+		atomicAdd(&B.ctr->ext_fast, (unsigned long long)L.stat[3]);
+		atomicAdd(&B.ctr->ref_bases, (unsigned long long)((u64)L.stat[5] << 32 | L.stat[4]));
 		atomicAdd(&B.ctr->n_regs_raw, (unsigned long long)nraw);
 	}
 }

@@ -339,14 +339,22 @@ struct ParFile {
 	}
 	// A mapped file that is truncated while it is being read raises SIGBUS in whichever thread touches the missing pages; without a handler that is a
 	// silent crash of a long run.  The handler can only say so and leave (async-signal-safe calls only).
-	static void on_sigbus(int) {
+	// (Only a fault INSIDE one of the mapped inputs is reported that way: any other SIGBUS -- a driver mapping, a bug -- gets the default action back.)
+	struct MappedRange { std::atomic<const char*> lo{nullptr}; std::atomic<size_t> len{0}; };
+	static MappedRange *mapped_ranges() { static MappedRange r[8]; return r; }
+	static void on_sigbus(int sig, siginfo_t *si, void *) {
+		const char *a = si ? (const char*)si->si_addr : nullptr;
+		bool ours = false;
+		for (int k = 0; k < 8; ++k) { const char *lo = mapped_ranges()[k].lo.load(); const size_t n = mapped_ranges()[k].len.load(); if (lo && a >= lo && a < lo + n) ours = true; }
+		if (!ours) { signal(sig, SIG_DFL); raise(sig); return; }
 		static const char msg[] = "[bwa-amd] SIGBUS: an input file shrank while it was being read (plain FASTQ files are mapped); no SAM after this point is valid\n";
 		if (::write(2, msg, sizeof msg - 1) < 0) {}
 		_exit(74);                                                   // EX_IOERR
 	}
-	static void guard_mapped_input() {
+	static void guard_mapped_input(const char *lo, size_t len) {
 		static std::once_flag once;
-		std::call_once(once, [] { struct sigaction sa; memset(&sa, 0, sizeof sa); sa.sa_handler = on_sigbus; sigemptyset(&sa.sa_mask); sigaction(SIGBUS, &sa, nullptr); });
+		std::call_once(once, [] { struct sigaction sa; memset(&sa, 0, sizeof sa); sa.sa_sigaction = on_sigbus; sa.sa_flags = SA_SIGINFO; sigemptyset(&sa.sa_mask); sigaction(SIGBUS, &sa, nullptr); });
+		for (int k = 0; k < 8; ++k) { const char *none = nullptr; if (mapped_ranges()[k].lo.compare_exchange_strong(none, lo)) { mapped_ranges()[k].len = len; break; } }
 	}
 	bool open(const char *fn, ParPool *pl) {      // true: this file is read in blocks
 		const int f = ::open(fn, O_RDONLY);
@@ -359,8 +367,10 @@ struct ParFile {
 			if (mp == MAP_FAILED) { ::close(f); return false; }
 			madvise(mp, size, MADV_SEQUENTIAL);
 			map = (const char*)mp;
-			guard_mapped_input();
-			if (getenv("BWAGPU_CLI_TEST_SHRINK") && truncate(fn, (off_t)(size / 8192 * 4096)) != 0) {}   // (tests: the file loses its second half under the mapping)
+			guard_mapped_input(map, size);
+#ifdef BWAGPU_CLI_TEST_HOOKS      // (the mock-runtime build of the tests only: the shipped program never touches its input files)
+			if (getenv("BWAGPU_CLI_TEST_SHRINK") && truncate(fn, (off_t)(size / 8192 * 4096)) != 0) {}   // (the file loses its second half under the mapping)
+#endif
 		}
 		fd = f; path = fn; pool = pl;
 		if (getenv("BWAGPU_CLI_PAR_BLOCK")) { blk = (size_t)atoll(getenv("BWAGPU_CLI_PAR_BLOCK")); if (blk < 16) blk = 16; }   // (tests: cuts in every position)

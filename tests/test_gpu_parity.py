@@ -287,6 +287,43 @@ def test_device_matesw_records_match_the_host(medium):
     host.close()
 
 
+@pytest.mark.parametrize("n_processed", [(1 << 24) - 3000, (1 << 25) + (1 << 24) + 7000])
+def test_pair_ids_beyond_2_to_23_with_device_records(medium, n_processed):
+    """mem_pair / mem_matesw hash the pair's number n_processed + i >> 1 through an `id << 8` that wraps at 2^23 pairs (bwamem_pair.c:208,248):
+    a batch deep inside a run -- n_processed >= 2^24 reads, crossing the wrap inside the batch in the first case -- with the DEVICE's regions, CIGAR records and
+    mate-rescue alignments attached must still give the reference's mem_process_seqs text for that n_processed."""
+    import hostapi
+    from bwa_amd.api import PES_DTYPE
+    gpu, orc, ref, g = medium
+    host = hostapi.HostFinalize(testdata.medium_index()[0])
+    r1, r2 = simdata.make_reads_pe(g, 6000, seed=355, sub=0.02)
+    rng = np.random.default_rng(356)
+    noisy = rng.random(r2.shape[0]) < 0.3                      # a third of the second mates too noisy to map on their own: mate rescue has work
+    r2 = np.where(noisy[:, None] & (rng.random(r2.shape) < 0.10), (r2 + rng.integers(1, 4, r2.shape)) % 4, r2).astype(np.uint8)
+    reads = np.empty((2 * r1.shape[0], r1.shape[1]), dtype=np.uint8); reads[0::2], reads[1::2] = r1, r2
+    seqs, off = testdata.flat(reads)
+    opt = default_opt(); opt.flag |= 2
+    counts, regs = gpu.align(opt, seqs, off)
+    pes = host.pestat(opt, counts, regs)
+    dpes = np.zeros(4, dtype=PES_DTYPE)
+    for k in ("low", "high", "failed"):
+        dpes[k] = pes[k]
+    msw = gpu.matesw(opt, dpes)
+    cigs, ops = gpu.cigars(opt), gpu.cigar_ops()
+    assert (msw["r"] >= 0).sum() > 300 and (cigs["n_cigar"] > 0).sum() > 5000
+    names = [f"q{i >> 1}" for i in range(off.shape[0] - 1)]
+    quals = bytes((33 + (np.arange(seqs.shape[0]) % 40)).astype(np.uint8))
+    ascii_ = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    want = ref.process_seqs(opt, names, ascii_[seqs].tobytes(), quals, off, n_processed=n_processed)
+    got = host.regs2sam(opt, names, seqs, quals, off, counts, regs, n_processed=n_processed, msw=msw, cigs=cigs, cig_ops=ops)
+    if got != want:
+        for a, b in zip(want.split(b"\n"), got.split(b"\n")):
+            assert a == b, f"first differing SAM line (n_processed {n_processed})\nwant {a[:300]!r}\ngot  {b[:300]!r}"
+    assert got == want
+    assert want != ref.process_seqs(opt, names, ascii_[seqs].tobytes(), quals, off, n_processed=0), "the pair ids made no difference: the test does not reach the hash"
+    host.close()
+
+
 def test_index_broadcast_over_rccl_single_rank(small):
     """The multi-GPU start-up path on one GPU: a world_size-1 RCCL group, the index buffers wrapped as device tensors
     (CUDA array interface) and broadcast; the handle must align exactly like one created directly."""
