@@ -190,12 +190,7 @@ DEVFN int cw_inorder(i32 *nd, int root, i32 *out, i32 *stk, int lane)
 	return n;
 }
 
-DEVFN int wave_excl_scan_add(int v, int lane)
-{
-	int inc = v;
-	for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-	return inc - v;
-}
+DEVFN int wave_excl_scan_add(int v, int lane) { (void)lane; return wave_incl_scan_add(v) - v; }      // (DPP steps, dev_extw.h: no shuffle addresses to keep in registers)
 
 // One read.  NC/CC/SC: nodes, chains and seeds this tier keeps in LDS (0: in the read's HBM region).  Returns false when the read
 // outgrows the tier, nothing having been published.
@@ -327,8 +322,7 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 			const int before = imax(wave_shift_up1(inc, 0), run_max);        // largest end among the earlier over-abundant intervals
 			int add = 0;
 			if (use) { const int from = sb > before ? sb : before; add = se > from ? se - from : 0; }
-			for (int o = 32; o > 0; o >>= 1) add += __shfl_xor(add, o);
-			l_rep += add;
+			l_rep += wave_sum(add);
 			run_max = imax(run_max, __builtin_amdgcn_readlane(inc, 63));
 		}
 		frac_rep = (float)l_rep / len;
@@ -463,7 +457,7 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 			}
 		}
 		k += __popcll(mk);
-		m_tot = __shfl(my_m + cn, 63);
+		m_tot = __builtin_amdgcn_readlane(my_m + cn, 63);
 	}
 	wave_sync();
 	// the caller reserves the read's range of the region arena (one atomic per chunk of reads) and sets reg_off
@@ -509,7 +503,7 @@ template <int TIER, int NC, int CC, int SC> __global__ void __launch_bounds__(25
 			if (my_st == 2) (TIER == 0 ? B.chain_todo : B.chain_todo2)[at + __popcll(md & ((1ull << lane) - 1))] = my_r;
 		}
 		const int excl = wave_excl_scan_add(my_m, lane);
-		const int total = __shfl(excl + my_m, 63);
+		const int total = __builtin_amdgcn_readlane(excl + my_m, 63);
 		if (total > 0) {
 			u64 roff = 0;
 			if (lane == 0) roff = atomicAdd(&B.ctr->reg_used, (unsigned long long)total);

@@ -353,7 +353,7 @@ template <bool DIAG_ONLY> __device__ void cigar_region(const DevIndex &ix, const
 			if (l_query == rlen && w2 == 0) {     // no gap possible: one M run, score by direct comparison (bwa.c:171-174)
 				int s = 0;
 				for (int j = lane; j < l_query; j += 64) s += opt.mat[ref_base(ix, t0 + (i64)j * tdir) * 5 + query[q0 + j * qdir]];
-				for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+				s = wave_sum(s);
 				score = s; n_ops = 1;
 				if (lane == 0) L.ops[0] = (u32)l_query << 4;
 				wave_sync();
@@ -609,7 +609,7 @@ __device__ void cigar_region_long(const DevIndex &ix, const bwagpu_opt_t &opt, c
 		if (l_query == rlen && w2 == 0) {
 			int s = 0;
 			for (int j = lane; j < l_query; j += 64) s += opt.mat[ref_base(ix, t0 + (i64)j * tdir) * 5 + query[q0 + j * qdir]];
-			for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+			s = wave_sum(s);
 			score = s; n_ops = 1;
 			if (lane == 0) S.ops[0] = (u32)l_query << 4;
 			__threadfence();

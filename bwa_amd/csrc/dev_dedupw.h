@@ -165,7 +165,7 @@ template <bool BLK = false> __device__ int wave_global_score(const DevIndex &ix,
 	if (l_query == rlen && w_ == 0) {
 		int s = 0;
 		for (int i = lane; i < l_query; i += 64) s += opt.mat[ref_base(ix, t0 + (i64)i * tdir) * 5 + query[q0 + i * qdir]];
-		for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+		s = wave_sum(s);
 		return s;
 	}
 	int max_ins = trunc_div_add(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins, opt.e_ins, 1);

@@ -57,6 +57,20 @@ DEVFN int wave_incl_scan_max(int v)
 	v = imax(v, __builtin_amdgcn_update_dpp(I32_MIN, v, DPP_ROW_BCAST31, 0xc, 0xf, false));
 	return v;
 }
+// Inclusive prefix SUM over the 64 lanes, the same six DPP steps (lanes without a source add `old` = 0); lane 63 ends up with the wave's total.
+// (The shuffle forms -- __shfl_up / __shfl_xor loops -- are ds_bpermute with a computed address per step: six address registers that LLVM hoists out of
+// the kernel's loops and, in k_extend_wave, spills.)
+DEVFN int wave_incl_scan_add(int v)
+{
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(1), 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(2), 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(4), 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(8), 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST15, 0xa, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST31, 0xc, 0xf, false);
+	return v;
+}
+DEVFN int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_add(v), 63); }
 // value of the lane below (lane 0 receives `fill`)
 DEVFN int wave_shift_up1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHR1, 0xf, 0xf, false); }
 DEVFN int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }   // pin a wave-uniform value into an SGPR
@@ -70,6 +84,11 @@ DEVFN u64 wave_ballot(bool p) { return __ballot(p); }
 DEVFN i64 uni64(i64 v)
 {
 	int lo = __builtin_amdgcn_readfirstlane((int)(u32)(u64)v), hi = __builtin_amdgcn_readfirstlane((int)(u32)((u64)v >> 32));
+	return (i64)((u64)(u32)hi << 32 | (u32)lo);
+}
+DEVFN i64 readlane_i64_(i64 v, int l)
+{
+	int lo = __builtin_amdgcn_readlane((int)(u32)(u64)v, l), hi = __builtin_amdgcn_readlane((int)(u32)((u64)v >> 32), l);
 	return (i64)((u64)(u32)hi << 32 | (u32)lo);
 }
 DEVFN i64 lane0_i64(i64 v)       // broadcast lane 0's value
@@ -160,8 +179,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			const int j = b + lane;
 			int loss = 0;
 			if (j < qlen) loss = mat_max - SCORE_AT(ref_base(ix, t0 + (i64)j * tdir), j);
-			for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o);
-			P += loss;
+			P += wave_sum(loss);
 		}
 		if (P < oe_min && (zdrop <= 0 || P < zdrop) && h0 > P) {
 			int best = h0, best_i = -1, run = h0;
@@ -169,8 +187,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 				const int j = b + lane;
 				int sc = 0;
 				if (j < qlen) sc = SCORE_AT(ref_base(ix, t0 + (i64)j * tdir), j);
-				int inc = sc;                                  // inclusive prefix sum over the wave
-				for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+				const int inc = wave_incl_scan_add(sc);        // inclusive prefix sum over the wave
 				const int v = run + inc;
 				// first lane of this chunk whose value exceeds everything before it: maximum of (v << 6 | 63 - lane)
 				const int key = wave_incl_scan_max(j < qlen ? (v << 6 | (63 - lane)) : I32_MIN);
@@ -554,8 +571,28 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 }
 
 // minimum / maximum of a 64-bit value over the wave (every lane receives it)
-DEVFN i64 wave_min_i64(i64 v) { for (int o = 32; o > 0; o >>= 1) { const int lo = __shfl_xor((int)(u32)(u64)v, o), hi = __shfl_xor((int)(u32)((u64)v >> 32), o); const i64 t = (i64)((u64)(u32)hi << 32 | (u32)lo); v = t < v ? t : v; } return v; }
-DEVFN i64 wave_max_i64(i64 v) { for (int o = 32; o > 0; o >>= 1) { const int lo = __shfl_xor((int)(u32)(u64)v, o), hi = __shfl_xor((int)(u32)((u64)v >> 32), o); const i64 t = (i64)((u64)(u32)hi << 32 | (u32)lo); v = t > v ? t : v; } return v; }
+template <int CTRL, int RM> DEVFN i64 dpp_i64(i64 v)       // the 64-bit value of the DPP source lane (a lane without one, or outside the row mask: its own)
+{
+	const int lo = (int)(u32)(u64)v, hi = (int)(u32)((u64)v >> 32);
+	const int l2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, RM, 0xf, false), h2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, RM, 0xf, false);
+	return (i64)((u64)(u32)h2 << 32 | (u32)l2);
+}
+DEVFN i64 wave_min_i64(i64 v)
+{
+	i64 t;
+	t = dpp_i64<DPP_ROW_SHR(1), 0xf>(v); v = t < v ? t : v; t = dpp_i64<DPP_ROW_SHR(2), 0xf>(v); v = t < v ? t : v;
+	t = dpp_i64<DPP_ROW_SHR(4), 0xf>(v); v = t < v ? t : v; t = dpp_i64<DPP_ROW_SHR(8), 0xf>(v); v = t < v ? t : v;
+	t = dpp_i64<DPP_ROW_BCAST15, 0xa>(v); v = t < v ? t : v; t = dpp_i64<DPP_ROW_BCAST31, 0xc>(v); v = t < v ? t : v;
+	return readlane_i64_(v, 63);
+}
+DEVFN i64 wave_max_i64(i64 v)
+{
+	i64 t;
+	t = dpp_i64<DPP_ROW_SHR(1), 0xf>(v); v = t > v ? t : v; t = dpp_i64<DPP_ROW_SHR(2), 0xf>(v); v = t > v ? t : v;
+	t = dpp_i64<DPP_ROW_SHR(4), 0xf>(v); v = t > v ? t : v; t = dpp_i64<DPP_ROW_SHR(8), 0xf>(v); v = t > v ? t : v;
+	t = dpp_i64<DPP_ROW_BCAST15, 0xa>(v); v = t > v ? t : v; t = dpp_i64<DPP_ROW_BCAST31, 0xc>(v); v = t > v ? t : v;
+	return readlane_i64_(v, 63);
+}
 
 // Ascending sort of n DISTINCT 64-bit keys by the whole wave: a bitonic network in its all-ascending form (the first step of every merge stage
 // pairs i with i ^ (2k - 1), the others i with i ^ j), so that positions past n behave as +infinity and pairs reaching there are skipped.  For
@@ -735,12 +772,11 @@ template <bool RING> __device__ void ext_chain_wave(const DevIndex &ix, const bw
 			else { a.qe = l_query; a.re = re + x.gtle; a.truesc += x.gscore - sc0; }
 		} else { a.qe = l_query; a.re = s.rbeg + s.len; }
 		int cov = 0;
-		for (int i = lane; i < n; i += 64) {   // seedcov (bwamem.c:801-805): lanes stride over the chain's seeds
+		for (int i = opaque_lane(); i < n; i += 64) {   // seedcov (bwamem.c:801-805): lanes stride over the chain's seeds
 			bwagpu_seed_t t = seeds[i];
 			if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) cov += t.len;
 		}
-		for (int o = 32; o > 0; o >>= 1) cov += __shfl_xor(cov, o);
-		a.seedcov = cov;
+		a.seedcov = wave_sum(cov);
 		a.w = aw0 > aw1 ? aw0 : aw1;
 		a.seedlen0 = s.len;
 		a.frac_rep = c.frac_rep;

@@ -38,7 +38,7 @@ def _sim_cli():
     srcs = [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith(".cpp")]
     deps = srcs + [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".h")] + [os.path.join(sim, "libbwagpu_hostsim.so")]
     if not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in deps):
-        subprocess.run(["g++"] + b.HOST_FLAGS + srcs + ["-o", out, "-L" + sim, "-lbwagpu_hostsim", "-Wl,-rpath," + sim, "-lz", "-lpthread"], check=True)
+        subprocess.run(["g++"] + b.HOST_FLAGS + ["-DBWAGPU_CLI_TEST_HOOKS"] + srcs + ["-o", out, "-L" + sim, "-lbwagpu_hostsim", "-Wl,-rpath," + sim, "-lz", "-lpthread"], check=True)
     return out
 
 

@@ -16,7 +16,7 @@ fi
 HOSTSRC=$ROOT/bwa_amd/csrc/host
 if [ ! -e $OUT/bwa-amd-sim-san ] || [ $LIB -nt $OUT/bwa-amd-sim-san ] || [ -n "$(find $HOSTSRC -newer $OUT/bwa-amd-sim-san \( -name '*.h' -o -name '*.cpp' \) | head -1)" ]; then
   # the command line (reader, encoder, device, finalize and writer threads) and the host finalize library, same flags
-  g++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer $HOSTSRC/*.cpp -o $OUT/bwa-amd-sim-san \
+  g++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -DBWAGPU_CLI_TEST_HOOKS $HOSTSRC/*.cpp -o $OUT/bwa-amd-sim-san \
       -L$OUT -lbwagpu_hostsim_san -Wl,-rpath,$OUT -lz -lpthread
   g++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer $(ls $HOSTSRC/*.cpp | grep -v main_) -o $OUT/libbwamem_host_san.so -lpthread
 fi
