@@ -261,7 +261,7 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=3100.0)
     ap.add_argument("--cache", default=os.environ.get("BWA_AMD_CACHE", "/tmp/bwa_amd_bench"))
     ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU (handles sharing the index)")
-    ap.add_argument("--dense-sa", type=int, default=4, help="densify the SA on the device to this interval (0 = keep the reference's 32)")
+    ap.add_argument("--dense-sa", type=int, default=1, help="densify the SA on the device to this interval (0 = keep the reference's 32)")
     ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads of the single-end parity / CPU-baseline sample; the paired-end one has this many reads too")
     ap.add_argument("--e2e-reads", type=int, default=12_000_000, help="reads of the end-to-end runs (pipeline fill and drain cost ~0.8 s whatever the length)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference runs (and with them the parity gate)")

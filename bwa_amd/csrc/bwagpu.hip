@@ -1062,8 +1062,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			hipLaunchKernelGGL(k_publish_blk, dim3((unsigned)pb), block, 0, h->stream, *opt, B);
 		}
 		else {
-			hipLaunchKernelGGL(k_publish, grid, block, 0, h->stream, *opt, B);
-			hipLaunchKernelGGL(k_expand, grid, block, 0, h->stream, *opt, B);
+			hipLaunchKernelGGL(k_publish, grid, block, 0, h->stream, *opt, B);      // (sorts, reserves and expands: k_expand's loop is its last step)
 		}
 		HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "publish+expand", hipGetErrorString(e_)); }

@@ -307,6 +307,20 @@ __global__ void __launch_bounds__(256) k_publish(bwagpu_opt_t opt, Batch B)
 		if (noff + nnode > (u64)B.node_cap) { atomicOr(&B.ctr->overflow, 4ull); B.intv_n[r] = 0; continue; }
 		B.seed_n[r] = (i32)ns; B.seed_off[r] = (i64)soff; B.node_off[r] = (i64)noff;
 		nintv += (u64)n;
+		// ... and its SA rows (mem_chain's k-loop, bwamem.c:304-305) straight away: the intervals are in this lane's cache lines now (k_expand was a
+		// launch of its own re-reading them, 2 ms per million reads)
+		i64 sl_ = (i64)soff;
+		for (int i = 0; i < n; ++i) {
+			const Intv3 p = iv[i];
+			const int step = p.x2 > (u64)opt.max_occ ? (int)(p.x2 / opt.max_occ) : 1;
+			int count = 0;
+			const i32 qb = (i32)(p.info >> 32), ln = (i32)((u32)p.info - (u32)(p.info >> 32));
+			for (i64 k = 0; (u64)k < p.x2 && count < opt.max_occ; k += step, ++count, ++sl_) {
+				B.slot_pos[sl_] = p.x0 + (u64)k;
+				B.slot_qbeg[sl_] = qb;
+				B.slot_len[sl_] = ln;
+			}
+		}
 	}
 	if (B.stats) atomicAdd(&B.ctr->n_intv, (unsigned long long)nintv);
 }
@@ -892,29 +906,6 @@ template <int BLK, bool MRG = false> __global__ void __launch_bounds__(256, 3) k
 		}
 	}
 	if (B.stats) { atomicAdd(&B.ctr->occ_blocks, (unsigned long long)nblk); atomicAdd(&B.ctr->tab_lookups, (unsigned long long)ntab); }
-}
-
-// One lane per SA interval: expand it into its SA rows (mem_chain's k-loop, bwamem.c:304-305) in the read's slot range.
-__global__ void __launch_bounds__(256) k_expand(bwagpu_opt_t opt, Batch B)
-{
-	for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < B.n_reads; r += gridDim.x * blockDim.x) {
-		const int n = B.intv_n[r];
-		if (n == 0 || B.seed_n[r] == 0) continue;
-		const Intv3 *iv = B.intv + B.intv_off[r];
-		const i64 soff = B.seed_off[r];
-		i64 s = 0;
-		for (int i = 0; i < n; ++i) {
-			Intv3 p = iv[i];
-			int step = p.x2 > (u64)opt.max_occ ? (int)(p.x2 / opt.max_occ) : 1;
-			int count = 0;
-			const i32 qb = (i32)(p.info >> 32), sl = (i32)((u32)p.info - (u32)(p.info >> 32));
-			for (i64 k = 0; (u64)k < p.x2 && count < opt.max_occ; k += step, ++count, ++s) {
-				B.slot_pos[soff + s] = p.x0 + (u64)k;
-				B.slot_qbeg[soff + s] = qb;
-				B.slot_len[soff + s] = sl;
-			}
-		}
-	}
 }
 
 // SA lookups (bwt_sa, bwt.c:86-96): ~31 dependent LF steps each with the reference's sa_intv = 32, a single read when the

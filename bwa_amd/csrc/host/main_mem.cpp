@@ -899,9 +899,15 @@ int main(int argc, char *argv[])
 	}
 	bwagpu_set_taps(gpu, 0);
 	bwagpu_set_cigar_filter(gpu, getenv("BWAGPU_CLI_CIGAR_FILTER") ? atoi(getenv("BWAGPU_CLI_CIGAR_FILTER")) : 1);   // (clones inherit it)
-	{	// SA look-ups walk ~31 LF steps with the reference's interval of 32; HBM has room for a denser array (same values)
-		const int dense = getenv("BWAGPU_CLI_DENSE_SA") ? atoi(getenv("BWAGPU_CLI_DENSE_SA")) : 4;
-		if (dense > 0) { int rc = bwagpu_densify_sa(gpu, dense); if (rc != BWAGPU_OK && g_verbose >= 2) fprintf(stderr, "[W::%s] SA not densified: %s\n", "main_mem", bwagpu_strerror(rc)); }
+	{	// SA look-ups walk ~31 LF steps with the reference's interval of 32; HBM has room for the full array (same values): 8 bytes per text position, 50 GB for a
+		// human genome, one look-up = one 8-byte read (k_sa 3.1 -> 0.9 ms per million reads against an interval of 4).  If that much is not to be had: the next intervals up.
+		const int dense = getenv("BWAGPU_CLI_DENSE_SA") ? atoi(getenv("BWAGPU_CLI_DENSE_SA")) : 1;
+		for (int dn = dense; dn > 0 && dn < 32; dn *= 2) {
+			const int rc = bwagpu_densify_sa(gpu, dn);
+			if (rc == BWAGPU_OK) break;
+			if (g_verbose >= 2) fprintf(stderr, "[W::%s] SA not densified to an interval of %d: %s\n", "main_mem", dn, bwagpu_strerror(rc));
+			if (rc != BWAGPU_ENOMEM) break;
+		}
 	}
 
 	// input: BWAGPU_CLI_PARSE_THREADS parser threads for plain FASTQ files (0: the streaming reader alone; the default when one device takes the batches)

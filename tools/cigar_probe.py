@@ -14,7 +14,7 @@ n = int(os.environ.get("READS", "666668")) // 2 * 2
 opt = default_opt(); opt.flag |= 2
 r1, r2 = simdata.make_reads_pe(g, n // 2, seed=1000)
 rd = bench.interleave(r1, r2)
-gpu = BwaGpu(prefix); gpu.densify_sa(4); gpu.set_taps(False)
+gpu = BwaGpu(prefix); gpu.densify_sa(1); gpu.set_taps(False)
 gpu.L.bwagpu_set_cigar_filter.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_int]
 gpu.upload(np.ascontiguousarray(rd.reshape(-1)), np.arange(0, n + 1, dtype=np.int64) * rd.shape[1])
 gpu.run(opt); gpu.run(opt)

@@ -16,7 +16,7 @@ ap.add_argument("--read-len", type=int, default=10000)
 ap.add_argument("--rounds", type=int, default=4)
 a = ap.parse_args()
 fa, g, _ = bench.build_or_load_index(3100.0, "/tmp/bwa_amd_bench", 0, lambda: None)
-gpu = BwaGpu(fa); gpu.densify_sa(4); gpu.set_taps(False)
+gpu = BwaGpu(fa); gpu.densify_sa(1); gpu.set_taps(False)
 rd = simdata.make_reads_long(g, a.reads, length=a.read_len, seed=7)
 gpu.upload(np.ascontiguousarray(rd.reshape(-1)), np.arange(0, a.reads + 1, dtype=np.int64) * a.read_len)
 opt = pacbio_opt()

@@ -23,7 +23,7 @@ def main():
     a = ap.parse_args()
     import torch
     fa, g, _ = bench.build_or_load_index(a.genome_mbp, a.cache, 0, lambda: torch.cuda.synchronize())
-    gpu = BwaGpu(fa); gpu.densify_sa(4); gpu.set_taps(False)
+    gpu = BwaGpu(fa); gpu.densify_sa(1); gpu.set_taps(False)
     for kv in a.options.split():
         k, v = kv.split("=", 1); gpu.set_option(k, int(v))
     rd = simdata.make_reads_long(g, a.reads, length=a.read_len, seed=7)      # SURVEY 8d's PacBio-like model: 1.5 % sub, 4 % del, 9 % ins

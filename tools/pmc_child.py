@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--prefix", required=True)
 ap.add_argument("--batch", required=True)
-ap.add_argument("--dense-sa", type=int, default=4)
+ap.add_argument("--dense-sa", type=int, default=1)
 ap.add_argument("--layout", default="pe")
 a = ap.parse_args()
 from bwa_amd.api import BwaGpu

@@ -16,7 +16,7 @@ opt = default_opt(); opt.flag |= 2
 sizes = [int(x) for x in os.environ.get("READS", "1000000").split(",")]
 r1, r2 = simdata.make_reads_pe(g, max(sizes) // 2, seed=1000)
 rd_all = bench.interleave(r1, r2)
-gpu = BwaGpu(prefix); gpu.densify_sa(4); gpu.set_taps(False)
+gpu = BwaGpu(prefix); gpu.densify_sa(1); gpu.set_taps(False)
 gpu.L.bwagpu_debug_prof.argtypes = [C.c_void_p, C.c_void_p]
 for cfg in (sys.argv[1:] or [""]):
     sets = {}

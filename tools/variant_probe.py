@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--streams", type=int, default=3)
     ap.add_argument("--passes", type=int, default=2)
     ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--dense-sa", type=int, default=4)
+    ap.add_argument("--dense-sa", type=int, default=1)
     ap.add_argument("--lib", default=os.environ.get("BWA_AMD_PROBE_LIB"), help="(tests) the mock-runtime build of the library")
     ap.add_argument("--long-reads", type=int, default=0, help="long-read mode (BASELINE configs[4]): this many reads of --long-len bases, -x pacbio, one batch, one handle")
     ap.add_argument("--long-len", type=int, default=10000)
