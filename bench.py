@@ -356,6 +356,7 @@ def main():
     # one untimed instrumented solo pass: algorithmic work counters of batch 0 (roofline numerator) and solo kernel times
     # (the algorithm's own work: with the seeding kernel's iteration budget off no read is given up half-way and seeded again by the task kernels;
     # the product's counters, rework included, are reported beside it)
+    gpu.set_option("share", 100)      # (the solo passes: every kernel with the whole chip, whatever the handle count makes the default -- bwagpu_config.h)
     gpu.set_stats(True)
     gpu.set_option("seed_budget", 0)
     gpu.run(opt)
@@ -368,6 +369,7 @@ def main():
     solo = gpu.stats()
     stage_keys = ("ms_seed", "ms_publish", "ms_sa", "ms_chain", "ms_seedsw", "ms_extend", "ms_dedup", "ms_total")
     stage_ms = {k: solo[k] for k in stage_keys}
+    gpu.set_option("share", -1)
 
     def worker(hdl, n_pass):
         for _ in range(n_pass):

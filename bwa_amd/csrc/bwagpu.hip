@@ -916,7 +916,11 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 	// the chip.  A kernel whose workgroups live until its work runs out holds every slot it got: launched to fill the chip, the kernels of the
 	// batches in flight take turns; launched for a share, kernels of different batches -- the memory-bound seeding of one, the issue-bound
 	// extension of another -- run side by side.
-	auto share = [&](long long g) { if (long_batch || cfg.share >= 100 || cfg.share <= 0) return g; const long long v = g * cfg.share / 100; return v < 1 ? 1ll : v; };
+	// auto (-1): half the chip per kernel when at least three handles share this index -- three batches in flight, the way `bwa-amd mem` and the bench's timed loop
+	// drive a device -- else all of it.  Measured with three batches in flight (profiles/r05_share_ab.log): 108.3 ms per step at 100, 105.2-105.7 at 50 (105.1 at 40,
+	// 107.1 at 60), i.e. -2.7 %, for +10 % on a batch that has the chip to itself (131.8 -> 144.8 ms) -- round 4 measured nothing; the kernels' balance has moved.
+	const long long share_pct = cfg.share >= 0 ? cfg.share : (h->ibuf->refs.load() >= 3 ? 50 : 100);
+	auto share = [&](long long g) { if (long_batch || share_pct >= 100 || share_pct <= 0) return g; const long long v = g * share_pct / 100; return v < 1 ? 1ll : v; };
 	auto pick = [&](long long v, long long dflt_long) { return v >= 0 ? v : (long_batch ? dflt_long : 0); };
 	// Pass 1 of long-read batches as independent tasks (option seed_tasks; dev_seed.h, k_seed's LR): one task per read and min_seed_len-th
 	// position.  The host only says where each read's tasks begin; a task finds its read by bisection.

@@ -37,7 +37,7 @@
 	X(seed_input_order,  0)    /* seeding: reads in input order instead of heaviest first (diagnostics)                                                 */ \
 	X(seed_pass3_inline, 0)    /* seeding: pass 3 inside k_seed's state machine instead of k_seed3 (A/B)                                                */ \
 	X(seed_grid,         0)    /* seeding: resident workgroups of k_seed (0: fill the chip; measurements)                                               */ \
-	X(share,             100)  /* short reads: percent of a chip-filling launch that the hot path's persistent kernels take (kernels of different batches side by side)  */ \
+	X(share,             -1)   /* short reads: percent of a chip-filling launch that the hot path's persistent kernels take (kernels of different batches side by side); auto: 50 when three or more handles share the index, else 100 */ \
 	X(chain_lds,         1)    /* chaining: 0 = the LDS tiers defer every read to the HBM tier (test hook)                                              */ \
 	X(ext_occ,           6)    /* extension: waves per SIMD the short-read kernel's register allocation aims at (4 or 6)                                */ \
 	X(dedup_wave,        0)    /* 1 = the wave-per-read de-duplication kernel for short reads as well (test hook)                                       */ \

@@ -80,11 +80,15 @@ def main():
             for hdl, (flat, off) in zip(handles, batches):
                 hdl.set_taps(False)
                 hdl.upload(flat, off)
+            if "share" not in sets:
+                gpu.set_option("share", 100)                      # (the solo passes: every kernel with the whole chip; the default would be half of it with three handles on the index)
             gpu.run(opt)                                          # warm-up: arenas learn their sizes
             solo = []
             for _ in range(args.passes):
                 gpu.run(opt)
                 solo.append(gpu.stats())
+            if "share" not in sets:
+                gpu.set_option("share", -1)
             keys = ("ms_seed", "ms_publish", "ms_sa", "ms_chain", "ms_extend", "ms_dedup", "ms_total")
             res["stage_ms_solo"] = {k: round(min(s[k] for s in solo), 3) for k in keys}
             counts, regs = gpu.download()
