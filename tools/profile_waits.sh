@@ -5,7 +5,7 @@ tag=${1:-waits}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag; mkdir -p $out
-B="python bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline --no-e2e --no-longread"
+B="python bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline --no-e2e --no-longread --no-pmc"
 timeout -s KILL 150 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM --output-format csv -d $out/p1 -o c -- $B > $out/p1.log 2>&1; echo "pass rc $?"
 tail -3 $out/p1.log | cut -c1-200
 python tools/sq_summary.py $out/p1 $out/waits.md "solo batch of 1 M reads; $B" 2>&1 | grep "k_seed<true\|k_extend_wave\|k_chain_wave\|k_dedup\|kernel\|---" | cut -c1-300
