@@ -233,6 +233,25 @@ extern "C" int bwagpu_set_option(bwagpu_t *h, const char *key, long long value)
 	// the index-side options shape what bwagpu_create / bwagpu_index_ready derive from the index: per handle they can only be set before that
 	// happens (a handle created with NULL arrays, ahead of the broadcast); otherwise use bwagpu_set_default_option before creating the handle
 	if ((f == &h->cfg.occ32 || f == &h->cfg.occ32_sb_shift || f == &h->cfg.ptab_m) && (h->ix.occ32 || h->ix.ptab) && *f != value) return BWAGPU_EINVAL;
+	// ranges: sizes and counts that the batch calls cast to int or multiply, and the two options with a fixed set of kernel instances behind them
+	// (-1 = auto where the list says so)
+	{
+		const BwagpuConfig &c = h->cfg;
+		auto in = [&](long long lo, long long hi) { return value >= lo && value <= hi; };
+		bool ok = true;
+		if (f == &c.ext_occ) ok = value == 4 || value == 6;
+		else if (f == &c.seed_mrg) ok = value == -1 || value == 0 || value == 2;
+		else if (f == &c.share) ok = in(-1, 100);
+		else if (f == &c.seed_task_stack || f == &c.seed_p2_cap || f == &c.mem_cap || f == &c.seed_grid || f == &c.cig_ops_cap || f == &c.idx_desc_max_mb) ok = in(0, 0x3fffffff);
+		else if (f == &c.seed_budget) ok = in(-1, 0x3fffffff);
+		else if (f == &c.seed_lds_ent) ok = in(-1, 64);
+		else if (f == &c.dedup_ring) ok = value == 0 || (in(256, 4096) && (value & (value - 1)) == 0);
+		else if (f == &c.cigl_mib) ok = in(0, 1 << 20);
+		else if (f == &c.cig_tiers) ok = in(0, 2);
+		else if (f == &c.ptab_m) ok = in(0, PTAB_MAX);
+		else if (f == &c.occ32_sb_shift) ok = in(8, 32);
+		if (!ok) return BWAGPU_EINVAL;
+	}
 	*f = value;
 	if (f == &h->cfg.pinned_results) g_results.on = value;
 	if (f == &h->cfg.pinned_min_kb) g_results.min_kb = value < 0 ? 0 : value;
@@ -1299,7 +1318,7 @@ extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_
 		if (ext_cap < 1) ext_cap = 1;
 		// third tier (k_cigar_long): segments, bands and operation counts beyond the LDS tiers' limits; one 64-thread workgroup per region at a time,
 		// each with a direction matrix of its own in HBM.  A sizing pass (k_cigar_long_plan) counts the regions the LDS tiers left and the largest
-		// matrix any of them can ask for; the scratch is as many such matrices as there are regions, at most 1024 and at most option cigl_mib (16 GiB).
+		// matrix any of them can ask for; the scratch is as many such matrices as there are regions, at most 1024 and at most option cigl_mib (32 GiB).
 		const bool long_tier = h->cfg.cig_long != 0;
 		const i64 cigl_budget = (i64)h->cfg.cigl_mib << 20;
 		const bool cig_trace = h->cfg.cig_trace != 0;

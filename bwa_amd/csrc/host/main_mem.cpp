@@ -1016,7 +1016,10 @@ int main(int argc, char *argv[])
 	});
 
 	std::thread reader([&] {      // stage 1: input, pairing classes
-		int64_t n_processed = 0; long no = 0;
+		// (BWAGPU_CLI_N_PROCESSED0: the number the run's first read gets -- mem_pair's tie-breaking hash takes the pair's number in the whole run, bwamem_pair.c:208,248, and
+		// wraps at 2^23 pairs: the tests start a small input just below that)
+		const int64_t n_processed0 = getenv("BWAGPU_CLI_N_PROCESSED0") ? atoll(getenv("BWAGPU_CLI_N_PROCESSED0")) : 0;
+		int64_t n_processed = n_processed0; long no = 0;
 		for (;;) {
 			WorkP w(new Work()); w->no = no;
 			{ std::lock_guard<std::mutex> l(pool_m); if (!batch_pool.empty()) { w->in = std::move(batch_pool.back()); batch_pool.pop_back(); } }
@@ -1048,7 +1051,7 @@ int main(int argc, char *argv[])
 			busy_read += now_s() - tr;
 			to_enc.push(std::move(w));
 		}
-		n_works = no; n_reads_total = (long)n_processed;
+		n_works = no; n_reads_total = (long)(n_processed - n_processed0);
 		cpu_read = thread_cpu_s();
 		to_enc.close();
 	});

@@ -176,6 +176,52 @@ def test_cli_gpu_block_parallel_input(tmp_path):
     assert _run(refapi.REF_BWA, ["-C", fa, weird]) == _run(cli, ["-C", fa, weird], env), "awkward file"
 
 
+def _pair_id_run(cli, fa, g, tmp_path, n_pairs, K, n0, threads, env_extra, seed):
+    """(SAM records of `cli` started at read number n0, the compiled reference's mem_process_seqs batch by batch with each batch's n_processed)"""
+    from bwa_amd.structs import default_opt
+    r1, r2 = simdata.make_reads_pe(g, n_pairs, seed=seed, sub=0.02)
+    f1, f2 = str(tmp_path / "p1.fq"), str(tmp_path / "p2.fq")
+    simdata.write_fastq(f1, r1, suffix="/1"); simdata.write_fastq(f2, r2, suffix="/2")
+    args = ["-K", str(K), "-t", str(threads), fa, f1, f2]
+    got = _run(cli, args, dict(os.environ, BWAGPU_CLI_N_PROCESSED0=str(n0), **env_extra))
+    ref = refapi.RefIndex(fa)
+    opt = default_opt(); opt.flag |= 2; opt.n_threads = threads
+    L = r1.shape[1]
+    per = -(-K // L); per += per & 1
+    want = b""
+    inter = np.empty((2 * r1.shape[0], L), dtype=np.uint8); inter[0::2], inter[1::2] = r1, r2
+    for lo in range(0, inter.shape[0], per):
+        rd = inter[lo:lo + per]
+        names = [f"r{(lo + i) >> 1}" for i in range(rd.shape[0])]
+        want += ref.process_seqs(opt, names, simdata._ASCII[rd].tobytes(), b"I" * (rd.shape[0] * L), np.arange(0, rd.shape[0] + 1, dtype=np.int64) * L, n_processed=n0 + lo)
+    ref.close()
+    body = lambda t: b"".join(l for l in t.splitlines(True) if not l.startswith(b"@"))
+    return body(got), want, args, body
+
+
+@pytest.mark.skipif(not refapi.have_ref(), reason="oracle/_ref not built")
+def test_cli_hostsim_run_starting_at_a_read_number(tmp_path):
+    """BWAGPU_CLI_N_PROCESSED0 (the number of the run's first read) reaches mem_pair / mem_matesw through every batch: four batches of the mock-runtime
+    command line just below pair id 2^23 equal the reference's mem_process_seqs called with the same numbers."""
+    prefix, g = testdata.small_index()
+    got, want, _, _ = _pair_id_run(_sim_cli(), prefix, g, tmp_path, 40, 3000, (1 << 24) - 30, 2, dict(BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1", BWAGPU_PTAB_M="6"), seed=408)
+    assert got == want
+
+
+@pytest.mark.gpu
+def test_cli_gpu_pair_ids_across_2_to_23(tmp_path):
+    """`bwa-amd mem` deep inside a long run: the run's first read is given the number 2^24 - 9000 (BWAGPU_CLI_N_PROCESSED0), so that the pair ids cross 2^23 -- where
+    mem_pair's `id << 8` wraps (bwamem_pair.c:208,248) -- inside the second of five batches, with device CIGARs and mate rescue on.  The reference
+    side is its own mem_process_seqs, called batch by batch (the batches `-K 2000000` forms) with each batch's n_processed."""
+    assert refapi.have_ref(), "oracle/_ref (the compiled reference) is missing on the GPU box"
+    from bwa_amd import build as b
+    _, cli = b.build_host(verbose=False)
+    fa, g = testdata.medium_index()
+    got, want, args, body = _pair_id_run(cli, fa, g, tmp_path, 30000, 2000000, (1 << 24) - 9000, 4, {}, seed=407)
+    assert got == want, "bwa-amd mem with pair ids across 2^23 differs from mem_process_seqs"
+    assert body(_run(cli, args)) != want, "the pair ids made no difference: the test does not reach the hash"
+
+
 @pytest.mark.gpu
 def test_cli_gpu_two_devices(tmp_path):
     """BWAGPU_DEVICES on hardware: when the box has at least two GPUs, `bwa-amd mem` with every batch split over devices

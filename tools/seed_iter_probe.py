@@ -62,6 +62,8 @@ for cfg in (sys.argv[1:] or [""]):
         gpu.L.bwagpu_debug_seed_x2(gpu.h, x2)
         print(f"    index-block steps per read: forward {x2[0] / n:.1f} ({x2[2] / n:.1f} on one-row intervals, in {x2[4] / n:.2f} runs), backward {x2[1] / n:.1f} "
               f"({x2[3] / n:.1f} on one-row intervals, in {x2[5] / n:.2f} runs); one-row share of all block steps {100.0 * (x2[2] + x2[3]) / max(x2[0] + x2[1], 1):.1f}%", flush=True)
+        print(f"    interval-stack entries taken from HBM scratch: {out[10] / n:.1f} lane steps per read ({out[11] / n:.1f} of them served by the entry fetched a step ahead); "
+              f"wave iterations that read the stack from HBM: {out[12] / max(it, 1) * 100:.1f}%", flush=True)
         print("    iterations per read: " + ", ".join(f"<{1 << b}: {100.0 * hist[b] / tot_r:.1f}% of reads / {100.0 * hist[32 + b] / tot_i:.1f}% of iterations" for b in range(32) if hist[b]), flush=True)
     for k, v in old.items():
         gpu.set_option(k, v)
