@@ -91,7 +91,7 @@ struct bwagpu_s {
 	DevBuf d_seq_2b, d_seq_flags; int rd_words = 0;   // per-read 2-bit copies for k_seed's LDS (k_pack_reads2b)
 	DevBuf d_pack_off, d_regs_packed, d_pack_read, d_cigs, d_seq, d_seq_nib, d_off, d_ctr, d_tmp_intv, d_intv_n, d_intv_off, d_intv, d_seed_n, d_seed_off;
 	DevBuf d_slot_pos, d_slot_qbeg, d_slot_len, d_slot_rid, d_slot_blob;
-	DevBuf d_order, d_bin_cnt, d_chain_todo, d_seed_w, d_seed_order, d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
+	DevBuf d_order, d_bin_cnt, d_seed_w, d_seed_order, d_chain_n, d_node_off, d_nodes, d_reg_off, d_reg_cap_r, d_reg_n_raw, d_reg_n, d_regs, d_regs_raw, d_dp_h, d_dp_e, d_minhsp;
 	i64 slot_cap = 0, node_cap = 0, reg_cap = 0; int mem_cap = 0;
 	double need_slot = 0, need_node = 0, need_reg = 0; int need_mem = 0;   // per-base arena needs learnt from earlier batches of this handle
 	std::vector<i64> h_off;
@@ -470,7 +470,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 	}
 	DevBuf *all[] = { &h->d_heavy, &h->d_p2_tasks, &h->d_vr_tab, &h->d_vr_ovf, &h->d_intv_n3, &h->d_cigl_list, &h->d_cigl_z, &h->d_cigl_ops, &h->d_cigl_md, &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
-		&h->d_order, &h->d_bin_cnt, &h->d_chain_todo, &h->d_seed_w, &h->d_seed_order, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
+		&h->d_order, &h->d_bin_cnt, &h->d_seed_w, &h->d_seed_order, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
 	for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
 	if (h->ev_wait) (void)hipEventDestroy(h->ev_wait);
@@ -865,7 +865,7 @@ static int alloc_batch(bwagpu_t *h, int n_threads, int seed_lanes)
 	bad |= h->d_dp_h.ensure((size_t)n_waves * (h->max_len + 2) * DPS * 4);
 	bad |= h->d_dp_e.ensure((size_t)n_waves * (h->max_len + 2) * DPS * 4);
 	bad |= h->d_minhsp.ensure((size_t)(h->max_len + 2) * 4);
-	bad |= h->d_order.ensure((size_t)n * 4 + 16); bad |= h->d_bin_cnt.ensure(2 * ORDER_BINS * 4); bad |= h->d_chain_todo.ensure((size_t)n * 8 + 32); bad |= h->d_seed_w.ensure((size_t)n * 4 + 16); bad |= h->d_seed_order.ensure((size_t)n * 4 + 16);
+	bad |= h->d_order.ensure((size_t)n * 4 + 16); bad |= h->d_bin_cnt.ensure(2 * ORDER_BINS * 4); bad |= h->d_seed_w.ensure((size_t)n * 4 + 16); bad |= h->d_seed_order.ensure((size_t)n * 4 + 16);
 	if (bad) { h->err = "hipMalloc failed (batch arenas)"; return BWAGPU_ENOMEM; }
 	return 0;
 }
@@ -1000,11 +1000,10 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.regs_raw = h->taps_on ? h->d_regs_raw.as<bwagpu_alnreg_t>() : nullptr;
 		B.dp_h = h->d_dp_h.as<i32>(); B.dp_e = h->d_dp_e.as<i32>(); B.dp_waves = dp_wave_count(h, n_threads);
 		B.seedsw_minhsp = h->d_minhsp.as<i32>();
-		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>(); B.chain_todo = h->d_chain_todo.as<i32>(); B.chain_todo2 = B.chain_todo + n + 4; B.seed_w = h->d_seed_w.as<i32>(); B.seed_order = nullptr;
+		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>(); B.seed_w = h->d_seed_w.as<i32>(); B.seed_order = nullptr;
 		B.seed_prio = cfg.seed_prio != 0;
 		B.seed_no_virt = cfg.seed_no_virt != 0;
 		B.seed_pass3_inline = cfg.seed_pass3_inline != 0;
-		B.chain_lds_off = cfg.chain_lds == 0;
 		B.task_step = opt->min_seed_len; B.n_vreads = n_vreads; B.vr_ovf_run = 0; B.vr_room = 0; B.seed_stack_cap = 0; B.intv_n3 = nullptr;
 		if (seed_tasks) { B.vr_first = h->d_vr_tab.as<i32>(); B.vr_ovf = h->d_vr_ovf.as<i32>(); B.intv_n3 = h->d_intv_n3.as<i32>(); }
 		B.task_tpr = 0; B.p2_tasks = nullptr; B.p2_cap = 0; B.heavy_list = nullptr; B.seed_budget = 0;
@@ -1094,13 +1093,10 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		hipLaunchKernelGGL(k_sa, dim3((unsigned)sa_blocks), block, 0, h->stream, h->ix, B);
 		HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_sa", hipGetErrorString(e_)); }
-		{	// wave per read, heaviest reads (most seeds) first; reads that outgrow the LDS tier are redone by the HBM tier
+		{	// wave per read, heaviest reads (most seeds) first
 			if (int rc2 = order_reads(h, B, B.seed_n)) return rc2;
-			i64 nblk = ((i64)n + 3) / 4, cap = share(256 * 8);
-			hipLaunchKernelGGL((k_chain_wave<0, 10, 32, 128>), dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)CW_LDS_BYTES(10, 32, 128) * 4, h->stream, h->ix, *opt, B);
-			// (the deferred reads are known on the device only: the grids of tiers 1 and 2 are sized for a full chip, or for every read of a small batch)
-			hipLaunchKernelGGL((k_chain_wave<1, 16, 64, 0>), dim3((unsigned)(nblk < share(256 * 5) ? nblk : share(256 * 5))), block, (size_t)CW_LDS_BYTES(16, 64, 0) * 4, h->stream, h->ix, *opt, B);
-			hipLaunchKernelGGL((k_chain_wave<2, 0, 0, 0>), dim3((unsigned)(nblk < share(256 * 7) ? nblk : share(256 * 7))), block, (size_t)CW_LDS_BYTES(0, 0, 0) * 4, h->stream, h->ix, *opt, B);
+			i64 nblk = ((i64)n + 3) / 4, cap = share(256 * 7);
+			hipLaunchKernelGGL(k_chain_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)CW_LDS_BYTES * 4, h->stream, h->ix, *opt, B);
 		}
 		HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_chain", hipGetErrorString(e_)); }
@@ -1202,7 +1198,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		h->stats.n_seeds = (i64)c.seed_used;
 		h->stats.n_intv = (i64)c.n_intv;
 		h->stats.n_chains = (i64)c.n_chains; h->stats.n_regs_raw = (i64)c.n_regs_raw; h->stats.n_regs = (i64)c.n_regs;
-		h->stats.n_tab_lookups = (i64)c.tab_lookups; h->stats.n_bt_nodes = (i64)c.bt_nodes; h->stats.n_chain_recs = (i64)c.chain_recs; h->stats.n_chain_deferred = (i64)c.n_chain_todo; h->stats.n_chain_deferred2 = (i64)c.n_chain_todo2;
+		h->stats.n_tab_lookups = (i64)c.tab_lookups; h->stats.n_bt_nodes = (i64)c.bt_nodes; h->stats.n_chain_recs = (i64)c.chain_recs;
 		h->stats.n_occ_blocks = (i64)c.occ_blocks; h->stats.n_lf_steps = (i64)c.lf_steps;
 		h->stats.n_ext_calls = (i64)c.ext_calls; h->stats.n_ext_cells = (i64)c.ext_cells; h->stats.n_ext_fast = (i64)c.ext_fast;
 		h->stats.n_glb_calls = (i64)c.glb_calls; h->stats.n_glb_cells = (i64)c.glb_cells; h->stats.ref_bases = (i64)c.ref_bases;

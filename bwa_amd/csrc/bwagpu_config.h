@@ -38,7 +38,6 @@
 	X(seed_pass3_inline, 0)    /* seeding: pass 3 inside k_seed's state machine instead of k_seed3 (A/B)                                                */ \
 	X(seed_grid,         0)    /* seeding: resident workgroups of k_seed (0: fill the chip; measurements)                                               */ \
 	X(share,             -1)   /* short reads: percent of a chip-filling launch that the hot path's persistent kernels take (kernels of different batches side by side); auto: 50 when three or more handles share the index, else 100 */ \
-	X(chain_lds,         1)    /* chaining: 0 = the LDS tiers defer every read to the HBM tier (test hook)                                              */ \
 	X(ext_occ,           6)    /* extension: waves per SIMD the short-read kernel's register allocation aims at (4 or 6)                                */ \
 	X(dedup_wave,        0)    /* 1 = the wave-per-read de-duplication kernel for short reads as well (test hook)                                       */ \
 	X(dedup_ring,        0)    /* ring columns of that kernel (0: from the batch; test hook: a power of two, 256..4096)                                 */ \

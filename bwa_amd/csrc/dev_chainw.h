@@ -11,20 +11,19 @@
 // entries at once.  Everything that is not order-dependent is lane-parallel: chain weights (lane per chain), the pairwise filter
 // (64 kept chains per step; the reference's "stop at the first chain that drops this one" is a find-first-set on the ballot), the
 // flattening of the kept chains.
-// Three tiers, each a launch of the same template: <nodes, chains, seeds> kept per read in LDS.
-//   tier 0  <10, 32, 128>   ~7 KB of LDS per wave -> 20+ waves per CU; takes nine reads out of ten: tree, chain records, the read's
-//                          seeds and their links all in LDS, so that nothing in the order-dependent loop waits on HBM;
-//   tier 1  <16, 64, 0>    reads with more seeds or chains than that: tree and chain records in LDS (~9 KB per wave), seeds in HBM;
-//   tier 2  <0, 0, 0>      everything in the read's HBM region (reads inside repeat families: hundreds of chains), at full occupancy.
-// A read that outgrows its tier is appended to the next tier's work list, nothing of it having been published.
+// Storage: tree, chain records, seed links, sort keys in the read's own region of HBM (RegionView); LDS holds the traversal stack and the weight sort's
+// pairs.  Rounds 2-4 ran three tiers of one template -- tree and chain records in LDS for reads that fit, HBM for the rest -- on the premise that the tree's
+// memory is what a look-up costs.  It is not (the per-seed cost is the wave-uniform logic: 5-7 us per seed in every tier), and in round 5 the HBM form alone
+// measured as fast as the three together (24.2 vs 24.9 ms per million reads, profiles/r05_chain_tiers.log), with the root node -- where every look-up
+// starts -- held in registers (RootCache).  One kernel, one form.
 #pragma once
 #include "dev_chain.h"
 #include "dev_extw.h"
 
 #define CW_STACK_INTS 32
-// LDS bytes of one wave: nodes, chain records, sort pairs, filter records {int4 kinfo, i32 kept, i32 ord}, seeds {i64 pos, i32 qbeg, len, next}, stack
-#define CW_PW_HBM_TIER 512       // HBM tier: chains whose {weight, index} pairs are sorted in LDS (a serial sort in HBM costs ~1 us per step)
-#define CW_LDS_BYTES(NC, CC, SC) ((NC) * BT_NODE_INTS * 4 + (CC) * (64 + 8 + 16 + 4 + 4) + (SC) * 20 + CW_STACK_INTS * 4 + ((NC) == 0 ? CW_PW_HBM_TIER * 8 : 0))
+// LDS bytes of one wave: the traversal stack and the {weight, index} pairs of up to CW_PW_HBM_TIER chains (a serial sort in HBM costs ~1 us per step)
+#define CW_PW_HBM_TIER 512
+#define CW_LDS_BYTES (CW_STACK_INTS * 4 + CW_PW_HBM_TIER * 8)
 
 DEVFN i64 *cw_pos(i32 *node) { return (i64*)(node + 22); }
 DEVFN i64 readlane_i64(i64 v, int l)
@@ -74,13 +73,19 @@ DEVFN int cw_search(const NodeRegs &nr, i64 pos, int lane, int &r)
 // full node, a following insertion of the same position (the seed did not merge into the chain found) would descend along exactly
 // this path and split nothing, so it can be done on the leaf still held in registers (cw_insert_at) without a second descent.
 struct LowerPath { int leaf, i; bool direct; NodeRegs nr; };
-DEVFN int cw_lower(i32 *nd, int root, i64 pos, int lane, u32 &visits, LowerPath &P)
+// The root node as the wave last loaded it.  Every look-up starts at the root, and in the HBM tier every node costs a dependent memory round trip (three to
+// four per seed: root, inner node, leaf, chain record): the root's -- a third of the descent -- is saved as long as nobody has written to the root since.
+// node = -1: nothing cached.  Writers call cw_touch() with the node they are about to modify.
+struct RootCache { int node; NodeRegs nr; };
+DEVFN void cw_touch(RootCache &rc, int x) { if (x == rc.node) rc.node = -1; }
+DEVFN int cw_lower(i32 *nd, int root, i64 pos, int lane, u32 &visits, LowerPath &P, RootCache &rc)
 {
 	int x = root, low = -1, i;
 	bool full = false, leaf;
 	NodeRegs nr;
 	for (;;) {
-		nr = cw_load(nd, x, lane);
+		if (x == rc.node) nr = rc.nr;
+		else { nr = cw_load(nd, x, lane); if (x == root) { rc.node = x; rc.nr = nr; } }
 		int r = 0;
 		i = cw_search(nr, pos, lane, r);
 		++visits;
@@ -94,8 +99,9 @@ DEVFN int cw_lower(i32 *nd, int root, i64 pos, int lane, u32 &visits, LowerPath 
 	return low;
 }
 // the leaf step of __kb_putp_aux (kbtree.h:199-206) on a leaf already in registers: key k / position pos go in after entry i
-DEVFN void cw_insert_at(i32 *nd, const LowerPath &P, int k, i64 pos, int lane)
+DEVFN void cw_insert_at(i32 *nd, const LowerPath &P, int k, i64 pos, int lane, RootCache &rc)
 {
+	cw_touch(rc, P.leaf);
 	i32 *X = nd + P.leaf * BT_NODE_INTS;
 	const int i = P.i, n = nr_n(P.nr);
 	if (lane > 2 + i && lane < 2 + n) X[lane + 1] = P.nr.hdr;
@@ -104,8 +110,9 @@ DEVFN void cw_insert_at(i32 *nd, const LowerPath &P, int k, i64 pos, int lane)
 	wave_sync();
 }
 // __kb_split (kbtree.h:173-190): y = child i of x is full; its upper half moves to a new node z, its median key up into x
-DEVFN void cw_split(i32 *nd, int &n_nodes, int x, int i, int y, int lane)
+DEVFN void cw_split(i32 *nd, int &n_nodes, int x, int i, int y, int lane, RootCache &rc)
 {
+	cw_touch(rc, x); cw_touch(rc, y);
 	const int z = n_nodes++;
 	i32 *X = nd + x * BT_NODE_INTS, *Y = nd + y * BT_NODE_INTS, *Z = nd + z * BT_NODE_INTS;
 	const NodeRegs xr = cw_load(nd, x, lane), yr = cw_load(nd, y, lane);
@@ -125,15 +132,15 @@ DEVFN void cw_split(i32 *nd, int &n_nodes, int x, int i, int y, int lane)
 	wave_sync();
 }
 // kb_putp / __kb_putp_aux (kbtree.h:191-224)
-DEVFN void cw_insert(i32 *nd, int &n_nodes, int &root, int &height, int k, i64 pos, int lane)
+DEVFN void cw_insert(i32 *nd, int &n_nodes, int &root, int &height, int k, i64 pos, int lane, RootCache &rc)
 {
 	if (uni(nd[root * BT_NODE_INTS]) == BT_MAXK) {
 		++height;
 		const int s = n_nodes++;
 		if (lane == 0) { nd[s * BT_NODE_INTS] = 0; nd[s * BT_NODE_INTS + 1] = 1; nd[s * BT_NODE_INTS + 2 + BT_MAXK] = root; }
 		wave_sync();
-		cw_split(nd, n_nodes, s, 0, root, lane);
-		root = s;
+		cw_split(nd, n_nodes, s, 0, root, lane, rc);
+		root = s; rc.node = -1;
 	}
 	int x = root;
 	for (;;) {
@@ -142,6 +149,7 @@ DEVFN void cw_insert(i32 *nd, int &n_nodes, int &root, int &height, int k, i64 p
 		int r = 0;
 		if (!nr_internal(xr)) {
 			const int i = cw_search(xr, pos, lane, r), n = nr_n(xr);
+			cw_touch(rc, x);
 			wave_sync();
 			if (lane > 2 + i && lane < 2 + n) X[lane + 1] = xr.hdr;                  // keys i+1.. move up by one
 			if (lane > i && lane < n) cw_pos(X)[lane + 1] = xr.key;
@@ -152,7 +160,7 @@ DEVFN void cw_insert(i32 *nd, int &n_nodes, int &root, int &height, int k, i64 p
 		int i = cw_search(xr, pos, lane, r) + 1;
 		const int c = nr_child(xr, i);
 		if (uni(nd[c * BT_NODE_INTS]) == BT_MAXK) {
-			cw_split(nd, n_nodes, x, i, c, lane);
+			cw_split(nd, n_nodes, x, i, c, lane, rc);
 			xr = cw_load(nd, x, lane);
 			if (pos > readlane_i64(xr.key, i)) ++i;
 		}
@@ -192,10 +200,8 @@ DEVFN int cw_inorder(i32 *nd, int root, i32 *out, i32 *stk, int lane)
 
 DEVFN int wave_excl_scan_add(int v, int lane) { (void)lane; return wave_incl_scan_add(v) - v; }      // (DPP steps, dev_extw.h: no shuffle addresses to keep in registers)
 
-// One read.  NC/CC/SC: nodes, chains and seeds this tier keeps in LDS (0: in the read's HBM region).  Returns false when the read
-// outgrows the tier, nothing having been published.
-template <int NC, int CC, int SC>
-__device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, unsigned char *lds, u64 &n_visits, u64 &n_recs, int &out_k, int &out_m)
+// One read.
+__device__ void chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, unsigned char *lds, u64 &n_visits, u64 &n_recs, int &out_k, int &out_m)
 {
 	out_k = 0; out_m = 0;
 	const int lane = threadIdx.x & 63;
@@ -207,37 +213,18 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 	const i64 so = uni64(so_);
 	if (ns == 0) {
 		if (lane == 0) { B.chain_n[r] = 0; B.reg_off[r] = 0; B.reg_cap_r[r] = 0; B.reg_n_raw[r] = 0; B.reg_n[r] = 0; }
-		return true;
+		return;
 	}
-	if (NC > 0 && SC > 0 && ns > SC) return false;            // tier 0 takes the reads whose seeds fit its LDS cache
 	const RegionView R = region_of(B.slot_blob, so, ns);
-	// ---- storage of this tier ----
-	i32 *nd; ChainRec *ch; int2 *pw; int4 *kinfo; i32 *kept, *ord, *stk;
-	if (NC > 0) {
-		unsigned char *p = lds;
-		nd = (i32*)p; p += NC * BT_NODE_INTS * 4;
-		ch = (ChainRec*)p; p += CC * 64;
-		pw = (int2*)p; p += CC * 8;
-		kinfo = (int4*)p; p += CC * 16;
-		kept = (i32*)p; p += CC * 4;
-		ord = (i32*)p; p += CC * 4;
-		stk = (i32*)(p + SC * 20);
-	} else {
-		nd = B.nodes + uni64(no_) * BT_NODE_INTS; ch = R.chain; pw = (int2*)R.srt; kinfo = R.kinfo; kept = R.kept; ord = R.ord; stk = (i32*)lds;
-		if (ns <= CW_PW_HBM_TIER) pw = (int2*)(lds + CW_STACK_INTS * 4);   // (n <= n_ch <= ns)
-	}
-	const u64 *gpos = B.slot_pos + so;
-	const i32 *gqb = B.slot_qbeg + so, *gln = B.slot_len + so, *srid = B.slot_rid + so;
-	const i64 *pos; const i32 *sqb, *sln; i32 *next;
-	if (SC > 0) {   // the read's seeds and their chain links in LDS
-		unsigned char *p = lds + NC * BT_NODE_INTS * 4 + CC * (64 + 8 + 16 + 4 + 4);
-		i64 *lp = (i64*)p; i32 *lq = (i32*)(p + SC * 8), *ll = (i32*)(p + SC * 12);
-		next = (i32*)(p + SC * 16);
-		for (int i = lane; i < ns; i += 64) { lp[i] = (i64)gpos[i]; lq[i] = gqb[i]; ll[i] = gln[i]; }
-		pos = lp; sqb = lq; sln = ll;
-	} else { pos = (const i64*)gpos; sqb = gqb; sln = gln; next = R.next; }
+	// ---- storage: the read's region of HBM; LDS for the traversal stack and (up to CW_PW_HBM_TIER chains) the weight sort's pairs ----
+	i32 *nd = B.nodes + uni64(no_) * BT_NODE_INTS; ChainRec *ch = R.chain; int2 *pw = (int2*)R.srt; int4 *kinfo = R.kinfo; i32 *kept = R.kept, *ord = R.ord, *stk = (i32*)lds;
+	if (ns <= CW_PW_HBM_TIER) pw = (int2*)(lds + CW_STACK_INTS * 4);   // (n <= n_ch <= ns)
+	const i64 *pos = (const i64*)(B.slot_pos + so);
+	const i32 *sqb = B.slot_qbeg + so, *sln = B.slot_len + so, *srid = B.slot_rid + so;
+	i32 *next = R.next;
 	// ---- mem_chain (bwamem.c:299-334): one B-tree look-up / insertion per seed, in seed order ----
 	int n_nodes = 1, root = 0, n_ch = 0, height = 1;
+	RootCache rc; rc.node = -1; rc.nr.hdr = 0; rc.nr.key = 0;
 	if (lane == 0) { nd[0] = 0; nd[1] = 0; }
 	wave_sync();
 	u32 visits = 0, recs = 0;
@@ -255,7 +242,7 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 			bool add = true;
 			LowerPath path; path.direct = false;
 			if (n_ch) {
-				const int lo = cw_lower(nd, root, rbeg, lane, visits, path);
+				const int lo = cw_lower(nd, root, rbeg, lane, visits, path, rc);
 				if (lo >= 0) {   // test_and_merge (bwamem.c:216-237)
 					ChainRec *c = ch + lo;
 					++recs;
@@ -284,8 +271,6 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 				}
 			}
 			if (add) {
-				// an insertion allocates at most two nodes for a root split plus one per level below the (new) root
-				if (NC > 0 && (n_ch >= CC || n_nodes + height + 2 > NC)) return false;   // outgrew this tier
 				if (lane == 0) {
 					ChainRec c;
 					c.pos = rbeg; c.last_rbeg = rbeg; c.first = c.last = s; c.first_qbeg = c.last_qbeg = qbeg; c.last_len = slen;
@@ -294,19 +279,19 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 					ch[n_ch] = c;
 				}
 				wave_sync();
-				if (path.direct) cw_insert_at(nd, path, n_ch, rbeg, lane);
-				else cw_insert(nd, n_nodes, root, height, n_ch, rbeg, lane);
+				if (path.direct) cw_insert_at(nd, path, n_ch, rbeg, lane, rc);
+				else cw_insert(nd, n_nodes, root, height, n_ch, rbeg, lane, rc);
 				++n_ch; ++recs;
 			}
 		}
 	}
 	n_visits += visits; n_recs += recs;
-	if (B.stats && lane == 0) {      // (diagnostics: the reads that finish in this tier, by chains and by seeds -- bwagpu_debug_chain_hist)
-		const int t = NC == 0 ? 2 : SC > 0 ? 0 : 1, cb = n_ch / 16 < 31 ? n_ch / 16 : 31, sb = ns / 32 < 31 ? ns / 32 : 31;
-		atomicAdd(&B.ctr->chain_hist[t][cb], 1ull); atomicAdd(&B.ctr->chain_seeds[t][sb], 1ull);
+	if (B.stats && lane == 0) {      // (diagnostics: reads by chains and by seeds -- bwagpu_debug_chain_hist)
+		const int cb = n_ch / 16 < 31 ? n_ch / 16 : 31, sb = ns / 32 < 31 ? ns / 32 : 31;
+		atomicAdd(&B.ctr->chain_hist[0][cb], 1ull); atomicAdd(&B.ctr->chain_seeds[0][sb], 1ull);
 	}
 	if (lane == 0) { B.chain_n[r] = 0; B.reg_off[r] = 0; B.reg_cap_r[r] = 0; B.reg_n_raw[r] = 0; B.reg_n[r] = 0; }
-	if (n_ch == 0) return true;
+	if (n_ch == 0) return;
 	// Fraction of the read covered by over-abundant seeds (bwamem.c:291-298).  The reference merges the intervals -- sorted by
 	// start -- into runs and adds up the runs' lengths; that is the length of their union, and with M(k) the largest end before
 	// interval k the union is the sum of max(0, end_k - max(start_k, M(k))): a prefix maximum, 64 intervals per step.
@@ -359,7 +344,7 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 		k += __popcll(m);
 	}
 	n = k;
-	if (n == 0) return true;
+	if (n == 0) return;
 	wave_sync();
 	// ks_introsort by weight (bwamem.c:367): {weight, index} pairs, literal comparison sequence, one lane
 	for (int i = lane; i < n; i += 64) pw[i] = make_int2(ch[ord[i]].w, ord[i]);
@@ -463,22 +448,20 @@ __device__ bool chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 	// the caller reserves the read's range of the region arena (one atomic per chunk of reads) and sets reg_off
 	if (k && lane == 0) { B.chain_n[r] = k; B.reg_cap_r[r] = m_tot; }
 	out_k = k; out_m = m_tot;
-	return true;
 }
 
-// TIER 0: every read, heaviest first (B.order by seed count); a read that outgrows a tier goes to the next tier's work list
-// (B.chain_todo / B.chain_todo2).  4 waves per workgroup, CW_LDS_BYTES(NC, CC, SC) of dynamic LDS per wave.
-template <int TIER, int NC, int CC, int SC> __global__ void __launch_bounds__(256) k_chain_wave(DevIndex ix, bwagpu_opt_t opt, Batch B)
+// Every read, heaviest first (B.order by seed count).  4 waves per workgroup, CW_LDS_BYTES of dynamic LDS per wave.
+__global__ void __launch_bounds__(256) k_chain_wave(DevIndex ix, bwagpu_opt_t opt, Batch B)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, cw_lds)
 	const int lane = threadIdx.x & 63;
-	unsigned char *lds = cw_lds + (size_t)(threadIdx.x >> 6) * CW_LDS_BYTES(NC, CC, SC);
+	unsigned char *lds = cw_lds + (size_t)(threadIdx.x >> 6) * CW_LDS_BYTES;
 	u64 visits = 0, recs = 0, nch = 0;
-	const long long n_items = TIER == 0 ? (long long)B.n_reads : TIER == 1 ? (long long)B.ctr->n_chain_todo : (long long)B.ctr->n_chain_todo2;
-	unsigned long long *cursor = TIER == 0 ? &B.ctr->next_chain : TIER == 1 ? &B.ctr->next_chain_b : &B.ctr->next_chain_c;
-	const i32 *items = TIER == 0 ? B.order : TIER == 1 ? B.chain_todo : B.chain_todo2;
-	// Reads are drawn in chunks (one at a time at the heavy head of the list) and everything a read needs from a global counter --
-	// its place in the next tier's list, its range of the region arena -- is reserved once per chunk: lane j keeps the j-th read's results.
+	const long long n_items = (long long)B.n_reads;
+	unsigned long long *cursor = &B.ctr->next_chain;
+	const i32 *items = B.order;
+	// Reads are drawn in chunks (one at a time at the heavy head of the list) and a read's range of the region arena is reserved once per chunk:
+	// lane j keeps the j-th read's results.
 	int step = 1;
 	for (;;) {
 		const long long b = wave_fetch_n(cursor, step);
@@ -486,21 +469,14 @@ template <int TIER, int NC, int CC, int SC> __global__ void __launch_bounds__(25
 		const int cnt = (int)(b + step <= n_items ? step : n_items - b);
 		if (b >= WQ_SINGLE) step = WQ_CHUNK;
 		const int my_r = lane < cnt ? items[b + lane] : -1;
-		int my_st = 0, my_m = 0, my_k = 0;
+		int my_m = 0, my_k = 0;
 		for (int j = 0; j < cnt; ++j) {
 			const int r = __builtin_amdgcn_readlane(my_r, j);
 			int kk = 0, mm = 0;
-			const bool ok = (TIER < 2 && B.chain_lds_off) ? false : chain_read_wave<NC, CC, SC>(ix, opt, B, r, lds, visits, recs, kk, mm);
+			chain_read_wave(ix, opt, B, r, lds, visits, recs, kk, mm);
 			wave_sync();
-			if (lane == j) { my_st = ok ? 1 : 2; my_k = kk; my_m = mm; }
-			if (ok) nch += (u64)kk;
-		}
-		const u64 md = __ballot(my_st == 2);              // (tier 2 never fails)
-		if (md) {
-			unsigned long long at = 0;
-			if (lane == 0) at = atomicAdd(TIER == 0 ? &B.ctr->n_chain_todo : &B.ctr->n_chain_todo2, (unsigned long long)__popcll(md));
-			at = (unsigned long long)lane0_i64((i64)at);
-			if (my_st == 2) (TIER == 0 ? B.chain_todo : B.chain_todo2)[at + __popcll(md & ((1ull << lane) - 1))] = my_r;
+			if (lane == j) { my_k = kk; my_m = mm; }
+			nch += (u64)kk;
 		}
 		const int excl = wave_excl_scan_add(my_m, lane);
 		const int total = __builtin_amdgcn_readlane(excl + my_m, 63);
@@ -508,7 +484,7 @@ template <int TIER, int NC, int CC, int SC> __global__ void __launch_bounds__(25
 			u64 roff = 0;
 			if (lane == 0) roff = atomicAdd(&B.ctr->reg_used, (unsigned long long)total);
 			roff = (u64)lane0_i64((i64)roff);
-			if (my_st == 1 && my_k > 0) {
+			if (my_k > 0) {
 				if (roff + excl + my_m > (u64)B.reg_cap) { atomicOr(&B.ctr->overflow, 8ull); B.chain_n[my_r] = 0; }
 				else B.reg_off[my_r] = (i64)(roff + excl);
 			}

@@ -93,8 +93,6 @@ struct Counters {          // device-side bump allocators + flags
 	HotCounter next_ext_;    // work counter of the wave extension kernel (position in Batch::order)
 	HotCounter next_seedsw_; // work counter of the wave-per-read seed re-scoring kernel (long reads)
 	HotCounter next_chain_, next_dedup_;       // work counters of the chaining and de-duplication kernels
-	HotCounter next_chain_b_, n_chain_todo_;   // second tier of the wave-per-read chaining kernel: its work counter and the length of its work list
-	HotCounter next_chain_c_, n_chain_todo2_;  // third tier
 	HotCounter cig_ext_used_;                  // operations written to the batch's CIGAR operation array (records with more than 6 operations)
 	unsigned long long intv_used;
 	unsigned long long overflow;   // bit0 intv, bit1 seed, bit2 node, bit3 reg, bit4 tmp-intv scratch
@@ -105,7 +103,7 @@ struct Counters {          // device-side bump allocators + flags
 	unsigned long long ext_fast;                   // ksw_extend2 calls answered by the diagonal rule (no DP)
 	unsigned long long bt_nodes, chain_recs;       // B-tree nodes visited by look-ups / chain records touched (k_chain's algorithmic bytes)
 	unsigned long long wave_hist[2][96];           // stats runs of k_extend_wave [0] / k_dedup_wave [1]: reads by floor(log2(time the wave spent on the read, in 10 ns units)) + 1; then, per bin, the DP calls and the DP cells (>> 10) of those reads (bwagpu_debug_hist)
-	unsigned long long chain_hist[3][32];          // stats runs of k_chain_wave: per tier, reads that finished there by min(31, chains before the filter / 16) (bwagpu_debug_chain_hist)
+	unsigned long long chain_hist[3][32];          // stats runs of k_chain_wave: reads by min(31, chains before the filter / 16) in row 0 (rows 1-2: the tiers of rounds 2-4, now zero) (bwagpu_debug_chain_hist)
 	unsigned long long chain_seeds[3][32];         // ... and by min(31, seeds / 32)
 	unsigned long long seed_hist[64];              // k_seed's stats instance: reads by floor(log2(iterations spent on the read)) + 1, then the iterations summed per bin (bwagpu_debug_hist)
 	unsigned long long seed_x2[8];                 // k_seed's stats instance: extension steps that read index blocks, [0] forward / [1] backward in all, [2] / [3] those on an interval of ONE row (a unique match: the step is a comparison with the next text base), [4] / [5] forward / backward runs of such steps (maximal, per search), [6] prefix-table steps (bwagpu_debug_seed_x2)
@@ -126,10 +124,6 @@ struct Counters {          // device-side bump allocators + flags
 #define next_seedsw next_seedsw_.v
 #define next_chain next_chain_.v
 #define next_dedup next_dedup_.v
-#define next_chain_b next_chain_b_.v
-#define n_chain_todo n_chain_todo_.v
-#define next_chain_c next_chain_c_.v
-#define n_chain_todo2 n_chain_todo2_.v
 #define cig_ext_used cig_ext_used_.v
 
 // Sub-arrays of one read's private region (n = its number of seed slots); offsets keep every array naturally aligned.
@@ -189,7 +183,6 @@ struct Batch {
 	// per read, and the next read of the lane starts in a fresh region).
 	u8 *slot_blob;
 	i32 *chain_n;              // per read: chains after filtering
-	i32 *chain_todo, *chain_todo2; // reads deferred by tier 0 / tier 1 of k_chain_wave to the next tier
 	// --- pass 1 of long-read batches as independent tasks (k_seed<LR = 1>, option seed_tasks): task t of read r searches position (t - vr_first[r]) * task_step
 	int task_step, n_vreads;        // min_seed_len; number of tasks of the batch
 	int task_tpr;                   // > 0 (short-read batches, the heavy reads only): task t = position (t % task_tpr) * task_step of read heavy_list[t / task_tpr], for t < n_heavy * task_tpr
@@ -202,7 +195,6 @@ struct Batch {
 	i32 *intv_n3;                   // per read: the entries pass 3 (k_seed3, run first) left at the head of its interval list
 	int seed_prio;             // waves holding the heaviest 3 % of k_seed's reads run at raised issue priority (option seed_prio = 0 turns it off)
 	int seed_pass3_inline;     // A/B switch (option seed_pass3_inline = 1): pass 3 inside k_seed's state machine as in round 1, instead of k_seed3
-	int chain_lds_off;         // test hook (option chain_lds = 0): the LDS tiers defer every read
 	// --- B-tree nodes
 	i64 *node_off;             // per read
 	i32 *nodes; i64 node_cap;  // 21 ints per node

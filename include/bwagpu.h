@@ -186,9 +186,9 @@ typedef struct {
 	int64_t n_tab_lookups;   /* 16-byte prefix-table entries read by seeding in place of index blocks (stats only) */
 	int64_t n_bt_nodes;      /* B-tree nodes (160 B) visited by chaining's look-ups (stats only)               */
 	int64_t n_chain_recs;    /* chain records (64 B) read or created by chaining (stats only)                  */
-	int64_t n_chain_deferred;/* reads whose chaining outgrew tier 0 of k_chain_wave (LDS-resident seeds, 32 chains) */
+	int64_t n_chain_deferred;/* (rounds 2-4: reads whose chaining outgrew the first LDS tier; 0 since round 5 -- one chaining kernel, no tiers) */
 	int64_t n_ext_fast;      /* ksw_extend2 calls answered without DP (diagonal rule, dev_extw.h)              */
-	int64_t n_chain_deferred2;/* ... and tier 1 (96 chains in LDS): chained in the read's HBM region           */
+	int64_t n_chain_deferred2;/* (likewise: always 0)                                                               */
 	/* the calls after bwagpu_batch_run, filled by them (HIP events on the handle's stream; 0 until the call has run for this batch): */
 	float ms_pack;           /* bwagpu_batch_download: packing the used region records on the device          */
 	float ms_download_copy;  /* ... and their device-to-host copy                                              */

@@ -560,29 +560,22 @@ def heavy_case():
     n_kept = np.array([orc.chains(opt, cand[i], 1)[0].shape[0] for i in top])
     pick = list(top[:2]) + [int(top[i]) for i in np.argsort(n_kept)[::-1][:2]]
     assert n_chains[pick[0]] > 200 and n_kept.max() > 100, (n_chains[top], n_kept)
-    mid = [int(i) for i in np.nonzero((n_chains >= 36) & (n_chains <= 60))[0][:2]]    # more than tier 0 holds, fewer than tier 1's limit
+    mid = [int(i) for i in np.nonzero((n_chains >= 36) & (n_chains <= 60))[0][:2]]    # a few dozen chains: B-trees of two levels
     assert len(mid) == 2
-    reads = np.concatenate([cand[pick[:1]], cand[pick[2:3]], cand[mid], cand[:1]])      # most chains, most kept chains, two for tier 1, an ordinary read
+    reads = np.concatenate([cand[pick[:1]], cand[pick[2:3]], cand[mid], cand[:1]])      # most chains, most kept chains, two middling ones, an ordinary read
     yield fa, orc, reads
     orc.close()
 
 
-@pytest.mark.parametrize("lds", ["1", "0"])
-def test_hostsim_wave_chaining_heavy_reads(monkeypatch, heavy_case, lds):
-    """k_chain_wave on reads with many chains (repeat-rich genome): multi-level B-trees with splits, duplicate keys, the
-    64-wide chain filter and the flattening of hundreds of chains must reproduce the oracle's chains exactly -- with the tree in
-    LDS (reads that outgrow it fall through to the HBM tier) and with the LDS tier switched off (every read in the HBM tier)."""
+def test_hostsim_wave_chaining_heavy_reads(monkeypatch, heavy_case):
+    """k_chain_wave on reads with many chains (repeat-rich genome): multi-level B-trees with splits, duplicate keys, the root node cached in
+    registers across look-ups and insertions, the 64-wide chain filter and the flattening of hundreds of chains must reproduce the oracle's chains exactly."""
     fa, orc, reads = heavy_case
     opt = default_opt()
-    s2 = sim_handle(fa, chain_lds=int(lds))
+    s2 = sim_handle(fa)
     s2.set_taps(True); s2.set_stats(True)
     seqs, off = testdata.flat(reads)
     c, r = s2.align(opt, seqs, off)
-    st = s2.stats()
-    if lds == "0":
-        assert st["n_chain_deferred"] == st["n_chain_deferred2"] == len(reads)
-    else:   # some reads stay in tier 0, some run in tier 1 (LDS tree, seeds in HBM), the heaviest in tier 2
-        assert 1 <= st["n_chain_deferred2"] < st["n_chain_deferred"] < len(reads), st
     cn, ch, cs = s2.tap_chains()
     kc = ks = 0
     for i, rd in enumerate(reads):

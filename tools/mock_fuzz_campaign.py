@@ -27,7 +27,6 @@ OPT_SETS = [
     {"seed_task_stack": 2, "seed_lds_ent": 3},
     {"occ32": 0},
     {"ptab_m": 6, "seed_lds_ent": 3},
-    {"chain_lds": 0},
     {"ext_occ": 4},
 ]
 LAYOUT = ("occ32", "occ32_sb_shift", "ptab_m")     # applied when the index is laid out: such a set gets a handle of its own

@@ -32,8 +32,8 @@ def summarize(note, fd, wd):
         f, w = max(F[k]), max(W.get(k, [0.0]))
         res[k] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "launches_seen": len(F[k]),
                   "hbm_bytes_per_launch": (f + w) * 1024.0}
-    # the three tiers of the chaining kernel are one stage: k_chain = their sum
-    tiers = [k for k in res if k.startswith("k_chain_wave<")]
+    # the chaining stage under its bench name (rounds 2-4: three template instances, summed)
+    tiers = [k for k in res if k.startswith("k_chain_wave")]
     if tiers:
         res["k_chain"] = {"FETCH_SIZE_KB": sum(res[k]["FETCH_SIZE_KB"] for k in tiers), "WRITE_SIZE_KB": sum(res[k]["WRITE_SIZE_KB"] for k in tiers),
                           "launches_seen": min(res[k]["launches_seen"] for k in tiers), "hbm_bytes_per_launch": sum(res[k]["hbm_bytes_per_launch"] for k in tiers)}

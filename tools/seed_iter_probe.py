@@ -53,9 +53,9 @@ for cfg in (sys.argv[1:] or [""]):
         ch = (C.c_ulonglong * 192)()
         gpu.L.bwagpu_debug_chain_hist.argtypes = [C.c_void_p, C.c_void_p]
         gpu.L.bwagpu_debug_chain_hist(gpu.h, ch)
-        for t in range(3):
+        for t in range(1):      # (rows 1-2 were the LDS tiers of rounds 2-4)
             tot = max(sum(ch[t * 64: t * 64 + 32]), 1)
-            print(f"    chaining tier {t}: {tot} reads; by chains (x16): " + " ".join(f"{b}:{ch[t * 64 + b]}" for b in range(32) if ch[t * 64 + b])
+            print(f"    chaining: {tot} reads; by chains (x16): " + " ".join(f"{b}:{ch[t * 64 + b]}" for b in range(32) if ch[t * 64 + b])
                   + " | by seeds (x32): " + " ".join(f"{b}:{ch[t * 64 + 32 + b]}" for b in range(32) if ch[t * 64 + 32 + b]), flush=True)
         x2 = (C.c_ulonglong * 8)()
         gpu.L.bwagpu_debug_seed_x2.argtypes = [C.c_void_p, C.c_void_p]
