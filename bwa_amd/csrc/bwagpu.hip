@@ -247,7 +247,8 @@ extern "C" int bwagpu_set_option(bwagpu_t *h, const char *key, long long value)
 		else if (f == &c.seed_lds_ent) ok = in(-1, 64);
 		else if (f == &c.dedup_ring) ok = value == 0 || (in(256, 4096) && (value & (value - 1)) == 0);
 		else if (f == &c.cigl_mib) ok = in(0, 1 << 20);
-		else if (f == &c.cig_tiers) ok = in(0, 2);
+		else if (f == &c.cig_tiers || f == &c.chain_regs) ok = in(0, 2);
+		else if (f == &c.chain_flt_lds) ok = in(0, CW_FLT_LDS);
 		else if (f == &c.ptab_m) ok = in(0, PTAB_MAX);
 		else if (f == &c.occ32_sb_shift) ok = in(8, 32);
 		if (!ok) return BWAGPU_EINVAL;
@@ -1093,9 +1094,10 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		hipLaunchKernelGGL(k_sa, dim3((unsigned)sa_blocks), block, 0, h->stream, h->ix, B);
 		HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_sa", hipGetErrorString(e_)); }
+		B.chain_regs = (int)cfg.chain_regs; B.chain_flt_lds = (int)(cfg.chain_flt_lds < CW_FLT_LDS ? cfg.chain_flt_lds : CW_FLT_LDS);
 		{	// wave per read, heaviest reads (most seeds) first
 			if (int rc2 = order_reads(h, B, B.seed_n)) return rc2;
-			i64 nblk = ((i64)n + 3) / 4, cap = share(256 * 7);
+			i64 nblk = ((i64)n + 3) / 4, cap = share(256 * 5);   // (5 workgroups per CU: __launch_bounds__ of k_chain_wave)
 			hipLaunchKernelGGL(k_chain_wave, dim3((unsigned)(nblk < cap ? nblk : cap)), block, (size_t)CW_LDS_BYTES * 4, h->stream, h->ix, *opt, B);
 		}
 		HIPCHK(h, hipEventRecord(h->ev[3], h->stream));

@@ -103,7 +103,7 @@ struct Counters {          // device-side bump allocators + flags
 	unsigned long long ext_fast;                   // ksw_extend2 calls answered by the diagonal rule (no DP)
 	unsigned long long bt_nodes, chain_recs;       // B-tree nodes visited by look-ups / chain records touched (k_chain's algorithmic bytes)
 	unsigned long long wave_hist[2][96];           // stats runs of k_extend_wave [0] / k_dedup_wave [1]: reads by floor(log2(time the wave spent on the read, in 10 ns units)) + 1; then, per bin, the DP calls and the DP cells (>> 10) of those reads (bwagpu_debug_hist)
-	unsigned long long chain_hist[3][32];          // stats runs of k_chain_wave: reads by min(31, chains before the filter / 16) in row 0 (rows 1-2: the tiers of rounds 2-4, now zero) (bwagpu_debug_chain_hist)
+	unsigned long long chain_hist[3][32];          // stats runs of k_chain_wave: reads by min(31, chains before the filter / 16); row 0: chained in registers, row 1: in the B-tree, row 2: 10 ns ticks by phase (CW_PHASE, dev_chainw.h) (bwagpu_debug_chain_hist)
 	unsigned long long chain_seeds[3][32];         // ... and by min(31, seeds / 32)
 	unsigned long long seed_hist[64];              // k_seed's stats instance: reads by floor(log2(iterations spent on the read)) + 1, then the iterations summed per bin (bwagpu_debug_hist)
 	unsigned long long seed_x2[8];                 // k_seed's stats instance: extension steps that read index blocks, [0] forward / [1] backward in all, [2] / [3] those on an interval of ONE row (a unique match: the step is a comparison with the next text base), [4] / [5] forward / backward runs of such steps (maximal, per search), [6] prefix-table steps (bwagpu_debug_seed_x2)
@@ -212,6 +212,8 @@ struct Batch {
 	const i32 *seedsw_minhsp;
 	// --- heavy-first processing order of the reads (k_order_*): reads binned by log2(weight), heaviest bin first, so
 	// that the few reads with thousands of seeds start first and lanes of a wave get reads of similar cost
+	int chain_flt_lds;         // chains up to which the chain filter's arrays live in LDS (<= CW_FLT_LDS)
+	int chain_regs;            // option chain_regs: 0 = every read is chained in the B-tree form, 1 = register form up to 64 chains, 2 = up to 256
 	i32 *order;                // [n_reads] permutation of read indices
 	u32 *bin_cnt;              // [2 * ORDER_BINS]: counts, then fill cursors / starts
 };

@@ -33,7 +33,11 @@ DEVFN void dev_combsort(T *a, int n, LT lt)
 	if (gap != 1) dev_insertion(a, 0, n, lt);
 }
 
-template <class T, class LT>
+// FINISH = false: without the final insertion sort; the caller finishes with any STABLE sort of what the quicksort passes leave (the insertion
+// sort is one, and the result of a stable sort does not depend on the method: a wave does it in parallel, dev_chainw.h).  Note that those passes
+// do not leave tidy blocks: the scan from the left starts at the range's SECOND element, so the first one can stay on the wrong side of the pivot
+// until the insertion sort carries it home -- the finishing sort has to be a full one.
+template <class T, class LT, bool FINISH = true>
 __device__ void dev_introsort(T *a, int n, LT lt)
 {
 	struct Frame { int l, r, d; } stack[40]; // the smaller side is iterated, the larger pushed: depth <= log2 n
@@ -70,5 +74,5 @@ __device__ void dev_introsort(T *a, int n, LT lt)
 			--top; s = stack[top].l; t = stack[top].r; d = stack[top].d;
 		}
 	}
-	dev_insertion(a, 0, n, lt);
+	if (FINISH) dev_insertion(a, 0, n, lt);
 }

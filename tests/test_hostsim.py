@@ -561,21 +561,51 @@ def heavy_case():
     pick = list(top[:2]) + [int(top[i]) for i in np.argsort(n_kept)[::-1][:2]]
     assert n_chains[pick[0]] > 200 and n_kept.max() > 100, (n_chains[top], n_kept)
     mid = [int(i) for i in np.nonzero((n_chains >= 36) & (n_chains <= 60))[0][:2]]    # a few dozen chains: B-trees of two levels
-    assert len(mid) == 2
-    reads = np.concatenate([cand[pick[:1]], cand[pick[2:3]], cand[mid], cand[:1]])      # most chains, most kept chains, two middling ones, an ordinary read
+    mid += [int(i) for i in np.nonzero((n_chains >= 70) & (n_chains <= 250))[0][:2]]  # more than one lane-array of chains, fewer than four
+    assert len(mid) == 4, np.sort(n_chains)[::-1][:40]
+    # Reads that put two chains on the same reference position (duplicate keys in the chain tree): a stretch of the genome, more than the band width of
+    # other sequence, and the same stretch again -- the second copy's seeds start where the first copy's chains do and cannot join them (bwamem.c:229).
+    rng = np.random.default_rng(11)
+    L = cand.shape[1]
+    twice, few, many = [], False, False
+    for p0 in rng.integers(0, g.shape[0] - 200, size=60):
+        rd = np.concatenate([g[p0:p0 + 40], rng.integers(0, 4, size=L - 80).astype(np.uint8), g[p0:p0 + 40]])
+        if (rd > 3).any():
+            continue
+        hdr = orc.chains(opt, rd, 0)[0]
+        dup = hdr.shape[0] > np.unique(hdr["pos"]).shape[0]
+        if dup and hdr.shape[0] <= 9 and not few:
+            few = True; twice.append(rd)
+        elif dup and 9 < hdr.shape[0] <= 64 and not many:
+            many = True; twice.append(rd)
+    assert few and many, "no read with two chains on one position found (in a one-node tree, in a larger one)"
+    reads = np.concatenate([cand[pick[:1]], cand[pick[2:3]], cand[mid], cand[:1], np.stack(twice)])   # most chains, most kept chains, four middling ones, an ordinary read, duplicate keys
     yield fa, orc, reads
     orc.close()
 
 
-def test_hostsim_wave_chaining_heavy_reads(monkeypatch, heavy_case):
-    """k_chain_wave on reads with many chains (repeat-rich genome): multi-level B-trees with splits, duplicate keys, the root node cached in
-    registers across look-ups and insertions, the 64-wide chain filter and the flattening of hundreds of chains must reproduce the oracle's chains exactly."""
+@pytest.mark.parametrize("regs,flt_lds", [(2, 256), (1, 256), (0, 256), (2, 0), (2, 40)])
+def test_hostsim_wave_chaining_heavy_reads(monkeypatch, heavy_case, regs, flt_lds):
+    """k_chain_wave on reads with many chains (repeat-rich genome).  Register form (chains one per lane, exact for distinct positions and for one-node
+    trees): lane shifts on insertion, kbtree's rules for equal positions, the hand-over to the tree form at the 65th chain or at a duplicate position in a
+    larger tree.  Tree form (all of it with chain_regs = 0): multi-level B-trees with splits, duplicate keys, the root node cached in registers across
+    look-ups and insertions.  Then the weight sort (quicksort passes by one lane, the stable finish by all), the 64-wide chain filter with its arrays in LDS
+    or (chain_flt_lds below a read's chain count) in the read's HBM region, and the flattening of hundreds of chains.  All must reproduce the oracle's chains exactly."""
+    import ctypes as C
     fa, orc, reads = heavy_case
     opt = default_opt()
-    s2 = sim_handle(fa)
+    s2 = sim_handle(fa, chain_regs=regs, chain_flt_lds=flt_lds)
     s2.set_taps(True); s2.set_stats(True)
     seqs, off = testdata.flat(reads)
     c, r = s2.align(opt, seqs, off)
+    hist = (C.c_ulonglong * 192)()
+    s2.L.bwagpu_debug_chain_hist.argtypes = [C.c_void_p, C.c_void_p]
+    assert s2.L.bwagpu_debug_chain_hist(s2.h, hist) == 0
+    in_regs, in_tree = sum(hist[0:32]), sum(hist[64:96])
+    assert in_regs + in_tree == reads.shape[0]
+    assert (in_regs >= 4 and in_tree >= 2) if regs else in_regs == 0, (in_regs, in_tree)
+    wide = sum(hist[4:32])           # reads that finished in the register form with 64 chains or more: the four-array form
+    assert wide >= 2 if regs == 2 else wide == 0, list(hist[0:32])
     cn, ch, cs = s2.tap_chains()
     kc = ks = 0
     for i, rd in enumerate(reads):

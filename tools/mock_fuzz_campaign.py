@@ -20,6 +20,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 DP_SETS = [{}, {"dedup_blk": 0}, {"seedsw_lds": 0}]
 OPT_SETS = [
     {},
+    {"chain_regs": 0},
+    {"chain_regs": 1},
     {"seed_mrg": 0},
     {"seed_mrg": 2, "seed_lds_ent": 2},
     {"seed_budget": 150, "seed_p2_cap": 2},

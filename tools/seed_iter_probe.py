@@ -53,10 +53,14 @@ for cfg in (sys.argv[1:] or [""]):
         ch = (C.c_ulonglong * 192)()
         gpu.L.bwagpu_debug_chain_hist.argtypes = [C.c_void_p, C.c_void_p]
         gpu.L.bwagpu_debug_chain_hist(gpu.h, ch)
-        for t in range(1):      # (rows 1-2 were the LDS tiers of rounds 2-4)
+        for t in range(2):      # row 0: reads chained in registers, row 1: in the B-tree
             tot = max(sum(ch[t * 64: t * 64 + 32]), 1)
-            print(f"    chaining: {tot} reads; by chains (x16): " + " ".join(f"{b}:{ch[t * 64 + b]}" for b in range(32) if ch[t * 64 + b])
+            print(f"    chaining, {('register form', 'tree form')[t]}: {tot} reads; by chains (x16): " + " ".join(f"{b}:{ch[t * 64 + b]}" for b in range(32) if ch[t * 64 + b])
                   + " | by seeds (x32): " + " ".join(f"{b}:{ch[t * 64 + 32 + b]}" for b in range(32) if ch[t * 64 + 32 + b]), flush=True)
+        ph = [ch[128 + i] for i in range(9)]
+        names = ["register-form seed loop", "tree-form seed loop", "repeat fraction + in-order list", "weights", "sort", "pairwise filter", "publishing"]
+        tot = max(sum(ph[:7]), 1)
+        print("    chaining, wave time by phase: " + ", ".join(f"{nm} {100.0 * v / tot:.1f}%" for nm, v in zip(names, ph)) + f"; {tot / 1e5:.1f} wave-ms in all over {ph[8]} reads that kept chains past the weight filter, longest read {ph[7] / 100.0:.0f} us", flush=True)
         x2 = (C.c_ulonglong * 8)()
         gpu.L.bwagpu_debug_seed_x2.argtypes = [C.c_void_p, C.c_void_p]
         gpu.L.bwagpu_debug_seed_x2(gpu.h, x2)
