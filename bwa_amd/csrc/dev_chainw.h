@@ -235,6 +235,9 @@ DEVFN int chain_seeds_lanes(const DevIndex &ix, const bwagpu_opt_t &opt, int ns,
 	int lane, u32 &recs, ChainLanes (&K)[CL_SLOTS], int &n_ch, bool &has_dup, int &s_next)
 {
 	const i64 l_pac = ix.l_pac;
+	u64 m_in[KS];                                                    // the lanes of each array that hold a chain
+#pragma unroll
+	for (int j = 0; j < KS; ++j) { const int nj = n_ch - 64 * j; m_in[j] = nj >= 64 ? ~0ull : nj > 0 ? (1ull << nj) - 1 : 0ull; }
 	for (int base = s_next & ~63; base < ns; base += 64) {
 		const int li_ = base + lane;
 		i64 v_rbeg = 0; int v_qb = 0, v_len = 0, v_rid = -1;
@@ -246,18 +249,14 @@ DEVFN int chain_seeds_lanes(const DevIndex &ix, const bwagpu_opt_t &opt, int ns,
 			if (rid < 0) continue;
 			const int qbeg = __builtin_amdgcn_readlane(v_qb, t), slen = __builtin_amdgcn_readlane(v_len, t);
 			const i64 rbeg = readlane_i64(v_rbeg, t);
-			// lower bound: the number of smaller keys; eq: the key at that place equals rbeg
-			int lo = 0; u64 m_eq[KS];
+			// lower bound: the number of smaller keys; eq: the key at that place equals rbeg -- the array is sorted, so that is the case when any key does
+			int lo = 0; u64 any_eq = 0;
 #pragma unroll
 			for (int j = 0; j < KS; ++j) {
-				const int nj = n_ch - 64 * j;
-				const u64 m_in = nj >= 64 ? ~0ull : nj > 0 ? (1ull << nj) - 1 : 0ull;
-				lo += __popcll(wave_ballot(K[j].pos < rbeg) & m_in);
-				m_eq[j] = wave_ballot(K[j].pos == rbeg) & m_in;
+				lo += __popcll(wave_ballot(K[j].pos < rbeg) & m_in[j]);
+				any_eq |= wave_ballot(K[j].pos == rbeg) & m_in[j];
 			}
-			bool eq = false;
-#pragma unroll
-			for (int j = 0; j < KS; ++j) if ((lo >> 6) == j) eq = (m_eq[j] >> (lo & 63)) & 1;
+			const bool eq = any_eq != 0;
 			const int li = eq ? lo : lo - 1;                             // the chain kb_intervalp hands to test_and_merge (-1: none)
 			// test_and_merge (bwamem.c:216-237): the lanes of the chain's slot on their own chains, lane li % 64's answer counts
 			bool hit = false;
@@ -268,11 +267,13 @@ DEVFN int chain_seeds_lanes(const DevIndex &ix, const bwagpu_opt_t &opt, int ns,
 				const bool me = lane == (li & 63) && li >= 0;
 				const int c_fqb = (int)(C.a & 0xffff), c_lqb = (int)(C.a >> 16), c_ll = (int)(C.b & 0xffff);
 				const i64 c_lrb = C.pos + (i64)C.d;
-				const i64 qend = c_lqb + c_ll, rend = c_lrb + c_ll;
+				const int qend = c_lqb + c_ll; const i64 rend = c_lrb + c_ll;
 				const bool contained = qbeg >= c_fqb && qbeg + slen <= qend && rbeg >= C.pos && rbeg + slen <= rend;
-				const bool strand = (c_lrb < l_pac || C.pos < l_pac) && rbeg >= l_pac;
-				const i64 x = qbeg - c_lqb, y = rbeg - c_lrb;
-				const bool fits = y >= 0 && x - y <= opt.w && y - x <= opt.w && x - c_ll < opt.max_chain_gap && y - c_ll < opt.max_chain_gap;
+				const bool strand = C.pos < l_pac && rbeg >= l_pac;      // (bwamem.c:227 also asks last_rbeg < l_pac: implied, last_rbeg >= pos)
+				// bwamem.c:229: y >= 0, |x - y| <= w, x - last_len < max_chain_gap, y - last_len < max_chain_gap.  x is a difference of read offsets; a y that does
+				// not fit 30 bits fails y - x <= w (the caller's check: w < 2^30 - 2^16), so from there on 32-bit arithmetic is exact
+				const int x = qbeg - c_lqb; const i64 y64 = rbeg - c_lrb; const int y = (int)y64;
+				const bool fits = (u64)y64 < (1ull << 30) && x - y <= opt.w && y - x <= opt.w && x - c_ll < opt.max_chain_gap && y - c_ll < opt.max_chain_gap;
 				const bool mine = me && rid == C.rid;
 				const bool hit_c = mine && contained, hit_m = mine && !contained && !strand && fits;
 				if (hit_m) {
@@ -287,6 +288,8 @@ DEVFN int chain_seeds_lanes(const DevIndex &ix, const bwagpu_opt_t &opt, int ns,
 			if (n_ch >= BT_MAXK && (has_dup || eq)) return -1;
 			if (n_ch == 64 * KS) { s_next = s; return 1; }
 			has_dup = has_dup || eq;
+#pragma unroll
+			for (int j = 0; j < KS; ++j) if ((n_ch >> 6) == j) m_in[j] |= 1ull << (n_ch & 63);
 			const int p = li + 1;
 			const u32 new_a = (u32)qbeg | (u32)qbeg << 16, new_b = (u32)slen | 0x10000u, new_c = (u32)s | (u32)s << 16;
 #pragma unroll
@@ -370,7 +373,7 @@ __device__ void chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 	long long t_ph = B.stats ? wall_clock64() : 0; const long long t_read = t_ph;
 	u32 visits = 0, recs = 0;
 	// (the register form packs seed slots, read offsets and seed counts into 16 bits and a chain's reference span into 32)
-	const bool packs = len < 65536 && ns < 65536 && (i64)ns * ((i64)opt.w + 1) + 65536 < (1ll << 31);
+	const bool packs = len < 65536 && ns < 65536 && opt.w < (1 << 30) - 65536 && (i64)ns * ((i64)opt.w + 1) + 65536 < (1ll << 31);
 	int n_ch = B.chain_regs <= 0 || !packs ? -1 : chain_seeds_regs(ix, opt, ns, pos, sqb, sln, srid, next, ch, ord, lane, recs, B.chain_regs);
 	const bool tree = n_ch < 0;
 	CW_PHASE(0);
@@ -478,8 +481,10 @@ __device__ void chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 			oi = ord[i];
 			ChainRec &c = ch[oi];
 			// mem_chain_weight (bwamem.c:239-258): the query-side and the reference-side coverage, one walk along the chain for both
+			// (a chain of one seed weighs the seed's length: no walk -- in repeat-rich reads, where the chains are many, most are such)
 			i64 end = 0, rend = 0; int wq = 0, w = 0;
-			for (int s = c.first; s >= 0; ) {
+			if (c.n == 1) wq = w = c.last_len;
+			else for (int s = c.first; s >= 0; ) {
 				const int qb = sqb[s], sl = sln[s]; const i64 rb = pos[s];
 				s = next[s];
 				if (qb >= end) wq += sl; else if (qb + sl > end) wq += (int)(qb + sl - end);
@@ -611,7 +616,11 @@ __device__ void chain_read_wave(const DevIndex &ix, const bwagpu_opt_t &opt, con
 			h.n_seeds = c.n; h.rid = c.rid; h.w = c.w; h.kept = kp; h.is_alt = c.is_alt; h.frac_rep = frac_rep; h.pos = c.pos;
 			oc[my_k] = h;
 			int m = my_m;
-			for (int s = c.first; s >= 0; s = next[s]) {
+			if (c.n == 1) {                                    // the record says all there is to say about its one seed
+				bwagpu_seed_t sd;
+				sd.rbeg = c.pos; sd.qbeg = c.first_qbeg; sd.len = c.last_len; sd.score = sd.len; sd.pad_ = 0;
+				os[m] = sd;
+			} else for (int s = c.first; s >= 0; s = next[s]) {
 				bwagpu_seed_t sd;
 				sd.rbeg = pos[s]; sd.qbeg = sqb[s]; sd.len = sln[s]; sd.score = sd.len; sd.pad_ = 0;
 				os[m++] = sd;
