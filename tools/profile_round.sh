@@ -12,7 +12,7 @@ B="python bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline --no-e2e -
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- $B > $out/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- $B > $out/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- $B > $out/write.log 2>&1
-python tools/pmc_summary.py "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes on: $B (500 k pairs of 2x150 bp vs the 3.1 Gbp stand-in, dense SA 4); per launch; bytes = (FETCH_SIZE + WRITE_SIZE) KiB * 1024; Infinity-Cache hits are included" $out/fetch $out/write $out/pmc.json
+python tools/pmc_summary.py "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes on: $B (500 k pairs of 2x150 bp vs the 3.1 Gbp stand-in, full SA); per launch; bytes = (FETCH_SIZE + WRITE_SIZE) KiB * 1024; Infinity-Cache hits are included" $out/fetch $out/write $out/pmc.json
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/sq -o s -- $B > $out/sq.log 2>&1
 python tools/sq_summary.py $out/sq $out/sq_counters.md "solo batch of 1 M reads (500 k pairs of 2x150 bp) vs the 3.1 Gbp stand-in; $B"
 find $out -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
