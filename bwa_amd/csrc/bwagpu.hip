@@ -901,6 +901,12 @@ extern "C" int bwagpu_batch_reserve(bwagpu_t *h, int n_reads, int64_t n_bases, i
 	const i64 tot = (i64)n_reads * 4;        // (packed results: ~3.2 regions per read on a repeat-rich genome)
 	bad |= h->d_pack_off.ensure((size_t)n_reads * 8); bad |= h->d_regs_packed.ensure((size_t)tot * sizeof(bwagpu_alnreg_t)); bad |= h->d_pack_read.ensure((size_t)tot * 4);
 	bad |= h->d_cigs.ensure((size_t)tot * sizeof(bwagpu_cigar_t)); bad |= h->d_cig_ext.ensure((size_t)(tot * 4 + 65536) * 4);
+	// ... and the page-locked blocks its results will be copied into (regions, CIGAR records, operation array: ~0.4 GB per 667 k reads; page-locking costs
+	// more than the copy -- ~0.2 ms per MB -- and the pool keeps what it is given back, so the handle's first batch finds them)
+	if (h->cfg.reserve_results) {
+		void *r0 = result_alloc((size_t)tot * sizeof(bwagpu_alnreg_t)), *r1 = result_alloc((size_t)tot * sizeof(bwagpu_cigar_t)), *r2 = result_alloc((size_t)tot * 2 * 4);
+		bwagpu_free(r0); bwagpu_free(r1); bwagpu_free(r2);
+	}
 	h->n_reads = n0; h->n_bases = b0; h->max_len = m0; h->have_batch = have0; h->ran = ran0;
 	h->slot_cap = sc0; h->node_cap = nc0; h->reg_cap = rc0; h->mem_cap = mc0;
 	if (bad) { h->err = "hipMalloc failed (reserve)"; return BWAGPU_ENOMEM; }

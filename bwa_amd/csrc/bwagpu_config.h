@@ -50,6 +50,7 @@
 	X(cigl_mib,          32768)/* CIGAR stage: scratch budget of that tier in MiB (32 GiB: 1024 direction matrices of a 10 kb read's widest band)                                                                      */ \
 	X(cig_trace,         0)    /* CIGAR stage: print the launches' times (waits for the stream after each)                                              */ \
 	X(debug_sync,        0)    /* wait and report after every stage of bwagpu_batch_run                                                                 */ \
+	X(reserve_results,   1)    /* bwagpu_batch_reserve also page-locks the result blocks of a batch of that shape (0: the first download does; A/B)      */ \
 	X(pinned_results,    1)    /* PROCESS-WIDE (the result pool is shared by all handles): large results in pooled page-locked blocks (0: plain malloc)  */ \
 	X(pinned_min_kb,     1024) /* PROCESS-WIDE: results below this size come from malloc (tests: 0 pools everything)                                    */
 

@@ -796,7 +796,7 @@ template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwa
 	const i64 qoff = uni64(B.off[r]);
 	const u8 *query = B.seq + qoff;
 	int l_query = uni((int)(B.off[r + 1] - qoff));
-	i64 so = uni64(B.seed_off[r]), l_pac = ix.l_pac;
+	i64 so = uni64(B.seed_off[r]);
 	const RegionView R = region_of(B.slot_blob, so, uni(B.seed_n[r]));
 	const bwagpu_chain_t *chains = R.cchain;
 	const bwagpu_seed_t *seeds_all = R.cseed;

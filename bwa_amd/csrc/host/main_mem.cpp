@@ -932,6 +932,7 @@ int main(int argc, char *argv[])
 	const int chunk = fixed_chunk > 0 ? fixed_chunk : opt.chunk_size * opt.n_threads;
 	const bool long_preset = mode && (strcmp(mode, "pacbio") == 0 || strcmp(mode, "pbref") == 0 || strcmp(mode, "ont2d") == 0);
 	const double t_start = now_s(), cpu_start = process_cpu_s();
+	const bool tl_trace = getenv("BWAGPU_CLI_TRACE") != nullptr;      // (with the other trace lines: when each stage held each batch, seconds since here)
 	if (getenv("BWAGPU_CLI_PARSE_ONLY")) {   // diagnostics: speed of the input stage alone
 		Batch b; long n = 0, bp = 0;
 		const bool dump = atoi(getenv("BWAGPU_CLI_PARSE_ONLY")) == 2;      // (tests: what the input stage delivers, batch by batch)
@@ -1049,6 +1050,7 @@ int main(int argc, char *argv[])
 			}
 			n_processed += n; ++no; ++progress;
 			busy_read += now_s() - tr;
+			if (tl_trace) fprintf(stderr, "[D::timeline] batch %ld read %.3f .. %.3f\n", no - 1, tr - t_start, now_s() - t_start);
 			to_enc.push(std::move(w));
 		}
 		n_works = no; n_reads_total = (long)(n_processed - n_processed0);
@@ -1069,6 +1071,7 @@ int main(int argc, char *argv[])
 			}
 			busy_enc += now_s() - te;
 			++progress;
+			if (tl_trace) fprintf(stderr, "[D::timeline] batch %ld encode %.3f .. %.3f\n", w->no, te - t_start, now_s() - t_start);
 			to_dev.push(std::move(w));
 		}
 		cpu_enc = thread_cpu_s();
@@ -1091,7 +1094,9 @@ int main(int argc, char *argv[])
 			{ std::unique_lock<std::mutex> l(dm); dcv.wait(l, [&] { return w->no - next_fin <= (long)n_work; }); }   // do not run ahead of the host
 			if (d < 16) dev_no[d] = (int)w->no;
 			++progress;
+			const double td = now_s();
 			for (Sub &u : w->subs) { device_sub(workers[(size_t)d], u, ref, pes0); ++progress; busy_dev_us += (long)(u.t_dev * 1e6); }
+			if (tl_trace) fprintf(stderr, "[D::timeline] batch %ld device %.3f .. %.3f (slot %d)\n", w->no, td - t_start, now_s() - t_start, d);
 			std::lock_guard<std::mutex> l(dm);
 			const long no = w->no;
 			done[no] = std::move(w);
@@ -1120,6 +1125,7 @@ int main(int argc, char *argv[])
 		if (!w->by_read) { std::lock_guard<std::mutex> l(pool_m); if (!out_pool.empty()) { w->out = std::move(out_pool.back()); out_pool.pop_back(); } }
 		for (Sub &u : w->subs) finalize_sub(ref, *w, u, pes0, rg_id.c_str(), copy_comment != 0);
 		busy_fin += now_s() - tf;
+		if (tl_trace) fprintf(stderr, "[D::timeline] batch %ld finalize %.3f .. %.3f\n", w->no, tf - t_start, now_s() - t_start);
 		{
 			std::lock_guard<std::mutex> l(pool_m);
 			w->in.blocks.clear();                 // (the parsed blocks go back to their pool now, not when the batch is next used)

@@ -50,6 +50,10 @@ def main():
                     print("[e2e]    " + m2.group(0), flush=True)
                 steps = re.findall(r"upload ([\d.]+) run ([\d.]+) download\+cigars ([\d.]+) pestat\+matesw ([\d.]+) s", p.stderr)
                 after = re.findall(r"after the hot path, ms: pack ([\d.]+) download copy ([\d.]+) cigar kernels ([\d.]+) cigar copies ([\d.]+)", p.stderr)
+                for ln in re.findall(r"\[D::device_sub\] \d+ reads.*", p.stderr)[:6]:
+                    print("[e2e]    " + ln, flush=True)
+                for ln in re.findall(r"\[D::timeline\].*", p.stderr):
+                    print("[e2e]    " + ln, flush=True)
                 for ln in re.findall(r"\[D::device_sub\] stage ms:.*", p.stderr):
                     print("[e2e]    " + ln, flush=True)
                 if after:
