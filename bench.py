@@ -182,7 +182,15 @@ def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: 
     if after and dev_ms:      # download_cigars split by the library's own HIP events (kernels vs copies), averaged over the batches
         for k_, name in enumerate(("pack_kernel", "download_copy", "cigar_kernels", "cigar_copies")):
             dev_ms[name] = round(sum(float(a_[k_]) for a_ in after) / len(after), 1)
-    return {"reads_per_s": float(m.group(3)), "n": n_reads, "wall_s": wall, "stages": busy.group(1) if busy else "", "stage_us_per_read": stage_us, "handles": int(hm.group(1)) if hm else None, "device_stage_ms_per_batch": dev_ms,
+    # when the batches left the device stage (the program's timeline trace): past the pipeline's fill, one full-size batch every `gap` seconds
+    steady = None
+    ends = sorted(float(x) for x in re.findall(r"\[D::timeline\] batch \d+ device [\d.]+ \.\. ([\d.]+)", p.stderr))
+    if len(ends) >= 8 and dev_ms.get("reads_per_batch"):
+        body = ends[3:-1]          # (after the handles' first batches; the last batch is short)
+        gap = (body[-1] - body[0]) / (len(body) - 1)
+        steady = {"Mreads_s": round(dev_ms["reads_per_batch"] / gap / 1e6, 3), "ms_per_batch": round(gap * 1e3, 1), "first_batch_out_s": round(ends[0], 3),
+                  "what": "full-size batches leaving the device stage between the pipeline's fill and its drain (time between the 4th and the last full batch / batches): the rate a longer input approaches; `value` is the whole run including fill and drain"}
+    return {"reads_per_s": float(m.group(3)), "n": n_reads, "wall_s": wall, "stages": busy.group(1) if busy else "", "stage_us_per_read": stage_us, "handles": int(hm.group(1)) if hm else None, "device_stage_ms_per_batch": dev_ms, "steady_state": steady,
             "n_batches": len(re.findall(r"\[M::process\] read \d+ sequences", p.stderr)), "retries": sum(retries) if retries else 0, "cpu_us_per_read": cpu_us}
 
 
@@ -277,7 +285,7 @@ def main():
     ap.add_argument("--long-sample", type=int, default=2000, help="reads of the long-read CPU-baseline / parity prefix (the reference does ~200 reads/s on 16 threads: ~10 s); "
                     "the product aligns them in >= 9 batches, three per device handle")
     ap.add_argument("--e2e-handles", type=int, default=5, help="a second FASTQ->SAM run of the paired-end sample with this many batches in flight (BWAGPU_CLI_STREAMS; the default run uses 3); 0 = skip")
-    ap.add_argument("--variants", default="seed_mrg=0;ext_occ=4;seed_budget=4096;seed_budget=16384;chain_regs=0", help="';'-separated library option settings (bwagpu_set_option names) to A/B against the defaults in a child process (tools/variant_probe.py); '' = none")
+    ap.add_argument("--variants", default="seed_mrg=0;ext_occ=4;chain_regs=0;chain_regs=1", help="';'-separated library option settings (bwagpu_set_option names) to A/B against the defaults in a child process (tools/variant_probe.py); '' = none")
     ap.add_argument("--timed-sample", type=int, default=20000, help="reads of timed batch 0 whose regions are compared with the compiled reference's mem_align1_core (parity.timed_batch); 0 = skip")
     ap.add_argument("--instr-pairs", type=int, default=30000, help="pairs the counter-instrumented reference runs on (b_alg_per_read)")
     ap.add_argument("--variants-timeout", type=float, default=70.0, help="seconds for the short-read child process (the long-read one gets 0.8 of it)")
@@ -601,7 +609,7 @@ def main():
             e2e = run_product(prefix, [f1, f2], threads, None, devices=devices)
             if e2e:
                 out["end_to_end_pe"] = {"value": round(e2e["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "n_gpus": world, "stages": e2e["stages"], "stage_us_per_read": e2e["stage_us_per_read"],
-                                        "device_stage_ms_per_batch": e2e["device_stage_ms_per_batch"], "handles": e2e["handles"], "retries": e2e["retries"], "cpu_us_per_read": e2e["cpu_us_per_read"],
+                                        "device_stage_ms_per_batch": e2e["device_stage_ms_per_batch"], "steady_state": e2e.get("steady_state"), "handles": e2e["handles"], "retries": e2e["retries"], "cpu_us_per_read": e2e["cpu_us_per_read"],
                                         "what": f"`bwa-amd mem -t {threads}` on {n_e // 2} pairs as two FASTQ files (the BASELINE metric's layout, SAM discarded; the same command's SAM is what parity.pe compares): parsing + H2D + "
                                                 f"device hot path + device CIGARs and mate-rescue alignments + D2H + mem_pestat/pairing/SAM text on the host, batches of 100 Mbp"
                                                 + (f", every batch split over devices {devices} (BWAGPU_DEVICES)" if world > 1 else "") + "; wall time after the index is loaded"}

@@ -372,7 +372,8 @@ void bwagpu_trim(void);
  * already resident in HBM: upload -> run (device only, asynchronous kernels + one final sync) -> download. */
 int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, const int64_t *off);
 /* Optional, any time: allocate the device buffers a batch of about this shape will need (they are only ever grown), so that the handle's
- * first batch does not pay for them inside a pipeline. */
+ * first batch does not pay for them inside a pipeline.  Unless option reserve_results is 0 it also page-locks the result blocks of such a batch
+ * (about 150 bytes per region at 4 regions per read) and hands them to the pool bwagpu_free() feeds, where the batch's downloads find them. */
 int bwagpu_batch_reserve(bwagpu_t *h, int n_reads, int64_t n_bases, int max_len);
 int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt);
 int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg_t **regs_out, int64_t *n_regs_out);
