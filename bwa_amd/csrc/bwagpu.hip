@@ -65,6 +65,7 @@ struct bwagpu_s {
 	DevIndex ix = {};
 	struct IndexBufs {
 		DevBuf d_bwt, d_sa, d_pac, d_ctg_off, d_ctg_len, d_ctg_alt, d_ptab, d_occ32, d_occ_sb; std::atomic<int> refs{1};
+		std::atomic<int> busy{0};      // handles on this index that are inside a call that launches kernels (share auto)
 		// per-base arena needs learnt by any handle on this index (a re-run for arena growth doubles a batch's device time, so a
 		// cloned handle should not have to learn them again); written and read under `m`
 		std::mutex m; double need_slot = 0, need_node = 0, need_reg = 0; int need_mem = 0;
@@ -913,9 +914,11 @@ extern "C" int bwagpu_batch_reserve(bwagpu_t *h, int n_reads, int64_t n_bases, i
 	return BWAGPU_OK;
 }
 
+namespace { struct BusyGuard { std::atomic<int> &c; int others; explicit BusyGuard(std::atomic<int> &c_) : c(c_), others(c_.fetch_add(1)) {} ~BusyGuard() { --c; } }; }
 extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 {
 	if (!h || !opt || !h->have_batch) return BWAGPU_EINVAL;
+	const BusyGuard busy(h->ibuf->busy);
 	if (opt->e_del <= 0 || opt->e_ins <= 0 || opt->max_occ <= 0 || opt->min_seed_len <= 0 || opt->w < 0) return BWAGPU_EINVAL;
 	HIPCHK(h, hipSetDevice(h->device));
 	memset(&h->stats, 0, sizeof h->stats);
@@ -943,9 +946,10 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 	// batches in flight take turns; launched for a share, kernels of different batches -- the memory-bound seeding of one, the issue-bound
 	// extension of another -- run side by side.
 	// auto (-1): half the chip per kernel when at least three handles share this index -- three batches in flight, the way `bwa-amd mem` and the bench's timed loop
-	// drive a device -- else all of it.  Measured with three batches in flight (profiles/r05_share_ab.log): 108.3 ms per step at 100, 105.2-105.7 at 50 (105.1 at 40,
+	// drive a device -- and another of them has kernels in flight as this run starts; else all of it (a lone handle; the first batch of a pipeline, which has
+	// the chip to itself while the reader is still parsing the second: 151 -> ~90 ms, `profiles/r05_e2e_reserve_results.log`).  Measured with three batches in flight (profiles/r05_share_ab.log): 108.3 ms per step at 100, 105.2-105.7 at 50 (105.1 at 40,
 	// 107.1 at 60), i.e. -2.7 %, for +10 % on a batch that has the chip to itself (131.8 -> 144.8 ms) -- round 4 measured nothing; the kernels' balance has moved.
-	const long long share_pct = cfg.share >= 0 ? cfg.share : (h->ibuf->refs.load() >= 3 ? 50 : 100);
+	const long long share_pct = cfg.share >= 0 ? cfg.share : (h->ibuf->refs.load() >= 3 && busy.others > 0 ? 50 : 100);
 	auto share = [&](long long g) { if (long_batch || share_pct >= 100 || share_pct <= 0) return g; const long long v = g * share_pct / 100; return v < 1 ? 1ll : v; };
 	auto pick = [&](long long v, long long dflt_long) { return v >= 0 ? v : (long_batch ? dflt_long : 0); };
 	// Pass 1 of long-read batches as independent tasks (option seed_tasks; dev_seed.h, k_seed's LR): one task per read and min_seed_len-th
@@ -1300,6 +1304,7 @@ extern "C" int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg
 extern "C" int bwagpu_batch_cigars(bwagpu_t *h, const bwagpu_opt_t *opt, bwagpu_cigar_t **out, int64_t *n_out)
 {
 	if (!h || !opt || !h->ran || h->packed_tot < 0 || !out || !n_out) return BWAGPU_EINVAL;
+	const BusyGuard busy(h->ibuf->busy);
 	if (opt->e_del <= 0 || opt->e_ins <= 0) return BWAGPU_EINVAL;
 	HIPCHK(h, hipSetDevice(h->device));
 	const i64 tot = h->packed_tot;
@@ -1440,6 +1445,7 @@ extern "C" int bwagpu_batch_matesw(bwagpu_t *h, const bwagpu_opt_t *opt, const b
 {
 	if (!h || !opt || !pes || !h->ran || h->packed_tot < 0 || !out || !n_out) return BWAGPU_EINVAL;
 	if (opt->e_del <= 0 || opt->e_ins <= 0 || (h->n_reads & 1)) return BWAGPU_EINVAL;
+	const BusyGuard busy(h->ibuf->busy);
 	static_assert(sizeof(bwagpu_matesw_t) == 56 && sizeof(MateTask) == 24 && sizeof(bwagpu_pes_t) == 16, "layout");
 	HIPCHK(h, hipSetDevice(h->device));
 	const int n = h->n_reads;
