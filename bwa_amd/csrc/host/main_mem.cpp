@@ -244,7 +244,7 @@ struct Reader {
 	}
 };
 
-// ---- block-parallel input (BWAGPU_CLI_PARSE_THREADS=N; default 4 when the batches are split over several devices) ---------------
+// ---- block-parallel input (BWAGPU_CLI_PARSE_THREADS=N; default 4) ---------------
 // One thread parses ~8 M records per second; one MI355X takes half of that, a node of eight needs four times it.  A plain FASTQ file is
 // therefore read in blocks that end on a record boundary, the blocks are parsed by a pool of threads (parse_fast_record, the streaming
 // reader's own fast path) into arenas of their own, and the batch builder copies finished records out in file order -- one memcpy per
@@ -910,9 +910,10 @@ int main(int argc, char *argv[])
 		}
 	}
 
-	// input: BWAGPU_CLI_PARSE_THREADS parser threads for plain FASTQ files (0: the streaming reader alone; the default when one device takes the batches)
-	int n_devices_env = 1; if (const char *dl = getenv("BWAGPU_DEVICES")) for (const char *q = dl; *q; ++q) if (*q == ',') ++n_devices_env;
-	const int n_parse = getenv("BWAGPU_CLI_PARSE_THREADS") ? atoi(getenv("BWAGPU_CLI_PARSE_THREADS")) : (n_devices_env > 1 ? 4 : 0);
+	// input: BWAGPU_CLI_PARSE_THREADS parser threads for plain FASTQ files (0: the streaming reader alone).  Default 4 -- since round 5 for one device as well:
+	// its device stage lets a 667 k-read batch go every 79 ms and the streaming reader delivers one every 71-77, so every hiccup of the reader was the device's;
+	// with the blocks parsed by four threads the reader holds a batch 39-55 ms (6 M pairs: 5.67 / 5.83 -> 6.26 Mreads/s, profiles/r05_e2e_reserve_results.log)
+	const int n_parse = getenv("BWAGPU_CLI_PARSE_THREADS") ? atoi(getenv("BWAGPU_CLI_PARSE_THREADS")) : 4;
 	std::unique_ptr<ParPool> parse_pool(n_parse > 0 ? new ParPool(n_parse) : nullptr);
 	Source r1, r2; Source *pr2 = nullptr;
 	if (!r1.open(argv[optind + 1], parse_pool.get())) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", "main_mem", argv[optind + 1]); return 1; }
