@@ -182,16 +182,23 @@ def run_product(prefix: str, files, threads: int, out_sam: str | None, streams: 
     if after and dev_ms:      # download_cigars split by the library's own HIP events (kernels vs copies), averaged over the batches
         for k_, name in enumerate(("pack_kernel", "download_copy", "cigar_kernels", "cigar_copies")):
             dev_ms[name] = round(sum(float(a_[k_]) for a_ in after) / len(after), 1)
-    # when the batches left the device stage (the program's timeline trace): past the pipeline's fill, one full-size batch every `gap` seconds
-    steady = None
-    ends = sorted(float(x) for x in re.findall(r"\[D::timeline\] batch \d+ device [\d.]+ \.\. ([\d.]+)", p.stderr))
-    if len(ends) >= 8 and dev_ms.get("reads_per_batch"):
-        body = ends[3:-1]          # (after the handles' first batches; the last batch is short)
-        gap = (body[-1] - body[0]) / (len(body) - 1)
-        steady = {"Mreads_s": round(dev_ms["reads_per_batch"] / gap / 1e6, 3), "ms_per_batch": round(gap * 1e3, 1), "first_batch_out_s": round(ends[0], 3),
-                  "what": "full-size batches leaving the device stage between the pipeline's fill and its drain (time between the 4th and the last full batch / batches): the rate a longer input approaches; `value` is the whole run including fill and drain"}
+    steady = steady_state_from_trace(p.stderr, dev_ms.get("reads_per_batch"))
     return {"reads_per_s": float(m.group(3)), "n": n_reads, "wall_s": wall, "stages": busy.group(1) if busy else "", "stage_us_per_read": stage_us, "handles": int(hm.group(1)) if hm else None, "device_stage_ms_per_batch": dev_ms, "steady_state": steady,
             "n_batches": len(re.findall(r"\[M::process\] read \d+ sequences", p.stderr)), "retries": sum(retries) if retries else 0, "cpu_us_per_read": cpu_us}
+
+
+def steady_state_from_trace(stderr: str, reads_per_batch):
+    """`bwa-amd mem`'s timeline trace (BWAGPU_CLI_TRACE: `[D::timeline] batch N device a .. b`) -> the rate at which full-size batches leave the device
+    stage between the pipeline's fill and its drain; None when the run is too short to have such a part."""
+    ends = sorted(float(x) for x in re.findall(r"\[D::timeline\] batch \d+ device [\d.]+ \.\. ([\d.]+)", stderr))
+    if len(ends) < 8 or not reads_per_batch:
+        return None
+    body = ends[3:-1]          # (after the handles' first batches; the last batch is short)
+    gap = (body[-1] - body[0]) / (len(body) - 1)
+    if gap <= 0:
+        return None
+    return {"Mreads_s": round(reads_per_batch / gap / 1e6, 3), "ms_per_batch": round(gap * 1e3, 1), "first_batch_out_s": round(ends[0], 3),
+            "what": "full-size batches leaving the device stage between the pipeline's fill and its drain (time between the 4th and the last full batch / batches): the rate a longer input approaches; `value` is the whole run including fill and drain"}
 
 
 def measure_traffic(prefix: str, batch_file: str, dense_sa: int, layout: str, cache: str, limit_s: float = 45.0):

@@ -72,8 +72,8 @@ struct ChainRec {
 	i32 n;                 // number of seeds
 	i32 rid;
 	i32 w;                 // weight (mem_chain_weight)
-	i32 kept;              // mem_chain_t::kept (0 dropped, 1/2 overlapping, 3 clean)
-	i32 first_shadow;      // mem_chain_t::first: first chain shadowed by this one (-1 none)
+	i32 kept;              // (rounds 1-4: mem_chain_t::kept; since round 5 the filter keeps the kinds by sorted place -- dev_chainw.h `kind` -- and this stays 0)
+	i32 first_shadow;      // (likewise mem_chain_t::first: now the filter's `shadow` array; stays -1)
 	i32 is_alt;
 };
 

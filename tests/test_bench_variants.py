@@ -65,3 +65,19 @@ def test_variants_share_the_wall_budget(tmp_path):
     t = time.time()
     res = bench.run_variants(args, str(tmp_path / "none"), [], wall_left=38.0)      # 20.9 s for the first leg (its probe fails at once: no index), < 20 s left for the second
     assert res["short_reads"].get("rc") not in (None, 0) and time.time() - t < 25
+
+
+def test_steady_state_from_the_timeline_trace():
+    """bench.steady_state_from_trace: the FASTQ -> SAM run's steady rate is the spacing of the device stage's completions past the first three batches
+    (the handles' first ones, which include the pipeline's fill) and before the last (short) one."""
+    import bench
+    lines = ["[D::timeline] batch 0 read 0.050 .. 0.130", "[D::timeline] batch 0 device 0.150 .. 0.400 (slot 0)"]
+    t = 0.5
+    for b in range(1, 12):
+        lines.append(f"[D::timeline] batch {b} device {t - 0.2:.3f} .. {t:.3f} (slot {b % 3})")
+        lines.append(f"[D::timeline] batch {b} finalize {t:.3f} .. {t + 0.05:.3f}")
+        t += 0.08
+    got = bench.steady_state_from_trace("\n".join(lines), 500000)
+    assert got["first_batch_out_s"] == 0.4 and abs(got["ms_per_batch"] - 80.0) < 0.2 and abs(got["Mreads_s"] - 6.25) < 0.02
+    assert bench.steady_state_from_trace("\n".join(lines[:8]), 500000) is None       # too few batches
+    assert bench.steady_state_from_trace("\n".join(lines), None) is None

@@ -354,6 +354,23 @@ def test_hostsim_cloned_handle_shares_index(sim):
     assert_regs_equal(*a, *sim.align(opt, seqs, off), "original after the clone is destroyed")
 
 
+@pytest.mark.parametrize("results", [1, 0])
+def test_hostsim_batch_reserve(results):
+    """bwagpu_batch_reserve ahead of the first batch (device buffers of a batch of that shape and, unless reserve_results = 0, the page-locked result blocks,
+    handed to the pool the downloads draw from): the batch that follows -- smaller, and then larger than what was reserved -- gives the same regions as a
+    handle that reserved nothing."""
+    prefix, g = testdata.small_index()
+    opt = default_opt()
+    plain = sim_handle(prefix)
+    h = sim_handle(prefix, reserve_results=results, pinned_min_kb=0)
+    assert h.L.bwagpu_batch_reserve(h.h, 64, 64 * 150, 150) == 0
+    assert h.L.bwagpu_batch_reserve(h.h, 0, 0, 150) != 0            # (an empty shape is an argument error, and leaves the handle usable)
+    for n, seed in ((40, 61), (200, 62)):
+        seqs, off = testdata.flat(simdata.make_reads_se(g, n, seed=seed))
+        assert_regs_equal(*plain.align(opt, seqs, off), *h.align(opt, seqs, off), f"after bwagpu_batch_reserve, {n} reads")
+    h.close(); plain.close()
+
+
 def test_hostsim_interval_list_overflow_retries():
     """A deliberately tiny per-read interval capacity: the seeding kernel flags the overflow and the batch is re-run with a
     larger capacity; results are unchanged."""
