@@ -1,21 +1,26 @@
 // dev_chainw.h -- seeds -> chains (mem_chain, bwamem.c:277-342) and the chain filter (mem_chain_flt, bwamem.c:353-411),
-// one wavefront per read.
+// one wavefront per read, heaviest reads first, one kernel (k_chain_wave).
 //
 // Why not one lane per read (dev_chain.h, round 1): every lane walked its own B-tree and chain records, so each wave-wide load
 // touched 64 different cache lines (measured: 18 GB of HBM-side traffic per launch for < 1 GB of algorithmic bytes), the
 // pairwise chain filter of a read with hundreds of equally good chains (a read inside a repeat family: 640 chains, 200 k pair
 // tests) ran as one serial dependent-load loop -- 74 ms for a single read, the whole kernel's tail -- and the waves of a batch
-// advanced at the pace of their heaviest lane.  Here the order-dependent part (one B-tree look-up / insertion per seed, literally
-// kbtree's) runs wave-uniformly with the tree and the chain records in LDS: a node is fetched as one 160-byte
-// row, its nine keys are compared by nine lanes and the lower bound is a popcount of a ballot; node splits and shifts move all
-// entries at once.  Everything that is not order-dependent is lane-parallel: chain weights (lane per chain), the pairwise filter
-// (64 kept chains per step; the reference's "stop at the first chain that drops this one" is a find-first-set on the ballot), the
-// flattening of the kept chains.
-// Storage: tree, chain records, seed links, sort keys in the read's own region of HBM (RegionView); LDS holds the traversal stack and the weight sort's
-// pairs.  Rounds 2-4 ran three tiers of one template -- tree and chain records in LDS for reads that fit, HBM for the rest -- on the premise that the tree's
-// memory is what a look-up costs.  It is not (the per-seed cost is the wave-uniform logic: 5-7 us per seed in every tier), and in round 5 the HBM form alone
-// measured as fast as the three together (24.2 vs 24.9 ms per million reads, profiles/r05_chain_tiers.log), with the root node -- where every look-up
-// starts -- held in registers (RootCache).  One kernel, one form.
+// advanced at the pace of their heaviest lane.
+//
+// The order-dependent part -- one look-up / insertion per seed, in seed order, with kbtree's semantics -- has two forms:
+//   * register form (chain_seeds_lanes, round 5; 98.7 % of the bench batch's reads end here): a kbtree with distinct keys is a sorted set, so the read's
+//     chains are a sorted array held one chain per lane, up to CL_SLOTS per lane; look-up = compare masks + popcount, test_and_merge on every lane's own
+//     chain, insertion = a DPP shift of the lanes above the slot.  No memory access inside the loop but the seed-link stores.  See the comment there for
+//     when it is exact (distinct keys, or a one-node tree) and when the read is handed on;
+//   * tree form (the loop in chain_read_wave): kbtree literally, wave-uniform -- a node is fetched as one 160-byte row, its nine keys are compared by nine
+//     lanes and the lower bound is a popcount of a ballot, node splits and shifts move all entries at once; tree and chain records in the read's own
+//     region of HBM (RegionView), the root node -- where every look-up starts -- cached in registers (RootCache).
+// Rounds 2-4 ran the tree form in three tiers (tree and records in LDS for reads that fit) on the premise that the tree's memory is what a look-up costs.
+// It is not: the cost was the wave-uniform logic on the CU's one scalar unit, 5-7 us per seed in every tier, and the HBM form alone measured as fast as
+// the three together (profiles/r05_chain_tiers.log); the register form is what moved it (24.9 -> 12.7 ms per million reads, r05_chain_regs_ab.log).
+// Everything that is not order-dependent is lane-parallel: chain weights (lane per chain), the finish of the weight sort (every lane ranks its chain),
+// the pairwise filter (64 kept chains per step; the reference's "stop at the first chain that drops this one" is a find-first-set on the ballot), the
+// flattening of the kept chains.  LDS holds what the sort and the filter work on for reads of up to CW_FLT_LDS chains.
 #pragma once
 #include "dev_chain.h"
 #include "dev_extw.h"
@@ -78,7 +83,7 @@ DEVFN int cw_search(const NodeRegs &nr, i64 pos, int lane, int &r)
 // full node, a following insertion of the same position (the seed did not merge into the chain found) would descend along exactly
 // this path and split nothing, so it can be done on the leaf still held in registers (cw_insert_at) without a second descent.
 struct LowerPath { int leaf, i; bool direct; NodeRegs nr; };
-// The root node as the wave last loaded it.  Every look-up starts at the root, and in the HBM tier every node costs a dependent memory round trip (three to
+// The root node as the wave last loaded it.  Every look-up starts at the root, and in the tree form every node costs a dependent memory round trip (three to
 // four per seed: root, inner node, leaf, chain record): the root's -- a third of the descent -- is saved as long as nobody has written to the root since.
 // node = -1: nothing cached.  Writers call cw_touch() with the node they are about to modify.
 struct RootCache { int node; NodeRegs nr; };
