@@ -81,3 +81,28 @@ def test_steady_state_from_the_timeline_trace():
     assert got["first_batch_out_s"] == 0.4 and abs(got["ms_per_batch"] - 80.0) < 0.2 and abs(got["Mreads_s"] - 6.25) < 0.02
     assert bench.steady_state_from_trace("\n".join(lines[:8]), 500000) is None       # too few batches
     assert bench.steady_state_from_trace("\n".join(lines), None) is None
+
+
+def test_bench_run_product_parses_the_command_lines_trace(monkeypatch, tmp_path):
+    """bench.run_product end to end against the mock-runtime build of `bwa-amd mem`: the rate line, the stages' busy and CPU times, the device stage's
+    per-batch steps and the timeline trace (`steady_state`) are parsed from what the program really prints -- a change of a trace line's wording shows
+    up here, not as a missing field in the GPU box's bench line."""
+    import bench
+    import test_cli
+    from bwa_amd import simdata
+    prefix, g = testdata.small_index()
+    r1, r2 = simdata.make_reads_pe(g, 1000, seed=5)
+    f1, f2 = str(tmp_path / "a_1.fq"), str(tmp_path / "a_2.fq")
+    simdata.write_fastq(f1, r1); simdata.write_fastq(f2, r2)
+    os.makedirs(str(tmp_path / "root" / "bwa_amd"))
+    os.symlink(test_cli._sim_cli(), str(tmp_path / "root" / "bwa_amd" / "bwa-amd"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path / "root"))
+    monkeypatch.setenv("BWAGPU_PTAB_M", "6"); monkeypatch.setenv("BWAGPU_CLI_SERIALIZE", "1")
+    res = bench.run_product(prefix, [f1, f2], 2, None, streams=2, K=30000, timeout=900)
+    assert res is not None and res["n"] == 2000 and res["n_batches"] == 10 and res["retries"] == 0 and res["handles"] == 2
+    dev = res["device_stage_ms_per_batch"]
+    assert dev["reads_per_batch"] == 200 and dev["hot_path"] > 0 and dev["cigar_kernels"] >= 0
+    ss = res["steady_state"]
+    assert ss is not None and ss["ms_per_batch"] > 0 and ss["first_batch_out_s"] > 0
+    assert set(res["stage_us_per_read"]) >= {"read", "encode", "device", "finalize", "write"}
+    assert res["cpu_us_per_read"]["threads"] == 2
