@@ -1080,6 +1080,7 @@ int main(int argc, char *argv[])
 		{ std::lock_guard<std::mutex> l(dm); dcv.notify_all(); }
 	});
 
+	const long ahead = getenv("BWAGPU_CLI_AHEAD") ? atol(getenv("BWAGPU_CLI_AHEAD")) : 2;      // finished batches that may wait for the finalize stage beyond one per slot
 	std::vector<std::thread> devs;
 	for (int d = 0; d < n_work; ++d) devs.emplace_back([&, d] {      // stage 2: one host thread per slot (and, with whole batches, device)
 		// while the reader parses the first batch: the arenas of a batch of -K bases of short reads (150 bp assumed; anything else grows them
@@ -1092,7 +1093,10 @@ int main(int argc, char *argv[])
 			}
 		WorkP w;
 		while (to_dev.pop(w)) {
-			{ std::unique_lock<std::mutex> l(dm); dcv.wait(l, [&] { return w->no - next_fin <= (long)n_work; }); }   // do not run ahead of the host
+			// do not run far ahead of the host: a slot may start batch `no` while at most n_work + ahead batches before it are not finalized yet.  (Rounds 3-4: ahead = 0.
+			// A pipeline's first finalize calls are its slowest -- 156, 75, 62 ms for batches 0..2 of the bench run -- and with no slack every slot that finished its
+			// first batch waited for them: 69 + 121 + 80 ms of idle slots during the fill, profiles/r05_e2e_reserve_results.log.)
+			{ std::unique_lock<std::mutex> l(dm); dcv.wait(l, [&] { return w->no - next_fin <= (long)n_work + ahead; }); }
 			if (d < 16) dev_no[d] = (int)w->no;
 			++progress;
 			const double td = now_s();
