@@ -215,8 +215,10 @@ int bwagpu_debug_hist(bwagpu_t *h, unsigned long long out[256]);
 /* Diagnostics (stats on): the seeding kernel's index-block look-ups by interval size.  out[0] / out[1] = forward / backward extension steps that read
  * index blocks, out[2] / out[3] = those whose interval is a single row (a unique match), out[4] / out[5] = maximal runs of such steps. */
 int bwagpu_debug_seed_x2(bwagpu_t *h, unsigned long long out[8]);
-/* Diagnostics (stats on): the chaining tiers' reads by size.  out[t * 64 + b] = reads that finished in tier t (0, 1: the LDS tiers, 2: the HBM tier)
- * with 16 b .. 16 b + 15 chains (before the chain filter) (b = 31: more); out[t * 64 + 32 + b] = with 32 b .. 32 b + 31 seeds (tools/seed_iter_probe.py). */
+/* Diagnostics (stats on): the chaining kernel's reads by size and form.  out[t * 64 + b] = reads whose seeds were chained in form t (0: in registers,
+ * 1: in the B-tree) with 16 b .. 16 b + 15 chains (before the chain filter) (b = 31: more); out[t * 64 + 32 + b] = with 32 b .. 32 b + 31 seeds.
+ * out[128 .. 136] = the kernel's wave time in 10 ns ticks by phase (seed loop in registers, in the tree, repeat fraction + in-order list, weights, sort,
+ * pairwise filter, publishing), the longest read, and the reads counted (tools/seed_iter_probe.py prints all of it). */
 int bwagpu_debug_chain_hist(bwagpu_t *h, unsigned long long out[192]);
 
 /* ---- differential tests of the device DP routines ----------------------------------------------------------------------- */
