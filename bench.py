@@ -52,7 +52,7 @@ def log(*a):
     print(f"[{time.time() - _T0:7.1f}s]", *a, file=sys.stderr, flush=True)
 
 
-def build_or_load_index(genome_mbp: float, cache: str, rank: int, barrier):
+def build_or_load_index(genome_mbp: float, cache: str, rank: int, barrier, lib_path=None):
     """Seeded synthetic genome + reference-format index files, built on the GPU by bwagpu_index_build and cached on the box.
     Rank 0 builds; the genome's base codes are shared with the other ranks through a memory-mapped file."""
     from bwa_amd import simdata
@@ -66,7 +66,7 @@ def build_or_load_index(genome_mbp: float, cache: str, rank: int, barrier):
         g, lens = simdata.make_genome_large(total, n_contigs=24, seed=42, threads=4)
         t_gen = time.time() - t
         t = time.time()
-        info = build_index(prefix, g, [(f"chr{i + 1}", l) for i, l in enumerate(lens)])
+        info = build_index(prefix, g, [(f"chr{i + 1}", l) for i, l in enumerate(lens)], lib_path=lib_path)
         t_idx = time.time() - t
         np.save(prefix + ".codes.npy", g)
         del g
@@ -300,40 +300,64 @@ def main():
                     "when the line's own measurements are done (they end first; a leg that gets less than 20 s is skipped)")
     args = ap.parse_args()
 
+    # --gpus N > 1 means N ranks, one per GPU.  Launched bare (`python bench.py --gpus N`, no WORLD_SIZE in the environment) the script
+    # re-executes itself under torch.distributed.run with N ranks on this node; launched by the driver's own torch.distributed.run line it finds
+    # WORLD_SIZE == N.  Anything else -- a world size that is not --gpus -- is an error: a line that says n_gpus N must have run on N ranks.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        log(f"[bench] --gpus {args.gpus} without WORLD_SIZE: re-launching as {' '.join(cmd[1:8])} ...")
+        sys.stdout.flush(); sys.stderr.flush()
+        os.execv(sys.executable, cmd)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch `python bench.py --gpus N` bare, or under torch.distributed.run --nproc-per-node N")
+    # test hooks (tests/test_bench_ranks.py runs this very entry on a CPU box): the collective backend and the library that stands for the device
+    backend = os.environ.get("BWA_AMD_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm; "gloo" only with the mock-runtime library below
+    lib_path = os.environ.get("BWA_AMD_BENCH_LIB") or None             # default: bwa_amd/csrc/libbwagpu.so
+    on_gpu = backend == "nccl"
+    if not on_gpu and not lib_path:
+        sys.exit("bench.py: a CPU collective backend needs BWA_AMD_BENCH_LIB (the mock-runtime build); the product has no CPU path")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+        if on_gpu:
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
+    dev_id = local if on_gpu else 0
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     from bwa_amd import simdata
     from bwa_amd.api import BwaGpu
     from bwa_amd.structs import default_opt
 
     t_all = time.time()
-    prefix, g, idx_info = build_or_load_index(args.genome_mbp, args.cache, rank, barrier)
+    prefix, g, idx_info = build_or_load_index(args.genome_mbp, args.cache, rank, barrier, lib_path)
     bcast_s = None
     if dist is not None:                     # rank 0 loads + uploads, the others receive the index over RCCL/xGMI
         from bwa_amd import dist as bdist
         t_b = time.perf_counter()
-        gpu = bdist.broadcast_index(prefix, device=local, src=0)
+        gpu = bdist.broadcast_index(prefix, device=dev_id, src=0, lib_path=lib_path)
         barrier()
         bcast_s = time.perf_counter() - t_b
         if rank == 0:
             log(f"[bench] index loaded on rank 0 and broadcast to {world} ranks over RCCL in {bcast_s:.2f}s")
     else:
-        gpu = BwaGpu(prefix, device=local)   # index resident in this GPU's HBM (no CPU fallback: raises without a GPU)
+        gpu = BwaGpu(prefix, device=dev_id, lib_path=lib_path)   # index resident in this GPU's HBM (no CPU fallback: raises without a GPU)
     if args.dense_sa:
         gpu.densify_sa(args.dense_sa)
     gpu.set_taps(False)
@@ -400,10 +424,22 @@ def main():
     [t.start() for t in th]; [t.join() for t in th]
     barrier()
     dt = time.perf_counter() - t0
+    ranks_seen, per_rank = 1, None
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tdev = "cuda" if on_gpu else "cpu"
+        dt_own = dt
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        ones = torch.ones(1, dtype=torch.int64, device=tdev)            # the ranks the collective library itself reports: a sum of ones
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(ones.item())
+        mine = torch.tensor([batches[0].shape[0] * args.steps / dt_own / 1e6], dtype=torch.float64, device=tdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [round(float(x.item()), 4) for x in allr]
+        if ranks_seen != world or dist.get_world_size() != world:
+            sys.exit(f"bench.py: the collective reports {ranks_seen} ranks (world size {dist.get_world_size()}), expected {world}")
     counts, regs = gpu.download()
     digest = hashlib.sha256(counts.tobytes() + regs.tobytes()).hexdigest()[:16]
     cigar_stage = None
@@ -495,15 +531,17 @@ def main():
         except Exception:
             traffic = None
     layout = f"{n_batch // 2} pairs of 2x{args.read_len} bp (mates interleaved)" if pe else f"{n_batch} single-end {args.read_len} bp reads"
-    # the chip's measured ceilings for dependent random reads by request size (tools/randbw2.hip, profiles/r02_experiments.md; the
-    # cooperative-fetch variants are in tools/randbw3.hip / profiles/r03_randbw3.md)
-    ceil = {16: 48.3e9, 32: 37.8e9, 64: 23.0e9}
+    # the chip's measured ceiling for lane-private dependent random reads (tools/randbw4.hip, profiles/r05_randbw4.md): the memory pipeline charges
+    # 19 ps per DISTINCT block a lane asks for -- 52.5e9 requests/s -- whatever the request's size (16 or 32 bytes) or the number of load instructions.
+    # (Rounds 2-4 quoted 48.3 / 37.8 / 23.0e9 by request size: that benchmark's own 64-bit modulo, not the memory system.)
+    REQ_CEIL = 52.5e9
     n_blk, n_tab = work["n_occ_blocks"], work["n_tab_lookups"]
+    spill_per_read = round(work_product["n_stack_spill"] / nr, 1) if work_product.get("n_stack_spill") is not None else None     # interval-stack entries the lanes fetched back from HBM
     seed_s = stage_ms["ms_seed"] * 1e-3
     out = {
         "metric": "Mreads/s (whole job) 2x150 bp vs GRCh38-scale index; SAM bit-identical to bwa mem (gate: `parity`).  `value` = the hot path (mem_align1_core of every read) on batches resident in HBM, "
                   "as the bench contract times it; the SAM-producing FASTQ->SAM rate of the same build is `end_to_end_pe.value` (also in `summary`)",
-        "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 4), "unit": "Mreads/s", "n_gpus": ranks_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int32/u64 (integer DP + FM-index ranks)", "data": "synthetic",
         "config": {"workload": f"{layout} per GPU per step vs seeded synthetic {args.genome_mbp:g} Mbp genome (GRCh38 stand-in, seq_len {2 * int(args.genome_mbp * 1e6):.3g}; BASELINE configs[{2 if pe else 1}] layout)",
@@ -521,12 +559,17 @@ def main():
                                        f"16 bytes per prefix-table entry, l_seq/2 for the read; the device's own index blocks are {int(blk_bytes)} bytes, see achieved_device_layout",
                      "achieved_device_layout": round((alg["k_seed"] - (64.0 - blk_bytes) * work["n_occ_blocks"]) / (dur["k_seed"] * 1e-3) / 1e9, 2) if roof_k == "k_seed" and dur["k_seed"] > 0 else None,
                      "per_kernel": {k: dict({"ms": round(dur[k], 3), "alg_GB": round(alg[k] / 1e9, 3), "GB/s": round(alg[k] / (dur[k] * 1e-3) / 1e9, 1) if dur[k] > 0 else None}, **kernel_traffic(pj, k, alg[k])) for k in dur},
-                     "random_request_ceiling": {"requests_per_s_by_bytes": {str(k): v for k, v in ceil.items()},
-                                                "source": "tools/randbw2.hip on MI355X (profiles/r02_experiments.md): dependent random reads from a 4 GiB table saturate at 48.3 / 37.8 / 23.0 G/s for 16 / 32 / 64-byte requests",
-                                                # time the seeding stage's algorithmic requests alone would need at those ceilings (index blocks of the layout in use + 16-byte
-                                                # prefix-table entries; the interval stacks' spill traffic and the interval lists come on top)
+                     # the same kernel against the two yardsticks that fit it better than SURVEY 8(d)'s 64-byte unit: the bytes of the device's own layout, and requests
+                     "frac_device_bytes": round((alg["k_seed"] - (64.0 - blk_bytes) * n_blk) / seed_s / 1e9 / HBM_PEAK_GBS, 5) if seed_s > 0 else None,
+                     "frac_requests": round((n_blk + n_tab) / REQ_CEIL / seed_s, 4) if seed_s > 0 else None,
+                     "random_request_ceiling": {"requests_per_s": REQ_CEIL,
+                                                "source": "tools/randbw4.hip on MI355X (profiles/r05_randbw4.md): 19 ps per distinct random block a lane asks for, whatever its size",
+                                                # the seeding STAGE's algorithmic requests (index blocks + prefix-table entries of the budget-free algorithm; the interval stacks'
+                                                # spill requests, the task kernels' rework and the interval lists are the kernel's own making and are NOT counted as useful work)
+                                                "seeding_alg_requests_per_launch": n_blk + n_tab,
                                                 "seeding_alg_requests_per_s": round((n_blk + n_tab) / seed_s, 0) if seed_s > 0 else None,
-                                                "seeding_frac": round((n_blk / ceil[int(blk_bytes)] + n_tab / ceil[16]) / seed_s, 4) if seed_s > 0 else None},
+                                                "spill_requests_per_read": spill_per_read,
+                                                "seeding_frac": round((n_blk + n_tab) / REQ_CEIL / seed_s, 4) if seed_s > 0 else None},
                      "ext_gcups": round(work["n_ext_cells"] / (stage_ms["ms_extend"] * 1e-3) / 1e9, 1) if stage_ms["ms_extend"] > 0 else None},
         "stage_ms_solo": {k: round(v, 3) for k, v in stage_ms.items()},
         "cigar_stage": cigar_stage,
@@ -536,6 +579,9 @@ def main():
         "index_build": {"device_s": round(idx_info.get("build_ms", 0) / 1e3, 3) if idx_info else None,
                         "what": "bwagpu_index_build: suffix sort of forward+reverse text in HBM, BWT/Occ/SA in the reference's layout (byte-identical to bwa index)"},
     }
+    if per_rank is not None:
+        out["ranks"] = {"n": ranks_seen, "backend": backend + (" (RCCL)" if on_gpu else ""), "per_rank_Mreads_s": per_rank,
+                        "what": "n = all-reduce of ones over the collective library; every rank's own hot-path rate (its reads x steps / its own time); `value` = all ranks' reads / the slowest rank's time"}
     if bcast_s is not None:
         out["index_broadcast"] = {"ranks": world, "seconds": round(bcast_s, 3), "what": "rank 0 loads the index files and uploads; RCCL broadcast of .bwt/.sa/.pac buffers over xGMI; every rank then builds its 32-byte blocks and prefix tables"}
     gpu.close()
@@ -651,11 +697,30 @@ def main():
             except Exception as e:   # (the long-read leg must not take the headline line with it)
                 out["longread"] = {"error": repr(e)}
     if world == 1 and args.variants.strip() and not args.no_cpu_baseline:      # (a full run only: the profiling runs pass --no-cpu-baseline)
-        out["variants"] = run_variants(args, prefix, variant_files, max(0.0, args.wall_budget - (time.time() - _T0)))
+        # the A/B tables go to a side file (they were 15 KB of the line); the line keeps one row per configuration
+        var = run_variants(args, prefix, variant_files, max(0.0, args.wall_budget - (time.time() - _T0)))
+        side = os.path.join(ROOT, "gpurun_out", "bench_variants.json")
+        try:
+            os.makedirs(os.path.dirname(side), exist_ok=True)
+            json.dump(var, open(side, "w"))
+        except OSError:
+            side = None
+        brief = {"file": os.path.relpath(side, ROOT) if side else None, "what": var.get("what")}
+        for leg_name, leg in var.items():
+            if isinstance(leg, dict) and "runs" in leg:
+                brief[leg_name] = {"rc": leg.get("rc"), "wall_s": leg.get("wall_s"),
+                                   "runs": [dict({k_: r_.get(k_) for k_ in ("config", "ms_per_step", "ms_per_pass", "same_result_as_defaults", "error") if k_ in r_},
+                                                 **({"ms_total_solo": r_["stage_ms_solo"].get("ms_total")} if isinstance(r_.get("stage_ms_solo"), dict) else {})) for r_ in leg["runs"]]}
+            elif isinstance(leg, dict):
+                brief[leg_name] = leg
+        out["variants"] = brief
     out["bench_wall_s"] = round(time.time() - t_all, 1)
     # last on the line (a truncated tail of stdout still shows it) and once more on stderr: the numbers and the gates in one small object
     par_ = out.get("parity", {}); lr_ = out.get("longread", {}) if isinstance(out.get("longread"), dict) else {}
-    out["summary"] = {"value_hot_path_Mreads_s": out["value"], "end_to_end_pe_Mreads_s": out.get("end_to_end_pe", {}).get("value"), "roofline_frac": out["roofline"]["frac"],
+    e2e_v = out.get("end_to_end_pe", {}).get("value")
+    out["summary"] = {"fastq_to_sam_Mreads_s": e2e_v, "what": "fastq_to_sam = the BASELINE metric (bit-identical SAM out of FASTQ, `end_to_end_pe`); value_hot_path = the resident hot path the bench contract times (`value`)",
+                      "value_hot_path_Mreads_s": out["value"], "hot_path_over_fastq_to_sam": round(out["value"] / e2e_v, 3) if e2e_v else None,
+                      "end_to_end_pe_Mreads_s": e2e_v, "roofline_frac": out["roofline"]["frac"],
                       "cpu_baseline_Mreads_s": out.get("cpu_baseline", {}).get("value"),
                       "parity": {"se": par_.get("se"), "pe": par_.get("pe"), "multibatch": par_.get("multibatch"), "timed_batch": (par_.get("timed_batch") or {}).get("ok"),
                                  "e2e_tail": (par_.get("e2e_tail") or {}).get("ok"),

@@ -57,7 +57,7 @@ EXPORTS = [
     "bwagpu_index_info", "bwagpu_densify_sa", "bwagpu_set_stats", "bwagpu_get_stats", "bwagpu_align_bseq", "bwagpu_align_flat",
     "bwagpu_free", "bwagpu_batch_upload", "bwagpu_batch_run", "bwagpu_batch_download", "bwagpu_set_taps", "bwagpu_tap_intervals",
     "bwagpu_tap_chains", "bwagpu_tap_regs_raw", "bwagpu_index_buffers", "bwagpu_index_export", "bwagpu_clone", "bwagpu_index_ready",
-    "bwagpu_batch_cigars", "bwagpu_batch_cigar_ops", "bwagpu_debug_phase", "bwagpu_batch_matesw", "bwagpu_clone_to_device", "bwagpu_index_build", "bwagpu_built_free", "bwagpu_abi_sizes", "bwagpu_debug_prof", "bwagpu_debug_hist", "bwagpu_debug_seed_x2", "bwagpu_debug_chain_hist", "bwagpu_debug_dp", "bwagpu_set_cigar_filter", "bwagpu_batch_reserve",
+    "bwagpu_batch_cigars", "bwagpu_batch_cigar_ops", "bwagpu_debug_phase", "bwagpu_batch_matesw", "bwagpu_clone_to_device", "bwagpu_index_build", "bwagpu_built_free", "bwagpu_abi_sizes", "bwagpu_debug_prof", "bwagpu_debug_hist", "bwagpu_debug_seed_x2", "bwagpu_debug_chain_hist", "bwagpu_debug_dp", "bwagpu_set_cigar_filter", "bwagpu_batch_reserve", "bwagpu_batch_footprint", "bwagpu_mem_info",
     "bwagpu_trim", "bwagpu_set_option", "bwagpu_get_option", "bwagpu_set_default_option", "bwagpu_clear_default_options", "bwagpu_option_name",
 ]
 

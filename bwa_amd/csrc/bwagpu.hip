@@ -40,10 +40,14 @@
 
 #define BWAGPU_VERSION "bwagpu 0.1 (gfx950)"
 
+// bwagpu_batch_footprint: the allocation code itself run "dry" -- ensure() adds what it would allocate to *g_dry_sum and allocates nothing --, so that the
+// estimate cannot drift away from what bwagpu_batch_reserve / alloc_batch really ask for.
+static thread_local size_t *g_dry_sum = nullptr;
 struct DevBuf {
 	void *p = nullptr; size_t cap = 0;
 	int ensure(size_t bytes) {
 		if (bytes <= cap) return 0;
+		if (g_dry_sum) { *g_dry_sum += bytes + (bytes >> 3) + 256 - cap; return 0; }
 		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
 		size_t want = bytes + (bytes >> 3) + 256;
 		if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
@@ -209,10 +213,36 @@ namespace {
 std::mutex g_cfg_m;
 std::map<std::string, long long> g_cfg_defaults;     // bwagpu_set_default_option: applied to handles created afterwards, on top of the environment
 }
+// Ranges of the options (one test for all three ways in -- bwagpu_set_option, bwagpu_set_default_option, the environment): sizes and counts that the
+// batch calls cast to int or multiply, and the options with a fixed set of kernel instances behind them (-1 = auto where the list says so).
+// seed_lds_ent: 16 entries x 16 B x 256 lanes is the whole 64 KiB a workgroup's dynamic LDS may take.
+static bool option_in_range(const BwagpuConfig &c, const long long *f, long long value)
+{
+	auto in = [&](long long lo, long long hi) { return value >= lo && value <= hi; };
+	if (f == &c.ext_occ) return value == 4 || value == 6;
+	if (f == &c.seed_mrg) return value == -1 || value == 0 || value == 2;
+	if (f == &c.share) return in(-1, 100);
+	if (f == &c.seed_task_stack || f == &c.seed_p2_cap || f == &c.mem_cap || f == &c.seed_grid || f == &c.cig_ops_cap || f == &c.idx_desc_max_mb) return in(0, 0x3fffffff);
+	if (f == &c.seed_budget) return in(-1, 0x3fffffff);
+	if (f == &c.seed_lds_ent) return in(-1, 16);
+	if (f == &c.dedup_ring) return value == 0 || (in(256, 4096) && (value & (value - 1)) == 0);
+	if (f == &c.cigl_mib) return in(0, 1 << 20);
+	if (f == &c.cig_tiers || f == &c.chain_regs) return in(0, 2);
+	if (f == &c.chain_flt_lds) return in(0, CW_FLT_LDS);
+	if (f == &c.ptab_m) return in(0, PTAB_MAX);
+	if (f == &c.occ32_sb_shift) return in(8, 32);
+	return true;
+}
 static void init_config(BwagpuConfig &c)
 {
 	c = BwagpuConfig();
+	const BwagpuConfig dflt;
 	c.from_env();
+	// a value from the environment that is out of range is dropped with a warning (the handle keeps the compiled-in default); bwagpu_set_default_option
+	// refuses such values when they are set
+#define X(name, d) if (!option_in_range(c, &c.name, c.name)) { fprintf(stderr, "[W::bwagpu] BWAGPU_%s=%lld is out of range: ignored\n", #name, c.name); c.name = dflt.name; }
+	BWAGPU_OPTION_LIST(X)
+#undef X
 	std::lock_guard<std::mutex> l(g_cfg_m);
 	for (auto &kv : g_cfg_defaults) if (long long *f = c.field(kv.first.c_str())) *f = kv.second;
 	g_results.on = c.pinned_results; g_results.min_kb = c.pinned_min_kb < 0 ? 0 : c.pinned_min_kb; g_results.inited = true;
@@ -220,7 +250,8 @@ static void init_config(BwagpuConfig &c)
 extern "C" int bwagpu_set_default_option(const char *key, long long value)
 {
 	BwagpuConfig probe;
-	if (!probe.field(key)) return BWAGPU_EINVAL;
+	const long long *f = probe.field(key);
+	if (!f || !option_in_range(probe, f, value)) return BWAGPU_EINVAL;
 	std::lock_guard<std::mutex> l(g_cfg_m);
 	g_cfg_defaults[key] = value;
 	return BWAGPU_OK;
@@ -234,26 +265,7 @@ extern "C" int bwagpu_set_option(bwagpu_t *h, const char *key, long long value)
 	// the index-side options shape what bwagpu_create / bwagpu_index_ready derive from the index: per handle they can only be set before that
 	// happens (a handle created with NULL arrays, ahead of the broadcast); otherwise use bwagpu_set_default_option before creating the handle
 	if ((f == &h->cfg.occ32 || f == &h->cfg.occ32_sb_shift || f == &h->cfg.ptab_m) && (h->ix.occ32 || h->ix.ptab) && *f != value) return BWAGPU_EINVAL;
-	// ranges: sizes and counts that the batch calls cast to int or multiply, and the two options with a fixed set of kernel instances behind them
-	// (-1 = auto where the list says so)
-	{
-		const BwagpuConfig &c = h->cfg;
-		auto in = [&](long long lo, long long hi) { return value >= lo && value <= hi; };
-		bool ok = true;
-		if (f == &c.ext_occ) ok = value == 4 || value == 6;
-		else if (f == &c.seed_mrg) ok = value == -1 || value == 0 || value == 2;
-		else if (f == &c.share) ok = in(-1, 100);
-		else if (f == &c.seed_task_stack || f == &c.seed_p2_cap || f == &c.mem_cap || f == &c.seed_grid || f == &c.cig_ops_cap || f == &c.idx_desc_max_mb) ok = in(0, 0x3fffffff);
-		else if (f == &c.seed_budget) ok = in(-1, 0x3fffffff);
-		else if (f == &c.seed_lds_ent) ok = in(-1, 64);
-		else if (f == &c.dedup_ring) ok = value == 0 || (in(256, 4096) && (value & (value - 1)) == 0);
-		else if (f == &c.cigl_mib) ok = in(0, 1 << 20);
-		else if (f == &c.cig_tiers || f == &c.chain_regs) ok = in(0, 2);
-		else if (f == &c.chain_flt_lds) ok = in(0, CW_FLT_LDS);
-		else if (f == &c.ptab_m) ok = in(0, PTAB_MAX);
-		else if (f == &c.occ32_sb_shift) ok = in(8, 32);
-		if (!ok) return BWAGPU_EINVAL;
-	}
+	if (!option_in_range(h->cfg, f, value)) return BWAGPU_EINVAL;
 	*f = value;
 	if (f == &h->cfg.pinned_results) g_results.on = value;
 	if (f == &h->cfg.pinned_min_kb) g_results.min_kb = value < 0 ? 0 : value;
@@ -904,13 +916,35 @@ extern "C" int bwagpu_batch_reserve(bwagpu_t *h, int n_reads, int64_t n_bases, i
 	bad |= h->d_cigs.ensure((size_t)tot * sizeof(bwagpu_cigar_t)); bad |= h->d_cig_ext.ensure((size_t)(tot * 4 + 65536) * 4);
 	// ... and the page-locked blocks its results will be copied into (regions, CIGAR records, operation array: ~0.4 GB per 667 k reads; page-locking costs
 	// more than the copy -- ~0.2 ms per MB -- and the pool keeps what it is given back, so the handle's first batch finds them)
-	if (h->cfg.reserve_results) {
+	if (h->cfg.reserve_results && !g_dry_sum) {
 		void *r0 = result_alloc((size_t)tot * sizeof(bwagpu_alnreg_t)), *r1 = result_alloc((size_t)tot * sizeof(bwagpu_cigar_t)), *r2 = result_alloc((size_t)tot * 2 * 4);
 		bwagpu_free(r0); bwagpu_free(r1); bwagpu_free(r2);
 	}
 	h->n_reads = n0; h->n_bases = b0; h->max_len = m0; h->have_batch = have0; h->ran = ran0;
 	h->slot_cap = sc0; h->node_cap = nc0; h->reg_cap = rc0; h->mem_cap = mc0;
 	if (bad) { h->err = "hipMalloc failed (reserve)"; return BWAGPU_ENOMEM; }
+	return BWAGPU_OK;
+}
+
+// Device memory a handle's buffers would GROW by for a batch of this shape (bytes; what bwagpu_batch_reserve would allocate now), and the device's
+// free / total memory: what a caller needs to decide how much HBM it can spend on a denser suffix array before the batches arrive.
+extern "C" int64_t bwagpu_batch_footprint(bwagpu_t *h, int n_reads, int64_t n_bases, int max_len)
+{
+	if (!h || n_reads <= 0 || n_bases <= 0 || max_len <= 0 || max_len > 0x3fffffff) return -1;
+	size_t sum = 0;
+	g_dry_sum = &sum;
+	const int rc = bwagpu_batch_reserve(h, n_reads, n_bases, max_len);
+	g_dry_sum = nullptr;
+	return rc == BWAGPU_OK ? (int64_t)sum : -1;
+}
+extern "C" int bwagpu_mem_info(bwagpu_t *h, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+	if (!h) return BWAGPU_EINVAL;
+	HIPCHK(h, hipSetDevice(h->device));
+	size_t f = 0, t = 0;
+	HIPCHK(h, hipMemGetInfo(&f, &t));
+	if (free_bytes) *free_bytes = f;
+	if (total_bytes) *total_bytes = t;
 	return BWAGPU_OK;
 }
 

@@ -901,12 +901,37 @@ int main(int argc, char *argv[])
 	bwagpu_set_cigar_filter(gpu, getenv("BWAGPU_CLI_CIGAR_FILTER") ? atoi(getenv("BWAGPU_CLI_CIGAR_FILTER")) : 1);   // (clones inherit it)
 	{	// SA look-ups walk ~31 LF steps with the reference's interval of 32; HBM has room for the full array (same values): 8 bytes per text position, 50 GB for a
 		// human genome, one look-up = one 8-byte read (k_sa 3.1 -> 0.9 ms per million reads against an interval of 4).  If that much is not to be had: the next intervals up.
+		// The array must leave room for the batches: every handle (BWAGPU_CLI_STREAMS of them per device) grows arenas for a -K batch -- about 17 GB at the
+		// default -K with 150 bp reads -- and a device with less free memory than an idle MI355X (smaller parts, several processes per GPU) could take the
+		// full array and then fail its first batch.  So: the smallest interval whose array fits beside the handles' estimated footprint (the library's own
+		// allocation arithmetic run dry, bwagpu_batch_footprint, for reads of >= 100 bp -- shorter reads mean more reads per -K batch; + 15 % + 2 GB for the
+		// CIGAR / mate-rescue scratch that is sized by results).  BWAGPU_CLI_HBM_LIMIT_MB caps what the program takes the free memory to be.
 		const int dense = getenv("BWAGPU_CLI_DENSE_SA") ? atoi(getenv("BWAGPU_CLI_DENSE_SA")) : 1;
+		const int n_slots = getenv("BWAGPU_CLI_STREAMS") ? (atoi(getenv("BWAGPU_CLI_STREAMS")) > 1 ? atoi(getenv("BWAGPU_CLI_STREAMS")) : 1) : 3;
+		const int64_t chunk_est = fixed_chunk > 0 ? fixed_chunk : (int64_t)opt.chunk_size * opt.n_threads;
+		const bool long_est = mode && (strcmp(mode, "pacbio") == 0 || strcmp(mode, "pbref") == 0 || strcmp(mode, "ont2d") == 0);
+		const int len_est = long_est ? 10000 : 100;
+		const int64_t per_handle = bwagpu_batch_footprint(gpu, (int)(chunk_est / len_est) + 1024, chunk_est + (1 << 20), long_est ? 20000 : 256);
+		uint64_t free_b = 0, total_b = 0, seq_len = 0;
+		bwagpu_mem_info(gpu, &free_b, &total_b);
+		bwagpu_index_info(gpu, nullptr, nullptr, &seq_len, nullptr);
+		if (getenv("BWAGPU_CLI_HBM_LIMIT_MB")) { const uint64_t lim = (uint64_t)atoll(getenv("BWAGPU_CLI_HBM_LIMIT_MB")) << 20; if (lim < free_b) free_b = lim; }
+		const double need = per_handle > 0 ? (double)per_handle * n_slots * 1.15 + 2e9 : 0.0;
+		int chosen = 0;
 		for (int dn = dense; dn > 0 && dn < 32; dn *= 2) {
+			const double sa_bytes = 8.0 * ((double)seq_len / dn + 1);
+			if (free_b > 0 && sa_bytes + need > (double)free_b) {
+				if (g_verbose >= 3) fprintf(stderr, "[M::%s] SA interval %d needs %.1f GB beside %.1f GB for %d handles' batches; %.1f GB are free: trying the next interval\n", "main_mem", dn, sa_bytes / 1e9, need / 1e9, n_slots, free_b / 1e9);
+				continue;
+			}
 			const int rc = bwagpu_densify_sa(gpu, dn);
-			if (rc == BWAGPU_OK) break;
+			if (rc == BWAGPU_OK) { chosen = dn; break; }
 			if (g_verbose >= 2) fprintf(stderr, "[W::%s] SA not densified to an interval of %d: %s\n", "main_mem", dn, bwagpu_strerror(rc));
 			if (rc != BWAGPU_ENOMEM) break;
+		}
+		if (g_verbose >= 3) {
+			if (chosen) fprintf(stderr, "[M::%s] suffix array expanded on the device to interval %d (%.1f GB; %.1f GB free before, %.1f GB set aside for %d handles' batches)\n", "main_mem", chosen, 8.0 * ((double)seq_len / chosen + 1) / 1e9, free_b / 1e9, need / 1e9, n_slots);
+			else if (dense > 0 && dense < 32) fprintf(stderr, "[M::%s] suffix array kept at the index's own interval (no denser one fits beside the batches)\n", "main_mem");
 		}
 	}
 
@@ -1021,6 +1046,7 @@ int main(int argc, char *argv[])
 		// (BWAGPU_CLI_N_PROCESSED0: the number the run's first read gets -- mem_pair's tie-breaking hash takes the pair's number in the whole run, bwamem_pair.c:208,248, and
 		// wraps at 2^23 pairs: the tests start a small input just below that)
 		const int64_t n_processed0 = getenv("BWAGPU_CLI_N_PROCESSED0") ? atoll(getenv("BWAGPU_CLI_N_PROCESSED0")) : 0;
+		if (n_processed0 != 0 && g_verbose >= 2) fprintf(stderr, "[W::%s] BWAGPU_CLI_N_PROCESSED0=%lld: reads are numbered from there (pairing ties break as they would that deep in a run)\n", "main_mem", (long long)n_processed0);
 		int64_t n_processed = n_processed0; long no = 0;
 		for (;;) {
 			WorkP w(new Work()); w->no = no;
@@ -1112,6 +1138,8 @@ int main(int argc, char *argv[])
 
 	std::thread writer([&] {      // stage 4: output in input order
 		WorkP w;
+		if (getenv("BWAGPU_CLI_OUT_FROM_BATCH") && atol(getenv("BWAGPU_CLI_OUT_FROM_BATCH")) > 0 && g_verbose >= 2)
+			fprintf(stderr, "[W::%s] BWAGPU_CLI_OUT_FROM_BATCH=%s: the records of the batches before that one are NOT written\n", "main_mem", getenv("BWAGPU_CLI_OUT_FROM_BATCH"));
 		const long out_from = getenv("BWAGPU_CLI_OUT_FROM_BATCH") ? atol(getenv("BWAGPU_CLI_OUT_FROM_BATCH")) : 0;      // (bench.py's tail check: only the records of batches out_from.. are written)
 		while (to_out.pop(w)) { const double tw = now_s(); if (w->no >= out_from) for (auto &t : w->out) fwrite(t.data(), 1, w->by_read ? strnlen(t.data(), t.size()) : t.size(), stdout);
 			if (!w->by_read) { std::lock_guard<std::mutex> l(pool_m); if (out_pool.size() < 4) out_pool.push_back(std::move(w->out)); } /* (the reference fputs() a read's records, fastmap.c:116: a NUL -- the letter of base code 5, a '-' in the input -- ends them) */ busy_write += now_s() - tw; }

@@ -377,6 +377,11 @@ int bwagpu_batch_upload(bwagpu_t *h, int n, const uint8_t *seqs, const int64_t *
  * first batch does not pay for them inside a pipeline.  Unless option reserve_results is 0 it also page-locks the result blocks of such a batch
  * (about 150 bytes per region at 4 regions per read) and hands them to the pool bwagpu_free() feeds, where the batch's downloads find them. */
 int bwagpu_batch_reserve(bwagpu_t *h, int n_reads, int64_t n_bases, int max_len);
+/* Bytes of device memory the handle's buffers would grow by for a batch of this shape (what bwagpu_batch_reserve would allocate now; -1 on bad
+ * arguments), and the device's free / total memory (hipMemGetInfo).  `bwa-amd mem` sizes the dense suffix array with them: it takes the smallest
+ * SA interval that leaves room for its handles' batches. */
+int64_t bwagpu_batch_footprint(bwagpu_t *h, int n_reads, int64_t n_bases, int max_len);
+int bwagpu_mem_info(bwagpu_t *h, uint64_t *free_bytes, uint64_t *total_bytes);
 int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt);
 int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg_t **regs_out, int64_t *n_regs_out);
 

@@ -67,6 +67,8 @@ static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); if (*p) memset(*p, 0xCB, n < ((size_t)32 << 20) ? (n ? n : 1) : ((size_t)32 << 20));   /* (the first 32 MiB: scratch areas sized for a whole chip are never touched otherwise) */ return *p ? hipSuccess : hipErrorMock; }
 template <class T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+// (the mock's "device" reports a fixed amount of memory, MOCK_HIP_FREE_MB of it free -- tests of the callers' headroom arithmetic set it)
+static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { const char *e = getenv("MOCK_HIP_FREE_MB"); *t = (size_t)288 << 30; *f = e ? (size_t)atoll(e) << 20 : (size_t)280 << 30; return hipSuccess; }
 #define hipHostMallocDefault 0
 #define hipHostMallocPortable 1
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); if (*p) memset(*p, 0xCD, n < ((size_t)1 << 20) ? n : ((size_t)1 << 20)); return *p ? hipSuccess : hipErrorMock; }

@@ -400,3 +400,60 @@ def test_cli_input_file_that_shrinks_under_the_mapping(tmp_path):
     p = subprocess.run([cli, "mem", prefix, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
     assert p.returncode == 74, (p.returncode, p.stderr.decode()[-500:])
     assert b"SIGBUS" in p.stderr and b"shrank" in p.stderr
+
+
+def test_cli_sa_interval_leaves_room_for_the_batches(tmp_path):
+    """`bwa-amd mem` expands the suffix array on the device to the SMALLEST interval that still leaves room for its handles' batch arenas
+    (bwagpu_mem_info / bwagpu_batch_footprint: ADVICE r5 -- the full array fitted, the first batch then failed, on a device with less free memory
+    than an idle MI355X).  The mock device's free memory is what MOCK_HIP_FREE_MB says; the SAM is the same whatever interval is taken."""
+    cli = _sim_cli()
+    prefix, g = testdata.small_index()
+    r = simdata.make_reads_se(g, 12, seed=5)
+    fq = str(tmp_path / "r.fq")
+    simdata.write_fastq(fq, r)
+    import ctypes as C
+    from bwa_amd.api import BwaGpu
+    import hostsim_build
+    s = BwaGpu(prefix, lib_path=hostsim_build.build())
+    s.set_taps(False)                    # (as the command line does: the tap copies are part of the footprint)
+    s.L.bwagpu_batch_footprint.restype = C.c_int64
+    s.L.bwagpu_batch_footprint.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int]
+    K = 200000
+    per_handle = int(s.L.bwagpu_batch_footprint(s.h, K // 100 + 1024, K + (1 << 20), 256))
+    assert per_handle > 0
+    assert int(s.L.bwagpu_batch_footprint(s.h, 0, 10, 10)) == -1
+    fre, tot = C.c_uint64(), C.c_uint64()
+    assert s.L.bwagpu_mem_info(s.h, C.byref(fre), C.byref(tot)) == 0 and 0 < fre.value <= tot.value
+    seq_len = 2 * g.shape[0]
+    s.close()
+    need_mb = (per_handle * 3 * 1.15 + 2e9) / (1 << 20)
+    outs = {}
+    for label, free_mb, want in (("plenty", need_mb + 8.0 * seq_len / (1 << 20) + 64, "interval 1 "), ("tight", need_mb + 8.0 * seq_len / 2 / (1 << 20) + 0.7, "interval 2 "), ("none", need_mb * 0.5, "kept at the index's own interval")):
+        p = subprocess.run([cli, "mem", "-v", "3", "-K", str(K), prefix, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MOCK_HIP_FREE_MB=str(int(free_mb))))
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        assert want in p.stderr.decode(), (label, p.stderr.decode()[-1500:])
+        outs[label] = _body(p.stdout)
+    assert outs["plenty"] == outs["tight"] == outs["none"] and outs["plenty"].count(b"\n") >= 12
+    # the limit a user can set does the same as a fuller device
+    p = subprocess.run([cli, "mem", "-v", "3", "-K", str(K), prefix, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, BWAGPU_CLI_HBM_LIMIT_MB=str(int(need_mb * 0.5))))
+    assert p.returncode == 0 and "kept at the index's own interval" in p.stderr.decode()
+
+
+def test_option_ranges_apply_to_defaults_and_environment(monkeypatch):
+    """The range test of bwagpu_set_option also guards bwagpu_set_default_option (refused) and the environment (ignored with a warning): seed_lds_ent
+    above 16 entries per lane would exceed a workgroup's dynamic LDS and fail the launch instead of the call."""
+    import ctypes as C
+    from bwa_amd.api import BwaGpu
+    import hostsim_build
+    prefix, _ = testdata.small_index()
+    monkeypatch.setenv("BWAGPU_SEED_LDS_ENT", "40")
+    monkeypatch.setenv("BWAGPU_EXT_OCC", "5")
+    s = BwaGpu(prefix, lib_path=hostsim_build.build())
+    assert s.get_option("seed_lds_ent") == -1 and s.get_option("ext_occ") == 6
+    s.L.bwagpu_set_default_option.argtypes = [C.c_char_p, C.c_longlong]
+    assert s.L.bwagpu_set_default_option(b"seed_lds_ent", 17) != 0
+    assert s.L.bwagpu_set_default_option(b"seed_lds_ent", 16) == 0
+    s.L.bwagpu_clear_default_options()
+    with pytest.raises(Exception):
+        s.set_option("seed_lds_ent", 17)
+    s.close()
