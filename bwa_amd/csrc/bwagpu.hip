@@ -31,6 +31,7 @@
 #include "dev_chainw.h"
 #include "dev_ext.h"
 #include "dev_extw.h"
+#include "dev_extp.h"
 #include "dev_dedup.h"
 #include "dev_seedsw.h"
 #include "dev_cigar.h"
@@ -761,6 +762,8 @@ extern "C" int bwagpu_densify_sa(bwagpu_t *h, int new_intv)
 	return BWAGPU_OK;
 }
 
+static int sc_max_all(const bwagpu_opt_t *opt) { int m = 1; for (int k = 0; k < 25; ++k) if (opt->mat[k] > m) m = opt->mat[k]; return m; }
+
 // ---- batches -------------------------------------------------------------------------------------------------
 static const int BLOCK = 256;
 static const int MAX_RESIDENT_THREADS = 256 * 2048;   // 256 CUs x 32 waves x 64 lanes
@@ -1170,6 +1173,13 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			i64 nblk = ((i64)n + 3) / 4, cap = share(256 * 6);       // (six workgroups per CU are resident at 6 waves per SIMD)
 			const int occ = (int)cfg.ext_occ;   // waves per SIMD the register allocation aims at (measured at 3.1 Gbp in round 2: 4 -> 63 ms, 5 -> 58 ms, 6 -> 56 ms; round 4, with the window rows: 4 -> 37.9, 5 -> 37.0-38.3, 6 -> 35.4-36.1 ms; the instance for 5 is not built -- one state of the source made hipcc 7.2 fail on it with an unaligned 64-bit spill reload, and it never won)
 			const dim3 g((unsigned)(nblk < cap ? nblk : cap));
+			// the chains' first extensions -- most of the stage's DP cells -- four to a wavefront, ahead of the kernel that replays mem_chain2aln's order-dependent
+			// logic over them (dev_extp.h).  Not in stats runs: the work counters stay the one-wave routine's.
+			if (cfg.ext_pack && !h->stats_on && h->max_len < 65536 && opt->w > 0 && (i64)h->max_len * sc_max_all(opt) < (1 << 21)) {
+				B.ext_plan = 1;
+				const i64 pcap = share(256 * 5);
+				hipLaunchKernelGGL((k_ext_pack<5>), dim3((unsigned)(nblk < pcap ? nblk : pcap)), block, (size_t)XP_LDS_BYTES * 4, h->stream, h->ix, *opt, B);
+			}
 			if (occ == 4) hipLaunchKernelGGL((k_extend_wave<false, 4>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
 			else hipLaunchKernelGGL((k_extend_wave<false, 6>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
 		} else if (max_score < (1 << 24) && ring_cols <= 2048) {
@@ -1573,7 +1583,7 @@ extern "C" int bwagpu_align_bseq(bwagpu_t *h, const bwagpu_opt_t *opt, int n, bw
 // ---- differential tests of the DP routines (dev_debug.h) ---------------------------------------------------------------------
 extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, int n_cases, const bwagpu_dp_case_t *cases, const uint8_t *seqs, int64_t n_seq_bytes, int32_t *out)
 {
-	if (!h || !opt || n_cases < 0 || kind < 0 || kind > 5 || (n_cases > 0 && (!cases || !seqs || !out)) || n_seq_bytes < 0) return BWAGPU_EINVAL;
+	if (!h || !opt || n_cases < 0 || kind < 0 || kind > 7 || (n_cases > 0 && (!cases || !seqs || !out)) || n_seq_bytes < 0) return BWAGPU_EINVAL;
 	if (opt->e_del <= 0 || opt->e_ins <= 0) return BWAGPU_EINVAL;
 	if (n_cases == 0) return BWAGPU_OK;
 	static_assert(sizeof(bwagpu_dp_case_t) == 32, "layout");
@@ -1581,7 +1591,7 @@ extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, i
 	for (int i = 0; i < n_cases; ++i) {
 		const bwagpu_dp_case_t &c = cases[i];
 		if (c.q_len < 0 || c.t_len < 0 || c.q_off < 0 || c.t_off < 0 || (i64)c.q_off + c.q_len > n_seq_bytes || (i64)c.t_off + c.t_len > n_seq_bytes || c.w < 0) return BWAGPU_EINVAL;
-		if ((kind == 0 || kind == 1) && c.h0 <= 0) return BWAGPU_EINVAL;      // ksw_extend2 asserts h0 > 0 (ksw.c:420)
+		if ((kind == 0 || kind == 1 || kind >= 6) && c.h0 <= 0) return BWAGPU_EINVAL;      // ksw_extend2 asserts h0 > 0 (ksw.c:420)
 		if (c.q_len > max_q) max_q = c.q_len;
 		if (c.w > max_w) max_w = c.w;
 	}
@@ -1614,6 +1624,10 @@ extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, i
 			const int q_cap = dbg_blk && 8 * ring_cols + 32 + ((max_q + 15) & ~15) <= 65536 ? (max_q + 15) & ~15 : 0;
 			if (dbg_blk) hipLaunchKernelGGL(k_debug_global_ring<true>, dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), ring_cols, d_out.as<i32>(), q_cap);
 			else hipLaunchKernelGGL(k_debug_global_ring<false>, dim3(grid), dim3(64), (size_t)8 * ring_cols + 32 + q_cap, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), ring_cols, d_out.as<i32>(), q_cap);
+		} else if (kind == 6 || kind == 7) {
+			const int g4 = (n_cases + 3) / 4 < 2048 ? (n_cases + 3) / 4 : 2048;
+			if (kind == 6) hipLaunchKernelGGL((k_debug_extpack<4>), dim3(g4), dim3(64), (size_t)XP_LDS_BYTES, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), d_out.as<i32>());
+			else hipLaunchKernelGGL((k_debug_extpack<8>), dim3(g4), dim3(64), (size_t)XP_LDS_BYTES, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), d_out.as<i32>());
 		} else if (kind == 5) {
 			int max_t = 1; for (int i = 0; i < n_cases; ++i) if (cases[i].t_len > max_t) max_t = cases[i].t_len;
 			i64 z_cap = ((i64)max_t + 16) * ((CIGL_MAX_COLS + 15) & ~15); z_cap = (z_cap + 15) & ~(i64)15;

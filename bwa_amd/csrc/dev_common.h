@@ -93,13 +93,14 @@ struct Counters {          // device-side bump allocators + flags
 	HotCounter next_ext_;    // work counter of the wave extension kernel (position in Batch::order)
 	HotCounter next_seedsw_; // work counter of the wave-per-read seed re-scoring kernel (long reads)
 	HotCounter next_chain_, next_dedup_;       // work counters of the chaining and de-duplication kernels
+	HotCounter next_pack_;                     // ... and of the packed-extension kernel (k_ext_pack)
 	HotCounter cig_ext_used_;                  // operations written to the batch's CIGAR operation array (records with more than 6 operations)
 	unsigned long long intv_used;
 	unsigned long long overflow;   // bit0 intv, bit1 seed, bit2 node, bit3 reg, bit4 tmp-intv scratch
 	// algorithmic work counters (bwagpu_stats_t)
 	unsigned long long n_intv, n_chains, n_regs_raw, n_regs;
 	unsigned long long occ_blocks, lf_steps, ext_calls, ext_cells, glb_calls, glb_cells, ref_bases, sw_calls, sw_cells, tab_lookups;
-	unsigned long long prof[16];                   // diagnostics (bwagpu_debug_prof): k_seed's stats instance: [2] lane-slots of lanes out of reads, [3] of lanes waiting in a bookkeeping state, [4] of lanes running it, [5] sum over waves of the iteration at which the first lane ran out of reads, [6] iterations of the longest wave, [7] waves that did any work; [9] read windows k_seed fetched a step ahead (MRG 2, reads without an LDS copy), [10] k_seed lane steps that take an interval-stack entry from HBM scratch, [11] those served by an entry fetched a step ahead (MRG 2), [12] k_seed iterations that read the interval stack from HBM, [13..15] its wave iterations, bookkeeping iterations, extending lanes (stats runs)
+	unsigned long long prof[16];                   // diagnostics (bwagpu_debug_prof): k_seed's stats instance: [2] lane-slots of lanes out of reads, [3] of lanes waiting in a bookkeeping state, [4] of lanes running it, [5] sum over waves of the iteration at which the first lane ran out of reads, [6] iterations of the longest wave, [7] waves that did any work; [8] extensions answered by k_ext_pack; [9] read windows k_seed fetched a step ahead (MRG 2, reads without an LDS copy), [10] k_seed lane steps that take an interval-stack entry from HBM scratch, [11] those served by an entry fetched a step ahead (MRG 2), [12] k_seed iterations that read the interval stack from HBM, [13..15] its wave iterations, bookkeeping iterations, extending lanes (stats runs)
 	unsigned long long ext_fast;                   // ksw_extend2 calls answered by the diagonal rule (no DP)
 	unsigned long long bt_nodes, chain_recs;       // B-tree nodes visited by look-ups / chain records touched (k_chain's algorithmic bytes)
 	unsigned long long wave_hist[2][96];           // stats runs of k_extend_wave [0] / k_dedup_wave [1]: reads by floor(log2(time the wave spent on the read, in 10 ns units)) + 1; then, per bin, the DP calls and the DP cells (>> 10) of those reads (bwagpu_debug_hist)
@@ -124,6 +125,7 @@ struct Counters {          // device-side bump allocators + flags
 #define next_seedsw next_seedsw_.v
 #define next_chain next_chain_.v
 #define next_dedup next_dedup_.v
+#define next_pack next_pack_.v
 #define cig_ext_used cig_ext_used_.v
 
 // Sub-arrays of one read's private region (n = its number of seed slots); offsets keep every array naturally aligned.
@@ -214,6 +216,7 @@ struct Batch {
 	// that the few reads with thousands of seeds start first and lanes of a wave get reads of similar cost
 	int chain_flt_lds;         // chains up to which the chain filter's arrays live in LDS (<= CW_FLT_LDS)
 	int chain_regs;            // option chain_regs: 0 = every read is chained in the B-tree form, 1 = register form up to 64 chains, 2 = up to 256
+	int ext_plan;              // k_ext_pack has run: every chain's ExtPlan record (dev_extp.h) is in place of the chain pool, k_extend_wave takes windows, seed orders and answered extensions from there
 	i32 *order;                // [n_reads] permutation of read indices
 	u32 *bin_cnt;              // [2 * ORDER_BINS]: counts, then fill cursors / starts
 };

@@ -8,6 +8,7 @@
 // at it; everything else is the product code, called exactly as the product kernels call it.
 #pragma once
 #include "dev_extw.h"
+#include "dev_extp.h"
 #include "dev_cigar.h"
 #include "dev_dedupw.h"
 #include "dev_matesw.h"
@@ -62,6 +63,43 @@ template <bool RING> __global__ void __launch_bounds__(64) k_debug_extend(DevInd
 			i32 *o = out + (size_t)k * DBG_OUT_INTS;
 			o[0] = r.score; o[1] = r.qle; o[2] = r.tle; o[3] = r.gtle; o[4] = r.gscore; o[5] = r.max_off; o[6] = (i32)fast; o[7] = (i32)cells;
 		}
+	}
+}
+
+// kind 6 / 7: the packed extension routine of k_ext_pack (dev_extp.h), four cases per wavefront, four / eight columns per lane.  out[0..5] as kind 0,
+// out[6]: answered by the diagonal rule, out[7]: 1 = the routine vouches for the result (0: outside its conditions -- the product then runs kind 0's routine)
+template <int CPL> __global__ void __launch_bounds__(64) k_debug_extpack(DevIndex ix, bwagpu_opt_t opt, int n_cases, const bwagpu_dp_case_t *cases, const u8 *seqs, i32 *out)
+{
+	HIP_DYNAMIC_SHARED(unsigned char, dbg_lds)
+	const int lane = threadIdx.x & 63, grp = lane >> 4;
+	int8_t *mat = (int8_t*)dbg_lds;
+	if (lane < 25) mat[lane] = opt.mat[lane];
+	wave_sync();
+	PackConst C;
+	C.o_del = opt.o_del; C.e_del = opt.e_del; C.o_ins = opt.o_ins; C.e_ins = opt.e_ins; C.oe_del = opt.o_del + opt.e_del; C.oe_ins = opt.o_ins + opt.e_ins;
+	C.zdrop = opt.zdrop; C.mat = mat; C.prof = (int8_t*)(dbg_lds + 32); C.mat_max = opt_mat_max(opt);
+	for (int base = blockIdx.x * 4; base < n_cases; base += gridDim.x * 4) {
+		const int k = base + grp;
+		PackState<CPL> S;
+		#pragma unroll
+		for (int c = 0; c < CPL; ++c) { S.H[c] = 0; S.E[c] = 0; }
+		S.run = 0; S.done = 0; S.valid = 0; S.i = 0; S.end = 0; S.qlen = 1; S.tlen = 0; S.w = 0; S.h0 = 1; S.max = 0; S.max_i = S.max_j = S.max_ie = -1; S.gscore = -1; S.max_off = 0;
+		S.tdir = 1; S.t0 = 0; S.tpack = 0; S.tnext = 0; S.lq = 0; S.sq = 0;
+		u64 fast = 0;
+		{
+			const bwagpu_dp_case_t c = cases[k < n_cases ? k : n_cases - 1];
+			PackTask T;
+			T.q = seqs + c.q_off; T.qlen = c.q_len; T.tlen = c.t_len; T.w = c.w; T.end_bonus = c.end_bonus; T.h0 = c.h0;
+			dbg_case_geometry(c, ix.l_pac, T.q0, T.qdir, T.t0, T.tdir);
+			pack_init<CPL>(ix, C, T, S, k < n_cases, fast);
+		}
+		while (__ballot(S.run != 0)) pack_row<CPL>(ix, C, S);
+		if (k < n_cases && (lane & 15) == 0) {
+			const ExtRes r = pack_result(S);
+			i32 *o = out + (size_t)k * DBG_OUT_INTS;
+			o[0] = r.score; o[1] = r.qle; o[2] = r.tle; o[3] = r.gtle; o[4] = r.gscore; o[5] = r.max_off; o[6] = (i32)fast; o[7] = S.valid;
+		}
+		wave_sync();
 	}
 }
 

@@ -647,13 +647,15 @@ DEVFN bool wave_seed_covered(const bwagpu_opt_t &opt, const bwagpu_seed_t &s, in
 // the results -- exact, tested, and a loss on hardware: for 1 M short reads the kernel is throughput-bound (49.6 ms without, 55-61 ms with the two
 // extra launches and the serial replay of the 640-chain read), and the long-read kernel's slow reads have ONE chain with many extended seeds
 // (348 ms without, 800 ms with: profiles/r04_chain_parallel_*.jsonl).  Deleted; what stayed are the wave-parallel forms of the chain's serial steps.)
-template <bool RING> __device__ void ext_chain_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const WaveLds &L, const u8 *query, int l_query, int mat_max,
-															   const bwagpu_chain_t &c, const bwagpu_seed_t *seeds, u64 *srt, int n, bwagpu_alnreg_t *av, int &n_av)
+// The reference window a chain may reach (bwamem.c:669-683, bns_fetch_seq's clamp to the contig of seeds[0]: bntseq.c:426-451) and its seeds ordered by
+// score (bwamem.c:684-685): the two wave-cooperative steps mem_chain2aln starts with.  k_ext_pack (dev_extp.h) runs them ahead of the extensions and leaves
+// the results in the chain's ExtPlan; ext_chain_wave then finds them there.
+DEVFN void chain_window_wave(const DevIndex &ix, const bwagpu_opt_t &opt, int l_query, const bwagpu_seed_t *seeds, int n, i64 &rmax0_, i64 &rmax1_)
 {
 	const int lane = opaque_lane();
 	const i64 l_pac = ix.l_pac;
 	i64 rmax0 = l_pac << 1, rmax1 = 0;
-	for (int i = lane; i < n; i += 64) {      // (bwamem.c:671-678: the chain's reference window; lanes stride over the seeds -- a long read's chain has thousands)
+	for (int i = lane; i < n; i += 64) {      // (lanes stride over the seeds -- a long read's chain has thousands)
 		const bwagpu_seed_t t = seeds[i];
 		i64 b = t.rbeg - (t.qbeg + dev_max_gap(opt, t.qbeg));
 		i64 e = t.rbeg + t.len + ((l_query - t.qbeg - t.len) + dev_max_gap(opt, l_query - t.qbeg - t.len));
@@ -671,9 +673,12 @@ template <bool RING> __device__ void ext_chain_wave(const DevIndex &ix, const bw
 		if (rmax0 < fb) rmax0 = fb;
 		if (rmax1 > fe) rmax1 = fe;
 	}
-	rmax0 = uni64(rmax0); rmax1 = uni64(rmax1);
-	ext_stat_add(L, 0, 0, 0, (u64)(rmax1 - rmax0));
-	// the seeds by score (bwamem.c:684-685): keys score << 32 | index are distinct, so the order is the keys' own whatever sorts them
+	rmax0_ = uni64(rmax0); rmax1_ = uni64(rmax1);
+}
+// the seeds by score: keys score << 32 | index are distinct, so the order is the keys' own whatever sorts them
+DEVFN void chain_sort_wave(const bwagpu_seed_t *seeds, u64 *srt, int n)
+{
+	const int lane = opaque_lane();
 	if (n <= 32) {
 		if (lane == 0) {
 			for (int i = 0; i < n; ++i) srt[i] = (u64)seeds[i].score << 32 | (u32)i;
@@ -685,6 +690,23 @@ template <bool RING> __device__ void ext_chain_wave(const DevIndex &ix, const bw
 		wave_sync();
 		wave_sort_u64(srt, n);
 	}
+}
+
+struct ExtPlan;
+// an extension k_ext_pack has answered ahead of time (dev_extp.h; null / false: none)
+DEVFN bool plan_result(const ExtPlan *plan, bool right, ExtRes &x);
+DEVFN bool plan_window(const ExtPlan *plan, i64 &rmax0, i64 &rmax1);
+
+template <bool RING> __device__ void ext_chain_wave(const DevIndex &ix, const bwagpu_opt_t &opt, const WaveLds &L, const u8 *query, int l_query, int mat_max,
+															   const bwagpu_chain_t &c, const bwagpu_seed_t *seeds, u64 *srt, int n, bwagpu_alnreg_t *av, int &n_av, const ExtPlan *plan)
+{
+	const int lane = opaque_lane();
+	i64 rmax0, rmax1;
+	if (RING || !plan_window(plan, rmax0, rmax1)) {
+		chain_window_wave(ix, opt, l_query, seeds, n, rmax0, rmax1);
+		chain_sort_wave(seeds, srt, n);
+	}
+	ext_stat_add(L, 0, 0, 0, (u64)(rmax1 - rmax0));
 	// The seeds of this chain extended so far (not skipped: srt[] != 0 among the entries behind k), KS * 64 of them in registers, lane by lane.
 	// The "other diagonal" rule below asks whether ANY of them overlaps the seed at hand: the reference walks srt[k+1 .. n) and skips the
 	// zeroed entries (bwamem.c:716-717) -- for a long read's chain of ~2500 seeds, nearly all of them skipped, that walk was n^2 / 64 steps
@@ -743,6 +765,8 @@ template <bool RING> __device__ void ext_chain_wave(const DevIndex &ix, const bw
 		if (s.qbeg) {
 			ExtRes x; x.qle = x.tle = x.gtle = 0; x.gscore = -1; x.max_off = 0; x.score = -1;
 			int tl = (int)(s.rbeg - rmax0);
+			if (!RING && k == n - 1 && plan_result(plan, false, x)) a.score = x.score;      // (answered by k_ext_pack with the band opt.w, and not a result the loop below would re-run)
+			else
 			for (int i = 0; i < 2; ++i) {
 				int prev = a.score;
 				aw0 = opt.w << i;
@@ -759,6 +783,8 @@ template <bool RING> __device__ void ext_chain_wave(const DevIndex &ix, const bw
 			ExtRes x; x.qle = x.tle = x.gtle = 0; x.gscore = -1; x.max_off = 0; x.score = -1;
 			int sc0 = a.score, qe = s.qbeg + s.len;
 			i64 re = s.rbeg + s.len;
+			if (!RING && k == n - 1 && plan_result(plan, true, x)) a.score = x.score;
+			else
 			for (int i = 0; i < 2; ++i) {
 				int prev = a.score;
 				aw1 = opt.w << i;
@@ -818,7 +844,7 @@ template <bool RING> __device__ void ext_read_wave(const DevIndex &ix, const bwa
 		int n = uni(c.n_seeds);
 		sbeg += n;
 		if (n == 0) continue;
-		ext_chain_wave<RING>(ix, opt, L, query, l_query, mat_max, c, seeds, srt, n, av, n_av);
+		ext_chain_wave<RING>(ix, opt, L, query, l_query, mat_max, c, seeds, srt, n, av, n_av, B.ext_plan ? (const ExtPlan*)((const u8*)R.chain + (size_t)ci * 64) : nullptr);
 	}
 	if (lane == 0) B.reg_n_raw[r] = n_av;
 }

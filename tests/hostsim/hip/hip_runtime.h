@@ -111,6 +111,7 @@ static inline int mock_update_dpp(int old, int src, int ctrl, int row_mask, int 
 	if (!((row_mask >> row) & 1) || !((bank_mask >> ((l & 15) >> 2)) & 1)) return old;
 	if (ctrl >= 0 && ctrl <= 0xff) s = (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3);      // quad_perm
 	else if (ctrl >= 0x111 && ctrl <= 0x11f) { int n = ctrl - 0x110; s = (l & 15) >= n ? l - n : -1; }
+	else if (ctrl >= 0x121 && ctrl <= 0x12f) { int n = ctrl - 0x120; s = (l & ~15) | (((l & 15) - n) & 15); }   // row_ror:n (rotation within the row of 16)
 	else if (ctrl == 0x138) s = l >= 1 ? l - 1 : -1;
 	else if (ctrl == 0x130) s = l < 63 ? l + 1 : -1;                                   // wave_shl:1 (the lane above)
 	else if (ctrl == 0x142) s = row >= 1 ? row * 16 - 1 : -1;

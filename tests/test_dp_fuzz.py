@@ -255,6 +255,57 @@ def run_extend(dev, kind, n, max_len, seed, need_stale, very_wide=0):
         assert stale > 0, "no case exercised the stale-cell rule"
 
 
+def pack_cases(rng, n, cols):
+    """Cases for the packed extension routine of k_ext_pack (dev_extp.h): queries of up to cols - 1 bases (and a few beyond: the routine must say
+    'not mine'), the bands mem_chain2aln asks for (w = 100, the default) and odd ones, h0 from a seed's length; targets longer than the query
+    by up to 120 rows, so that the rows after the query's end -- deletion tails that leave the band on the left one column per row -- are many;
+    unrelated stretches (the zero-trimming), exact copies (the diagonal rule), N bases, both strands and directions."""
+    cs = CaseSet()
+    for it in range(n):
+        kind = it % 6
+        qlen = int(rng.integers(1, cols + (6 if it % 17 == 0 else 0)))
+        tlen = max(1, qlen + int(rng.integers(-12, 121)))
+        t = rng.integers(0, 4, size=tlen).astype(np.uint8)
+        src = np.resize(t, qlen) if tlen < qlen else t[:qlen]
+        if kind == 0:
+            q = src.copy()
+        elif kind == 1:
+            q = rng.integers(0, 5, size=qlen).astype(np.uint8)
+        else:
+            q = _mutate(rng, src, float(rng.choice([0.01, 0.03, 0.1, 0.25])), float(rng.choice([0.0, 0.01, 0.04])))
+            q = np.resize(q, qlen) if len(q) < qlen else q[:qlen]
+        if kind == 5 and qlen > 24:
+            a = int(rng.integers(4, qlen - 12)); q = q.copy(); q[a:a + 10] = rng.integers(0, 4, size=10)
+        w = 100 if it % 3 else int(rng.choice([1, 3, 10, 31, 63, 64, 127, 200, 400]))
+        h0 = int(rng.integers(19, 140)) if it % 4 else int(rng.integers(1, 300))
+        cs.add(q, t, w, h0, int(rng.choice([5, 5, 5, 9, 0])), int(rng.integers(0, 8)))      # (end bonus 5 = mem_chain2aln's pen_clip: with 0 the band limit of ksw.c:436-443 falls below qlen - 1 and the routine declines)
+    return cs
+
+
+def run_extend_pack(dev, kind, n, seed):
+    """kind 6 / 7: out[7] says whether the routine vouches for its result; where it does, the result is ksw_extend2's.  (Where it does not the
+    product runs the one-wave routine, kind 0.)"""
+    rng = np.random.default_rng(seed)
+    cols = 64 if kind == 6 else 128
+    vouched = total = fast = 0
+    for oi, o in enumerate(_opts()):
+        cs = pack_cases(rng, n // 4, cols)
+        cases, seqs = cs.arrays()
+        out = dev.debug_dp(o, kind, cases, seqs)
+        for k, (q, t, w, h0, eb) in enumerate(cs.py):
+            total += 1
+            if len(q) > cols - 1:
+                assert out[k, 7] == 0, f"kind {kind} opt {oi} case {k}: a query of {len(q)} bases was accepted"
+            if not out[k, 7]:
+                continue
+            vouched += 1
+            exp = ref_extend(o, q, t, w, h0, eb)
+            assert out[k, :6].tolist() == exp, f"kind {kind} opt {oi} case {k}: device {out[k, :8].tolist()} reference {exp} (qlen {len(q)} tlen {len(t)} w {w} h0 {h0} eb {eb} flags {cases['flags'][k]})"
+        fast += int(out[:, 6].sum())
+    assert vouched > total * 0.3, f"only {vouched} of {total} cases were answered"
+    assert fast > 0, "no case took the diagonal shortcut"
+
+
 def global_cases(rng, n, max_len, max_cols, big_gaps=False, wide=()):
     cs = CaseSet()
     for it in range(n):
@@ -395,6 +446,12 @@ def test_sim_ring_extension_wide_bands(sim):
     run_extend(sim, 1, 60, 400, seed=41, need_stale=False, very_wide=10)
 
 
+def test_sim_extend_pack_fuzz(sim):
+    """The packed extension routine (four extensions per wavefront, a DPP row of 16 lanes each; four and eight columns per lane)."""
+    run_extend_pack(sim, 6, 240, seed=51)
+    run_extend_pack(sim, 7, 200, seed=52)
+
+
 def test_sim_global_fuzz(sim):
     run_global(sim, 2, 160, 150, 192, 13)
     run_global(sim, 3, 80, 150, 1 << 30, 14)
@@ -418,6 +475,12 @@ def gpu():
 def test_gpu_extend_fuzz(gpu):
     run_extend(gpu, 0, 5000, 400, 21, need_stale=True)
     run_extend(gpu, 0, 1000, 1000, 22, need_stale=False)
+
+
+@pytest.mark.gpu
+def test_gpu_extend_pack_fuzz(gpu):
+    run_extend_pack(gpu, 6, 8000, seed=61)
+    run_extend_pack(gpu, 7, 8000, seed=62)
 
 
 @pytest.mark.gpu

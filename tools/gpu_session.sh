@@ -1,8 +1,10 @@
-# Scratch script of a GPU session (rewritten per session, run as `gpurun -- 'python tools/seed_iter_probe.py > /dev/null 2>&1; bash tools/gpu_session.sh'`:
-# the probe builds the 3.1 Gbp index under /tmp/bwa_amd_bench, which the commands below reuse).  The shape of a typical one -- an A/B of library options
-# with result digests, then the parity suite:
-mkdir -p gpurun_out/sNN
+# Scratch script of a GPU session (rewritten per session).  Session r6-1: the bench line of the tree as it stands, then FASTQ->SAM A/Bs
+# (slots ahead of the finalize stage 0 vs 2; 12 M vs 20 M reads), then the parity suite.
+mkdir -p gpurun_out/s1
 export TMPDIR=/tmp
-(timeout 500 python tools/variant_probe.py --prefix /tmp/bwa_amd_bench/g3100000000_s42 --codes /tmp/bwa_amd_bench/g3100000000_s42.codes.npy --steps 9 "chain_regs=0" > gpurun_out/sNN/variants.log 2>&1; echo "rc $?" >> gpurun_out/sNN/variants.log)
-(timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/sNN/pytest_parity.log 2>&1; echo "rc $?" >> gpurun_out/sNN/pytest_parity.log)
-tail -n 3 gpurun_out/sNN/pytest_parity.log
+(timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/s1/bench.json 2> gpurun_out/s1/bench.err; echo "rc $?" >> gpurun_out/s1/bench.err)
+tail -n 2 gpurun_out/s1/bench.err
+(timeout 600 python tools/e2e_bench.py --pe --reads 20000000 --env ";BWAGPU_CLI_AHEAD=0;BWAGPU_CLI_AHEAD=2;BWAGPU_CLI_AHEAD=0;BWAGPU_CLI_AHEAD=4" > gpurun_out/s1/e2e_ab.log 2>&1; echo "rc $?" >> gpurun_out/s1/e2e_ab.log)
+grep "reads/s" gpurun_out/s1/e2e_ab.log
+(timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/s1/pytest_gpu.log 2>&1; echo "rc $?" >> gpurun_out/s1/pytest_gpu.log)
+tail -n 3 gpurun_out/s1/pytest_gpu.log
