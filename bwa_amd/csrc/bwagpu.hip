@@ -679,7 +679,7 @@ extern "C" int bwagpu_debug_prof(bwagpu_t *h, unsigned long long out[16])
 	Counters c;
 	if (hipMemcpy(&c, h->d_ctr.p, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return BWAGPU_EHIP;
 	for (int i = 0; i < 16; ++i) out[i] = c.prof[i];
-	out[8] = c.n_vr_ovf;       // tasks of a long-read batch's pass 1 that were redone on full-size interval stacks
+	out[8] = c.n_vr_ovf + c.prof[8];       // long-read batches: tasks of pass 1 that were redone on full-size interval stacks; short-read batches: extensions k_ext_pack answered (the one is 0 where the other counts)
 	out[0] = c.n_heavy; out[1] = c.n_p2_tasks;       // short-read batches: reads whose passes 1-2 ran as tasks, and their pass-2 searches
 	return BWAGPU_OK;
 }
@@ -1178,7 +1178,8 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			if (cfg.ext_pack && !h->stats_on && h->max_len < 65536 && opt->w > 0 && (i64)h->max_len * sc_max_all(opt) < (1 << 21)) {
 				B.ext_plan = 1;
 				const i64 pcap = share(256 * 5);
-				hipLaunchKernelGGL((k_ext_pack<5>), dim3((unsigned)(nblk < pcap ? nblk : pcap)), block, (size_t)XP_LDS_BYTES * 4, h->stream, h->ix, *opt, B);
+				if (cfg.ext_pack == 5) hipLaunchKernelGGL((k_ext_pack<5>), dim3((unsigned)(nblk < pcap ? nblk : pcap)), block, (size_t)XP_LDS_BYTES * 4, h->stream, h->ix, *opt, B);
+				else hipLaunchKernelGGL((k_ext_pack<4>), dim3((unsigned)(nblk < share(256 * 4) ? nblk : share(256 * 4))), block, (size_t)XP_LDS_BYTES * 4, h->stream, h->ix, *opt, B);
 			}
 			if (occ == 4) hipLaunchKernelGGL((k_extend_wave<false, 4>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);
 			else hipLaunchKernelGGL((k_extend_wave<false, 6>), g, block, (size_t)lds_wave * 4, h->stream, h->ix, *opt, B, lds_wave, 0);

@@ -93,7 +93,7 @@ template <int CPL> __global__ void __launch_bounds__(64) k_debug_extpack(DevInde
 			dbg_case_geometry(c, ix.l_pac, T.q0, T.qdir, T.t0, T.tdir);
 			pack_init<CPL>(ix, C, T, S, k < n_cases, fast);
 		}
-		while (__ballot(S.run != 0)) pack_row<CPL>(ix, C, S);
+		while (__ballot(S.run != 0)) pack_row<CPL, true>(ix, C, S);
 		if (k < n_cases && (lane & 15) == 0) {
 			const ExtRes r = pack_result(S);
 			i32 *o = out + (size_t)k * DBG_OUT_INTS;

@@ -25,48 +25,50 @@
 typedef uint16_t u16;
 #define XP_LIST 192        // tasks a wave plans ahead per list (the left and the right extension of a chain are never in a list at the same time)
 
-// every lane of a 16-lane DPP row receives the row's maximum / bitwise OR / sum (rotations within the row: no lane is without a source)
+// every lane of a 16-lane DPP row receives the row's maximum / bitwise OR / sum (rotations within the row: no lane is without a source).  `old` is the
+// operation's identity in every step, which lets the compiler fold each mov_dpp + op pair into one v_max_i32_dpp / v_or_b32_dpp / v_add_u32_dpp
+// (with old = v it emitted a copy, the DPP move and the operation: three instructions and a wait state per step).
 DEVFN int row_allmax(int v)
 {
-	v = imax(v, __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(8), 0xf, 0xf, false));
-	v = imax(v, __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(4), 0xf, 0xf, false));
-	v = imax(v, __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(2), 0xf, 0xf, false));
-	v = imax(v, __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(1), 0xf, 0xf, false));
+	v = imax(v, __builtin_amdgcn_update_dpp(I32_MIN, v, DPP_ROW_ROR(8), 0xf, 0xf, false));
+	v = imax(v, __builtin_amdgcn_update_dpp(I32_MIN, v, DPP_ROW_ROR(4), 0xf, 0xf, false));
+	v = imax(v, __builtin_amdgcn_update_dpp(I32_MIN, v, DPP_ROW_ROR(2), 0xf, 0xf, false));
+	v = imax(v, __builtin_amdgcn_update_dpp(I32_MIN, v, DPP_ROW_ROR(1), 0xf, 0xf, false));
 	return v;
 }
 DEVFN int row_allor(int v)
 {
-	v |= __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(8), 0xf, 0xf, false);
-	v |= __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(4), 0xf, 0xf, false);
-	v |= __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(2), 0xf, 0xf, false);
-	v |= __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(1), 0xf, 0xf, false);
+	v |= __builtin_amdgcn_update_dpp(0, v, DPP_ROW_ROR(8), 0xf, 0xf, true);
+	v |= __builtin_amdgcn_update_dpp(0, v, DPP_ROW_ROR(4), 0xf, 0xf, true);
+	v |= __builtin_amdgcn_update_dpp(0, v, DPP_ROW_ROR(2), 0xf, 0xf, true);
+	v |= __builtin_amdgcn_update_dpp(0, v, DPP_ROW_ROR(1), 0xf, 0xf, true);
 	return v;
 }
 DEVFN int row_allsum(int v)
 {
-	v += __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(8), 0xf, 0xf, false);
-	v += __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(4), 0xf, 0xf, false);
-	v += __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(2), 0xf, 0xf, false);
-	v += __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(1), 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_ROR(8), 0xf, 0xf, true);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_ROR(4), 0xf, 0xf, true);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_ROR(2), 0xf, 0xf, true);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_ROR(1), 0xf, 0xf, true);
 	return v;
 }
-// lane L of a row: maximum over the row's lanes below L (XP_NEG for the row's first lane)
+// lane L of a row: maximum over the row's lanes below L (XP_NEG for the row's first lane; v > XP_NEG everywhere)
 DEVFN int row_excl_scan_max(int v)
 {
-	v = imax(v, __builtin_amdgcn_update_dpp(XP_NEG, v, DPP_ROW_SHR(1), 0xf, 0xf, false));
-	v = imax(v, __builtin_amdgcn_update_dpp(XP_NEG, v, DPP_ROW_SHR(2), 0xf, 0xf, false));
-	v = imax(v, __builtin_amdgcn_update_dpp(XP_NEG, v, DPP_ROW_SHR(4), 0xf, 0xf, false));
-	v = imax(v, __builtin_amdgcn_update_dpp(XP_NEG, v, DPP_ROW_SHR(8), 0xf, 0xf, false));
+	v = imax(v, __builtin_amdgcn_update_dpp(I32_MIN, v, DPP_ROW_SHR(1), 0xf, 0xf, false));
+	v = imax(v, __builtin_amdgcn_update_dpp(I32_MIN, v, DPP_ROW_SHR(2), 0xf, 0xf, false));
+	v = imax(v, __builtin_amdgcn_update_dpp(I32_MIN, v, DPP_ROW_SHR(4), 0xf, 0xf, false));
+	v = imax(v, __builtin_amdgcn_update_dpp(I32_MIN, v, DPP_ROW_SHR(8), 0xf, 0xf, false));
 	return __builtin_amdgcn_update_dpp(XP_NEG, v, DPP_ROW_SHR(1), 0xf, 0xf, false);
 }
 // ... sum over the row's lanes below L (0 for the first)
 DEVFN int row_excl_scan_add(int v)
 {
-	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(1), 0xf, 0xf, false);
-	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(2), 0xf, 0xf, false);
-	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(4), 0xf, 0xf, false);
-	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(8), 0xf, 0xf, false);
-	return __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(1), 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(1), 0xf, 0xf, true);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(2), 0xf, 0xf, true);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(4), 0xf, 0xf, true);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(8), 0xf, 0xf, true);
+	return __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(1), 0xf, 0xf, true);
 }
 // the value lane `src` (0..15) of this lane's row holds
 DEVFN int row_get(int v, int src) { return __shfl(v, (int)((threadIdx.x & 48) | (unsigned)src)); }
@@ -182,13 +184,17 @@ template <int CPL> DEVFN void pack_init(const DevIndex &ix, const PackConst &C, 
 
 // ---- one DP row for every group of the wave that is running (ALL 64 lanes execute this; groups that are not running compute on stale state and
 // commit nothing) ---------------------------------------------------------------------------------------------------------------------------
-template <int CPL> DEVFN void pack_row(const DevIndex &ix, const PackConst &C, PackState<CPL> &S)
+template <int CPL, bool KEEP> DEVFN void pack_row(const DevIndex &ix, const PackConst &C, PackState<CPL> &S)
 {
+	// KEEP: a group that is not running keeps its result (the test kernel collects the four results at the end; k_ext_pack collects a group's result
+	// before the next row, so there every update is unconditional -- selects instead of branches either way: the compiler turned `if (S.run) { ... }` into
+	// a dozen register copies per row around a divergent region)
 	const int gl = (int)(threadIdx.x & 15), grp = (int)((threadIdx.x >> 4) & 3), lb = gl * CPL;
 	const int e_ins = C.e_ins, e_del = C.e_del, oe_del = C.oe_del;
+	const bool run = S.run != 0;
 	// reference bases: sixteen rows per segment, gathered from the lanes' loads; the next segment's loads are in flight meanwhile
 	{
-		const bool seg = S.run && (S.i & 15) == 0;
+		const bool seg = run && (S.i & 15) == 0;
 		if (__ballot(seg)) {
 			const u32 tp = (u32)row_allor((int)((u32)S.tnext << (2 * gl)));
 			if (seg) {
@@ -206,7 +212,7 @@ template <int CPL> DEVFN void pack_row(const DevIndex &ix, const PackConst &C, P
 	#pragma unroll
 	for (int c = 0; c < CPL; ++c) {
 		const int sc = sp[c];
-		M[c] = S.H[c] + sc * imin(S.H[c], 1);                     // ksw.c:469: a dead diagonal cell stays dead (H >= 0)
+		M[c] = __mul24(sc, imin(S.H[c], 1)) + S.H[c];             // ksw.c:469: a dead diagonal cell stays dead (H >= 0)
 		u[c] = M[c] + lane_e + (c * e_ins - C.oe_ins);             // F's seeds, each with its column's offset: F(j) = max_{k<j} u_k - (j-1) e_ins (ksw.c:480-483; not floored at 0 -- E >= 0 makes H the same)
 		en[c] = imax3(S.E[c] - e_del, M[c] - oe_del, 0);           // E(i+1,j), ksw.c:475-479
 		p[c] = c ? imax(p[c - 1], u[c]) : u[c];
@@ -230,42 +236,42 @@ template <int CPL> DEVFN void pack_row(const DevIndex &ix, const PackConst &C, P
 	int hin = __builtin_amdgcn_update_dpp(0, hk[CPL - 1], DPP_ROW_SHR(1), 0xf, 0xf, true);
 	{
 		const int hdl = S.h0 - (C.o_del + e_del * (i + 1));
-		if (gl == 0) hin = i < S.w && hdl > 0 ? hdl : 0;
+		hin = gl == 0 ? (i < S.w ? imax(hdl, 0) : 0) : hin;
 	}
 	// the to-end score's source: h of column qlen - 1 (what the reference leaves in eh[qlen].h when the band reaches the query's end)
 	int h1 = hk[0];
 	#pragma unroll
 	for (int c = 1; c < CPL; ++c) h1 = S.sq == c ? hk[c] : h1;
 	h1 = row_get(h1, S.lq);
-#ifdef XP_TRACE
-	if (S.run && gl == 0 && getenv("XP_ROWS")) fprintf(stderr, "[row] g %d i %d tb %d m %d mj %d lp %d end %d qlen %d h1 %d tpack %08x\n", grp, i, tb, kmax >> 8, kmax & 255, lpm & 255, S.end, S.qlen, h1, S.tpack);
-#endif
-	if (S.run) {
-		#pragma unroll
-		for (int c = CPL - 1; c > 0; --c) S.H[c] = hk[c - 1];
-		S.H[0] = hin;
-		#pragma unroll
-		for (int c = 0; c < CPL; ++c) S.E[c] = en[c];
-		const int m = kmax >> 8, mj = kmax & 255;
-		if (S.end == S.qlen) { if (h1 >= S.gscore) S.max_ie = i; if (h1 > S.gscore) S.gscore = h1; }      // ksw.c:486-489
-		bool stop = m == 0;                                         // ksw.c:490
-		if (!stop) {
-			if (m > S.max) {
-				int off = mj - i; if (off < 0) off = -off;
-				S.max = m; S.max_i = i; S.max_j = mj;
-				if (off > S.max_off) S.max_off = off;
-			} else if (C.zdrop > 0) {
-				const int di = i - S.max_i, dj = mj - S.max_j;
-				if (di > dj) stop = S.max - m - (di - dj) * e_del > C.zdrop;
-				else stop = S.max - m - (dj - di) * e_ins > C.zdrop;
-			}
-		}
-		// band for the next row (ksw.c:502-505): the last non-zero column is the one after the last h > 0 (m > 0: there is one)
-		const int ne = (lpm & 255) + 3;
-		S.end = ne < S.qlen ? ne : S.qlen;
-		S.i = i + 1;
-		if (stop || S.i >= S.tlen) { S.run = 0; S.done = 1; }
+	#pragma unroll
+	for (int c = CPL - 1; c > 0; --c) S.H[c] = hk[c - 1];
+	S.H[0] = hin;
+	#pragma unroll
+	for (int c = 0; c < CPL; ++c) S.E[c] = en[c];
+	const int m = kmax >> 8, mj = kmax & 255;
+	const bool upd = KEEP ? run : true;
+	{	// ksw.c:486-489 (before the m == 0 test, as there)
+		const bool at_end = upd && S.end == S.qlen;
+		S.max_ie = at_end && h1 >= S.gscore ? i : S.max_ie;
+		S.gscore = at_end ? imax(S.gscore, h1) : S.gscore;
 	}
+	const bool nm = m > S.max;                                      // (m == 0 never is: max >= h0 > 0, so ksw.c:490's break needs no test here)
+	bool stop = m == 0;
+	{
+		const int d = (i - S.max_i) - (mj - S.max_j);
+		const int pen = d > 0 ? __mul24(d, e_del) : __mul24(-d, e_ins);
+		stop = stop || (C.zdrop > 0 && !nm && S.max - m - pen > C.zdrop);      // ksw.c:494-500
+		int off = mj - i; off = imax(off, -off);
+		const bool nmu = nm && upd;
+		S.max_off = nmu ? imax(S.max_off, off) : S.max_off;
+		S.max_i = nmu ? i : S.max_i; S.max_j = nmu ? mj : S.max_j; S.max = nmu ? m : S.max;
+	}
+	// band for the next row (ksw.c:502-505): the last non-zero column is the one after the last h > 0 (m > 0: there is one)
+	S.end = imin((lpm & 255) + 3, S.qlen);
+	S.i = i + 1;
+	const bool fin = stop || i + 1 >= S.tlen;
+	S.done = KEEP ? (run ? (int)fin : S.done) : (int)(run && fin);
+	S.run = run && !fin;
 }
 
 // the finished group's result as ksw_extend2 returns it
@@ -357,9 +363,10 @@ template <int CPL> __device__ void pack_phase(const DevIndex &ix, const bwagpu_o
 	int &n_list = CPL == 4 ? Q.n4 : Q.n8;
 	u64 *list = CPL == 4 ? Q.l4 : Q.l8;
 	for (;;) {
-		// finished groups: the result goes to the chain's plan; a left extension queues the right one
-		u64 dm = __ballot(S.done != 0);
+		// finished groups: the result goes to the chain's plan; a left extension queues the right one.  Idle groups: the next task of the list.
+		const u64 dm = __ballot(S.done != 0);
 		u64 rm = __ballot(S.run != 0);
+		if (dm || (n_list > 0 && (rm | dm) != ~0ull)) {
 		for (int g = 0; g < 4; ++g) {
 			const int l0 = g * 16;
 			bool fin = (dm >> l0) & 1;
@@ -416,8 +423,10 @@ template <int CPL> __device__ void pack_phase(const DevIndex &ix, const bwagpu_o
 				if (grp == g) { S.done = 0; S.run = 0; }
 			}
 		}
-		if (!__ballot(S.run != 0)) { if (n_list == 0) break; continue; }
-		pack_row<CPL>(ix, C, S);
+		rm = __ballot(S.run != 0);
+		}
+		if (!rm) { if (n_list == 0) break; continue; }
+		pack_row<CPL, false>(ix, C, S);
 	}
 }
 

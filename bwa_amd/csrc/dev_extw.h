@@ -151,6 +151,9 @@ DEVFN void ext_stat_add(const WaveLds &L, u32 calls, u64 cells, u32 fast, u64 re
 template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, const bwagpu_opt_t &opt, int mat_max, const u8 *q, int q0, const int qdir, int qlen,
 								   i64 t0, const int tdir, int tlen, int w, int end_bonus, int h0, const WaveLds &L, u64 &cells, u64 &fast)
 {
+#ifdef BWAGPU_FAKE_DP      // measurement builds only (tools/ext_control_floor.sh): every extension "answered" at once -- what is left of the kernel is mem_chain2aln's control
+	{ ExtRes r_; r_.score = h0 + qlen; r_.qle = qlen; r_.tle = qlen < tlen ? qlen : tlen; r_.gtle = r_.tle; r_.gscore = h0 + qlen; r_.max_off = 0; return r_; }
+#endif
 	const int lane = opaque_lane();
 	const int o_del = opt.o_del, e_del = opt.e_del, o_ins = opt.o_ins, e_ins = opt.e_ins;
 	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = opt.zdrop;

@@ -95,6 +95,7 @@ extern unsigned char *mock_dyn_lds;
 
 static inline int mock_lane() { return (int)(threadIdx.x & 63); }
 static inline long long wall_clock64() { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10; }   // (the device's constant 100 MHz counter)
+static inline int __mul24(int a, int b) { return ((a << 8) >> 8) * ((b << 8) >> 8); }
 static inline int __shfl(int v, int src) { uint64_t o[64], m; mock_exchange((uint32_t)v, o, &m); return (m >> (src & 63) & 1) ? (int)(uint32_t)o[src & 63] : v; }
 static inline int __shfl_up(int v, int d) { uint64_t o[64], m; mock_exchange((uint32_t)v, o, &m); int s = mock_lane() - d; return (s >= 0 && (m >> s & 1)) ? (int)(uint32_t)o[s] : v; }
 static inline int __shfl_down(int v, int d) { uint64_t o[64], m; mock_exchange((uint32_t)v, o, &m); int s = mock_lane() + d; return (s < 64 && (m >> s & 1)) ? (int)(uint32_t)o[s] : v; }
