@@ -278,7 +278,7 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU (handles sharing the index)")
     ap.add_argument("--dense-sa", type=int, default=1, help="densify the SA on the device to this interval (0 = keep the reference's 32)")
     ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads of the single-end parity / CPU-baseline sample; the paired-end one has this many reads too")
-    ap.add_argument("--e2e-reads", type=int, default=12_000_000, help="reads of the end-to-end runs (pipeline fill and drain cost ~0.8 s whatever the length)")
+    ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end runs: 10 M pairs, BASELINE configs[2] at its stated size (pipeline fill and drain cost ~0.5 s whatever the length)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference runs (and with them the parity gate)")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (roofline.traffic then comes from profiles/pmc_latest.json and says so)")
@@ -728,7 +728,39 @@ def main():
                       "longread_reads_s": lr_.get("reads_per_s"), "rc": rc_exit}
     log("[bench] SUMMARY " + json.dumps(out["summary"]))
     sys.stdout.flush()
-    print(json.dumps(out), flush=True)      # the one JSON line, last thing on stdout (RCCL prints a version banner of its own at start-up)
+    # The line stays under 8 KB (the driver keeps a tail of stdout): explanatory strings longer than 150 characters are cut there and kept whole, with
+    # everything else, in gpurun_out/bench_full.json (and on stderr).
+    full = os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(full), exist_ok=True)
+        json.dump(out, open(full, "w"))
+    except OSError:
+        full = None
+    log("[bench] FULL " + json.dumps(out))
+
+    def slim(o, limit):
+        if isinstance(o, dict):
+            return {k_: slim(v_, limit) for k_, v_ in o.items()}
+        if isinstance(o, list):
+            return [slim(v_, limit) for v_ in o]
+        if isinstance(o, str) and len(o) > limit:
+            return o[:limit - 3] + "..."
+        return o
+    line = slim(out, 120)
+    line["full_text"] = os.path.relpath(full, ROOT) if full else None
+    # ... and, while it is still too long, secondary tables go to the file alone (least important first; the contract's fields, `roofline`,
+    # `cpu_baseline`, `parity`, `end_to_end_pe` and `summary` always stay)
+    for path in (("variants",), ("roofline", "per_kernel"), ("longread", "by_batch_size"), ("b_alg_per_read",), ("end_to_end_pe", "more_handles"), ("roofline", "traffic_detail"),
+                 ("end_to_end_se",), ("roofline", "rework"), ("longread", "end_to_end"), ("cigar_stage",), ("end_to_end_pe", "device_stage_ms_per_batch"), ("longread", "dp_cells_per_read"),
+                 ("roofline", "random_request_ceiling"), ("work_per_read",), ("index_build",), ("longread", "stage_ms")):
+        if len(json.dumps(line)) < 7900:
+            break
+        o_ = line
+        for k_ in path[:-1]:
+            o_ = o_.get(k_) if isinstance(o_, dict) else None
+        if isinstance(o_, dict) and path[-1] in o_:
+            o_[path[-1]] = "in full_text"
+    print(json.dumps(line), flush=True)      # the one JSON line, last thing on stdout (RCCL prints a version banner of its own at start-up)
     sys.exit(rc_exit)
 
 

@@ -63,6 +63,7 @@ struct bwagpu_s {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[8] = {};
+	void *reserved[3] = {nullptr, nullptr, nullptr};   // page-locked result blocks of bwagpu_batch_reserve, held until the handle's first download
 	hipEvent_t ev_wait = nullptr;    // blocking-sync event: waiting for the stream must not spin on a host core (see wait_stream)
 	std::string err;
 	BwagpuConfig cfg;               // tuning and test options (bwagpu_config.h): environment read once at creation, then bwagpu_set_option
@@ -143,12 +144,13 @@ struct ResultPool {
 	std::map<void*, size_t> live;                   // blocks handed out -> capacity
 	std::multimap<size_t, void*> idle;              // capacity -> block
 	size_t pinned = 0;
-	std::atomic<long long> on{1}, min_kb{1024};
+	std::atomic<long long> on{1}, min_kb{1024}, cap_mb{16384};
+	std::atomic<bool> warned{false};
 	std::atomic<bool> inited{false};                // settings taken from a handle's options (init_config) or, for a block asked for before any handle exists, from the environment
-	const size_t cap_total = (size_t)4 << 30;
 	void *get(size_t bytes)
 	{
-		if (!inited.exchange(true)) { BwagpuConfig c; c.from_env(); on = c.pinned_results; min_kb = c.pinned_min_kb < 0 ? 0 : c.pinned_min_kb; }
+		if (!inited.exchange(true)) { BwagpuConfig c; c.from_env(); on = c.pinned_results; min_kb = c.pinned_min_kb < 0 ? 0 : c.pinned_min_kb; cap_mb = c.pinned_cap_mb < 0 ? 0 : c.pinned_cap_mb; }
+		const size_t cap_total = (size_t)cap_mb.load() << 20;
 		const bool enabled = on.load() != 0;                       // (options pinned_results / pinned_min_kb: process-wide, set whenever a handle is created or the option is set)
 		const size_t min_bytes = (size_t)min_kb.load() << 10;
 		if (!enabled || bytes < min_bytes) return malloc(bytes ? bytes : 1);
@@ -161,7 +163,10 @@ struct ResultPool {
 			if (it != idle.end() && it->first <= want * 2) { void *p = it->second; live[p] = it->first; idle.erase(it); return p; }
 			if (pinned + want > cap_total) {           // make room: drop idle blocks, smallest first
 				while (!idle.empty() && pinned + want > cap_total) { auto b = idle.begin(); (void)hipHostFree(b->second); pinned -= b->first; idle.erase(b); }
-				if (pinned + want > cap_total) return malloc(bytes);
+				if (pinned + want > cap_total) {
+					if (!warned.exchange(true)) fprintf(stderr, "[W::bwagpu] the page-locked result pool is full (%lld MiB, option pinned_cap_mb): further results are copied through pageable memory\n", cap_mb.load());
+					return malloc(bytes);
+				}
 			}
 			pinned += want;
 		}
@@ -246,7 +251,7 @@ static void init_config(BwagpuConfig &c)
 #undef X
 	std::lock_guard<std::mutex> l(g_cfg_m);
 	for (auto &kv : g_cfg_defaults) if (long long *f = c.field(kv.first.c_str())) *f = kv.second;
-	g_results.on = c.pinned_results; g_results.min_kb = c.pinned_min_kb < 0 ? 0 : c.pinned_min_kb; g_results.inited = true;
+	g_results.on = c.pinned_results; g_results.min_kb = c.pinned_min_kb < 0 ? 0 : c.pinned_min_kb; g_results.cap_mb = c.pinned_cap_mb < 0 ? 0 : c.pinned_cap_mb; g_results.inited = true;
 }
 extern "C" int bwagpu_set_default_option(const char *key, long long value)
 {
@@ -270,6 +275,7 @@ extern "C" int bwagpu_set_option(bwagpu_t *h, const char *key, long long value)
 	*f = value;
 	if (f == &h->cfg.pinned_results) g_results.on = value;
 	if (f == &h->cfg.pinned_min_kb) g_results.min_kb = value < 0 ? 0 : value;
+	if (f == &h->cfg.pinned_cap_mb) g_results.cap_mb = value < 0 ? 0 : value;
 	return BWAGPU_OK;
 }
 extern "C" int bwagpu_get_option(const bwagpu_t *h, const char *key, long long *value)
@@ -478,6 +484,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 {
 	if (!h) return;
 	struct LastOut { ~LastOut() { if (--g_live_handles == 0) g_results.trim(); } } last_out;      // (after the handle's own buffers are gone)
+	for (void *&p_ : h->reserved) { if (p_) bwagpu_free(p_); p_ = nullptr; }
 	if (h->ibuf && --h->ibuf->refs == 0) {
 		DevBuf *ib[] = { &h->ibuf->d_bwt, &h->ibuf->d_sa, &h->ibuf->d_pac, &h->ibuf->d_ctg_off, &h->ibuf->d_ctg_len, &h->ibuf->d_ctg_alt, &h->ibuf->d_ptab, &h->ibuf->d_occ32, &h->ibuf->d_occ_sb };
 		for (DevBuf *b : ib) b->release();
@@ -899,6 +906,8 @@ static int order_reads(bwagpu_t *h, const Batch &B, const i32 *weight)
 	return 0;
 }
 
+static void release_reserved(bwagpu_t *h) { for (void *&p : h->reserved) { if (p) bwagpu_free(p); p = nullptr; } }
+
 // Allocate now what a batch of this shape will need -- read arrays, arenas, scratch, packed results: device buffers are only ever grown, so
 // the first real batch of the handle finds them in place instead of spending ~0.4 s in hipMalloc inside the pipeline.
 extern "C" int bwagpu_batch_reserve(bwagpu_t *h, int n_reads, int64_t n_bases, int max_len)
@@ -920,8 +929,9 @@ extern "C" int bwagpu_batch_reserve(bwagpu_t *h, int n_reads, int64_t n_bases, i
 	// ... and the page-locked blocks its results will be copied into (regions, CIGAR records, operation array: ~0.4 GB per 667 k reads; page-locking costs
 	// more than the copy -- ~0.2 ms per MB -- and the pool keeps what it is given back, so the handle's first batch finds them)
 	if (h->cfg.reserve_results && !g_dry_sum) {
-		void *r0 = result_alloc((size_t)tot * sizeof(bwagpu_alnreg_t)), *r1 = result_alloc((size_t)tot * sizeof(bwagpu_cigar_t)), *r2 = result_alloc((size_t)tot * 2 * 4);
-		bwagpu_free(r0); bwagpu_free(r1); bwagpu_free(r2);
+		// (held by the handle until its first download asks for blocks: handles that reserve one after another would otherwise all be handed the same three idle blocks)
+		release_reserved(h);
+		h->reserved[0] = result_alloc((size_t)tot * sizeof(bwagpu_alnreg_t)); h->reserved[1] = result_alloc((size_t)tot * sizeof(bwagpu_cigar_t)); h->reserved[2] = result_alloc((size_t)tot * 2 * 4);
 	}
 	h->n_reads = n0; h->n_bases = b0; h->max_len = m0; h->have_batch = have0; h->ran = ran0;
 	h->slot_cap = sc0; h->node_cap = nc0; h->reg_cap = rc0; h->mem_cap = mc0;
@@ -1320,6 +1330,7 @@ extern "C" int bwagpu_batch_download(bwagpu_t *h, int32_t *counts, bwagpu_alnreg
 	HIPCHK(h, wait_stream(h));
 	i64 tot = 0;
 	for (int i = 0; i < n; ++i) { dst[i] = tot; tot += cnt[i]; if (counts) counts[i] = cnt[i]; }
+	release_reserved(h);      // (the blocks bwagpu_batch_reserve page-locked for this handle go back to the pool, where the next lines find them)
 	bwagpu_alnreg_t *res = (bwagpu_alnreg_t*)result_alloc((size_t)(tot ? tot : 1) * sizeof(bwagpu_alnreg_t));
 	if (!res) return BWAGPU_ENOMEM;
 	h->phase = 31;

@@ -53,7 +53,8 @@
 	X(debug_sync,        0)    /* wait and report after every stage of bwagpu_batch_run                                                                 */ \
 	X(reserve_results,   1)    /* bwagpu_batch_reserve also page-locks the result blocks of a batch of that shape (0: the first download does; A/B)      */ \
 	X(pinned_results,    1)    /* PROCESS-WIDE (the result pool is shared by all handles): large results in pooled page-locked blocks (0: plain malloc)  */ \
-	X(pinned_min_kb,     1024) /* PROCESS-WIDE: results below this size come from malloc (tests: 0 pools everything)                                    */
+	X(pinned_min_kb,     1024) /* PROCESS-WIDE: results below this size come from malloc (tests: 0 pools everything)                                    */ \
+	X(pinned_cap_mb,     16384)/* PROCESS-WIDE: bound of the page-locked result pool in MiB (a handle's batch of 667 k reads holds ~0.4 GB of results; five handles two batches ahead outgrew the 4 GiB of round 5 and fell back to pageable copies) */
 
 struct BwagpuConfig {
 #define X(name, dflt) long long name = dflt;

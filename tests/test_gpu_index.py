@@ -141,3 +141,27 @@ def test_big_index_hot_path_equals_compiled_reference(big):
     assert_regs_equal(*want, *gpu.align(o2, seqs, off), "seq_len > 2^32, PE mates")
     gpu.densify_sa(4)
     assert_regs_equal(*want, *gpu.align(o2, seqs, off), "seq_len > 2^32, PE mates, SA densified to 4")
+
+
+def test_big_index_cli_sam_equals_bwa_mem(big, tmp_path):
+    """`bwa-amd mem` against `bwa mem` on the seq_len > 2^32 index (GRCh38-scale SAM parity lived in bench.py only): 60 000 pairs in eight
+    batches over the command line's three device handles -- mem_pestat per batch, device CIGARs and mate rescue with reference coordinates beyond 2^32
+    (reverse-strand hits of reads from the first contigs), the dense suffix array sized against free HBM."""
+    import subprocess
+    from bwa_amd import build as b
+    need_ref()
+    gpu, ref, g, info = big
+    prefix = os.path.join(TMP, "g2200m")
+    _, cli = b.build_host(verbose=False)
+    r1, r2 = simdata.make_reads_pe(g[:400_000_000], 60000, seed=56)
+    f1, f2 = str(tmp_path / "b1.fq"), str(tmp_path / "b2.fq")
+    simdata.write_fastq(f1, r1, suffix="/1"); simdata.write_fastq(f2, r2, suffix="/2")
+    outs = []
+    for binary in (refapi.REF_BWA, cli):
+        p = subprocess.run([binary, "mem", "-K", "2400000", "-t", "16", "-v", "3", prefix, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()[-1000:]
+        if binary == cli:
+            assert p.stderr.count(b"[M::process] read ") >= 6, p.stderr.decode()[-600:]
+        outs.append(b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@PG")))
+    assert outs[0] == outs[1], "SAM on the seq_len > 2^32 index"
+    assert outs[0].count(b"\n") >= 120000
