@@ -684,6 +684,11 @@ def main():
                         out["end_to_end_pe"]["more_handles"] = {"handles": alt["handles"], "value": round(alt["reads_per_s"] / 1e6, 4), "stages": alt["stages"],
                                                                 "device_stage_ms_per_batch": alt["device_stage_ms_per_batch"], "what": f"BWAGPU_CLI_STREAMS={args.e2e_handles}, otherwise the same command"}
             if world == 1:
+                try:
+                    out["ingest_gz"] = ingest_gz(prefix, [f1, f2], threads, cache)
+                except Exception as e:
+                    out["ingest_gz"] = {"error": repr(e)}
+            if world == 1:
                 e2e = run_product(prefix, [f1], threads, None)          # (the first file alone, as single-end reads: no second copy of the sample to write)
                 if e2e:
                     out["end_to_end_se"] = {"value": round(e2e["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "stages": e2e["stages"], "stage_us_per_read": e2e["stage_us_per_read"], "what": f"the first FASTQ file alone: {n_e // 2} single-end reads"}
@@ -762,6 +767,53 @@ def main():
             o_[path[-1]] = "in full_text"
     print(json.dumps(line), flush=True)      # the one JSON line, last thing on stdout (RCCL prints a version banner of its own at start-up)
     sys.exit(rc_exit)
+
+
+def write_bgzf(path: str, data: bytes, level: int = 4):
+    """The bytes as a BGZF file (bgzip's format, SAM spec 4.1: gzip members of <= 64 KiB whose extra field BC holds the member's length) -- no bgzip here."""
+    import struct
+    import zlib
+    with open(path, "wb") as f:
+        for o in list(range(0, len(data), 65280)) + [len(data)]:          # (the last, empty block is the end-of-file marker)
+            chunk = data[o:o + 65280] if o < len(data) else b""
+            c = zlib.compressobj(level, zlib.DEFLATED, -15)
+            body = c.compress(chunk) + c.flush()
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1) + body + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+
+
+def ingest_gz(prefix, files, threads, cache, n_pairs=500_000):
+    """Compressed input: the input stage alone (`bwa-amd mem` with BWAGPU_CLI_PARSE_ONLY: read + inflate + parse, no alignment) on the first
+    n_pairs pairs of the end-to-end sample as a pair of plain gzip files (one zlib stream each: one inflating thread per file is all there can be) and as a
+    pair of BGZF files (blocks inflated by the input pool side by side)."""
+    import shutil
+    cli = os.path.join(ROOT, "bwa_amd", "bwa-amd")
+    res = {"pairs": n_pairs, "what": "input stage alone (read + inflate + parse; BWAGPU_CLI_PARSE_ONLY=1), Mreads/s: a pair of FASTQ files plain / gzip (one stream per file) / BGZF (blocks inflated in parallel)"}
+    subs = []
+    for k, f in enumerate(files):
+        with open(f, "rb") as fi:
+            data = b"".join(fi.readline() for _ in range(4 * n_pairs))
+        sub = os.path.join(cache, f"ingest_{k}.fq")
+        open(sub, "wb").write(data)
+        if shutil.which("gzip"):
+            subprocess.run(f"gzip -4 -c {sub} > {sub}.gz", shell=True, check=True)
+        write_bgzf(sub + ".bgzf.gz", data)
+        subs.append(sub)
+        del data
+    for name, ext in (("plain", ""), ("gzip", ".gz"), ("bgzf", ".bgzf.gz")):
+        fl = [s_ + ext for s_ in subs]
+        if not all(os.path.exists(x) for x in fl):
+            continue
+        p = subprocess.run([cli, "mem", "-t", str(threads), "-v", "3", prefix] + fl, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=dict(os.environ, BWAGPU_CLI_PARSE_ONLY="1"), timeout=120)
+        m = re.search(r"parsed (\d+) records \(\d+ bp\) in ([\d.]+) s", p.stderr)
+        if p.returncode == 0 and m and float(m.group(2)) > 0:
+            res[name + "_Mreads_s"] = round(int(m.group(1)) / float(m.group(2)) / 1e6, 3)
+    for s_ in subs:
+        for ext in ("", ".gz", ".bgzf.gz"):
+            try:
+                os.remove(s_ + ext)
+            except OSError:
+                pass
+    return res
 
 
 def e2e_tail_parity(args, prefix, files, r1, r2, n_e, threads, cache):

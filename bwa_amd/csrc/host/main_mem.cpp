@@ -114,20 +114,156 @@ static const char *parse_fast_record(const char *b, const char *e, Seq &s, Arena
 	return n4 + 1;
 }
 
+// A small pool of worker threads for the input stage: parsing blocks of plain FASTQ files (ParFile) and inflating the blocks of BGZF files (BgzfPipe).
+// A task carries its owner, so that a file that is closed early can take its queued tasks back.
+struct ParPool {
+	struct Task { void *owner; std::function<void()> run; };
+	std::mutex m; std::condition_variable cv; std::deque<Task> q; bool stop = false; std::vector<std::thread> th;
+	explicit ParPool(int n) { for (int i = 0; i < n; ++i) th.emplace_back([this] { loop(); }); }
+	~ParPool() { { std::lock_guard<std::mutex> l(m); stop = true; } cv.notify_all(); for (auto &t : th) t.join(); }
+	void push(void *owner, std::function<void()> f) { { std::lock_guard<std::mutex> l(m); q.push_back(Task{owner, std::move(f)}); } cv.notify_one(); }
+	int drop(void *owner) { std::lock_guard<std::mutex> l(m); int n = 0; for (auto it = q.begin(); it != q.end();) if (it->owner == owner) { it = q.erase(it); ++n; } else ++it; return n; }
+	void loop() {
+		for (;;) {
+			Task t;
+			{
+				std::unique_lock<std::mutex> l(m);
+				cv.wait(l, [&] { return stop || !q.empty(); });
+				if (q.empty()) return;
+				t = std::move(q.front()); q.pop_front();
+			}
+			t.run();
+		}
+	}
+};
+
+// ---- BGZF input (bgzip; the block-compressed gzip of htslib): independent blocks of at most 64 KiB, each a gzip member whose header says how long it is
+// (extra field "BC", SAM spec 4.1), so the blocks of a file can be inflated side by side -- one zlib stream inflates ~210 MB/s of FASTQ on a host core,
+// 0.7 M records/s per file, which is what `bwa-amd mem` delivered for ANY gzip input ("compressed input at the product's speed").  The file is
+// mapped; one thread walks the block headers and queues groups of blocks (~0.5 MB compressed) to the pool; the reader takes the inflated groups in file
+// order.  What comes out is the same byte stream gzread would deliver (bseq_read over kseq.h's gzread, bwa.c:79-112) and goes through the same parser.
+// A plain gzip file (one stream, no block sizes) cannot be split and keeps its single inflating thread.
+struct BgzfGroup { const unsigned char *src = nullptr; size_t src_len = 0; std::vector<char> out; size_t out_len = 0; bool done = false, bad = false; };
+struct BgzfPipe {
+	int fd = -1; const unsigned char *map = nullptr; size_t size = 0; ParPool *pool = nullptr; std::string path;
+	std::mutex m; std::condition_variable cv;
+	std::deque<std::shared_ptr<BgzfGroup>> inflight; bool io_done = false, stop = false, bad = false; int pending = 0;
+	std::thread io; std::shared_ptr<BgzfGroup> cur; size_t cpos = 0;
+	// total length of the BGZF block at p (header .. trailer), or 0 if p does not start one
+	static size_t block_len(const unsigned char *p, size_t n) {
+		if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+		const size_t xlen = p[10] | (size_t)p[11] << 8;
+		if (12 + xlen > n) return 0;
+		for (size_t o = 12; o + 4 <= 12 + xlen;) {
+			const size_t sl = p[o + 2] | (size_t)p[o + 3] << 8;
+			if (p[o] == 'B' && p[o + 1] == 'C' && sl == 2 && o + 6 <= 12 + xlen) { const size_t bs = (p[o + 4] | (size_t)p[o + 5] << 8) + 1; return bs >= 12 + xlen + 8 && bs <= n ? bs : 0; }
+			o += 4 + sl;
+		}
+		return 0;
+	}
+	static bool is_bgzf(const char *fn) {
+		const int f = ::open(fn, O_RDONLY); if (f < 0) return false;
+		unsigned char h[64]; const ssize_t n = pread(f, h, sizeof h, 0); struct stat st; const bool reg = fstat(f, &st) == 0 && S_ISREG(st.st_mode);
+		::close(f);
+		if (!reg || n < 18) return false;
+		// (block_len wants the whole block in view: here only its header is, so the length is read without the bound)
+		if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+		const size_t xlen = h[10] | (size_t)h[11] << 8;
+		for (size_t o = 12; o + 6 <= 12 + xlen && o + 6 <= (size_t)n;) { const size_t sl = h[o + 2] | (size_t)h[o + 3] << 8; if (h[o] == 'B' && h[o + 1] == 'C' && sl == 2) return true; o += 4 + sl; }
+		return false;
+	}
+	~BgzfPipe() {
+		{ std::lock_guard<std::mutex> l(m); stop = true; }
+		cv.notify_all();
+		if (io.joinable()) io.join();
+		if (pool) { const int n = pool->drop(this); std::unique_lock<std::mutex> l(m); pending -= n; cv.wait(l, [&] { return pending == 0; }); }
+		if (map) munmap((void*)map, size);
+		if (fd >= 0) ::close(fd);
+	}
+	bool open(const char *fn, ParPool *pl) {
+		fd = ::open(fn, O_RDONLY); if (fd < 0) return false;
+		struct stat st; if (fstat(fd, &st) != 0 || st.st_size <= 0) return false;
+		size = (size_t)st.st_size;
+		void *mp = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+		if (mp == MAP_FAILED) return false;
+		madvise(mp, size, MADV_SEQUENTIAL);
+		map = (const unsigned char*)mp; pool = pl; path = fn;
+		io = std::thread([this] { scan(); });
+		return true;
+	}
+	static void inflate_group(BgzfGroup &G) {
+		size_t want = 0;
+		for (size_t o = 0; o < G.src_len;) { const size_t bl = block_len(G.src + o, G.src_len - o); if (!bl) { G.bad = true; return; } const unsigned char *t = G.src + o + bl - 4; want += t[0] | (size_t)t[1] << 8 | (size_t)t[2] << 16 | (size_t)t[3] << 24; o += bl; }
+		if (G.out.size() < want) G.out.resize(want);
+		z_stream z; memset(&z, 0, sizeof z);
+		if (inflateInit2(&z, -15) != Z_OK) { G.bad = true; return; }
+		size_t w = 0;
+		for (size_t o = 0; o < G.src_len && !G.bad;) {
+			const size_t bl = block_len(G.src + o, G.src_len - o);
+			const unsigned char *b = G.src + o, *t = b + bl - 8;
+			const size_t xlen = b[10] | (size_t)b[11] << 8, isize = t[4] | (size_t)t[5] << 8 | (size_t)t[6] << 16 | (size_t)t[7] << 24;
+			const uint32_t crc = t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+			z.next_in = (Bytef*)(b + 12 + xlen); z.avail_in = (uInt)(bl - 12 - xlen - 8);
+			Bytef spare[8];                                            // (an empty block -- bgzip's end-of-file marker -- still needs somewhere to "write")
+			z.next_out = isize ? (Bytef*)G.out.data() + w : spare; z.avail_out = isize ? (uInt)isize : (uInt)sizeof spare;
+			const int rc = inflate(&z, Z_FINISH);
+			if (rc != Z_STREAM_END || z.total_out != isize || (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)G.out.data() + w, (uInt)isize) != crc) G.bad = true;
+			w += isize; o += bl;
+			inflateReset(&z);
+		}
+		inflateEnd(&z);
+		G.out_len = w;
+	}
+	void scan() {
+		size_t off = 0;
+		const size_t group_bytes = getenv("BWAGPU_CLI_BGZF_GROUP") ? (size_t)atoll(getenv("BWAGPU_CLI_BGZF_GROUP")) : (size_t)512 << 10;   // (tests: a block per group)
+		while (off < size) {
+			{ std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return stop || inflight.size() < 16; }); if (stop) break; }
+			size_t end = off;
+			while (end < size && end - off < group_bytes) { const size_t bl = block_len(map + end, size - end); if (!bl) break; end += bl; }
+			if (end == off) { std::lock_guard<std::mutex> l(m); bad = true; break; }       // not a BGZF block where one must start: a corrupt or truncated file
+			std::shared_ptr<BgzfGroup> G(new BgzfGroup());
+			G->src = map + off; G->src_len = end - off;
+			BgzfGroup *gp = G.get();
+			{ std::lock_guard<std::mutex> l(m); inflight.push_back(G); ++pending; }
+			auto work = [this, gp] { inflate_group(*gp); std::lock_guard<std::mutex> l(m); gp->done = true; --pending; cv.notify_all(); };
+			if (pool) pool->push(this, work); else work();
+			off = end;
+		}
+		{ std::lock_guard<std::mutex> l(m); io_done = true; }
+		cv.notify_all();
+	}
+	// the next bytes of the inflated stream (blocking; in file order): > 0 bytes, 0 at the end, -1 for a damaged file
+	int read(char *dst, size_t cap) {
+		for (;;) {
+			if (cur && cpos < cur->out_len) { const size_t n = cur->out_len - cpos < cap ? cur->out_len - cpos : cap; memcpy(dst, cur->out.data() + cpos, n); cpos += n; return (int)n; }
+			cur.reset();
+			std::unique_lock<std::mutex> l(m);
+			cv.wait(l, [&] { return (!inflight.empty() && inflight.front()->done) || (inflight.empty() && io_done); });
+			if (inflight.empty()) return bad ? -1 : 0;
+			cur = std::move(inflight.front()); inflight.pop_front(); cpos = 0;
+			l.unlock(); cv.notify_all();
+			if (cur->bad) return -1;
+		}
+	}
+};
+
 struct Reader {
+	std::unique_ptr<BgzfPipe> bg;      // a BGZF file: blocks inflated by the pool (else fp / raw_fd)
 	gzFile fp = nullptr; int raw_fd = -1; std::vector<char> buf; int pos = 0, len = 0; int last = 0; bool eof = false;
 	// The file is read (and, for gzip input, inflated) by a thread of its own, one buffer ahead of the parser: inflating a FASTQ stream
 	// costs several times what parsing it does, and for paired input the two files' streams then inflate side by side.
 	std::thread ahead; std::mutex m; std::condition_variable cv;
 	std::vector<char> nbuf; int nlen = 0; bool nfull = false, stop = false;
 	~Reader() {
-		if (ahead.joinable()) { { std::lock_guard<std::mutex> l(m); stop = true; } cv.notify_all(); ahead.join(); }
+		if (ahead.joinable()) { { std::lock_guard<std::mutex> l(m); stop = true; } cv.notify_all(); ahead.join(); }      // (a read in flight completes: the pipe below is still alive)
+		bg.reset();
 		if (fp) gzclose(fp); else if (raw_fd >= 0) ::close(raw_fd);
 	}
 	// A regular file that does not start with the gzip magic is read with read(2) straight into the buffer: zlib's transparent mode
 	// would copy every byte twice more.  Everything else (gzip files, stdin) goes through zlib as in the reference (kseq.h over gzread,
 	// fastmap.c:357-372).
-	bool open(const char *fn) {
+	bool open(const char *fn, ParPool *pool = nullptr) {
 		size_t cap = 1 << 20;
 		if (getenv("BWAGPU_CLI_BUF")) { cap = (size_t)atoll(getenv("BWAGPU_CLI_BUF")); if (cap < 8) cap = 8; }   // (tests: records that straddle buffer ends)
 		buf.resize(cap); nbuf.resize(cap);
@@ -137,6 +273,11 @@ struct Reader {
 			unsigned char magic[2] = { 0, 0 };
 			struct stat st;
 			if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && pread(fd, magic, 2, 0) >= 0 && !(magic[0] == 0x1f && magic[1] == 0x8b)) { raw_fd = fd; return true; }
+			if (pool && !getenv("BWAGPU_CLI_NO_BGZF") && BgzfPipe::is_bgzf(fn)) {
+				bg.reset(new BgzfPipe());
+				if (bg->open(fn, pool)) { ::close(fd); return true; }
+				bg.reset();
+			}
 			fp = gzdopen(fd, "r");
 			if (!fp) ::close(fd);
 		} else fp = gzdopen(fileno(stdin), "r");
@@ -145,7 +286,8 @@ struct Reader {
 	}
 	int read_some(char *dst, size_t cap) {
 		int n;
-		if (raw_fd >= 0) { do n = (int)::read(raw_fd, dst, cap); while (n < 0 && errno == EINTR); }
+		if (bg) n = bg->read(dst, cap);
+		else if (raw_fd >= 0) { do n = (int)::read(raw_fd, dst, cap); while (n < 0 && errno == EINTR); }
 		else n = gzread(fp, dst, (unsigned)cap);
 		return n;
 	}
@@ -168,6 +310,7 @@ struct Reader {
 		}
 		cv.notify_all();
 		pos = 0;
+		if (len < 0 && bg) { fprintf(stderr, "[E::%s] `%s' is a damaged or truncated BGZF file (a block does not inflate to its recorded size and checksum)\n", "main_mem", bg->path.c_str()); exit(EXIT_FAILURE); }
 		if (len <= 0) { len = 0; eof = true; return false; }
 		return true;
 	}
@@ -267,13 +410,6 @@ static std::shared_ptr<ParBlock> new_block()
 	if (!b) b = new ParBlock();
 	return std::shared_ptr<ParBlock>(b, [](ParBlock *x) { std::lock_guard<std::mutex> l(g_blk_m); if (g_blk_pool.size() < 256) g_blk_pool.push_back(x); else delete x; });
 }
-struct ParFile;
-struct ParPool {
-	std::mutex m; std::condition_variable cv; std::deque<std::pair<ParFile*, ParBlock*>> q; bool stop = false; std::vector<std::thread> th;
-	explicit ParPool(int n) { for (int i = 0; i < n; ++i) th.emplace_back([this] { run(); }); }
-	~ParPool() { { std::lock_guard<std::mutex> l(m); stop = true; } cv.notify_all(); for (auto &t : th) t.join(); }
-	void run();
-};
 struct ParFile {
 	std::string path; int fd = -1; const char *map = nullptr; size_t size = 0; size_t blk = (size_t)4 << 20; ParPool *pool = nullptr;
 	std::mutex m; std::condition_variable cv;
@@ -289,11 +425,9 @@ struct ParFile {
 		{ std::lock_guard<std::mutex> l(m); stop = true; }
 		cv.notify_all();
 		if (io.joinable()) io.join();
-		{	// blocks of this file still waiting in the pool's queue are taken back; those being parsed are waited for
-			std::lock_guard<std::mutex> lp(pool->m);
-			for (auto it = pool->q.begin(); it != pool->q.end();) if (it->first == this) { it = pool->q.erase(it); std::lock_guard<std::mutex> l(m); --pending; } else ++it;
-		}
+		const int taken = pool->drop(this);      // blocks of this file still waiting in the pool's queue are taken back; those being parsed are waited for
 		std::unique_lock<std::mutex> l(m);
+		pending -= taken;
 		cv.wait(l, [&] { return pending == 0; });
 	}
 	// the last position in [1, n) that starts a line with '@' and whose next-but-one line starts with '+' (0: none)
@@ -310,6 +444,14 @@ struct ParFile {
 			if (e2[1] == '+') return ls;
 		}
 		return 0;
+	}
+	void parse_block(ParBlock &B) {
+		const char *b = B.raw, *e = b + B.len, *p = b;
+		if (B.text.capacity() < B.len) B.text.reserve(B.len + 1024);
+		Seq s;
+		while (p < e) { const char *nx = parse_fast_record(p, e, s, B.text); if (!nx) break; B.seqs.push_back(s); p = nx; }
+		B.end_at = (size_t)(p - b);
+		std::lock_guard<std::mutex> l(m); B.parsed = true; --pending; cv.notify_all();   // (notified under the lock: shutdown() may let the file go as soon as pending is 0)
 	}
 	void read_blocks() {      // (cuts only: the file is mapped, its pages are first touched by the threads that parse them)
 		size_t off = 0;
@@ -330,8 +472,7 @@ struct ParFile {
 			const bool end = eof || B->whole;
 			ParBlock *raw_ptr = B.get();
 			{ std::lock_guard<std::mutex> l(m); inflight.push_back(B); ++pending; }
-			{ std::lock_guard<std::mutex> lp(pool->m); pool->q.emplace_back(this, raw_ptr); }
-			pool->cv.notify_one();
+			pool->push(this, [this, raw_ptr] { parse_block(*raw_ptr); });
 			if (end) break;                                          // after a block without a cut the consumer goes to the streaming reader
 		}
 		{ std::lock_guard<std::mutex> l(m); io_done = true; }
@@ -407,31 +548,12 @@ struct ParFile {
 		}
 	}
 };
-void ParPool::run()
-{
-	for (;;) {
-		std::pair<ParFile*, ParBlock*> t;
-		{
-			std::unique_lock<std::mutex> l(m);
-			cv.wait(l, [&] { return stop || !q.empty(); });
-			if (q.empty()) return;
-			t = q.front(); q.pop_front();
-		}
-		ParBlock &B = *t.second;
-		const char *b = B.raw, *e = b + B.len, *p = b;
-		if (B.text.capacity() < B.len) B.text.reserve(B.len + 1024);
-		Seq s;
-		while (p < e) { const char *nx = parse_fast_record(p, e, s, B.text); if (!nx) break; B.seqs.push_back(s); p = nx; }
-		B.end_at = (size_t)(p - b);
-		{ std::lock_guard<std::mutex> l(t.first->m); B.parsed = true; --t.first->pending; t.first->cv.notify_all(); }   // (notified under the lock: shutdown() may let the file go as soon as pending is 0)
-	}
-}
 // an input file: read in blocks when it is a plain file and a pool is given, through the streaming reader otherwise
 struct Source {
 	Reader ser; std::unique_ptr<ParFile> par;
 	bool open(const char *fn, ParPool *pool) {
 		if (pool && strcmp(fn, "-")) { par.reset(new ParFile()); if (par->open(fn, pool)) return true; par.reset(); }
-		return ser.open(fn);
+		return ser.open(fn, pool);
 	}
 	bool read(Seq &s, Arena &A, std::vector<std::shared_ptr<ParBlock>> &hold, long batch_id) { return par ? par->read(s, A, hold, batch_id) : ser.read(s, A); }
 };
@@ -938,7 +1060,10 @@ int main(int argc, char *argv[])
 	// input: BWAGPU_CLI_PARSE_THREADS parser threads for plain FASTQ files (0: the streaming reader alone).  Default 4 -- since round 5 for one device as well:
 	// its device stage lets a 667 k-read batch go every 79 ms and the streaming reader delivers one every 71-77, so every hiccup of the reader was the device's;
 	// with the blocks parsed by four threads the reader holds a batch 39-55 ms (6 M pairs: 5.67 / 5.83 -> 6.26 Mreads/s, profiles/r05_e2e_reserve_results.log)
-	const int n_parse = getenv("BWAGPU_CLI_PARSE_THREADS") ? atoi(getenv("BWAGPU_CLI_PARSE_THREADS")) : 4;
+	bool any_bgzf = false;
+	for (int k = optind + 1; k < argc && k <= optind + 2; ++k) if (strcmp(argv[k], "-") && BgzfPipe::is_bgzf(argv[k])) any_bgzf = true;
+	// (BGZF input: the pool inflates -- ~210 MB/s of FASTQ per thread --, so it gets up to eight threads, half of -t)
+	const int n_parse = getenv("BWAGPU_CLI_PARSE_THREADS") ? atoi(getenv("BWAGPU_CLI_PARSE_THREADS")) : (any_bgzf ? (opt.n_threads / 2 > 8 ? 8 : (opt.n_threads / 2 < 4 ? 4 : opt.n_threads / 2)) : 4);
 	std::unique_ptr<ParPool> parse_pool(n_parse > 0 ? new ParPool(n_parse) : nullptr);
 	Source r1, r2; Source *pr2 = nullptr;
 	if (!r1.open(argv[optind + 1], parse_pool.get())) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", "main_mem", argv[optind + 1]); return 1; }

@@ -457,3 +457,67 @@ def test_option_ranges_apply_to_defaults_and_environment(monkeypatch):
     with pytest.raises(Exception):
         s.set_option("seed_lds_ent", 17)
     s.close()
+
+
+def _write_bgzf(path, data: bytes, rng, eof_marker=True, empty_block_at=None):
+    """BGZF as bgzip writes it (SAM spec 4.1): gzip members of at most 64 KiB with the extra field BC = member length - 1; block sizes drawn at random so that
+    records straddle blocks everywhere; optionally an empty block in the middle and the 28-byte end-of-file marker."""
+    import struct
+    import zlib
+
+    def block(chunk: bytes) -> bytes:
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        bsize = 12 + 6 + len(body) + 8
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1) + body +
+                struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+    out, o, k = [], 0, 0
+    while o < len(data):
+        n = int(rng.integers(1, 65281)) if k % 3 else int(rng.integers(1, 400))
+        out.append(block(data[o:o + n])); o += n; k += 1
+        if empty_block_at is not None and k == empty_block_at:
+            out.append(block(b""))
+    if eof_marker:
+        out.append(block(b""))
+    with open(path, "wb") as f:
+        f.write(b"".join(out))
+    return len(out)
+
+
+def test_cli_bgzf_input_is_inflated_in_parallel(tmp_path):
+    """BGZF (bgzip) FASTQ files: the blocks are inflated by the input pool side by side (BgzfPipe, main_mem.cpp) and the parser must see exactly the byte
+    stream gzread delivers (bwa.c:79-112 over kseq.h): the records of the BGZF files equal the records of the plain files, whatever the grouping of
+    blocks and the parser's buffer size; the SAM equals `bwa mem`'s on the same .gz files; a plain gzip file keeps the single-stream reader; a damaged
+    block is an error, not a silently shorter input."""
+    import shutil
+    cli = _sim_cli()
+    prefix, g = testdata.small_index()
+    rng = np.random.default_rng(9)
+    r1, r2 = simdata.make_reads_pe(g, 3000, seed=410)
+    f1, f2 = str(tmp_path / "b1.fq"), str(tmp_path / "b2.fq")
+    simdata.write_fastq(f1, r1, suffix="/1"); simdata.write_fastq(f2, r2, suffix="/2")
+    n_blk = _write_bgzf(f1 + ".gz", open(f1, "rb").read(), rng, empty_block_at=3)
+    _write_bgzf(f2 + ".gz", open(f2, "rb").read(), rng, eof_marker=False)
+    assert n_blk > 20
+
+    def dump(files, **env):
+        p = subprocess.run([cli, "mem", "-v", "3", "-K", "90000", prefix] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, BWAGPU_CLI_PARSE_ONLY="2", **env))
+        assert p.returncode == 0, p.stderr.decode()[-800:]
+        return b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@"))      # (the SAM header comes first: @PG holds the file names)
+    want = dump([f1, f2])
+    assert want.count(b"\n") > 6000
+    for env in ({}, {"BWAGPU_CLI_BGZF_GROUP": "1"}, {"BWAGPU_CLI_BUF": "4099"}, {"BWAGPU_CLI_PARSE_THREADS": "1"}, {"BWAGPU_CLI_NO_BGZF": "1"}, {"BWAGPU_CLI_PARSE_THREADS": "0"}):
+        assert dump([f1 + ".gz", f2 + ".gz"], **env) == want, env
+    # the same through the aligner, against `bwa mem` reading the same BGZF files with gzread
+    if refapi.have_ref():
+        s1, s2 = str(tmp_path / "s1.fq"), str(tmp_path / "s2.fq")
+        simdata.write_fastq(s1, r1[:24], suffix="/1"); simdata.write_fastq(s2, r2[:24], suffix="/2")
+        _write_bgzf(s1 + ".gz", open(s1, "rb").read(), rng); _write_bgzf(s2 + ".gz", open(s2, "rb").read(), rng)
+        assert _run(refapi.REF_BWA, [prefix, s1 + ".gz", s2 + ".gz"]) == _run(cli, [prefix, s1 + ".gz", s2 + ".gz"])
+    # a flipped byte inside a block's compressed data
+    bad = str(tmp_path / "bad.fq.gz")
+    raw = bytearray(open(f1 + ".gz", "rb").read())
+    raw[len(raw) // 2] ^= 0x5a
+    open(bad, "wb").write(bytes(raw))
+    p = subprocess.run([cli, "mem", "-v", "3", prefix, bad], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, BWAGPU_CLI_PARSE_ONLY="1"))
+    assert p.returncode != 0 and b"BGZF" in p.stderr, p.stderr.decode()[-400:]

@@ -1,5 +1,7 @@
-# Session r6-4: what is left of k_extend_wave when every ksw_extend2 call returns at once (a -DBWAGPU_FAKE_DP build: regions are nonsense, the time is mem_chain2aln's control)
-mkdir -p gpurun_out/s4
+# Session r6-5: the GPU suite with the new tests; FASTQ->SAM at 20 M reads with 3 / 4 / 5 handles now that the result pool holds 16 GiB.
+mkdir -p gpurun_out/s5
 export TMPDIR=/tmp
-(LIB=tools/_scratch/libbwagpu_fake.so timeout 600 python tools/ext_pack_probe.py 0 0 > gpurun_out/s4/fake.log 2>&1; echo "rc $?" >> gpurun_out/s4/fake.log)
-grep -a "ext_pack\|stats run\|rc " gpurun_out/s4/fake.log
+(timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/s5/pytest_gpu.log 2>&1; echo "rc $?" >> gpurun_out/s5/pytest_gpu.log)
+tail -n 4 gpurun_out/s5/pytest_gpu.log
+(timeout 700 python tools/e2e_bench.py --pe --reads 20000000 --streams 3,4,5,3,4 --env "BWAGPU_CLI_AHEAD=0" > gpurun_out/s5/e2e_streams.log 2>&1; echo "rc $?" >> gpurun_out/s5/e2e_streams.log)
+grep "reads/s" gpurun_out/s5/e2e_streams.log
