@@ -291,7 +291,7 @@ def main():
     ap.add_argument("--long-steps", type=int, default=2)
     ap.add_argument("--long-sample", type=int, default=2000, help="reads of the long-read CPU-baseline / parity prefix (the reference does ~200 reads/s on 16 threads: ~10 s); "
                     "the product aligns them in >= 9 batches, three per device handle")
-    ap.add_argument("--e2e-handles", type=int, default=5, help="a second FASTQ->SAM run of the paired-end sample with this many batches in flight (BWAGPU_CLI_STREAMS; the default run uses 3); 0 = skip")
+    ap.add_argument("--e2e-handles", type=int, default=0, help="a second FASTQ->SAM run of the paired-end sample with this many batches in flight (BWAGPU_CLI_STREAMS; the default run uses 3); 0 = skip (the default since round 6: 4 and 5 handles measured 5.1-6.0 and 4.7 against 5.9-6.2 Mreads/s with 3, gpurun_out/s5)")
     ap.add_argument("--variants", default="ext_pack=1;seed_mrg=0;ext_occ=4;chain_regs=0", help="';'-separated library option settings (bwagpu_set_option names) to A/B against the defaults in a child process (tools/variant_probe.py); '' = none")
     ap.add_argument("--timed-sample", type=int, default=20000, help="reads of timed batch 0 whose regions are compared with the compiled reference's mem_align1_core (parity.timed_batch); 0 = skip")
     ap.add_argument("--instr-pairs", type=int, default=30000, help="pairs the counter-instrumented reference runs on (b_alg_per_read)")

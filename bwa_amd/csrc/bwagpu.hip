@@ -75,6 +75,7 @@ struct bwagpu_s {
 		// per-base arena needs learnt by any handle on this index (a re-run for arena growth doubles a batch's device time, so a
 		// cloned handle should not have to learn them again); written and read under `m`
 		std::mutex m; double need_slot = 0, need_node = 0, need_reg = 0; int need_mem = 0;
+		long batches = 0, mem_events = 0;      // batches run on this index; those that had to be redone with longer interval lists (see the end of bwagpu_batch_run)
 	};
 	IndexBufs *ibuf = nullptr;      // shared by bwagpu_clone()d handles
 	i64 l_pac = 0; int n_seqs = 0; u64 seq_len = 0; int sa_intv = 0;
@@ -1249,8 +1250,15 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			if (h->slot_cap / nbd > h->need_slot) h->need_slot = h->slot_cap / nbd;
 			if (h->node_cap / nbd > h->need_node) h->need_node = h->node_cap / nbd;
 			if (h->reg_cap / nbd > h->need_reg) h->need_reg = h->reg_cap / nbd;
-			if (h->mem_cap > h->need_mem && cfg.mem_cap <= 0) h->need_mem = h->mem_cap;
 			std::lock_guard<std::mutex> l(h->ibuf->m);
+			// The interval lists' capacity is a stride (read r's list sits at r * mem_cap), so a longer one costs every read of every later batch: four times the
+			// arena, and k_publish / k_chain_wave walking lists 24 KB apart (measured after one retry in a 20 M-read run: k_publish 2.5 -> 20 ms in the batches that
+			// followed, 16 GB per handle).  One read in ~20 million of the bench's genome leaves more than 256 intervals; redoing that one batch is the cheaper
+			// answer, so the longer lists are only kept once overflows recur (two or more, and more often than one batch in sixteen).
+			++h->ibuf->batches;
+			if (h->stats.retry_mask & 16) ++h->ibuf->mem_events;
+			const bool keep_mem = h->ibuf->mem_events >= 2 && h->ibuf->mem_events * 16 > h->ibuf->batches;
+			if (h->mem_cap > h->need_mem && cfg.mem_cap <= 0 && (keep_mem || !(h->stats.retry_mask & 16))) h->need_mem = h->mem_cap;
 			if (h->need_slot > h->ibuf->need_slot) h->ibuf->need_slot = h->need_slot;
 			if (h->need_node > h->ibuf->need_node) h->ibuf->need_node = h->need_node;
 			if (h->need_reg > h->ibuf->need_reg) h->ibuf->need_reg = h->need_reg;

@@ -1231,7 +1231,9 @@ int main(int argc, char *argv[])
 		{ std::lock_guard<std::mutex> l(dm); dcv.notify_all(); }
 	});
 
-	const long ahead = getenv("BWAGPU_CLI_AHEAD") ? atol(getenv("BWAGPU_CLI_AHEAD")) : 2;      // finished batches that may wait for the finalize stage beyond one per slot
+	// finished batches that may wait for the finalize stage beyond one per slot.  Round 5's last commit made it 2 without an A/B; round 6 measured, 20 M reads,
+	// one session each (gpurun_out/s1, s5): 0 -> 6.15 / 6.17 / 6.19 / 5.92 Mreads/s, 2 -> 6.32 / 5.60, 4 -> 4.98: no gain on average and a wider spread, back to 0
+	const long ahead = getenv("BWAGPU_CLI_AHEAD") ? atol(getenv("BWAGPU_CLI_AHEAD")) : 0;
 	std::vector<std::thread> devs;
 	for (int d = 0; d < n_work; ++d) devs.emplace_back([&, d] {      // stage 2: one host thread per slot (and, with whole batches, device)
 		// while the reader parses the first batch: the arenas of a batch of -K bases of short reads (150 bp assumed; anything else grows them
