@@ -403,6 +403,14 @@ def main():
     gpu.set_option("seed_budget", -1)
     gpu.run(opt)
     work_product = gpu.stats()
+    try:        # k_seed's stats instance counts the lane steps that fetch an interval-stack entry back from its HBM spill area (bwagpu_debug_prof[10])
+        import ctypes as C_
+        prof_ = (C_.c_ulonglong * 16)()
+        gpu.L.bwagpu_debug_prof.argtypes = [C_.c_void_p, C_.c_void_p]
+        if gpu.L.bwagpu_debug_prof(gpu.h, prof_) == 0:
+            work_product["n_stack_spill"] = int(prof_[10])
+    except Exception:
+        pass
     gpu.set_stats(False)
     gpu.run(opt)
     solo = gpu.stats()
@@ -659,6 +667,14 @@ def main():
             n_e = max(args.e2e_reads, n_batch) // 2 * 2
             r1, r2 = simdata.make_reads_pe(g, n_e // 2, length=args.read_len, seed=77)
             simdata.write_fastq(f1, r1, suffix="/1"); simdata.write_fastq(f2, r2, suffix="/2")
+            # (only the last batches' reads are needed again, by the tail gate: the 3 GB of the rest go back before the timed run -- inside this process the
+            # command line ran 5-15 % below the stand-alone tools/e2e_bench.py, whose only difference is what the parent holds)
+            per_batch_ = -(-100_000_000 // args.read_len); per_batch_ += per_batch_ & 1
+            lo_tail = max(0, -(-n_e // per_batch_) - max(0, args.tail_batches)) * per_batch_
+            r1_tail, r2_tail = r1[lo_tail // 2:].copy(), r2[lo_tail // 2:].copy()
+            del r1, r2
+            import gc
+            gc.collect()
             e2e = run_product(prefix, [f1, f2], threads, None, devices=devices)
             if e2e:
                 out["end_to_end_pe"] = {"value": round(e2e["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "n_gpus": world, "stages": e2e["stages"], "stage_us_per_read": e2e["stage_us_per_read"],
@@ -670,7 +686,7 @@ def main():
                     out["end_to_end_pe"]["vs_cpu_baseline"] = round(e2e["reads_per_s"] / ref_pe["reads_per_s"], 1)
                 if args.tail_batches > 0 and world == 1:
                     try:
-                        out["parity"]["e2e_tail"] = e2e_tail_parity(args, prefix, [f1, f2], r1, r2, n_e, threads, cache)
+                        out["parity"]["e2e_tail"] = e2e_tail_parity(args, prefix, [f1, f2], r1_tail, r2_tail, lo_tail, n_e, threads, cache)
                     except Exception as e:
                         out["parity"]["e2e_tail"] = {"ok": False, "error": repr(e)}
                     if not out["parity"]["e2e_tail"].get("ok"):
@@ -692,7 +708,7 @@ def main():
                 e2e = run_product(prefix, [f1], threads, None)          # (the first file alone, as single-end reads: no second copy of the sample to write)
                 if e2e:
                     out["end_to_end_se"] = {"value": round(e2e["reads_per_s"] / 1e6, 4), "unit": "Mreads/s", "stages": e2e["stages"], "stage_us_per_read": e2e["stage_us_per_read"], "what": f"the first FASTQ file alone: {n_e // 2} single-end reads"}
-            del r1, r2
+            del r1_tail, r2_tail
         if world == 1 and not args.no_longread:
             try:
                 out["longread"] = longread_bench(args, prefix, g, threads, cache)
@@ -816,7 +832,7 @@ def ingest_gz(prefix, files, threads, cache, n_pairs=500_000):
     return res
 
 
-def e2e_tail_parity(args, prefix, files, r1, r2, n_e, threads, cache):
+def e2e_tail_parity(args, prefix, files, r1, r2, lo_tail, n_e, threads, cache):      # (r1, r2: the pairs from read number lo_tail on)
     """Arena re-use at depth, at full batch size: the SAM of the LAST batches of the end-to-end input (every handle's last batch: its arenas, learnt sizes and
     packed buffers have been through five or six batches by then) against the compiled reference's mem_process_seqs on exactly those batches.  The reference is
     called per batch through tests/refapi.py with the batch's own n_processed -- mem_pair's tie-breaking hash takes the pair's number in the whole run
@@ -846,7 +862,7 @@ def e2e_tail_parity(args, prefix, files, r1, r2, n_e, threads, cache):
     hw = hashlib.sha256(); want_n = 0
     for bi in range(b0, n_b):
         lo, hi = bi * per_batch, min(n_e, (bi + 1) * per_batch)
-        rd = interleave(r1[lo // 2: hi // 2], r2[lo // 2: hi // 2])
+        rd = interleave(r1[(lo - lo_tail) // 2: (hi - lo_tail) // 2], r2[(lo - lo_tail) // 2: (hi - lo_tail) // 2])
         names = [f"r{(lo + i) >> 1}" for i in range(hi - lo)]
         txt = ref.process_seqs(opt, names, simdata._ASCII[rd].tobytes(), b"I" * (rd.shape[0] * L), np.arange(0, rd.shape[0] + 1, dtype=np.int64) * L, n_processed=lo)
         hw.update(txt); want_n += txt.count(b"\n")

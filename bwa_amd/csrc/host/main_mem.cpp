@@ -657,6 +657,7 @@ struct Sub {      // one mem_process_seqs call (bwamem.c:1235-1264) on the reads
 	bwagpu_matesw_t *msw = nullptr; int64_t n_msw = 0;   // device-side mate-rescue alignments (bwagpu_batch_matesw)
 	Pestat pes[4]; bool have_pes = false;     // insert-size windows, when they had to be computed before the finalize stage
 	double t_dev = 0;
+	bool quiet = false;                       // a slot's warm-up batch: no trace or mem_pestat lines
 };
 struct Work { long no = 0; Batch in; std::vector<Sub> subs; std::vector<std::string> out; bool by_read = false; /* SAM text in output order: one string per chunk of reads, or (by_read, smart pairing) per read */ };
 typedef std::unique_ptr<Work> WorkP;
@@ -710,8 +711,8 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 	std::unique_lock<std::mutex> serial(g_dev_mutex, std::defer_lock);
 	if (g_dev_serialize) serial.lock();
 	const double t0 = now_s();
-	const bool trace = getenv("BWAGPU_CLI_TRACE") != nullptr;
 	const int n = (int)u.idx.size();
+	const bool trace = getenv("BWAGPU_CLI_TRACE") != nullptr && !u.quiet;      // (not for the slots' warm-up batches: the bench scripts average these lines)
 	const bool pe = (u.opt.flag & F_PE) != 0;
 	int D = (int)gpus.size();
 	const int units = pe ? n / 2 : n, per = pe ? 2 : 1;
@@ -769,7 +770,7 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 			const double tp = now_s();
 			std::vector<int64_t> roff((size_t)n + 1, 0);
 			for (int i = 0; i < n; ++i) roff[i + 1] = roff[i] + u.counts[i];
-			pestat_flat(u.opt, ref.l_pac, n, u.all, roff.data(), u.pes, g_verbose >= 3, u.opt.n_threads < 4 ? u.opt.n_threads : 4);
+			pestat_flat(u.opt, ref.l_pac, n, u.all, roff.data(), u.pes, g_verbose >= 3 && !u.quiet, u.opt.n_threads < 4 ? u.opt.n_threads : 4);
 			t_pes = now_s() - tp;
 		});
 		u.have_pes = true;
@@ -999,6 +1000,22 @@ int main(int argc, char *argv[])
 	// ---- index: host copy for the finalize code, device copy for the hot path ----
 	const std::string prefix = argv[optind];
 	RefSeqs ref; std::string err;
+	// While the index is read and uploaded (seconds of file and device work on this thread), a helper thread page-locks the base arrays of the first batches
+	// and touches the parse blocks' text arenas: the pipeline's first batches otherwise pay for them one after the other on the two threads that pace its
+	// fill -- the encoder (hipHostMalloc of 100 MB: batch 0 took 145-180 ms there against 30-50 in the steady state) and the reader (90-130 ms against 25-45).
+	struct Prewarm { std::vector<HostBuf> flats; std::thread th; ~Prewarm() { if (th.joinable()) th.join(); } } prewarm;
+	if (!getenv("BWAGPU_CLI_NO_PREWARM")) {
+		const int64_t chunk0 = fixed_chunk > 0 ? fixed_chunk : (int64_t)opt.chunk_size * opt.n_threads;
+		const int n_flat = getenv("BWAGPU_CLI_STREAMS") ? (atoi(getenv("BWAGPU_CLI_STREAMS")) > 0 ? atoi(getenv("BWAGPU_CLI_STREAMS")) + 1 : 2) : 4;
+		const bool par_blocks = !(getenv("BWAGPU_CLI_PARSE_THREADS") && atoi(getenv("BWAGPU_CLI_PARSE_THREADS")) <= 0);
+		prewarm.th = std::thread([&prewarm, chunk0, n_flat, par_blocks] {
+			if (chunk0 > 0 && chunk0 <= ((int64_t)1 << 31)) for (int k = 0; k < n_flat && k < 6; ++k) { HostBuf b; b.need((size_t)chunk0 + (1 << 20)); prewarm.flats.push_back(std::move(b)); }
+			if (par_blocks) {
+				std::vector<std::shared_ptr<ParBlock>> hold;
+				for (int k = 0; k < 40; ++k) { hold.push_back(new_block()); Arena &t = hold.back()->text; t.reserve(((size_t)4 << 20) + 1024); t.resize(t.capacity()); for (size_t o = 0; o < t.size(); o += 4096) t[o] = 1; t.clear(); hold.back()->seqs.reserve(20000); }
+			}      // (the blocks go back to the pool new_block() draws from)
+		});
+	}
 	if (!load_refseqs(prefix, ref, err)) { fprintf(stderr, "[E::%s] fail to locate the index files: %s\n", "main_mem", err.c_str()); return 1; }
 	if (ignore_alt) for (auto &ctg : ref.ctg) ctg.is_alt = 0;
 	bwagpu_t *gpu = nullptr;
@@ -1145,6 +1162,9 @@ int main(int argc, char *argv[])
 	// text arenas and base arrays of finished batches are handed back to the reader: re-using them saves a few hundred MB of
 	// first-touch page faults per batch on the one thread that paces the pipeline
 	std::mutex pool_m; std::vector<Batch> batch_pool; std::vector<HostBuf> flat_pool; std::vector<std::vector<std::string>> out_pool;   // (and the chunk strings of written batches)
+	if (prewarm.th.joinable()) prewarm.th.join();
+	for (auto &b_ : prewarm.flats) flat_pool.push_back(std::move(b_));
+	prewarm.flats.clear();
 	std::mutex dm; std::condition_variable dcv; std::map<long, WorkP> done; long next_fin = 0;   // device -> finalize, re-ordered
 	std::atomic<long> n_works(-1), n_reads_total(0);
 	double busy_read = 0, busy_enc = 0, busy_fin = 0, busy_write = 0; std::atomic<long> busy_dev_us(0);   // per-stage busy time (-v 3 summary)
@@ -1244,6 +1264,29 @@ int main(int argc, char *argv[])
 				const int rc = bwagpu_batch_reserve(hh, (int)((int64_t)chunk / 150 / (int64_t)workers[(size_t)d].size()) + 1024, (int64_t)chunk / (int64_t)workers[(size_t)d].size() + (1 << 20), 256);
 				if (rc != BWAGPU_OK && g_verbose >= 2) fprintf(stderr, "[W::%s] could not reserve the batch arenas ahead of the first batch (%s: %s); they are grown batch by batch instead\n", "main_mem", bwagpu_strerror(rc), bwagpu_last_error(hh));
 			}
+		// ... and while the reader and the encoder are busy with the first batch (the device idles for a quarter of a second then): one small batch of reads cut from the
+		// reference itself through this slot's whole device path -- hot path, CIGARs, insert-size windows, mate rescue.  A handle's first batch otherwise pays for
+		// the first launch of every kernel (code objects are loaded on first use), the first page-locked staging and scratch buffers of the CIGAR and mate-rescue
+		// stages: batch 0 of the bench run spent 216-300 ms in its device stage where a lone batch of that size needs ~130.  The results are dropped.
+		const int warm_reads = getenv("BWAGPU_CLI_WARMUP_READS") ? atoi(getenv("BWAGPU_CLI_WARMUP_READS")) & ~1 : (g_dev_serialize ? 0 : 4096);      // (the mock runtime of the CPU tests: only on request, and small)
+		if (warm_reads > 0 && !long_preset && ref.l_pac > 100000) {
+			Sub u; u.opt = opt; u.quiet = true;
+			const int n_w = warm_reads, L_w = 150, span = 400;
+			u.idx.resize((size_t)n_w); for (int i = 0; i < n_w; ++i) u.idx[(size_t)i] = i;
+			u.off.assign((size_t)n_w + 1, 0); for (int i = 0; i < n_w; ++i) u.off[(size_t)i + 1] = u.off[(size_t)i] + L_w;
+			u.flat.need((size_t)n_w * L_w + 1); u.counts.assign((size_t)n_w, 0);
+			std::vector<uint8_t> seg;
+			const int64_t stride = (ref.l_pac - span - 1) / (n_w / 2 + 1);
+			for (int k = 0; k < n_w / 2; ++k) {      // pair k: the two ends of a 400-base stretch (forward / reverse complement), a slot's own stretches
+				const int64_t p0 = 1 + (int64_t)k * stride + (int64_t)d * 1009 % (stride > 1 ? stride : 1);
+				ref.get_seq(p0, p0 + span, seg);
+				if ((int)seg.size() < span) seg.resize((size_t)span, 0);
+				uint8_t *a = u.flat.data() + u.off[(size_t)2 * k], *b = u.flat.data() + u.off[(size_t)2 * k + 1];
+				for (int j = 0; j < L_w; ++j) { a[j] = seg[(size_t)j]; b[j] = (uint8_t)(seg[(size_t)(span - 1 - j)] < 4 ? 3 - seg[(size_t)(span - 1 - j)] : 4); }
+			}
+			device_sub(workers[(size_t)d], u, ref, pes0);
+			bwagpu_free(u.all); u.all = nullptr; bwagpu_free(u.cigs); u.cigs = nullptr; bwagpu_free(u.cig_ops); u.cig_ops = nullptr; bwagpu_free(u.msw); u.msw = nullptr;
+		}
 		WorkP w;
 		while (to_dev.pop(w)) {
 			// do not run far ahead of the host: a slot may start batch `no` while at most n_work + ahead batches before it are not finalized yet.  (Rounds 3-4: ahead = 0.

@@ -429,14 +429,31 @@ def test_cli_sa_interval_leaves_room_for_the_batches(tmp_path):
     need_mb = (per_handle * 3 * 1.15 + 2e9) / (1 << 20)
     outs = {}
     for label, free_mb, want in (("plenty", need_mb + 8.0 * seq_len / (1 << 20) + 64, "interval 1 "), ("tight", need_mb + 8.0 * seq_len / 2 / (1 << 20) + 0.7, "interval 2 "), ("none", need_mb * 0.5, "kept at the index's own interval")):
-        p = subprocess.run([cli, "mem", "-v", "3", "-K", str(K), prefix, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MOCK_HIP_FREE_MB=str(int(free_mb))))
+        p = subprocess.run([cli, "mem", "-v", "3", "-K", str(K), prefix, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, BWAGPU_CLI_SERIALIZE="1", BWAGPU_PTAB_M="6", MOCK_HIP_FREE_MB=str(int(free_mb))))
         assert p.returncode == 0, p.stderr.decode()[-2000:]
         assert want in p.stderr.decode(), (label, p.stderr.decode()[-1500:])
         outs[label] = _body(p.stdout)
     assert outs["plenty"] == outs["tight"] == outs["none"] and outs["plenty"].count(b"\n") >= 12
     # the limit a user can set does the same as a fuller device
-    p = subprocess.run([cli, "mem", "-v", "3", "-K", str(K), prefix, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, BWAGPU_CLI_HBM_LIMIT_MB=str(int(need_mb * 0.5))))
+    p = subprocess.run([cli, "mem", "-v", "3", "-K", str(K), prefix, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, BWAGPU_CLI_SERIALIZE="1", BWAGPU_PTAB_M="6", BWAGPU_CLI_HBM_LIMIT_MB=str(int(need_mb * 0.5))))
     assert p.returncode == 0 and "kept at the index's own interval" in p.stderr.decode()
+
+
+def test_cli_slot_warmup_batch_leaves_the_sam_alone(tmp_path):
+    """Every device slot of `bwa-amd mem` runs one small batch of reads cut from the reference through its whole device path while the first real batch is
+    still being read (kernels' first launches, first scratch and staging buffers): the batches that follow on the same handles -- learnt arena sizes, the
+    insert-size windows -- must produce the SAM they produce without it."""
+    if not refapi.have_ref():
+        pytest.skip("oracle/_ref not built")
+    cli = _sim_cli()
+    prefix, g = testdata.small_index()
+    r1, r2 = simdata.make_reads_pe(g, 16, seed=415)
+    f1, f2 = str(tmp_path / "w1.fq"), str(tmp_path / "w2.fq")
+    simdata.write_fastq(f1, r1, suffix="/1"); simdata.write_fastq(f2, r2, suffix="/2")
+    base = dict(os.environ, BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1", BWAGPU_PTAB_M="6")
+    want = _run(refapi.REF_BWA, ["-K", "2400", prefix, f1, f2])
+    assert _run(cli, ["-K", "2400", prefix, f1, f2], dict(base, BWAGPU_CLI_WARMUP_READS="8")) == want
+    assert _run(cli, ["-K", "2400", prefix, f1, f2], base) == want
 
 
 def test_option_ranges_apply_to_defaults_and_environment(monkeypatch):
@@ -501,7 +518,7 @@ def test_cli_bgzf_input_is_inflated_in_parallel(tmp_path):
     assert n_blk > 20
 
     def dump(files, **env):
-        p = subprocess.run([cli, "mem", "-v", "3", "-K", "90000", prefix] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, BWAGPU_CLI_PARSE_ONLY="2", **env))
+        p = subprocess.run([cli, "mem", "-v", "3", "-K", "90000", prefix] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, BWAGPU_CLI_SERIALIZE="1", BWAGPU_PTAB_M="6", BWAGPU_CLI_PARSE_ONLY="2", **env))
         assert p.returncode == 0, p.stderr.decode()[-800:]
         return b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@"))      # (the SAM header comes first: @PG holds the file names)
     want = dump([f1, f2])
@@ -513,7 +530,7 @@ def test_cli_bgzf_input_is_inflated_in_parallel(tmp_path):
         s1, s2 = str(tmp_path / "s1.fq"), str(tmp_path / "s2.fq")
         simdata.write_fastq(s1, r1[:24], suffix="/1"); simdata.write_fastq(s2, r2[:24], suffix="/2")
         _write_bgzf(s1 + ".gz", open(s1, "rb").read(), rng); _write_bgzf(s2 + ".gz", open(s2, "rb").read(), rng)
-        assert _run(refapi.REF_BWA, [prefix, s1 + ".gz", s2 + ".gz"]) == _run(cli, [prefix, s1 + ".gz", s2 + ".gz"])
+        assert _run(refapi.REF_BWA, [prefix, s1 + ".gz", s2 + ".gz"]) == _run(cli, [prefix, s1 + ".gz", s2 + ".gz"], dict(os.environ, BWAGPU_CLI_SERIALIZE="1", BWAGPU_PTAB_M="6"))
     # a flipped byte inside a block's compressed data
     bad = str(tmp_path / "bad.fq.gz")
     raw = bytearray(open(f1 + ".gz", "rb").read())

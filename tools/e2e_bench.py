@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--env", default="", help="environment sets to compare, separated by ';' (an empty set = defaults)")
     ap.add_argument("--chunk", default="100000000")
     ap.add_argument("--pe", action="store_true")
+    ap.add_argument("--hold", type=int, default=0, help="1: this (parent) process first opens a device context the way bench.py has one by the time it runs the command line -- torch.cuda, a handle on the index, closed again -- and keeps it; 2: ... and keeps the handle open")
     ap.add_argument("--cache", default=os.environ.get("BWA_AMD_CACHE", "/tmp/bwa_amd_bench"))
     a = ap.parse_args()
     import torch
@@ -35,6 +36,15 @@ def main():
         simdata.write_fastq(f1, simdata.make_reads_se(g, a.reads, seed=77))
         files = [f1]
     print(f"[e2e] inputs written in {time.time() - t:.1f}s", flush=True)
+    held = None
+    if a.hold:
+        from bwa_amd.api import BwaGpu
+        torch.zeros(1, device="cuda")
+        held = BwaGpu(fa)
+        held.densify_sa(1)
+        if a.hold == 1:
+            held.close(); held = None
+        print(f"[e2e] parent holds a device context (--hold {a.hold})", flush=True)
     cli = os.path.join(ROOT, "bwa_amd", "bwa-amd")
     for th in a.threads.split(","):
         for st in a.streams.split(","):
