@@ -657,7 +657,6 @@ struct Sub {      // one mem_process_seqs call (bwamem.c:1235-1264) on the reads
 	bwagpu_matesw_t *msw = nullptr; int64_t n_msw = 0;   // device-side mate-rescue alignments (bwagpu_batch_matesw)
 	Pestat pes[4]; bool have_pes = false;     // insert-size windows, when they had to be computed before the finalize stage
 	double t_dev = 0;
-	bool quiet = false;                       // a slot's warm-up batch: no trace or mem_pestat lines
 };
 struct Work { long no = 0; Batch in; std::vector<Sub> subs; std::vector<std::string> out; bool by_read = false; /* SAM text in output order: one string per chunk of reads, or (by_read, smart pairing) per read */ };
 typedef std::unique_ptr<Work> WorkP;
@@ -712,7 +711,7 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 	if (g_dev_serialize) serial.lock();
 	const double t0 = now_s();
 	const int n = (int)u.idx.size();
-	const bool trace = getenv("BWAGPU_CLI_TRACE") != nullptr && !u.quiet;      // (not for the slots' warm-up batches: the bench scripts average these lines)
+	const bool trace = getenv("BWAGPU_CLI_TRACE") != nullptr;
 	const bool pe = (u.opt.flag & F_PE) != 0;
 	int D = (int)gpus.size();
 	const int units = pe ? n / 2 : n, per = pe ? 2 : 1;
@@ -770,7 +769,7 @@ static void device_sub(const std::vector<bwagpu_t*> &gpus, Sub &u, const RefSeqs
 			const double tp = now_s();
 			std::vector<int64_t> roff((size_t)n + 1, 0);
 			for (int i = 0; i < n; ++i) roff[i + 1] = roff[i] + u.counts[i];
-			pestat_flat(u.opt, ref.l_pac, n, u.all, roff.data(), u.pes, g_verbose >= 3 && !u.quiet, u.opt.n_threads < 4 ? u.opt.n_threads : 4);
+			pestat_flat(u.opt, ref.l_pac, n, u.all, roff.data(), u.pes, g_verbose >= 3, u.opt.n_threads < 4 ? u.opt.n_threads : 4);
 			t_pes = now_s() - tp;
 		});
 		u.have_pes = true;
@@ -1264,29 +1263,10 @@ int main(int argc, char *argv[])
 				const int rc = bwagpu_batch_reserve(hh, (int)((int64_t)chunk / 150 / (int64_t)workers[(size_t)d].size()) + 1024, (int64_t)chunk / (int64_t)workers[(size_t)d].size() + (1 << 20), 256);
 				if (rc != BWAGPU_OK && g_verbose >= 2) fprintf(stderr, "[W::%s] could not reserve the batch arenas ahead of the first batch (%s: %s); they are grown batch by batch instead\n", "main_mem", bwagpu_strerror(rc), bwagpu_last_error(hh));
 			}
-		// ... and while the reader and the encoder are busy with the first batch (the device idles for a quarter of a second then): one small batch of reads cut from the
-		// reference itself through this slot's whole device path -- hot path, CIGARs, insert-size windows, mate rescue.  A handle's first batch otherwise pays for
-		// the first launch of every kernel (code objects are loaded on first use), the first page-locked staging and scratch buffers of the CIGAR and mate-rescue
-		// stages: batch 0 of the bench run spent 216-300 ms in its device stage where a lone batch of that size needs ~130.  The results are dropped.
-		const int warm_reads = getenv("BWAGPU_CLI_WARMUP_READS") ? atoi(getenv("BWAGPU_CLI_WARMUP_READS")) & ~1 : (g_dev_serialize ? 0 : 4096);      // (the mock runtime of the CPU tests: only on request, and small)
-		if (warm_reads > 0 && !long_preset && ref.l_pac > 100000) {
-			Sub u; u.opt = opt; u.quiet = true;
-			const int n_w = warm_reads, L_w = 150, span = 400;
-			u.idx.resize((size_t)n_w); for (int i = 0; i < n_w; ++i) u.idx[(size_t)i] = i;
-			u.off.assign((size_t)n_w + 1, 0); for (int i = 0; i < n_w; ++i) u.off[(size_t)i + 1] = u.off[(size_t)i] + L_w;
-			u.flat.need((size_t)n_w * L_w + 1); u.counts.assign((size_t)n_w, 0);
-			std::vector<uint8_t> seg;
-			const int64_t stride = (ref.l_pac - span - 1) / (n_w / 2 + 1);
-			for (int k = 0; k < n_w / 2; ++k) {      // pair k: the two ends of a 400-base stretch (forward / reverse complement), a slot's own stretches
-				const int64_t p0 = 1 + (int64_t)k * stride + (int64_t)d * 1009 % (stride > 1 ? stride : 1);
-				ref.get_seq(p0, p0 + span, seg);
-				if ((int)seg.size() < span) seg.resize((size_t)span, 0);
-				uint8_t *a = u.flat.data() + u.off[(size_t)2 * k], *b = u.flat.data() + u.off[(size_t)2 * k + 1];
-				for (int j = 0; j < L_w; ++j) { a[j] = seg[(size_t)j]; b[j] = (uint8_t)(seg[(size_t)(span - 1 - j)] < 4 ? 3 - seg[(size_t)(span - 1 - j)] : 4); }
-			}
-			device_sub(workers[(size_t)d], u, ref, pes0);
-			bwagpu_free(u.all); u.all = nullptr; bwagpu_free(u.cigs); u.cigs = nullptr; bwagpu_free(u.cig_ops); u.cig_ops = nullptr; bwagpu_free(u.msw); u.msw = nullptr;
-		}
+		// (Round 6 also ran a small warm-up batch through every slot here, while the first batch is being read -- kernels' first launches, first staging
+		// buffers.  Batch 0's hot path fell from 214 to 104 ms and the run as a whole did not move: 6.00 / 6.00 / 5.91 with, 6.21 / 6.09 / 5.90 Mreads/s without
+		// (gpurun_out/s10) -- the three slots then start together and share the chip from the first millisecond; with the CIGAR and mate-rescue stages in the
+		// warm-up it was worse, their result-sized buffers had to be grown by the first real batches and a grown buffer is a hipFree, a device-wide wait.  Removed.)
 		WorkP w;
 		while (to_dev.pop(w)) {
 			// do not run far ahead of the host: a slot may start batch `no` while at most n_work + ahead batches before it are not finalized yet.  (Rounds 3-4: ahead = 0.

@@ -439,23 +439,6 @@ def test_cli_sa_interval_leaves_room_for_the_batches(tmp_path):
     assert p.returncode == 0 and "kept at the index's own interval" in p.stderr.decode()
 
 
-def test_cli_slot_warmup_batch_leaves_the_sam_alone(tmp_path):
-    """Every device slot of `bwa-amd mem` runs one small batch of reads cut from the reference through its whole device path while the first real batch is
-    still being read (kernels' first launches, first scratch and staging buffers): the batches that follow on the same handles -- learnt arena sizes, the
-    insert-size windows -- must produce the SAM they produce without it."""
-    if not refapi.have_ref():
-        pytest.skip("oracle/_ref not built")
-    cli = _sim_cli()
-    prefix, g = testdata.small_index()
-    r1, r2 = simdata.make_reads_pe(g, 16, seed=415)
-    f1, f2 = str(tmp_path / "w1.fq"), str(tmp_path / "w2.fq")
-    simdata.write_fastq(f1, r1, suffix="/1"); simdata.write_fastq(f2, r2, suffix="/2")
-    base = dict(os.environ, BWAGPU_CLI_STREAMS="2", BWAGPU_CLI_SERIALIZE="1", BWAGPU_PTAB_M="6")
-    want = _run(refapi.REF_BWA, ["-K", "2400", prefix, f1, f2])
-    assert _run(cli, ["-K", "2400", prefix, f1, f2], dict(base, BWAGPU_CLI_WARMUP_READS="8")) == want
-    assert _run(cli, ["-K", "2400", prefix, f1, f2], base) == want
-
-
 def test_option_ranges_apply_to_defaults_and_environment(monkeypatch):
     """The range test of bwagpu_set_option also guards bwagpu_set_default_option (refused) and the environment (ignored with a warning): seed_lds_ent
     above 16 entries per lane would exceed a workgroup's dynamic LDS and fail the launch instead of the call."""

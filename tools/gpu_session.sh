@@ -1,7 +1,5 @@
-# Session r6-8: why is FASTQ->SAM slower inside bench.py than from the stand-alone tool?  The tool with and without a device context in the parent process.
-mkdir -p gpurun_out/s8
+# Session r6-10: the slots' warm-up batch without the result-sized stages, on / off (three runs each, interleaved).
+mkdir -p gpurun_out/s10
 export TMPDIR=/tmp
-(timeout 600 python tools/e2e_bench.py --pe --reads 20000000 --streams 3,3 > gpurun_out/s8/plain.log 2>&1; echo "rc $?" >> gpurun_out/s8/plain.log)
-grep "reads/s" gpurun_out/s8/plain.log
-(timeout 600 python tools/e2e_bench.py --pe --reads 20000000 --streams 3,3 --hold 1 > gpurun_out/s8/hold1.log 2>&1; echo "rc $?" >> gpurun_out/s8/hold1.log)
-grep "reads/s" gpurun_out/s8/hold1.log
+(timeout 900 python tools/e2e_bench.py --pe --reads 20000000 --streams 3 --env ";BWAGPU_CLI_WARMUP_READS=0;;BWAGPU_CLI_WARMUP_READS=0;;BWAGPU_CLI_WARMUP_READS=0" > gpurun_out/s10/warm_ab.log 2>&1; echo "rc $?" >> gpurun_out/s10/warm_ab.log)
+grep "reads/s" gpurun_out/s10/warm_ab.log
