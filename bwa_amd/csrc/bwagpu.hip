@@ -1061,6 +1061,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 		B.seedsw_minhsp = h->d_minhsp.as<i32>();
 		B.order = h->d_order.as<i32>(); B.bin_cnt = h->d_bin_cnt.as<u32>(); B.seed_w = h->d_seed_w.as<i32>(); B.seed_order = nullptr;
 		B.seed_prio = cfg.seed_prio != 0;
+		B.ext_blk = cfg.ext_blk != 0;
 		B.seed_no_virt = cfg.seed_no_virt != 0;
 		B.seed_pass3_inline = cfg.seed_pass3_inline != 0;
 		B.task_step = opt->min_seed_len; B.n_vreads = n_vreads; B.vr_ovf_run = 0; B.vr_room = 0; B.seed_stack_cap = 0; B.intv_n3 = nullptr;
@@ -1631,11 +1632,11 @@ extern "C" int bwagpu_debug_dp(bwagpu_t *h, const bwagpu_opt_t *opt, int kind, i
 		if (kind == 0) {
 			if (max_q > WAVE_EXT_MAX_LEN) { rc = BWAGPU_EINVAL; goto done; }
 			const size_t lds = (8 * (size_t)(max_q + 2 + 64) + 5 * (size_t)((max_q + 64 + 3) & ~3) + 32 + 15) & ~(size_t)15;
-			hipLaunchKernelGGL((k_debug_extend<false>), dim3(grid), dim3(64), lds, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, 0, d_out.as<i32>());
+			hipLaunchKernelGGL((k_debug_extend<false>), dim3(grid), dim3(64), lds, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, 0, d_out.as<i32>(), 0);
 		} else if (kind == 1) {
 			int ring_cols = 256; while (ring_cols < 2 * max_w + 4 + 128) ring_cols <<= 1;
 			if (ring_cols > 4096) { rc = BWAGPU_EINVAL; goto done; }
-			hipLaunchKernelGGL((k_debug_extend<true>), dim3(grid), dim3(64), (size_t)8 * ring_cols + 32, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, ring_cols, d_out.as<i32>());
+			hipLaunchKernelGGL((k_debug_extend<true>), dim3(grid), dim3(64), (size_t)8 * ring_cols + 32, h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), max_q, ring_cols, d_out.as<i32>(), (int)(h->cfg.ext_blk != 0));
 		} else if (kind == 2) {
 			hipLaunchKernelGGL(k_debug_global, dim3(grid), dim3(64), (size_t)CIG_LDS_BYTES(CIG_Z_BIG), h->stream, ix, *opt, n_cases, d_cases.as<bwagpu_dp_case_t>(), d_seq.as<u8>(), d_out.as<i32>());
 		} else if (kind == 3) {

@@ -39,6 +39,7 @@
 	X(seed_grid,         0)    /* seeding: resident workgroups of k_seed (0: fill the chip; measurements)                                               */ \
 	X(share,             -1)   /* short reads: percent of a chip-filling launch that the hot path's persistent kernels take (kernels of different batches side by side); auto: 50 when three or more handles share the index, else 100 */ \
 	X(ext_pack,          0)    /* extension, short reads: 1 / 5 = the chains' first extensions four to a wavefront ahead of k_extend_wave (k_ext_pack at 4 / 5 waves per SIMD, dev_extp.h); measured slower than a wavefront per extension (profiles/r06_ext_pack.md): off, kept as an A/B switch */ \
+	X(ext_blk,           -1)   /* extension, long reads: a row's band (up to 255 columns) in one pass, four columns per lane; auto: on (0: one pass per 64 columns, the round-3..5 form) */ \
 	X(ext_occ,           6)    /* extension: waves per SIMD the short-read kernel's register allocation aims at (4 or 6)                                */ \
 	X(chain_regs,        2)    /* chaining: the chains of a read kept in registers, one per lane, while that is exact: 2 = up to 256 chains (four per lane), 1 = up to 64, 0 = every read through the B-tree (A/B and tests) */ \
 	X(chain_flt_lds,     256)  /* chaining: reads of up to this many chains keep the weight sort's and the chain filter's arrays in LDS (at most 256; tests: 0 sends every read down the HBM path) */ \

@@ -216,6 +216,7 @@ struct Batch {
 	// that the few reads with thousands of seeds start first and lanes of a wave get reads of similar cost
 	int chain_flt_lds;         // chains up to which the chain filter's arrays live in LDS (<= CW_FLT_LDS)
 	int chain_regs;            // option chain_regs: 0 = every read is chained in the B-tree form, 1 = register form up to 64 chains, 2 = up to 256
+	int ext_blk;               // long reads (ring mode of k_extend_wave): rows of up to 255 columns in one pass, four columns per lane (option ext_blk)
 	int ext_plan;              // k_ext_pack has run: every chain's ExtPlan record (dev_extp.h) is in place of the chain pool, k_extend_wave takes windows, seed orders and answered extensions from there
 	i32 *order;                // [n_reads] permutation of read indices
 	u32 *bin_cnt;              // [2 * ORDER_BINS]: counts, then fill cursors / starts

@@ -27,12 +27,12 @@ DEVFN void dbg_case_geometry(const bwagpu_dp_case_t &c, i64 l_pac, int &q0, int 
 
 // kind 0 / 1: wave_ksw_extend2 as k_extend_wave sets it up (columns + read profile in LDS / ring mode)
 template <bool RING> __global__ void __launch_bounds__(64) k_debug_extend(DevIndex ix, bwagpu_opt_t opt, int n_cases, const bwagpu_dp_case_t *cases, const u8 *seqs,
-																			 int max_q, int ring_cols, i32 *out)
+																			 int max_q, int ring_cols, i32 *out, int blk)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, dbg_lds)
 	const int lane = threadIdx.x & 63;
 	WaveLds L;
-	L.stat = nullptr;
+	L.stat = nullptr; L.blk = RING ? blk : 0;
 	L.eh = (int2*)dbg_lds;
 	if (RING) {
 		int8_t *m = (int8_t*)(dbg_lds + (size_t)8 * ring_cols);

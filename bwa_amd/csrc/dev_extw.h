@@ -136,7 +136,7 @@ DEVFN bwagpu_seed_t uni_seed(bwagpu_seed_t s) { s.rbeg = uni64(s.rbeg); s.qbeg =
 // from a 25-entry copy of the matrix (mat) and the query bases in global memory.
 // (Round 3 also had an optional per-wave LDS copy of a long read and a four-columns-per-lane row form for long reads behind switches; on hardware the copy
 // made both long-read DP kernels 14-18 % slower -- its LDS halves the resident waves -- and the row form gained nothing, BENCH_r03 variants: both deleted.)
-struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t *mat;
+struct WaveLds { int2 *eh; int8_t *qp; int qstride; int ring_mask; const int8_t *mat; int blk; /* RING: rows of up to 255 columns in one pass, four columns per lane (option ext_blk) */
 	u32 *stat; /* stats runs: the wave's work counters in LDS -- [0..1] DP cells, [2] calls, [3] calls answered by the diagonal rule, [4..5] reference bases --; null otherwise.
 	              (As u64 registers threaded through the call chain they were ten registers live across every extension of a kernel that spills.) */ };
 DEVFN void ext_stat_add(const WaveLds &L, u32 calls, u64 cells, u32 fast, u64 refb)
@@ -216,6 +216,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 	}
 	int init_hi = -1;                                  // RING: columns 0..init_hi hold valid (initial or computed) values
 	int q_pre = 4, q_pre_beg = -1;                     // RING: the query bases of columns q_pre_beg + lane, asked for a row ahead (see the multi-pass rows)
+	int qb_bb = -8; u32 qb_w = 0, qb_n = 0;            // RING, four columns per lane: the block the packed bases qb_w belong to, and the next block's
 	int lim = trunc_div_add(qlen * mat_max + end_bonus - o_ins, e_ins, 1); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	lim = trunc_div_add(qlen * mat_max + end_bonus - o_del, e_del, 1); if (lim < 1) lim = 1; if (w > lim) w = lim;
 	w = uni(w);
@@ -494,6 +495,72 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			// starts (for the usual case that the band moves on by one column; anything else loads it here).  (Measured on 6000 x 10 kb reads: the stage's
 			// time did not move, 361-411 ms either way -- the row's dependent DPP/LDS chain at one wave per SIMD is the longer wait; kept because it is never slower.)
 			int qc_next = 4;
+			if (RING && L.blk && beg < end && end - (beg & ~3) <= 255) {
+				// Four adjacent columns per lane: the whole band of a long read's row (2 w + 1 <= 255 columns with the presets' w = 100) in ONE pass -- one pair of
+				// prefix scans, one round of ballots and lane reads per row instead of one per 64 columns.  The scalar pipe is the busy unit of this kernel
+				// (profiles/r05_longread_experiments.md): the pass loop below spends ~30 scalar instructions per pass, three to four passes per row.  A lane
+				// reads and writes its own four ring slots only (two 16-byte LDS accesses each way); H(i,j) reaches column j+1 inside the lane or, for a lane's
+				// first column, by a lane shift.  Slots outside [beg, end] are written back as they were read: the stale-cell rule.  The lane's four query bases are
+				// kept packed in a register while the band's first block stays where it is (beg & ~3 moves every ~4 rows; the next block's bases are
+				// loaded one move ahead).
+				const int bb = beg & ~3, j0 = bb + 4 * lane, pr = j0 & L.ring_mask;
+				auto qload = [&](int jb) { u32 v = 0; for (int c = 0; c < 4; ++c) { const int j = jb + c; v |= (u32)(j < qlen ? QBASE(q0 + j * qdir) : 4) << (8 * c); } return v; };
+				if (bb != qb_bb) {
+					if (bb == qb_bb + 4 && qb_bb >= 0) qb_w = qb_n; else qb_w = qload(j0);
+					qb_n = qload(j0 + 4); qb_bb = bb;
+				}
+				const int4 a0 = *(const int4*)&eh[pr], a1 = *(const int4*)&eh[pr + 2];
+				const int ox[4] = { a0.x, a0.z, a1.x, a1.z }, oy[4] = { a0.y, a0.w, a1.y, a1.w };
+				const int8_t *mrow = L.mat + tb * 5;
+				int M4[4], pre[4], run = W_NEG;
+				#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const int j = j0 + c; const bool act = j >= beg && j < end;
+					const int sc = mrow[(qb_w >> (8 * c)) & 255u];
+					M4[c] = ox[c] ? wadd(ox[c], sc) : 0;                       // ksw.c:469
+					pre[c] = run;
+					run = imax(run, act ? imax(wsub(M4[c], oe_ins), 0) + j * e_ins : W_NEG);
+				}
+				const int inc = wave_incl_scan_max(run);
+				const int exl = wave_shift_up1(inc, W_NEG);                     // best insertion start among the columns of the lanes below
+				int hv[4], en[4], key = -1; u32 nzb = 0;
+				#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const int j = j0 + c; const bool act = j >= beg && j < end;
+					const int f = j == beg ? 0 : imax(exl, pre[c]) - (j - 1) * e_ins;
+					hv[c] = imax(imax(M4[c], oy[c]), f);                       // ksw.c:470-471 (used for active columns only)
+					en[c] = imax(imax(wsub(oy[c], e_del), wsub(M4[c], oe_del)), 0);   // ksw.c:475-479
+					key = imax(key, act ? (hv[c] << 8 | (4 * lane + c)) : -1);  // last column wins ties (ksw.c:473-474)
+				}
+				const int hv3 = hv[3];
+				const int hl = wave_shift_up1(hv3, h1_init);                   // H(i, j0 - 1): the lane below's last column
+				int nx[4], ny[4];
+				#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const int j = j0 + c; const bool act = j >= beg && j < end;
+					const int hleft = c ? hv[c - 1] : hl;
+					nx[c] = j == beg ? h1_init : (j > beg && j <= end ? hleft : ox[c]);
+					ny[c] = act ? en[c] : (j == end ? 0 : oy[c]);
+					if (act && (nx[c] | ny[c]) != 0) nzb |= 1u << c;
+				}
+				*(int4*)&eh[pr] = make_int4(nx[0], ny[0], nx[1], ny[1]);
+				*(int4*)&eh[pr + 2] = make_int4(nx[2], ny[2], nx[3], ny[3]);
+				const u64 any = wave_ballot(nzb != 0);
+				if (any) {
+					const int fl = __builtin_ctzll(any), ll = 63 - __builtin_clzll(any);
+					const int lo_c = __builtin_ctz(nzb | 16u), hi_c = 31 - __builtin_clz(nzb | 1u);       // the lane's first / last non-zero slot (meaningful where nzb != 0)
+					first_nz = bb + 4 * fl + __builtin_amdgcn_readlane(lo_c, fl);
+					last_nz = bb + 4 * ll + __builtin_amdgcn_readlane(hi_c, ll);
+				}
+				const int kk = __builtin_amdgcn_readlane(wave_incl_scan_max(key), 63);
+				if (kk >= 0) { m = kk >> 8; mj = bb + (kk & 255); }
+				{	// H(i, end-1): what the reference's column loop leaves in h1
+					const int le = end - 1 - bb, se = le & 3;
+					const int hs = se == 0 ? hv[0] : (se == 1 ? hv[1] : (se == 2 ? hv[2] : hv[3]));
+					hprev = __builtin_amdgcn_readlane(hs, le >> 2);
+				}
+				wave_sync();
+			} else {
 			if (RING) {
 				const int j0 = beg + lane;
 				qc_next = (beg == q_pre_beg) ? q_pre : (j0 < qlen ? QBASE(q0 + j0 * qdir) : 4);
@@ -541,6 +608,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			}
 			if (lane == 0) { eh[EHI(end)].x = beg < end ? hprev : h1_init; eh[EHI(end)].y = 0; }
 			wave_sync();
+			}
 		}
 		const int h1 = beg < end ? hprev : h1_init;      // H(i, end-1) as left in h1 by the reference's column loop
 		const int jfin = beg < end ? end : beg;
@@ -873,6 +941,7 @@ template <bool RING, int OCC> __global__ void __launch_bounds__(256, OCC) k_exte
 		L.mat = m; L.ring_mask = 0;
 	}
 	// (the mat copy takes 25 of the 32 bytes behind the columns / the ring; the stats counters the 32 after that)
+	L.blk = RING ? B.ext_blk : 0;
 	L.stat = B.stats ? (u32*)((unsigned char*)L.mat + 32) : nullptr;
 	if (B.stats && lane < 8) ((u32*)((unsigned char*)L.mat + 32))[lane] = 0;
 	wave_sync();

@@ -421,7 +421,16 @@ def test_sim_extend_fuzz(sim):
 
 
 def test_sim_extend_ring_fuzz(sim):
+    """Ring mode (long reads) in both row forms: a row's band in one pass with four columns per lane (option ext_blk, the default since round 6) and one pass
+    per 64 columns; bands of 200-255 columns and an unrelated stretch in the middle take the one-pass form through its widest rows and its trimming."""
+    assert sim.get_option("ext_blk") == -1
     run_extend(sim, 1, 120, 160, 12, need_stale=False)
+    run_extend(sim, 1, 60, 400, 17, need_stale=False, very_wide=6)
+    sim.set_option("ext_blk", 0)
+    try:
+        run_extend(sim, 1, 120, 160, 12, need_stale=False)
+    finally:
+        sim.set_option("ext_blk", -1)
 
 
 def test_sim_ring_global_both_forms(sim):
@@ -486,6 +495,11 @@ def test_gpu_extend_pack_fuzz(gpu):
 @pytest.mark.gpu
 def test_gpu_extend_ring_fuzz(gpu):
     run_extend(gpu, 1, 5000, 400, 23, need_stale=True)
+    gpu.set_option("ext_blk", 0)
+    try:
+        run_extend(gpu, 1, 2000, 400, 28, need_stale=True)
+    finally:
+        gpu.set_option("ext_blk", -1)
 
 
 @pytest.mark.gpu
