@@ -289,11 +289,16 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 	// matters; zero cells are dead, ksw.c:469; with gscore >= 0 the band has touched the query's end, so no column still holds an unvisited first-row
 	// value).  Later rows then have m <= B and h1 <= B:  B <= max  means no row raises max / max_i / max_j / max_off (ksw.c:491: strict), and
 	// B < gscore  means none updates gscore / max_ie (ksw.c:486-489: h1 >= gscore).  The remaining exits (m == 0, z-drop) return the same values.
-	// Tested on the parked rows' flush and, near the query's end, every fourth row; the DP fuzz holds every returned field to the reference's.
+	// The test needs max and gscore, which the window rows only bring up to date every 32 rows (parked bookkeeping).  Two scalars stand in: m_run >= the
+	// largest row maximum and g_run >= the largest to-end score of ALL rows computed so far.  Without a z-drop among the parked rows they equal max and gscore;
+	// with one, the extension has already ended at that row and whatever is skipped after it was never part of the result (the flush after the loop cuts the
+	// parked rows there as always).  Tested every second row from eight rows before the query's end on, and every 32 rows before; the DP fuzz holds every
+	// returned field to the reference's.
 	const int tail_from = qlen - 8;
+	int m_run = h0, g_run = -1;
 	auto tail_done = [&](int cand) -> bool {
 		const int B = __builtin_amdgcn_readlane(wave_incl_scan_max(cand), 63);
-		return gscore >= 0 && B <= max && B < gscore;
+		return g_run >= 0 && B <= m_run && B < g_run;
 	};
 	int i = 0;
 	while (i < tlen) {
@@ -319,7 +324,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 				// a segment: rows up to the next multiple of 64 (the reference bases in treg), the 32nd parked row, or the last row
 				if ((i & 63) == 0) { const int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
 				int i_end = (i | 63) + 1; if (i_end > tlen) i_end = tlen; if (i_end > i + 32 - hist_n) i_end = i + 32 - hist_n;
-				if (i >= tail_from && i_end > i + 4) i_end = i + 4;
+				if (i >= tail_from && i_end > i + 2) i_end = i + 2;
 				i_end = uni(i_end);
 				int sc_next = qcol[__builtin_amdgcn_readlane(treg, i & 63) * qs];
 				int key;
@@ -342,9 +347,11 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 					const u64 nz = wave_ballot((hleft | e_new) != 0) & wave_ballot(wr);      // (two compare masks and a scalar AND: the ballot of a conjunction is rebuilt from 0/1 values)
 					key = __builtin_amdgcn_readlane(kmax, 63);
 					hist_k = lane == hist_n ? key : hist_k;
+					m_run = imax(m_run, key >> 11);
 					if (hi == qhi) {                                  // H(i, end-1) feeds the to-end score (ksw.c:486-489); rows that do not touch the query's end leave the -1 of the last flush
 						const int h1 = __builtin_amdgcn_readlane(hleft, hi);
 						hist_h1 = lane == hist_n ? h1 : hist_h1;
+						g_run = imax(g_run, h1);
 					}
 					++hist_n; ++i; cells32 += (u32)nact;
 					if (key < 2048) break;                           // m == 0 (ksw.c:490)
@@ -361,9 +368,9 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 				if (key < 2048) why = 1;
 				else {
 					if (hi > 63 || hi <= lo) why = 2;
-					if (hist_n == 32 || i >= tail_from) {
-						if (hist_flush()) why = 1;
-						else if (why == 0 && gscore >= 0) {
+					if (hist_n == 32 && hist_flush()) why = 1;
+					if (why == 0 && g_run >= 0 && (hist_n == 0 || i >= tail_from)) {
+						{
 							const bool inb = (unsigned)(lane - lo) <= (unsigned)(hi - lo);       // the band's columns and column `end`
 							const int pot = (qlen - jcol) * mat_max;
 							if (tail_done(inb ? imax(sth > 0 ? sth + pot : 0, ste > 0 ? ste + pot - mat_max : 0) : 0)) why = 1;
@@ -397,7 +404,7 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 			do {
 				if ((i & 63) == 0) { const int ii = i + lane; treg = ii < tlen ? ref_base(ix, t0 + (i64)ii * tdir) : 0; }
 				int i_end = (i | 63) + 1; if (i_end > tlen) i_end = tlen; if (i_end > i + 32 - hist_n) i_end = i + 32 - hist_n;
-				if (i >= tail_from && i_end > i + 4) i_end = i + 4;
+				if (i >= tail_from && i_end > i + 2) i_end = i + 2;
 				i_end = uni(i_end);
 				int scA_next, scB_next; { const int o = __builtin_amdgcn_readlane(treg, i & 63) * qs; scA_next = qcA[o]; scB_next = qcB[o]; }
 				int key;
@@ -425,9 +432,11 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 					const u64 xA = nzA | (mwA & ~wave_ballot(actA)), xB = nzB | (mwB & ~wave_ballot(actB));
 					key = __builtin_amdgcn_readlane(kmax, 63);
 					hist_k = lane == hist_n ? key : hist_k;
+					m_run = imax(m_run, key >> 11);
 					if (hi == qhi) {                                  // H(i, end-1), what column `end` has just stored (ksw.c:485-489)
 						const int h1 = (hi & 1) ? __builtin_amdgcn_readlane(hA, hi >> 1) : __builtin_amdgcn_readlane(hleftA, hi >> 1);
 						hist_h1 = lane == hist_n ? h1 : hist_h1;
+						g_run = imax(g_run, h1);
 					}
 					++hist_n; ++i; cells32 += (u32)nact;
 					if (key < 2048) break;                           // m == 0 (ksw.c:490)
@@ -448,9 +457,9 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 				if (key < 2048) why = 1;
 				else {
 					if (hi > 127 || hi - lo <= 63) why = 2;
-					if (hist_n == 32 || i >= tail_from) {
-						if (hist_flush()) why = 1;
-						else if (why == 0 && gscore >= 0) {
+					if (hist_n == 32 && hist_flush()) why = 1;
+					if (why == 0 && g_run >= 0 && (hist_n == 0 || i >= tail_from)) {
+						{
 							const bool inA = (unsigned)(2 * lane - lo) <= (unsigned)(hi - lo), inB = (unsigned)(2 * lane + 1 - lo) <= (unsigned)(hi - lo);
 							const int potA = (qlen - jA) * mat_max, potB = potA - mat_max;
 							const int cA = inA ? imax(shA > 0 ? shA + potA : 0, seA > 0 ? seA + potA - mat_max : 0) : 0;
@@ -646,7 +655,8 @@ template <bool RING> __device__ ExtRes wave_ksw_extend2(const DevIndex &ix, cons
 		}
 		const int h1 = beg < end ? hprev : h1_init;      // H(i, end-1) as left in h1 by the reference's column loop
 		const int jfin = beg < end ? end : beg;
-		if (jfin == qlen) { if (h1 >= gscore) max_ie = i; if (h1 > gscore) gscore = h1; }
+		if (jfin == qlen) { if (h1 >= gscore) max_ie = i; if (h1 > gscore) gscore = h1; g_run = imax(g_run, h1); }
+		m_run = imax(m_run, m);
 		stop = m == 0;
 		if (m > max) {
 			int off = mj - i; if (off < 0) off = -off;
