@@ -1,9 +1,12 @@
-# Session r6-13 (the cheaper test: running scalars, every second row): rows that cannot change the result are not computed (k_extend_wave's window rows) -- stage times, digest, DP fuzz and parity on the device.
-mkdir -p gpurun_out/s13
+# Session r6-14: the round's final tree -- GPU suite, smoke, the bench line (driver's arguments), profiles.
+mkdir -p gpurun_out/s14
 export TMPDIR=/tmp
-(timeout 600 python tools/ext_pack_probe.py 0 0 > gpurun_out/s13/probe.log 2>&1; echo "rc $?" >> gpurun_out/s13/probe.log)
-grep -a "ext_pack\|stats run\|rc " gpurun_out/s13/probe.log
-(timeout 900 python -m pytest tests/test_dp_fuzz.py tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/s13/pytest.log 2>&1; echo "rc $?" >> gpurun_out/s13/pytest.log)
-tail -n 3 gpurun_out/s13/pytest.log
-(timeout 500 python tools/variant_probe.py --prefix /tmp/bwa_amd_bench/g3100000000_s42 --codes /tmp/bwa_amd_bench/g3100000000_s42.codes.npy --steps 9 > gpurun_out/s13/step.log 2>&1; echo "rc $?" >> gpurun_out/s13/step.log)
-tail -n 2 gpurun_out/s13/step.log | cut -c1-400
+(timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/s14/pytest_gpu.log 2>&1; echo "rc $?" >> gpurun_out/s14/pytest_gpu.log)
+grep -a "passed\|failed" gpurun_out/s14/pytest_gpu.log
+(timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/s14/smoke.log 2>&1; echo "rc $?" >> gpurun_out/s14/smoke.log); tail -n 2 gpurun_out/s14/smoke.log
+(timeout 1200 python bench.py --steps 20 --warmup 5 > gpurun_out/s14/bench.json 2> gpurun_out/s14/bench.err; echo "rc $?" >> gpurun_out/s14/bench.err)
+grep -a "SUMMARY\|^rc" gpurun_out/s14/bench.err | tail -2 | cut -c1-420
+wc -c gpurun_out/s14/bench.json
+cp gpurun_out/bench_full.json gpurun_out/s14/bench_full.json 2>/dev/null
+(timeout 900 bash tools/profile_round.sh r06b > gpurun_out/s14/profile.log 2>&1; echo "rc $?" >> gpurun_out/s14/profile.log)
+tail -n 2 gpurun_out/s14/profile.log
