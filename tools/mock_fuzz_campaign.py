@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-DP_SETS = [{}, {"dedup_blk": 0}, {"seedsw_lds": 0}]
+DP_SETS = [{}, {"dedup_blk": 0}, {"seedsw_lds": 0}, {"ext_blk": 0}]
 OPT_SETS = [
     {},
     {"chain_regs": 0},
@@ -30,6 +30,8 @@ OPT_SETS = [
     {"occ32": 0},
     {"ptab_m": 6, "seed_lds_ent": 3},
     {"ext_occ": 4},
+    {"ext_pack": 1},
+    {"ext_blk": 0},
 ]
 LAYOUT = ("occ32", "occ32_sb_shift", "ptab_m")     # applied when the index is laid out: such a set gets a handle of its own
 
