@@ -1,12 +1,16 @@
-# Session r6-14: the round's final tree -- GPU suite, smoke, the bench line (driver's arguments), profiles.
-mkdir -p gpurun_out/s14
+# Session r6-15: with the extension faster, where is the best split of the chip between the batches in flight?  `share` (percent of a chip-filling launch per
+# persistent kernel) and the number of batches in flight, step time over 12 steps each.
+mkdir -p gpurun_out/s15
 export TMPDIR=/tmp
-(timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/s14/pytest_gpu.log 2>&1; echo "rc $?" >> gpurun_out/s14/pytest_gpu.log)
-grep -a "passed\|failed" gpurun_out/s14/pytest_gpu.log
-(timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/s14/smoke.log 2>&1; echo "rc $?" >> gpurun_out/s14/smoke.log); tail -n 2 gpurun_out/s14/smoke.log
-(timeout 1200 python bench.py --steps 20 --warmup 5 > gpurun_out/s14/bench.json 2> gpurun_out/s14/bench.err; echo "rc $?" >> gpurun_out/s14/bench.err)
-grep -a "SUMMARY\|^rc" gpurun_out/s14/bench.err | tail -2 | cut -c1-420
-wc -c gpurun_out/s14/bench.json
-cp gpurun_out/bench_full.json gpurun_out/s14/bench_full.json 2>/dev/null
-(timeout 900 bash tools/profile_round.sh r06b > gpurun_out/s14/profile.log 2>&1; echo "rc $?" >> gpurun_out/s14/profile.log)
-tail -n 2 gpurun_out/s14/profile.log
+python tools/seed_iter_probe.py > /dev/null 2>&1
+P="--prefix /tmp/bwa_amd_bench/g3100000000_s42 --codes /tmp/bwa_amd_bench/g3100000000_s42.codes.npy --steps 12"
+(timeout 500 python tools/variant_probe.py $P --streams 3 "share=100" "share=70" "share=50" "share=35" > gpurun_out/s15/share3.log 2>&1; echo "rc $?" >> gpurun_out/s15/share3.log)
+(timeout 500 python tools/variant_probe.py $P --streams 2 "share=100" "share=60" > gpurun_out/s15/share2.log 2>&1; echo "rc $?" >> gpurun_out/s15/share2.log)
+(timeout 500 python tools/variant_probe.py $P --streams 4 "share=50" "share=35" "share=25" > gpurun_out/s15/share4.log 2>&1; echo "rc $?" >> gpurun_out/s15/share4.log)
+python - <<'PY'
+import json
+for f in ("share3","share2","share4"):
+    for ln in open(f"gpurun_out/s15/{f}.log"):
+        if ln.startswith("{"):
+            d=json.loads(ln); print(f, d["config"], d.get("ms_per_step"), d.get("Mreads_s"), d.get("same_result_as_defaults"))
+PY
