@@ -93,6 +93,7 @@ struct bwagpu_s {
 	i64 cigl_z_cap = 0;                          // bytes per direction matrix of the long CIGAR tier's scratch (grows with the batches)
 	DevBuf d_cigl_z, d_cigl_ops, d_cigl_md, d_cigl_list;      // scratch of the long-segment CIGAR tier (k_cigar_long): direction matrices, operations, MD strings per workgroup
 	DevBuf d_cig_ext; i64 cig_ext_n = -1;   // operation array of the last bwagpu_batch_cigars (records with 7..64 operations point into it)
+	DevBuf d_dd_tmp;                            // short-read batches: staging areas of k_dedup_wave<.., LIST>'s waves (the kept records of a read in their final order)
 	DevBuf d_heavy;                             // short-read batches: the reads the lane-per-read seeding kernel gave up (their passes 1-2 run as tasks)
 	DevBuf d_p2_tasks; double p2_factor = 1.;   // pass-2 tasks of a short-read batch's heavy reads (grown on overflow bit 5)
 	DevBuf d_vr_tab, d_vr_ovf, d_intv_n3;   // pass 1 of long-read batches as tasks (k_seed<LR>): the reads' first tasks, the list of tasks to redo on full-size stacks, pass 3's entries per read
@@ -230,7 +231,8 @@ static bool option_in_range(const BwagpuConfig &c, const long long *f, long long
 	if (f == &c.seed_mrg) return value == -1 || value == 0 || value == 2;
 	if (f == &c.share) return in(-1, 100);
 	if (f == &c.seed_task_stack || f == &c.seed_p2_cap || f == &c.mem_cap || f == &c.seed_grid || f == &c.cig_ops_cap || f == &c.idx_desc_max_mb) return in(0, 0x3fffffff);
-	if (f == &c.seed_budget) return in(-1, 0x3fffffff);
+	if (f == &c.seed_budget || f == &c.dedup_heavy) return in(-1, 0x3fffffff);
+	if (f == &c.dedup_stage || f == &c.dedup_big) return in(-1, 1024);
 	if (f == &c.seed_lds_ent) return in(-1, 16);
 	if (f == &c.dedup_ring) return value == 0 || (in(256, 4096) && (value & (value - 1)) == 0);
 	if (f == &c.cigl_mib) return in(0, 1 << 20);
@@ -491,7 +493,7 @@ extern "C" void bwagpu_destroy(bwagpu_t *h)
 		for (DevBuf *b : ib) b->release();
 		delete h->ibuf;
 	}
-	DevBuf *all[] = { &h->d_heavy, &h->d_p2_tasks, &h->d_vr_tab, &h->d_vr_ovf, &h->d_intv_n3, &h->d_cigl_list, &h->d_cigl_z, &h->d_cigl_ops, &h->d_cigl_md, &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
+	DevBuf *all[] = { &h->d_heavy, &h->d_dd_tmp, &h->d_p2_tasks, &h->d_vr_tab, &h->d_vr_ovf, &h->d_intv_n3, &h->d_cigl_list, &h->d_cigl_z, &h->d_cigl_ops, &h->d_cigl_md, &h->d_seq_2b, &h->d_seq_flags, &h->d_cig_ext, &h->d_msw_tasks, &h->d_msw_out, &h->d_msw_pes, &h->d_msw_scratch, &h->d_pack_off, &h->d_regs_packed, &h->d_pack_read, &h->d_cigs, &h->d_seq, &h->d_seq_nib, &h->d_off, &h->d_ctr, &h->d_tmp_intv,
 		&h->d_intv_n, &h->d_intv_off, &h->d_intv, &h->d_seed_n, &h->d_seed_off, &h->d_slot_pos, &h->d_slot_qbeg, &h->d_slot_len, &h->d_slot_rid, &h->d_slot_blob, &h->d_chain_n, &h->d_node_off,
 		&h->d_order, &h->d_bin_cnt, &h->d_seed_w, &h->d_seed_order, &h->d_nodes, &h->d_reg_off, &h->d_reg_cap_r, &h->d_reg_n_raw, &h->d_reg_n, &h->d_regs, &h->d_regs_raw, &h->d_dp_h, &h->d_dp_e, &h->d_minhsp };
 	for (DevBuf *b : all) b->release();
@@ -1033,6 +1035,25 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 							 h->seq_len < ((u64)1 << 37) && !cfg.seed_pass3_inline && opt->max_mem_intv > 0;
 	const int heavy_lanes = heavy_tasks ? (int)(((i64)n * heavy_tpr + BLOCK - 1) / BLOCK * BLOCK < 256 * 3 * BLOCK ? ((i64)n * heavy_tpr + BLOCK - 1) / BLOCK * BLOCK : 256 * 3 * BLOCK) : 0;
 	if (heavy_tasks && (h->d_intv_n3.ensure((size_t)n * 4 + 16) || h->d_heavy.ensure((size_t)n * 4 + 16))) { h->err = "hipMalloc failed (seeding tasks)"; return BWAGPU_ENOMEM; }
+	// k_dedup's list of the reads it leaves to the wave-per-read kernel: the seeding kernels' list of heavy reads, free again by then
+	const int dd_heavy_min = long_batch || cfg.dedup_wave || h->seq_len >= ((u64)1 << 47) || h->max_len >= (1 << 16) ? 0 : (int)(cfg.dedup_heavy < 0 ? 3 : cfg.dedup_heavy);     // (the bounds: DdKey, dev_dedupp.h)
+	struct { int rc, q_cap, cap_m, cap_b; size_t lds0; long long blk_m, blk_b; } dd = { 0, 0, 0, 0, 0, 0, 0 };
+	if (dd_heavy_min > 0) {
+		int need = 8 * opt->w + 4 + 128; if (need < h->max_len / 4 + 132) need = h->max_len / 4 + 132;
+		dd.rc = 256; while (dd.rc < need && dd.rc < 4096) dd.rc <<= 1;
+		dd.q_cap = (h->max_len + 15) & ~15;
+		if (8 * dd.rc + 32 + dd.q_cap > 65536) dd.q_cap = 0;
+		dd.lds0 = (size_t)8 * dd.rc + 32 + dd.q_cap;
+		const long long room = (65536 - (long long)dd.lds0) / (long long)DDP_LDS_PER_REG;       // regions a workgroup's LDS holds next to the ring
+		dd.cap_m = (int)(cfg.dedup_stage < 0 ? 128 : cfg.dedup_stage); if (dd.cap_m > room) dd.cap_m = (int)(room > 0 ? room : 0);
+		dd.cap_b = (int)(cfg.dedup_big < 0 ? room : cfg.dedup_big); if (dd.cap_b > room) dd.cap_b = (int)(room > 0 ? room : 0);
+		const long long wpc_m = (160 * 1024) / (long long)(dd.lds0 + DDW_PAR_BYTES(dd.cap_m)), wpc_b = (160 * 1024) / (long long)(dd.lds0 + DDW_PAR_BYTES(dd.cap_b));
+		dd.blk_m = share(256 * (wpc_m > 12 ? 12 : wpc_m)); dd.blk_b = share(256 * (wpc_b > 12 ? 12 : wpc_b));
+		const long long dpw = dp_wave_count(h, n_threads), cap = dpw > 0 ? dpw : 1;       // (dp_h / dp_e hold one scratch region per wave)
+		if (dd.blk_m > cap) dd.blk_m = cap; if (dd.blk_b > cap) dd.blk_b = cap;
+		if (dd.blk_m > n) dd.blk_m = n; if (dd.blk_b > n) dd.blk_b = n;
+		if (h->d_heavy.ensure((size_t)n * 4 + 16) || h->d_dd_tmp.ensure(((size_t)dd.blk_m * dd.cap_m + (size_t)dd.blk_b * dd.cap_b) * sizeof(bwagpu_alnreg_t) + 16)) { h->err = "hipMalloc failed (de-duplication lists)"; return BWAGPU_ENOMEM; }
+	}
 	for (int attempt = 0; attempt < 12; ++attempt) {
 		h->phase = 20 + attempt * 100;
 		int rc = alloc_batch(h, n_threads, seed_tasks ? (int)(((size_t)task_lanes * TASK_STACK_CAP + (size_t)(h->max_len + PTAB_MAX)) / (size_t)(h->max_len + 1 + PTAB_MAX))   // (the tasks' small spill areas, in units of a full-size one)
@@ -1221,10 +1242,27 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			int wpb = rc_ <= 1024 ? 4 : (rc_ <= 2048 ? 2 : 1);
 			while (wpb > 1 && (8 * rc_ + 32 + q_cap) * wpb > 65536) wpb >>= 1;
 			i64 nblk = ((i64)n + wpb - 1) / wpb, cap = B.dp_waves / wpb > 0 ? B.dp_waves / wpb : 1;   // dp_h/dp_e hold one scratch region per wave
-			if (dedup_blk && q_cap) hipLaunchKernelGGL(k_dedup_wave<true>, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)(8 * rc_ + 32 + q_cap) * wpb, h->stream, h->ix, *opt, B, rc_, q_cap);
-			else hipLaunchKernelGGL(k_dedup_wave<false>, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)(8 * rc_ + 32 + q_cap) * wpb, h->stream, h->ix, *opt, B, rc_, q_cap);
-		} else
+			if (dedup_blk && q_cap) hipLaunchKernelGGL(k_dedup_wave<true>, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)(8 * rc_ + 32 + q_cap) * wpb, h->stream, h->ix, *opt, B, rc_, q_cap, 0, 0, (bwagpu_alnreg_t*)nullptr);
+			else hipLaunchKernelGGL(k_dedup_wave<false>, dim3((unsigned)(nblk < cap ? nblk : cap)), dim3(64 * wpb), (size_t)(8 * rc_ + 32 + q_cap) * wpb, h->stream, h->ix, *opt, B, rc_, q_cap, 0, 0, (bwagpu_alnreg_t*)nullptr);
+		} else {
+			// Lane per read for the reads with one or two regions (nine in ten of the headline's); the others are listed by k_dedup and done by two more
+			// launches, one wavefront per read with the decisions' operands in LDS (dedup_read_par, dev_dedupp.h): the reads of up to dedup_stage regions
+			// (16.6 KB of LDS per wave, nine to a CU), then the few with more (up to dedup_big regions in 64 KB; beyond that, in place in HBM).
+			B.dd_heavy_min = dd_heavy_min; B.dd_list = h->d_heavy.as<i32>();
+			B.dd_stage_cap = dd.cap_m > 0 ? dd.cap_m : 0x3fffffff;      // (no LDS arrays: one list, every read in place)
 			hipLaunchKernelGGL(k_dedup, dim3((unsigned)share(grid.x)), block, 0, h->stream, h->ix, *opt, B);
+			if (B.dd_heavy_min > 0) {
+				bwagpu_alnreg_t *tmp = h->d_dd_tmp.as<bwagpu_alnreg_t>();
+				const size_t lds_m = dd.lds0 + DDW_PAR_BYTES(dd.cap_m), lds_b = dd.lds0 + DDW_PAR_BYTES(dd.cap_b);
+				if (dd.q_cap) hipLaunchKernelGGL((k_dedup_wave<true, true>), dim3((unsigned)dd.blk_m), dim3(64), lds_m, h->stream, h->ix, *opt, B, dd.rc, dd.q_cap, dd.cap_m, 0, tmp);
+				else hipLaunchKernelGGL((k_dedup_wave<false, true>), dim3((unsigned)dd.blk_m), dim3(64), lds_m, h->stream, h->ix, *opt, B, dd.rc, dd.q_cap, dd.cap_m, 0, tmp);
+				if (dd.cap_m > 0) {
+					tmp += (size_t)dd.blk_m * dd.cap_m;
+					if (dd.q_cap) hipLaunchKernelGGL((k_dedup_wave<true, true>), dim3((unsigned)dd.blk_b), dim3(64), lds_b, h->stream, h->ix, *opt, B, dd.rc, dd.q_cap, dd.cap_b, 1, tmp);
+					else hipLaunchKernelGGL((k_dedup_wave<false, true>), dim3((unsigned)dd.blk_b), dim3(64), lds_b, h->stream, h->ix, *opt, B, dd.rc, dd.q_cap, dd.cap_b, 1, tmp);
+				}
+			}
+		}
 		HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
 		if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(h->stream); fprintf(stderr, "[bwagpu] attempt %d: %s done (%s)\n", attempt, "k_dedup", hipGetErrorString(e_)); }
 		HIPCHK(h, hipGetLastError());

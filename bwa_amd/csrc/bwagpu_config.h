@@ -43,6 +43,9 @@
 	X(ext_occ,           6)    /* extension: waves per SIMD the short-read kernel's register allocation aims at (4 or 6)                                */ \
 	X(chain_regs,        2)    /* chaining: the chains of a read kept in registers, one per lane, while that is exact: 2 = up to 256 chains (four per lane), 1 = up to 64, 0 = every read through the B-tree (A/B and tests) */ \
 	X(chain_flt_lds,     256)  /* chaining: reads of up to this many chains keep the weight sort's and the chain filter's arrays in LDS (at most 256; tests: 0 sends every read down the HBM path) */ \
+	X(dedup_heavy,       -1)   /* short reads: k_dedup leaves reads with at least this many regions to the wave-per-read kernel; 0 = none, auto: 3      */ \
+	X(dedup_stage,       -1)   /* ... with the decisions' operands in LDS for reads of up to this many regions (first launch); 0 = every read in place in HBM, auto: 128 */ \
+	X(dedup_big,         -1)   /* ... and for the reads with more, up to this many (second launch, 64 KB of LDS per wave); 0 = those in place, auto: what fits (893) */ \
 	X(dedup_wave,        0)    /* 1 = the wave-per-read de-duplication kernel for short reads as well (test hook)                                       */ \
 	X(dedup_ring,        0)    /* ring columns of that kernel (0: from the batch; test hook: a power of two, 256..4096)                                 */ \
 	X(mem_cap,           0)    /* capacity of a read's interval list (0: from the batch; test hook: a small value forces the retry path)                */ \

@@ -94,6 +94,7 @@ struct Counters {          // device-side bump allocators + flags
 	HotCounter next_seedsw_; // work counter of the wave-per-read seed re-scoring kernel (long reads)
 	HotCounter next_chain_, next_dedup_;       // work counters of the chaining and de-duplication kernels
 	HotCounter next_pack_;                     // ... and of the packed-extension kernel (k_ext_pack)
+	HotCounter n_dd_heavy_, n_dd_big_, next_dd_heavy_, next_dd_big_;    // short-read batches: the reads k_dedup left to the wave-per-read kernel (several regions; more regions than that kernel's LDS copy holds), and the work counter over both
 	HotCounter cig_ext_used_;                  // operations written to the batch's CIGAR operation array (records with more than 6 operations)
 	unsigned long long intv_used;
 	unsigned long long overflow;   // bit0 intv, bit1 seed, bit2 node, bit3 reg, bit4 tmp-intv scratch
@@ -126,6 +127,10 @@ struct Counters {          // device-side bump allocators + flags
 #define next_chain next_chain_.v
 #define next_dedup next_dedup_.v
 #define next_pack next_pack_.v
+#define n_dd_heavy n_dd_heavy_.v
+#define next_dd_heavy next_dd_heavy_.v
+#define n_dd_big n_dd_big_.v
+#define next_dd_big next_dd_big_.v
 #define cig_ext_used cig_ext_used_.v
 
 // Sub-arrays of one read's private region (n = its number of seed slots); offsets keep every array naturally aligned.
@@ -189,6 +194,9 @@ struct Batch {
 	int task_step, n_vreads;        // min_seed_len; number of tasks of the batch
 	int task_tpr;                   // > 0 (short-read batches, the heavy reads only): task t = position (t % task_tpr) * task_step of read heavy_list[t / task_tpr], for t < n_heavy * task_tpr
 	i32 *heavy_list;                // the reads the lane-per-read kernel gave up after seed_budget iterations (n_heavy of them); their passes 1-2 run as tasks
+	i32 *dd_list;                   // k_dedup: the reads with at least dd_heavy_min regions, left to k_dedup_wave<.., LIST = true>: n_dd_heavy of them from the front, and from the
+	                                // back (entry n_reads - 1 downwards) the n_dd_big reads with more than dd_stage_cap regions
+	int dd_heavy_min, dd_stage_cap; // dd_heavy_min 0 = k_dedup does every read itself
 	int seed_budget;                // ... that budget (0: none)
 	i64 *p2_tasks; long long p2_cap; // pass-2 searches of the heavy reads as tasks (k_seed<LR = 3>): read << 32 | index of the pass-1 entry to re-seed
 	const i32 *vr_first;            // per read: its first task (n_reads + 1 entries)

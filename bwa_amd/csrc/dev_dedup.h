@@ -177,7 +177,14 @@ __global__ void __launch_bounds__(256) k_dedup(DevIndex ix, bwagpu_opt_t opt, Ba
 		const long long base = wave_fetch_n(&B.ctr->next_dedup, 64);
 		if (base >= B.n_reads) break;
 		const int r = (int)base + lane;
-		if (r < B.n_reads) { dedup_read(ix, opt, B, r, H, E, calls, cells); nreg += B.reg_n[r]; }
+		// A read with many regions is a long serial job for one lane (sorts, the pair loop, the patch alignments) while the other 63 wait:
+		// those go to a list that k_dedup_wave<.., LIST> works through with one wavefront per read.
+		if (r < B.n_reads) {
+			const int n_raw = B.dd_heavy_min > 0 ? B.reg_n_raw[r] : 0;
+			if (n_raw > B.dd_stage_cap && n_raw >= B.dd_heavy_min) B.dd_list[B.n_reads - 1 - (long long)atomicAdd(&B.ctr->n_dd_big, 1ull)] = r;      // (more regions than the LDS copy holds: from the far end)
+			else if (n_raw >= B.dd_heavy_min && B.dd_heavy_min > 0) B.dd_list[atomicAdd(&B.ctr->n_dd_heavy, 1ull)] = r;
+			else { dedup_read(ix, opt, B, r, H, E, calls, cells); nreg += B.reg_n[r]; }
+		}
 	}
 	if (B.stats) {
 		atomicAdd(&B.ctr->glb_calls, (unsigned long long)calls);

@@ -9,7 +9,8 @@
 #include "dev_extw.h"
 
 struct DedupLds { i32 *hd, *e; const int8_t *mat; int ring_mask; i32 *H, *E; /* lane 0's HBM scratch columns (dev_ksw_global2_score) for bands wider than the ring */
-	u8 *qbuf; int qcap; /* four-columns-per-lane form (option dedup_blk, the default): room for a patch alignment's query segment in alignment order */ };
+	u8 *qbuf; int qcap; /* four-columns-per-lane form (option dedup_blk, the default): room for a patch alignment's query segment in alignment order */
+	struct DdHot *hot; struct DdKey *keys; i32 *ord, *ord2; int par_cap; bwagpu_alnreg_t *tmp; /* dedup_read_par (dev_dedupp.h): per-region arrays in LDS for reads of up to par_cap regions (0: none), and the wave's staging area in HBM */ };
 
 // ksw_global2 without traceback (ksw.c:540-619), columns in a ring of ring_mask+1 entries, lazily initialised
 __device__ int wave_global2_score_ring(const DevIndex &ix, const bwagpu_opt_t &opt, const u8 *q, int q0, int qdir, int qlen, i64 t0, int tdir, int tlen,
@@ -293,19 +294,27 @@ template <bool BLK = false> __device__ void dedup_read_wave(const DevIndex &ix, 
 	wave_sync();
 }
 
+#include "dev_dedupp.h"
+
 // One wavefront per read.
 // BLK (option dedup_blk, default on): patch alignments with four columns per lane
-template <bool BLK = false> __global__ void __launch_bounds__(256) k_dedup_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int ring_cols, int q_cap)
+// LIST (short-read batches): the reads k_dedup handed over in Batch::dd_list -- list 0: from the front (n_dd_heavy reads of up to Batch::dd_stage_cap
+// regions), list 1: from the back (n_dd_big reads with more) -- through dedup_read_par when the LDS arrays hold the read's regions (par_cap), one
+// wave per workgroup.
+#define DDW_PAR_BYTES(cap) ((size_t)(cap) * DDP_LDS_PER_REG)
+template <bool BLK = false, bool LIST = false> __global__ void __launch_bounds__(256) k_dedup_wave(DevIndex ix, bwagpu_opt_t opt, Batch B, int ring_cols, int q_cap, int par_cap, int list, bwagpu_alnreg_t *par_tmp)
 {
 	HIP_DYNAMIC_SHARED(unsigned char, ddw_lds)
 	const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	unsigned char *base = ddw_lds + (size_t)wave_in_blk * (8 * ring_cols + 32 + q_cap);
+	unsigned char *base = ddw_lds + (size_t)wave_in_blk * (8 * ring_cols + 32 + q_cap + DDW_PAR_BYTES(par_cap));
 	DedupLds L;
 	L.hd = (i32*)base; L.e = L.hd + ring_cols; L.ring_mask = ring_cols - 1;
 	int8_t *m = (int8_t*)(base + (size_t)8 * ring_cols);
 	if (lane < 25) m[lane] = opt.mat[lane];
 	L.mat = m;
 	L.qbuf = base + (size_t)8 * ring_cols + 32; L.qcap = q_cap;
+	L.hot = (DdHot*)(L.qbuf + q_cap); L.keys = (DdKey*)(L.hot + par_cap); L.ord = (i32*)(L.keys + par_cap); L.ord2 = L.ord + par_cap; L.par_cap = par_cap;      // (q_cap is a multiple of 16)
+	L.tmp = par_tmp + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_blk) * par_cap;
 	{
 		const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_blk;
 		L.H = B.dp_h + wave * (B.max_len + 2) * DPS; L.E = B.dp_e + wave * (B.max_len + 2) * DPS;
@@ -313,11 +322,12 @@ template <bool BLK = false> __global__ void __launch_bounds__(256) k_dedup_wave(
 	wave_sync();
 	u64 calls = 0, cells = 0, nreg = 0;
 	for (;;) {
-		const long long k = wave_fetch(&B.ctr->next_dedup);
-		if (k >= B.n_reads) break;
-		const int r = (int)k;
+		const long long k = wave_fetch(!LIST ? &B.ctr->next_dedup : (list ? &B.ctr->next_dd_big : &B.ctr->next_dd_heavy));
+		if (k >= (!LIST ? (long long)B.n_reads : (long long)(list ? B.ctr->n_dd_big : B.ctr->n_dd_heavy))) break;
+		const int r = !LIST ? (int)k : uni(list ? B.dd_list[B.n_reads - 1 - k] : B.dd_list[k]);
 		const long long t_0 = B.stats ? wall_clock64() : 0; const u64 c_0 = calls, x_0 = cells;
-		dedup_read_wave<BLK>(ix, opt, B, r, L, calls, cells);
+		if (LIST && uni(B.reg_n_raw[r]) <= L.par_cap) dedup_read_par<BLK>(ix, opt, B, r, L, calls, cells);
+		else dedup_read_wave<BLK>(ix, opt, B, r, L, calls, cells);
 		if (B.stats && lane == 0) {
 			const long long dt = wall_clock64() - t_0;
 			const int bin = dt > 0 ? (64 - __clzll(dt) < 31 ? 64 - __clzll(dt) : 31) : 0;

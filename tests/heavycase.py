@@ -83,3 +83,22 @@ def check(dev, chk, reads, regs):
         kc += cn[i]; ks += int(hdr["n"].sum())
     assert_regs_equal(*chk.align(opt, seqs, off), c, r, "heavy chaining")
     dev.set_stats(False)
+
+
+def patch_reads(g, n, seed=5):
+    """Reads whose alignment breaks into several regions on one diagonal, which mem_patch_reg (bwamem.c:432-461) then joins again: 250 bp with two to
+    four clusters of three adjacent mismatches, to be aligned with zdrop = 8 (patch_opt) so that an extension stops at a cluster.  Several joins per
+    read, in sequence (a joined region goes on to meet the next one), and joins that fail the 0.9 score test."""
+    rng = np.random.default_rng(seed + 2)
+    reads = simdata.make_reads_se(g, n, length=250, seed=seed)
+    for rd in reads:
+        for pos in rng.choice(np.arange(40, 210, 45), size=int(rng.integers(2, 5)), replace=False):
+            for k in range(3):
+                rd[pos + k] = (rd[pos + k] + 1 + rng.integers(0, 3)) % 4
+    return reads
+
+
+def patch_opt():
+    opt = default_opt()
+    opt.zdrop = 8
+    return opt

@@ -451,6 +451,17 @@ def test_pacbio_10kb_reads_at_scale_under_the_long_read_defaults(medium):
     assert_regs_equal(want[0][:120], want[1][:n120], c3, r3, "pacbio 10 kb x 120, round-3 kernel forms")
 
 
+def _heavy():
+    """tests/heavycase.py's genome, index and hard reads, built once per session."""
+    import heavycase
+    global _HEAVY
+    try:
+        _HEAVY
+    except NameError:
+        _HEAVY = heavycase.build()
+    return _HEAVY
+
+
 @pytest.mark.parametrize("regs,flt_lds", [(2, 256), (1, 256), (0, 256), (2, 0), (2, 40)])
 def test_gpu_wave_chaining_heavy_reads(regs, flt_lds):
     """The device twin of tests/test_hostsim.py::test_hostsim_wave_chaining_heavy_reads (VERDICT r5: round 5's chaining forms had their directed test on
@@ -462,12 +473,7 @@ def test_gpu_wave_chaining_heavy_reads(regs, flt_lds):
     import refapi
     from bwa_amd.api import BwaGpu
     assert refapi.have_ref(), "oracle/_ref (the compiled reference) is missing on the GPU box"
-    global _HEAVY
-    try:
-        _HEAVY
-    except NameError:
-        _HEAVY = heavycase.build()
-    fa, orc, reads = _HEAVY
+    fa, orc, reads = _heavy()
     ref = refapi.RefIndex(fa)
     gpu = BwaGpu(fa, options={"chain_regs": regs, "chain_flt_lds": flt_lds})
     heavycase.check(gpu, ref, reads, regs)
@@ -500,6 +506,54 @@ def test_ext_pack_gives_identical_results(medium):
                 g2.L.bwagpu_debug_prof(g2.h, prof)
                 assert prof[8] > reads.shape[0], f"k_ext_pack answered only {prof[8]} extensions of {reads.shape[0]} reads"
         g2.close()
+
+
+@pytest.mark.parametrize("heavy_min,stage,big", [(0, -1, -1), (2, 16, -1), (2, 16, 32), (8, 0, -1), (-1, 512, 0)])
+def test_dedup_list_gives_identical_results(medium, heavy_min, stage, big):
+    """k_dedup lists the reads with several regions for k_dedup_wave<.., LIST> (dedup_read_par, dev_dedupp.h: operands in LDS, the lanes over the
+    regions), options dedup_heavy / dedup_stage / dedup_big (3 regions, 128, what 64 KB hold by default, which the other tests run): with no list; with
+    nearly every read listed, small arrays in the first launch and the rest in the second; the same with reads beyond the second launch's arrays (done in
+    place); a middling bound with every listed read in place; one launch with large arrays.  The regions equal the compiled reference's -- ordinary reads,
+    odd options, 250 bp reads, and the repeat-rich genome's reads with hundreds of regions."""
+    from bwa_amd.api import BwaGpu
+    gpu, orc, ref, g = medium
+    fa, _ = testdata.medium_index()
+    odd = golden_opts()["odd"]
+    sets = [("se150", simdata.make_reads_se(g, 8000, seed=81), default_opt()), ("se150 odd options", simdata.make_reads_se(g, 3000, seed=82, sub=0.03), odd),
+            ("se250 noisy", simdata.make_reads_se(g, 2000, length=250, seed=83, sub=0.03, dele=0.005, ins=0.005), default_opt())]
+    g2 = BwaGpu(fa, options={"dedup_heavy": heavy_min, "dedup_stage": stage, "dedup_big": big})
+    for name, reads, opt in sets:
+        seqs, off = testdata.flat(reads)
+        assert_regs_equal(*ref.align(opt, seqs, off), *g2.align(opt, seqs, off), f"dedup_heavy = {heavy_min}, dedup_stage = {stage}, dedup_big = {big}, {name}")
+    g2.close()
+    import refapi
+    hfa, horc, hreads = _heavy()
+    hg = simdata.make_genome(500_000, n_contigs=2, seed=5, n_interspersed=2000, divergence=0.04)[0]      # (heavycase.build's genome)
+    rep_reads = simdata.make_reads_se(hg, 1500, seed=84, sub=0.05)
+    g3, href = BwaGpu(hfa, options={"dedup_heavy": heavy_min, "dedup_stage": stage, "dedup_big": big}), refapi.RefIndex(hfa)
+    for name, reads in (("hard reads", hreads), ("repeat-rich genome", rep_reads)):
+        seqs, off = testdata.flat(reads)
+        assert_regs_equal(*href.align(default_opt(), seqs, off), *g3.align(default_opt(), seqs, off), f"dedup_heavy = {heavy_min}, {name}")
+    g3.close(); href.close()
+
+
+@pytest.mark.parametrize("heavy_min", [-1, 2, 0])
+def test_dedup_patch_joins(medium, heavy_min):
+    """The device twin of tests/test_hostsim.py::test_hostsim_dedup_patch_joins, 4000 reads against the compiled reference: regions that mem_patch_reg
+    joins (several per read, in sequence), through k_dedup alone and through the listed reads' dedup_read_par."""
+    import heavycase
+    from bwa_amd.api import BwaGpu
+    gpu, orc, ref, g = medium
+    fa, _ = testdata.medium_index()
+    reads, opt = heavycase.patch_reads(g, 4000, seed=9), heavycase.patch_opt()
+    seqs, off = testdata.flat(reads)
+    want = ref.align(opt, seqs, off)
+    assert int(((want[1]["ncomp_isalt"] & 0x3fffffff) > 1).sum()) >= 1000, "no joined regions in the test's reads"
+    g2 = BwaGpu(fa, options={"dedup_heavy": heavy_min})
+    g2.set_stats(True)
+    assert_regs_equal(*want, *g2.align(opt, seqs, off), f"patch joins, dedup_heavy = {heavy_min}")
+    assert g2.stats()["n_glb_calls"] >= 10000
+    g2.close()
 
 
 def test_many_contigs_with_alt_at_scale(tmp_path):

@@ -580,6 +580,59 @@ def test_hostsim_wave_chaining_heavy_reads(monkeypatch, heavy_case, regs, flt_ld
     s2.close()
 
 
+def dedup_list_reads(dev, n_reads):
+    """Reads the wave-per-read de-duplication kernel did (its stats histogram, bwagpu_debug_hist out[160..192))."""
+    import ctypes as C
+    hist = (C.c_ulonglong * 256)()
+    dev.L.bwagpu_debug_hist.argtypes = [C.c_void_p, C.c_void_p]
+    assert dev.L.bwagpu_debug_hist(dev.h, hist) == 0
+    return sum(hist[160:192])
+
+
+@pytest.mark.parametrize("heavy_min,stage,big", [(0, -1, -1), (-1, -1, -1), (2, 16, -1), (2, 16, 32), (8, 0, -1), (-1, 512, 0)])
+def test_hostsim_dedup_hands_heavy_reads_to_the_wave_kernel(heavy_case, heavy_min, stage, big):
+    """k_dedup keeps the reads with few regions (one lane each) and lists the others for k_dedup_wave<.., LIST> (option dedup_heavy: 0 = none,
+    auto = 3 regions), which runs dedup_read_par (dev_dedupp.h: operands in LDS, the lanes over the regions -- the stable finish of both sorts, the
+    redundancy scan 64 regions at a time, compactions by prefix counts) in two launches: reads of up to dedup_stage regions (auto 128; 0 = every
+    listed read in place in HBM, the long reads' routine), then those of up to dedup_big (auto: what 64 KB hold; beyond it in place).  The regions equal
+    the oracle's whichever way a read went, and the list is used when it should be."""
+    fa, orc, reads = heavy_case
+    opt = default_opt()
+    s2 = sim_handle(fa, dedup_heavy=heavy_min, dedup_stage=stage, dedup_big=big)
+    s2.set_stats(True); s2.set_taps(True)
+    more = simdata.make_reads_se(simdata.make_genome(500_000, n_contigs=2, seed=5, n_interspersed=2000, divergence=0.04)[0], 40, seed=85, sub=0.05)   # (heavycase.build's genome: reads of 1..80 regions)
+    seqs, off = testdata.flat(np.concatenate([reads, more]))
+    c, r = s2.align(opt, seqs, off)
+    assert_regs_equal(*orc.align(opt, seqs, off), c, r, f"dedup_heavy={heavy_min} dedup_stage={stage} dedup_big={big}")
+    n_raw = s2.tap_regs_raw()[0]
+    done = dedup_list_reads(s2, reads.shape[0])
+    lo = 3 if heavy_min < 0 else heavy_min
+    assert done == (int((n_raw >= lo).sum()) if heavy_min else 0), (done, n_raw)
+    assert heavy_min == 0 or (done >= 6 and ((n_raw >= lo) & (n_raw <= 16)).sum() >= 2), n_raw
+    assert stage != 16 or ((n_raw > 16) & (n_raw <= 32)).sum() >= 2 and (n_raw > 32).sum() >= 2, n_raw          # (reads for the second launch, and beyond its arrays when dedup_big = 32)
+    s2.close()
+
+
+@pytest.mark.parametrize("heavy_min", [-1, 2, 0])
+def test_hostsim_dedup_patch_joins(heavy_min):
+    """mem_patch_reg in the de-duplication kernels: reads that break into regions on one diagonal and are joined again (tests/heavycase.py::patch_reads),
+    through k_dedup alone (dedup_heavy = 0) and through the listed reads' dedup_read_par, where a patch alignment is the one event of the redundancy
+    scan that is handled in sequence -- the scan goes on behind it with the changed region.  Regions equal the oracle's; joins did happen."""
+    import heavycase
+    prefix, g = testdata.small_index()
+    orc = orcapi.OrcIndex(prefix)
+    reads, opt = heavycase.patch_reads(g, 24), heavycase.patch_opt()
+    seqs, off = testdata.flat(reads)
+    want = orc.align(opt, seqs, off)
+    assert int(((want[1]["ncomp_isalt"] & 0x3fffffff) > 1).sum()) >= 8, "no joined regions in the test's reads"
+    s2 = sim_handle(prefix, dedup_heavy=heavy_min)
+    s2.set_stats(True)
+    assert_regs_equal(*want, *s2.align(opt, seqs, off), f"patch joins, dedup_heavy={heavy_min}")
+    assert s2.stats()["n_glb_calls"] >= 100
+    assert dedup_list_reads(s2, reads.shape[0]) >= (20 if heavy_min else 0)
+    s2.close(); orc.close()
+
+
 def _alt_prefix(tmp_path, prefix, alt_names):
     """The same index under a new prefix, plus a .alt file (first column = contig name, bntseq.c:185-205)."""
     new = str(tmp_path / "alt_idx")
