@@ -80,7 +80,8 @@ DEVFN bool ddp_patch_may(const DevIndex &ix, const bwagpu_opt_t &opt, const DdHo
 	return true;
 }
 
-template <bool BLK> __device__ void dedup_read_par(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const DedupLds &L, u64 &calls, u64 &cells)
+// Returns false, with nothing changed, for a read whose coordinates do not fit the sort keys (the caller then takes the in-place routine).
+template <bool BLK> __device__ bool dedup_read_par(const DevIndex &ix, const bwagpu_opt_t &opt, const Batch &B, int r, const DedupLds &L, u64 &calls, u64 &cells)
 {
 	const int lane = threadIdx.x & 63;
 	const int n = uni(B.reg_n_raw[r]);                   // (the caller checked n <= L.par_cap)
@@ -93,7 +94,7 @@ template <bool BLK> __device__ void dedup_read_par(const DevIndex &ix, const bwa
 			B.reg_n[r] = n;
 		}
 		wave_sync();
-		return;
+		return true;
 	}
 	DdHot *hot = L.hot; DdKey *keys = L.keys; i32 *ord = L.ord, *ord2 = L.ord2;
 	wave_sync();                                         // (the arrays' last readers: the read before)
@@ -105,7 +106,7 @@ template <bool BLK> __device__ void dedup_read_par(const DevIndex &ix, const bwa
 		keys[i] = ddp_key_end(h_, i);
 		odd |= h_.rb < 0 || h_.rb >= ((i64)1 << 48) || h_.qb < 0 || h_.qb >= (1 << 16);
 	}
-	if (wave_ballot(odd)) { wave_sync(); dedup_read_wave<BLK>(ix, opt, B, r, L, calls, cells); return; }       // ... then in place, with the full-width keys
+	if (wave_ballot(odd)) { wave_sync(); return false; }   // ... then in place, with the full-width keys
 	for (int i = lane; i < n; i += 64) ga[i].n_comp = 1;   // bwamem.c:468
 	wave_sync();
 	// ---- by end position (bwamem.c:467)
@@ -222,4 +223,5 @@ template <bool BLK> __device__ void dedup_read_par(const DevIndex &ix, const bwa
 	}
 	if (lane == 0) B.reg_n[r] = nf;
 	wave_sync();
+	return true;
 }

@@ -326,8 +326,9 @@ template <bool BLK = false, bool LIST = false> __global__ void __launch_bounds__
 		if (k >= (!LIST ? (long long)B.n_reads : (long long)(list ? B.ctr->n_dd_big : B.ctr->n_dd_heavy))) break;
 		const int r = !LIST ? (int)k : uni(list ? B.dd_list[B.n_reads - 1 - k] : B.dd_list[k]);
 		const long long t_0 = B.stats ? wall_clock64() : 0; const u64 c_0 = calls, x_0 = cells;
-		if (LIST && uni(B.reg_n_raw[r]) <= L.par_cap) dedup_read_par<BLK>(ix, opt, B, r, L, calls, cells);
-		else dedup_read_wave<BLK>(ix, opt, B, r, L, calls, cells);
+		bool done = false;
+		if (LIST && uni(B.reg_n_raw[r]) <= L.par_cap) done = dedup_read_par<BLK>(ix, opt, B, r, L, calls, cells);
+		if (!done) dedup_read_wave<BLK>(ix, opt, B, r, L, calls, cells);
 		if (B.stats && lane == 0) {
 			const long long dt = wall_clock64() - t_0;
 			const int bin = dt > 0 ? (64 - __clzll(dt) < 31 ? 64 - __clzll(dt) : 31) : 0;

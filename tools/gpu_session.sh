@@ -1,23 +1,18 @@
-# Session r6-26: dedup_read_par with 16-byte sort keys: does it run on the device, parity, then timing.  Every command under its own time limit.
-mkdir -p gpurun_out/s26
+# Session r6-28: the list launch of k_dedup_wave takes 69 ms inside bench.py and 0.7 ms inside tools/variant_probe.py: what is different?
+mkdir -p gpurun_out/s28
 export TMPDIR=/tmp
-(timeout -s KILL 40 python -u tools/dedup_debug.py - "" > gpurun_out/s26/dflt.log 2>&1; echo "rc $?" >> gpurun_out/s26/dflt.log); tail -2 gpurun_out/s26/dflt.log | cut -c1-200
-(timeout -s KILL 40 python -u tools/dedup_debug.py - "dedup_heavy=0" > gpurun_out/s26/none.log 2>&1; echo "rc $?" >> gpurun_out/s26/none.log); tail -2 gpurun_out/s26/none.log | cut -c1-200
-grep -q "^OK" gpurun_out/s26/dflt.log || exit 0
-(timeout -s KILL 600 python -m pytest tests/test_gpu_parity.py -q -x -k "dedup or golden_regs or medium_short or medium_paired or heavy_reads" > gpurun_out/s26/pytest.log 2>&1; echo "rc $?" >> gpurun_out/s26/pytest.log); tail -3 gpurun_out/s26/pytest.log
-grep -q "rc 0" gpurun_out/s26/pytest.log || exit 0
-timeout -s KILL 300 python tools/seed_iter_probe.py > /dev/null 2>&1
-P="--prefix /tmp/bwa_amd_bench/g3100000000_s42 --codes /tmp/bwa_amd_bench/g3100000000_s42.codes.npy"
-(timeout -s KILL 300 python tools/dedup_hist_probe.py $P > gpurun_out/s26/hist.json 2> gpurun_out/s26/hist.err; echo "rc $?" >> gpurun_out/s26/hist.err)
-(timeout -s KILL 600 python tools/variant_probe.py $P --steps 12 --streams 3 "dedup_heavy=0" "dedup_heavy=2" "dedup_heavy=5" "dedup_stage=64" "dedup_stage=256" "dedup_big=0" > gpurun_out/s26/dd.log 2>&1; echo "rc $?" >> gpurun_out/s26/dd.log)
-python - <<'PY'
-import json
-try:
-    d=json.load(open("gpurun_out/s26/hist.json"))
-    for r in d["wave_kernel_reads_by_time"]: print(r)
-    print(d["stats"])
-except Exception as e: print("hist:", e)
-for ln in open("gpurun_out/s26/dd.log"):
+B="--steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-e2e --no-longread --no-pmc"
+getd() { python - "$1" <<'PY'
+import json,sys
+for ln in open(sys.argv[1]):
     if ln.startswith("{"):
-        d=json.loads(ln); print(d["config"], d.get("ms_per_step"), d.get("Mreads_s"), d.get("same_result_as_defaults"), d.get("stage_ms_solo",{}).get("ms_dedup"), d.get("error"))
+        d=json.loads(ln); print(sys.argv[1], d.get("config") if isinstance(d.get("config"),str) else "", "ms_dedup", (d.get("stage_ms_solo") or {}).get("ms_dedup"), "ms/step", d.get("ms_per_step"))
 PY
+}
+(timeout -s KILL 400 python bench.py $B --variants "" > gpurun_out/s28/a.json 2> gpurun_out/s28/a.log); getd gpurun_out/s28/a.json
+(BWAGPU_DEDUP_HEAVY=0 timeout -s KILL 300 python bench.py $B --variants "" > gpurun_out/s28/b.json 2> gpurun_out/s28/b.log); getd gpurun_out/s28/b.json
+P="--prefix /tmp/bwa_amd_bench/g3100000000_s42 --codes /tmp/bwa_amd_bench/g3100000000_s42.codes.npy --steps 3 --streams 1"
+(timeout -s KILL 300 python tools/variant_probe.py $P > gpurun_out/s28/c.json 2> gpurun_out/s28/c.log); getd gpurun_out/s28/c.json
+(timeout -s KILL 300 python -c "import torch, runpy, sys; torch.cuda.init(); x = torch.zeros(8, device='cuda'); sys.argv = ['variant_probe.py'] + '$P'.split(); runpy.run_path('tools/variant_probe.py', run_name='__main__')" > gpurun_out/s28/d.json 2> gpurun_out/s28/d.log); getd gpurun_out/s28/d.json
+(timeout -s KILL 300 python bench.py $B --variants "" --dense-sa 0 > gpurun_out/s28/e.json 2> gpurun_out/s28/e.log); getd gpurun_out/s28/e.json
+(timeout -s KILL 300 python tools/variant_probe.py $P --dense-sa 0 > gpurun_out/s28/f.json 2> gpurun_out/s28/f.log); getd gpurun_out/s28/f.json
