@@ -1,18 +1,17 @@
-# Session r6-28: the list launch of k_dedup_wave takes 69 ms inside bench.py and 0.7 ms inside tools/variant_probe.py: what is different?
-mkdir -p gpurun_out/s28
+# Session r6-29: validation of the tree with the new de-duplication path: A/B first, then the -m gpu suite, smoke, the default bench line, kernel trace + PMC.
+mkdir -p gpurun_out/s29
 export TMPDIR=/tmp
-B="--steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-e2e --no-longread --no-pmc"
-getd() { python - "$1" <<'PY'
-import json,sys
-for ln in open(sys.argv[1]):
+timeout -s KILL 300 python tools/seed_iter_probe.py > /dev/null 2>&1
+P="--prefix /tmp/bwa_amd_bench/g3100000000_s42 --codes /tmp/bwa_amd_bench/g3100000000_s42.codes.npy"
+(timeout -s KILL 300 python tools/variant_probe.py $P --steps 12 --streams 3 "dedup_heavy=0" > gpurun_out/s29/dd.log 2>&1; echo "rc $?" >> gpurun_out/s29/dd.log)
+python - <<'PY'
+import json
+for ln in open("gpurun_out/s29/dd.log"):
     if ln.startswith("{"):
-        d=json.loads(ln); print(sys.argv[1], d.get("config") if isinstance(d.get("config"),str) else "", "ms_dedup", (d.get("stage_ms_solo") or {}).get("ms_dedup"), "ms/step", d.get("ms_per_step"))
+        d=json.loads(ln); print(d["config"], d.get("ms_per_step"), d.get("Mreads_s"), d.get("same_result_as_defaults"), d.get("stage_ms_solo",{}).get("ms_dedup"), d.get("error"))
 PY
-}
-(timeout -s KILL 400 python bench.py $B --variants "" > gpurun_out/s28/a.json 2> gpurun_out/s28/a.log); getd gpurun_out/s28/a.json
-(BWAGPU_DEDUP_HEAVY=0 timeout -s KILL 300 python bench.py $B --variants "" > gpurun_out/s28/b.json 2> gpurun_out/s28/b.log); getd gpurun_out/s28/b.json
-P="--prefix /tmp/bwa_amd_bench/g3100000000_s42 --codes /tmp/bwa_amd_bench/g3100000000_s42.codes.npy --steps 3 --streams 1"
-(timeout -s KILL 300 python tools/variant_probe.py $P > gpurun_out/s28/c.json 2> gpurun_out/s28/c.log); getd gpurun_out/s28/c.json
-(timeout -s KILL 300 python -c "import torch, runpy, sys; torch.cuda.init(); x = torch.zeros(8, device='cuda'); sys.argv = ['variant_probe.py'] + '$P'.split(); runpy.run_path('tools/variant_probe.py', run_name='__main__')" > gpurun_out/s28/d.json 2> gpurun_out/s28/d.log); getd gpurun_out/s28/d.json
-(timeout -s KILL 300 python bench.py $B --variants "" --dense-sa 0 > gpurun_out/s28/e.json 2> gpurun_out/s28/e.log); getd gpurun_out/s28/e.json
-(timeout -s KILL 300 python tools/variant_probe.py $P --dense-sa 0 > gpurun_out/s28/f.json 2> gpurun_out/s28/f.log); getd gpurun_out/s28/f.json
+(timeout -s KILL 1500 python -m pytest tests -m gpu -x -q > gpurun_out/s29/pytest_gpu.log 2>&1; echo "rc $?" >> gpurun_out/s29/pytest_gpu.log); tail -3 gpurun_out/s29/pytest_gpu.log
+(timeout -s KILL 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/s29/smoke.log 2>&1; echo "rc $?" >> gpurun_out/s29/smoke.log); tail -2 gpurun_out/s29/smoke.log
+(timeout -s KILL 900 python bench.py --steps 20 --warmup 5 > gpurun_out/s29/bench.json 2> gpurun_out/s29/bench.log; echo "rc $?" >> gpurun_out/s29/bench.log); tail -1 gpurun_out/s29/bench.log; cp gpurun_out/bench_full.json gpurun_out/s29/bench_full.json; cp gpurun_out/bench_variants.json gpurun_out/s29/ 2>/dev/null
+timeout -s KILL 900 bash tools/profile_round.sh s29/short > gpurun_out/s29/profile_short.log 2>&1
+head -16 gpurun_out/s29/short/kernel_stats.csv | cut -c1-150
