@@ -1248,7 +1248,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			// Lane per read for the reads with one or two regions (nine in ten of the headline's); the others are listed by k_dedup and done by two more
 			// launches, one wavefront per read with the decisions' operands in LDS (dedup_read_par, dev_dedupp.h): the reads of up to dedup_stage regions
 			// (16.6 KB of LDS per wave, nine to a CU), then the few with more (up to dedup_big regions in 64 KB; beyond that, in place in HBM).
-			B.dd_heavy_min = dd_heavy_min; B.dd_list = h->d_heavy.as<i32>();
+			B.dd_heavy_min = dd_heavy_min; B.dd_list = h->d_heavy.as<i32>(); B.dd_prio = cfg.dedup_prio != 0;
 			B.dd_stage_cap = dd.cap_m > 0 ? dd.cap_m : 0x3fffffff;      // (no LDS arrays: one list, every read in place)
 			hipLaunchKernelGGL(k_dedup, dim3((unsigned)share(grid.x)), block, 0, h->stream, h->ix, *opt, B);
 			if (B.dd_heavy_min > 0) {

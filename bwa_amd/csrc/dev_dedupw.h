@@ -320,6 +320,9 @@ template <bool BLK = false, bool LIST = false> __global__ void __launch_bounds__
 		L.H = B.dp_h + wave * (B.max_len + 2) * DPS; L.E = B.dp_e + wave * (B.max_len + 2) * DPS;
 	}
 	wave_sync();
+	// The listed reads' waves are few, short and latency-bound (a chain of LDS round trips per region), and with three batches on the chip they share their
+	// SIMDs with the throughput kernels of the other two: at raised issue priority they get their instructions in when they are ready (option dedup_prio).
+	if (LIST && B.dd_prio) __builtin_amdgcn_s_setprio(3);
 	u64 calls = 0, cells = 0, nreg = 0;
 	for (;;) {
 		const long long k = wave_fetch(!LIST ? &B.ctr->next_dedup : (list ? &B.ctr->next_dd_big : &B.ctr->next_dd_heavy));

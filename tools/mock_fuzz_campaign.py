@@ -32,6 +32,9 @@ OPT_SETS = [
     {"ext_occ": 4},
     {"ext_pack": 1},
     {"ext_blk": 0},
+    {"dedup_heavy": 0},
+    {"dedup_heavy": 2, "dedup_stage": 8, "dedup_big": 24},
+    {"dedup_heavy": 2, "dedup_stage": 0},
 ]
 LAYOUT = ("occ32", "occ32_sb_shift", "ptab_m")     # applied when the index is laid out: such a set gets a handle of its own
 
