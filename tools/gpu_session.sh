@@ -1,14 +1,16 @@
-# Session r6-33: validation of the final tree: the -m gpu suite, smoke, the default bench line, kernel trace + PMC of the short-read batch.
-mkdir -p gpurun_out/s33
+# Session r6-34: the seeding kernels' interval-stack entries in LDS at 12 instead of 16 bytes (no x1): parity, solo seeding time for several depths, step time.
+mkdir -p gpurun_out/s34
 export TMPDIR=/tmp
-(timeout -s KILL 1500 python -m pytest tests -m gpu -x -q > gpurun_out/s33/pytest_gpu.log 2>&1; echo "rc $?" >> gpurun_out/s33/pytest_gpu.log); grep -n "passed\|failed" gpurun_out/s33/pytest_gpu.log | tail -2
-(timeout -s KILL 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/s33/smoke.log 2>&1; echo "rc $?" >> gpurun_out/s33/smoke.log); tail -2 gpurun_out/s33/smoke.log
-(timeout -s KILL 900 python bench.py --steps 20 --warmup 5 > gpurun_out/s33/bench.json 2> gpurun_out/s33/bench.log; echo "rc $?" >> gpurun_out/s33/bench.log); tail -1 gpurun_out/s33/bench.log; cp gpurun_out/bench_full.json gpurun_out/s33/bench_full.json; cp gpurun_out/bench_variants.json gpurun_out/s33/ 2>/dev/null
-timeout -s KILL 900 bash tools/profile_round.sh s33/short > gpurun_out/s33/profile_short.log 2>&1
-grep -n "dedup\|k_publish\|k_chain\|k_extend_wave" gpurun_out/s33/short/kernel_stats.csv | cut -c1-60,110-220
+(timeout -s KILL 60 python -u tools/dedup_debug.py - "" > gpurun_out/s34/dflt.log 2>&1; echo "rc $?" >> gpurun_out/s34/dflt.log); tail -2 gpurun_out/s34/dflt.log | cut -c1-200
+grep -q "^OK" gpurun_out/s34/dflt.log || exit 0
+(timeout -s KILL 600 python -m pytest tests/test_gpu_parity.py -q -x -k "golden or medium_short or short_read_batches or edge" > gpurun_out/s34/pytest.log 2>&1; echo "rc $?" >> gpurun_out/s34/pytest.log); tail -3 gpurun_out/s34/pytest.log
+timeout -s KILL 300 python tools/seed_iter_probe.py > gpurun_out/s34/probe.log 2>&1
+grep -n "interval-stack\|k_seed(+k_seed3)" gpurun_out/s34/probe.log | cut -c1-330
+P="--prefix /tmp/bwa_amd_bench/g3100000000_s42 --codes /tmp/bwa_amd_bench/g3100000000_s42.codes.npy"
+(timeout -s KILL 900 python tools/variant_probe.py $P --steps 18 --streams 3 "seed_lds_ent=7" "seed_lds_ent=8" "seed_lds_ent=10" "seed_lds_ent=11" "seed_lds_ent=13" > gpurun_out/s34/lds.log 2>&1; echo "rc $?" >> gpurun_out/s34/lds.log)
 python - <<'PY'
 import json
-d=json.load(open('gpurun_out/s33/bench_full.json'))
-print(d['value'], d['ms_per_step'], d['bench_wall_s'], d['stage_ms_solo'])
-print(json.dumps(d['summary'])[:600])
+for ln in open("gpurun_out/s34/lds.log"):
+    if ln.startswith("{"):
+        d=json.loads(ln); print(d["config"], d.get("ms_per_step"), d.get("Mreads_s"), d.get("same_result_as_defaults"), d.get("stage_ms_solo",{}).get("ms_seed"), d.get("error"))
 PY
