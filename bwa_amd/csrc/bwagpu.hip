@@ -232,7 +232,7 @@ static bool option_in_range(const BwagpuConfig &c, const long long *f, long long
 	if (f == &c.share) return in(-1, 100);
 	if (f == &c.seed_task_stack || f == &c.seed_p2_cap || f == &c.mem_cap || f == &c.seed_grid || f == &c.cig_ops_cap || f == &c.idx_desc_max_mb) return in(0, 0x3fffffff);
 	if (f == &c.seed_budget || f == &c.dedup_heavy) return in(-1, 0x3fffffff);
-	if (f == &c.dedup_stage || f == &c.dedup_big) return in(-1, 1024);
+	if (f == &c.dedup_stage || f == &c.dedup_big || f == &c.dedup_net) return in(-1, 1024);
 	if (f == &c.seed_lds_ent) return in(-1, 16);
 	if (f == &c.dedup_ring) return value == 0 || (in(256, 4096) && (value & (value - 1)) == 0);
 	if (f == &c.cigl_mib) return in(0, 1 << 20);
@@ -1248,7 +1248,7 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 			// Lane per read for the reads with one or two regions (nine in ten of the headline's); the others are listed by k_dedup and done by two more
 			// launches, one wavefront per read with the decisions' operands in LDS (dedup_read_par, dev_dedupp.h): the reads of up to dedup_stage regions
 			// (16.6 KB of LDS per wave, nine to a CU), then the few with more (up to dedup_big regions in 64 KB; beyond that, in place in HBM).
-			B.dd_heavy_min = dd_heavy_min; B.dd_list = h->d_heavy.as<i32>(); B.dd_prio = cfg.dedup_prio != 0;
+			B.dd_heavy_min = dd_heavy_min; B.dd_list = h->d_heavy.as<i32>(); B.dd_prio = cfg.dedup_prio != 0; B.dd_net = (int)(cfg.dedup_net < 0 ? 129 : cfg.dedup_net);
 			B.dd_stage_cap = dd.cap_m > 0 ? dd.cap_m : 0x3fffffff;      // (no LDS arrays: one list, every read in place)
 			hipLaunchKernelGGL(k_dedup, dim3((unsigned)share(grid.x)), block, 0, h->stream, h->ix, *opt, B);
 			if (B.dd_heavy_min > 0) {

@@ -46,6 +46,7 @@
 	X(dedup_heavy,       -1)   /* short reads: k_dedup leaves reads with at least this many regions to the wave-per-read kernel; 0 = none, auto: 3      */ \
 	X(dedup_stage,       -1)   /* ... with the decisions' operands in LDS for reads of up to this many regions (first launch); 0 = every read in place in HBM, auto: 128 */ \
 	X(dedup_big,         -1)   /* ... and for the reads with more, up to this many (second launch, 64 KB of LDS per wave); 0 = those in place, auto: what fits (893) */ \
+	X(dedup_net,         -1)   /* ... and finishes the sorts of reads with at least this many regions by a bitonic network instead of by counting; 0 = never, auto: 129 */ \
 	X(dedup_prio,        1)    /* ... whose waves run at raised issue priority (0: A/B)                                                              */ \
 	X(dedup_wave,        0)    /* 1 = the wave-per-read de-duplication kernel for short reads as well (test hook)                                       */ \
 	X(dedup_ring,        0)    /* ring columns of that kernel (0: from the batch; test hook: a power of two, 256..4096)                                 */ \

@@ -197,6 +197,7 @@ struct Batch {
 	i32 *dd_list;                   // k_dedup: the reads with at least dd_heavy_min regions, left to k_dedup_wave<.., LIST = true>: n_dd_heavy of them from the front, and from the
 	                                // back (entry n_reads - 1 downwards) the n_dd_big reads with more than dd_stage_cap regions
 	int dd_heavy_min, dd_stage_cap; // dd_heavy_min 0 = k_dedup does every read itself
+	int dd_net;                     // reads of at least this many regions finish their sorts by a sorting network instead of by counting (option dedup_net; 0: never)
 	int dd_prio;                    // the list launches' waves run at raised issue priority (option dedup_prio)
 	int seed_budget;                // ... that budget (0: none)
 	i64 *p2_tasks; long long p2_cap; // pass-2 searches of the heavy reads as tasks (k_seed<LR = 3>): read << 32 | index of the pass-1 entry to re-seed

@@ -68,6 +68,31 @@ template <bool BEST> DEVFN void ddp_rank(const DdKey *keys, int n, i32 *out, int
 	}
 }
 
+// The same finish for the reads with hundreds of regions, where counting is n^2 / 64 steps (a read of 900 regions: most of its 2 ms): with its place in
+// the array as the last part of its key every element is distinct, the stable order is a total one, and any sorting network produces it -- a bitonic
+// one here, over N = the power of two above n (the elements beyond n are "greater than all"; the caller has checked that the LDS behind keys[] holds N).
+// The place goes where the key has room for it: END: lo = place : index; BEST: lo = {rb, qb} : place (16 bits) : index (16 bits).
+template <bool BEST> DEVFN void ddp_bitonic(DdKey *keys, int n, int N, i32 *out, int lane)
+{
+	for (int x = lane; x < N; x += 64) {
+		DdKey k; k.hi = ~0ull; k.lo = ~0ull;
+		if (x < n) { k = keys[x]; k.lo = BEST ? (k.lo & 0xffffffff00000000ull) | (u64)(u32)x << 16 | (k.lo & 0xffffu) : (u64)(u32)x << 32 | (k.lo & 0xffffffffu); }
+		keys[x] = k;
+	}
+	wave_sync();
+	for (int k = 2; k <= N; k <<= 1)
+		for (int j = k >> 1; j > 0; j >>= 1) {
+			for (int t = lane; t < (N >> 1); t += 64) {
+				const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;      // the t-th pair of this step: i has bit j clear
+				const DdKey a = keys[i], b = keys[p];
+				const bool a_gt_b = a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo);        // (lo as a whole: its low bits are the place, then the index)
+				if (((i & k) == 0) == a_gt_b) { keys[i] = b; keys[p] = a; }
+			}
+			wave_sync();
+		}
+	for (int x = lane; x < n; x += 64) out[x] = (int)(BEST ? (u32)keys[x].lo & 0xffffu : (u32)keys[x].lo);
+}
+
 // mem_patch_reg's tests ahead of its alignment (bwamem.c:436-445), for a lane's own pair
 DEVFN bool ddp_patch_may(const DevIndex &ix, const bwagpu_opt_t &opt, const DdHot &a, const DdHot &b)
 {
@@ -112,7 +137,11 @@ template <bool BLK> __device__ bool dedup_read_par(const DevIndex &ix, const bwa
 	// ---- by end position (bwamem.c:467)
 	if (lane == 0) dev_introsort<DdKey, DdKeyLessEnd, false>(keys, n, DdKeyLessEnd());
 	wave_sync();
-	ddp_rank<false>(keys, n, ord, lane);
+	const int cap_n = L.par_cap + L.par_cap / 2;          // elements of 16 bytes the LDS from keys[] on holds (keys, ord, ord2)
+	{
+		int N = 16; while (N < n) N <<= 1;
+		if (B.dd_net > 0 && n >= B.dd_net && N <= cap_n) ddp_bitonic<false>(keys, n, N, ord, lane); else ddp_rank<false>(keys, n, ord, lane);
+	}
 	wave_sync();
 	// ---- the redundancy scan (bwamem.c:470-497)
 	const float mlr = opt.mask_level_redun; const int gap = opt.max_chain_gap;
@@ -191,7 +220,10 @@ template <bool BLK> __device__ bool dedup_read_par(const DevIndex &ix, const bwa
 	wave_sync();
 	if (lane == 0) dev_introsort<DdKey, DdKeyLessBest, false>(keys, m, DdKeyLessBest());
 	wave_sync();
-	ddp_rank<true>(keys, m, ord, lane);
+	{
+		int N = 16; while (N < m) N <<= 1;
+		if (B.dd_net > 0 && m >= B.dd_net && N <= cap_n && m < 65536) ddp_bitonic<true>(keys, m, N, ord, lane); else ddp_rank<true>(keys, m, ord, lane);
+	}
 	wave_sync();
 	// ---- identical hits (bwamem.c:505-513): every region that equals the one before it goes
 	int nf = 0;

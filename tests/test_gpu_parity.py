@@ -508,8 +508,8 @@ def test_ext_pack_gives_identical_results(medium):
         g2.close()
 
 
-@pytest.mark.parametrize("heavy_min,stage,big", [(0, -1, -1), (2, 16, -1), (2, 16, 32), (8, 0, -1), (-1, 512, 0)])
-def test_dedup_list_gives_identical_results(medium, heavy_min, stage, big):
+@pytest.mark.parametrize("heavy_min,stage,big,net", [(0, -1, -1, -1), (2, 16, -1, 12), (2, 16, 32, 0), (8, 0, -1, -1), (-1, 512, 0, 4)])
+def test_dedup_list_gives_identical_results(medium, heavy_min, stage, big, net):
     """k_dedup lists the reads with several regions for k_dedup_wave<.., LIST> (dedup_read_par, dev_dedupp.h: operands in LDS, the lanes over the
     regions), options dedup_heavy / dedup_stage / dedup_big (3 regions, 128, what 64 KB hold by default, which the other tests run): with no list; with
     nearly every read listed, small arrays in the first launch and the rest in the second; the same with reads beyond the second launch's arrays (done in
@@ -521,16 +521,16 @@ def test_dedup_list_gives_identical_results(medium, heavy_min, stage, big):
     odd = golden_opts()["odd"]
     sets = [("se150", simdata.make_reads_se(g, 8000, seed=81), default_opt()), ("se150 odd options", simdata.make_reads_se(g, 3000, seed=82, sub=0.03), odd),
             ("se250 noisy", simdata.make_reads_se(g, 2000, length=250, seed=83, sub=0.03, dele=0.005, ins=0.005), default_opt())]
-    g2 = BwaGpu(fa, options={"dedup_heavy": heavy_min, "dedup_stage": stage, "dedup_big": big})
+    g2 = BwaGpu(fa, options={"dedup_heavy": heavy_min, "dedup_stage": stage, "dedup_big": big, "dedup_net": net})
     for name, reads, opt in sets:
         seqs, off = testdata.flat(reads)
-        assert_regs_equal(*ref.align(opt, seqs, off), *g2.align(opt, seqs, off), f"dedup_heavy = {heavy_min}, dedup_stage = {stage}, dedup_big = {big}, {name}")
+        assert_regs_equal(*ref.align(opt, seqs, off), *g2.align(opt, seqs, off), f"dedup_heavy = {heavy_min}, dedup_stage = {stage}, dedup_big = {big}, dedup_net = {net}, {name}")
     g2.close()
     import refapi
     hfa, horc, hreads = _heavy()
     hg = simdata.make_genome(500_000, n_contigs=2, seed=5, n_interspersed=2000, divergence=0.04)[0]      # (heavycase.build's genome)
     rep_reads = simdata.make_reads_se(hg, 1500, seed=84, sub=0.05)
-    g3, href = BwaGpu(hfa, options={"dedup_heavy": heavy_min, "dedup_stage": stage, "dedup_big": big}), refapi.RefIndex(hfa)
+    g3, href = BwaGpu(hfa, options={"dedup_heavy": heavy_min, "dedup_stage": stage, "dedup_big": big, "dedup_net": net}), refapi.RefIndex(hfa)
     for name, reads in (("hard reads", hreads), ("repeat-rich genome", rep_reads)):
         seqs, off = testdata.flat(reads)
         assert_regs_equal(*href.align(default_opt(), seqs, off), *g3.align(default_opt(), seqs, off), f"dedup_heavy = {heavy_min}, {name}")

@@ -589,21 +589,22 @@ def dedup_list_reads(dev, n_reads):
     return sum(hist[160:192])
 
 
-@pytest.mark.parametrize("heavy_min,stage,big", [(0, -1, -1), (-1, -1, -1), (2, 16, -1), (2, 16, 32), (8, 0, -1), (-1, 512, 0)])
-def test_hostsim_dedup_hands_heavy_reads_to_the_wave_kernel(heavy_case, heavy_min, stage, big):
+@pytest.mark.parametrize("heavy_min,stage,big,net", [(0, -1, -1, -1), (-1, -1, -1, -1), (2, 16, -1, 12), (2, 16, 32, 0), (8, 0, -1, -1), (-1, 512, 0, 4)])
+def test_hostsim_dedup_hands_heavy_reads_to_the_wave_kernel(heavy_case, heavy_min, stage, big, net):
     """k_dedup keeps the reads with few regions (one lane each) and lists the others for k_dedup_wave<.., LIST> (option dedup_heavy: 0 = none,
     auto = 3 regions), which runs dedup_read_par (dev_dedupp.h: operands in LDS, the lanes over the regions -- the stable finish of both sorts, the
     redundancy scan 64 regions at a time, compactions by prefix counts) in two launches: reads of up to dedup_stage regions (auto 128; 0 = every
     listed read in place in HBM, the long reads' routine), then those of up to dedup_big (auto: what 64 KB hold; beyond it in place).  The regions equal
-    the oracle's whichever way a read went, and the list is used when it should be."""
+    the oracle's whichever way a read went, and the list is used when it should be.  dedup_net: the reads whose sorts are finished by the sorting network
+    (auto: 129 regions and more, i.e. none of these reads; 12 / 4: most of the listed ones; 0: none)."""
     fa, orc, reads = heavy_case
     opt = default_opt()
-    s2 = sim_handle(fa, dedup_heavy=heavy_min, dedup_stage=stage, dedup_big=big)
+    s2 = sim_handle(fa, dedup_heavy=heavy_min, dedup_stage=stage, dedup_big=big, dedup_net=net)
     s2.set_stats(True); s2.set_taps(True)
     more = simdata.make_reads_se(simdata.make_genome(500_000, n_contigs=2, seed=5, n_interspersed=2000, divergence=0.04)[0], 40, seed=85, sub=0.05)   # (heavycase.build's genome: reads of 1..80 regions)
     seqs, off = testdata.flat(np.concatenate([reads, more]))
     c, r = s2.align(opt, seqs, off)
-    assert_regs_equal(*orc.align(opt, seqs, off), c, r, f"dedup_heavy={heavy_min} dedup_stage={stage} dedup_big={big}")
+    assert_regs_equal(*orc.align(opt, seqs, off), c, r, f"dedup_heavy={heavy_min} dedup_stage={stage} dedup_big={big} dedup_net={net}")
     n_raw = s2.tap_regs_raw()[0]
     done = dedup_list_reads(s2, reads.shape[0])
     lo = 3 if heavy_min < 0 else heavy_min

@@ -22,7 +22,7 @@ BOUNDS = {
     "k_extend_wave<false, 6>": (80, 496, 4),                   # six waves per SIMD
     "k_extend_wave<true, 4>": (96, 496, 0),
     "k_dedup": (112, 592, 0),
-    "k_dedup_wave<true, true>": (168, 800, 0),                 # three waves per SIMD (nine one-wave workgroups per CU by LDS)
+    "k_dedup_wave<true, true>": (170, 800, 0),                 # three waves per SIMD (512 / 3 = 170 registers; ten one-wave workgroups per CU by LDS)
     "k_dedup_wave<true, false>": (144, 592, 0),
     "k_cigar<true>": (96, 0, 0),
     "k_cigar<false>": (144, 0, 0),
