@@ -1,15 +1,14 @@
-# Session r6-35: the sorts of reads with hundreds of regions finished by a bitonic network instead of by counting (option dedup_net): parity, solo stage time, step.
-mkdir -p gpurun_out/s35
+# Session r6-36: validation of the final tree: the -m gpu suite, smoke, the default bench line, kernel trace + PMC of the short-read batch.
+mkdir -p gpurun_out/s36
 export TMPDIR=/tmp
-(timeout -s KILL 60 python -u tools/dedup_debug.py - "dedup_net=4" > gpurun_out/s35/dflt.log 2>&1; echo "rc $?" >> gpurun_out/s35/dflt.log); tail -2 gpurun_out/s35/dflt.log | cut -c1-200
-grep -q "^OK" gpurun_out/s35/dflt.log || exit 0
-(timeout -s KILL 600 python -m pytest tests/test_gpu_parity.py -q -x -k "dedup or golden or heavy_reads" > gpurun_out/s35/pytest.log 2>&1; echo "rc $?" >> gpurun_out/s35/pytest.log); tail -3 gpurun_out/s35/pytest.log
-timeout -s KILL 300 python tools/seed_iter_probe.py > /dev/null 2>&1
-P="--prefix /tmp/bwa_amd_bench/g3100000000_s42 --codes /tmp/bwa_amd_bench/g3100000000_s42.codes.npy"
-(timeout -s KILL 600 python tools/variant_probe.py $P --steps 18 --streams 3 "dedup_net=0" "dedup_net=65" "dedup_net=33" "dedup_net=0" > gpurun_out/s35/net.log 2>&1; echo "rc $?" >> gpurun_out/s35/net.log)
+(timeout -s KILL 1500 python -m pytest tests -m gpu -x -q > gpurun_out/s36/pytest_gpu.log 2>&1; echo "rc $?" >> gpurun_out/s36/pytest_gpu.log); grep -n "passed\|failed" gpurun_out/s36/pytest_gpu.log | tail -2
+(timeout -s KILL 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/s36/smoke.log 2>&1; echo "rc $?" >> gpurun_out/s36/smoke.log); tail -2 gpurun_out/s36/smoke.log
+(timeout -s KILL 900 python bench.py --steps 20 --warmup 5 > gpurun_out/s36/bench.json 2> gpurun_out/s36/bench.log; echo "rc $?" >> gpurun_out/s36/bench.log); tail -1 gpurun_out/s36/bench.log; cp gpurun_out/bench_full.json gpurun_out/s36/bench_full.json; cp gpurun_out/bench_variants.json gpurun_out/s36/ 2>/dev/null
+timeout -s KILL 900 bash tools/profile_round.sh s36/short > gpurun_out/s36/profile_short.log 2>&1
+grep -n "dedup" gpurun_out/s36/short/kernel_stats.csv | cut -c1-60,110-220
 python - <<'PY'
 import json
-for ln in open("gpurun_out/s35/net.log"):
-    if ln.startswith("{"):
-        d=json.loads(ln); print(d["config"], d.get("ms_per_step"), d.get("Mreads_s"), d.get("same_result_as_defaults"), d.get("stage_ms_solo",{}).get("ms_dedup"), d.get("error"))
+d=json.load(open('gpurun_out/s36/bench_full.json'))
+print(d['value'], d['ms_per_step'], d['bench_wall_s'], d['stage_ms_solo'])
+print(json.dumps(d['summary'])[:600])
 PY
