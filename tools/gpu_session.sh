@@ -1,14 +1,15 @@
-# Session r6-36: validation of the final tree: the -m gpu suite, smoke, the default bench line, kernel trace + PMC of the short-read batch.
-mkdir -p gpurun_out/s36
+# Session r6-37: share of the chip per persistent kernel with three batches in flight, after the de-duplication rewrite; and four batches in flight.
+mkdir -p gpurun_out/s37
 export TMPDIR=/tmp
-(timeout -s KILL 1500 python -m pytest tests -m gpu -x -q > gpurun_out/s36/pytest_gpu.log 2>&1; echo "rc $?" >> gpurun_out/s36/pytest_gpu.log); grep -n "passed\|failed" gpurun_out/s36/pytest_gpu.log | tail -2
-(timeout -s KILL 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/s36/smoke.log 2>&1; echo "rc $?" >> gpurun_out/s36/smoke.log); tail -2 gpurun_out/s36/smoke.log
-(timeout -s KILL 900 python bench.py --steps 20 --warmup 5 > gpurun_out/s36/bench.json 2> gpurun_out/s36/bench.log; echo "rc $?" >> gpurun_out/s36/bench.log); tail -1 gpurun_out/s36/bench.log; cp gpurun_out/bench_full.json gpurun_out/s36/bench_full.json; cp gpurun_out/bench_variants.json gpurun_out/s36/ 2>/dev/null
-timeout -s KILL 900 bash tools/profile_round.sh s36/short > gpurun_out/s36/profile_short.log 2>&1
-grep -n "dedup" gpurun_out/s36/short/kernel_stats.csv | cut -c1-60,110-220
+timeout -s KILL 300 python tools/seed_iter_probe.py > /dev/null 2>&1
+P="--prefix /tmp/bwa_amd_bench/g3100000000_s42 --codes /tmp/bwa_amd_bench/g3100000000_s42.codes.npy --steps 18"
+(timeout -s KILL 600 python tools/variant_probe.py $P --streams 3 "share=35" "share=50" "share=65" "share=80" "share=100" > gpurun_out/s37/share3.log 2>&1; echo "rc $?" >> gpurun_out/s37/share3.log)
+(timeout -s KILL 400 python tools/variant_probe.py $P --streams 4 "share=35" "share=50" > gpurun_out/s37/share4.log 2>&1; echo "rc $?" >> gpurun_out/s37/share4.log)
+(timeout -s KILL 400 python tools/variant_probe.py $P --streams 2 "share=50" "share=100" > gpurun_out/s37/share2.log 2>&1; echo "rc $?" >> gpurun_out/s37/share2.log)
 python - <<'PY'
 import json
-d=json.load(open('gpurun_out/s36/bench_full.json'))
-print(d['value'], d['ms_per_step'], d['bench_wall_s'], d['stage_ms_solo'])
-print(json.dumps(d['summary'])[:600])
+for f in ("share3","share4","share2"):
+    for ln in open(f"gpurun_out/s37/{f}.log"):
+        if ln.startswith("{"):
+            d=json.loads(ln); print(f, d["config"], d.get("ms_per_step"), d.get("Mreads_s"), d.get("same_result_as_defaults"))
 PY

@@ -34,6 +34,7 @@ OPT_SETS = [
     {"ext_blk": 0},
     {"dedup_heavy": 0},
     {"dedup_heavy": 2, "dedup_stage": 8, "dedup_big": 24},
+    {"dedup_heavy": 2, "dedup_stage": 64, "dedup_net": 4},
     {"dedup_heavy": 2, "dedup_stage": 0},
 ]
 LAYOUT = ("occ32", "occ32_sb_shift", "ptab_m")     # applied when the index is laid out: such a set gets a handle of its own
