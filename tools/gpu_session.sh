@@ -1,15 +1,12 @@
-# Session r6-37: share of the chip per persistent kernel with three batches in flight, after the de-duplication rewrite; and four batches in flight.
-mkdir -p gpurun_out/s37
+# Session r6-40: the seeding kernel's iteration budget (reads given up to the task kernels after that many iterations): solo stage time and step time.
+mkdir -p gpurun_out/s40
 export TMPDIR=/tmp
 timeout -s KILL 300 python tools/seed_iter_probe.py > /dev/null 2>&1
-P="--prefix /tmp/bwa_amd_bench/g3100000000_s42 --codes /tmp/bwa_amd_bench/g3100000000_s42.codes.npy --steps 18"
-(timeout -s KILL 600 python tools/variant_probe.py $P --streams 3 "share=35" "share=50" "share=65" "share=80" "share=100" > gpurun_out/s37/share3.log 2>&1; echo "rc $?" >> gpurun_out/s37/share3.log)
-(timeout -s KILL 400 python tools/variant_probe.py $P --streams 4 "share=35" "share=50" > gpurun_out/s37/share4.log 2>&1; echo "rc $?" >> gpurun_out/s37/share4.log)
-(timeout -s KILL 400 python tools/variant_probe.py $P --streams 2 "share=50" "share=100" > gpurun_out/s37/share2.log 2>&1; echo "rc $?" >> gpurun_out/s37/share2.log)
+P="--prefix /tmp/bwa_amd_bench/g3100000000_s42 --codes /tmp/bwa_amd_bench/g3100000000_s42.codes.npy --steps 30"
+(timeout -s KILL 900 python tools/variant_probe.py $P --streams 3 "seed_budget=10240" "seed_budget=8192" "seed_budget=10240" "seed_budget=9216" "seed_budget=11264" "seed_budget=8192" "seed_budget=10240" > gpurun_out/s40/budget.log 2>&1; echo "rc $?" >> gpurun_out/s40/budget.log)
 python - <<'PY'
 import json
-for f in ("share3","share4","share2"):
-    for ln in open(f"gpurun_out/s37/{f}.log"):
-        if ln.startswith("{"):
-            d=json.loads(ln); print(f, d["config"], d.get("ms_per_step"), d.get("Mreads_s"), d.get("same_result_as_defaults"))
+for ln in open("gpurun_out/s40/budget.log"):
+    if ln.startswith("{"):
+        d=json.loads(ln); print(d["config"], d.get("ms_per_step"), d.get("Mreads_s"), d.get("same_result_as_defaults"), d.get("stage_ms_solo",{}).get("ms_seed"), d.get("error"))
 PY
