@@ -1024,7 +1024,10 @@ extern "C" int bwagpu_batch_run(bwagpu_t *h, const bwagpu_opt_t *opt)
 	if (dbg_sync) fprintf(stderr, "[bwagpu] pass 1 by tasks: %d tasks on %d lanes (max_len %d, step %d)\n", n_vreads, task_lanes, h->max_len, opt->min_seed_len);
 	// Short-read batches: a read on which a lane of the lane-per-read kernel has spent more than option seed_budget iterations (default 8192: 0.15 % of
 	// the bench's reads -- and the whole of that kernel's critical path; measured over budgets 2048..8192: profiles/r04_seed_budget_ab.jsonl) is given up there and seeded by the task kernels afterwards (dev_seed.h, LR).
-	const int seed_budget = (int)(cfg.seed_budget < 0 ? 8192 : cfg.seed_budget);
+	// Round 6 (profiles/r06_seed_budget.md): alone on the chip the stage is shortest at ~6 k iterations (50.5 ms against 55.5 at 8192, 59.8 at 12288: the main
+	// kernel's tail of nearly empty waves ends sooner); with other batches' kernels on the chip that tail costs nothing -- they fill it -- and the step is best
+	// with fewer reads handed to the chip-filling task kernels (86.3-87.6 ms at 12288 against 87.1-89.1 at 8192).  So auto follows the same signal as `share`.
+	const int seed_budget = (int)(cfg.seed_budget < 0 ? (share_pct < 100 ? 12288 : 6144) : cfg.seed_budget);
 	const int heavy_tpr = opt->min_seed_len > 0 ? (h->max_len + opt->min_seed_len - 1) / opt->min_seed_len : 0;
 	// The one-trip seeding kernels (MRG = 2) address the index through buffer descriptors: 32-bit byte offsets into tables of less than 4 GiB.  The heavy
 	// reads' task kernels exist in that form only, so an index beyond a descriptor's reach (occ32 above 4 GiB: a genome of more than ~4.3 Gbp; a deep

@@ -24,7 +24,7 @@
 	X(idx_desc_max_mb,   0)    /* index: tables above this many MiB count as beyond a buffer descriptor's reach (0: the hardware's 4 GiB; test hook for the fallback kernels) */ \
 	X(seed_mrg,          -1)   /* seeding: 0 = loads as the compiler schedules them, 2 = one memory round trip per iteration; auto: 2                    */ \
 	X(seed_tasks,        -1)   /* seeding: pass 1 of long reads as independent tasks, one per min_seed_len-th position (0: the lane-per-read chain); auto: on for long reads */ \
-	X(seed_budget,       -1)   /* seeding, short reads: iterations after which the lane-per-read kernel gives a read up to the task kernels; auto: 8192, 0: never           */ \
+	X(seed_budget,       -1)   /* seeding, short reads: iterations after which the lane-per-read kernel gives a read up to the task kernels; auto: 6144 for a batch alone on the chip, 12288 next to other batches (as `share`), 0: never           */ \
 	X(seed_p2_cap,       0)    /* seeding: entries of the heavy reads' pass-2 task list (0: 16 per heavy read; tests: a tiny list forces the retry)                             */ \
 	X(seed_task_stack,   0)    /* seeding: packed interval-stack entries a task lane may spill (0: 256; tests: tiny stacks force the second launch)      */ \
 	X(publish_blk,       -1)   /* interval sort + SA-row expansion by one workgroup per read; auto: on for long reads                                   */ \

@@ -1,12 +1,15 @@
-# Session r6-40: the seeding kernel's iteration budget (reads given up to the task kernels after that many iterations): solo stage time and step time.
-mkdir -p gpurun_out/s40
+# Session r6-42: validation of the final tree: the -m gpu suite, smoke, the default bench line, kernel trace + PMC of the short-read batch.
+mkdir -p gpurun_out/s42
 export TMPDIR=/tmp
-timeout -s KILL 300 python tools/seed_iter_probe.py > /dev/null 2>&1
-P="--prefix /tmp/bwa_amd_bench/g3100000000_s42 --codes /tmp/bwa_amd_bench/g3100000000_s42.codes.npy --steps 30"
-(timeout -s KILL 900 python tools/variant_probe.py $P --streams 3 "seed_budget=10240" "seed_budget=8192" "seed_budget=10240" "seed_budget=9216" "seed_budget=11264" "seed_budget=8192" "seed_budget=10240" > gpurun_out/s40/budget.log 2>&1; echo "rc $?" >> gpurun_out/s40/budget.log)
+(timeout -s KILL 1500 python -m pytest tests -m gpu -x -q > gpurun_out/s42/pytest_gpu.log 2>&1; echo "rc $?" >> gpurun_out/s42/pytest_gpu.log); grep -n "passed\|failed" gpurun_out/s42/pytest_gpu.log | tail -2
+(timeout -s KILL 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/s42/smoke.log 2>&1; echo "rc $?" >> gpurun_out/s42/smoke.log); tail -2 gpurun_out/s42/smoke.log
+(timeout -s KILL 900 python bench.py --steps 20 --warmup 5 > gpurun_out/s42/bench.json 2> gpurun_out/s42/bench.log; echo "rc $?" >> gpurun_out/s42/bench.log); tail -1 gpurun_out/s42/bench.log; cp gpurun_out/bench_full.json gpurun_out/s42/bench_full.json; cp gpurun_out/bench_variants.json gpurun_out/s42/ 2>/dev/null
+timeout -s KILL 900 bash tools/profile_round.sh s42/short > gpurun_out/s42/profile_short.log 2>&1
+grep -n "k_seed" gpurun_out/s42/short/kernel_stats.csv | cut -c1-70,100-200
 python - <<'PY'
 import json
-for ln in open("gpurun_out/s40/budget.log"):
-    if ln.startswith("{"):
-        d=json.loads(ln); print(d["config"], d.get("ms_per_step"), d.get("Mreads_s"), d.get("same_result_as_defaults"), d.get("stage_ms_solo",{}).get("ms_seed"), d.get("error"))
+d=json.load(open('gpurun_out/s42/bench_full.json'))
+print(d['value'], d['ms_per_step'], d['bench_wall_s'], d['stage_ms_solo'])
+print(d['roofline']['frac'], d['roofline']['frac_requests'], d['roofline']['kernel_ms'])
+print(json.dumps(d['summary'])[:600])
 PY
